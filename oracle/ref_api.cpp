@@ -1,0 +1,269 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY — builds oracle/_ref/libsdrpp_ref*.so (git-ignored, shipped to the GPU box).
+//
+// Thin extern "C" wrapper around the REFERENCE'S OWN code, compiled where it lies under /root/reference:
+//   * core/src/dsp/**            header-only DSP library (RxVFO, RationalResampler, FIR, demodulators, ...)
+//   * core/src/signal_path/iq_frontend.cpp   included verbatim (FFT branch + Reshaper + Splitter + threads)
+// against the restated third-party arithmetic in oracle/shim (volk/volk.h, fftw3.h) and three stub headers
+// (gui/gui.h, core.h, utils/flog.h).  No reference source is copied into this repository.
+//
+// The wrapper exists so that tests can (a) validate oracle/oracle.c bit-for-bit against the reference's classes and
+// (b) generate tests/golden/*.npz, and so that bench.py can time the reference's process() code as the CPU baseline
+// (cpu_baseline.kind = "reference").
+#include <cstring>
+#include <cstdio>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+
+#include <dsp/channel/rx_vfo.h>
+#include <dsp/demod/broadcast_fm.h>
+#include <dsp/demod/fm.h>
+#include <dsp/demod/am.h>
+#include <dsp/demod/ssb.h>
+#include <dsp/filter/deephasis.h>
+#include <dsp/multirate/rational_resampler.h>
+#include <dsp/taps/low_pass.h>
+#include <dsp/taps/high_pass.h>
+#include <dsp/window/nuttall.h>
+#include <dsp/window/blackman.h>
+
+// The reference translation unit itself (its relative includes resolve next to it).
+#include <signal_path/iq_frontend.cpp>
+
+using dsp::complex_t;
+using dsp::stereo_t;
+
+extern "C" {
+
+// ---- host maths ------------------------------------------------------------------------------------------------------
+int ref_low_pass(double cutoff, double transWidth, double sampleRate, int odd, float* out, int max) {
+    dsp::tap<float> t = dsp::taps::lowPass(cutoff, transWidth, sampleRate, odd != 0);
+    int n = t.size;
+    memcpy(out, t.taps, sizeof(float) * (size_t)(n < max ? n : max));
+    dsp::taps::free(t);
+    return n;
+}
+int ref_high_pass(double cutoff, double transWidth, double sampleRate, int odd, float* out, int max) {
+    dsp::tap<float> t = dsp::taps::highPass(cutoff, transWidth, sampleRate, odd != 0);
+    int n = t.size;
+    memcpy(out, t.taps, sizeof(float) * (size_t)(n < max ? n : max));
+    dsp::taps::free(t);
+    return n;
+}
+double ref_nuttall(double n, double N) { return dsp::window::nuttall(n, N); }
+double ref_blackman(double n, double N) { return dsp::window::blackman(n, N); }
+
+// ---- RxVFO -------------------------------------------------------------------------------------------------------------
+struct RefRxVFO {
+    dsp::channel::RxVFO vfo;
+    complex_t* work;
+};
+void* ref_rxvfo_create(double inSR, double outSR, double bandwidth, double offset) {
+    RefRxVFO* r = new RefRxVFO;
+    r->vfo.init(NULL, inSR, outSR, bandwidth, offset);
+    r->work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
+    return r;
+}
+void ref_rxvfo_destroy(void* h) {
+    RefRxVFO* r = (RefRxVFO*)h;
+    dsp::buffer::free(r->work);
+    // RxVFO's destructor asserts/joins only if initialised with a stream thread; never started here.
+    delete r;
+}
+void ref_rxvfo_set_offset(void* h, double offset) { ((RefRxVFO*)h)->vfo.setOffset(offset); }
+// count <= 1 000 000 (STREAM_BUFFER_SIZE, dsp/stream.h:9); out must hold `count` complex samples.
+int ref_rxvfo_process(void* h, int count, const float* in, float* out) {
+    RefRxVFO* r = (RefRxVFO*)h;
+    return r->vfo.process(count, (const complex_t*)in, (complex_t*)out);
+}
+
+// ---- demodulators ---------------------------------------------------------------------------------------------------------
+enum { REF_WFM = 0, REF_NFM = 1, REF_AM = 2, REF_USB = 3, REF_LSB = 4, REF_DSB = 5 };
+struct RefDemod {
+    int mode;
+    dsp::demod::BroadcastFM* wfm = NULL;
+    dsp::demod::FM<stereo_t>* nfm = NULL;
+    dsp::demod::AM<stereo_t>* am = NULL;
+    dsp::demod::SSB<stereo_t>* ssb = NULL;
+};
+void* ref_demod_create(int mode, double bandwidth, double ifSR, int lowPass, double agcAttack, double agcDecay, int carrierAgc) {
+    RefDemod* d = new RefDemod;
+    d->mode = mode;
+    if (mode == REF_WFM) {
+        d->wfm = new dsp::demod::BroadcastFM;
+        d->wfm->init(NULL, bandwidth / 2.0f, ifSR, false, lowPass != 0, false); // wfm.h:78 with stereo/RDS off (wfm.h:363-365)
+    }
+    else if (mode == REF_NFM) {
+        d->nfm = new dsp::demod::FM<stereo_t>;
+        d->nfm->init(NULL, ifSR, bandwidth, lowPass != 0); // nfm.h:29
+    }
+    else if (mode == REF_AM) {
+        d->am = new dsp::demod::AM<stereo_t>;
+        d->am->init(NULL, carrierAgc ? dsp::demod::AM<stereo_t>::AGCMode::CARRIER : dsp::demod::AM<stereo_t>::AGCMode::AUDIO, bandwidth,
+                    agcAttack / ifSR, agcDecay / ifSR, 100.0 / ifSR, ifSR); // radio am.h:34
+    }
+    else {
+        d->ssb = new dsp::demod::SSB<stereo_t>;
+        auto m = (mode == REF_USB) ? dsp::demod::SSB<stereo_t>::Mode::USB : ((mode == REF_LSB) ? dsp::demod::SSB<stereo_t>::Mode::LSB : dsp::demod::SSB<stereo_t>::Mode::DSB);
+        d->ssb->init(NULL, m, bandwidth, ifSR, agcAttack / ifSR, agcDecay / ifSR); // radio usb.h:34
+    }
+    return d;
+}
+void ref_demod_destroy(void* h) {
+    RefDemod* d = (RefDemod*)h;
+    delete d->wfm; delete d->nfm; delete d->am; delete d->ssb;
+    delete d;
+}
+int ref_demod_process(void* h, int count, const float* in, float* out) {
+    RefDemod* d = (RefDemod*)h;
+    complex_t* cin = (complex_t*)in; // the reference's process() signatures are non-const
+    if (d->wfm) { int rds = 0; return d->wfm->process(count, cin, (stereo_t*)out, rds, NULL); }
+    if (d->nfm) { return d->nfm->process(count, cin, (stereo_t*)out); }
+    if (d->am) { return d->am->process(count, cin, (stereo_t*)out); }
+    return d->ssb->process(count, cin, (stereo_t*)out);
+}
+
+// ---- RationalResampler<stereo_t/complex_t> and Deemphasis (AF chain, radio_module.h:102-110) ----------------------------------
+void* ref_resampler_create(double inSR, double outSR) {
+    auto* r = new dsp::multirate::RationalResampler<complex_t>;
+    r->init(NULL, inSR, outSR);
+    return r;
+}
+void ref_resampler_destroy(void* h) { delete (dsp::multirate::RationalResampler<complex_t>*)h; }
+int ref_resampler_process(void* h, int count, const float* in, float* out) {
+    return ((dsp::multirate::RationalResampler<complex_t>*)h)->process(count, (const complex_t*)in, (complex_t*)out);
+}
+void* ref_deemp_create(double tau, double sr) {
+    auto* d = new dsp::filter::Deemphasis<stereo_t>;
+    d->init(NULL, tau, sr);
+    return d;
+}
+void ref_deemp_destroy(void* h) { delete (dsp::filter::Deemphasis<stereo_t>*)h; }
+void ref_deemp_process(void* h, int count, const float* in, float* out) {
+    ((dsp::filter::Deemphasis<stereo_t>*)h)->process(count, (const stereo_t*)in, (stereo_t*)out);
+}
+
+// ---- IQFrontEnd: the real threaded graph (inBuf -> preproc -> Splitter -> Reshaper -> Handler -> handler()) --------------------
+struct RefFrontEnd {
+    IQFrontEnd fe;
+    dsp::stream<complex_t> in;
+    int fftSize;
+    std::mutex mtx;
+    std::vector<float> lines; // appended, fftSize floats per line
+    std::vector<float> cur;
+    std::atomic<int> nlines{ 0 };
+};
+static float* ref_fe_acquire(void* ctx) {
+    RefFrontEnd* f = (RefFrontEnd*)ctx;
+    f->cur.assign((size_t)f->fftSize, 0.0f);
+    return f->cur.data();
+}
+static void ref_fe_release(void* ctx) {
+    RefFrontEnd* f = (RefFrontEnd*)ctx;
+    std::lock_guard<std::mutex> lck(f->mtx);
+    f->lines.insert(f->lines.end(), f->cur.begin(), f->cur.end());
+    f->nlines++;
+}
+// window: 0 RECTANGULAR, 1 BLACKMAN, 2 NUTTALL (iq_frontend.h:18-22)
+void* ref_frontend_create(double sampleRate, int fftSize, double fftRate, int window) {
+    RefFrontEnd* f = new RefFrontEnd;
+    f->fftSize = fftSize;
+    f->fe.init(&f->in, sampleRate, /*buffering*/ false, /*decim*/ 1, /*dcBlocking*/ false, fftSize, fftRate, (IQFrontEnd::FFTWindow)window,
+               ref_fe_acquire, ref_fe_release, f);
+    // The application always re-applies the FFT settings after init (display.cpp:86-92); that is what installs the
+    // fftshift-ed window.
+    f->fe.setFFTWindow((IQFrontEnd::FFTWindow)window);
+    f->fe.start();
+    return f;
+}
+// Feeds `count` samples as blocks of `blockSize` (<= 1e6) and waits until `expectLines` lines have been produced.
+int ref_frontend_feed(void* h, const float* iq, long long count, int blockSize, int expectLines, int timeoutMs) {
+    RefFrontEnd* f = (RefFrontEnd*)h;
+    long long done = 0;
+    while (done < count) {
+        int n = (int)((count - done) < blockSize ? (count - done) : blockSize);
+        memcpy(f->in.writeBuf, iq + 2 * done, sizeof(complex_t) * (size_t)n);
+        if (!f->in.swap(n)) { return -1; }
+        done += n;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    while (f->nlines.load() < expectLines) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeoutMs) { break; }
+    }
+    return f->nlines.load();
+}
+int ref_frontend_lines(void* h, float* out, int maxLines) {
+    RefFrontEnd* f = (RefFrontEnd*)h;
+    std::lock_guard<std::mutex> lck(f->mtx);
+    int n = f->nlines.load();
+    if (n > maxLines) { n = maxLines; }
+    memcpy(out, f->lines.data(), sizeof(float) * (size_t)n * f->fftSize);
+    return n;
+}
+void ref_frontend_destroy(void* h) {
+    RefFrontEnd* f = (RefFrontEnd*)h;
+    f->fe.stop();
+    delete f;
+}
+
+// ---- CPU baseline: the reference's per-VFO process() chain + FFT handler, `nthreads` worker threads ------------------------------
+// Workload = BASELINE cfg 3: nVfo x (RxVFO(inSR -> 250 kHz, bw 150 kHz) + BroadcastFM mono) and one windowed FFT + log-power
+// every `fftInterval` samples, input handed over in blocks of `blockSize` (= sr/200, file_source/main.cpp:157).  VFOs are dealt
+// round-robin to the worker threads (the reference itself runs one thread per block; this partition has less hand-off overhead, i.e.
+// it flatters the CPU).  Returns seconds of wall time for `totalSamples` input samples.
+double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, double inSR, int nVfo, const double* offsets, int fftSize, int nthreads) {
+    std::vector<dsp::channel::RxVFO*> vfos((size_t)nVfo);
+    std::vector<dsp::demod::BroadcastFM*> dem((size_t)nVfo);
+    for (int v = 0; v < nVfo; v++) {
+        vfos[v] = new dsp::channel::RxVFO;
+        vfos[v]->init(NULL, inSR, 250000.0, 150000.0, offsets[v]);
+        dem[v] = new dsp::demod::BroadcastFM;
+        dem[v]->init(NULL, 75000.0, 250000.0, false, true, false);
+    }
+    // FFT branch state (what IQFrontEnd::handler does per frame)
+    std::vector<float> window((size_t)fftSize);
+    for (int i = 0; i < fftSize; i++) { window[i] = dsp::window::nuttall(i, fftSize) * ((i % 2) ? -1.0f : 1.0f); }
+    fftwf_complex* fin = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+    fftwf_complex* fout = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+    fftwf_plan plan = fftwf_plan_dft_1d(fftSize, fin, fout, FFTW_FORWARD, FFTW_ESTIMATE);
+    std::vector<float> db((size_t)fftSize);
+
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) {
+        th.emplace_back([&, t]() {
+            complex_t* work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
+            stereo_t* audio = dsp::buffer::alloc<stereo_t>(STREAM_BUFFER_SIZE);
+            for (long long pos = 0; pos + blockSize <= totalSamples; pos += blockSize) {
+                const complex_t* blk = (const complex_t*)(iq + 2 * pos);
+                for (int v = t; v < nVfo; v += nthreads) {
+                    int n = vfos[v]->process(blockSize, blk, work);
+                    int rds = 0;
+                    dem[v]->process(n, work, audio, rds, NULL);
+                }
+            }
+            if (t == 0) {
+                // dense framing: every fftSize samples one frame (skip = 0)
+                for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
+                    volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
+                    fftwf_execute(plan);
+                    volk_32fc_s32f_power_spectrum_32f(db.data(), (lv_32fc_t*)fout, fftSize, fftSize);
+                }
+            }
+            dsp::buffer::free(work);
+            dsp::buffer::free(audio);
+        });
+    }
+    for (auto& x : th) { x.join(); }
+    auto t1 = std::chrono::steady_clock::now();
+    for (int v = 0; v < nVfo; v++) { delete vfos[v]; delete dem[v]; }
+    fftwf_destroy_plan(plan);
+    fftwf_free(fin);
+    fftwf_free(fout);
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+} // extern "C"

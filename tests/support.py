@@ -1,0 +1,284 @@
+"""ctypes access to the test oracle (oracle/liboracle.so) and, when present, the compiled reference
+(oracle/_ref/libsdrpp_ref.so).  TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg import this module; nothing under sdrplusplus_amd/ does."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+PLANS_PATH = os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def build_oracle():
+    """(Re)build oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "all"], check=True)
+
+
+_oracle = None
+_ref = {}
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.sdrpp_oracle_log2f.restype = C.c_float
+        L.sdrpp_oracle_log2f.argtypes = [C.c_float]
+        L.sdrpp_oracle_log2f_non_ieee.restype = C.c_float
+        L.sdrpp_oracle_log2f_non_ieee.argtypes = [C.c_float]
+        L.sdrpp_oracle_fft.argtypes = [C.c_int, c_float_p, c_float_p]
+        L.sdrpp_oracle_twiddle.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p]
+        L.orc_nuttall.restype = C.c_double
+        L.orc_nuttall.argtypes = [C.c_double, C.c_double]
+        L.orc_blackman.restype = C.c_double
+        L.orc_blackman.argtypes = [C.c_double, C.c_double]
+        L.orc_estimate_tap_count.argtypes = [C.c_double, C.c_double]
+        for f in (L.orc_low_pass, L.orc_high_pass):
+            f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_float_p, C.c_int]
+        L.orc_gen_reshape_params.argtypes = [C.c_double, C.c_int, C.c_double, c_int_p, c_int_p]
+        L.orc_fft_window.argtypes = [C.c_int, C.c_int, c_float_p]
+        L.orc_power_spectrum.argtypes = [c_float_p, C.c_float, C.c_int, c_float_p]
+        L.orc_spectrum_create.restype = C.c_void_p
+        L.orc_spectrum_create.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p]
+        L.orc_spectrum_destroy.argtypes = [C.c_void_p]
+        L.orc_spectrum_push.argtypes = [C.c_void_p, c_float_p, C.c_int, c_float_p, C.c_int]
+        L.orc_do_zoom.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p]
+        L.orc_waterfall_view.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_int_p, c_int_p]
+        L.orc_palette_index.argtypes = [c_float_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int32)]
+        L.orc_plans_load.restype = C.c_void_p
+        L.orc_plans_load.argtypes = [C.c_char_p]
+        L.orc_plans_free.argtypes = [C.c_void_p]
+        L.orc_rxvfo_create.restype = C.c_void_p
+        L.orc_rxvfo_create.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_rxvfo_destroy.argtypes = [C.c_void_p]
+        L.orc_rxvfo_set_offset.argtypes = [C.c_void_p, C.c_double]
+        L.orc_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_rxvfo_info.argtypes = [C.c_void_p] + [c_int_p] * 8
+        L.orc_rxvfo_phase_delta.argtypes = [C.c_void_p, c_float_p, c_float_p]
+        L.orc_demod_create.restype = C.c_void_p
+        L.orc_demod_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.orc_demod_destroy.argtypes = [C.c_void_p]
+        L.orc_demod_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_demod_audio_taps.argtypes = [C.c_void_p]
+        L.orc_resampler_create.restype = C.c_void_p
+        L.orc_resampler_create.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.orc_resampler_destroy.argtypes = [C.c_void_p]
+        L.orc_resampler_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_resampler_info.argtypes = [C.c_void_p] + [c_int_p] * 6
+        L.orc_deemp_create.restype = C.c_void_p
+        L.orc_deemp_create.argtypes = [C.c_double, C.c_double]
+        L.orc_deemp_destroy.argtypes = [C.c_void_p]
+        L.orc_deemp_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_int16_to_float.argtypes = [C.POINTER(C.c_int16), c_float_p, C.c_int]
+        L.orc_fir_create.restype = C.c_void_p
+        L.orc_fir_create.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int]
+        L.orc_fir_destroy.argtypes = [C.c_void_p]
+        L.orc_fir_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_xlator_create.restype = C.c_void_p
+        L.orc_xlator_create.argtypes = [C.c_double, C.c_double]
+        L.orc_xlator_destroy.argtypes = [C.c_void_p]
+        L.orc_xlator_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_xlator_state.argtypes = [C.c_void_p] + [c_float_p] * 4
+        _oracle = L
+    return _oracle
+
+
+def ref_available(fast=False):
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libsdrpp_ref_fast.so" if fast else "libsdrpp_ref.so"))
+
+
+def ref(fast=False):
+    """The reference's own code compiled against oracle/shim (None if oracle/_ref was never built)."""
+    if fast not in _ref:
+        path = os.path.join(ORACLE_DIR, "_ref", "libsdrpp_ref_fast.so" if fast else "libsdrpp_ref.so")
+        if not os.path.exists(path):
+            _ref[fast] = None
+            return None
+        L = C.CDLL(path)
+        for f in (L.ref_low_pass, L.ref_high_pass):
+            f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_float_p, C.c_int]
+        L.ref_nuttall.restype = C.c_double
+        L.ref_nuttall.argtypes = [C.c_double, C.c_double]
+        L.ref_blackman.restype = C.c_double
+        L.ref_blackman.argtypes = [C.c_double, C.c_double]
+        L.ref_rxvfo_create.restype = C.c_void_p
+        L.ref_rxvfo_create.argtypes = [C.c_double] * 4
+        L.ref_rxvfo_destroy.argtypes = [C.c_void_p]
+        L.ref_rxvfo_set_offset.argtypes = [C.c_void_p, C.c_double]
+        L.ref_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.ref_demod_create.restype = C.c_void_p
+        L.ref_demod_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.ref_demod_destroy.argtypes = [C.c_void_p]
+        L.ref_demod_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.ref_resampler_create.restype = C.c_void_p
+        L.ref_resampler_create.argtypes = [C.c_double, C.c_double]
+        L.ref_resampler_destroy.argtypes = [C.c_void_p]
+        L.ref_resampler_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.ref_deemp_create.restype = C.c_void_p
+        L.ref_deemp_create.argtypes = [C.c_double, C.c_double]
+        L.ref_deemp_destroy.argtypes = [C.c_void_p]
+        L.ref_deemp_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.ref_frontend_create.restype = C.c_void_p
+        L.ref_frontend_create.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int]
+        L.ref_frontend_feed.argtypes = [C.c_void_p, c_float_p, C.c_longlong, C.c_int, C.c_int, C.c_int]
+        L.ref_frontend_lines.argtypes = [C.c_void_p, c_float_p, C.c_int]
+        L.ref_frontend_destroy.argtypes = [C.c_void_p]
+        L.ref_bench_cfg3.restype = C.c_double
+        L.ref_bench_cfg3.argtypes = [c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int]
+        _ref[fast] = L
+    return _ref[fast]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Convenience wrappers (numpy in / numpy out).  Complex data is np.complex64; stereo audio is float32 [n, 2].
+# ---------------------------------------------------------------------------------------------------------------------
+_plans_handle = None
+
+
+def plans_handle():
+    global _plans_handle
+    if _plans_handle is None:
+        _plans_handle = oracle().orc_plans_load(PLANS_PATH.encode())
+        assert _plans_handle, "cannot load " + PLANS_PATH
+    return _plans_handle
+
+
+def c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def oracle_fft(x):
+    x = c64(x)
+    out = np.empty_like(x)
+    oracle().sdrpp_oracle_fft(len(x), _fp(x.view(np.float32)), _fp(out.view(np.float32)))
+    return out
+
+
+def oracle_low_pass(cutoff, trans, sr, odd=False):
+    n = oracle().orc_estimate_tap_count(trans, sr) + 1
+    t = np.zeros(n, dtype=np.float32)
+    n = oracle().orc_low_pass(cutoff, trans, sr, int(odd), _fp(t), len(t))
+    return t[:n].copy()
+
+
+def oracle_fft_window(kind, nz):
+    w = np.empty(nz, dtype=np.float32)
+    oracle().orc_fft_window(kind, nz, _fp(w))
+    return w
+
+
+class OracleSpectrum:
+    """Reshaper + IQFrontEnd::handler restatement (streaming)."""
+
+    def __init__(self, fft_size, nz, skip, window):
+        self.N, self.nz, self.skip = fft_size, nz, skip
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        self.h = oracle().orc_spectrum_create(fft_size, nz, skip, _fp(w))
+
+    def push(self, iq):
+        iq = c64(iq)
+        max_lines = len(iq) // max(1, self.nz + self.skip) + 2
+        out = np.empty((max_lines, self.N), dtype=np.float32)
+        n = oracle().orc_spectrum_push(self.h, _fp(iq.view(np.float32)), len(iq), _fp(out), max_lines)
+        return out[:n].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            oracle().orc_spectrum_destroy(self.h)
+            self.h = None
+
+
+def oracle_do_zoom(offset, width, out_size, line):
+    line = np.ascontiguousarray(line, dtype=np.float32)
+    out = np.empty(out_size, dtype=np.float32)
+    oracle().orc_do_zoom(offset, width, len(line), out_size, _fp(line), _fp(out))
+    return out
+
+
+def oracle_palette_index(zoomed, wmin, wmax):
+    z = np.ascontiguousarray(zoomed, dtype=np.float32)
+    idx = np.empty(len(z), dtype=np.int32)
+    oracle().orc_palette_index(_fp(z), len(z), wmin, wmax, idx.ctypes.data_as(C.POINTER(C.c_int32)))
+    return idx
+
+
+class _Chain:
+    """RxVFO + demodulator pair driven block by block, backed by either the oracle or the compiled reference."""
+
+    def __init__(self, lib, prefix, in_sr, out_sr, bw, offset, mode, low_pass=True, agc_attack=50.0, agc_decay=5.0, carrier_agc=False):
+        self.lib, self.p = lib, prefix
+        g = lambda name: getattr(lib, prefix + name)
+        if prefix == "orc_":
+            self.vfo = g("rxvfo_create")(plans_handle(), in_sr, out_sr, bw, offset)
+        else:
+            self.vfo = g("rxvfo_create")(in_sr, out_sr, bw, offset)
+        self.dem = None
+        if mode is not None:
+            self.dem = g("demod_create")(mode, bw, out_sr, int(low_pass), agc_attack, agc_decay, int(carrier_agc))
+
+    def vfo_process(self, iq):
+        iq = c64(iq)
+        out = np.empty(len(iq) + 16, dtype=np.complex64)
+        n = getattr(self.lib, self.p + "rxvfo_process")(self.vfo, len(iq), _fp(iq.view(np.float32)), _fp(out.view(np.float32)))
+        return out[:n].copy()
+
+    def demod_process(self, ifs):
+        ifs = c64(ifs)
+        out = np.empty((len(ifs) + 1, 2), dtype=np.float32)
+        n = getattr(self.lib, self.p + "demod_process")(self.dem, len(ifs), _fp(ifs.view(np.float32)), _fp(out))
+        return out[:n].copy()
+
+    def process(self, iq):
+        ifs = self.vfo_process(iq)
+        if self.dem is None:
+            return ifs, None
+        return ifs, self.demod_process(ifs)
+
+    def set_offset(self, offset):
+        getattr(self.lib, self.p + "rxvfo_set_offset")(self.vfo, offset)
+
+    def close(self):
+        if self.vfo:
+            getattr(self.lib, self.p + "rxvfo_destroy")(self.vfo)
+            self.vfo = None
+        if self.dem:
+            getattr(self.lib, self.p + "demod_destroy")(self.dem)
+            self.dem = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def OracleChain(*a, **k):
+    return _Chain(oracle(), "orc_", *a, **k)
+
+
+def RefChain(*a, fast=False, **k):
+    lib = ref(fast)
+    assert lib is not None, "oracle/_ref not built"
+    return _Chain(lib, "ref_", *a, **k)
+
+
+def oracle_rxvfo_info(chain):
+    vals = [C.c_int() for _ in range(8)]
+    oracle().orc_rxvfo_info(chain.vfo, *[C.byref(v) for v in vals])
+    keys = ["mode", "predec", "interp", "decim", "rtaps", "taps_per_phase", "chan_taps", "filter_needed"]
+    return dict(zip(keys, [v.value for v in vals]))
+
+
+MODES = {"WFM": 0, "NFM": 1, "AM": 2, "USB": 3, "LSB": 4, "DSB": 5}
