@@ -1,0 +1,172 @@
+/*
+ * sdrpp_gpu.h — C-ABI of the MI355X (gfx950) implementation of SDR++'s streaming-DSP hot path.
+ *
+ * One `sdrpp_ctx` = one wideband IQ stream on one GPU = what one `IQFrontEnd` owns in the reference
+ * (core/src/signal_path/iq_frontend.h:12-109): the FFT -> log-power -> waterfall-line branch and N per-VFO channelisers
+ * (dsp::channel::RxVFO, core/src/dsp/channel/rx_vfo.h) followed by the radio module's demodulators
+ * (decoder_modules/radio/src/demodulators/{wfm,nfm,am,usb,lsb,dsb}.h).  All arithmetic runs in hand-written HIP
+ * kernels; there is NO CPU fallback — every entry point returns SDRPP_ERR_NO_DEVICE when no gfx950 device exists.
+ *
+ * Conventions: plain C, opaque context, `int` return (0 = OK, negative = error, see sdrpp_strerror), no exceptions,
+ * no C++ or torch types.  Complex IQ is interleaved float32 {re, im} (dsp::complex_t, core/src/dsp/types.h:6-92);
+ * audio is interleaved float32 {l, r} (dsp::stereo_t, types.h:94-127).  A context is thread-compatible: one caller
+ * thread at a time (the reference serialises reconfiguration with block::ctrlMtx + tempStop/tempStart,
+ * core/src/dsp/block.h:46-62; the host block wrappers in sdrplusplus_amd/host keep that rule).
+ *
+ * The taps / window / NCO constants are passed IN by the caller, designed with the reference's own double-precision
+ * host maths (dsp/taps, dsp/window, dsp/multirate/decim/plans.h) so that they stay bit-identical to what an
+ * SDR++ build computes; sdrpp_design_* below restate that maths for callers that do not link SDR++'s headers.
+ */
+#ifndef SDRPP_GPU_H
+#define SDRPP_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRPP_OK 0
+#define SDRPP_ERR_NO_DEVICE (-1)   /* no HIP device / not gfx950 / HIP runtime error at create */
+#define SDRPP_ERR_INVALID (-2)     /* bad argument or call sequence */
+#define SDRPP_ERR_NOMEM (-3)       /* hipMalloc failed */
+#define SDRPP_ERR_HIP (-4)         /* HIP runtime error (message in sdrpp_last_error) */
+#define SDRPP_ERR_UNSUPPORTED (-5) /* parameter outside what the kernels implement */
+#define SDRPP_ERR_NOT_FOUND (-6)   /* unknown VFO id (IQFrontEnd::removeVFO logs the same condition, iq_frontend.cpp:164-167) */
+
+typedef struct sdrpp_ctx sdrpp_ctx;
+
+/* ---- lifecycle ----------------------------------------------------------------------------------------------------- */
+/* Replaces IQFrontEnd::init's allocation half (iq_frontend.cpp:17-71).  `max_push` = largest sample count one
+ * sdrpp_push* call will carry (the reference's streams carry <= 1 000 000, core/src/dsp/stream.h:9; device-resident
+ * callers may use larger batches). */
+int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** ctx);
+int sdrpp_destroy(sdrpp_ctx* ctx);
+const char* sdrpp_strerror(int code);
+const char* sdrpp_last_error(const sdrpp_ctx* ctx);
+/* Run all work of this context on the caller's HIP stream (hipStream_t cast to void*), e.g. torch's current stream;
+ * NULL restores the context-owned stream. */
+int sdrpp_set_stream(sdrpp_ctx* ctx, void* hip_stream);
+int sdrpp_sync(sdrpp_ctx* ctx);
+/* Human-readable device name / arch into buf (for logs and bench records). */
+int sdrpp_device_info(sdrpp_ctx* ctx, char* buf, int buflen);
+
+/* ---- host-side design maths (pure CPU, double precision; restates the reference's header maths) ---------------------- */
+/* dsp/taps/low_pass.h:7-11, high_pass.h:7-15 (Nuttall-windowed sinc, tap count int(3.8*sr/tw)).  Return the tap count;
+ * write min(count, max) taps.  Call with max = 0 to size the buffer. */
+int sdrpp_design_low_pass(double cutoff, double trans_width, double sample_rate, int odd_tap_count, float* taps, int max);
+int sdrpp_design_high_pass(double cutoff, double trans_width, double sample_rate, int odd_tap_count, float* taps, int max);
+/* iq_frontend.cpp:280-291: kind 0 RECTANGULAR, 1 BLACKMAN, 2 NUTTALL; includes the (-1)^i fftshift factor. */
+int sdrpp_design_fft_window(int kind, int nz, float* window);
+/* iq_frontend.h:59-63 */
+void sdrpp_design_reshape_params(double sample_rate, int fft_size, double fft_rate, int* skip, int* nz);
+/* frequency_xlator.h:17,28: phaseDelta = (float)cos(w), (float)sin(w), w = 2*pi*(offset_hz/sample_rate). */
+void sdrpp_design_phase_delta(double offset_hz, double sample_rate, float* re, float* im);
+/* rational_resampler.h:120-165: picks the power-of-two pre-decimation, the polyphase L/M and designs the polyphase taps
+ * (already multiplied by L).  mode: 0 BOTH, 1 DECIM_ONLY, 2 RESAMP_ONLY, 3 NONE.  `max_ratio` = 1 << plans_len
+ * (power_decimator.h:29-31; 8192 for the reference's tables).  Returns tap count (0 if no polyphase stage). */
+int sdrpp_design_resampler(double in_sr, double out_sr, int max_ratio, int* mode, int* predec_ratio, int* interp, int* decim,
+                           float* taps, int max);
+/* gui/widgets/waterfall.cpp:891-894 (view -> bin window) */
+void sdrpp_design_waterfall_view(double view_offset, double view_bandwidth, double whole_bandwidth, int raw_fft_size,
+                                 int* draw_data_start, int* draw_data_size);
+
+/* ---- FFT -> log-power -> waterfall line (replaces Reshaper + Handler + IQFrontEnd::handler, iq_frontend.cpp:248-309,
+ *      and WaterFall::pushFFT's doZoom + palette index, waterfall.cpp:65-90, 889-906) --------------------------------------- */
+/* fft_size: power of two 1024..1048576.  Frame k covers stream samples [k*(nz+skip), k*(nz+skip)+nz) since the last
+ * configure/reset (reshaper.h:101-128); fftIn[nz:fft_size] is zero (iq_frontend.cpp:301).  `window` has nz floats.
+ * Reconfiguring drops the partial frame, like updateFFTPath's tempStop/tempStart. */
+int sdrpp_fft_configure(sdrpp_ctx* ctx, int fft_size, int nz, int skip, const float* window);
+int sdrpp_fft_disable(sdrpp_ctx* ctx);
+/* doZoom(draw_data_start, draw_data_size, fft_size, data_width) then palette index
+ * (int)((clamp(v, wf_min, wf_max) - wf_min) / (wf_max - wf_min) * 999999).  data_width = 0 disables the zoomed outputs. */
+int sdrpp_fft_set_view(sdrpp_ctx* ctx, int draw_data_start, int draw_data_size, int data_width, float wf_min, float wf_max);
+/* Lines produced by the most recent push (each overwrites the previous push's). */
+int sdrpp_fft_lines(sdrpp_ctx* ctx);
+/* Copy line `first`..`first+n-1` of the last push to host memory: raw dB lines (fft_size floats each, DC-centred — what
+ * acquireFFTBuffer/releaseFFTBuffer hand to the waterfall), zoomed lines (data_width floats) and palette indices.
+ * Any destination may be NULL.  Returns the number of lines copied. */
+int sdrpp_fft_read(sdrpp_ctx* ctx, int first, int n, float* raw_host, float* zoomed_host, int32_t* index_host);
+/* Device pointers to the same buffers (valid until the next push). */
+int sdrpp_fft_device_buffers(sdrpp_ctx* ctx, const float** raw, const float** zoomed, const int32_t** index, int* n_lines);
+
+/* ---- VFO bank (replaces Splitter fan-out + N x RxVFO + radio demodulators) --------------------------------------------------- */
+#define SDRPP_MAX_DECIM_STAGES 4
+
+enum sdrpp_demod_mode {
+    SDRPP_DEMOD_RAW = -1, /* no demodulator: output = RxVFO::out (complex IF)                                        */
+    SDRPP_DEMOD_WFM = 0,  /* dsp::demod::BroadcastFM mono branch (broadcast_fm.h:146,205-211)                        */
+    SDRPP_DEMOD_NFM = 1,  /* dsp::demod::FM<stereo_t> (fm.h:79-96)                                                   */
+    SDRPP_DEMOD_AM = 2,   /* dsp::demod::AM<stereo_t> (am.h:101-133)                                                 */
+    SDRPP_DEMOD_USB = 3,  /* dsp::demod::SSB<stereo_t> (ssb.h:77-92)                                                 */
+    SDRPP_DEMOD_LSB = 4,
+    SDRPP_DEMOD_DSB = 5
+};
+
+typedef struct sdrpp_vfo_desc {
+    /* FrequencyXlator (frequency_xlator.h:14-30): phaseDelta for -offset at the input rate */
+    float phase_delta_re, phase_delta_im;
+    /* PowerDecimator (power_decimator.h:93-111): stages of the chosen plan, in order; n_stages = 0 for ratio 1 */
+    int n_stages;
+    int stage_decim[SDRPP_MAX_DECIM_STAGES];
+    int stage_ntaps[SDRPP_MAX_DECIM_STAGES];
+    const float* stage_taps[SDRPP_MAX_DECIM_STAGES];
+    /* PolyphaseResampler (polyphase_resampler.h:69-99): interp == decim -> stage absent; taps already scaled by interp */
+    int interp, decim;
+    int resamp_ntaps;
+    const float* resamp_taps;
+    /* RxVFO channel filter (rx_vfo.h:95-98, 117-121); chan_ntaps = 0 when bandwidth == out rate (filterNeeded false) */
+    int chan_ntaps;
+    const float* chan_taps;
+    /* demodulator */
+    int demod;                /* enum sdrpp_demod_mode */
+    float inv_deviation;      /* Quadrature::_invDeviation = 1/hzToRads(deviation, if_rate) (quadrature.h:19-26)         */
+    int audio_ntaps;          /* WFM alFir / NFM fir / AM lpf real taps; 0 = filter bypassed (fm.h:88, broadcast_fm.h:205) */
+    const float* audio_taps;
+    /* loop::AGC (agc.h:15-27), used by AM (audio or carrier AGC) and SSB */
+    float agc_set_point, agc_attack, agc_decay, agc_max_gain, agc_max_output_amp, agc_init_gain;
+    int am_carrier_agc;       /* AM: 1 = AGCMode::CARRIER, 0 = AGCMode::AUDIO (am.h:14-17)                               */
+    float dc_block_rate;      /* AM: DCBlocker rate (am.h:32 -> dc_blocker.h:54-60)                                       */
+    float ssb_phase_delta_re, ssb_phase_delta_im; /* SSB second xlator (ssb.h:24,106-117)                                */
+} sdrpp_vfo_desc;
+
+/* IQFrontEnd::addVFO / removeVFO (iq_frontend.cpp:140-183).  Arrays in `desc` are copied.  *id receives a handle. */
+int sdrpp_vfo_add(sdrpp_ctx* ctx, const sdrpp_vfo_desc* desc, int* id);
+int sdrpp_vfo_remove(sdrpp_ctx* ctx, int id);
+int sdrpp_vfo_count(sdrpp_ctx* ctx);
+/* RxVFO::setOffset (rx_vfo.h:72-77): only phaseDelta changes, phase stays continuous. */
+int sdrpp_vfo_set_phase_delta(sdrpp_ctx* ctx, int id, float re, float im);
+/* RxVFO::setBandwidth (rx_vfo.h:60-70): swap the channel-filter taps, history kept (fir.h:31-52). n = 0 bypasses. */
+int sdrpp_vfo_set_channel_taps(sdrpp_ctx* ctx, int id, const float* taps, int n);
+/* RxVFO::reset + demod reset: clears histories, NCO phase and loop states. */
+int sdrpp_vfo_reset(sdrpp_ctx* ctx, int id);
+/* Output of the most recent push: number of samples (stereo frames, or complex IF samples in RAW mode). */
+int sdrpp_vfo_out_count(sdrpp_ctx* ctx, int id);
+/* Copy up to max samples (2 floats each) to host memory; returns the count copied (what RxVFO::run/demod swap()). */
+int sdrpp_vfo_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
+/* Device pointers: demodulated audio (or IF in RAW mode) and the complex IF stream (RxVFO::out) of the last push. */
+int sdrpp_vfo_device_buffers(sdrpp_ctx* ctx, int id, const float** out, int* n_out, const float** if_out, int* n_if);
+
+/* ---- data path ------------------------------------------------------------------------------------------------------------ */
+/* One block of IQ, as Splitter::run hands to every bound stream (splitter.h:46-61).  Host pointer: copied H2D first.
+ * Device pointer: read in place (must stay valid until the next sdrpp_sync / stream synchronisation).  Runs the FFT
+ * branch and every VFO; asynchronous on the context's stream — outputs are readable after sdrpp_sync (the read calls
+ * synchronise themselves). */
+int sdrpp_push(sdrpp_ctx* ctx, const float* iq_host, int64_t count);
+int sdrpp_push_device(sdrpp_ctx* ctx, const float* iq_dev, int64_t count);
+/* file_source path (source_modules/file_source/src/main.cpp:154-167): interleaved int16 IQ converted on the device
+ * (x / 32768), halving the PCIe bytes.  Host pointer. */
+int sdrpp_push_int16(sdrpp_ctx* ctx, const int16_t* iq_host, int64_t count);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
+/* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.
+ * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc */
+#define SDRPP_NUM_KERNEL_FAMILIES 10
+int sdrpp_timing_enable(sdrpp_ctx* ctx, int on);
+int sdrpp_timing_read(sdrpp_ctx* ctx, double* ms_per_family, int64_t* launches_per_family);
+const char* sdrpp_kernel_family_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRPP_GPU_H */

@@ -73,11 +73,33 @@ float sdrpp_oracle_log2f_non_ieee(float x) {
     return isinf(r) ? copysignf(127.0f, r) : r;
 }
 
-/* Twiddle e^{-2 pi i e / L}: both components computed in double and rounded once to float. */
+/* Twiddle tw(e, L) = e^{-2 pi i e / L} as two floats.  Only angles in [0, pi/4] are evaluated (double libm, rounded
+ * once to float); every other entry follows by the exact symmetries of sine and cosine, so the table is exactly
+ * symmetric: tw(0) = (1, -0), tw(L/4) = (-0, -1), tw(e + L/4) = -j * tw(e) bit for bit. */
 void sdrpp_oracle_twiddle(int e, int L, float* re, float* im) {
-    const double a = 2.0 * DB_M_PI * ((double)e / (double)L);
-    *re = (float)cos(a);
-    *im = (float)(-sin(a));
+    int Lv = L, ev = ((e % L) + L) % L;
+    if (Lv < 8) { ev *= 8 / Lv; Lv = 8; }
+    const int quarter = Lv / 4, qd = ev / quarter, r = ev % quarter;
+    float c, s;
+    if (r <= Lv / 8) {
+        const double a = 2.0 * DB_M_PI * ((double)r / (double)Lv);
+        c = (float)cos(a);
+        s = (float)sin(a);
+    }
+    else {
+        const double a = 2.0 * DB_M_PI * ((double)(quarter - r) / (double)Lv);
+        c = (float)sin(a);
+        s = (float)cos(a);
+    }
+    float cv, sv; /* cos and sin of the full angle */
+    switch (qd) {
+    case 0: cv = c; sv = s; break;
+    case 1: cv = -s; sv = c; break;
+    case 2: cv = -c; sv = -s; break;
+    default: cv = s; sv = -c; break;
+    }
+    *re = cv;
+    *im = -sv;
 }
 
 #define ORC_FFT_SINGLE_PASS_MAX 4096
@@ -91,14 +113,14 @@ static unsigned bitrev(unsigned v, int bits) {
     return r;
 }
 
-/* Sub-FFT, L = 2^lg <= 4096: classic radix-2 decimation in time on the bit-reversed sequence.
- * Butterfly (u, v, w = tw(k, M)):
- *   k == 0      : X0 = u + v                     X1 = u - v
- *   4k == M     : X0 = (u.re + v.im, u.im - v.re) X1 = (u.re - v.im, u.im + v.re)        (w = -j, exact)
- *   otherwise   : X0.re = fmaf(-w.im, v.im, fmaf(w.re, v.re, u.re))
- *                 X0.im = fmaf( w.im, v.re, fmaf(w.re, v.im, u.im))
- *                 X1    = fmaf(2, u, -X0)        (per component)
- * tw(k, M) is read as tw(k * L/M, L) — the same float because k/M is exact in binary. */
+/* Sub-FFT, L = 2^lg <= 4096: classic radix-2 decimation in time on the bit-reversed sequence.  Every butterfly
+ * (u, v, w = tw(k, M)), including the ones with w = 1 and w = -j, is
+ *     X0.re = fmaf(-w.im, v.im, fmaf(w.re, v.re, u.re))
+ *     X0.im = fmaf( w.im, v.re, fmaf(w.re, v.im, u.im))
+ *     X1    = fmaf(2, u, -X0)                                   (per component)
+ * i.e. six fused multiply-adds.  Because tw(0) and tw(M/4) are exact, X0 degenerates to u + v resp.
+ * (u.re + v.im, u.im - v.re) for them, bit for bit (up to the sign of a zero, which never reaches the dB output).
+ * tw(k, M) is read as tw(k * L/M, L) - the same float because the symmetric table only depends on k/M. */
 static void sub_fft(int lg, const float* in, int in_stride /* complex elements */, float* y, const float* tw /* L/2 pairs */) {
     const int L = 1 << lg;
     for (int p = 0; p < L; p++) {
@@ -113,22 +135,12 @@ static void sub_fft(int lg, const float* in, int in_stride /* complex elements *
                 float* U = &y[2 * (b + k)];
                 float* V = &y[2 * (b + k + H)];
                 const float ur = U[0], ui = U[1], vr = V[0], vi = V[1];
-                if (k == 0) {
-                    U[0] = ur + vr; U[1] = ui + vi;
-                    V[0] = ur - vr; V[1] = ui - vi;
-                }
-                else if (4 * k == M) {
-                    U[0] = ur + vi; U[1] = ui - vr;
-                    V[0] = ur - vi; V[1] = ui + vr;
-                }
-                else {
-                    const float wr = tw[2 * k * tstep], wi = tw[2 * k * tstep + 1];
-                    const float x0r = fmaf(-wi, vi, fmaf(wr, vr, ur));
-                    const float x0i = fmaf(wi, vr, fmaf(wr, vi, ui));
-                    U[0] = x0r; U[1] = x0i;
-                    V[0] = fmaf(2.0f, ur, -x0r);
-                    V[1] = fmaf(2.0f, ui, -x0i);
-                }
+                const float wr = tw[2 * k * tstep], wi = tw[2 * k * tstep + 1];
+                const float x0r = fmaf(-wi, vi, fmaf(wr, vr, ur));
+                const float x0i = fmaf(wi, vr, fmaf(wr, vi, ui));
+                U[0] = x0r; U[1] = x0i;
+                V[0] = fmaf(2.0f, ur, -x0r);
+                V[1] = fmaf(2.0f, ui, -x0i);
             }
         }
     }
@@ -159,8 +171,7 @@ static const float* get_tw_full(int lg) {
 /* Forward unnormalised DFT, sign -1, n = 2^m, 1 <= m <= 20 (what fftwf_plan_dft_1d(FFTW_FORWARD) computes,
  * iq_frontend.cpp:62,255).  n <= 4096: one sub-FFT.  n > 4096: four-step, N1 = 2^floor(m/2), N2 = n / N1:
  *   A[k1][n2] = subFFT_N1 over n1 of x[N2*n1 + n2]
- *   B[k1][n2] = A[k1][n2] * tw(n2*k1, n)      (n2*k1 == 0: copy; else re = fmaf(a.re, w.re, -(a.im*w.im)),
- *                                                                      im = fmaf(a.re, w.im,   a.im*w.re ))
+ *   B[k1][n2] = A[k1][n2] * tw(n2*k1, n):  re = fmaf(a.re, w.re, -(a.im*w.im)),  im = fmaf(a.re, w.im, a.im*w.re)
  *   X[k1 + N1*k2] = subFFT_N2 over n2 of B[k1][n2]
  * Not thread-safe on first use of a size (table cache); tests and the baseline warm it from one thread. */
 void sdrpp_oracle_fft(int n, const float* in, float* out) {
@@ -191,16 +202,11 @@ void sdrpp_oracle_fft(int n, const float* in, float* out) {
             const float ar = col[2 * k1], ai = col[2 * k1 + 1];
             float* dst = &B[2 * ((size_t)k1 * N2 + n2)];
             const size_t e = (size_t)n2 * k1;
-            if (e == 0) {
-                dst[0] = ar; dst[1] = ai;
-            }
-            else {
-                const float wr = twN[2 * e], wi = twN[2 * e + 1];
-                const float p = ai * wi;
-                const float q = ai * wr;
-                dst[0] = fmaf(ar, wr, -p);
-                dst[1] = fmaf(ar, wi, q);
-            }
+            const float wr = twN[2 * e], wi = twN[2 * e + 1];
+            const float p = ai * wi;
+            const float q = ai * wr;
+            dst[0] = fmaf(ar, wr, -p);
+            dst[1] = fmaf(ar, wi, q);
         }
     }
     for (int k1 = 0; k1 < N1; k1++) {

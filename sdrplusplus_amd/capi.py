@@ -1,0 +1,357 @@
+"""ctypes binding of the C-ABI in include/sdrpp_gpu.h (sdrplusplus_amd/csrc/libsdrpp_gpu.so).
+
+The library is the product: every data-path call runs hand-written HIP kernels on a gfx950 device and there is no CPU
+fallback — `Context()` raises `SdrppError` (SDRPP_ERR_NO_DEVICE) when no GPU is present, and importing this module
+raises `ImportError` when the shared library has not been built (`python -c "import __graft_entry__ as g; g.build()"`).
+
+Tests may point SDRPP_GPU_LIB at the fiber-emulator build (tests/emu) to exercise host logic without a GPU; nothing in
+this package does so on its own.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libsdrpp_gpu.so")
+
+MAX_DECIM_STAGES = 4
+NUM_KERNEL_FAMILIES = 10
+
+DEMOD_RAW, DEMOD_WFM, DEMOD_NFM, DEMOD_AM, DEMOD_USB, DEMOD_LSB, DEMOD_DSB = -1, 0, 1, 2, 3, 4, 5
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class VfoDesc(C.Structure):
+    """struct sdrpp_vfo_desc (include/sdrpp_gpu.h)."""
+
+    _fields_ = [
+        ("phase_delta_re", C.c_float),
+        ("phase_delta_im", C.c_float),
+        ("n_stages", C.c_int),
+        ("stage_decim", C.c_int * MAX_DECIM_STAGES),
+        ("stage_ntaps", C.c_int * MAX_DECIM_STAGES),
+        ("stage_taps", c_float_p * MAX_DECIM_STAGES),
+        ("interp", C.c_int),
+        ("decim", C.c_int),
+        ("resamp_ntaps", C.c_int),
+        ("resamp_taps", c_float_p),
+        ("chan_ntaps", C.c_int),
+        ("chan_taps", c_float_p),
+        ("demod", C.c_int),
+        ("inv_deviation", C.c_float),
+        ("audio_ntaps", C.c_int),
+        ("audio_taps", c_float_p),
+        ("agc_set_point", C.c_float),
+        ("agc_attack", C.c_float),
+        ("agc_decay", C.c_float),
+        ("agc_max_gain", C.c_float),
+        ("agc_max_output_amp", C.c_float),
+        ("agc_init_gain", C.c_float),
+        ("am_carrier_agc", C.c_int),
+        ("dc_block_rate", C.c_float),
+        ("ssb_phase_delta_re", C.c_float),
+        ("ssb_phase_delta_im", C.c_float),
+    ]
+
+
+class SdrppError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sdrpp error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+_lib_path = None
+
+
+def lib_path():
+    return os.environ.get("SDRPP_GPU_LIB", DEFAULT_LIB)
+
+
+def load():
+    """Load (once) and prototype the shared library."""
+    global _lib, _lib_path
+    path = lib_path()
+    if _lib is not None and _lib_path == path:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError("%s not built — run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.sdrpp_create.argtypes = [C.c_int, C.c_int64, C.POINTER(vp)]
+    L.sdrpp_destroy.argtypes = [vp]
+    L.sdrpp_strerror.restype = C.c_char_p
+    L.sdrpp_strerror.argtypes = [C.c_int]
+    L.sdrpp_last_error.restype = C.c_char_p
+    L.sdrpp_last_error.argtypes = [vp]
+    L.sdrpp_set_stream.argtypes = [vp, vp]
+    L.sdrpp_sync.argtypes = [vp]
+    L.sdrpp_device_info.argtypes = [vp, C.c_char_p, C.c_int]
+    for f in (L.sdrpp_design_low_pass, L.sdrpp_design_high_pass):
+        f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_float_p, C.c_int]
+    L.sdrpp_design_fft_window.argtypes = [C.c_int, C.c_int, c_float_p]
+    L.sdrpp_design_reshape_params.restype = None
+    L.sdrpp_design_reshape_params.argtypes = [C.c_double, C.c_int, C.c_double, c_int_p, c_int_p]
+    L.sdrpp_design_phase_delta.restype = None
+    L.sdrpp_design_phase_delta.argtypes = [C.c_double, C.c_double, c_float_p, c_float_p]
+    L.sdrpp_design_resampler.argtypes = [C.c_double, C.c_double, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_float_p, C.c_int]
+    L.sdrpp_design_waterfall_view.restype = None
+    L.sdrpp_design_waterfall_view.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_int_p, c_int_p]
+    L.sdrpp_fft_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_float_p]
+    L.sdrpp_fft_disable.argtypes = [vp]
+    L.sdrpp_fft_set_view.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.sdrpp_fft_lines.argtypes = [vp]
+    L.sdrpp_fft_read.argtypes = [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_int32_p]
+    L.sdrpp_fft_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p]
+    L.sdrpp_vfo_add.argtypes = [vp, C.POINTER(VfoDesc), c_int_p]
+    L.sdrpp_vfo_remove.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_count.argtypes = [vp]
+    L.sdrpp_vfo_set_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
+    L.sdrpp_vfo_set_channel_taps.argtypes = [vp, C.c_int, c_float_p, C.c_int]
+    L.sdrpp_vfo_reset.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_out_count.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_read.argtypes = [vp, C.c_int, c_float_p, C.c_int]
+    L.sdrpp_vfo_device_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(vp), c_int_p]
+    L.sdrpp_push.argtypes = [vp, c_float_p, C.c_int64]
+    L.sdrpp_push_device.argtypes = [vp, vp, C.c_int64]
+    L.sdrpp_push_int16.argtypes = [vp, C.POINTER(C.c_int16), C.c_int64]
+    L.sdrpp_timing_enable.argtypes = [vp, C.c_int]
+    L.sdrpp_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.sdrpp_kernel_family_name.restype = C.c_char_p
+    L.sdrpp_kernel_family_name.argtypes = [C.c_int]
+    _lib, _lib_path = L, path
+    return L
+
+
+# symbols include/sdrpp_gpu.h declares (checked by the CPU test-suite against the built library)
+EXPORTED_SYMBOLS = [
+    "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_device_info",
+    "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
+    "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view",
+    "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_device_buffers",
+    "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
+    "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
+    "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
+    "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
+]
+
+
+# ---- host-side design helpers (pure CPU maths inside the library) ---------------------------------------------------------
+def design_low_pass(cutoff, trans_width, sample_rate, odd=False):
+    L = load()
+    n = L.sdrpp_design_low_pass(cutoff, trans_width, sample_rate, int(odd), None, 0)
+    taps = np.zeros(max(n, 1), dtype=np.float32)
+    L.sdrpp_design_low_pass(cutoff, trans_width, sample_rate, int(odd), taps.ctypes.data_as(c_float_p), n)
+    return taps[:n]
+
+
+def design_high_pass(cutoff, trans_width, sample_rate, odd=False):
+    L = load()
+    n = L.sdrpp_design_high_pass(cutoff, trans_width, sample_rate, int(odd), None, 0)
+    taps = np.zeros(max(n, 1), dtype=np.float32)
+    L.sdrpp_design_high_pass(cutoff, trans_width, sample_rate, int(odd), taps.ctypes.data_as(c_float_p), n)
+    return taps[:n]
+
+
+def design_fft_window(kind, nz):
+    w = np.empty(nz, dtype=np.float32)
+    rc = load().sdrpp_design_fft_window(kind, nz, w.ctypes.data_as(c_float_p))
+    if rc:
+        raise SdrppError(rc, "bad window parameters")
+    return w
+
+
+def design_reshape_params(sample_rate, fft_size, fft_rate):
+    skip, nz = C.c_int(), C.c_int()
+    load().sdrpp_design_reshape_params(sample_rate, fft_size, fft_rate, C.byref(skip), C.byref(nz))
+    return nz.value, skip.value
+
+
+def design_phase_delta(offset_hz, sample_rate):
+    re, im = C.c_float(), C.c_float()
+    load().sdrpp_design_phase_delta(offset_hz, sample_rate, C.byref(re), C.byref(im))
+    return re.value, im.value
+
+
+def design_resampler(in_sr, out_sr, max_ratio=8192):
+    L = load()
+    mode, predec, interp, decim = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    n = L.sdrpp_design_resampler(in_sr, out_sr, max_ratio, C.byref(mode), C.byref(predec), C.byref(interp), C.byref(decim), None, 0)
+    taps = np.zeros(max(n, 1), dtype=np.float32)
+    if n > 0:
+        L.sdrpp_design_resampler(in_sr, out_sr, max_ratio, C.byref(mode), C.byref(predec), C.byref(interp), C.byref(decim), taps.ctypes.data_as(c_float_p), n)
+    return dict(mode=mode.value, predec=predec.value, interp=interp.value, decim=decim.value, taps=taps[:n])
+
+
+def design_waterfall_view(view_offset, view_bandwidth, whole_bandwidth, raw_fft_size):
+    start, size = C.c_int(), C.c_int()
+    load().sdrpp_design_waterfall_view(view_offset, view_bandwidth, whole_bandwidth, raw_fft_size, C.byref(start), C.byref(size))
+    return start.value, size.value
+
+
+# ---- context ---------------------------------------------------------------------------------------------------------------------
+class Context:
+    """One wideband IQ stream on one GPU (what one IQFrontEnd owns in the reference)."""
+
+    def __init__(self, device=0, max_push=1_000_000):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.sdrpp_create(device, int(max_push), C.byref(h))
+        if rc:
+            raise SdrppError(rc, self.L.sdrpp_strerror(rc).decode())
+        self.h = h
+        self.max_push = int(max_push)
+        self._keep = []  # numpy arrays referenced by descriptors during vfo_add
+        self.fft_size = 0
+        self.data_width = 0
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise SdrppError(rc, "%s: %s" % (self.L.sdrpp_strerror(rc).decode(), self.L.sdrpp_last_error(self.h).decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sdrpp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        buf = C.create_string_buffer(512)
+        self._chk(self.L.sdrpp_device_info(self.h, buf, 512))
+        return buf.value.decode()
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self.L.sdrpp_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        self._chk(self.L.sdrpp_sync(self.h))
+
+    # FFT branch
+    def fft_configure(self, fft_size, nz, skip, window):
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        assert len(w) == nz
+        self._chk(self.L.sdrpp_fft_configure(self.h, fft_size, nz, skip, w.ctypes.data_as(c_float_p)))
+        self.fft_size = fft_size
+
+    def fft_disable(self):
+        self._chk(self.L.sdrpp_fft_disable(self.h))
+
+    def fft_set_view(self, draw_start, draw_size, data_width, wf_min=-120.0, wf_max=0.0):
+        self._chk(self.L.sdrpp_fft_set_view(self.h, draw_start, draw_size, data_width, wf_min, wf_max))
+        self.data_width = data_width
+
+    def fft_lines(self):
+        return self._chk(self.L.sdrpp_fft_lines(self.h))
+
+    def fft_read(self, raw=True, zoomed=True):
+        n = self.fft_lines()
+        raw_a = np.empty((n, self.fft_size), dtype=np.float32) if raw else None
+        zo = np.empty((n, self.data_width), dtype=np.float32) if (zoomed and self.data_width) else None
+        ix = np.empty((n, self.data_width), dtype=np.int32) if (zoomed and self.data_width) else None
+        if n:
+            self._chk(self.L.sdrpp_fft_read(self.h, 0, n, raw_a.ctypes.data_as(c_float_p) if raw_a is not None else None,
+                                            zo.ctypes.data_as(c_float_p) if zo is not None else None,
+                                            ix.ctypes.data_as(c_int32_p) if ix is not None else None))
+        return raw_a, zo, ix
+
+    def fft_device_buffers(self):
+        raw, zo, ix, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        self._chk(self.L.sdrpp_fft_device_buffers(self.h, C.byref(raw), C.byref(zo), C.byref(ix), C.byref(n)))
+        return raw.value, zo.value, ix.value, n.value
+
+    # VFO bank
+    def vfo_add(self, desc, keepalive=()):
+        vid = C.c_int()
+        self._chk(self.L.sdrpp_vfo_add(self.h, C.byref(desc), C.byref(vid)))
+        del keepalive
+        return vid.value
+
+    def vfo_remove(self, vid):
+        self._chk(self.L.sdrpp_vfo_remove(self.h, vid))
+
+    def vfo_count(self):
+        return self._chk(self.L.sdrpp_vfo_count(self.h))
+
+    def vfo_set_phase_delta(self, vid, re, im):
+        self._chk(self.L.sdrpp_vfo_set_phase_delta(self.h, vid, re, im))
+
+    def vfo_set_channel_taps(self, vid, taps):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        self._chk(self.L.sdrpp_vfo_set_channel_taps(self.h, vid, t.ctypes.data_as(c_float_p), len(t)))
+
+    def vfo_reset(self, vid):
+        self._chk(self.L.sdrpp_vfo_reset(self.h, vid))
+
+    def vfo_out_count(self, vid):
+        return self._chk(self.L.sdrpp_vfo_out_count(self.h, vid))
+
+    def vfo_read(self, vid):
+        n = self.vfo_out_count(vid)
+        out = np.empty((max(n, 1), 2), dtype=np.float32)
+        got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
+        return out[:got]
+
+    def vfo_device_buffers(self, vid):
+        o, i = C.c_void_p(), C.c_void_p()
+        no, ni = C.c_int(), C.c_int()
+        self._chk(self.L.sdrpp_vfo_device_buffers(self.h, vid, C.byref(o), C.byref(no), C.byref(i), C.byref(ni)))
+        return o.value, no.value, i.value, ni.value
+
+    def vfo_read_if(self, vid):
+        """Complex IF stream (RxVFO::out) of the last push, copied from the device through the host-visible path."""
+        import ctypes
+        _, _, ptr, n = self.vfo_device_buffers(vid)
+        self.sync()
+        out = np.empty(max(n, 1), dtype=np.complex64)
+        if n:
+            _copy_from_device(self.L, out.ctypes.data, ptr, n * 8)
+        return out[:n]
+
+    # data path
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        self._chk(self.L.sdrpp_push(self.h, iq.view(np.float32).ctypes.data_as(c_float_p), len(iq)))
+
+    def push_int16(self, iq_i16):
+        a = np.ascontiguousarray(iq_i16, dtype=np.int16)
+        self._chk(self.L.sdrpp_push_int16(self.h, a.ctypes.data_as(C.POINTER(C.c_int16)), len(a) // 2))
+
+    def push_device(self, dev_ptr, count):
+        self._chk(self.L.sdrpp_push_device(self.h, C.c_void_p(dev_ptr), int(count)))
+
+    # measurement
+    def timing_enable(self, on=True):
+        self._chk(self.L.sdrpp_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        ms = (C.c_double * NUM_KERNEL_FAMILIES)()
+        ln = (C.c_int64 * NUM_KERNEL_FAMILIES)()
+        self._chk(self.L.sdrpp_timing_read(self.h, ms, ln))
+        return {self.L.sdrpp_kernel_family_name(i).decode(): (ms[i], ln[i]) for i in range(NUM_KERNEL_FAMILIES)}
+
+
+_hip = None
+
+
+def _copy_from_device(L, host_ptr, dev_ptr, nbytes):
+    """hipMemcpy D2H through the HIP runtime the library itself links (emulator build: plain memmove)."""
+    global _hip
+    if "emu" in os.path.basename(lib_path()):
+        C.memmove(host_ptr, dev_ptr, nbytes)
+        return
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = _hip.hipMemcpy(C.c_void_p(host_ptr), C.c_void_p(dev_ptr), nbytes, 2)
+    if rc:
+        raise SdrppError(-4, "hipMemcpy D2H failed (%d)" % rc)

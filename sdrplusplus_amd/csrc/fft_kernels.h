@@ -1,0 +1,406 @@
+// FFT -> log-power -> waterfall-line kernels for gfx950 (wave64, LDS-staged radix-2^4 register rounds).
+//
+// What the reference does per frame on one CPU thread (core/src/signal_path/iq_frontend.cpp:248-267):
+//   fftIn[0:nz] = x * window (volk_32fc_32f_multiply_32fc), fftIn[nz:N] = 0; X = FFT_N(fftIn) (fftwf_execute);
+//   dB[k] = 10*log10(|X[k]|^2 / N^2) (volk_32fc_s32f_power_spectrum_32f) written into the waterfall's raw line;
+// then WaterFall::pushFFT max-decimates the line to `dataWidth` pixels and maps each to a palette index
+// (core/src/gui/widgets/waterfall.cpp:65-90, 889-906).
+//
+// FFT algorithm (identical, operation for operation, to the test oracle so palette indices can be compared bit-exactly):
+//   * sub-FFT of length L <= 4096: radix-2 decimation in time on the bit-reversed sequence; every butterfly is the
+//     6-FMA form  X0 = u + w*v (two nested fmaf per component),  X1 = fmaf(2, u, -X0);  twiddles come from an exactly
+//     symmetric float table tw(e, L) (host generated, sdrpp_host::twiddle).  Groups of four consecutive stages run in
+//     registers (16 points per work-item); between groups the points are exchanged through LDS.  The grouping does not
+//     change any rounding: each butterfly sees the same operands whatever the schedule.
+//   * N > 4096: four-step N = N1 x N2 (N1 = 2^floor(m/2)): pass 1 = N1-point column FFTs (stride N2) + multiplication by
+//     tw(n2*k1, N) (re = fmaf(a.re, w.re, -(a.im*w.im)), im = fmaf(a.re, w.im, a.im*w.re)) into a scratch matrix
+//     A[k1][n2]; pass 2 = N2-point row FFTs, X[k1 + N1*k2], fused with the dB conversion.
+// All floating-point contraction is disabled for this translation unit (-ffp-contract=off); FMAs are explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdrpp_k {
+
+// Two-source sample accessor: index i is relative to the first sample of the current push; i < 0 reaches into the
+// history kept from earlier pushes (hist holds the most recent hist_len samples, oldest first).
+struct IqSrc {
+    const float2* cur;
+    const float2* hist;
+    int hist_len;
+    long long n_cur;  // valid samples in `cur`
+};
+__device__ __forceinline__ float2 iq_load(const IqSrc& s, long long i) {
+    return (i >= 0) ? s.cur[i] : s.hist[s.hist_len + i];
+}
+// Tile loaders may run past the last sample a (partial) tile really needs: those reads return zero instead of touching
+// memory beyond the caller's buffer.
+__device__ __forceinline__ float2 iq_load_clamped(const IqSrc& s, long long i) {
+    if (i >= s.n_cur) { return make_float2(0.0f, 0.0f); }
+    return iq_load(s, i);
+}
+
+// ---- butterflies -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bfly(float2& u, float2& v, const float2 w) {
+    const float x0r = fmaf(-w.y, v.y, fmaf(w.x, v.x, u.x));
+    const float x0i = fmaf(w.y, v.x, fmaf(w.x, v.y, u.y));
+    v.x = fmaf(2.0f, u.x, -x0r);
+    v.y = fmaf(2.0f, u.y, -x0i);
+    u.x = x0r;
+    u.y = x0i;
+}
+// w == tw(0) = (1, -0): X0 degenerates to u + v (same rounding as the general form)
+__device__ __forceinline__ void bfly_one(float2& u, float2& v) {
+    const float x0r = u.x + v.x;
+    const float x0i = u.y + v.y;
+    v.x = fmaf(2.0f, u.x, -x0r);
+    v.y = fmaf(2.0f, u.y, -x0i);
+    u.x = x0r;
+    u.y = x0i;
+}
+// w == tw(M/4) = (-0, -1) = -j
+__device__ __forceinline__ void bfly_mj(float2& u, float2& v) {
+    const float x0r = u.x + v.y;
+    const float x0i = u.y - v.x;
+    v.x = fmaf(2.0f, u.x, -x0r);
+    v.y = fmaf(2.0f, u.y, -x0i);
+    u.x = x0r;
+    u.y = x0i;
+}
+
+// ---- one group of G <= 4 consecutive radix-2 stages on 16 register-resident points ----------------------------------------
+// Stages S0+1 .. S0+G of an L = 2^LG point sub-FFT.  A work-item with index t (0 .. L/16-1) owns NG = 16 >> G groups of
+// 2^G points; group i is q = t + i*(L/16) -> lo = q mod 2^S0, hi = q >> S0, and point j of the group sits at position
+// p = (hi << (S0+G)) | (j << S0) | lo.  `tw` holds tw(e, L) for e < L/2 (LDS).
+template <int LG, int S0, int G>
+struct FftRound {
+    static constexpr int NG = 16 >> G;
+    static constexpr int TPF = (1 << LG) / 16;
+    static constexpr int GS = 1 << G;
+
+    __device__ static __forceinline__ int pos(int t, int i, int j) {
+        const int q = t + i * TPF;
+        const int lo = q & ((1 << S0) - 1);
+        const int hi = q >> S0;
+        return (hi << (S0 + G)) | (j << S0) | lo;
+    }
+
+    __device__ static __forceinline__ void compute(float2 (&r)[16], int t, const float2* tw) {
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            const int q = t + i * TPF;
+            const int lo = q & ((1 << S0) - 1);
+#pragma unroll
+            for (int u = 1; u <= G; u++) {
+                const int half = 1 << (u - 1);
+                const int sh = LG - S0 - u;  // table index = k << sh, k = (kj << S0) | lo
+                float2 wst[8];
+#pragma unroll
+                for (int kj = 0; kj < half; kj++) {
+                    float2 w;
+                    bool one = false, mj = false;
+                    if (half >= 2 && kj >= half / 2) {
+                        // tw(k + M/4) = -j * tw(k), exact by construction of the table
+                        const float2 wp = wst[kj - half / 2];
+                        w = make_float2(wp.y, -wp.x);
+                        if (S0 == 0 && kj == half / 2) { mj = true; }
+                    }
+                    else {
+                        if (S0 == 0 && kj == 0) {
+                            one = true;
+                            w = make_float2(1.0f, -0.0f);
+                        }
+                        else {
+                            w = tw[(((kj << S0) | lo)) << sh];
+                        }
+                    }
+                    wst[kj] = w;
+#pragma unroll
+                    for (int b = 0; b < GS / (2 * half); b++) {
+                        const int j0 = b * 2 * half + kj;
+                        const int j1 = j0 + half;
+                        if (one) { bfly_one(r[i * GS + j0], r[i * GS + j1]); }
+                        else if (mj) { bfly_mj(r[i * GS + j0], r[i * GS + j1]); }
+                        else { bfly(r[i * GS + j0], r[i * GS + j1], w); }
+                    }
+                }
+            }
+        }
+    }
+};
+
+// Number of stages in round `R` (rounds start at stage 0, 4, 8) of an LG-stage sub-FFT.
+constexpr int fft_round_stages(int LG, int S0) { return (LG - S0) >= 4 ? 4 : (LG - S0); }
+
+// Runs every round after the first on a [positions] LDS image.  `IDX` maps a position to an LDS element index (padding /
+// column interleave); after the call r[] holds the points of the LAST round: point (i, j) is output bin
+// FftRound<LG, S0_last, G_last>::pos(t, i, j).
+template <int LG, int S0, class IDX>
+__device__ __forceinline__ void fft_rounds_after_first(float2 (&r)[16], int t, const float2* tw, float2* data, const IDX& idx) {
+    constexpr int Gprev = fft_round_stages(LG, S0 - 4);
+    constexpr int G = fft_round_stages(LG, S0);
+    using Prev = FftRound<LG, S0 - 4, Gprev>;
+    using Cur = FftRound<LG, S0, G>;
+    __syncthreads();  // previous readers of `data` are done
+#pragma unroll
+    for (int i = 0; i < Prev::NG; i++) {
+#pragma unroll
+        for (int j = 0; j < Prev::GS; j++) { data[idx(Prev::pos(t, i, j))] = r[i * Prev::GS + j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < Cur::NG; i++) {
+#pragma unroll
+        for (int j = 0; j < Cur::GS; j++) { r[i * Cur::GS + j] = data[idx(Cur::pos(t, i, j))]; }
+    }
+    Cur::compute(r, t, tw);
+    if constexpr (S0 + G < LG) { fft_rounds_after_first<LG, S0 + 4, IDX>(r, t, tw, data, idx); }
+}
+
+// Last round's geometry for an LG-stage sub-FFT.
+template <int LG>
+struct FftLast {
+    static constexpr int S0 = (LG <= 4) ? 0 : ((LG <= 8) ? 4 : 8);
+    static constexpr int G = LG - S0;
+    using Round = FftRound<LG, S0, G>;
+};
+
+// ---- log-power (VOLK power_spectrum generic; log2 per the shared specification) -------------------------------------------
+__device__ __forceinline__ float spec_log2f_non_ieee(float x) {
+    // log2 of a non-negative float: subnormals rescaled by 2^23; mantissa folded into [sqrt(1/2), sqrt(2)); degree-9
+    // polynomial in f = m - 1 evaluated with fmaf (Horner); result = fmaf(f, P, e).  An infinite result becomes +-127
+    // (VOLK's log2f_non_ieee).
+    if (x != x) { return x; }
+    if (x < 0.0f) { return __uint_as_float(0x7fc00000u); }
+    if (x == 0.0f) { return -127.0f; }
+    unsigned u = __float_as_uint(x);
+    if (u == 0x7f800000u) { return 127.0f; }
+    int e = 0;
+    if (u < 0x00800000u) {
+        u = __float_as_uint(x * 8388608.0f);
+        e = -23;
+    }
+    e += (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m >= 1.41421354f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float f = m - 1.0f;
+    float p = -0.107497893f;
+    p = fmaf(p, f, 0.184760332f);
+    p = fmaf(p, f, -0.191388384f);
+    p = fmaf(p, f, 0.204857647f);
+    p = fmaf(p, f, -0.239608124f);
+    p = fmaf(p, f, 0.288552552f);
+    p = fmaf(p, f, -0.360696554f);
+    p = fmaf(p, f, 0.480898529f);
+    p = fmaf(p, f, -0.721347332f);
+    p = fmaf(p, f, 1.44269502f);
+    return fmaf(f, p, (float)e);
+}
+__device__ __forceinline__ float power_db(const float2 X, const float inv_norm) {
+    const float re = X.x * inv_norm;
+    const float im = X.y * inv_norm;
+    const float p = (re * re) + (im * im);
+    return 3.01029995663981209120f * spec_log2f_non_ieee(p);
+}
+
+struct FrameGeom {
+    long long first_start;  // push-relative index of sample 0 of frame 0 of this launch (may be negative: history)
+    int stride;             // nz + skip
+    int nz;                 // windowed samples per frame; the rest of the N inputs is zero
+    int nframes;
+};
+
+__device__ __forceinline__ float2 load_windowed(const IqSrc& src, const FrameGeom& g, const float* __restrict__ window, int frame, int i) {
+    if (i >= g.nz) { return make_float2(0.0f, 0.0f); }
+    const float2 x = iq_load(src, g.first_start + (long long)frame * g.stride + i);
+    const float w = window[i];
+    return make_float2(x.x * w, x.y * w);
+}
+
+// ---- N <= 4096: whole transform in one workgroup ------------------------------------------------------------------------------
+struct IdxPad16 {
+    __device__ __forceinline__ int operator()(int p) const { return p + (p >> 4); }
+};
+
+template <int LG, int FPW>
+__global__ __launch_bounds__(((1 << LG) / 16) * FPW) void fft_single_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
+                                                                           const float2* __restrict__ tw_g, float* __restrict__ out_db) {
+    constexpr int L = 1 << LG;
+    constexpr int TPF = L / 16;
+    constexpr int PITCH = L + L / 16;
+    __shared__ float2 tw[L / 2];
+    __shared__ float2 data[FPW * PITCH];
+    const int t = threadIdx.x % TPF;
+    const int fl = threadIdx.x / TPF;
+    const int frame = blockIdx.x * FPW + fl;
+    const bool live = frame < g.nframes;
+    for (int e = threadIdx.x; e < L / 2; e += TPF * FPW) { tw[e] = tw_g[e]; }
+    float2 r[16];
+    using R0 = FftRound<LG, 0, 4>;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = R0::pos(t, 0, j);
+        const int n = (int)(__brev((unsigned)p) >> (32 - LG));
+        r[j] = live ? load_windowed(src, g, window, frame, n) : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();  // twiddle table visible
+    R0::compute(r, t, tw);
+    float2* mydata = &data[fl * PITCH];
+    fft_rounds_after_first<LG, 4, IdxPad16>(r, t, tw, mydata, IdxPad16());
+    using RL = typename FftLast<LG>::Round;
+    if (live) {
+        const float inv = 1.0f / (float)L;
+        float* dst = out_db + (size_t)frame * L;
+#pragma unroll
+        for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+            for (int j = 0; j < RL::GS; j++) { dst[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+        }
+    }
+}
+
+// ---- N > 4096, pass 1: column FFTs + inter-pass twiddle ---------------------------------------------------------------------------
+struct IdxCols {
+    int ncols, c;
+    __device__ __forceinline__ int operator()(int p) const { return p * ncols + c; }
+};
+
+// grid.x = nframes * (N2 / C); block = (N1/16) * C work-items, column index fastest.
+// scratch layout: A[frame][k1][n2] (n2 contiguous); tw_n2k1 has the same [k1][n2] layout and holds tw(n2*k1, N).
+template <int LG1, int C>
+__global__ __launch_bounds__(((1 << LG1) / 16) * C) void fft_pass1_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
+                                                                         const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1,
+                                                                         float2* __restrict__ scratch, int lg2) {
+    constexpr int L1 = 1 << LG1;
+    constexpr int TPF = L1 / 16;
+    __shared__ float2 tw[L1 / 2];
+    __shared__ float2 data[L1 * C];
+    const int N2 = 1 << lg2;
+    const int tiles = N2 / C;
+    const int frame = blockIdx.x / tiles;
+    const int c0 = (blockIdx.x % tiles) * C;
+    const int c = threadIdx.x % C;
+    const int t = threadIdx.x / C;
+    const int n2 = c0 + c;
+    for (int e = threadIdx.x; e < L1 / 2; e += TPF * C) { tw[e] = tw1_g[e]; }
+    float2 r[16];
+    using R0 = FftRound<LG1, 0, 4>;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = R0::pos(t, 0, j);
+        const int n1 = (int)(__brev((unsigned)p) >> (32 - LG1));
+        r[j] = load_windowed(src, g, window, frame, (n1 << lg2) + n2);
+    }
+    __syncthreads();
+    R0::compute(r, t, tw);
+    IdxCols idx{ C, c };
+    fft_rounds_after_first<LG1, 4, IdxCols>(r, t, tw, data, idx);
+    using RL = typename FftLast<LG1>::Round;
+    float2* dst = scratch + ((size_t)frame << (LG1 + lg2));
+#pragma unroll
+    for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+        for (int j = 0; j < RL::GS; j++) {
+            const int k1 = RL::pos(t, i, j);
+            const size_t o = ((size_t)k1 << lg2) + n2;
+            const float2 a = r[i * RL::GS + j];
+            const float2 w = tw_n2k1[o];
+            const float pp = a.y * w.y;
+            const float qq = a.y * w.x;
+            dst[o] = make_float2(fmaf(a.x, w.x, -pp), fmaf(a.x, w.y, qq));
+        }
+    }
+}
+
+// ---- N > 4096, pass 2: row FFTs + dB, output bin k = k1 + N1*k2 ------------------------------------------------------------------
+struct IdxRowPad {
+    int base;
+    __device__ __forceinline__ int operator()(int p) const { return base + p + (p >> 4); }
+};
+
+// grid.x = nframes * (N1 / R); block = (N2/16) * R work-items, t fastest (coalesced row reads).
+template <int LG2, int R>
+__global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
+                                                                         float* __restrict__ out_db, int lg1, int nframes) {
+    constexpr int L2 = 1 << LG2;
+    constexpr int TPF = L2 / 16;
+    constexpr int PITCH = L2 + L2 / 16;
+    __shared__ float2 tw[L2 / 2];
+    __shared__ float2 data[R * PITCH];
+    const int N1 = 1 << lg1;
+    const int tiles = N1 / R;
+    const int frame = blockIdx.x / tiles;
+    const int r0 = (blockIdx.x % tiles) * R;
+    const int t = threadIdx.x % TPF;
+    const int row = threadIdx.x / TPF;
+    for (int e = threadIdx.x; e < L2 / 2; e += TPF * R) { tw[e] = tw2_g[e]; }
+    const float2* srcrow = scratch + ((size_t)frame << (LG2 + lg1)) + ((size_t)(r0 + row) << LG2);
+    float2 r[16];
+    using R0 = FftRound<LG2, 0, 4>;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = R0::pos(t, 0, j);
+        const int n = (int)(__brev((unsigned)p) >> (32 - LG2));
+        r[j] = srcrow[n];
+    }
+    __syncthreads();
+    R0::compute(r, t, tw);
+    IdxRowPad idx{ row * PITCH };
+    fft_rounds_after_first<LG2, 4, IdxRowPad>(r, t, tw, data, idx);
+    using RL = typename FftLast<LG2>::Round;
+    // dB values are transposed through LDS so that consecutive lanes write consecutive k1 (k = k1 + N1*k2).
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(data);  // [k2][R + 1]
+    const float inv = 1.0f / (float)((size_t)1 << (LG2 + lg1));
+#pragma unroll
+    for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+        for (int j = 0; j < RL::GS; j++) {
+            const int k2 = RL::pos(t, i, j);
+            tile[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
+        }
+    }
+    __syncthreads();
+    float* dst = out_db + ((size_t)frame << (LG2 + lg1)) + r0;
+    for (int e = threadIdx.x; e < L2 * R; e += TPF * R) {
+        const int k2 = e / R;
+        const int rr = e % R;
+        dst[((size_t)k2 << lg1) + rr] = tile[k2 * (R + 1) + rr];
+    }
+    (void)nframes;
+}
+
+// ---- doZoom max-decimation + palette index (waterfall.cpp:65-90, 899-905) -------------------------------------------------------------
+// The float32 running index of doZoom is evaluated on the host once per view change (sdrpp_host::zoomTable); here each
+// pixel takes the maximum of its bin range with the reference's comparison (`if (in > max) max = in`, -inf start).
+__global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
+                                                          const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
+                                                          float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index) {
+    const int line = blockIdx.y;
+    const float* in = lines + (size_t)line * fft_size;
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < data_width; px += gridDim.x * blockDim.x) {
+        const int s = zstart[px];
+        const int n = zcount[px];
+        float m = __uint_as_float(0xff800000u);  // -inf
+        for (int j = 0; j < n; j++) {
+            const float v = in[s + j];
+            if (v > m) { m = v; }
+        }
+        zoomed[(size_t)line * data_width + px] = m;
+        const float range = wf_max - wf_min;
+        const float v = (m < wf_min) ? wf_min : ((wf_max < m) ? wf_max : m);
+        const float pixel = (v - wf_min) / range;
+        index[(size_t)line * data_width + px] = (int32_t)(pixel * 999999.0f);
+    }
+}
+
+// int16 IQ -> float (file_source/main.cpp:162: volk_16i_s32f_convert_32f(out, in, 32768.0f, n))
+__global__ __launch_bounds__(256) void int16_to_float_kernel(const int16_t* __restrict__ in, float* __restrict__ out, long long n) {
+    const float inv = 1.0f / 32768.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { out[i] = ((float)in[i]) * inv; }
+}
+
+}  // namespace sdrpp_k

@@ -1,0 +1,1259 @@
+// C-ABI implementation (include/sdrpp_gpu.h): context, streaming state, per-push planning and kernel launches.
+// One context = one IQ stream on one GPU; everything is enqueued on one HIP stream so a push is a fixed sequence of
+// launches whose sizes are computed on the host from integer state (decimation offsets, polyphase phase, frame position).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sdrpp_gpu.h"
+#include "fft_kernels.h"
+#include "host_design.h"
+#include "vfo_kernels.h"
+
+using namespace sdrpp_k;
+
+namespace {
+
+constexpr int kArenaSlots = 8;
+constexpr size_t kArenaBytes = 4u << 20;
+constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
+constexpr size_t kScratchBytes = 64u << 20;
+constexpr int kMaxLds = 64 * 1024;
+
+enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC };
+const char* kFamilyNames[SDRPP_NUM_KERNEL_FAMILIES] = { "fft_pass1", "fft_pass2", "fft_single", "zoom_palette", "vfo_stage1",
+                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc" };
+
+struct Stream {
+    int width = 2;
+    int hist_len = 0;
+    float* data = nullptr;
+    size_t cap = 0;  // samples
+    float* hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    int n = 0;
+};
+
+struct Vfo {
+    int id = 0;
+    sdrpp_vfo_desc d{};
+    std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
+    std::vector<float> rtaps, ctaps_chan, ataps;
+    // NCO
+    double theta = 0.0, phi = 0.0;
+    std::vector<float2> modtaps;  // stage-1 modulated taps
+    bool modtaps_dirty = true;
+    // integer streaming state
+    int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+    int tpp = 0, pphase = 0, poff = 0;
+    // device constants
+    float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+    float* d_bank = nullptr;
+    float* d_chan = nullptr;
+    int chan_ntaps = 0;
+    float* d_audio = nullptr;
+    int audio_ntaps = 0;
+    // device loop state: [AgcState agc][AgcState carrier][float dc]
+    char* d_state = nullptr;
+    double theta2 = 0.0, phi2 = 0.0;
+    // streams: 0..nstages-1 decimator outputs (index 0 also used by the rotate-only path), then poly, chan, dem, out
+    std::vector<Stream> st;
+    int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
+};
+
+struct TimingPair { hipEvent_t a, b; int family; };
+
+}  // namespace
+
+struct sdrpp_ctx {
+    int device = 0;
+    int64_t max_push = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string devinfo;
+
+    // input
+    float* iq_stage = nullptr;        // H2D landing buffer (max_push complex)
+    int16_t* iq_stage16 = nullptr;
+    float* iq_hist[2] = { nullptr, nullptr };
+    int iq_hist_cap = 0;              // samples of history kept
+    int iq_cur = 0;
+
+    // job arena
+    char* arena_host[kArenaSlots] = {};
+    hipEvent_t arena_ev[kArenaSlots] = {};
+    bool arena_used[kArenaSlots] = {};
+    char* arena_dev = nullptr;
+    int arena_slot = 0;
+    size_t arena_off = 0;
+
+    // FFT
+    bool fft_on = false;
+    int fft_size = 0, fft_lg = 0, nz = 0, skip = 0;
+    float* d_window = nullptr;
+    float2* d_tw1 = nullptr;   // tw(e, N1) / tw(e, N) for single pass, e < L/2
+    float2* d_tw2 = nullptr;
+    float2* d_twn = nullptr;   // [k1][n2] tw(n2*k1, N)
+    float2* d_scratch = nullptr;
+    float* d_lines = nullptr;
+    size_t lines_cap = 0;
+    int64_t fft_pos = 0, fft_next = 0;
+    int n_lines = 0;
+    // view
+    int view_start = 0, view_size = 0, data_width = 0;
+    float wf_min = -120.0f, wf_max = 0.0f;
+    int32_t* d_zstart = nullptr;
+    int32_t* d_zcount = nullptr;
+    float* d_zoomed = nullptr;
+    int32_t* d_index = nullptr;
+    size_t zoom_cap = 0;
+
+    // VFOs
+    std::map<int, std::unique_ptr<Vfo>> vfos;
+    int next_id = 1;
+    // cached stage-1 job tap arrays, keyed by membership signature
+    std::map<std::string, float2*> s1_tap_cache;
+
+    // timing
+    bool timing = false;
+    std::vector<TimingPair> tpairs;
+    std::vector<hipEvent_t> ev_pool;
+    double fam_ms[SDRPP_NUM_KERNEL_FAMILIES] = {};
+    int64_t fam_launch[SDRPP_NUM_KERNEL_FAMILIES] = {};
+};
+
+namespace {
+
+int fail(sdrpp_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) { c->err = buf; }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                           \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) { return fail((c), SDRPP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+
+template <class T>
+int dev_alloc(sdrpp_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16));
+    if (e != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); }
+    *p = (T*)q;
+    return SDRPP_OK;
+}
+template <class T>
+void dev_free(T*& p) {
+    if (p) { (void)hipFree((void*)p); p = nullptr; }
+}
+template <class T>
+int upload(sdrpp_ctx* c, T** dst, const T* src, size_t count) {
+    dev_free(*dst);
+    if (count == 0) { return SDRPP_OK; }
+    int rc = dev_alloc(c, dst, count);
+    if (rc) { return rc; }
+    HIPCHK(c, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return SDRPP_OK;
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) { l++; }
+    return l;
+}
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ---- timing --------------------------------------------------------------------------------------------------------------
+hipEvent_t get_event(sdrpp_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void timing_flush(sdrpp_ctx* c) {
+    if (c->tpairs.empty()) { return; }
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->tpairs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->fam_ms[p.family] += ms; }
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+    }
+    c->tpairs.clear();
+}
+struct FamilyTimer {
+    sdrpp_ctx* c;
+    int fam;
+    hipEvent_t a = nullptr;
+    FamilyTimer(sdrpp_ctx* c_, int f) : c(c_), fam(f) {
+        c->fam_launch[fam]++;
+        if (c->timing) {
+            a = get_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~FamilyTimer() {
+        if (c->timing && a) {
+            hipEvent_t b = get_event(c);
+            (void)hipEventRecord(b, c->stream);
+            c->tpairs.push_back({ a, b, fam });
+            if (c->tpairs.size() > 8192) { timing_flush(c); }
+        }
+    }
+};
+
+// ---- job arena -------------------------------------------------------------------------------------------------------------
+int arena_begin(sdrpp_ctx* c) {
+    c->arena_slot = (c->arena_slot + 1) % kArenaSlots;
+    if (c->arena_used[c->arena_slot]) { HIPCHK(c, hipEventSynchronize(c->arena_ev[c->arena_slot])); }
+    c->arena_off = 0;
+    return SDRPP_OK;
+}
+template <class T>
+T* arena_push(sdrpp_ctx* c, const std::vector<T>& v, T** host_copy = nullptr) {
+    if (v.empty()) { return nullptr; }
+    size_t off = (c->arena_off + 63) & ~(size_t)63;
+    size_t bytes = v.size() * sizeof(T);
+    if (off + bytes > kArenaBytes) { return nullptr; }
+    memcpy(c->arena_host[c->arena_slot] + off, v.data(), bytes);
+    if (host_copy) { *host_copy = (T*)(c->arena_host[c->arena_slot] + off); }
+    c->arena_off = off + bytes;
+    return (T*)(c->arena_dev + off);
+}
+int arena_commit(sdrpp_ctx* c) {
+    if (c->arena_off == 0) { return SDRPP_OK; }
+    HIPCHK(c, hipMemcpyAsync(c->arena_dev, c->arena_host[c->arena_slot], c->arena_off, hipMemcpyHostToDevice, c->stream));
+    return SDRPP_OK;
+}
+int arena_end(sdrpp_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->arena_ev[c->arena_slot], c->stream));
+    c->arena_used[c->arena_slot] = true;
+    return SDRPP_OK;
+}
+
+// ---- streams ---------------------------------------------------------------------------------------------------------------
+int stream_alloc(sdrpp_ctx* c, Stream& s, int width, int hist_len, size_t cap) {
+    s.width = width;
+    s.hist_len = hist_len;
+    s.cap = cap;
+    s.cur = 0;
+    s.n = 0;
+    int rc = dev_alloc(c, &s.data, (cap + 16) * width);
+    if (rc) { return rc; }
+    for (int i = 0; i < 2; i++) {
+        rc = dev_alloc(c, &s.hist[i], (size_t)std::max(hist_len, 1) * width);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(s.hist[i], 0, (size_t)std::max(hist_len, 1) * width * sizeof(float)));
+    }
+    return SDRPP_OK;
+}
+void stream_free(Stream& s) {
+    dev_free(s.data);
+    dev_free(s.hist[0]);
+    dev_free(s.hist[1]);
+}
+StreamIn stream_in(const Stream& s) { return StreamIn{ s.data, s.hist[s.cur], s.hist_len, s.n }; }
+
+int ensure_iq_hist(sdrpp_ctx* c, int need) {
+    if (need <= c->iq_hist_cap) { return SDRPP_OK; }
+    int cap = std::max(need, 1024);
+    float* nh[2] = { nullptr, nullptr };
+    for (int i = 0; i < 2; i++) {
+        int rc = dev_alloc(c, &nh[i], (size_t)cap * 2);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(nh[i], 0, (size_t)cap * 2 * sizeof(float)));
+    }
+    if (c->iq_hist[c->iq_cur] && c->iq_hist_cap > 0) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // keep the most recent samples at the END of the larger buffer
+        HIPCHK(c, hipMemcpy(nh[0] + (size_t)(cap - c->iq_hist_cap) * 2, c->iq_hist[c->iq_cur], (size_t)c->iq_hist_cap * 2 * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    dev_free(c->iq_hist[0]);
+    dev_free(c->iq_hist[1]);
+    c->iq_hist[0] = nh[0];
+    c->iq_hist[1] = nh[1];
+    c->iq_cur = 0;
+    c->iq_hist_cap = cap;
+    return SDRPP_OK;
+}
+
+// ---- VFO helpers -------------------------------------------------------------------------------------------------------------
+void build_modtaps(Vfo& v) {
+    const int K = v.d.stage_ntaps[0];
+    v.modtaps.resize((size_t)K);
+    const double kc = 0.5 * (double)(K - 1);
+    for (int k = 0; k < K; k++) {
+        double t = ((double)k - kc) * v.theta;
+        t -= std::rint(t);
+        const double a = 2.0 * 3.14159265358979323846 * t;
+        const double h = (double)v.staps[0][(size_t)k];
+        v.modtaps[(size_t)k] = make_float2((float)(h * std::cos(a)), (float)(h * std::sin(a)));
+    }
+    v.modtaps_dirty = false;
+}
+
+void vfo_free(Vfo& v) {
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { dev_free(v.d_staps[i]); }
+    dev_free(v.d_bank);
+    dev_free(v.d_chan);
+    dev_free(v.d_audio);
+    dev_free(v.d_state);
+    for (auto& s : v.st) { stream_free(s); }
+    v.st.clear();
+}
+
+int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
+    v.phi = 0.0;
+    v.phi2 = 0.0;
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.soff[i] = 0; }
+    v.pphase = 0;
+    v.poff = 0;
+    for (auto& s : v.st) {
+        for (int i = 0; i < 2; i++) {
+            if (s.hist[i]) { HIPCHK(c, hipMemsetAsync(s.hist[i], 0, (size_t)std::max(s.hist_len, 1) * s.width * sizeof(float), c->stream)); }
+        }
+        s.n = 0;
+    }
+    AgcState st[2];
+    for (int i = 0; i < 2; i++) {
+        st[i].set_point = v.d.agc_set_point;
+        st[i].attack = v.d.agc_attack;
+        st[i].inv_attack = 1.0f - v.d.agc_attack;
+        st[i].decay = v.d.agc_decay;
+        st[i].inv_decay = 1.0f - v.d.agc_decay;
+        st[i].max_gain = v.d.agc_max_gain;
+        st[i].max_output_amp = v.d.agc_max_output_amp;
+        st[i].amp = v.d.agc_set_point / v.d.agc_init_gain;  // agc.h:25
+    }
+    char blob[2 * sizeof(AgcState) + sizeof(float)];
+    memcpy(blob, st, sizeof(st));
+    float zero = 0.0f;
+    memcpy(blob + sizeof(st), &zero, sizeof(float));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(v.d_state, blob, sizeof(blob), hipMemcpyHostToDevice));
+    return SDRPP_OK;
+}
+
+// Number of outputs a decimating stage produces from n inputs with carried offset `off` (decimating_fir.h:51-62).
+inline int decim_nout(int n, int off, int D) { return (n > off) ? (n - off + D - 1) / D : 0; }
+// Outputs of the polyphase resampler (polyphase_resampler.h:75-93): smallest m with poff + (pphase + m*M)/L >= n.
+inline int poly_nout(int n, int poff, int pphase, int L, int M) {
+    if (n <= poff) { return 0; }
+    const long long need = (long long)L * (n - poff) - pphase;  // A_m >= L*(n - poff)
+    return (int)((need + M - 1) / M);
+}
+
+template <class K, class... A>
+void launch(sdrpp_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+    hipLaunchKernelGGL(kernel, grid, block, lds, c->stream, args...);
+}
+
+int pick_tile(int D, int K, int width_bytes) {
+    for (int tile : { 256, 128, 64 }) {
+        const int extra = (K - 1 + D - 1) / D;
+        const size_t lds = (size_t)D * (tile + extra + 1) * width_bytes;
+        if (lds <= (size_t)kMaxLds) { return tile; }
+    }
+    return 0;
+}
+size_t fir_lds(int tile, int D, int K, int width_bytes) {
+    const int extra = (K - 1 + D - 1) / D;
+    return (size_t)D * (tile + extra + 1) * width_bytes;
+}
+
+// ---- FFT launches ---------------------------------------------------------------------------------------------------------------
+template <int LG, int FPW>
+void launch_single(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out) {
+    const int blocks = (g.nframes + FPW - 1) / FPW;
+    launch(c, fft_single_kernel<LG, FPW>, dim3(blocks), dim3(((1 << LG) / 16) * FPW), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1, out);
+}
+template <int LG1, int C>
+void launch_p1(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, int lg2) {
+    const int blocks = g.nframes * ((1 << lg2) / C);
+    launch(c, fft_pass1_kernel<LG1, C>, dim3(blocks), dim3(((1 << LG1) / 16) * C), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1,
+           (const float2*)c->d_twn, c->d_scratch, lg2);
+}
+template <int LG2, int R>
+void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out) {
+    const int blocks = nframes * ((1 << lg1) / R);
+    launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes);
+}
+
+int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out) {
+    const int m = c->fft_lg;
+    if (m <= 12) {
+        FamilyTimer t(c, F_FFTS);
+        switch (m) {
+        case 10: launch_single<10, 4>(c, src, g, out); break;
+        case 11: launch_single<11, 2>(c, src, g, out); break;
+        case 12: launch_single<12, 1>(c, src, g, out); break;
+        default: return fail(c, SDRPP_ERR_UNSUPPORTED, "fft size 2^%d unsupported", m);
+        }
+        return SDRPP_OK;
+    }
+    const int lg1 = m / 2, lg2 = m - lg1;
+    {
+        FamilyTimer t(c, F_FFT1);
+        switch (lg1) {
+        case 6: launch_p1<6, 64>(c, src, g, lg2); break;
+        case 7: launch_p1<7, 32>(c, src, g, lg2); break;
+        case 8: launch_p1<8, 16>(c, src, g, lg2); break;
+        case 9: launch_p1<9, 8>(c, src, g, lg2); break;
+        case 10: launch_p1<10, 4>(c, src, g, lg2); break;
+        default: return fail(c, SDRPP_ERR_UNSUPPORTED, "fft pass-1 size 2^%d unsupported", lg1);
+        }
+    }
+    {
+        FamilyTimer t(c, F_FFT2);
+        switch (lg2) {
+        case 7: launch_p2<7, 32>(c, g.nframes, lg1, out); break;
+        case 8: launch_p2<8, 16>(c, g.nframes, lg1, out); break;
+        case 9: launch_p2<9, 8>(c, g.nframes, lg1, out); break;
+        case 10: launch_p2<10, 4>(c, g.nframes, lg1, out); break;
+        default: return fail(c, SDRPP_ERR_UNSUPPORTED, "fft pass-2 size 2^%d unsupported", lg2);
+        }
+    }
+    return SDRPP_OK;
+}
+
+int ensure_zoom(sdrpp_ctx* c, size_t lines) {
+    if (c->data_width <= 0) { return SDRPP_OK; }
+    const size_t need = lines * (size_t)c->data_width;
+    if (need <= c->zoom_cap) { return SDRPP_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c->d_zoomed);
+    dev_free(c->d_index);
+    int rc = dev_alloc(c, &c->d_zoomed, need);
+    if (rc) { return rc; }
+    rc = dev_alloc(c, &c->d_index, need);
+    if (rc) { return rc; }
+    c->zoom_cap = need;
+    return SDRPP_OK;
+}
+
+int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
+    c->n_lines = 0;
+    if (!c->fft_on) { return SDRPP_OK; }
+    const int64_t P = (int64_t)c->nz + c->skip;
+    const int64_t end = c->fft_pos + count;
+    int64_t nframes = 0;
+    if (end - c->nz - c->fft_next * P >= 0) { nframes = (end - c->nz - c->fft_next * P) / P + 1; }
+    if (nframes > 0) {
+        if ((size_t)nframes > c->lines_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: %lld frames exceed line capacity %zu", (long long)nframes, c->lines_cap); }
+        const size_t per_chunk = std::max<size_t>(1, kScratchBytes / ((size_t)c->fft_size * sizeof(float2)));
+        for (int64_t f0 = 0; f0 < nframes; f0 += (int64_t)per_chunk) {
+            FrameGeom g;
+            g.nframes = (int)std::min<int64_t>((int64_t)per_chunk, nframes - f0);
+            g.stride = (int)P;
+            g.nz = c->nz;
+            g.first_start = (c->fft_next + f0) * P - c->fft_pos;
+            int rc = run_fft_chunk(c, src, g, c->d_lines + (size_t)f0 * c->fft_size);
+            if (rc) { return rc; }
+        }
+        if (c->data_width > 0) {
+            int rc = ensure_zoom(c, (size_t)nframes);
+            if (rc) { return rc; }
+            FamilyTimer t(c, F_ZOOM);
+            launch(c, zoom_palette_kernel, dim3((c->data_width + 255) / 256, (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, c->fft_size, c->data_width,
+                   (const int32_t*)c->d_zstart, (const int32_t*)c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index);
+        }
+        c->fft_next += nframes;
+    }
+    c->fft_pos = end;
+    c->n_lines = (int)nframes;
+    return SDRPP_OK;
+}
+
+// ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
+struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; };
+
+int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
+    if (c->vfos.empty()) { return SDRPP_OK; }
+    const int n_in = (int)count;
+    std::vector<S1Member> s1;
+    std::vector<RotJob> rot;
+    std::vector<FirJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 1..3 used
+    std::vector<PolyJob> poly;
+    std::vector<FirJob> chan;
+    std::vector<QuadJob> quad;
+    std::vector<SeqJob> seq;
+    std::vector<FirJob> audio;
+    int max_rot = 0;
+
+    for (auto& kv : c->vfos) {
+        Vfo& v = *kv.second;
+        Stream* cur = &v.st[(size_t)v.i_first];
+        if (v.d.n_stages == 0) {
+            rot.push_back(RotJob{ v.theta, v.phi, (float2*)cur->data, n_in });
+            cur->n = n_in;
+            max_rot = std::max(max_rot, n_in);
+        }
+        else {
+            const int D = v.d.stage_decim[0];
+            const int nout = decim_nout(n_in, v.soff[0], D);
+            if (v.modtaps_dirty) { build_modtaps(v); }
+            s1.push_back(S1Member{ &v, v.d.stage_ntaps[0], ilog2(D), v.soff[0], nout, v.phi });
+            v.soff[0] = v.soff[0] + nout * D - n_in;
+            cur->n = nout;
+            for (int s = 1; s < v.d.n_stages; s++) {
+                Stream* nxt = &v.st[(size_t)v.i_first + s];
+                const int Ds = v.d.stage_decim[s];
+                const int no = decim_nout(cur->n, v.soff[s], Ds);
+                lvl[s].push_back(FirJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no });
+                v.soff[s] = v.soff[s] + no * Ds - cur->n;
+                nxt->n = no;
+                cur = nxt;
+            }
+        }
+        if (v.i_poly >= 0) {
+            Stream* nxt = &v.st[(size_t)v.i_poly];
+            const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
+            poly.push_back(PolyJob{ stream_in(*cur), (float2*)nxt->data, v.d_bank, v.d.interp, v.d.decim, v.tpp, v.pphase, v.poff, no });
+            const long long A = (long long)v.pphase + (long long)no * v.d.decim;
+            v.pphase = (int)(A % v.d.interp);
+            v.poff = v.poff + (int)(A / v.d.interp) - cur->n;
+            nxt->n = no;
+            cur = nxt;
+        }
+        if (v.i_chan >= 0 && v.chan_ntaps > 0) {
+            Stream* nxt = &v.st[(size_t)v.i_chan];
+            chan.push_back(FirJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n });
+            nxt->n = cur->n;
+            cur = nxt;
+        }
+        v.i_if = (int)(cur - &v.st[0]);
+        const int nif = cur->n;
+        AgcState* agc = (AgcState*)v.d_state;
+        float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
+        if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
+            Stream& dem = v.st[(size_t)v.i_dem];
+            Stream& out = v.st[(size_t)v.i_out];
+            quad.push_back(QuadJob{ stream_in(*cur), dem.data, v.d.inv_deviation, nif });
+            dem.n = nif;
+            audio.push_back(FirJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif });
+            out.n = nif;
+        }
+        else if (v.d.demod == SDRPP_DEMOD_AM) {
+            Stream& dem = v.st[(size_t)v.i_dem];
+            Stream& out = v.st[(size_t)v.i_out];
+            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, 0.0, 0.0 });
+            dem.n = nif;
+            audio.push_back(FirJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif });
+            out.n = nif;
+        }
+        else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
+            Stream& out = v.st[(size_t)v.i_out];
+            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, out.data, agc, agc + 1, dc, 0.0f, 0, v.theta2, v.phi2 });
+            out.n = nif;
+            double p2 = v.phi2 + (double)nif * v.theta2;
+            v.phi2 = p2 - std::floor(p2);
+        }
+        double p = v.phi + (double)n_in * v.theta;
+        v.phi = p - std::floor(p);
+        // history carries for every stream that has a consumer with memory
+        for (auto& s : v.st) {
+            if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width }); }
+        }
+    }
+
+    // ---- stage 1: group VFOs with identical geometry, VT per job ----
+    std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
+        if (a.K != b.K) { return a.K < b.K; }
+        if (a.lgD != b.lgD) { return a.lgD < b.lgD; }
+        if (a.off0 != b.off0) { return a.off0 < b.off0; }
+        if (a.nout != b.nout) { return a.nout < b.nout; }
+        return a.v->id < b.v->id;
+    });
+    struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
+    S1Launch s1l[4];
+    const int vts[4] = { 8, 4, 2, 1 };
+    for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; }
+    size_t i = 0;
+    while (i < s1.size()) {
+        size_t j = i;
+        while (j < s1.size() && s1[j].K == s1[i].K && s1[j].lgD == s1[i].lgD && s1[j].off0 == s1[i].off0 && s1[j].nout == s1[i].nout) { j++; }
+        size_t g = i;
+        while (g < j) {
+            const size_t left = j - g;
+            int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
+            const int vt = vts[li];
+            // tap array for this membership (cached on the device)
+            std::string key;
+            bool dirty = false;
+            for (int m = 0; m < vt; m++) {
+                char b[64];
+                snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
+                key += b;
+            }
+            (void)dirty;
+            float2* d_taps = nullptr;
+            auto it = c->s1_tap_cache.find(key);
+            if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
+            else {
+                const int K = s1[g].K;
+                std::vector<float2> host((size_t)K * vt);
+                for (int k = 0; k < K; k++) {
+                    for (int m = 0; m < vt; m++) { host[(size_t)k * vt + m] = s1[g + m].v->modtaps[(size_t)k]; }
+                }
+                if (c->s1_tap_cache.size() > 4096) {  // retune churn: drop everything (rare)
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
+                    c->s1_tap_cache.clear();
+                }
+                int rc = dev_alloc(c, &d_taps, host.size());
+                if (rc) { return rc; }
+                HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));  // `host` is pageable and goes out of scope
+                c->s1_tap_cache[key] = d_taps;
+            }
+            Stage1Job job{};
+            job.nv = vt;
+            job.ntaps = s1[g].K;
+            job.log2_decim = s1[g].lgD;
+            job.off0 = s1[g].off0;
+            job.nout = s1[g].nout;
+            job.ctaps = d_taps;
+            for (int m = 0; m < vt; m++) {
+                Vfo* v = s1[g + m].v;
+                job.theta[m] = v->theta;
+                job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
+                job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+            }
+            s1l[li].jobs.push_back(job);
+            s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
+            const int D = 1 << job.log2_decim;
+            const int tile = pick_tile(D, job.ntaps, 8);
+            if (tile == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
+            s1l[li].tile = std::min(s1l[li].tile, tile);
+            g += (size_t)vt;
+        }
+        i = j;
+    }
+
+    // ---- upload all job arrays in one copy ----
+    Stage1Job* d_s1[4] = {};
+    for (int k = 0; k < 4; k++) {
+        if (!s1l[k].jobs.empty()) {
+            for (auto& jb : s1l[k].jobs) { s1l[k].lds = std::max(s1l[k].lds, fir_lds(s1l[k].tile, 1 << jb.log2_decim, jb.ntaps, 8)); }
+            d_s1[k] = arena_push(c, s1l[k].jobs);
+            if (!d_s1[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
+    }
+    RotJob* d_rot = arena_push(c, rot);
+    FirJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
+    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
+    PolyJob* d_poly = arena_push(c, poly);
+    FirJob* d_chan = arena_push(c, chan);
+    QuadJob* d_quad = arena_push(c, quad);
+    SeqJob* d_seq = arena_push(c, seq);
+    FirJob* d_audio = arena_push(c, audio);
+    CarryJob* d_carry = arena_push(c, carry);
+    if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!quad.empty() && !d_quad) || (!seq.empty() && !d_seq) ||
+        (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
+        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
+    }
+    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+        if (!lvl[s].empty() && !d_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    }
+    int rc = arena_commit(c);
+    if (rc) { return rc; }
+
+    // ---- launches ----
+    {
+        FamilyTimer t(c, F_S1);
+        for (int k = 0; k < 4; k++) {
+            if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }
+            const dim3 grid((s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (unsigned)s1l[k].jobs.size());
+            const dim3 block(s1l[k].tile);
+            switch (s1l[k].vt) {
+            case 8: launch(c, vfo_stage1_kernel<8>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            case 4: launch(c, vfo_stage1_kernel<4>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            case 2: launch(c, vfo_stage1_kernel<2>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            default: launch(c, vfo_stage1_kernel<1>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            }
+        }
+        if (!rot.empty() && max_rot > 0) {
+            launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
+        }
+    }
+    auto launch_fir = [&](std::vector<FirJob>& jobs, FirJob* d_jobs, int width, bool stereo) -> int {
+        if (jobs.empty()) { return SDRPP_OK; }
+        int max_nout = 0, tile = 256;
+        for (auto& jb : jobs) {
+            max_nout = std::max(max_nout, jb.nout);
+            const int t = pick_tile(1 << jb.log2_decim, jb.ntaps, width * 4);
+            if (t == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+            tile = std::min(tile, t);
+        }
+        if (max_nout == 0) { return SDRPP_OK; }
+        size_t lds = 0;
+        for (auto& jb : jobs) { lds = std::max(lds, fir_lds(tile, 1 << jb.log2_decim, jb.ntaps, width * 4)); }
+        const dim3 grid((max_nout + tile - 1) / tile, (unsigned)jobs.size());
+        if (width == 2) { launch(c, vfo_fir_kernel<2, false>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
+        else if (stereo) { launch(c, vfo_fir_kernel<1, true>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
+        else { launch(c, vfo_fir_kernel<1, false>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
+        return SDRPP_OK;
+    };
+    {
+        FamilyTimer t(c, F_DECIM);
+        for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+            rc = launch_fir(lvl[s], d_lvl[s], 2, false);
+            if (rc) { return rc; }
+        }
+    }
+    if (!poly.empty()) {
+        FamilyTimer t(c, F_POLY);
+        int max_nout = 0;
+        size_t lds = 0;
+        const int tile = 256;
+        for (auto& jb : poly) {
+            max_nout = std::max(max_nout, jb.nout);
+            const size_t ns = (size_t)((long long)tile * jb.decim / jb.interp) + jb.tpp + 4;
+            lds = std::max(lds, ns * sizeof(float2));
+        }
+        if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
+        if (max_nout > 0) { launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)poly.size()), dim3(tile), lds, (const PolyJob*)d_poly); }
+    }
+    {
+        FamilyTimer t(c, F_FIR);
+        rc = launch_fir(chan, d_chan, 2, false);
+        if (rc) { return rc; }
+    }
+    {
+        FamilyTimer t(c, F_DEMOD);
+        if (!quad.empty()) {
+            int mx = 0;
+            for (auto& q : quad) { mx = std::max(mx, q.n); }
+            if (mx > 0) { launch(c, vfo_quadrature_kernel, dim3(std::min((mx + 255) / 256, 4096), (unsigned)quad.size()), dim3(256), 0, (const QuadJob*)d_quad); }
+        }
+        if (!seq.empty()) { launch(c, vfo_sequential_kernel, dim3(((unsigned)seq.size() + 63) / 64), dim3(64), 0, (const SeqJob*)d_seq, (int)seq.size()); }
+    }
+    {
+        FamilyTimer t(c, F_FIR);
+        rc = launch_fir(audio, d_audio, 1, true);
+        if (rc) { return rc; }
+    }
+    if (!carry.empty()) {
+        FamilyTimer t(c, F_MISC);
+        int mx = 0;
+        for (auto& cj : carry) { mx = std::max(mx, cj.hist_len * cj.width); }
+        launch(c, carry_kernel, dim3(std::max(1, std::min((mx + 255) / 256, 1024)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+    }
+    // flip the ping-pong side of every carried stream
+    for (auto& kv : c->vfos) {
+        for (auto& s : kv.second->st) {
+            if (s.hist_len > 0 && s.data) { s.cur ^= 1; }
+        }
+    }
+    return SDRPP_OK;
+}
+
+int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
+    if (count == 0) { return SDRPP_OK; }
+    int need_hist = 1;
+    if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
+    for (auto& kv : c->vfos) {
+        if (kv.second->d.n_stages > 0) { need_hist = std::max(need_hist, kv.second->d.stage_ntaps[0] - 1); }
+    }
+    int rc = ensure_iq_hist(c, need_hist);
+    if (rc) { return rc; }
+    rc = arena_begin(c);
+    if (rc) { return rc; }
+    IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
+    rc = do_fft(c, src, count);
+    if (rc) { return rc; }
+    std::vector<CarryJob> carry;
+    carry.push_back(CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2 });
+    if (c->vfos.empty()) {
+        CarryJob* d_carry = arena_push(c, carry);
+        rc = arena_commit(c);
+        if (rc) { return rc; }
+        FamilyTimer t(c, F_MISC);
+        launch(c, carry_kernel, dim3(std::max(1, std::min((c->iq_hist_cap * 2 + 255) / 256, 1024)), 1), dim3(256), 0, (const CarryJob*)d_carry);
+    }
+    else {
+        rc = do_vfos(c, src, count, carry);
+        if (rc) { return rc; }
+    }
+    c->iq_cur ^= 1;
+    rc = arena_end(c);
+    if (rc) { return rc; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e)); }
+    return SDRPP_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+const char* sdrpp_strerror(int code) {
+    switch (code) {
+    case SDRPP_OK: return "ok";
+    case SDRPP_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case SDRPP_ERR_INVALID: return "invalid argument or call sequence";
+    case SDRPP_ERR_NOMEM: return "device memory allocation failed";
+    case SDRPP_ERR_HIP: return "HIP runtime error";
+    case SDRPP_ERR_UNSUPPORTED: return "unsupported parameter";
+    case SDRPP_ERR_NOT_FOUND: return "no such VFO";
+    default: return "unknown error";
+    }
+}
+
+const char* sdrpp_kernel_family_name(int family) { return (family >= 0 && family < SDRPP_NUM_KERNEL_FAMILIES) ? kFamilyNames[family] : "?"; }
+
+int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
+    if (!out || max_push <= 0 || max_push > ((int64_t)1 << 28)) { return SDRPP_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { return SDRPP_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { return SDRPP_ERR_NO_DEVICE; }
+    sdrpp_ctx* c = new sdrpp_ctx;
+    c->device = device;
+    c->max_push = max_push;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        char b[600];
+        snprintf(b, sizeof(b), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        c->devinfo = b;
+    }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SDRPP_ERR_NO_DEVICE;
+    }
+    c->stream = c->own_stream;
+    for (int i = 0; i < kArenaSlots; i++) {
+        if (hipHostMalloc((void**)&c->arena_host[i], kArenaBytes, hipHostMallocDefault) != hipSuccess || hipEventCreate(&c->arena_ev[i]) != hipSuccess) {
+            sdrpp_destroy(c);
+            return SDRPP_ERR_NOMEM;
+        }
+    }
+    if (dev_alloc(c, &c->arena_dev, kArenaBytes) != SDRPP_OK || dev_alloc(c, &c->iq_stage, (size_t)max_push * 2 + 32) != SDRPP_OK) {
+        sdrpp_destroy(c);
+        return SDRPP_ERR_NOMEM;
+    }
+    *out = c;
+    return SDRPP_OK;
+}
+
+int sdrpp_destroy(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_OK; }
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (auto& kv : c->vfos) { vfo_free(*kv.second); }
+    c->vfos.clear();
+    for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
+    for (auto& p : c->tpairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) { (void)hipEventDestroy(e); }
+    for (int i = 0; i < kArenaSlots; i++) {
+        if (c->arena_host[i]) { (void)hipHostFree(c->arena_host[i]); }
+        if (c->arena_ev[i]) { (void)hipEventDestroy(c->arena_ev[i]); }
+    }
+    dev_free(c->arena_dev);
+    dev_free(c->iq_stage);
+    dev_free(c->iq_stage16);
+    dev_free(c->iq_hist[0]);
+    dev_free(c->iq_hist[1]);
+    dev_free(c->d_window);
+    dev_free(c->d_tw1);
+    dev_free(c->d_tw2);
+    dev_free(c->d_twn);
+    dev_free(c->d_scratch);
+    dev_free(c->d_lines);
+    dev_free(c->d_zstart);
+    dev_free(c->d_zcount);
+    dev_free(c->d_zoomed);
+    dev_free(c->d_index);
+    if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); }
+    delete c;
+    return SDRPP_OK;
+}
+
+const char* sdrpp_last_error(const sdrpp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return SDRPP_OK;
+}
+
+int sdrpp_sync(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDRPP_OK;
+}
+
+int sdrpp_device_info(sdrpp_ctx* c, char* buf, int buflen) {
+    if (!c || !buf || buflen <= 0) { return SDRPP_ERR_INVALID; }
+    snprintf(buf, (size_t)buflen, "%s", c->devinfo.c_str());
+    return SDRPP_OK;
+}
+
+// ---- FFT ---------------------------------------------------------------------------------------------------------------------
+int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const float* window) {
+    if (!c || !window) { return SDRPP_ERR_INVALID; }
+    if (!is_pow2(fft_size) || fft_size < 1024 || fft_size > (1 << 20)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft_size %d: need a power of two in [1024, 1048576]", fft_size); }
+    if (nz <= 0 || nz > fft_size || skip < 0) { return fail(c, SDRPP_ERR_INVALID, "bad framing nz=%d skip=%d", nz, skip); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fft_on = false;
+    const int m = ilog2(fft_size);
+    int rc = upload(c, &c->d_window, window, (size_t)nz);
+    if (rc) { return rc; }
+    auto half_table = [](int L) {
+        std::vector<float2> t((size_t)std::max(L / 2, 1));
+        for (int e = 0; e < L / 2; e++) { sdrpp_host::twiddle(e, L, &t[(size_t)e].x, &t[(size_t)e].y); }
+        return t;
+    };
+    dev_free(c->d_tw2);
+    dev_free(c->d_twn);
+    dev_free(c->d_scratch);
+    if (m <= 12) {
+        auto t = half_table(fft_size);
+        rc = upload(c, &c->d_tw1, t.data(), t.size());
+        if (rc) { return rc; }
+    }
+    else {
+        const int lg1 = m / 2, lg2 = m - lg1;
+        const int N1 = 1 << lg1, N2 = 1 << lg2;
+        auto t1 = half_table(N1);
+        auto t2 = half_table(N2);
+        rc = upload(c, &c->d_tw1, t1.data(), t1.size());
+        if (rc) { return rc; }
+        rc = upload(c, &c->d_tw2, t2.data(), t2.size());
+        if (rc) { return rc; }
+        std::vector<float2> full((size_t)fft_size);
+        for (int e = 0; e < fft_size; e++) { sdrpp_host::twiddle(e, fft_size, &full[(size_t)e].x, &full[(size_t)e].y); }
+        std::vector<float2> tn((size_t)fft_size);
+        for (int k1 = 0; k1 < N1; k1++) {
+            for (int n2 = 0; n2 < N2; n2++) { tn[(size_t)k1 * N2 + n2] = full[(size_t)k1 * n2]; }
+        }
+        rc = upload(c, &c->d_twn, tn.data(), tn.size());
+        if (rc) { return rc; }
+        const size_t per_chunk = std::max<size_t>(1, kScratchBytes / ((size_t)fft_size * sizeof(float2)));
+        rc = dev_alloc(c, &c->d_scratch, per_chunk * (size_t)fft_size);
+        if (rc) { return rc; }
+    }
+    const size_t lines = (size_t)(c->max_push / ((int64_t)nz + skip)) + 2;
+    dev_free(c->d_lines);
+    rc = dev_alloc(c, &c->d_lines, lines * (size_t)fft_size);
+    if (rc) { return rc; }
+    c->lines_cap = lines;
+    c->fft_size = fft_size;
+    c->fft_lg = m;
+    c->nz = nz;
+    c->skip = skip;
+    c->fft_pos = 0;
+    c->fft_next = 0;
+    c->n_lines = 0;
+    c->fft_on = true;
+    if (c->data_width > 0) { return sdrpp_fft_set_view(c, c->view_start, c->view_size, c->data_width, c->wf_min, c->wf_max); }
+    return SDRPP_OK;
+}
+
+int sdrpp_fft_disable(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fft_on = false;
+    c->n_lines = 0;
+    return SDRPP_OK;
+}
+
+int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float wf_min, float wf_max) {
+    if (!c || data_width < 0) { return SDRPP_ERR_INVALID; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->view_start = start;
+    c->view_size = size;
+    c->data_width = data_width;
+    c->wf_min = wf_min;
+    c->wf_max = wf_max;
+    c->zoom_cap = 0;
+    dev_free(c->d_zoomed);
+    dev_free(c->d_index);
+    if (data_width == 0 || c->fft_size == 0) { return SDRPP_OK; }
+    std::vector<int32_t> zs, zc;
+    sdrpp_host::zoomTable(start, size, c->fft_size, data_width, zs, zc);
+    int rc = upload(c, &c->d_zstart, zs.data(), zs.size());
+    if (rc) { return rc; }
+    rc = upload(c, &c->d_zcount, zc.data(), zc.size());
+    if (rc) { return rc; }
+    return ensure_zoom(c, c->lines_cap);
+}
+
+int sdrpp_fft_lines(sdrpp_ctx* c) { return c ? c->n_lines : SDRPP_ERR_INVALID; }
+
+int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
+    if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
+    if (first >= c->n_lines) { return 0; }
+    n = std::min(n, c->n_lines - first);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (raw) { HIPCHK(c, hipMemcpy(raw, c->d_lines + (size_t)first * c->fft_size, (size_t)n * c->fft_size * sizeof(float), hipMemcpyDeviceToHost)); }
+    if (c->data_width > 0) {
+        if (zoomed) { HIPCHK(c, hipMemcpy(zoomed, c->d_zoomed + (size_t)first * c->data_width, (size_t)n * c->data_width * sizeof(float), hipMemcpyDeviceToHost)); }
+        if (index) { HIPCHK(c, hipMemcpy(index, c->d_index + (size_t)first * c->data_width, (size_t)n * c->data_width * sizeof(int32_t), hipMemcpyDeviceToHost)); }
+    }
+    else if (zoomed || index) {
+        return fail(c, SDRPP_ERR_INVALID, "no view configured (sdrpp_fft_set_view)");
+    }
+    return n;
+}
+
+int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoomed, const int32_t** index, int* n_lines) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (raw) { *raw = c->d_lines; }
+    if (zoomed) { *zoomed = c->d_zoomed; }
+    if (index) { *index = c->d_index; }
+    if (n_lines) { *n_lines = c->n_lines; }
+    return SDRPP_OK;
+}
+
+// ---- VFOs ----------------------------------------------------------------------------------------------------------------------
+int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
+    if (!c || !d || !id) { return SDRPP_ERR_INVALID; }
+    if (d->n_stages < 0 || d->n_stages > SDRPP_MAX_DECIM_STAGES) { return fail(c, SDRPP_ERR_INVALID, "n_stages %d", d->n_stages); }
+    for (int s = 0; s < d->n_stages; s++) {
+        if (!is_pow2(d->stage_decim[s]) || d->stage_ntaps[s] <= 0 || !d->stage_taps[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage %d: decimation must be a power of two with taps", s); }
+    }
+    const bool has_poly = (d->interp != d->decim);
+    if (has_poly && (d->interp <= 0 || d->decim <= 0 || d->resamp_ntaps <= 0 || !d->resamp_taps)) { return fail(c, SDRPP_ERR_INVALID, "bad polyphase description"); }
+    if (d->chan_ntaps < 0 || d->chan_ntaps > kChanHistCap + 1) { return fail(c, SDRPP_ERR_UNSUPPORTED, "channel filter of %d taps (max %d)", d->chan_ntaps, kChanHistCap + 1); }
+    if (d->demod < SDRPP_DEMOD_RAW || d->demod > SDRPP_DEMOD_DSB) { return fail(c, SDRPP_ERR_INVALID, "demod %d", d->demod); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto v = std::make_unique<Vfo>();
+    v->id = c->next_id++;
+    v->d = *d;
+    int rc;
+    // capacities
+    size_t cap = (size_t)c->max_push;
+    auto add_stream = [&](int width, int hist, size_t capn) -> int {
+        v->st.emplace_back();
+        int r = stream_alloc(c, v->st.back(), width, hist, capn);
+        return r ? -1 : (int)v->st.size() - 1;
+    };
+    // what consumes the decimator / rotator output
+    const int tpp = has_poly ? (d->resamp_ntaps + d->interp - 1) / d->interp : 0;
+    const bool fm = (d->demod == SDRPP_DEMOD_WFM || d->demod == SDRPP_DEMOD_NFM);
+    auto hist_after_decim = [&]() -> int {
+        if (has_poly) { return tpp - 1; }
+        return kChanHistCap;  // channel filter (possibly enabled later) or the discriminator
+    };
+    for (int s = 0; s < d->n_stages; s++) {
+        v->staps[s].assign(d->stage_taps[s], d->stage_taps[s] + d->stage_ntaps[s]);
+        v->d.stage_taps[s] = nullptr;
+        rc = upload(c, &v->d_staps[s], v->staps[s].data(), v->staps[s].size());
+        if (rc) { return rc; }
+        cap = cap / (size_t)d->stage_decim[s] + 2;
+        const int hist = (s + 1 < d->n_stages) ? d->stage_ntaps[s + 1] - 1 : hist_after_decim();
+        if (add_stream(2, hist, cap) < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    if (d->n_stages == 0) {
+        if (add_stream(2, hist_after_decim(), cap) < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    v->i_first = 0;
+    if (has_poly) {
+        v->rtaps.assign(d->resamp_taps, d->resamp_taps + d->resamp_ntaps);
+        v->d.resamp_taps = nullptr;
+        v->tpp = tpp;
+        std::vector<float> bank((size_t)d->interp * tpp, 0.0f);
+        const int tot = d->interp * tpp;
+        for (int i = 0; i < tot; i++) { bank[(size_t)((d->interp - 1) - (i % d->interp)) * tpp + (size_t)(i / d->interp)] = (i < d->resamp_ntaps) ? v->rtaps[(size_t)i] : 0.0f; }  // polyphase_bank.h:31-34
+        rc = upload(c, &v->d_bank, bank.data(), bank.size());
+        if (rc) { return rc; }
+        cap = cap * (size_t)d->interp / (size_t)d->decim + 4;
+        v->i_poly = add_stream(2, kChanHistCap, cap);
+        if (v->i_poly < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    // channel-filter output stream always exists (taps may be enabled later); its consumer is the demodulator
+    v->i_chan = add_stream(2, 1, cap);
+    if (v->i_chan < 0) { return SDRPP_ERR_NOMEM; }
+    if (d->chan_ntaps > 0) {
+        if (!d->chan_taps) { return fail(c, SDRPP_ERR_INVALID, "chan_taps null"); }
+        v->ctaps_chan.assign(d->chan_taps, d->chan_taps + d->chan_ntaps);
+        rc = upload(c, &v->d_chan, v->ctaps_chan.data(), v->ctaps_chan.size());
+        if (rc) { return rc; }
+        v->chan_ntaps = d->chan_ntaps;
+    }
+    v->d.chan_taps = nullptr;
+    if (d->demod != SDRPP_DEMOD_RAW) {
+        if (fm || d->demod == SDRPP_DEMOD_AM) {
+            static const float unit = 1.0f;  // fm.h:165-168 loadDummyTaps: a single unit tap when the low-pass is off
+            const float* at = d->audio_ntaps > 0 ? d->audio_taps : &unit;
+            const int an = d->audio_ntaps > 0 ? d->audio_ntaps : 1;
+            if (d->audio_ntaps > 0 && !d->audio_taps) { return fail(c, SDRPP_ERR_INVALID, "audio_taps null"); }
+            v->ataps.assign(at, at + an);
+            v->audio_ntaps = an;
+            rc = upload(c, &v->d_audio, v->ataps.data(), v->ataps.size());
+            if (rc) { return rc; }
+            v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
+            if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
+        }
+        v->i_out = add_stream(2, 0, cap);
+        if (v->i_out < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    v->d.audio_taps = nullptr;
+    rc = dev_alloc(c, &v->d_state, 2 * sizeof(AgcState) + sizeof(float));
+    if (rc) { return rc; }
+    v->theta = sdrpp_host::turnsPerSample(d->phase_delta_re, d->phase_delta_im);
+    v->theta2 = sdrpp_host::turnsPerSample(d->ssb_phase_delta_re, d->ssb_phase_delta_im);
+    if (d->demod < SDRPP_DEMOD_USB) { v->theta2 = 0.0; }
+    v->modtaps_dirty = true;
+    rc = vfo_reset_state(c, *v);
+    if (rc) { return rc; }
+    *id = v->id;
+    c->vfos[v->id] = std::move(v);
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    vfo_free(*it->second);
+    c->vfos.erase(it);
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_count(sdrpp_ctx* c) { return c ? (int)c->vfos.size() : SDRPP_ERR_INVALID; }
+
+int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Vfo& v = *it->second;
+    v.d.phase_delta_re = re;
+    v.d.phase_delta_im = im;
+    v.theta = sdrpp_host::turnsPerSample(re, im);
+    v.modtaps_dirty = true;
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
+    if (!c || n < 0 || n > kChanHistCap + 1 || (n > 0 && !taps)) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Vfo& v = *it->second;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    v.ctaps_chan.assign(taps, taps + n);
+    v.chan_ntaps = n;
+    v.d.chan_ntaps = n;
+    if (n > 0) { return upload(c, &v.d_chan, v.ctaps_chan.data(), v.ctaps_chan.size()); }
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    return vfo_reset_state(c, *it->second);
+}
+
+static Stream* out_stream(Vfo& v) { return (v.d.demod == SDRPP_DEMOD_RAW) ? &v.st[(size_t)v.i_if] : &v.st[(size_t)v.i_out]; }
+
+int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    return out_stream(*it->second)->n;
+}
+
+int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
+    if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = out_stream(*it->second);
+    const int n = std::min(max, s->n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n > 0) { HIPCHK(c, hipMemcpy(dst, s->data, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
+    return n;
+}
+
+int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out, const float** if_out, int* n_if) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Vfo& v = *it->second;
+    Stream* o = out_stream(v);
+    if (out) { *out = o->data; }
+    if (n_out) { *n_out = o->n; }
+    if (if_out) { *if_out = v.st[(size_t)v.i_if].data; }
+    if (n_if) { *n_if = v.st[(size_t)v.i_if].n; }
+    return SDRPP_OK;
+}
+
+// ---- data path --------------------------------------------------------------------------------------------------------------------
+int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
+    if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return c ? fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push) : SDRPP_ERR_INVALID; }
+    if (count == 0) { return SDRPP_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the landing buffer is single: the previous push must have consumed it
+    HIPCHK(c, hipMemcpyAsync(c->iq_stage, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return push_common(c, c->iq_stage, count);
+}
+
+int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
+    if (!c || (!iq_dev && count > 0) || count < 0 || count > c->max_push) { return c ? fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push) : SDRPP_ERR_INVALID; }
+    return push_common(c, iq_dev, count);
+}
+
+int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
+    if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return SDRPP_ERR_INVALID; }
+    if (count == 0) { return SDRPP_OK; }
+    if (!c->iq_stage16) {
+        int rc = dev_alloc(c, &c->iq_stage16, (size_t)c->max_push * 2);
+        if (rc) { return rc; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->iq_stage16, iq_host, (size_t)count * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    {
+        FamilyTimer t(c, F_MISC);
+        const long long n = (long long)count * 2;
+        launch(c, int16_to_float_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, (const int16_t*)c->iq_stage16, c->iq_stage, n);
+    }
+    return push_common(c, c->iq_stage, count);
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------------------------------
+int sdrpp_timing_enable(sdrpp_ctx* c, int on) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    timing_flush(c);
+    c->timing = on != 0;
+    for (int i = 0; i < SDRPP_NUM_KERNEL_FAMILIES; i++) {
+        c->fam_ms[i] = 0.0;
+        c->fam_launch[i] = 0;
+    }
+    return SDRPP_OK;
+}
+
+int sdrpp_timing_read(sdrpp_ctx* c, double* ms, int64_t* launches) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    timing_flush(c);
+    for (int i = 0; i < SDRPP_NUM_KERNEL_FAMILIES; i++) {
+        if (ms) { ms[i] = c->fam_ms[i]; }
+        if (launches) { launches[i] = c->fam_launch[i]; }
+    }
+    return SDRPP_OK;
+}
+
+}  // extern "C"

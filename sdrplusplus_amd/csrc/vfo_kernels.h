@@ -1,0 +1,394 @@
+// Per-VFO channeliser + demodulator kernels for gfx950.
+//
+// Reference data flow per VFO and per input block (core/src/dsp/channel/rx_vfo.h:89-100):
+//   FrequencyXlator (VOLK rotator, full input rate)  ->  PowerDecimator cascade of DecimatingFIR stages
+//   (dsp/filter/decimating_fir.h:45-68)  ->  PolyphaseResampler (dsp/multirate/polyphase_resampler.h:69-99)  ->
+//   channel FIR (dsp/filter/fir.h:62-83)  ->  demodulator (dsp/demod/{quadrature,fm,broadcast_fm,am,ssb}.h).
+// The reference runs one thread per block and one VOLK dot product per output sample; every VFO re-reads its own copy of
+// the input (Splitter memcpy).  Here the time axis is split across workgroups (each stream keeps the (taps-1)-sample
+// history of its consumer in a small side buffer, so results do not depend on how the input is cut into pushes), all
+// VFOs of a launch are processed by the same grid, and the full-rate stage reads the shared IQ buffer once per tile.
+//
+// Numerics: summation order inside a dot product and the NCO differ from the reference's sequential fp32 recursion
+// (VOLK's own SIMD kernels differ from its generic ones in the same way); parity is by tolerance (1e-5 RMS), see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <sdrpp_gfx950.h>
+#include "fft_kernels.h"
+
+namespace sdrpp_k {
+
+// A stream of `width`-float samples: this push's samples in `data`, the previous `hist_len` samples in `hist`.
+struct StreamIn {
+    const float* data;
+    const float* hist;
+    int hist_len;
+    int n;  // valid samples in `data`
+};
+__device__ __forceinline__ float2 stream_load2(const StreamIn& s, int i) {
+    const float2* d = reinterpret_cast<const float2*>(s.data);
+    const float2* h = reinterpret_cast<const float2*>(s.hist);
+    if (i >= s.n) { return make_float2(0.0f, 0.0f); }  // tile over-read past the end of this push
+    return (i >= 0) ? d[i] : h[s.hist_len + i];
+}
+__device__ __forceinline__ float stream_load1(const StreamIn& s, int i) {
+    if (i >= s.n) { return 0.0f; }
+    return (i >= 0) ? s.data[i] : s.hist[s.hist_len + i];
+}
+
+// =====================================================================================================================
+// Stage 1: frequency translation folded into the first decimating FIR, VT VFOs per work-item sharing one LDS input tile
+// =====================================================================================================================
+// Reference:  r[n] = x[n] * e^{j(phi0 + n*theta)}  (rotator), then  y[j] = sum_k h[k] * r[i0 + k],  i0 = off0 + j*D - (K-1).
+// Same sum:   y[j] = e^{j(phi0 + (i0 + kc)*theta)} * sum_k g[k] * x[i0 + k],   g[k] = h[k] * e^{j(k - kc)*theta}
+// with complex taps g (host, double precision -> float) and ONE phasor per output instead of one per input sample.
+// theta = arg(phaseDelta) of the reference's float phaseDelta, phi0 accumulated on the host in double.
+#define SDRPP_S1_MAX_VT 8
+struct Stage1Job {
+    int nv;                  // VFOs handled by this job (<= VT of the launch)
+    int ntaps, log2_decim, off0, nout;
+    const float2* ctaps;     // [ntaps][VT] modulated taps, VFO index fastest
+    double theta[SDRPP_S1_MAX_VT];  // turns per input sample
+    double phi0[SDRPP_S1_MAX_VT];   // turns at push-relative sample index 0
+    float2* out[SDRPP_S1_MAX_VT];
+};
+
+// grid = (ceil(max nout / TILE), njobs); block = TILE work-items; dynamic LDS = D * pitch float2 with
+// pitch = TILE + ceil((K-1)/D) + 1.  LDS image is de-interleaved by decimation phase: sample s of the tile lives at
+// [s mod D][s div D], so lane j reads x[j*D + k] at [k mod D][j + k div D] — consecutive lanes, consecutive addresses.
+template <int VT>
+__global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, xs)
+    const Stage1Job& job = jobs[blockIdx.y];
+    const int tile = blockDim.x;
+    const int j0 = blockIdx.x * tile;
+    if (j0 >= job.nout) { return; }
+    const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
+    const int extra = (K - 1 + D - 1) >> lgD;
+    const int pitch = tile + extra + 1;
+    const int nsamp = (tile - 1) * D + K;
+    const long long base = (long long)job.off0 + (long long)j0 * D - (K - 1);  // push-relative index of tile sample 0
+    for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = iq_load_clamped(src, base + s); }
+    __syncthreads();
+    const int j = threadIdx.x;
+    float2 acc[VT];
+#pragma unroll
+    for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
+    const UniformF32 g = as_uniform(job.ctaps);  // taps are wave-uniform: fetched with scalar loads
+    for (int k = 0; k < K; k++) {
+        const float2 x = xs[(k & (D - 1)) * pitch + (k >> lgD) + j];
+#pragma unroll
+        for (int v = 0; v < VT; v++) {
+            const float2 w = make_float2(g[2 * (k * VT + v)], g[2 * (k * VT + v) + 1]);
+            acc[v].x = fmaf(w.x, x.x, acc[v].x);
+            acc[v].x = fmaf(-w.y, x.y, acc[v].x);
+            acc[v].y = fmaf(w.x, x.y, acc[v].y);
+            acc[v].y = fmaf(w.y, x.x, acc[v].y);
+        }
+    }
+    if (j0 + j >= job.nout) { return; }
+    const double centre = (double)(base + (long long)j * D) + 0.5 * (double)(K - 1);
+#pragma unroll
+    for (int v = 0; v < VT; v++) {
+        if (v < job.nv) {
+            double ph = fma(centre, job.theta[v], job.phi0[v]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            float2 y;
+            y.x = fmaf(acc[v].x, cs, -(acc[v].y * sn));
+            y.y = fmaf(acc[v].x, sn, acc[v].y * cs);
+            job.out[v][j0 + j] = y;
+        }
+    }
+}
+
+// Rotation only (VFOs whose output rate is above half the input rate have no decimation stage: power_decimator.h:53-56).
+struct RotJob {
+    double theta, phi0;
+    float2* out;
+    int n;
+};
+__global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob* __restrict__ jobs) {
+    const RotJob& job = jobs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+        double ph = fma((double)i, job.theta, job.phi0);
+        ph -= rint(ph);
+        float sn, cs;
+        sincospif(2.0f * (float)ph, &sn, &cs);
+        const float2 x = iq_load(src, i);
+        job.out[i] = make_float2(fmaf(x.x, cs, -(x.y * sn)), fmaf(x.x, sn, x.y * cs));
+    }
+}
+
+// =====================================================================================================================
+// Generic (decimating) FIR with real taps on complex / stereo (WIDTH 2) or real (WIDTH 1) streams.
+//   out[j] = sum_k taps[k] * in[off0 + j*D + k - (K-1)]      (decimating_fir.h:51-61, fir.h:67-77)
+// STEREO: WIDTH 1 input, output written as {v, v} (convert::MonoToStereo / LRToStereo(x, x)).
+// =====================================================================================================================
+struct FirJob {
+    StreamIn in;
+    float* out;
+    const float* taps;
+    int ntaps, log2_decim, off0, nout;
+};
+
+template <int WIDTH, bool STEREO>
+__global__ __launch_bounds__(256) void vfo_fir_kernel(const FirJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const FirJob& job = jobs[blockIdx.y];
+    const int tile = blockDim.x;
+    const int j0 = blockIdx.x * tile;
+    if (j0 >= job.nout) { return; }
+    const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
+    const int extra = (K - 1 + D - 1) >> lgD;
+    const int pitch = tile + extra + 1;
+    const int nsamp = (tile - 1) * D + K;
+    const int base = job.off0 + j0 * D - (K - 1);
+    const int j = threadIdx.x;
+    const UniformF32 taps = as_uniform(job.taps);  // wave-uniform -> scalar loads
+    if constexpr (WIDTH == 2) {
+        float2* xs = reinterpret_cast<float2*>(smem);
+        for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = stream_load2(job.in, base + s); }
+        __syncthreads();
+        float2 acc = make_float2(0.0f, 0.0f);
+        for (int k = 0; k < K; k++) {
+            const float2 x = xs[(k & (D - 1)) * pitch + (k >> lgD) + j];
+            const float h = taps[k];
+            acc.x = fmaf(h, x.x, acc.x);
+            acc.y = fmaf(h, x.y, acc.y);
+        }
+        if (j0 + j < job.nout) { reinterpret_cast<float2*>(job.out)[j0 + j] = acc; }
+    }
+    else {
+        float* xs = smem;
+        for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = stream_load1(job.in, base + s); }
+        __syncthreads();
+        float acc = 0.0f;
+        for (int k = 0; k < K; k++) { acc = fmaf(taps[k], xs[(k & (D - 1)) * pitch + (k >> lgD) + j], acc); }
+        if (j0 + j < job.nout) {
+            if constexpr (STEREO) { reinterpret_cast<float2*>(job.out)[j0 + j] = make_float2(acc, acc); }
+            else { job.out[j0 + j] = acc; }
+        }
+    }
+}
+
+// =====================================================================================================================
+// Polyphase rational resampler (polyphase_resampler.h:75-93):
+//   A_n = phase0 + n*M;  out[n] = sum_k bank[A_n mod L][k] * in[offset0 + A_n div L + k - (tpp-1)]
+// bank[(L-1) - (i mod L)][i div L] = taps[i] (polyphase_bank.h:31-34) is laid out [phase][tpp] on the host.
+// =====================================================================================================================
+struct PolyJob {
+    StreamIn in;
+    float2* out;
+    const float* bank;  // [interp][tpp]
+    int interp, decim, tpp, phase0, off0, nout;
+};
+
+__global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, xs)
+    const PolyJob& job = jobs[blockIdx.y];
+    const int tile = blockDim.x;
+    const int n0 = blockIdx.x * tile;
+    if (n0 >= job.nout) { return; }
+    const int L = job.interp, M = job.decim, tpp = job.tpp;
+    const long long a0 = (long long)job.phase0 + (long long)n0 * M;
+    int nlast = n0 + tile - 1;
+    if (nlast >= job.nout) { nlast = job.nout - 1; }
+    const long long a1 = (long long)job.phase0 + (long long)nlast * M;
+    const int first = job.off0 + (int)(a0 / L) - (tpp - 1);  // stream index of the first sample this tile needs
+    const int nsamp = (int)(a1 / L) - (int)(a0 / L) + tpp;
+    for (int s = threadIdx.x; s < nsamp; s += tile) { xs[s] = stream_load2(job.in, first + s); }
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    if (n >= job.nout) { return; }
+    const long long a = (long long)job.phase0 + (long long)n * M;
+    const int ph = (int)(a % L);
+    const int rel = (int)(a / L) - (int)(a0 / L);
+    const float* __restrict__ t = job.bank + (size_t)ph * tpp;
+    float2 acc = make_float2(0.0f, 0.0f);
+    for (int k = 0; k < tpp; k++) {
+        const float2 x = xs[rel + k];
+        const float h = t[k];
+        acc.x = fmaf(h, x.x, acc.x);
+        acc.y = fmaf(h, x.y, acc.y);
+    }
+    job.out[n] = acc;
+}
+
+// =====================================================================================================================
+// FM discriminator (quadrature.h:39-46): out[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation
+// =====================================================================================================================
+struct QuadJob {
+    StreamIn in;  // complex IF stream, hist_len >= 1
+    float* out;
+    float inv_deviation;
+    int n;
+};
+__device__ __forceinline__ float normalize_phase(float d) {
+    const float FL_PI = 3.1415926535f;  // math/constants.h:4, math/normalize_phase.h:6-9
+    if (d > FL_PI) { d -= 2.0f * FL_PI; }
+    else if (d <= -FL_PI) { d += 2.0f * FL_PI; }
+    return d;
+}
+__global__ __launch_bounds__(256) void vfo_quadrature_kernel(const QuadJob* __restrict__ jobs) {
+    const QuadJob& job = jobs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+        const float2 c = stream_load2(job.in, i);
+        const float2 p = stream_load2(job.in, i - 1);
+        const float cp = atan2f(c.y, c.x);
+        const float pp = atan2f(p.y, p.x);
+        job.out[i] = normalize_phase(cp - pp) * job.inv_deviation;
+    }
+}
+
+// =====================================================================================================================
+// Sequential tails at IF rate — one work-item per VFO, exactly the reference's per-sample recursions:
+//   AM  (am.h:101-131): [carrier AGC] -> |x| -> DC blocker (dc_blocker.h:54-60) -> [audio AGC] -> (LPF runs afterwards as a FIR job)
+//   SSB (ssb.h:77-92) : second translation (closed-form NCO) -> Re{} -> AGC (agc.h:70-109) -> {v, v}
+// The AGC look-ahead on clipping scans to the end of the push (the reference scans to the end of its block).
+// =====================================================================================================================
+struct AgcState {
+    float set_point, attack, inv_attack, decay, inv_decay, max_gain, max_output_amp, amp;
+};
+struct SeqJob {
+    int mode;  // 2 AM, 3/4/5 SSB family
+    int n;
+    const float2* in;  // complex IF samples of this push
+    float* out;        // AM: float (to the LPF stream); SSB: stereo float2
+    AgcState* agc;     // persistent (device)
+    AgcState* carrier_agc;
+    float* dc_offset;  // persistent
+    float dc_rate;
+    int carrier_mode;
+    double theta2, phi2;  // SSB NCO, turns
+};
+
+__device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
+    float gain;
+    if (inAmp != 0.0f) {
+        a.amp = (inAmp > a.amp) ? ((a.amp * a.inv_attack) + (inAmp * a.attack)) : ((a.amp * a.inv_decay) + (inAmp * a.decay));
+        const float g = a.set_point / a.amp;
+        gain = (a.max_gain < g) ? a.max_gain : g;
+    }
+    else {
+        gain = 1.0f;
+    }
+    return gain;
+}
+
+__global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __restrict__ jobs, int njobs) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= njobs) { return; }
+    const SeqJob job = jobs[id];
+    if (job.mode == 2) {
+        AgcState agc = *job.agc;
+        AgcState cagc = *job.carrier_agc;
+        float off = *job.dc_offset;
+        for (int i = 0; i < job.n; i++) {
+            float2 x = job.in[i];
+            if (job.carrier_mode) {
+                float inAmp = sqrtf((x.x * x.x) + (x.y * x.y));
+                float gain = agc_gain(cagc, inAmp);
+                if (inAmp * gain > cagc.max_output_amp) {
+                    float maxAmp = 0.0f;
+                    for (int j = i; j < job.n; j++) {
+                        const float2 y = job.in[j];
+                        const float a = sqrtf((y.x * y.x) + (y.y * y.y));
+                        if (a > maxAmp) { maxAmp = a; }
+                    }
+                    cagc.amp = maxAmp;
+                    const float g = cagc.set_point / cagc.amp;
+                    gain = (cagc.max_gain < g) ? cagc.max_gain : g;
+                }
+                x.x = x.x * gain;
+                x.y = x.y * gain;
+            }
+            const float mag = sqrtf((x.x * x.x) + (x.y * x.y));
+            float v = mag - off;
+            off += v * job.dc_rate;
+            if (!job.carrier_mode) {
+                // audio AGC sees the DC-blocked envelope; its look-ahead needs the not-yet-computed future samples of the same
+                // recursion, so it re-runs the DC blocker forward from the current state (exactly what the reference's
+                // in-place buffer holds at that moment).
+                float inAmp = fabsf(v);
+                float gain = agc_gain(agc, inAmp);
+                if (inAmp * gain > agc.max_output_amp) {
+                    float maxAmp = inAmp;
+                    float o2 = off;
+                    for (int j = i + 1; j < job.n; j++) {
+                        const float2 y = job.in[j];
+                        const float m2 = sqrtf((y.x * y.x) + (y.y * y.y));
+                        const float v2 = m2 - o2;
+                        o2 += v2 * job.dc_rate;
+                        const float a2 = fabsf(v2);
+                        if (a2 > maxAmp) { maxAmp = a2; }
+                    }
+                    agc.amp = maxAmp;
+                    const float g = agc.set_point / agc.amp;
+                    gain = (agc.max_gain < g) ? agc.max_gain : g;
+                }
+                v = v * gain;
+            }
+            job.out[i] = v;
+        }
+        *job.agc = agc;
+        *job.carrier_agc = cagc;
+        *job.dc_offset = off;
+    }
+    else {
+        AgcState agc = *job.agc;
+        float2* out = reinterpret_cast<float2*>(job.out);
+        for (int i = 0; i < job.n; i++) {
+            const float2 x = job.in[i];
+            double ph = fma((double)i, job.theta2, job.phi2);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            const float re = fmaf(x.x, cs, -(x.y * sn));
+            float inAmp = fabsf(re);
+            float gain = agc_gain(agc, inAmp);
+            if (inAmp * gain > agc.max_output_amp) {
+                float maxAmp = inAmp;
+                for (int j = i + 1; j < job.n; j++) {
+                    const float2 y = job.in[j];
+                    double p2 = fma((double)j, job.theta2, job.phi2);
+                    p2 -= rint(p2);
+                    float s2, c2;
+                    sincospif(2.0f * (float)p2, &s2, &c2);
+                    const float a2 = fabsf(fmaf(y.x, c2, -(y.y * s2)));
+                    if (a2 > maxAmp) { maxAmp = a2; }
+                }
+                agc.amp = maxAmp;
+                const float g = agc.set_point / agc.amp;
+                gain = (agc.max_gain < g) ? agc.max_gain : g;
+            }
+            const float v = re * gain;
+            out[i] = make_float2(v, v);
+        }
+        *job.agc = agc;
+    }
+}
+
+// =====================================================================================================================
+// History carry: after a push of n samples, the new history of a stream is the last hist_len samples of (old history ++ data).
+// Written to the stream's alternate history buffer (ping-pong), so the update is race-free for any n.
+// =====================================================================================================================
+struct CarryJob {
+    const float* data;
+    const float* old_hist;
+    float* new_hist;
+    int hist_len, n, width;
+};
+__global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) {
+    const CarryJob& job = jobs[blockIdx.y];
+    const int total = job.hist_len * job.width;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int i = e / job.width, c = e % job.width;
+        const long long s = (long long)job.n + i;  // index into old_hist ++ data
+        job.new_hist[e] = (s < job.hist_len) ? job.old_hist[s * job.width + c] : job.data[(s - job.hist_len) * job.width + c];
+    }
+}
+
+}  // namespace sdrpp_k

@@ -1,0 +1,186 @@
+// TEST INFRASTRUCTURE ONLY — a tiny single-threaded HIP *emulator* so the product's kernel sources
+// (sdrplusplus_amd/csrc/*.hip) can be compiled with g++ and executed on a machine without a GPU, purely to check
+// indexing / streaming-state logic in `-m "not gpu"` tests (tests/emu/Makefile builds tests/emu/libsdrpp_gpu_emu.so).
+// It is NOT a fallback: the product library is always the hipcc build, the Python binding refuses to load this file
+// unless a test asks for it explicitly, and no `-m gpu` test, smoke() or bench.py ever touches it.
+//
+// Model: one workgroup at a time; each work-item is a ucontext fiber; __syncthreads() yields round-robin until all
+// fibers of the block have arrived.  Only the HIP subset the product uses is provided.
+#pragma once
+#include <ucontext.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+static inline float2 make_float2(float x, float y) { return float2{ x, y }; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{ x, y, z, w }; }
+static inline int2 make_int2(int x, int y) { return int2{ x, y }; }
+
+namespace hipemu {
+    struct State {
+        dim3 tIdx, bIdx, bDim, gDim;
+        std::vector<ucontext_t> ctx;
+        std::vector<char*> stacks;
+        std::vector<int> done;
+        ucontext_t sched;
+        int cur = -1;
+        std::function<void()> body;
+        alignas(64) char dynshared[160 * 1024];
+    };
+    inline State& S() { static State s; return s; }
+    inline void trampoline() {
+        State& s = S();
+        s.body();
+        s.done[s.cur] = 1;
+        swapcontext(&s.ctx[s.cur], &s.sched);
+    }
+    inline void set_tid(int i) {
+        State& s = S();
+        s.tIdx.x = i % s.bDim.x;
+        s.tIdx.y = (i / s.bDim.x) % s.bDim.y;
+        s.tIdx.z = i / (s.bDim.x * s.bDim.y);
+    }
+    inline void run_block(int nthreads) {
+        State& s = S();
+        const size_t STK = 256 * 1024;
+        if ((int)s.ctx.size() < nthreads) {
+            size_t old = s.ctx.size();
+            s.ctx.resize(nthreads);
+            s.stacks.resize(nthreads, nullptr);
+            for (size_t i = old; i < (size_t)nthreads; i++) { s.stacks[i] = (char*)malloc(STK); }
+        }
+        s.done.assign(nthreads, 0);
+        for (int i = 0; i < nthreads; i++) {
+            getcontext(&s.ctx[i]);
+            s.ctx[i].uc_stack.ss_sp = s.stacks[i];
+            s.ctx[i].uc_stack.ss_size = STK;
+            s.ctx[i].uc_link = &s.sched;
+            makecontext(&s.ctx[i], (void (*)())trampoline, 0);
+        }
+        int remaining = nthreads;
+        while (remaining > 0) {
+            remaining = 0;
+            for (int i = 0; i < nthreads; i++) {
+                if (s.done[i]) { continue; }
+                s.cur = i;
+                set_tid(i);
+                swapcontext(&s.sched, &s.ctx[i]);
+                if (!s.done[i]) { remaining++; }
+            }
+        }
+    }
+    inline void syncthreads() {
+        State& s = S();
+        int me = s.cur;
+        swapcontext(&s.ctx[me], &s.sched);
+        s.cur = me;
+        set_tid(me);
+    }
+}
+#define threadIdx (hipemu::S().tIdx)
+#define blockIdx (hipemu::S().bIdx)
+#define blockDim (hipemu::S().bDim)
+#define gridDim (hipemu::S().gDim)
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::S().dynshared;
+static inline void __syncthreads() { hipemu::syncthreads(); }
+
+typedef int hipError_t;
+typedef struct hipemuStream* hipStream_t;
+typedef struct hipemuEvent { double t; }* hipEvent_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+#define hipErrorOutOfMemory 2
+#define hipErrorNoDevice 100
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+#define hipStreamNonBlocking 1
+#define hipHostMallocDefault 0
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : hipErrorOutOfMemory; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : hipErrorOutOfMemory; }
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { memmove(d, s, n); return 0; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return 0; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{ 0 }; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "hipemu (CPU fiber emulator, tests only)");
+    strcpy(p->gcnArchName, "emu");
+    p->multiProcessorCount = 1;
+    return 0;
+}
+
+template <typename... KArgs, typename... Args>
+static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, Args... args) {
+    hipemu::State& s = hipemu::S();
+    if (getenv("SDRPP_EMU_TRACE")) { fprintf(stderr, "[hipemu] launch grid=(%u,%u,%u) block=(%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z); }
+    s.gDim = grid;
+    s.bDim = block;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    for (unsigned bz = 0; bz < grid.z; bz++) {
+        for (unsigned by = 0; by < grid.y; by++) {
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                s.bIdx = dim3(bx, by, bz);
+                s.body = [&]() { kernel(static_cast<KArgs>(args)...); };
+                hipemu::run_block(nthreads);
+            }
+        }
+    }
+}
+
+// device intrinsics used by the kernels
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline void sincospif(float x, float* s, float* c) {
+    const double a = 3.14159265358979323846 * (double)x;
+    *s = (float)sin(a);
+    *c = (float)cos(a);
+}
+static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) { *p = v; } return o; }
+static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
+using std::min;
+using std::max;
