@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json headline metric on MI355X.
+
+Workload (config.workload = "cfg3"): 10 MS/s synthetic IQ, 65536-pt Nuttall FFT + log-power + waterfall line (dense
+framing: every sample transformed) AND 32 VFOs x WFM (frequency translation, 8/2/2 decimating FIR cascade, 4/5 polyphase
+resampler, 126-tap channel filter, FM discriminator, 237-tap audio low-pass), all inside one `sdrpp_push_device` call.
+A "step" = one pass of that hot path over one batch of `--push` complex samples already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Multi-GPU: independent IQ streams, one per GPU (weak scaling); the only exchange is the RCCL gather of the finished
+(zoomed) waterfall lines to rank 0, inside the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def make_input(torch, n, nvfo, sr, seed, device):
+    """cfg 3 signal generated on the device (float64 phase, rounded once): 8 tones + AWGN + nvfo FM carriers."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n, device=device, dtype=torch.float64)
+    x = torch.complex(torch.randn(n, generator=g, device=device, dtype=torch.float32), torch.randn(n, generator=g, device=device, dtype=torch.float32)).to(torch.complex128) * 1e-4
+    fr = [0.0625, -0.125, 0.20001, -0.3123, 0.4101, -0.0417, 0.3333, -0.4499]
+    amp = [0.1, 0.03, 0.01, 3e-3, 1e-3, 3e-4, 1e-4, 1e-5]
+    two_pi = 6.283185307179586
+    for f, a in zip(fr, amp):
+        x += a * torch.polar(torch.ones_like(t), two_pi * f * t)
+    for k in range(nvfo):
+        carrier = (k - (nvfo - 1) / 2.0) * 300e3
+        tone = 400.0 + 50.0 * k
+        ph = two_pi * (carrier / sr) * t + (75e3 / tone) * torch.sin(two_pi * (tone / sr) * t)
+        x += 0.05 * torch.polar(torch.ones_like(t), ph)
+    return x.to(torch.complex64).contiguous()
+
+
+def cpu_baseline(sr, nvfo, fft_size, block):
+    """Reference code (oracle/_ref, reference headers + restated VOLK/FFTW) timed on this host: same cfg-3 workload,
+    bounded sample sized for roughly 10-20 s of CPU work."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import support as S
+
+    lib = S.ref(fast=True)
+    kind = "reference"
+    if lib is None:
+        return None
+    from sdrplusplus_amd import workloads
+
+    cores = os.cpu_count() or 1
+    offs = np.array([c for _, _, _, c, _ in workloads.vfo_plan(3, nvfo)], dtype=np.float64)
+    offs_p = offs.ctypes.data_as(C.POINTER(C.c_double))
+    n0 = block * 20
+    x = workloads.synth(3, n0, seed=21, nvfo=nvfo)
+    lib.ref_bench_cfg3(S._fp(x.view(np.float32)), block * 2, block, sr, nvfo, offs_p, fft_size, cores)  # warm caches / tables
+    t = lib.ref_bench_cfg3(S._fp(x.view(np.float32)), n0, block, sr, nvfo, offs_p, fft_size, cores)
+    rate = n0 / t
+    n1 = int(min(max(rate * 12.0, n0), 200 * block) // block * block)  # ~12 s, at most 10 M samples
+    if n1 > n0:
+        reps = -(-n1 // n0)
+        xx = np.tile(x, reps)[:n1]
+        t = lib.ref_bench_cfg3(S._fp(xx.view(np.float32)), n1, block, sr, nvfo, offs_p, fft_size, cores)
+        rate, n0 = n1 / t, n1
+    return {
+        "value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
+        "sample": "%d samples of cfg3 (%d VFO x WFM via the reference's RxVFO::process + BroadcastFM::process, %d-pt FFT + log-power per %d "
+                  "samples) in blocks of %d, %d worker threads over VFOs, reference headers compiled -O3 -march=native against the restated "
+                  "VOLK (vectorised dot products) / FFT shim — genuine libvolk/libfftw3f are not installed; %.1f s of CPU time"
+                  % (n0, nvfo, fft_size, fft_size, block, cores, t),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--push", type=int, default=1 << 22, help="complex samples per step (multiple of the FFT size)")
+    ap.add_argument("--nvfo", type=int, default=32)
+    ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 32 MiB > the 256 MiB MALL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fft-only", action="store_true", help="BASELINE cfg2 (no VFOs) instead of cfg3")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # backend "nccl" is RCCL on ROCm
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    from sdrplusplus_amd import capi, workloads
+
+    sr, N = 10e6, 65536
+    push = (args.push // N) * N
+    nvfo = 0 if args.fft_only else args.nvfo
+    cfg = 2 if args.fft_only else 3
+    bufs = [make_input(torch, push, nvfo, sr, 0x5D2B0001 + 1000 * rank + b, device) for b in range(args.nbuf)]
+    ctx = capi.Context(local, max_push=push)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
+    info = workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo)
+    lines_per_push = push // N
+    lines = torch.empty((lines_per_push, 1024), dtype=torch.float32, device=device)
+    gathered = [torch.empty_like(lines) for _ in range(world)] if (dist is not None and rank == 0) else None
+
+    def step(i):
+        ctx.push_device(bufs[i % args.nbuf].data_ptr(), push)
+        if dist is not None:
+            ctx.fft_copy_device(0, lines_per_push, zoomed_ptr=lines.data_ptr())
+            dist.gather(lines, gathered, dst=0)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fam = ctx.timing_read()
+    ctx.timing_enable(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: the work was really done (outputs have the expected sizes)
+    assert ctx.fft_lines() == lines_per_push
+    for vid in info["vids"][:1]:
+        assert abs(ctx.vfo_out_count(vid) - push // 40) <= 2
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_samples = world * push * args.steps
+    value = total_samples / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (HIP events around every launch of the family, on the launch stream) ----
+    K1, D1 = 44, 8  # cfg 3 stage-1 plan: fir_32_8 (44 taps, decimate by 8)
+    bytes_per_launch = {  # compulsory HBM bytes of ONE launch of each kernel family (DESIGN.md "Kernels")
+        "vfo_stage1": push * (8 + nvfo * 8.0 / D1),
+        "fft_pass1": push * (8 + 8),
+        "fft_pass2": push * (8 + 4),
+        "vfo_decim": push * nvfo * (8.0 / 8 + 8.0 / 16) + push * nvfo * (8.0 / 16 + 8.0 / 32),
+        "vfo_poly": push * nvfo * (8.0 / 32 + 8.0 / 40),
+        "vfo_fir": push * nvfo * (8.0 / 40 * 2 + 4.0 / 40 + 8.0 / 40),
+        "demod": push * nvfo * (8.0 / 40 + 4.0 / 40),
+        "zoom_palette": push * 4.0,
+    }
+    flops_per_launch = {
+        "vfo_stage1": push * nvfo * K1 * 8.0 / D1,
+        "fft_pass1": push * (3 * 2 * 8 + 8 + 2),   # 8 radix-2 stages x 6 FMA per butterfly (3 per point) + window + twiddle
+        "fft_pass2": push * (3 * 2 * 8 + 12),
+    }
+    kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}
+    dom = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
+    roof = None
+    roof_valu = None
+    if dom is not None and dom in bytes_per_launch:
+        dur = kernel_ms[dom] * 1e-3
+        ach = bytes_per_launch[dom] / dur / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch[dom], "avg_launch_ms": round(kernel_ms[dom], 4),
+                "note": "this kernel is FP32-VALU-bound (no dense contraction, MFMA unused): see roofline_valu" if dom.startswith("vfo") else ""}
+        if dom in flops_per_launch:
+            tf = flops_per_launch[dom] / dur / 1e12
+            roof_valu = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 5)}
+    path_bytes = 12.0 + (nvfo * (250e3 / sr) * 8 + (8 if nvfo else 0) - (8 if nvfo else 0))  # FFT 12 B + VFO outputs (IQ read once, shared)
+    path_bytes = 12.0 + nvfo * (250e3 / sr) * 8
+    roof_path = {"bound": "hbm", "achieved": round(value * 1e6 / world * path_bytes / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(value * 1e6 / world * path_bytes / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_sample": path_bytes,
+                 "note": "whole step, per GPU: SURVEY.md 8(d) path figure x ingest rate"}
+
+    out = {
+        "metric": "IQ Msamples/s ingested (65536-pt FFT + 32 VFO WFM)" if not args.fft_only else "IQ Msamples/s ingested (65536-pt FFT only, cfg2)",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg%d: 10 MS/s-format synthetic IQ, 65536-pt dense FFT + log-power waterfall%s" % (cfg, (" + %d VFO x WFM (xlate+FIR+resample+FM demod)" % nvfo) if nvfo else ""),
+                   "samples_per_step_per_gpu": push, "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
+                   "input_batches_rotated": args.nbuf, "device": ctx.device_info()},
+        "roofline": roof, "roofline_valu": roof_valu, "roofline_path": roof_path,
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
+        "realtime_factor": round(value * 1e6 / world / sr, 1),
+    }
+    if world == 1 and not args.no_cpu_baseline and not args.fft_only:
+        try:
+            out["cpu_baseline"] = cpu_baseline(sr, nvfo, N, int(sr / 200))
+            if out["cpu_baseline"]:
+                out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,8 @@ const char* sdrpp_last_error(const sdrpp_ctx* ctx);
  * NULL restores the context-owned stream. */
 int sdrpp_set_stream(sdrpp_ctx* ctx, void* hip_stream);
 int sdrpp_sync(sdrpp_ctx* ctx);
+/* ABI self-description for foreign-function bindings: returns the ABI version and, if non-NULL, sizeof(sdrpp_vfo_desc). */
+int sdrpp_abi_version(int* sizeof_vfo_desc);
 /* Human-readable device name / arch into buf (for logs and bench records). */
 int sdrpp_device_info(sdrpp_ctx* ctx, char* buf, int buflen);
 
@@ -87,6 +89,9 @@ int sdrpp_fft_lines(sdrpp_ctx* ctx);
  * acquireFFTBuffer/releaseFFTBuffer hand to the waterfall), zoomed lines (data_width floats) and palette indices.
  * Any destination may be NULL.  Returns the number of lines copied. */
 int sdrpp_fft_read(sdrpp_ctx* ctx, int first, int n, float* raw_host, float* zoomed_host, int32_t* index_host);
+/* Same, but into DEVICE memory of the caller (asynchronous D2D copies on the context's stream) — e.g. torch tensors that
+ * are then handed to an RCCL gather of waterfall lines. */
+int sdrpp_fft_copy_device(sdrpp_ctx* ctx, int first, int n, float* raw_dev, float* zoomed_dev, int32_t* index_dev);
 /* Device pointers to the same buffers (valid until the next push). */
 int sdrpp_fft_device_buffers(sdrpp_ctx* ctx, const float** raw, const float** zoomed, const int32_t** index, int* n_lines);
 

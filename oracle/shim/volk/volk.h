@@ -10,8 +10,8 @@
 //
 // Two build flavours:
 //   default              : strict sequential fp32 sums  -> bit-exact ground truth for oracle/oracle.c
-//   -DSDRPP_SHIM_SIMD    : dot products with 16 lane-partial sums (what VOLK's AVX/AVX-512 protokernels
-//                          do), compiled -O3 -march=native; used only for CPU-baseline TIMING.
+//   -DSDRPP_SHIM_SIMD    : dot products as vectorised reductions (lane-partial sums, what VOLK's AVX/AVX-512
+//                          protokernels do), compiled -O3 -march=native -fopenmp-simd; used only for CPU-baseline TIMING.
 #pragma once
 #include <complex>
 #include <cmath>
@@ -161,35 +161,23 @@ static inline void volk_32f_x2_dot_prod_32f(float* result, const float* input, c
     *result = acc;
 }
 #else
-// Lane-partial sums like VOLK's a_avx/u_avx512f protokernels (timing flavour only).
+// Vectorised reductions (what VOLK's a_avx/u_avx512f protokernels do: lane-partial sums, horizontal add at the end).
+// Timing flavour only; compiled with -O3 -march=native -fopenmp-simd.
 static inline void volk_32fc_32f_dot_prod_32fc(lv_32fc_t* result, const lv_32fc_t* input, const float* taps, unsigned int n) {
     const float* ap = (const float*)input;
-    float accr[16] = { 0 }, acci[16] = { 0 };
-    unsigned int i = 0;
-    for (; i + 16 <= n; i += 16) {
-        for (int l = 0; l < 16; l++) {
-            accr[l] += ap[2 * (i + l)] * taps[i + l];
-            acci[l] += ap[2 * (i + l) + 1] * taps[i + l];
-        }
-    }
     float re = 0.0f, im = 0.0f;
-    for (int l = 0; l < 16; l++) { re += accr[l]; im += acci[l]; }
-    for (; i < n; i++) {
+#pragma omp simd reduction(+ : re, im)
+    for (unsigned int i = 0; i < n; i++) {
         re += ap[2 * i] * taps[i];
         im += ap[2 * i + 1] * taps[i];
     }
     *result = lv_32fc_t(re, im);
 }
 static inline void volk_32f_x2_dot_prod_32f(float* result, const float* input, const float* taps, unsigned int n) {
-    float acc[16] = { 0 };
-    unsigned int i = 0;
-    for (; i + 16 <= n; i += 16) {
-        for (int l = 0; l < 16; l++) { acc[l] += input[i + l] * taps[i + l]; }
-    }
-    float r = 0.0f;
-    for (int l = 0; l < 16; l++) { r += acc[l]; }
-    for (; i < n; i++) { r += input[i] * taps[i]; }
-    *result = r;
+    float acc = 0.0f;
+#pragma omp simd reduction(+ : acc)
+    for (unsigned int i = 0; i < n; i++) { acc += input[i] * taps[i]; }
+    *result = acc;
 }
 #endif
 

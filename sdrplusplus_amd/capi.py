@@ -91,6 +91,10 @@ def load():
     L.sdrpp_set_stream.argtypes = [vp, vp]
     L.sdrpp_sync.argtypes = [vp]
     L.sdrpp_device_info.argtypes = [vp, C.c_char_p, C.c_int]
+    L.sdrpp_abi_version.argtypes = [c_int_p]
+    sz = C.c_int()
+    if L.sdrpp_abi_version(C.byref(sz)) != 1 or sz.value != C.sizeof(VfoDesc):
+        raise ImportError("sdrpp_vfo_desc layout mismatch: library %d bytes, binding %d" % (sz.value, C.sizeof(VfoDesc)))
     for f in (L.sdrpp_design_low_pass, L.sdrpp_design_high_pass):
         f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_float_p, C.c_int]
     L.sdrpp_design_fft_window.argtypes = [C.c_int, C.c_int, c_float_p]
@@ -106,6 +110,7 @@ def load():
     L.sdrpp_fft_set_view.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
     L.sdrpp_fft_lines.argtypes = [vp]
     L.sdrpp_fft_read.argtypes = [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_int32_p]
+    L.sdrpp_fft_copy_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.sdrpp_fft_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p]
     L.sdrpp_vfo_add.argtypes = [vp, C.POINTER(VfoDesc), c_int_p]
     L.sdrpp_vfo_remove.argtypes = [vp, C.c_int]
@@ -129,10 +134,10 @@ def load():
 
 # symbols include/sdrpp_gpu.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
-    "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_device_info",
+    "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view",
-    "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_device_buffers",
+    "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
@@ -263,6 +268,9 @@ class Context:
                                             zo.ctypes.data_as(c_float_p) if zo is not None else None,
                                             ix.ctypes.data_as(c_int32_p) if ix is not None else None))
         return raw_a, zo, ix
+
+    def fft_copy_device(self, first, n, raw_ptr=None, zoomed_ptr=None, index_ptr=None):
+        return self._chk(self.L.sdrpp_fft_copy_device(self.h, first, n, C.c_void_p(raw_ptr), C.c_void_p(zoomed_ptr), C.c_void_p(index_ptr)))
 
     def fft_device_buffers(self):
         raw, zo, ix, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()

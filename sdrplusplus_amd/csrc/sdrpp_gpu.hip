@@ -54,6 +54,7 @@ struct Vfo {
     // integer streaming state
     int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
     int tpp = 0, pphase = 0, poff = 0;
+    long long seen = 0;  // input samples this VFO has consumed since it was added / reset (bounds its view of the IQ history)
     // device constants
     float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
     float* d_bank = nullptr;
@@ -324,6 +325,7 @@ void vfo_free(Vfo& v) {
 int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     v.phi = 0.0;
     v.phi2 = 0.0;
+    v.seen = 0;
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.soff[i] = 0; }
     v.pphase = 0;
     v.poff = 0;
@@ -484,7 +486,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
 }
 
 // ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
-struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; };
+struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; };
 
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
@@ -511,7 +513,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int D = v.d.stage_decim[0];
             const int nout = decim_nout(n_in, v.soff[0], D);
             if (v.modtaps_dirty) { build_modtaps(v); }
-            s1.push_back(S1Member{ &v, v.d.stage_ntaps[0], ilog2(D), v.soff[0], nout, v.phi });
+            const int K0 = v.d.stage_ntaps[0];
+            const int min_idx = (v.seen >= K0 - 1) ? -(K0 - 1) : -(int)v.seen;  // older samples predate this VFO: zero
+            s1.push_back(S1Member{ &v, K0, ilog2(D), v.soff[0], nout, v.phi, min_idx });
             v.soff[0] = v.soff[0] + nout * D - n_in;
             cur->n = nout;
             for (int s = 1; s < v.d.n_stages; s++) {
@@ -569,6 +573,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         double p = v.phi + (double)n_in * v.theta;
         v.phi = p - std::floor(p);
+        v.seen += n_in;
         // history carries for every stream that has a consumer with memory
         for (auto& s : v.st) {
             if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width }); }
@@ -581,6 +586,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (a.lgD != b.lgD) { return a.lgD < b.lgD; }
         if (a.off0 != b.off0) { return a.off0 < b.off0; }
         if (a.nout != b.nout) { return a.nout < b.nout; }
+        if (a.min_idx != b.min_idx) { return a.min_idx < b.min_idx; }
         return a.v->id < b.v->id;
     });
     struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
@@ -590,7 +596,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     size_t i = 0;
     while (i < s1.size()) {
         size_t j = i;
-        while (j < s1.size() && s1[j].K == s1[i].K && s1[j].lgD == s1[i].lgD && s1[j].off0 == s1[i].off0 && s1[j].nout == s1[i].nout) { j++; }
+        while (j < s1.size() && s1[j].K == s1[i].K && s1[j].lgD == s1[i].lgD && s1[j].off0 == s1[i].off0 && s1[j].nout == s1[i].nout && s1[j].min_idx == s1[i].min_idx) { j++; }
         size_t g = i;
         while (g < j) {
             const size_t left = j - g;
@@ -631,6 +637,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             job.log2_decim = s1[g].lgD;
             job.off0 = s1[g].off0;
             job.nout = s1[g].nout;
+            job.min_idx = s1[g].min_idx;
             job.ctaps = d_taps;
             for (int m = 0; m < vt; m++) {
                 Vfo* v = s1[g + m].v;
@@ -768,7 +775,13 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
 }
 
 int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
-    if (count == 0) { return SDRPP_OK; }
+    if (count == 0) {  // an empty block produces nothing (and changes no state)
+        c->n_lines = 0;
+        for (auto& kv : c->vfos) {
+            for (auto& s : kv.second->st) { s.n = 0; }
+        }
+        return SDRPP_OK;
+    }
     int need_hist = 1;
     if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
     for (auto& kv : c->vfos) {
@@ -820,6 +833,11 @@ const char* sdrpp_strerror(int code) {
     case SDRPP_ERR_NOT_FOUND: return "no such VFO";
     default: return "unknown error";
     }
+}
+
+int sdrpp_abi_version(int* sizeof_vfo_desc) {
+    if (sizeof_vfo_desc) { *sizeof_vfo_desc = (int)sizeof(sdrpp_vfo_desc); }
+    return 1;
 }
 
 const char* sdrpp_kernel_family_name(int family) { return (family >= 0 && family < SDRPP_NUM_KERNEL_FAMILIES) ? kFamilyNames[family] : "?"; }
@@ -1020,6 +1038,17 @@ int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, in
     return n;
 }
 
+int sdrpp_fft_copy_device(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
+    if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
+    if (first >= c->n_lines) { return 0; }
+    n = std::min(n, c->n_lines - first);
+    if (raw) { HIPCHK(c, hipMemcpyAsync(raw, c->d_lines + (size_t)first * c->fft_size, (size_t)n * c->fft_size * sizeof(float), hipMemcpyDeviceToDevice, c->stream)); }
+    if ((zoomed || index) && c->data_width <= 0) { return fail(c, SDRPP_ERR_INVALID, "no view configured (sdrpp_fft_set_view)"); }
+    if (zoomed) { HIPCHK(c, hipMemcpyAsync(zoomed, c->d_zoomed + (size_t)first * c->data_width, (size_t)n * c->data_width * sizeof(float), hipMemcpyDeviceToDevice, c->stream)); }
+    if (index) { HIPCHK(c, hipMemcpyAsync(index, c->d_index + (size_t)first * c->data_width, (size_t)n * c->data_width * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream)); }
+    return n;
+}
+
 int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoomed, const int32_t** index, int* n_lines) {
     if (!c) { return SDRPP_ERR_INVALID; }
     if (raw) { *raw = c->d_lines; }
@@ -1206,7 +1235,7 @@ int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out
 // ---- data path --------------------------------------------------------------------------------------------------------------------
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return c ? fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push) : SDRPP_ERR_INVALID; }
-    if (count == 0) { return SDRPP_OK; }
+    if (count == 0) { return push_common(c, nullptr, 0); }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the landing buffer is single: the previous push must have consumed it
     HIPCHK(c, hipMemcpyAsync(c->iq_stage, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     return push_common(c, c->iq_stage, count);
@@ -1219,7 +1248,7 @@ int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
 
 int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
     if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return SDRPP_ERR_INVALID; }
-    if (count == 0) { return SDRPP_OK; }
+    if (count == 0) { return push_common(c, nullptr, 0); }
     if (!c->iq_stage16) {
         int rc = dev_alloc(c, &c->iq_stage16, (size_t)c->max_push * 2);
         if (rc) { return rc; }

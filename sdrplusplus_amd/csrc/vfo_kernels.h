@@ -48,6 +48,8 @@ __device__ __forceinline__ float stream_load1(const StreamIn& s, int i) {
 struct Stage1Job {
     int nv;                  // VFOs handled by this job (<= VT of the launch)
     int ntaps, log2_decim, off0, nout;
+    int min_idx;             // samples before this push-relative index read as zero (a VFO added or reset mid-stream starts
+                             // from an all-zero history: fir.h:24-26 clears the delay line)
     const float2* ctaps;     // [ntaps][VT] modulated taps, VFO index fastest
     double theta[SDRPP_S1_MAX_VT];  // turns per input sample
     double phi0[SDRPP_S1_MAX_VT];   // turns at push-relative sample index 0
@@ -69,7 +71,10 @@ __global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1
     const int pitch = tile + extra + 1;
     const int nsamp = (tile - 1) * D + K;
     const long long base = (long long)job.off0 + (long long)j0 * D - (K - 1);  // push-relative index of tile sample 0
-    for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = iq_load_clamped(src, base + s); }
+    for (int s = threadIdx.x; s < nsamp; s += tile) {
+        const long long gi = base + s;
+        xs[(s & (D - 1)) * pitch + (s >> lgD)] = (gi < job.min_idx) ? make_float2(0.0f, 0.0f) : iq_load_clamped(src, gi);
+    }
     __syncthreads();
     const int j = threadIdx.x;
     float2 acc[VT];

@@ -1,0 +1,55 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libsdrpp_gpu_emu.so")
+REAL_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", "libsdrpp_gpu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """CPU-side artefacts: oracle (+ compiled reference where /root/reference exists), product library (cross-compiled),
+    and the test-only emulator build of the same kernel sources."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")) or os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "all"], check=True)
+    if not os.path.exists(REAL_LIB):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "sdrplusplus_amd", "csrc"), "-s", "all"], check=True)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    _ensure_built()
+
+
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    """'gpu' = the product library on a real device (parity tests proper).  'emu' = the SAME kernel sources compiled
+    against the fiber emulator in tests/emu, run on the CPU: a logic check of indexing/streaming state, never a product
+    path."""
+    from sdrplusplus_amd import capi
+
+    old = os.environ.get("SDRPP_GPU_LIB")
+    if request.param == "emu":
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s"], check=True)
+        os.environ["SDRPP_GPU_LIB"] = EMU_LIB
+    else:
+        os.environ.pop("SDRPP_GPU_LIB", None)
+        assert capi.lib_path() == REAL_LIB
+    yield request.param
+    if old is None:
+        os.environ.pop("SDRPP_GPU_LIB", None)
+    else:
+        os.environ["SDRPP_GPU_LIB"] = old

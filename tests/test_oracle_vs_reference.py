@@ -1,0 +1,128 @@
+"""Pins the oracle (oracle/oracle.c) against the reference's own code compiled in the build container (oracle/_ref):
+every comparison is BIT-EXACT.  Skipped where oracle/_ref was never built (no /root/reference and no prebuilt .so)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.skipif(not S.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def _noise(n, seed, scale=0.1):
+    r = np.random.default_rng(seed)
+    return ((r.standard_normal(n) + 1j * r.standard_normal(n)) * scale).astype(np.complex64)
+
+
+@pytest.mark.parametrize("args", [(75000.0, 7500.0, 250000.0), (6250.0, 625.0, 50000.0), (15000.0, 4000.0, 250000.0), (1400.0, 140.0, 24000.0)])
+def test_low_pass_taps_bit_exact(args):
+    t = S.oracle_low_pass(*args)
+    buf = np.zeros(len(t) + 8, np.float32)
+    n = S.ref().ref_low_pass(*args, 0, S._fp(buf), len(buf))
+    assert n == len(t) and np.array_equal(buf[:n], t)
+
+
+def test_high_pass_and_windows_bit_exact():
+    o, r = S.oracle(), S.ref()
+    a = np.zeros(4096, np.float32)
+    b = np.zeros(4096, np.float32)
+    na = o.orc_high_pass(300.0, 100.0, 48000.0, 0, S._fp(a), 4096)
+    nb = r.ref_high_pass(300.0, 100.0, 48000.0, 0, S._fp(b), 4096)
+    assert na == nb and np.array_equal(a[:na], b[:nb])
+    for n in (0.0, 1.0, 17.5, 4095.0):
+        assert o.orc_nuttall(n, 4096.0) == r.ref_nuttall(n, 4096.0)
+        assert o.orc_blackman(n, 4096.0) == r.ref_blackman(n, 4096.0)
+
+
+CASES = [  # (input rate, mode, offset, block)
+    (10e6, "WFM", 1.35e6, 50000),
+    (2.4e6, "WFM", 300e3, 12000),
+    (61.44e6, "NFM", -3.2e6, 307200),
+    (61.44e6, "AM", 600e3, 307200),
+    (61.44e6, "USB", 1.0014e6, 307200),
+    (61.44e6, "LSB", -7.6786e6, 307200),
+    (61.44e6, "DSB", 2.0e6, 307200),
+]
+
+
+@pytest.mark.parametrize("sr,mode,offset,block", CASES)
+def test_rxvfo_and_demod_bit_exact(sr, mode, offset, block):
+    from sdrplusplus_amd import radio
+
+    if_rate, bw = radio.RADIO_DEFAULTS[mode]
+    oc = S.OracleChain(sr, if_rate, bw, offset, S.MODES[mode])
+    rc = S.RefChain(sr, if_rate, bw, offset, S.MODES[mode])
+    x = _noise(block * 3, 42)
+    t = np.arange(len(x)) / sr
+    x = (x + 0.3 * (1 + 0.3 * np.cos(2 * np.pi * 1000 * t)) * np.exp(2j * np.pi * offset * t)).astype(np.complex64)
+    for b in range(3):
+        blk = x[b * block:(b + 1) * block]
+        oi, oa = oc.process(blk)
+        ri, ra = rc.process(blk)
+        assert np.array_equal(oi, ri), "RxVFO::out differs in block %d" % b
+        assert np.array_equal(oa, ra), "demodulator output differs in block %d" % b
+
+
+def test_retune_mid_stream_bit_exact():
+    oc = S.OracleChain(10e6, 250e3, 150e3, 1.0e6, None)
+    rc = S.RefChain(10e6, 250e3, 150e3, 1.0e6, None)
+    x = _noise(150000, 5)
+    for b, off in enumerate((1.0e6, -2.2e6, 0.3e6)):
+        oc.set_offset(off)
+        rc.set_offset(off)
+        oi, _ = oc.process(x[b * 50000:(b + 1) * 50000])
+        ri, _ = rc.process(x[b * 50000:(b + 1) * 50000])
+        assert np.array_equal(oi, ri)
+
+
+def test_frontend_lines_bit_exact():
+    """IQFrontEnd (threads, Splitter, Reshaper, handler — iq_frontend.cpp verbatim) vs the streaming restatement."""
+    o, r = S.oracle(), S.ref()
+    sr, N = 2.4e6, 4096
+    skip, nz = C.c_int(), C.c_int()
+    o.orc_gen_reshape_params(sr, N, 20.0, C.byref(skip), C.byref(nz))
+    assert (nz.value, skip.value) == (4096, 115904)
+    # The reference's Reshaper hands a frame on only after it has also consumed that frame's `skip` samples
+    # (ring_buffer.h:66-110: read, then skip, then swap); the restatement publishes a line as soon as its nz samples
+    # are in.  Same lines, `skip` samples earlier — so feed whole frame periods here.
+    n = 12000 * 50
+    x = (_noise(n, 9, 0.01) + 0.5 * np.exp(2j * np.pi * 0.125 * np.arange(n))).astype(np.complex64)
+    w = S.oracle_fft_window(2, nz.value)
+    sp = S.OracleSpectrum(N, nz.value, skip.value, w)
+    ol = np.concatenate([sp.push(x[b * 12000:(b + 1) * 12000]) for b in range(50)])
+    fe = r.ref_frontend_create(sr, N, 20.0, 2)
+    got = r.ref_frontend_feed(fe, S._fp(x.view(np.float32)), n, 12000, len(ol), 10000)
+    rl = np.empty((max(got, 1), N), np.float32)
+    got = r.ref_frontend_lines(fe, S._fp(rl), got)
+    r.ref_frontend_destroy(fe)
+    assert got == len(ol) == 5
+    assert np.array_equal(rl[:got], ol)
+
+
+def test_af_resampler_and_deemphasis_bit_exact():
+    """'next' row: RationalResampler 250k -> 48k and Deemphasis (radio_module.h:102-110)."""
+    o, r = S.oracle(), S.ref()
+    x = _noise(25000, 3)
+    oh = o.orc_resampler_create(S.plans_handle(), 250000.0, 48000.0, 2)
+    rh = r.ref_resampler_create(250000.0, 48000.0)
+    info = [C.c_int() for _ in range(6)]
+    o.orc_resampler_info(oh, *[C.byref(v) for v in info])
+    assert [v.value for v in info][1:5] == [4, 96, 125, 9500]  # predec 4, 96/125, 9500 taps
+    for b in range(2):
+        blk = np.ascontiguousarray(x[b * 12500:(b + 1) * 12500])
+        oo = np.empty(len(blk) + 64, np.complex64)
+        ro = np.empty(len(blk) + 64, np.complex64)
+        no = o.orc_resampler_process(oh, len(blk), S._fp(blk.view(np.float32)), S._fp(oo.view(np.float32)))
+        nr = r.ref_resampler_process(rh, len(blk), S._fp(blk.view(np.float32)), S._fp(ro.view(np.float32)))
+        assert no == nr and np.array_equal(oo[:no], ro[:nr])
+    o.orc_resampler_destroy(oh)
+    r.ref_resampler_destroy(rh)
+    od, rd = o.orc_deemp_create(50e-6, 48000.0), r.ref_deemp_create(50e-6, 48000.0)
+    a = np.ascontiguousarray(x[:4800].view(np.float32).reshape(-1, 2))
+    oa, ra = np.empty_like(a), np.empty_like(a)
+    o.orc_deemp_process(od, len(a), S._fp(a), S._fp(oa))
+    r.ref_deemp_process(rd, len(a), S._fp(a), S._fp(ra))
+    assert np.array_equal(oa, ra)
+    o.orc_deemp_destroy(od)
+    r.ref_deemp_destroy(rd)

@@ -1,0 +1,150 @@
+"""FFT -> log-power -> waterfall-line parity: product kernels vs the oracle, BIT-EXACT (raw dB lines, zoomed lines, palette
+indices).  Runs on the real device under `-m gpu` and on the CPU fiber emulator of the same kernel sources otherwise."""
+import numpy as np
+import pytest
+
+import support as S
+
+
+def _ctx(max_push):
+    from sdrplusplus_amd import capi
+
+    return capi.Context(0, max_push=max_push)
+
+
+def _signal(n, seed):
+    r = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = (r.standard_normal(n) + 1j * r.standard_normal(n)) * 0.01 + 0.3 * np.exp(2j * np.pi * 0.1003 * t) + 1e-3 * np.exp(-2j * np.pi * 0.31 * t)
+    return x.astype(np.complex64)
+
+
+def _oracle_view(lines, start, size, width, lo, hi):
+    oz = np.stack([S.oracle_do_zoom(start, size, width, l) for l in lines])
+    oi = np.stack([S.oracle_palette_index(z, lo, hi) for z in oz])
+    return oz, oi
+
+
+@pytest.mark.parametrize("lg", list(range(10, 21)))
+def test_every_fft_size_bit_exact(backend, lg):
+    from sdrplusplus_amd import capi
+
+    N = 1 << lg
+    reps = 3 if lg <= 16 else 1
+    n = N * reps + 5
+    ctx = _ctx(n)
+    w = capi.design_fft_window(2, N)
+    assert np.array_equal(w, S.oracle_fft_window(2, N))
+    ctx.fft_configure(N, N, 0, w)
+    view = (N // 8, N // 2, 733, -110.0, -15.0)
+    ctx.fft_set_view(*view)
+    x = _signal(n, lg)
+    ctx.push(x)
+    raw, zo, ix = ctx.fft_read()
+    ol = S.OracleSpectrum(N, N, 0, w).push(x)
+    assert raw.shape == ol.shape == (reps, N)
+    assert np.array_equal(raw, ol)
+    oz, oi = _oracle_view(ol, *view)
+    assert np.array_equal(zo, oz) and np.array_equal(ix, oi)
+    ctx.close()
+
+
+@pytest.mark.parametrize("window_kind", [0, 1, 2])
+def test_reference_default_framing_streaming(backend, window_kind):
+    """fftRate framing (keep nz, skip the rest) across pushes of awkward sizes, incl. empty and 1-sample pushes."""
+    from sdrplusplus_amd import capi
+
+    sr, N = 2.4e6, 4096
+    nz, skip = capi.design_reshape_params(sr, N, 300.0)
+    assert (nz, skip) == (4096, 3904)
+    w = capi.design_fft_window(window_kind, nz)
+    assert np.array_equal(w, S.oracle_fft_window(window_kind, nz))
+    ctx = _ctx(120000)
+    ctx.fft_configure(N, nz, skip, w)
+    ctx.fft_set_view(0, N, 1024, -120.0, 0.0)
+    sp = S.OracleSpectrum(N, nz, skip, w)
+    x = _signal(240000, 7)
+    pos, total = 0, 0
+    for sz in [12000, 0, 1, 4095, 4096, 30000, 7, 100000, 20000, 3904, 4097]:
+        blk = x[pos:pos + sz]
+        pos += sz
+        ctx.push(blk)
+        raw, zo, ix = ctx.fft_read()
+        ol = sp.push(blk) if sz else np.empty((0, N), np.float32)
+        assert raw.shape == ol.shape, (sz, raw.shape, ol.shape)
+        if len(ol):
+            assert np.array_equal(raw, ol)
+            oz, oi = _oracle_view(ol, 0, N, 1024, -120.0, 0.0)
+            assert np.array_equal(zo, oz) and np.array_equal(ix, oi)
+        total += len(ol)
+    assert total == (pos - nz) // (nz + skip) + 1
+    ctx.close()
+
+
+def test_zero_padded_frames_and_reconfigure(backend):
+    """interval < fft size: nz < N inputs, the rest of the FFT input is zero (iq_frontend.cpp:301)."""
+    from sdrplusplus_amd import capi
+
+    ctx = _ctx(40000)
+    x = _signal(80000, 9)
+    for (sr, N, rate) in [(1e6, 4096, 400.0), (1e6, 65536, 20.0), (2.4e6, 1024, 20.0)]:
+        nz, skip = capi.design_reshape_params(sr, N, rate)
+        w = capi.design_fft_window(2, nz)
+        ctx.fft_configure(N, nz, skip, w)  # reconfigure restarts the framing, like updateFFTPath
+        sp = S.OracleSpectrum(N, nz, skip, w)
+        pos = 0
+        for sz in [2499, 1, 40000, 12345, 25000]:
+            blk = x[pos:pos + sz]
+            pos += sz
+            ctx.push(blk)
+            raw, _, _ = ctx.fft_read(zoomed=False)
+            ol = sp.push(blk)
+            assert raw.shape == ol.shape and np.array_equal(raw, ol), (N, nz, skip, sz)
+    ctx.close()
+
+
+def test_view_changes_and_extreme_inputs(backend):
+    from sdrplusplus_amd import capi
+
+    N = 8192
+    ctx = _ctx(N)
+    w = capi.design_fft_window(2, N)
+    ctx.fft_configure(N, N, 0, w)
+    cases = {
+        "zeros": np.zeros(N, np.complex64),  # -> VOLK's clamped log2: -127 * 3.0103 dB in every bin
+        "dc": np.full(N, 1.0 + 0.0j, np.complex64),
+        "tiny": (_signal(N, 1) * 1e-30).astype(np.complex64),  # denormal powers
+        "huge": (_signal(N, 2) * 1e15).astype(np.complex64),
+    }
+    views = [(0, N, 600, -120.0, 0.0), (N // 2 - 50, 100, 1024, -70.0, 0.0), (-7, N, 333, -200.0, 50.0), (N - 40, 300, 64, -120.0, 0.0)]
+    for name, x in cases.items():
+        for view in views:
+            start, size = capi.design_waterfall_view(0.0, 1.0, 1.0, N) if view[0] == 0 else (view[0], view[1])
+            ctx.fft_set_view(start, size, view[2], view[3], view[4])
+            ctx.push(x)
+            raw, zo, ix = ctx.fft_read()
+            ol = S.OracleSpectrum(N, N, 0, w).push(x)
+            assert np.array_equal(raw, ol), name
+            oz, oi = _oracle_view(ol, start, size, view[2], view[3], view[4])
+            assert np.array_equal(zo, oz, equal_nan=True) and np.array_equal(ix, oi), (name, view)
+    ctx.close()
+
+
+def test_int16_ingest_matches_file_source_conversion(backend):
+    """cfg 1 input format: int16 IQ converted on the device exactly like volk_16i_s32f_convert_32f(.., 32768)."""
+    from sdrplusplus_amd import capi, workloads
+
+    x = workloads.synth(1, 24000, seed=1)
+    i16 = workloads.to_int16_wav_samples(x)
+    xf = np.empty(len(i16), np.float32)
+    S.oracle().orc_int16_to_float(i16.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int16)), S._fp(xf), len(i16))
+    xc = xf.view(np.complex64)
+    nz, skip = capi.design_reshape_params(2.4e6, 4096, 200.0)
+    w = capi.design_fft_window(2, nz)
+    ctx = _ctx(24000)
+    ctx.fft_configure(4096, nz, skip, w)
+    ctx.push_int16(i16)
+    raw, _, _ = ctx.fft_read(zoomed=False)
+    ol = S.OracleSpectrum(4096, nz, skip, w).push(xc)
+    assert len(ol) == 2 and np.array_equal(raw, ol)
+    ctx.close()
