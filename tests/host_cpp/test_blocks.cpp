@@ -1,0 +1,87 @@
+// Drives the C++ host mirror (sdrplusplus_amd/host/sdrpp_gpu_blocks.h) the way SDR++ drives IQFrontEnd: a source thread
+// swap()s IQ blocks into a dsp::stream, the front end delivers dB lines through acquire/release callbacks and per-VFO blocks
+// on dsp::streams read by sink threads.  Outputs are written to files and compared with the oracle by tests/test_host_cpp.py.
+//   usage: test_blocks <plans.bin> <iq.f32> <sample_rate> <block> <fft_size> <fft_rate> <outdir>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../sdrplusplus_amd/host/sdrpp_gpu_blocks.h"
+
+struct LineSink {
+    int fftSize;
+    std::vector<float> cur;
+    std::vector<float> all;
+    int acquired = 0, released = 0;
+};
+static float* acquire(void* c) { LineSink* s = (LineSink*)c; s->acquired++; s->cur.assign((size_t)s->fftSize, 0.0f); return s->cur.data(); }
+static void release(void* c) { LineSink* s = (LineSink*)c; s->released++; s->all.insert(s->all.end(), s->cur.begin(), s->cur.end()); }
+
+template <class T>
+static void drain(dsp::stream<T>* st, std::vector<float>* dst) {
+    while (true) {
+        int n = st->read();
+        if (n < 0) { break; }
+        const float* p = (const float*)st->readBuf;
+        dst->insert(dst->end(), p, p + 2 * (size_t)n);
+        st->flush();
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 8) { fprintf(stderr, "usage\n"); return 2; }
+    sdrpp_gpu::DecimPlans plans;
+    if (!plans.load(argv[1])) { fprintf(stderr, "cannot load plans\n"); return 1; }
+    std::ifstream f(argv[2], std::ios::binary | std::ios::ate);
+    const size_t bytes = (size_t)f.tellg();
+    f.seekg(0);
+    std::vector<float> iq(bytes / 4);
+    f.read((char*)iq.data(), (std::streamsize)bytes);
+    const double sr = atof(argv[3]);
+    const int block = atoi(argv[4]), fftSize = atoi(argv[5]);
+    const double fftRate = atof(argv[6]);
+    const std::string outdir = argv[7];
+    const size_t nsamp = iq.size() / 2;
+
+    dsp::stream<dsp::complex_t> src;
+    LineSink lines{ fftSize };
+    sdrpp_gpu::IQFrontEnd fe;
+    fe.init(&src, sr, false, 1, false, fftSize, fftRate, sdrpp_gpu::IQFrontEnd::NUTTALL, acquire, release, &lines, 0, &plans);
+    sdrpp_gpu::RxVFO* raw = fe.addVFO("raw", 250000.0, 150000.0, sr / 8);
+    sdrpp_gpu::RxVFO* wfm = fe.addVFO("radio", 250000.0, 150000.0, 300000.0);
+    if (!raw || !wfm) { return 1; }
+    wfm->attachDemod(sdrpp_gpu::Demod::WFM);
+    if (fe.addVFO("raw", 1.0, 1.0, 0.0) != nullptr) { fprintf(stderr, "duplicate VFO name accepted\n"); return 1; }
+    fe.removeVFO("nope");  // logs, like the reference
+
+    std::vector<float> ifOut, audioOut;
+    std::thread t1(drain<dsp::complex_t>, &raw->out, &ifOut);
+    std::thread t2(drain<dsp::stereo_t>, &wfm->audio, &audioOut);
+    fe.start();
+    size_t pos = 0;
+    int blk = 0;
+    while (pos + (size_t)block <= nsamp) {
+        memcpy(src.writeBuf, &iq[2 * pos], sizeof(float) * 2 * (size_t)block);
+        if (!src.swap(block)) { break; }
+        pos += (size_t)block;
+        blk++;
+        if (blk == 3) { raw->setOffset(-sr / 4); }  // retune while running (phase-continuous)
+    }
+    // let the last block drain: a final empty swap is not part of the reference protocol, so wait on the line/audio counts instead
+    std::this_thread::sleep_for(std::chrono::milliseconds(300));
+    fe.stop();
+    raw->out.stopReader();
+    wfm->audio.stopReader();
+    t1.join();
+    t2.join();
+    auto dump = [&](const char* name, const std::vector<float>& v) {
+        std::ofstream o(outdir + "/" + name, std::ios::binary);
+        o.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));
+    };
+    dump("lines.f32", lines.all);
+    dump("if.f32", ifOut);
+    dump("audio.f32", audioOut);
+    printf("blocks %d lines %d (acquire %d release %d) if %zu audio %zu\n", blk, (int)(lines.all.size() / (size_t)fftSize), lines.acquired, lines.released, ifOut.size() / 2, audioOut.size() / 2);
+    return (lines.acquired == lines.released) ? 0 : 1;
+}
