@@ -56,8 +56,12 @@ struct Vfo {
     int tpp = 0, pphase = 0, poff = 0;
     long long seen = 0;  // input samples this VFO has consumed since it was added / reset (bounds its view of the IQ history)
     // device constants
-    float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+    float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };  // phase-major, padded (FirBJob)
+    int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
     float* d_bank = nullptr;
+    float* d_cyc = nullptr;  // blocked polyphase: [interp][rows][lmax] cycle tap tables (one per carried phase)
+    int cyc_rows = 0, cyc_lmax = 0;
+    int chan_kp = 0, audio_kp = 0;
     float* d_chan = nullptr;
     int chan_ntaps = 0;
     float* d_audio = nullptr;
@@ -298,6 +302,21 @@ int ensure_iq_hist(sdrpp_ctx* c, int need) {
 }
 
 // ---- VFO helpers -------------------------------------------------------------------------------------------------------------
+// Phase-major, zero-padded tap layout of the register-blocked FIR kernel: t[p][q] = h[D*q + p], q < kp (multiple of R).
+std::vector<float> blocked_taps(const float* h, int K, int D, int* kp_out) {
+    const int R = SDRPP_FIR_R;
+    const int per = (K + D - 1) / D;
+    const int kp = ((per + R - 1) / R) * R;
+    std::vector<float> t((size_t)D * kp, 0.0f);
+    for (int k = 0; k < K; k++) { t[(size_t)(k % D) * kp + (size_t)(k / D)] = h[k]; }
+    *kp_out = kp;
+    return t;
+}
+int upload_blocked(sdrpp_ctx* c, float** dst, const float* h, int K, int D, int* kp) {
+    std::vector<float> t = blocked_taps(h, K, D, kp);
+    return upload(c, dst, t.data(), t.size());
+}
+
 void build_modtaps(Vfo& v) {
     const int K = v.d.stage_ntaps[0];
     v.modtaps.resize((size_t)K);
@@ -315,6 +334,7 @@ void build_modtaps(Vfo& v) {
 void vfo_free(Vfo& v) {
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { dev_free(v.d_staps[i]); }
     dev_free(v.d_bank);
+    dev_free(v.d_cyc);
     dev_free(v.d_chan);
     dev_free(v.d_audio);
     dev_free(v.d_state);
@@ -493,12 +513,13 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     const int n_in = (int)count;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;
-    std::vector<FirJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 1..3 used
+    std::vector<FirBJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 1..3 used
     std::vector<PolyJob> poly;
-    std::vector<FirJob> chan;
+    std::vector<PolyBJob> polyb[2];  // [0]: LMAX 4, [1]: LMAX 8
+    std::vector<FirBJob> chan;
     std::vector<QuadJob> quad;
     std::vector<SeqJob> seq;
-    std::vector<FirJob> audio;
+    std::vector<FirBJob> audio;
     int max_rot = 0;
 
     for (auto& kv : c->vfos) {
@@ -522,7 +543,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 Stream* nxt = &v.st[(size_t)v.i_first + s];
                 const int Ds = v.d.stage_decim[s];
                 const int no = decim_nout(cur->n, v.soff[s], Ds);
-                lvl[s].push_back(FirJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no });
+                lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] });
                 v.soff[s] = v.soff[s] + no * Ds - cur->n;
                 nxt->n = no;
                 cur = nxt;
@@ -531,7 +552,13 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (v.i_poly >= 0) {
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
-            poly.push_back(PolyJob{ stream_in(*cur), (float2*)nxt->data, v.d_bank, v.d.interp, v.d.decim, v.tpp, v.pphase, v.poff, no });
+            if (v.d_cyc) {
+                polyb[v.cyc_lmax == 4 ? 0 : 1].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
+                                                                  v.tpp, v.poff, no, v.cyc_rows });
+            }
+            else {
+                poly.push_back(PolyJob{ stream_in(*cur), (float2*)nxt->data, v.d_bank, v.d.interp, v.d.decim, v.tpp, v.pphase, v.poff, no });
+            }
             const long long A = (long long)v.pphase + (long long)no * v.d.decim;
             v.pphase = (int)(A % v.d.interp);
             v.poff = v.poff + (int)(A / v.d.interp) - cur->n;
@@ -540,7 +567,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            chan.push_back(FirJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n });
+            chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp });
             nxt->n = cur->n;
             cur = nxt;
         }
@@ -553,7 +580,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream& out = v.st[(size_t)v.i_out];
             quad.push_back(QuadJob{ stream_in(*cur), dem.data, v.d.inv_deviation, nif });
             dem.n = nif;
-            audio.push_back(FirJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif });
+            audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp });
             out.n = nif;
         }
         else if (v.d.demod == SDRPP_DEMOD_AM) {
@@ -561,7 +588,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream& out = v.st[(size_t)v.i_out];
             seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, 0.0, 0.0 });
             dem.n = nif;
-            audio.push_back(FirJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif });
+            audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp });
             out.n = nif;
         }
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
@@ -666,14 +693,16 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
     }
     RotJob* d_rot = arena_push(c, rot);
-    FirJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
+    FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
     PolyJob* d_poly = arena_push(c, poly);
-    FirJob* d_chan = arena_push(c, chan);
+    PolyBJob* d_polyb[2] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]) };
+    FirBJob* d_chan = arena_push(c, chan);
     QuadJob* d_quad = arena_push(c, quad);
     SeqJob* d_seq = arena_push(c, seq);
-    FirJob* d_audio = arena_push(c, audio);
+    FirBJob* d_audio = arena_push(c, audio);
     CarryJob* d_carry = arena_push(c, carry);
+    if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!quad.empty() && !d_quad) || (!seq.empty() && !d_seq) ||
         (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
@@ -702,22 +731,26 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
         }
     }
-    auto launch_fir = [&](std::vector<FirJob>& jobs, FirJob* d_jobs, int width, bool stereo) -> int {
+    auto launch_fir = [&](std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo) -> int {
         if (jobs.empty()) { return SDRPP_OK; }
-        int max_nout = 0, tile = 256;
+        const int R = SDRPP_FIR_R;
+        int max_nout = 0, threads = 256;
+        auto lds_for = [&](const FirBJob& jb, int nt) { return (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * width * 4; };
         for (auto& jb : jobs) {
             max_nout = std::max(max_nout, jb.nout);
-            const int t = pick_tile(1 << jb.log2_decim, jb.ntaps, width * 4);
-            if (t == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
-            tile = std::min(tile, t);
+            int nt = 256;
+            while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
+            if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+            threads = std::min(threads, nt);
         }
         if (max_nout == 0) { return SDRPP_OK; }
         size_t lds = 0;
-        for (auto& jb : jobs) { lds = std::max(lds, fir_lds(tile, 1 << jb.log2_decim, jb.ntaps, width * 4)); }
+        for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
+        const int tile = threads * R;
         const dim3 grid((max_nout + tile - 1) / tile, (unsigned)jobs.size());
-        if (width == 2) { launch(c, vfo_fir_kernel<2, false>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
-        else if (stereo) { launch(c, vfo_fir_kernel<1, true>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
-        else { launch(c, vfo_fir_kernel<1, false>, grid, dim3(tile), lds, (const FirJob*)d_jobs); }
+        if (width == 2) { launch(c, vfo_firb_kernel<2, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
+        else if (stereo) { launch(c, vfo_firb_kernel<1, true>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
+        else { launch(c, vfo_firb_kernel<1, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         return SDRPP_OK;
     };
     {
@@ -739,6 +772,25 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
         if (max_nout > 0) { launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)poly.size()), dim3(tile), lds, (const PolyJob*)d_poly); }
+    }
+    for (int li = 0; li < 2; li++) {
+        if (polyb[li].empty()) { continue; }
+        FamilyTimer t(c, F_POLY);
+        int max_cycles = 0, threads = 256;
+        size_t lds = 0;
+        auto lds_for = [&](const PolyBJob& jb, int nt) { return (size_t)jb.decim * (size_t)(nt + jb.rows / jb.decim + 2) * sizeof(float2); };
+        for (auto& jb : polyb[li]) {
+            max_cycles = std::max(max_cycles, (jb.nout + jb.interp - 1) / jb.interp);
+            int nt = 256;
+            while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
+            if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
+            threads = std::min(threads, nt);
+        }
+        for (auto& jb : polyb[li]) { lds = std::max(lds, lds_for(jb, threads)); }
+        if (max_cycles == 0) { continue; }
+        const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)polyb[li].size());
+        if (li == 0) { launch(c, vfo_polyb_kernel<4>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[0]); }
+        else { launch(c, vfo_polyb_kernel<8>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[1]); }
     }
     {
         FamilyTimer t(c, F_FIR);
@@ -1091,7 +1143,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     for (int s = 0; s < d->n_stages; s++) {
         v->staps[s].assign(d->stage_taps[s], d->stage_taps[s] + d->stage_ntaps[s]);
         v->d.stage_taps[s] = nullptr;
-        rc = upload(c, &v->d_staps[s], v->staps[s].data(), v->staps[s].size());
+        rc = upload_blocked(c, &v->d_staps[s], v->staps[s].data(), (int)v->staps[s].size(), d->stage_decim[s], &v->s_kp[s]);
         if (rc) { return rc; }
         cap = cap / (size_t)d->stage_decim[s] + 2;
         const int hist = (s + 1 < d->n_stages) ? d->stage_ntaps[s + 1] - 1 : hist_after_decim();
@@ -1110,6 +1162,20 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         for (int i = 0; i < tot; i++) { bank[(size_t)((d->interp - 1) - (i % d->interp)) * tpp + (size_t)(i / d->interp)] = (i < d->resamp_ntaps) ? v->rtaps[(size_t)i] : 0.0f; }  // polyphase_bank.h:31-34
         rc = upload(c, &v->d_bank, bank.data(), bank.size());
         if (rc) { return rc; }
+        if (d->interp <= 8) {  // register-blocked kernel: per carried phase, taps of one full phase cycle
+            const int L = d->interp, M = d->decim, lmax = (L <= 4) ? 4 : 8, rows = tpp + M;
+            std::vector<float> cyc((size_t)L * rows * lmax, 0.0f);
+            for (int ph0 = 0; ph0 < L; ph0++) {
+                for (int r = 0; r < L; r++) {
+                    const int A = ph0 + r * M, ph = A % L, o = A / L;
+                    for (int k = 0; k < tpp; k++) { cyc[((size_t)ph0 * rows + (size_t)(k + o)) * lmax + r] = bank[(size_t)ph * tpp + k]; }
+                }
+            }
+            rc = upload(c, &v->d_cyc, cyc.data(), cyc.size());
+            if (rc) { return rc; }
+            v->cyc_rows = rows;
+            v->cyc_lmax = lmax;
+        }
         cap = cap * (size_t)d->interp / (size_t)d->decim + 4;
         v->i_poly = add_stream(2, kChanHistCap, cap);
         if (v->i_poly < 0) { return SDRPP_ERR_NOMEM; }
@@ -1120,7 +1186,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     if (d->chan_ntaps > 0) {
         if (!d->chan_taps) { return fail(c, SDRPP_ERR_INVALID, "chan_taps null"); }
         v->ctaps_chan.assign(d->chan_taps, d->chan_taps + d->chan_ntaps);
-        rc = upload(c, &v->d_chan, v->ctaps_chan.data(), v->ctaps_chan.size());
+        rc = upload_blocked(c, &v->d_chan, v->ctaps_chan.data(), (int)v->ctaps_chan.size(), 1, &v->chan_kp);
         if (rc) { return rc; }
         v->chan_ntaps = d->chan_ntaps;
     }
@@ -1133,7 +1199,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             if (d->audio_ntaps > 0 && !d->audio_taps) { return fail(c, SDRPP_ERR_INVALID, "audio_taps null"); }
             v->ataps.assign(at, at + an);
             v->audio_ntaps = an;
-            rc = upload(c, &v->d_audio, v->ataps.data(), v->ataps.size());
+            rc = upload_blocked(c, &v->d_audio, v->ataps.data(), (int)v->ataps.size(), 1, &v->audio_kp);
             if (rc) { return rc; }
             v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
             if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
@@ -1188,7 +1254,7 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     v.ctaps_chan.assign(taps, taps + n);
     v.chan_ntaps = n;
     v.d.chan_ntaps = n;
-    if (n > 0) { return upload(c, &v.d_chan, v.ctaps_chan.data(), v.ctaps_chan.size()); }
+    if (n > 0) { return upload_blocked(c, &v.d_chan, v.ctaps_chan.data(), n, 1, &v.chan_kp); }
     return SDRPP_OK;
 }
 

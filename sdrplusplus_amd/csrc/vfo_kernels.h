@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <sdrpp_gfx950.h>
 #include "fft_kernels.h"
 
@@ -393,6 +394,149 @@ __global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__
         const int i = e / job.width, c = e % job.width;
         const long long s = (long long)job.n + i;  // index into old_hist ++ data
         job.new_hist[e] = (s < job.hist_len) ? job.old_hist[s * job.width + c] : job.data[(s - job.hist_len) * job.width + c];
+    }
+}
+
+
+// =====================================================================================================================
+// Register-blocked kernels (round-1 optimisation of the measured bottleneck).
+//
+// The generic FIR above issues one ds_read per two FMAs and is LDS-bound at ~10 TFLOP/s.  Here every work-item computes
+// R = 8 consecutive outputs with a circular window of R registers: each input sample is read from LDS once and used for
+// R outputs (R*R FMAs per R reads), taps are wave-uniform and arrive through scalar loads, R at a time.
+//
+// Decimation by D is handled as D ordinary FIRs over the polyphase components c_p[i] = x[base + D*i + p] with taps
+// h_p[q] = h[D*q + p] (host lays them out phase-major, zero-padded to a multiple of R):
+//      out[j] = sum_p sum_q h_p[q] * c_p[j + q]
+// LDS image: component p, element e (tile-relative) at [p][e mod R][e div R]; work-item t reads elements t*R + m, i.e.
+// [p][m mod R][t + m div R] — consecutive lanes, consecutive addresses.
+// =====================================================================================================================
+#define SDRPP_FIR_R 8
+struct FirBJob {
+    StreamIn in;
+    float* out;
+    const float* taps;  // [D][kp_pad], phase-major, zero padded
+    int ntaps, log2_decim, off0, nout, kp_pad;
+};
+
+template <int WIDTH, bool STEREO>
+__global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict__ jobs) {
+    constexpr int R = SDRPP_FIR_R;
+    HIP_DYNAMIC_SHARED(float, smem)
+    const FirBJob& job = jobs[blockIdx.y];
+    const int nthreads = blockDim.x;
+    const int tile = nthreads * R;
+    const int j0 = blockIdx.x * tile;
+    if (j0 >= job.nout) { return; }
+    const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD, kp = job.kp_pad;
+    const int P1 = nthreads + kp / R + 1;  // columns per (phase, residue) row
+    const int P2 = R * P1;
+    // component elements needed per phase: tile + kp - 1 (+R-1 preload slack) -> all inside R * P1
+    const int ncomp = R * P1;
+    const int base = job.off0 + j0 * D - (K - 1);  // stream index of component 0, element 0
+    const int nvalid = (tile - 1) * D + K;         // samples a full tile really needs; the rest is zero-filled
+    typedef typename std::conditional<WIDTH == 2, float2, float>::type T;
+    T* xs = reinterpret_cast<T*>(smem);
+    for (int s = threadIdx.x; s < ncomp * D; s += nthreads) {
+        const int p = s & (D - 1), e = s >> lgD;
+        T v;
+        if constexpr (WIDTH == 2) { v = (s < nvalid) ? stream_load2(job.in, base + s) : make_float2(0.0f, 0.0f); }
+        else { v = (s < nvalid) ? stream_load1(job.in, base + s) : 0.0f; }
+        xs[p * P2 + (e & (R - 1)) * P1 + (e >> 3)] = v;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const UniformF32 taps = as_uniform(job.taps);
+    T acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if constexpr (WIDTH == 2) { acc[r] = make_float2(0.0f, 0.0f); }
+        else { acc[r] = 0.0f; }
+    }
+    for (int p = 0; p < D; p++) {
+        const T* xp = xs + p * P2 + t;
+        T w[R];
+#pragma unroll
+        for (int m = 0; m < R - 1; m++) { w[m] = xp[m * P1]; }  // elements 0 .. R-2 (m div R == 0)
+        for (int q0 = 0; q0 < kp; q0 += R) {
+            const int col = (q0 >> 3);
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                // element m = q0 + u + R - 1 -> residue (u - 1) mod R, column col + (u >= 1)
+                const int res = (u + R - 1) & (R - 1);
+                w[res] = xp[res * P1 + col + (u >= 1 ? 1 : 0)];
+                const float h = taps[p * kp + q0 + u];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const T x = w[(u + r) & (R - 1)];
+                    if constexpr (WIDTH == 2) {
+                        acc[r].x = fmaf(h, x.x, acc[r].x);
+                        acc[r].y = fmaf(h, x.y, acc[r].y);
+                    }
+                    else { acc[r] = fmaf(h, x, acc[r]); }
+                }
+            }
+        }
+    }
+    const int jo = j0 + t * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (jo + r < job.nout) {
+            if constexpr (WIDTH == 2) { reinterpret_cast<float2*>(job.out)[jo + r] = acc[r]; }
+            else if constexpr (STEREO) { reinterpret_cast<float2*>(job.out)[jo + r] = make_float2(acc[r], acc[r]); }
+            else { job.out[jo + r] = acc[r]; }
+        }
+    }
+}
+
+// Polyphase resampler, register-blocked over one full phase cycle per work-item: outputs n = c*L + r (r = 0..L-1) of cycle c
+// use phases (phase0 + r*M) mod L and input offsets c*M + o_r, o_r = (phase0 + r*M) div L — the SAME (phase, o_r) pattern for
+// every cycle, so the taps are wave-uniform.  The host tabulates, for every phase0, cyc[m][r] = bank[phase_r][m - o_r] (0
+// outside the filter), m = 0 .. tpp + M - 1; a work-item walks its tpp + M inputs once, doing LMAX FMAs (complex: 2x) per read.
+struct PolyBJob {
+    StreamIn in;
+    float2* out;
+    const float* cyc;  // [rows][LMAX] for this push's phase0
+    int interp, decim, tpp, off0, nout, rows;
+};
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void vfo_polyb_kernel(const PolyBJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, xs)
+    const PolyBJob& job = jobs[blockIdx.y];
+    const int nthreads = blockDim.x;
+    const int L = job.interp, M = job.decim, rows = job.rows;
+    const int c0 = blockIdx.x * nthreads;  // first cycle of this block
+    if (c0 * L >= job.nout) { return; }
+    const int P1 = nthreads + rows / M + 2;  // columns per residue row
+    const int first = job.off0 + c0 * M - (job.tpp - 1);
+    const int need = (nthreads - 1) * M + rows;
+    for (int s = threadIdx.x; s < M * P1; s += nthreads) {
+        // element s of the tile lives at [s mod M][s div M]
+        const float2 v = (s < need) ? stream_load2(job.in, first + s) : make_float2(0.0f, 0.0f);
+        xs[(s % M) * P1 + (s / M)] = v;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const UniformF32 cyc = as_uniform(job.cyc);
+    float2 acc[LMAX];
+#pragma unroll
+    for (int r = 0; r < LMAX; r++) { acc[r] = make_float2(0.0f, 0.0f); }
+    int res = 0, col = t;  // element t*M + m -> residue m mod M, column t + m div M
+    for (int m = 0; m < rows; m++) {
+        const float2 x = xs[res * P1 + col];
+#pragma unroll
+        for (int r = 0; r < LMAX; r++) {
+            const float h = cyc[m * LMAX + r];
+            acc[r].x = fmaf(h, x.x, acc[r].x);
+            acc[r].y = fmaf(h, x.y, acc[r].y);
+        }
+        if (++res == M) { res = 0; col++; }
+    }
+    const int n0 = (c0 + t) * L;
+#pragma unroll
+    for (int r = 0; r < LMAX; r++) {
+        if (r < L && n0 + r < job.nout) { job.out[n0 + r] = acc[r]; }
     }
 }
 
