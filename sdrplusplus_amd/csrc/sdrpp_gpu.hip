@@ -57,6 +57,7 @@ struct Vfo {
     long long seen = 0;  // input samples this VFO has consumed since it was added / reset (bounds its view of the IQ history)
     // device constants
     float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };  // phase-major, padded (FirBJob)
+    float* d_staps_nat[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };  // natural order (fused front kernel)
     int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
     float* d_bank = nullptr;
     float* d_cyc = nullptr;  // blocked polyphase: [interp][rows][lmax] cycle tap tables (one per carried phase)
@@ -318,21 +319,25 @@ int upload_blocked(sdrpp_ctx* c, float** dst, const float* h, int K, int D, int*
 }
 
 void build_modtaps(Vfo& v) {
+    // g[k] = h[k] * exp(j*2*pi*(k - kc)*theta), kc = (K-1)/2, for the first (K+1)/2 taps; the other half is the conjugate
+    // mirror (stage1_accumulate).  An odd K has a real centre tap.
     const int K = v.d.stage_ntaps[0];
-    v.modtaps.resize((size_t)K);
+    const int npairs = (K + 1) / 2;
+    v.modtaps.resize((size_t)npairs);
     const double kc = 0.5 * (double)(K - 1);
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < npairs; k++) {
         double t = ((double)k - kc) * v.theta;
         t -= std::rint(t);
         const double a = 2.0 * 3.14159265358979323846 * t;
         const double h = (double)v.staps[0][(size_t)k];
         v.modtaps[(size_t)k] = make_float2((float)(h * std::cos(a)), (float)(h * std::sin(a)));
     }
+    if (K & 1) { v.modtaps[(size_t)npairs - 1] = make_float2(v.staps[0][(size_t)npairs - 1], 0.0f); }
     v.modtaps_dirty = false;
 }
 
 void vfo_free(Vfo& v) {
-    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { dev_free(v.d_staps[i]); }
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { dev_free(v.d_staps[i]); dev_free(v.d_staps_nat[i]); }
     dev_free(v.d_bank);
     dev_free(v.d_cyc);
     dev_free(v.d_chan);
@@ -506,7 +511,19 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
 }
 
 // ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
-struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; };
+struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; };
+
+// Stage-2 outputs per block of the fused front kernel (0 = do not fuse: the recomputed overlap would dominate or LDS would overflow).
+int front2_t2(int K1, int D1, int K2, int D2, int vt) {
+    const int tile = 256;
+    if (K2 >= tile) { return 0; }
+    const int t2 = (tile - K2) / D2 + 1;
+    if (t2 * D2 * 4 < tile * 3) { return 0; }  // more than 25 % of the stage-1 work would be recomputed overlap
+    if (D2 < 2) { return 0; }
+    const size_t lds = ((size_t)D1 * (tile + (K1 - 1 + D1 - 1) / D1 + 1) + (size_t)vt * (tile + 16) + (size_t)vt) * sizeof(float2);
+    return lds <= (size_t)kMaxLds ? t2 : 0;
+}
+
 
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
@@ -515,7 +532,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<RotJob> rot;
     std::vector<FirBJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 1..3 used
     std::vector<PolyJob> poly;
-    std::vector<PolyBJob> polyb[2];  // [0]: LMAX 4, [1]: LMAX 8
+    std::vector<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
     std::vector<FirBJob> chan;
     std::vector<QuadJob> quad;
     std::vector<SeqJob> seq;
@@ -535,11 +552,31 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int nout = decim_nout(n_in, v.soff[0], D);
             if (v.modtaps_dirty) { build_modtaps(v); }
             const int K0 = v.d.stage_ntaps[0];
-            const int min_idx = (v.seen >= K0 - 1) ? -(K0 - 1) : -(int)v.seen;  // older samples predate this VFO: zero
-            s1.push_back(S1Member{ &v, K0, ilog2(D), v.soff[0], nout, v.phi, min_idx });
+            S1Member mem{ &v, K0, ilog2(D), v.soff[0], nout, v.phi, 0, 0, 0, 0, 0, 0 };
+            int need = K0 - 1;
+            int first_sep = 1;  // first stage that runs as its own FIR launch
+            if (v.d.n_stages >= 2 && front2_t2(K0, D, v.d.stage_ntaps[1], v.d.stage_decim[1], 8) > 0) {
+                const int D2 = v.d.stage_decim[1];
+                mem.fused = 1;
+                mem.K2 = v.d.stage_ntaps[1];
+                mem.lgD2 = ilog2(D2);
+                mem.off2 = v.soff[1];
+                mem.nout2 = decim_nout(nout, v.soff[1], D2);
+                need = K0 - 1 + D * (mem.K2 - 1);
+                first_sep = 2;
+            }
+            mem.min_idx = (v.seen >= need) ? -need : -(int)v.seen;  // older samples predate this VFO: zero
+            s1.push_back(mem);
             v.soff[0] = v.soff[0] + nout * D - n_in;
             cur->n = nout;
-            for (int s = 1; s < v.d.n_stages; s++) {
+            if (mem.fused) {
+                Stream* nxt = &v.st[(size_t)v.i_first + 1];
+                v.soff[1] = v.soff[1] + mem.nout2 * v.d.stage_decim[1] - nout;
+                cur->n = 0;  // the stage-1 stream is never materialised
+                nxt->n = mem.nout2;
+                cur = nxt;
+            }
+            for (int s = first_sep; s < v.d.n_stages; s++) {
                 Stream* nxt = &v.st[(size_t)v.i_first + s];
                 const int Ds = v.d.stage_decim[s];
                 const int no = decim_nout(cur->n, v.soff[s], Ds);
@@ -553,7 +590,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
             if (v.d_cyc) {
-                polyb[v.cyc_lmax == 4 ? 0 : 1].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
+                polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
             }
             else {
@@ -607,23 +644,34 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
     }
 
-    // ---- stage 1: group VFOs with identical geometry, VT per job ----
+    // ---- stage 1 (optionally fused with stage 2): group VFOs with identical geometry, VT per job ----
+    auto same = [](const S1Member& a, const S1Member& b) {
+        return a.fused == b.fused && a.K == b.K && a.lgD == b.lgD && a.off0 == b.off0 && a.nout == b.nout && a.min_idx == b.min_idx && a.K2 == b.K2 &&
+               a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2;
+    };
     std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
+        if (a.fused != b.fused) { return a.fused < b.fused; }
         if (a.K != b.K) { return a.K < b.K; }
         if (a.lgD != b.lgD) { return a.lgD < b.lgD; }
         if (a.off0 != b.off0) { return a.off0 < b.off0; }
         if (a.nout != b.nout) { return a.nout < b.nout; }
         if (a.min_idx != b.min_idx) { return a.min_idx < b.min_idx; }
+        if (a.K2 != b.K2) { return a.K2 < b.K2; }
+        if (a.lgD2 != b.lgD2) { return a.lgD2 < b.lgD2; }
+        if (a.off2 != b.off2) { return a.off2 < b.off2; }
+        if (a.nout2 != b.nout2) { return a.nout2 < b.nout2; }
         return a.v->id < b.v->id;
     });
     struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
+    struct F2Launch { int vt; std::vector<Front2Job> jobs; int max_blocks = 0; size_t lds = 0; };
     S1Launch s1l[4];
+    F2Launch f2l[4];
     const int vts[4] = { 8, 4, 2, 1 };
-    for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; }
+    for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
     size_t i = 0;
     while (i < s1.size()) {
         size_t j = i;
-        while (j < s1.size() && s1[j].K == s1[i].K && s1[j].lgD == s1[i].lgD && s1[j].off0 == s1[i].off0 && s1[j].nout == s1[i].nout && s1[j].min_idx == s1[i].min_idx) { j++; }
+        while (j < s1.size() && same(s1[j], s1[i])) { j++; }
         size_t g = i;
         while (g < j) {
             const size_t left = j - g;
@@ -631,21 +679,29 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int vt = vts[li];
             // tap array for this membership (cached on the device)
             std::string key;
-            bool dirty = false;
             for (int m = 0; m < vt; m++) {
                 char b[64];
                 snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
                 key += b;
             }
-            (void)dirty;
             float2* d_taps = nullptr;
             auto it = c->s1_tap_cache.find(key);
             if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
             else {
-                const int K = s1[g].K;
-                std::vector<float2> host((size_t)K * vt);
+                const int K = (s1[g].K + 1) / 2;  // tap pairs
+                std::vector<float2> host((size_t)K * vt + (size_t)256 * vt);
                 for (int k = 0; k < K; k++) {
                     for (int m = 0; m < vt; m++) { host[(size_t)k * vt + m] = s1[g + m].v->modtaps[(size_t)k]; }
+                }
+                // NCO advance inside a 256-output tile: exp(j*2*pi*theta*D1*j) (fused front kernel)
+                for (int m = 0; m < vt; m++) {
+                    const double step = s1[g + m].v->theta * (double)(1 << s1[g].lgD);
+                    for (int jj = 0; jj < 256; jj++) {
+                        double tt = step * (double)jj;
+                        tt -= std::rint(tt);
+                        const double a = 2.0 * 3.14159265358979323846 * tt;
+                        host[(size_t)K * vt + (size_t)jj * vt + m] = make_float2((float)std::cos(a), (float)std::sin(a));
+                    }
                 }
                 if (c->s1_tap_cache.size() > 4096) {  // retune churn: drop everything (rare)
                     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -658,26 +714,55 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 HIPCHK(c, hipStreamSynchronize(c->stream));  // `host` is pageable and goes out of scope
                 c->s1_tap_cache[key] = d_taps;
             }
-            Stage1Job job{};
-            job.nv = vt;
-            job.ntaps = s1[g].K;
-            job.log2_decim = s1[g].lgD;
-            job.off0 = s1[g].off0;
-            job.nout = s1[g].nout;
-            job.min_idx = s1[g].min_idx;
-            job.ctaps = d_taps;
-            for (int m = 0; m < vt; m++) {
-                Vfo* v = s1[g + m].v;
-                job.theta[m] = v->theta;
-                job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
-                job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+            const S1Member& h = s1[g];
+            if (h.fused) {
+                Front2Job job{};
+                job.nv = vt;
+                job.ntaps1 = h.K;
+                job.log2_decim1 = h.lgD;
+                job.off1 = h.off0;
+                job.ntaps2 = h.K2;
+                job.log2_decim2 = h.lgD2;
+                job.off2 = h.off2;
+                job.nout2 = h.nout2;
+                job.t2 = front2_t2(h.K, 1 << h.lgD, h.K2, 1 << h.lgD2, 8);
+                job.min_idx = h.min_idx;
+                job.ctaps = d_taps;
+                job.ptab = d_taps + (size_t)((h.K + 1) / 2) * vt;
+                job.taps2 = h.v->d_staps_nat[1];
+                for (int m = 0; m < vt; m++) {
+                    Vfo* v = s1[g + m].v;
+                    job.theta[m] = v->theta;
+                    job.phi0[m] = s1[g + m].phi0;
+                    job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
+                }
+                f2l[li].jobs.push_back(job);
+                f2l[li].max_blocks = std::max(f2l[li].max_blocks, (job.nout2 + job.t2 - 1) / job.t2);
+                const int D1 = 1 << h.lgD;
+                f2l[li].lds = std::max(f2l[li].lds, ((size_t)D1 * (256 + (h.K - 1 + D1 - 1) / D1 + 1) + (size_t)vt * 272 + (size_t)vt) * sizeof(float2));
             }
-            s1l[li].jobs.push_back(job);
-            s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
-            const int D = 1 << job.log2_decim;
-            const int tile = pick_tile(D, job.ntaps, 8);
-            if (tile == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
-            s1l[li].tile = std::min(s1l[li].tile, tile);
+            else {
+                Stage1Job job{};
+                job.nv = vt;
+                job.ntaps = h.K;
+                job.log2_decim = h.lgD;
+                job.off0 = h.off0;
+                job.nout = h.nout;
+                job.min_idx = h.min_idx;
+                job.ctaps = d_taps;
+                for (int m = 0; m < vt; m++) {
+                    Vfo* v = s1[g + m].v;
+                    job.theta[m] = v->theta;
+                    job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
+                    job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+                }
+                s1l[li].jobs.push_back(job);
+                s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
+                const int D = 1 << job.log2_decim;
+                const int tile = pick_tile(D, job.ntaps, 8);
+                if (tile == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
+                s1l[li].tile = std::min(s1l[li].tile, tile);
+            }
             g += (size_t)vt;
         }
         i = j;
@@ -692,17 +777,24 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!d_s1[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
     }
+    Front2Job* d_f2[4] = {};
+    for (int k = 0; k < 4; k++) {
+        if (!f2l[k].jobs.empty()) {
+            d_f2[k] = arena_push(c, f2l[k].jobs);
+            if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
+    }
     RotJob* d_rot = arena_push(c, rot);
     FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
     PolyJob* d_poly = arena_push(c, poly);
-    PolyBJob* d_polyb[2] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]) };
+    PolyBJob* d_polyb[4] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]), arena_push(c, polyb[2]), arena_push(c, polyb[3]) };
     FirBJob* d_chan = arena_push(c, chan);
     QuadJob* d_quad = arena_push(c, quad);
     SeqJob* d_seq = arena_push(c, seq);
     FirBJob* d_audio = arena_push(c, audio);
     CarryJob* d_carry = arena_push(c, carry);
-    if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1]) || (!polyb[2].empty() && !d_polyb[2]) || (!polyb[3].empty() && !d_polyb[3])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!quad.empty() && !d_quad) || (!seq.empty() && !d_seq) ||
         (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
@@ -725,6 +817,24 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             case 4: launch(c, vfo_stage1_kernel<4>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
             case 2: launch(c, vfo_stage1_kernel<2>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
             default: launch(c, vfo_stage1_kernel<1>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            }
+        }
+        for (int k = 0; k < 4; k++) {
+            if (f2l[k].jobs.empty() || f2l[k].max_blocks == 0) { continue; }
+            const dim3 grid((unsigned)f2l[k].max_blocks, (unsigned)f2l[k].jobs.size());
+            const dim3 block(256);
+            // all jobs of a launch class share VT; the (44 taps, /8) first stage of the ratio-32 plan (10 MS/s -> 312.5 kS/s) has a
+            // fully unrolled instance, everything else runs the generic loop
+            bool all_44_3 = true;
+            for (auto& jb : f2l[k].jobs) { all_44_3 = all_44_3 && jb.ntaps1 == 44 && jb.log2_decim1 == 3; }
+            switch (f2l[k].vt) {
+            case 8:
+                if (all_44_3) { launch(c, vfo_front2_kernel<8, 44, 3>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
+                else { launch(c, vfo_front2_kernel<8, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
+                break;
+            case 4: launch(c, vfo_front2_kernel<4, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
+            case 2: launch(c, vfo_front2_kernel<2, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
+            default: launch(c, vfo_front2_kernel<1, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
             }
         }
         if (!rot.empty() && max_rot > 0) {
@@ -773,7 +883,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
         if (max_nout > 0) { launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)poly.size()), dim3(tile), lds, (const PolyJob*)d_poly); }
     }
-    for (int li = 0; li < 2; li++) {
+    for (int li = 0; li < 4; li++) {
         if (polyb[li].empty()) { continue; }
         FamilyTimer t(c, F_POLY);
         int max_cycles = 0, threads = 256;
@@ -789,8 +899,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         for (auto& jb : polyb[li]) { lds = std::max(lds, lds_for(jb, threads)); }
         if (max_cycles == 0) { continue; }
         const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)polyb[li].size());
-        if (li == 0) { launch(c, vfo_polyb_kernel<4>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[0]); }
-        else { launch(c, vfo_polyb_kernel<8>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[1]); }
+        if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[0]); }
+        else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[1]); }
+        else if (li == 2) { launch(c, vfo_polyb_kernel<4, true>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[2]); }
+        else { launch(c, vfo_polyb_kernel<8, true>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[3]); }
     }
     {
         FamilyTimer t(c, F_FIR);
@@ -837,7 +949,9 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     int need_hist = 1;
     if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
     for (auto& kv : c->vfos) {
-        if (kv.second->d.n_stages > 0) { need_hist = std::max(need_hist, kv.second->d.stage_ntaps[0] - 1); }
+        const sdrpp_vfo_desc& d = kv.second->d;
+        if (d.n_stages > 0) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1); }
+        if (d.n_stages > 1) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }  // fused front
     }
     int rc = ensure_iq_hist(c, need_hist);
     if (rc) { return rc; }
@@ -1117,6 +1231,12 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     for (int s = 0; s < d->n_stages; s++) {
         if (!is_pow2(d->stage_decim[s]) || d->stage_ntaps[s] <= 0 || !d->stage_taps[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage %d: decimation must be a power of two with taps", s); }
     }
+    if (d->n_stages > 0) {  // the fused translation + FIR kernel uses the linear-phase pairing (all reference plans are symmetric)
+        const float* h = d->stage_taps[0];
+        for (int k = 0; k < d->stage_ntaps[0] / 2; k++) {
+            if (h[k] != h[d->stage_ntaps[0] - 1 - k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "first decimation stage must have symmetric (linear-phase) taps"); }
+        }
+    }
     const bool has_poly = (d->interp != d->decim);
     if (has_poly && (d->interp <= 0 || d->decim <= 0 || d->resamp_ntaps <= 0 || !d->resamp_taps)) { return fail(c, SDRPP_ERR_INVALID, "bad polyphase description"); }
     if (d->chan_ntaps < 0 || d->chan_ntaps > kChanHistCap + 1) { return fail(c, SDRPP_ERR_UNSUPPORTED, "channel filter of %d taps (max %d)", d->chan_ntaps, kChanHistCap + 1); }
@@ -1144,6 +1264,8 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         v->staps[s].assign(d->stage_taps[s], d->stage_taps[s] + d->stage_ntaps[s]);
         v->d.stage_taps[s] = nullptr;
         rc = upload_blocked(c, &v->d_staps[s], v->staps[s].data(), (int)v->staps[s].size(), d->stage_decim[s], &v->s_kp[s]);
+        if (rc) { return rc; }
+        rc = upload(c, &v->d_staps_nat[s], v->staps[s].data(), v->staps[s].size());
         if (rc) { return rc; }
         cap = cap / (size_t)d->stage_decim[s] + 2;
         const int hist = (s + 1 < d->n_stages) ? d->stage_ntaps[s + 1] - 1 : hist_after_decim();

@@ -51,11 +51,69 @@ struct Stage1Job {
     int ntaps, log2_decim, off0, nout;
     int min_idx;             // samples before this push-relative index read as zero (a VFO added or reset mid-stream starts
                              // from an all-zero history: fir.h:24-26 clears the delay line)
-    const float2* ctaps;     // [ntaps][VT] modulated taps, VFO index fastest
+    const float2* ctaps;     // [(ntaps+1)/2][VT] modulated tap pairs (see stage1_accumulate), VFO index fastest
     double theta[SDRPP_S1_MAX_VT];  // turns per input sample
     double phi0[SDRPP_S1_MAX_VT];   // turns at push-relative sample index 0
     float2* out[SDRPP_S1_MAX_VT];
 };
+
+
+// Symmetric-tap form of the translated FIR.  Every stage of the reference's decimation plans is linear phase (h[k] == h[K-1-k],
+// checked on the host; asymmetric taps fall back to nothing here — the host refuses them), so with the modulation centred on
+// the filter, g[K-1-k] = conj(g[k]) and
+//     g[k]*a + conj(g[k])*b = g.re * (a + b) + j * g.im * (a - b)            (a = x[i0+k], b = x[i0+K-1-k])
+// i.e. FOUR FMAs per tap PAIR and VFO instead of eight; the sum/difference are shared by all VT VFOs of the work-item.
+// ctaps: [npairs][VT] float2 (g.re, g.im), npairs = (K+1)/2; an odd K has its centre tap as a last "pair" with b = 0, g.im = 0.
+template <int VT>
+__device__ __forceinline__ void stage1_accumulate(const float2* xs, int pitch, int lgD, int K, int j, const UniformF32 g, float2 (&acc)[VT]) {
+    const int D = 1 << lgD;
+    const int npairs = (K + 1) >> 1;
+    const bool odd = (K & 1) != 0;
+    for (int k = 0; k < npairs; k++) {
+        const int kb = K - 1 - k;
+        const float2 a = xs[(k & (D - 1)) * pitch + (k >> lgD) + j];
+        float2 b = xs[(kb & (D - 1)) * pitch + (kb >> lgD) + j];
+        if (odd && k == npairs - 1) { b = make_float2(0.0f, 0.0f); }
+        const float sr = a.x + b.x, si = a.y + b.y, dr = a.x - b.x, di = a.y - b.y;
+#pragma unroll
+        for (int v = 0; v < VT; v++) {
+            const float gr = g[2 * (k * VT + v)], gi = g[2 * (k * VT + v) + 1];
+            acc[v].x = fmaf(gr, sr, acc[v].x);
+            acc[v].x = fmaf(-gi, di, acc[v].x);
+            acc[v].y = fmaf(gr, si, acc[v].y);
+            acc[v].y = fmaf(gi, dr, acc[v].y);
+        }
+    }
+}
+
+
+// Compile-time (K, log2 D) variant: fully unrolled, so every LDS offset is an instruction immediate and the tap fetches are
+// s_load_dwordx16 with constant offsets that the scheduler can hoist ahead of their use — no scalar address arithmetic at all
+// (the generic loop spends as many SALU as VALU instructions; one scalar unit serves the four SIMDs of a CU).
+template <int VT, int K, int LGD>
+__device__ __forceinline__ void stage1_accumulate_static(const float2* xs, int pitch, int j, const UniformF32 g, float2 (&acc)[VT]) {
+    constexpr int D = 1 << LGD;
+    constexpr int NP = (K + 1) / 2;
+    const float2* xj = xs + j;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int kb = K - 1 - k;
+        const float2 a = xj[(k & (D - 1)) * pitch + (k >> LGD)];
+        float2 b = xj[(kb & (D - 1)) * pitch + (kb >> LGD)];
+        if ((K & 1) && k == NP - 1) { b = make_float2(0.0f, 0.0f); }
+        const float sr = a.x + b.x, si = a.y + b.y, dr = a.x - b.x, di = a.y - b.y;
+#pragma unroll
+        for (int v = 0; v < VT; v++) {
+            const float gr = g[2 * (k * VT + v)], gi = g[2 * (k * VT + v) + 1];
+            acc[v].x = fmaf(gr, sr, acc[v].x);
+            acc[v].x = fmaf(-gi, di, acc[v].x);
+            acc[v].y = fmaf(gr, si, acc[v].y);
+            acc[v].y = fmaf(gi, dr, acc[v].y);
+        }
+    }
+}
 
 // grid = (ceil(max nout / TILE), njobs); block = TILE work-items; dynamic LDS = D * pitch float2 with
 // pitch = TILE + ceil((K-1)/D) + 1.  LDS image is de-interleaved by decimation phase: sample s of the tile lives at
@@ -81,18 +139,7 @@ __global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1
     float2 acc[VT];
 #pragma unroll
     for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
-    const UniformF32 g = as_uniform(job.ctaps);  // taps are wave-uniform: fetched with scalar loads
-    for (int k = 0; k < K; k++) {
-        const float2 x = xs[(k & (D - 1)) * pitch + (k >> lgD) + j];
-#pragma unroll
-        for (int v = 0; v < VT; v++) {
-            const float2 w = make_float2(g[2 * (k * VT + v)], g[2 * (k * VT + v) + 1]);
-            acc[v].x = fmaf(w.x, x.x, acc[v].x);
-            acc[v].x = fmaf(-w.y, x.y, acc[v].x);
-            acc[v].y = fmaf(w.x, x.y, acc[v].y);
-            acc[v].y = fmaf(w.y, x.x, acc[v].y);
-        }
-    }
+    stage1_accumulate<VT>(xs, pitch, lgD, K, j, as_uniform(job.ctaps), acc);  // taps are wave-uniform: scalar loads
     if (j0 + j >= job.nout) { return; }
     const double centre = (double)(base + (long long)j * D) + 0.5 * (double)(K - 1);
 #pragma unroll
@@ -500,7 +547,7 @@ struct PolyBJob {
     int interp, decim, tpp, off0, nout, rows;
 };
 
-template <int LMAX>
+template <int LMAX, bool LINEAR>
 __global__ __launch_bounds__(256) void vfo_polyb_kernel(const PolyBJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float2, xs)
     const PolyBJob& job = jobs[blockIdx.y];
@@ -508,13 +555,19 @@ __global__ __launch_bounds__(256) void vfo_polyb_kernel(const PolyBJob* __restri
     const int L = job.interp, M = job.decim, rows = job.rows;
     const int c0 = blockIdx.x * nthreads;  // first cycle of this block
     if (c0 * L >= job.nout) { return; }
-    const int P1 = nthreads + rows / M + 2;  // columns per residue row
+    const int P1 = nthreads + rows / M + 2;  // columns per residue row (de-interleaved layout)
     const int first = job.off0 + c0 * M - (job.tpp - 1);
     const int need = (nthreads - 1) * M + rows;
-    for (int s = threadIdx.x; s < M * P1; s += nthreads) {
-        // element s of the tile lives at [s mod M][s div M]
-        const float2 v = (s < need) ? stream_load2(job.in, first + s) : make_float2(0.0f, 0.0f);
-        xs[(s % M) * P1 + (s / M)] = v;
+    if constexpr (LINEAR) {
+        // odd M: lanes read t*M + m, a stride of 2*M dwords — conflict-free for ds_read_b64 (gcd(2M, 64) = 2), so the tile is
+        // stored as is and the row loop needs no address arithmetic
+        for (int s = threadIdx.x; s < need; s += nthreads) { xs[s] = stream_load2(job.in, first + s); }
+    }
+    else {
+        for (int s = threadIdx.x; s < M * P1; s += nthreads) {
+            const float2 v = (s < need) ? stream_load2(job.in, first + s) : make_float2(0.0f, 0.0f);
+            xs[(s % M) * P1 + (s / M)] = v;  // element s of the tile lives at [s mod M][s div M]
+        }
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -522,21 +575,148 @@ __global__ __launch_bounds__(256) void vfo_polyb_kernel(const PolyBJob* __restri
     float2 acc[LMAX];
 #pragma unroll
     for (int r = 0; r < LMAX; r++) { acc[r] = make_float2(0.0f, 0.0f); }
-    int res = 0, col = t;  // element t*M + m -> residue m mod M, column t + m div M
-    for (int m = 0; m < rows; m++) {
-        const float2 x = xs[res * P1 + col];
+    if constexpr (LINEAR) {
+        const float2* xp = xs + t * M;
+#pragma unroll 4
+        for (int m = 0; m < rows; m++) {
+            const float2 x = xp[m];
 #pragma unroll
-        for (int r = 0; r < LMAX; r++) {
-            const float h = cyc[m * LMAX + r];
-            acc[r].x = fmaf(h, x.x, acc[r].x);
-            acc[r].y = fmaf(h, x.y, acc[r].y);
+            for (int r = 0; r < LMAX; r++) {
+                const float h = cyc[m * LMAX + r];
+                acc[r].x = fmaf(h, x.x, acc[r].x);
+                acc[r].y = fmaf(h, x.y, acc[r].y);
+            }
         }
-        if (++res == M) { res = 0; col++; }
+    }
+    else {
+        int res = 0, col = t;  // element t*M + m -> residue m mod M, column t + m div M
+        for (int m = 0; m < rows; m++) {
+            const float2 x = xs[res * P1 + col];
+#pragma unroll
+            for (int r = 0; r < LMAX; r++) {
+                const float h = cyc[m * LMAX + r];
+                acc[r].x = fmaf(h, x.x, acc[r].x);
+                acc[r].y = fmaf(h, x.y, acc[r].y);
+            }
+            if (++res == M) { res = 0; col++; }
+        }
     }
     const int n0 = (c0 + t) * L;
 #pragma unroll
     for (int r = 0; r < LMAX; r++) {
         if (r < L && n0 + r < job.nout) { job.out[n0 + r] = acc[r]; }
+    }
+}
+
+// =====================================================================================================================
+// Fused front: stage 1 (translation folded into the first decimating FIR) + stage 2 (second decimating FIR) in ONE kernel.
+// The stage-1 outputs of a tile never leave the CU: they go to an LDS buffer and are consumed by stage 2 right away, which
+// removes the largest intermediate stream of the cascade (V * P/D1 complex samples written and read back per push).
+// Each block produces T2 stage-2 outputs per VFO from TS1 = (T2-1)*D2 + K2 <= blockDim stage-1 outputs; the K2-1 overlap
+// between neighbouring tiles is recomputed (a few %).  Stage-1 outputs with negative index (the delay line of stage 2) are
+// recomputed from the IQ history instead of being stored, so the only state is the IQ history and the integer offsets.
+// =====================================================================================================================
+struct Front2Job {
+    int nv;
+    int ntaps1, log2_decim1, off1;   // stage 1 (decimating_fir.h:51-62 state `offset`)
+    int ntaps2, log2_decim2, off2;   // stage 2
+    int nout2;                       // stage-2 outputs of this push
+    int t2;                          // stage-2 outputs per block
+    int min_idx;                     // IQ samples before this push-relative index read as zero
+    const float2* ctaps;             // [(ntaps1+1)/2][VT] modulated stage-1 tap pairs
+    const float2* ptab;              // [256][VT] exp(j*2*pi*theta_v*D1*j): NCO advance inside a tile (host, double -> float)
+    const float* taps2;              // [ntaps2] real taps, natural order
+    double theta[SDRPP_S1_MAX_VT];
+    double phi0[SDRPP_S1_MAX_VT];
+    float2* out[SDRPP_S1_MAX_VT];    // stage-2 output arrays
+};
+
+// NCO bookkeeping: the phasor of stage-1 output j of a tile is P_tile * ptab[j], P_tile = exp(j*2*pi*(phi0 + theta*(base + kc)))
+// evaluated once per block and VFO in double precision.  ptab[j] is applied to the stage-1 output; P_tile is constant over the
+// tile, so by linearity it is applied AFTER stage 2 (T2 instead of 256 complex multiplies per VFO).
+template <int VT, int K1S, int LGD1S>  // K1S > 0: stage-1 geometry known at compile time (fully unrolled)
+__global__ __launch_bounds__(256) void vfo_front2_kernel(IqSrc src, const Front2Job* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, smem2)
+    const Front2Job& job = jobs[blockIdx.y];
+    constexpr int tile = 256;  // stage-1 outputs computed per block (one per work-item); blockDim.x == 256
+    const int T2 = job.t2;
+    const int j2_0 = blockIdx.x * T2;
+    if (j2_0 >= job.nout2) { return; }
+    const int K1 = (K1S > 0) ? K1S : job.ntaps1, lgD1 = (K1S > 0) ? LGD1S : job.log2_decim1, D1 = 1 << lgD1;
+    const int K2 = job.ntaps2, lgD2 = job.log2_decim2, D2 = 1 << lgD2;
+    const int extra = (K1 - 1 + D1 - 1) >> lgD1;
+    const int pitch = tile + extra + 1;
+    float2* xs = smem2;                    // [D1][pitch] de-interleaved IQ tile
+    float2* s1 = smem2 + D1 * pitch;       // [VT][tile + 1] stage-1 outputs of this tile
+    constexpr int s1p = tile + 16;         // row pitch; the slack absorbs stage-2 reads of (unused) lanes past the tile
+    float2* ptile = s1 + VT * s1p;         // [VT] tile phasors
+    // first stage-1 output index this block needs (relative to the push's stage-1 output sequence; may be negative)
+    const int i1_0 = job.off2 + j2_0 * D2 - (K2 - 1);
+    const long long base = (long long)job.off1 + (long long)i1_0 * D1 - (K1 - 1);
+    const int nsamp = (tile - 1) * D1 + K1;
+    if (base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur) {
+        const float2* p = src.cur + base;  // whole tile inside this push: plain coalesced loads
+        for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D1 - 1)) * pitch + (s >> lgD1)] = p[s]; }
+    }
+    else {
+        for (int s = threadIdx.x; s < nsamp; s += tile) {
+            const long long gi = base + s;
+            xs[(s & (D1 - 1)) * pitch + (s >> lgD1)] = (gi < job.min_idx) ? make_float2(0.0f, 0.0f) : iq_load_clamped(src, gi);
+        }
+    }
+    if (threadIdx.x < VT && (int)threadIdx.x < job.nv) {
+        const int v = threadIdx.x;
+        double ph = fma((double)base + 0.5 * (double)(K1 - 1), job.theta[v], job.phi0[v]);
+        ph -= rint(ph);
+        float sn, cs;
+        sincospif(2.0f * (float)ph, &sn, &cs);
+        ptile[v] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    {
+        float2 acc[VT];
+#pragma unroll
+        for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
+        if constexpr (K1S > 0) { stage1_accumulate_static<VT, K1S, LGD1S>(xs, pitch, j, as_uniform(job.ctaps), acc); }
+        else { stage1_accumulate<VT>(xs, pitch, lgD1, K1, j, as_uniform(job.ctaps), acc); }
+        const float2* __restrict__ pt = job.ptab + (size_t)j * VT;
+#pragma unroll
+        for (int v = 0; v < VT; v++) {
+            const float2 t = pt[v];
+            s1[v * s1p + j] = make_float2(fmaf(acc[v].x, t.x, -(acc[v].y * t.y)), fmaf(acc[v].x, t.y, acc[v].y * t.x));
+        }
+    }
+    __syncthreads();
+    // stage 2: out2[j2] = P_tile * sum_k taps2[k] * s1[(j2 - j2_0) * D2 + k]; 256/VT lanes per VFO, outputs strided by that
+    constexpr int LPV = tile / VT;
+    constexpr int RB = (128 + LPV - 1) / LPV;  // T2 <= 123 because D2 >= 2
+    const int v = threadIdx.x / LPV, l = threadIdx.x % LPV;
+    int n2 = job.nout2 - j2_0;
+    if (n2 > T2) { n2 = T2; }
+    if (v < job.nv) {
+        const UniformF32 h2 = as_uniform(job.taps2);
+        const float2* sp = s1 + v * s1p + (l << lgD2);
+        float2 a[RB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) { a[r] = make_float2(0.0f, 0.0f); }
+        for (int k = 0; k < K2; k++) {
+            const float h = h2[k];
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const int idx = ((r * LPV) << lgD2) + k;
+                const float2 x = sp[idx];  // lanes past n2 read stale LDS (inside the padded row) and are never stored
+                a[r].x = fmaf(h, x.x, a[r].x);
+                a[r].y = fmaf(h, x.y, a[r].y);
+            }
+        }
+        const float2 P = ptile[v];
+        float2* o = job.out[v] + j2_0;
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const int jj = l + r * LPV;
+            if (jj < n2) { o[jj] = make_float2(fmaf(a[r].x, P.x, -(a[r].y * P.y)), fmaf(a[r].x, P.y, a[r].y * P.x)); }
+        }
     }
 }
 

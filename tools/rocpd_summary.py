@@ -28,7 +28,10 @@ def kernel_stats(path):
 
 def pmc_stats(path):
     db = sqlite3.connect(path)
-    rows = db.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%sdrpp_k::%' group by kernel_name, counter_name").fetchall()
+    # one row per (dispatch, counter, dimension instance): sum the instances of a dispatch first, then average over dispatches
+    rows = db.execute("select kernel_name, counter_name, count(*), avg(v), avg(d) from (select kernel_name, counter_name, dispatch_id, sum(value) as v, "
+                      "max(duration) as d from counters_collection where kernel_name like '%sdrpp_k::%' group by kernel_name, counter_name, dispatch_id) "
+                      "group by kernel_name, counter_name").fetchall()
     return [(short(k), c, n, v, d) for k, c, n, v, d in rows]
 
 
