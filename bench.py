@@ -58,20 +58,18 @@ def cpu_baseline(sr, nvfo, fft_size, block):
         return None
     from sdrplusplus_amd import workloads
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, max(nvfo, 1))  # one worker per VFO at most; thread 0 also runs the FFT branch
     offs = np.array([c for _, _, _, c, _ in workloads.vfo_plan(3, nvfo)], dtype=np.float64)
     offs_p = offs.ctypes.data_as(C.POINTER(C.c_double))
-    n0 = block * 20
+    n0 = block * 40  # 2 M samples, streamed `repeat` times
     x = workloads.synth(3, n0, seed=21, nvfo=nvfo)
-    lib.ref_bench_cfg3(S._fp(x.view(np.float32)), block * 2, block, sr, nvfo, offs_p, fft_size, cores)  # warm caches / tables
-    t = lib.ref_bench_cfg3(S._fp(x.view(np.float32)), n0, block, sr, nvfo, offs_p, fft_size, cores)
+    xp = S._fp(x.view(np.float32))
+    lib.ref_bench_cfg3(xp, block * 2, block, sr, nvfo, offs_p, fft_size, cores, 1)  # warm caches / tables
+    t = lib.ref_bench_cfg3(xp, n0, block, sr, nvfo, offs_p, fft_size, cores, 1)
+    repeat = int(max(1, min(400, round(15.0 / max(t, 1e-3)))))  # ~15 s of CPU time
+    t = lib.ref_bench_cfg3(xp, n0, block, sr, nvfo, offs_p, fft_size, cores, repeat)
+    n0 = n0 * repeat
     rate = n0 / t
-    n1 = int(min(max(rate * 12.0, n0), 200 * block) // block * block)  # ~12 s, at most 10 M samples
-    if n1 > n0:
-        reps = -(-n1 // n0)
-        xx = np.tile(x, reps)[:n1]
-        t = lib.ref_bench_cfg3(S._fp(xx.view(np.float32)), n1, block, sr, nvfo, offs_p, fft_size, cores)
-        rate, n0 = n1 / t, n1
     return {
         "value": round(rate / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
         "sample": "%d samples of cfg3 (%d VFO x WFM via the reference's RxVFO::process + BroadcastFM::process, %d-pt FFT + log-power per %d "
@@ -91,6 +89,7 @@ def main():
     ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 32 MiB > the 256 MiB MALL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fft-only", action="store_true", help="BASELINE cfg2 (no VFOs) instead of cfg3")
+    ap.add_argument("--cfg", type=int, default=0, help="explicit BASELINE config: 2 (FFT only), 3 (headline), 4 (61.44 MS/s, 128 mixed VFOs, 2^20-pt FFT)")
     args = ap.parse_args()
 
     import torch
@@ -113,11 +112,16 @@ def main():
 
     from sdrplusplus_amd import capi, workloads
 
-    sr, N = 10e6, 65536
-    push = (args.push // N) * N
-    nvfo = 0 if args.fft_only else args.nvfo
-    cfg = 2 if args.fft_only else 3
-    bufs = [make_input(torch, push, nvfo, sr, 0x5D2B0001 + 1000 * rank + b, device) for b in range(args.nbuf)]
+    cfg = args.cfg if args.cfg in (2, 3, 4) else (2 if args.fft_only else 3)
+    sr, N = workloads.CFG[cfg]["sr"], workloads.CFG[cfg]["fft"]
+    push = max(1, args.push // N) * N
+    nvfo = 0 if cfg == 2 else (args.nvfo if cfg == 3 else 128)
+    if cfg == 4:
+        import numpy as np
+        base = torch.from_numpy(workloads.synth(4, push, seed=0x5D2B + rank)).to(device)  # numpy generator (mixed NFM/AM/USB carriers)
+        bufs = [torch.roll(base, 4097 * b).contiguous() for b in range(args.nbuf)]
+    else:
+        bufs = [make_input(torch, push, nvfo, sr, 0x5D2B0001 + 1000 * rank + b, device) for b in range(args.nbuf)]
     ctx = capi.Context(local, max_push=push)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
     info = workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo)
@@ -134,10 +138,20 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # calibration (untimed): every kernel family bracketed by HIP events to find the dominant one and record the per-kernel split
+    ctx.timing_enable(True)
+    ncal = max(2, min(5, args.steps))
+    for i in range(ncal):
+        step(i)
+    torch.cuda.synchronize()
+    fam_all = ctx.timing_read()
+    kernel_ms_all = {k: v[0] / ncal for k, v in fam_all.items() if v[0] > 0}
+    dom = max(kernel_ms_all, key=kernel_ms_all.get) if kernel_ms_all else None
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.timing_enable(True)
+    # timed region: only the dominant family keeps its event pair (two event records per step on its launch stream)
+    ctx.timing_enable(True, families=[ctx.family_index(dom)] if dom else [])
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -155,8 +169,9 @@ def main():
 
     # sanity: the work was really done (outputs have the expected sizes)
     assert ctx.fft_lines() == lines_per_push
-    for vid in info["vids"][:1]:
-        assert abs(ctx.vfo_out_count(vid) - push // 40) <= 2
+    if cfg == 3:
+        for vid in info["vids"][:1]:
+            assert abs(ctx.vfo_out_count(vid) - push // 40) <= 2
 
     if rank != 0:
         if dist is not None:
@@ -168,27 +183,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (HIP events around every launch of the family, on the launch stream) ----
-    K1, D1 = 44, 8  # cfg 3 stage-1 plan: fir_32_8 (44 taps, decimate by 8)
+    K1, D1, K2, D2 = 44, 8, 12, 2  # cfg 3 plan (ratio 32): fir_32_8 (44 taps, /8) fused with fir_4_2 (12 taps, /2)
     bytes_per_launch = {  # compulsory HBM bytes of ONE launch of each kernel family (DESIGN.md "Kernels")
-        "vfo_stage1": push * (8 + nvfo * 8.0 / D1),
+        "vfo_stage1": push * (8 + nvfo * 8.0 / (D1 * D2)),
         "fft_pass1": push * (8 + 8),
         "fft_pass2": push * (8 + 4),
-        "vfo_decim": push * nvfo * (8.0 / 8 + 8.0 / 16) + push * nvfo * (8.0 / 16 + 8.0 / 32),
+        "vfo_decim": push * nvfo * (8.0 / 16 + 8.0 / 32),
         "vfo_poly": push * nvfo * (8.0 / 32 + 8.0 / 40),
-        "vfo_fir": push * nvfo * (8.0 / 40 * 2 + 4.0 / 40 + 8.0 / 40),
-        "demod": push * nvfo * (8.0 / 40 + 4.0 / 40),
+        "vfo_fir": push * nvfo * (8.0 / 40 * 2 + 8.0 / 40 * 2),
         "zoom_palette": push * 4.0,
     }
     flops_per_launch = {
-        "vfo_stage1": push * nvfo * K1 * 8.0 / D1,
+        # executed useful flops: 4 FMA per tap PAIR (linear-phase pairing) + phasor + stage 2 (complex data, real taps)
+        "vfo_stage1": push * nvfo * (((K1 + 1) // 2) * 8.0 / D1 + 8.0 / D1 + K2 * 4.0 / (D1 * D2)),
         "fft_pass1": push * (3 * 2 * 8 + 8 + 2),   # 8 radix-2 stages x 6 FMA per butterfly (3 per point) + window + twiddle
         "fft_pass2": push * (3 * 2 * 8 + 12),
     }
-    kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}
-    dom = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
+    kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}  # dominant family only, measured inside the timed region
     roof = None
     roof_valu = None
-    if dom is not None and dom in bytes_per_launch:
+    if dom is not None and dom in bytes_per_launch and cfg == 3:
         dur = kernel_ms[dom] * 1e-3
         ach = bytes_per_launch[dom] / dur / 1e9
         traffic = None
@@ -204,24 +218,27 @@ def main():
         if dom in flops_per_launch:
             tf = flops_per_launch[dom] / dur / 1e12
             roof_valu = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 5)}
-    path_bytes = 12.0 + (nvfo * (250e3 / sr) * 8 + (8 if nvfo else 0) - (8 if nvfo else 0))  # FFT 12 B + VFO outputs (IQ read once, shared)
-    path_bytes = 12.0 + nvfo * (250e3 / sr) * 8
+    # FFT 8 in + 4 out, VFO outputs at their IF rates; the IQ read is shared by both branches
+    out_rate = sum(r for _, r, _, _, _ in info["plan"]) if nvfo else 0.0
+    path_bytes = 12.0 + out_rate / sr * 8
     roof_path = {"bound": "hbm", "achieved": round(value * 1e6 / world * path_bytes / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(value * 1e6 / world * path_bytes / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_sample": path_bytes,
                  "note": "whole step, per GPU: SURVEY.md 8(d) path figure x ingest rate"}
 
     out = {
-        "metric": "IQ Msamples/s ingested (65536-pt FFT + 32 VFO WFM)" if not args.fft_only else "IQ Msamples/s ingested (65536-pt FFT only, cfg2)",
+        "metric": {3: "IQ Msamples/s ingested (65536-pt FFT + 32 VFO WFM)", 2: "IQ Msamples/s ingested (65536-pt FFT only, cfg2)", 4: "IQ Msamples/s ingested (2^20-pt FFT + 128 VFO mixed NFM/AM/USB, cfg4)"}[cfg],
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg%d: 10 MS/s-format synthetic IQ, 65536-pt dense FFT + log-power waterfall%s" % (cfg, (" + %d VFO x WFM (xlate+FIR+resample+FM demod)" % nvfo) if nvfo else ""),
+        "config": {"workload": "cfg%d: %.2f MS/s-format synthetic IQ, %d-pt dense FFT + log-power waterfall%s" % (cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, "WFM" if cfg == 3 else "NFM/AM/USB")) if nvfo else ""),
                    "samples_per_step_per_gpu": push, "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
                    "input_batches_rotated": args.nbuf, "device": ctx.device_info()},
         "roofline": roof, "roofline_valu": roof_valu, "roofline_path": roof_path,
-        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
+        "kernel_ms_note": "per-family HIP-event times from an untimed calibration pass (FFT branch and VFO bank run on two streams and overlap, so the "
+                          "entries sum to more than ms_per_step); roofline.avg_launch_ms is the dominant family re-measured inside the timed region",
         "realtime_factor": round(value * 1e6 / world / sr, 1),
     }
-    if world == 1 and not args.no_cpu_baseline and not args.fft_only:
+    if world == 1 and not args.no_cpu_baseline and cfg == 3:
         try:
             out["cpu_baseline"] = cpu_baseline(sr, nvfo, N, int(sr / 200))
             if out["cpu_baseline"]:

@@ -167,6 +167,8 @@ int sdrpp_push_int16(sdrpp_ctx* ctx, const int16_t* iq_host, int64_t count);
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.
  * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc */
 #define SDRPP_NUM_KERNEL_FAMILIES 10
+/* on = 0: off; 1: every family; 1 | (family_bitmask << 1): only the selected families (each timed launch costs two event
+ * records on its stream, so a throughput run instruments just the kernel it reports). */
 int sdrpp_timing_enable(sdrpp_ctx* ctx, int on);
 int sdrpp_timing_read(sdrpp_ctx* ctx, double* ms_per_family, int64_t* launches_per_family);
 const char* sdrpp_kernel_family_name(int family);

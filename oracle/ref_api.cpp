@@ -213,8 +213,9 @@ void ref_frontend_destroy(void* h) {
 // Workload = BASELINE cfg 3: nVfo x (RxVFO(inSR -> 250 kHz, bw 150 kHz) + BroadcastFM mono) and one windowed FFT + log-power
 // every `fftInterval` samples, input handed over in blocks of `blockSize` (= sr/200, file_source/main.cpp:157).  VFOs are dealt
 // round-robin to the worker threads (the reference itself runs one thread per block; this partition has less hand-off overhead, i.e.
-// it flatters the CPU).  Returns seconds of wall time for `totalSamples` input samples.
-double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, double inSR, int nVfo, const double* offsets, int fftSize, int nthreads) {
+// it flatters the CPU).  The buffer is streamed `repeat` times (filter state carries on).  Returns seconds of wall time for
+// repeat * totalSamples input samples.
+double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, double inSR, int nVfo, const double* offsets, int fftSize, int nthreads, int repeat) {
     std::vector<dsp::channel::RxVFO*> vfos((size_t)nVfo);
     std::vector<dsp::demod::BroadcastFM*> dem((size_t)nVfo);
     for (int v = 0; v < nVfo; v++) {
@@ -237,6 +238,7 @@ double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, do
         th.emplace_back([&, t]() {
             complex_t* work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
             stereo_t* audio = dsp::buffer::alloc<stereo_t>(STREAM_BUFFER_SIZE);
+            for (int rep = 0; rep < repeat; rep++)
             for (long long pos = 0; pos + blockSize <= totalSamples; pos += blockSize) {
                 const complex_t* blk = (const complex_t*)(iq + 2 * pos);
                 for (int v = t; v < nVfo; v += nthreads) {
@@ -247,6 +249,7 @@ double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, do
             }
             if (t == 0) {
                 // dense framing: every fftSize samples one frame (skip = 0)
+                for (int rep = 0; rep < repeat; rep++)
                 for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
                     volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
                     fftwf_execute(plan);

@@ -338,8 +338,21 @@ class Context:
         self._chk(self.L.sdrpp_push_device(self.h, C.c_void_p(dev_ptr), int(count)))
 
     # measurement
-    def timing_enable(self, on=True):
-        self._chk(self.L.sdrpp_timing_enable(self.h, int(on)))
+    def timing_enable(self, on=True, families=None):
+        """families: iterable of family indices to instrument (None = all)."""
+        v = int(bool(on))
+        if on and families is not None:
+            mask = 0
+            for f in families:
+                mask |= 1 << int(f)
+            v = (1 | (mask << 1)) if mask else 0
+        self._chk(self.L.sdrpp_timing_enable(self.h, v))
+
+    def family_index(self, name):
+        for i in range(NUM_KERNEL_FAMILIES):
+            if self.L.sdrpp_kernel_family_name(i).decode() == name:
+                return i
+        raise KeyError(name)
 
     def timing_read(self):
         ms = (C.c_double * NUM_KERNEL_FAMILIES)()

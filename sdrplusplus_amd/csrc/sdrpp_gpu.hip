@@ -83,7 +83,10 @@ struct sdrpp_ctx {
     int device = 0;
     int64_t max_push = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // main stream (VFO bank, copies); may be the caller's
+    hipStream_t fft_stream = nullptr;     // FFT branch runs here, concurrently with the VFO bank (HBM-bound vs VALU-bound)
+    hipStream_t launch_stream = nullptr;  // stream the next launches / timers go to
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::string devinfo;
 
@@ -131,6 +134,7 @@ struct sdrpp_ctx {
 
     // timing
     bool timing = false;
+    unsigned timing_mask = 0xffffffffu;  // families whose launches are bracketed by events while timing is on
     std::vector<TimingPair> tpairs;
     std::vector<hipEvent_t> ev_pool;
     double fam_ms[SDRPP_NUM_KERNEL_FAMILIES] = {};
@@ -198,6 +202,7 @@ hipEvent_t get_event(sdrpp_ctx* c) {
 void timing_flush(sdrpp_ctx* c) {
     if (c->tpairs.empty()) { return; }
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->fft_stream);
     for (auto& p : c->tpairs) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->fam_ms[p.family] += ms; }
@@ -212,15 +217,15 @@ struct FamilyTimer {
     hipEvent_t a = nullptr;
     FamilyTimer(sdrpp_ctx* c_, int f) : c(c_), fam(f) {
         c->fam_launch[fam]++;
-        if (c->timing) {
+        if (c->timing && ((c->timing_mask >> fam) & 1u)) {
             a = get_event(c);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, c->launch_stream);
         }
     }
     ~FamilyTimer() {
         if (c->timing && a) {
             hipEvent_t b = get_event(c);
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, c->launch_stream);
             c->tpairs.push_back({ a, b, fam });
             if (c->tpairs.size() > 8192) { timing_flush(c); }
         }
@@ -278,6 +283,29 @@ void stream_free(Stream& s) {
     dev_free(s.hist[1]);
 }
 StreamIn stream_in(const Stream& s) { return StreamIn{ s.data, s.hist[s.cur], s.hist_len, s.n }; }
+
+// Enlarge a stream's history (a consumer got more taps): the existing samples stay the most recent ones, older entries are
+// zero — exactly what fir.h:44-47 does to its delay line when the tap count grows.
+int stream_grow_hist(sdrpp_ctx* c, Stream& s, int new_len) {
+    if (new_len <= s.hist_len) { return SDRPP_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float* nh[2] = { nullptr, nullptr };
+    for (int i = 0; i < 2; i++) {
+        int rc = dev_alloc(c, &nh[i], (size_t)new_len * s.width);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(nh[i], 0, (size_t)new_len * s.width * sizeof(float)));
+    }
+    if (s.hist_len > 0) {
+        HIPCHK(c, hipMemcpy(nh[0] + (size_t)(new_len - s.hist_len) * s.width, s.hist[s.cur], (size_t)s.hist_len * s.width * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    dev_free(s.hist[0]);
+    dev_free(s.hist[1]);
+    s.hist[0] = nh[0];
+    s.hist[1] = nh[1];
+    s.cur = 0;
+    s.hist_len = new_len;
+    return SDRPP_OK;
+}
 
 int ensure_iq_hist(sdrpp_ctx* c, int need) {
     if (need <= c->iq_hist_cap) { return SDRPP_OK; }
@@ -391,7 +419,7 @@ inline int poly_nout(int n, int poff, int pphase, int L, int M) {
 
 template <class K, class... A>
 void launch(sdrpp_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
-    hipLaunchKernelGGL(kernel, grid, block, lds, c->stream, args...);
+    hipLaunchKernelGGL(kernel, grid, block, lds, c->launch_stream, args...);
 }
 
 int pick_tile(int D, int K, int width_bytes) {
@@ -500,7 +528,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             int rc = ensure_zoom(c, (size_t)nframes);
             if (rc) { return rc; }
             FamilyTimer t(c, F_ZOOM);
-            launch(c, zoom_palette_kernel, dim3((c->data_width + 255) / 256, (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, c->fft_size, c->data_width,
+            launch(c, zoom_palette_kernel, dim3((c->data_width + SDRPP_ZPX - 1) / SDRPP_ZPX, (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, c->fft_size, c->data_width,
                    (const int32_t*)c->d_zstart, (const int32_t*)c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index);
         }
         c->fft_next += nframes;
@@ -536,7 +564,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> chan;
     std::vector<QuadJob> quad;
     std::vector<SeqJob> seq;
-    std::vector<FirBJob> audio;
+    std::vector<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
+    std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     int max_rot = 0;
 
     for (auto& kv : c->vfos) {
@@ -613,11 +642,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         AgcState* agc = (AgcState*)v.d_state;
         float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
-            Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            quad.push_back(QuadJob{ stream_in(*cur), dem.data, v.d.inv_deviation, nif });
-            dem.n = nif;
-            audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp });
+            FirBJob jb{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation };
+            audio_fm.push_back(jb);
             out.n = nif;
         }
         else if (v.d.demod == SDRPP_DEMOD_AM) {
@@ -793,6 +820,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     QuadJob* d_quad = arena_push(c, quad);
     SeqJob* d_seq = arena_push(c, seq);
     FirBJob* d_audio = arena_push(c, audio);
+    FirBJob* d_audio_fm = arena_push(c, audio_fm);
+    if (!audio_fm.empty() && !d_audio_fm) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     CarryJob* d_carry = arena_push(c, carry);
     if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1]) || (!polyb[2].empty() && !d_polyb[2]) || (!polyb[3].empty() && !d_polyb[3])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!quad.empty() && !d_quad) || (!seq.empty() && !d_seq) ||
@@ -841,11 +870,15 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
         }
     }
-    auto launch_fir = [&](std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo) -> int {
+    auto launch_fir = [&](std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) -> int {
         if (jobs.empty()) { return SDRPP_OK; }
         const int R = SDRPP_FIR_R;
         int max_nout = 0, threads = 256;
-        auto lds_for = [&](const FirBJob& jb, int nt) { return (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * width * 4; };
+        auto lds_for = [&](const FirBJob& jb, int nt) {
+            size_t b = (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * width * 4;
+            if (quad) { b += ((size_t)nt * R + jb.ntaps + 2) * 4; }  // phase scratch of the fused discriminator
+            return b;
+        };
         for (auto& jb : jobs) {
             max_nout = std::max(max_nout, jb.nout);
             int nt = 256;
@@ -859,6 +892,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         const int tile = threads * R;
         const dim3 grid((max_nout + tile - 1) / tile, (unsigned)jobs.size());
         if (width == 2) { launch(c, vfo_firb_kernel<2, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
+        else if (quad) { launch(c, vfo_firb_kernel<1, true, true>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         else if (stereo) { launch(c, vfo_firb_kernel<1, true>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         else { launch(c, vfo_firb_kernel<1, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         return SDRPP_OK;
@@ -909,7 +943,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         rc = launch_fir(chan, d_chan, 2, false);
         if (rc) { return rc; }
     }
-    {
+    if (!quad.empty() || !seq.empty()) {
         FamilyTimer t(c, F_DEMOD);
         if (!quad.empty()) {
             int mx = 0;
@@ -922,12 +956,14 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         FamilyTimer t(c, F_FIR);
         rc = launch_fir(audio, d_audio, 1, true);
         if (rc) { return rc; }
+        rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
+        if (rc) { return rc; }
     }
     if (!carry.empty()) {
         FamilyTimer t(c, F_MISC);
         int mx = 0;
         for (auto& cj : carry) { mx = std::max(mx, cj.hist_len * cj.width); }
-        launch(c, carry_kernel, dim3(std::max(1, std::min((mx + 255) / 256, 1024)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+        launch(c, carry_kernel, dim3(std::max(1, std::min((mx + 255) / 256, 8)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
     }
     // flip the ping-pong side of every carried stream
     for (auto& kv : c->vfos) {
@@ -958,8 +994,17 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     rc = arena_begin(c);
     if (rc) { return rc; }
     IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
+    // fork: the FFT branch goes to its own stream and overlaps the VFO bank; both only read the IQ buffers
+    const bool fork = c->fft_on && !c->vfos.empty();
+    if (fork) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->fft_stream, c->ev_fork, 0));
+        c->launch_stream = c->fft_stream;
+    }
     rc = do_fft(c, src, count);
+    c->launch_stream = c->stream;
     if (rc) { return rc; }
+    if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->fft_stream)); }
     std::vector<CarryJob> carry;
     carry.push_back(CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2 });
     if (c->vfos.empty()) {
@@ -967,12 +1012,13 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
         rc = arena_commit(c);
         if (rc) { return rc; }
         FamilyTimer t(c, F_MISC);
-        launch(c, carry_kernel, dim3(std::max(1, std::min((c->iq_hist_cap * 2 + 255) / 256, 1024)), 1), dim3(256), 0, (const CarryJob*)d_carry);
+        launch(c, carry_kernel, dim3(std::max(1, std::min((c->iq_hist_cap * 2 + 255) / 256, 64)), 1), dim3(256), 0, (const CarryJob*)d_carry);
     }
     else {
         rc = do_vfos(c, src, count, carry);
         if (rc) { return rc; }
     }
+    if (fork) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     c->iq_cur ^= 1;
     rc = arena_end(c);
     if (rc) { return rc; }
@@ -1028,6 +1074,12 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         return SDRPP_ERR_NO_DEVICE;
     }
     c->stream = c->own_stream;
+    c->launch_stream = c->stream;
+    if (hipStreamCreateWithFlags(&c->fft_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_fork) != hipSuccess ||
+        hipEventCreate(&c->ev_join) != hipSuccess) {
+        sdrpp_destroy(c);
+        return SDRPP_ERR_NO_DEVICE;
+    }
     for (int i = 0; i < kArenaSlots; i++) {
         if (hipHostMalloc((void**)&c->arena_host[i], kArenaBytes, hipHostMallocDefault) != hipSuccess || hipEventCreate(&c->arena_ev[i]) != hipSuccess) {
             sdrpp_destroy(c);
@@ -1070,6 +1122,9 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     dev_free(c->d_zcount);
     dev_free(c->d_zoomed);
     dev_free(c->d_index);
+    if (c->ev_fork) { (void)hipEventDestroy(c->ev_fork); }
+    if (c->ev_join) { (void)hipEventDestroy(c->ev_join); }
+    if (c->fft_stream) { (void)hipStreamDestroy(c->fft_stream); }
     if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); }
     delete c;
     return SDRPP_OK;
@@ -1081,6 +1136,7 @@ int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
     if (!c) { return SDRPP_ERR_INVALID; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->launch_stream = c->stream;
     return SDRPP_OK;
 }
 
@@ -1256,9 +1312,12 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     // what consumes the decimator / rotator output
     const int tpp = has_poly ? (d->resamp_ntaps + d->interp - 1) / d->interp : 0;
     const bool fm = (d->demod == SDRPP_DEMOD_WFM || d->demod == SDRPP_DEMOD_NFM);
+    const bool fm_mode = (d->demod == SDRPP_DEMOD_WFM || d->demod == SDRPP_DEMOD_NFM);
+    const int if_hist = fm_mode ? std::max(d->audio_ntaps, 1) + 1 : 1;  // fused discriminator + audio FIR re-reads the IF history
+    const int chan_hist = ((std::max(std::max(d->chan_ntaps - 1, 1), if_hist) + 63) / 64) * 64;  // grown on demand by sdrpp_vfo_set_channel_taps
     auto hist_after_decim = [&]() -> int {
         if (has_poly) { return tpp - 1; }
-        return kChanHistCap;  // channel filter (possibly enabled later) or the discriminator
+        return chan_hist;  // channel filter or the discriminator
     };
     for (int s = 0; s < d->n_stages; s++) {
         v->staps[s].assign(d->stage_taps[s], d->stage_taps[s] + d->stage_ntaps[s]);
@@ -1299,11 +1358,11 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             v->cyc_lmax = lmax;
         }
         cap = cap * (size_t)d->interp / (size_t)d->decim + 4;
-        v->i_poly = add_stream(2, kChanHistCap, cap);
+        v->i_poly = add_stream(2, chan_hist, cap);
         if (v->i_poly < 0) { return SDRPP_ERR_NOMEM; }
     }
     // channel-filter output stream always exists (taps may be enabled later); its consumer is the demodulator
-    v->i_chan = add_stream(2, 1, cap);
+    v->i_chan = add_stream(2, if_hist, cap);
     if (v->i_chan < 0) { return SDRPP_ERR_NOMEM; }
     if (d->chan_ntaps > 0) {
         if (!d->chan_taps) { return fail(c, SDRPP_ERR_INVALID, "chan_taps null"); }
@@ -1323,8 +1382,10 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             v->audio_ntaps = an;
             rc = upload_blocked(c, &v->d_audio, v->ataps.data(), (int)v->ataps.size(), 1, &v->audio_kp);
             if (rc) { return rc; }
-            v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
-            if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
+            if (!fm) {  // AM: the sequential envelope/AGC kernel writes a real stream for the low-pass; FM demodulates inside the FIR kernel
+                v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
+                if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
+            }
         }
         v->i_out = add_stream(2, 0, cap);
         if (v->i_out < 0) { return SDRPP_ERR_NOMEM; }
@@ -1373,6 +1434,11 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // the stream that feeds the channel filter must remember n-1 samples
+        const int idx = (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1;
+        int rc = stream_grow_hist(c, v.st[(size_t)idx], n - 1);
+        if (rc) { return rc; }
+    }
     v.ctaps_chan.assign(taps, taps + n);
     v.chan_ntaps = n;
     v.d.chan_ntaps = n;
@@ -1456,6 +1522,7 @@ int sdrpp_timing_enable(sdrpp_ctx* c, int on) {
     if (!c) { return SDRPP_ERR_INVALID; }
     timing_flush(c);
     c->timing = on != 0;
+    c->timing_mask = (on > 1) ? (unsigned)(on >> 1) : 0xffffffffu;  // on = 1: all families; on = 1 | (mask << 1): selected ones
     for (int i = 0; i < SDRPP_NUM_KERNEL_FAMILIES; i++) {
         c->fam_ms[i] = 0.0;
         c->fam_launch[i] = 0;

@@ -464,9 +464,14 @@ struct FirBJob {
     float* out;
     const float* taps;  // [D][kp_pad], phase-major, zero padded
     int ntaps, log2_decim, off0, nout, kp_pad;
+    float inv_deviation;  // QUAD only
 };
 
-template <int WIDTH, bool STEREO>
+// QUAD (WIDTH 1, decimation 1): the input stream is the complex IF and the FM discriminator (quadrature.h:39-46) runs while the
+// tile is loaded — d[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation — so the demodulated stream never goes
+// to memory.  The reference keeps the previous phase as state; here it is recomputed from the IF history (atan2f(0, 0) = 0
+// reproduces the reset state).
+template <int WIDTH, bool STEREO, bool QUAD = false>
 __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict__ jobs) {
     constexpr int R = SDRPP_FIR_R;
     HIP_DYNAMIC_SHARED(float, smem)
@@ -484,12 +489,26 @@ __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict
     const int nvalid = (tile - 1) * D + K;         // samples a full tile really needs; the rest is zero-filled
     typedef typename std::conditional<WIDTH == 2, float2, float>::type T;
     T* xs = reinterpret_cast<T*>(smem);
-    for (int s = threadIdx.x; s < ncomp * D; s += nthreads) {
-        const int p = s & (D - 1), e = s >> lgD;
-        T v;
-        if constexpr (WIDTH == 2) { v = (s < nvalid) ? stream_load2(job.in, base + s) : make_float2(0.0f, 0.0f); }
-        else { v = (s < nvalid) ? stream_load1(job.in, base + s) : 0.0f; }
-        xs[p * P2 + (e & (R - 1)) * P1 + (e >> 3)] = v;
+    if constexpr (QUAD) {
+        float* phase = smem + ncomp;  // phase[i] = atan2f(x[base - 1 + i]), i = 0 .. nvalid
+        for (int s = threadIdx.x; s <= nvalid; s += nthreads) {
+            const float2 x = stream_load2(job.in, base - 1 + s);
+            phase[s] = atan2f(x.y, x.x);
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < ncomp; s += nthreads) {
+            const float v = (s < nvalid) ? normalize_phase(phase[s + 1] - phase[s]) * job.inv_deviation : 0.0f;
+            xs[(s & (R - 1)) * P1 + (s >> 3)] = v;
+        }
+    }
+    else {
+        for (int s = threadIdx.x; s < ncomp * D; s += nthreads) {
+            const int p = s & (D - 1), e = s >> lgD;
+            T v;
+            if constexpr (WIDTH == 2) { v = (s < nvalid) ? stream_load2(job.in, base + s) : make_float2(0.0f, 0.0f); }
+            else { v = (s < nvalid) ? stream_load1(job.in, base + s) : 0.0f; }
+            xs[p * P2 + (e & (R - 1)) * P1 + (e >> 3)] = v;
+        }
     }
     __syncthreads();
     const int t = threadIdx.x;

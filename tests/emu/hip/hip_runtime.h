@@ -139,6 +139,7 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{ 0
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
