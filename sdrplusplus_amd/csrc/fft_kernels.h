@@ -375,56 +375,37 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
 
 // ---- doZoom max-decimation + palette index (waterfall.cpp:65-90, 899-905) -------------------------------------------------------------
 // The float32 running index of doZoom is evaluated on the host once per view change (sdrpp_host::zoomTable: first bin and bin
-// count of every pixel).  A block owns ZPX = 64 consecutive pixels of one line: its work-items sweep the bins those pixels
-// cover with coalesced reads and fold each bin into the pixel(s) containing it through an LDS atomic max on an
-// order-preserving integer key.  max is order independent and the reference's `if (in > max)` never lets a NaN win, which the
-// NaN skip reproduces, so the result is bit-identical to the sequential scan.
+// count of every pixel).  A block owns ZPX = 64 consecutive pixels of one line, four work-items per pixel: each scans a quarter
+// of the pixel's bin range with the reference's comparison (`if (in > max) max = in`, -inf start, so a NaN never wins), then the
+// four partial maxima meet in LDS.  max is order independent: the result is bit-identical to the sequential scan.
 #define SDRPP_ZPX 64
-__device__ __forceinline__ int zoom_key(float v) {
-    const int i = __float_as_int(v);
-    return (i >= 0) ? i : (i ^ 0x7fffffff);
-}
-__device__ __forceinline__ float zoom_unkey(int k) { return __int_as_float((k >= 0) ? k : (k ^ 0x7fffffff)); }
-
 __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
                                                           const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
                                                           float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index) {
-    __shared__ int key[SDRPP_ZPX];
-    __shared__ int zs[SDRPP_ZPX];
-    __shared__ int zc[SDRPP_ZPX];
+    __shared__ float part[SDRPP_ZPX * 4];
     const int line = blockIdx.y;
-    const int px0 = blockIdx.x * SDRPP_ZPX;
-    const int npx = min(SDRPP_ZPX, data_width - px0);
+    const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int px = blockIdx.x * SDRPP_ZPX + p;
     const float* in = lines + (size_t)line * fft_size;
-    if ((int)threadIdx.x < SDRPP_ZPX) {
-        const int t = threadIdx.x;
-        key[t] = zoom_key(__uint_as_float(0xff800000u));  // -inf
-        zs[t] = (t < npx) ? zstart[px0 + t] : 0x7fffffff;
-        zc[t] = (t < npx) ? zcount[px0 + t] : 0;
-    }
-    __syncthreads();
-    const int lo = zs[0];
-    int hi = lo;
-    for (int t = 0; t < npx; t++) { hi = max(hi, zs[t] + zc[t]); }  // uniform, 64 iterations
-    for (int b = lo + (int)threadIdx.x; b < hi; b += blockDim.x) {
-        const float v = in[b];
-        if (v != v) { continue; }
-        // last pixel of this block whose range starts at or before b (zstart is non-decreasing)
-        int l = 0, r = npx - 1;
-        while (l < r) {
-            const int m = (l + r + 1) >> 1;
-            if (zs[m] <= b) { l = m; }
-            else { r = m - 1; }
-        }
-        const int k = zoom_key(v);
-        for (int p = l; p >= 0 && b < zs[p] + zc[p]; p--) {
-            if (b >= zs[p]) { atomicMax(&key[p], k); }
+    float m = __uint_as_float(0xff800000u);  // -inf
+    if (px < data_width) {
+        const int s = zstart[px], n = zcount[px];
+        const int chunk = (n + 3) >> 2;
+        const int b0 = s + q * chunk;
+        const int b1 = min(s + n, b0 + chunk);
+        for (int b = b0; b < b1; b++) {
+            const float v = in[b];
+            if (v > m) { m = v; }
         }
     }
+    part[threadIdx.x] = m;
     __syncthreads();
-    if ((int)threadIdx.x < npx) {
-        const int px = px0 + threadIdx.x;
-        const float m = zoom_unkey(key[threadIdx.x]);
+    if (q == 0 && px < data_width) {
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            const float v = part[threadIdx.x + i];
+            if (v > m) { m = v; }
+        }
         zoomed[(size_t)line * data_width + px] = m;
         const float range = wf_max - wf_min;
         const float v = (m < wf_min) ? wf_min : ((wf_max < m) ? wf_max : m);

@@ -548,7 +548,7 @@ int front2_t2(int K1, int D1, int K2, int D2, int vt) {
     const int t2 = (tile - K2) / D2 + 1;
     if (t2 * D2 * 4 < tile * 3) { return 0; }  // more than 25 % of the stage-1 work would be recomputed overlap
     if (D2 < 2) { return 0; }
-    const size_t lds = ((size_t)D1 * (tile + (K1 - 1 + D1 - 1) / D1 + 1) + (size_t)vt * (tile + 16) + (size_t)vt) * sizeof(float2);
+    const size_t lds = (std::max((size_t)D1 * (tile + (K1 - 1 + D1 - 1) / D1 + 1), (size_t)vt * (tile + 16)) + (size_t)vt) * sizeof(float2);
     return lds <= (size_t)kMaxLds ? t2 : 0;
 }
 
@@ -564,6 +564,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> chan;
     std::vector<QuadJob> quad;
     std::vector<SeqJob> seq;
+    std::vector<PreJob> pre;
     std::vector<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     int max_rot = 0;
@@ -650,14 +651,18 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         else if (v.d.demod == SDRPP_DEMOD_AM) {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, 0.0, 0.0 });
+            if (!v.d.am_carrier_agc) { pre.push_back(PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
+            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc });
             dem.n = nif;
             audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp });
             out.n = nif;
         }
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
+            Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, out.data, agc, agc + 1, dc, 0.0f, 0, v.theta2, v.phi2 });
+            pre.push_back(PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 });
+            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0 });
+            dem.n = 0;  // scratch only
             out.n = nif;
             double p2 = v.phi2 + (double)nif * v.theta2;
             v.phi2 = p2 - std::floor(p2);
@@ -667,7 +672,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         v.seen += n_in;
         // history carries for every stream that has a consumer with memory
         for (auto& s : v.st) {
-            if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width }); }
+            if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len }); }
         }
     }
 
@@ -766,7 +771,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 f2l[li].jobs.push_back(job);
                 f2l[li].max_blocks = std::max(f2l[li].max_blocks, (job.nout2 + job.t2 - 1) / job.t2);
                 const int D1 = 1 << h.lgD;
-                f2l[li].lds = std::max(f2l[li].lds, ((size_t)D1 * (256 + (h.K - 1 + D1 - 1) / D1 + 1) + (size_t)vt * 272 + (size_t)vt) * sizeof(float2));
+                f2l[li].lds = std::max(f2l[li].lds, (std::max((size_t)D1 * (256 + (h.K - 1 + D1 - 1) / D1 + 1), (size_t)vt * 272) + (size_t)vt) * sizeof(float2));
             }
             else {
                 Stage1Job job{};
@@ -787,8 +792,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
                 const int D = 1 << job.log2_decim;
                 const int tile = pick_tile(D, job.ntaps, 8);
-                if (tile == 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
-                s1l[li].tile = std::min(s1l[li].tile, tile);
+                if (tile == 0 && job.log2_decim < 5) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
+                if (tile > 0) { s1l[li].tile = std::min(s1l[li].tile, tile); }
             }
             g += (size_t)vt;
         }
@@ -819,6 +824,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     FirBJob* d_chan = arena_push(c, chan);
     QuadJob* d_quad = arena_push(c, quad);
     SeqJob* d_seq = arena_push(c, seq);
+    PreJob* d_pre = arena_push(c, pre);
+    if (!pre.empty() && !d_pre) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     FirBJob* d_audio = arena_push(c, audio);
     FirBJob* d_audio_fm = arena_push(c, audio_fm);
     if (!audio_fm.empty() && !d_audio_fm) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
@@ -839,6 +846,18 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         FamilyTimer t(c, F_S1);
         for (int k = 0; k < 4; k++) {
             if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }
+            bool direct = true;  // every job of the class decimates by >= 32: stream from global memory, no LDS tile
+            for (auto& jb : s1l[k].jobs) { direct = direct && jb.log2_decim >= 5; }
+            if (direct) {
+                const dim3 grid((s1l[k].max_nout + 255) / 256, (unsigned)s1l[k].jobs.size());
+                switch (s1l[k].vt) {
+                case 8: launch(c, vfo_stage1_direct_kernel<8>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                case 4: launch(c, vfo_stage1_direct_kernel<4>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                case 2: launch(c, vfo_stage1_direct_kernel<2>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                default: launch(c, vfo_stage1_direct_kernel<1>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                }
+                continue;
+            }
             const dim3 grid((s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (unsigned)s1l[k].jobs.size());
             const dim3 block(s1l[k].tile);
             switch (s1l[k].vt) {
@@ -887,6 +906,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             threads = std::min(threads, nt);
         }
         if (max_nout == 0) { return SDRPP_OK; }
+        // enough blocks to load-balance 256 CUs: shrink the tile while the grid has fewer than ~8 blocks per CU
+        while (threads > 64 && (size_t)((max_nout + threads * R - 1) / (threads * R)) * jobs.size() < 2048) { threads >>= 1; }
         size_t lds = 0;
         for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
         const int tile = threads * R;
@@ -930,8 +951,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
             threads = std::min(threads, nt);
         }
-        for (auto& jb : polyb[li]) { lds = std::max(lds, lds_for(jb, threads)); }
         if (max_cycles == 0) { continue; }
+        while (threads > 64 && (size_t)((max_cycles + threads - 1) / threads) * polyb[li].size() < 2048) { threads >>= 1; }
+        for (auto& jb : polyb[li]) { lds = std::max(lds, lds_for(jb, threads)); }
         const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)polyb[li].size());
         if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[0]); }
         else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[1]); }
@@ -950,6 +972,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             for (auto& q : quad) { mx = std::max(mx, q.n); }
             if (mx > 0) { launch(c, vfo_quadrature_kernel, dim3(std::min((mx + 255) / 256, 4096), (unsigned)quad.size()), dim3(256), 0, (const QuadJob*)d_quad); }
         }
+        if (!pre.empty()) {
+            int mx = 0;
+            for (auto& q : pre) { mx = std::max(mx, q.n); }
+            if (mx > 0) { launch(c, vfo_demod_pre_kernel, dim3(std::min((mx + 255) / 256, 1024), (unsigned)pre.size()), dim3(256), 0, (const PreJob*)d_pre); }
+        }
         if (!seq.empty()) { launch(c, vfo_sequential_kernel, dim3(((unsigned)seq.size() + 63) / 64), dim3(64), 0, (const SeqJob*)d_seq, (int)seq.size()); }
     }
     {
@@ -961,9 +988,14 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     if (!carry.empty()) {
         FamilyTimer t(c, F_MISC);
-        int mx = 0;
-        for (auto& cj : carry) { mx = std::max(mx, cj.hist_len * cj.width); }
-        launch(c, carry_kernel, dim3(std::max(1, std::min((mx + 255) / 256, 8)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+        // job 0 = the shared IQ stream (can be a whole FFT frame long): its own grid; the per-VFO histories are a few hundred samples
+        const int iq_elems = carry[0].need * carry[0].width;
+        launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
+        if (carry.size() > 1) {
+            int mx = 0;
+            for (size_t k = 1; k < carry.size(); k++) { mx = std::max(mx, carry[k].need * carry[k].width); }
+            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)carry.size() - 1), dim3(256), 0, (const CarryJob*)(d_carry + 1));
+        }
     }
     // flip the ping-pong side of every carried stream
     for (auto& kv : c->vfos) {
@@ -1006,13 +1038,28 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     if (rc) { return rc; }
     if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->fft_stream)); }
     std::vector<CarryJob> carry;
-    carry.push_back(CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2 });
+    {   // what the NEXT push can reach back to: the samples of the frame in progress and the deepest stage-1 (+ fused stage-2) window
+        int need = 1;
+        if (c->fft_on) {
+            const int64_t P = (int64_t)c->nz + c->skip;
+            const int64_t partial = c->fft_pos - c->fft_next * P;  // do_fft already advanced both
+            if (partial > 0) { need = std::max(need, (int)std::min<int64_t>(partial, c->nz - 1)); }
+        }
+        for (auto& kv : c->vfos) {
+            const sdrpp_vfo_desc& d = kv.second->d;
+            if (d.n_stages > 0) { need = std::max(need, d.stage_ntaps[0] - 1); }
+            if (d.n_stages > 1) { need = std::max(need, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }
+        }
+        need = std::min(need, c->iq_hist_cap);
+        carry.push_back(CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2, need });
+    }
     if (c->vfos.empty()) {
         CarryJob* d_carry = arena_push(c, carry);
         rc = arena_commit(c);
         if (rc) { return rc; }
         FamilyTimer t(c, F_MISC);
-        launch(c, carry_kernel, dim3(std::max(1, std::min((c->iq_hist_cap * 2 + 255) / 256, 64)), 1), dim3(256), 0, (const CarryJob*)d_carry);
+        const int iq_elems = carry[0].need * 2;
+        launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
     }
     else {
         rc = do_vfos(c, src, count, carry);
@@ -1386,6 +1433,10 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
                 v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
                 if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
             }
+        }
+        if (d->demod >= SDRPP_DEMOD_USB) {  // SSB: real scratch between the parallel translation and the sequential AGC
+            v->i_dem = add_stream(1, 0, cap);
+            if (v->i_dem < 0) { return SDRPP_ERR_NOMEM; }
         }
         v->i_out = add_stream(2, 0, cap);
         if (v->i_out < 0) { return SDRPP_ERR_NOMEM; }

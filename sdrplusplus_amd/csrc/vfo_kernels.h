@@ -157,6 +157,77 @@ __global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1
     }
 }
 
+// Large first-stage decimation (D >= 32: the 61.44 MS/s plans decimate by 64 with 257..400 taps).  An LDS tile for even 64
+// outputs would be ~36 KiB, leaving one wavefront per SIMD.  Consecutive outputs start D samples apart, so there is almost
+// no overlap between neighbouring lanes to exploit anyway: every lane streams its own K contiguous samples straight from
+// global memory (each 64-byte line is consumed over 8 iterations and stays in L1), no LDS, full occupancy.  Reuse is across
+// the VT VFOs of the work-item, exactly as in the tiled kernel.
+template <int VT>
+__global__ __launch_bounds__(256) void vfo_stage1_direct_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) {
+    const Stage1Job& job = jobs[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = job.ntaps, lgD = job.log2_decim;
+    const int jc = (j < job.nout) ? j : (job.nout - 1);  // lanes past the end redo the last output (no divergence), never store
+    if (job.nout <= 0) { return; }
+    const long long i0 = (long long)job.off0 + ((long long)jc << lgD) - (K - 1);
+    const int npairs = (K + 1) >> 1;
+    const bool odd = (K & 1) != 0;
+    const UniformF32 g = as_uniform(job.ctaps);
+    float2 acc[VT];
+#pragma unroll
+    for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
+    // block-uniform fast path: every window of this block lies inside the current push
+    const long long blk_first = (long long)job.off0 + ((long long)(blockIdx.x * blockDim.x) << lgD) - (K - 1);
+    const long long blk_last = (long long)job.off0 + ((long long)min((int)(blockIdx.x * blockDim.x + blockDim.x - 1), job.nout - 1) << lgD);
+    const bool inside = blk_first >= 0 && blk_first >= job.min_idx && blk_last < src.n_cur;
+    if (inside) {
+        const float2* __restrict__ xa = src.cur + i0;
+        for (int k = 0; k < npairs; k++) {
+            const float2 a = xa[k];
+            float2 b = xa[K - 1 - k];
+            if (odd && k == npairs - 1) { b = make_float2(0.0f, 0.0f); }
+            const float sr = a.x + b.x, si = a.y + b.y, dr = a.x - b.x, di = a.y - b.y;
+#pragma unroll
+            for (int v = 0; v < VT; v++) {
+                const float gr = g[2 * (k * VT + v)], gi = g[2 * (k * VT + v) + 1];
+                acc[v].x = fmaf(gr, sr, acc[v].x);
+                acc[v].x = fmaf(-gi, di, acc[v].x);
+                acc[v].y = fmaf(gr, si, acc[v].y);
+                acc[v].y = fmaf(gi, dr, acc[v].y);
+            }
+        }
+    }
+    else {
+        for (int k = 0; k < npairs; k++) {
+            const long long ia = i0 + k, ib = i0 + K - 1 - k;
+            const float2 a = (ia < job.min_idx) ? make_float2(0.0f, 0.0f) : iq_load_clamped(src, ia);
+            float2 b = (ib < job.min_idx) ? make_float2(0.0f, 0.0f) : iq_load_clamped(src, ib);
+            if (odd && k == npairs - 1) { b = make_float2(0.0f, 0.0f); }
+            const float sr = a.x + b.x, si = a.y + b.y, dr = a.x - b.x, di = a.y - b.y;
+#pragma unroll
+            for (int v = 0; v < VT; v++) {
+                const float gr = g[2 * (k * VT + v)], gi = g[2 * (k * VT + v) + 1];
+                acc[v].x = fmaf(gr, sr, acc[v].x);
+                acc[v].x = fmaf(-gi, di, acc[v].x);
+                acc[v].y = fmaf(gr, si, acc[v].y);
+                acc[v].y = fmaf(gi, dr, acc[v].y);
+            }
+        }
+    }
+    if (j >= job.nout) { return; }
+    const double centre = (double)i0 + 0.5 * (double)(K - 1);
+#pragma unroll
+    for (int v = 0; v < VT; v++) {
+        if (v < job.nv) {
+            double ph = fma(centre, job.theta[v], job.phi0[v]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            job.out[v][j] = make_float2(fmaf(acc[v].x, cs, -(acc[v].y * sn)), fmaf(acc[v].x, sn, acc[v].y * cs));
+        }
+    }
+}
+
 // Rotation only (VFOs whose output rate is above half the input rate have no decimation stage: power_decimator.h:53-56).
 struct RotJob {
     double theta, phi0;
@@ -305,17 +376,41 @@ __global__ __launch_bounds__(256) void vfo_quadrature_kernel(const QuadJob* __re
 struct AgcState {
     float set_point, attack, inv_attack, decay, inv_decay, max_gain, max_output_amp, amp;
 };
+// Parallel part of AM / SSB: everything before the first per-sample recursion.
+//   AM (audio AGC):  pre[i] = |x[i]|                         (volk_32fc_magnitude_32f, am.h:120)
+//   SSB:             pre[i] = Re{ x[i] * e^{j(phi2 + i*theta2)} }   (ssb.h:79-88: second translation + ComplexToReal)
+struct PreJob {
+    int mode, n;
+    const float2* in;
+    float* out;
+    double theta2, phi2;
+};
+__global__ __launch_bounds__(256) void vfo_demod_pre_kernel(const PreJob* __restrict__ jobs) {
+    const PreJob& job = jobs[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+        const float2 x = job.in[i];
+        if (job.mode == 2) { job.out[i] = sqrtf((x.x * x.x) + (x.y * x.y)); }
+        else {
+            double ph = fma((double)i, job.theta2, job.phi2);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            job.out[i] = fmaf(x.x, cs, -(x.y * sn));
+        }
+    }
+}
+
 struct SeqJob {
     int mode;  // 2 AM, 3/4/5 SSB family
     int n;
-    const float2* in;  // complex IF samples of this push
-    float* out;        // AM: float (to the LPF stream); SSB: stereo float2
+    const float2* in;  // complex IF samples of this push (AM carrier-AGC mode only)
+    float* pre;        // real samples from vfo_demod_pre_kernel; AM overwrites them in place with the low-pass input
+    float* out;        // SSB: stereo float2 output
     AgcState* agc;     // persistent (device)
     AgcState* carrier_agc;
     float* dc_offset;  // persistent
     float dc_rate;
     int carrier_mode;
-    double theta2, phi2;  // SSB NCO, turns
 };
 
 __device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
@@ -331,6 +426,7 @@ __device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
     return gain;
 }
 
+// One work-item per VFO: only the recursions (DC blocker, AGC) are left here.
 __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __restrict__ jobs, int njobs) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= njobs) { return; }
@@ -340,8 +436,9 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
         AgcState cagc = *job.carrier_agc;
         float off = *job.dc_offset;
         for (int i = 0; i < job.n; i++) {
-            float2 x = job.in[i];
+            float mag;
             if (job.carrier_mode) {
+                float2 x = job.in[i];
                 float inAmp = sqrtf((x.x * x.x) + (x.y * x.y));
                 float gain = agc_gain(cagc, inAmp);
                 if (inAmp * gain > cagc.max_output_amp) {
@@ -357,8 +454,11 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
                 }
                 x.x = x.x * gain;
                 x.y = x.y * gain;
+                mag = sqrtf((x.x * x.x) + (x.y * x.y));
             }
-            const float mag = sqrtf((x.x * x.x) + (x.y * x.y));
+            else {
+                mag = job.pre[i];
+            }
             float v = mag - off;
             off += v * job.dc_rate;
             if (!job.carrier_mode) {
@@ -371,9 +471,7 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
                     float maxAmp = inAmp;
                     float o2 = off;
                     for (int j = i + 1; j < job.n; j++) {
-                        const float2 y = job.in[j];
-                        const float m2 = sqrtf((y.x * y.x) + (y.y * y.y));
-                        const float v2 = m2 - o2;
+                        const float v2 = job.pre[j] - o2;
                         o2 += v2 * job.dc_rate;
                         const float a2 = fabsf(v2);
                         if (a2 > maxAmp) { maxAmp = a2; }
@@ -384,7 +482,7 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
                 }
                 v = v * gain;
             }
-            job.out[i] = v;
+            job.pre[i] = v;
         }
         *job.agc = agc;
         *job.carrier_agc = cagc;
@@ -394,23 +492,13 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
         AgcState agc = *job.agc;
         float2* out = reinterpret_cast<float2*>(job.out);
         for (int i = 0; i < job.n; i++) {
-            const float2 x = job.in[i];
-            double ph = fma((double)i, job.theta2, job.phi2);
-            ph -= rint(ph);
-            float sn, cs;
-            sincospif(2.0f * (float)ph, &sn, &cs);
-            const float re = fmaf(x.x, cs, -(x.y * sn));
+            const float re = job.pre[i];
             float inAmp = fabsf(re);
             float gain = agc_gain(agc, inAmp);
             if (inAmp * gain > agc.max_output_amp) {
                 float maxAmp = inAmp;
                 for (int j = i + 1; j < job.n; j++) {
-                    const float2 y = job.in[j];
-                    double p2 = fma((double)j, job.theta2, job.phi2);
-                    p2 -= rint(p2);
-                    float s2, c2;
-                    sincospif(2.0f * (float)p2, &s2, &c2);
-                    const float a2 = fabsf(fmaf(y.x, c2, -(y.y * s2)));
+                    const float a2 = fabsf(job.pre[j]);
                     if (a2 > maxAmp) { maxAmp = a2; }
                 }
                 agc.amp = maxAmp;
@@ -433,17 +521,18 @@ struct CarryJob {
     const float* old_hist;
     float* new_hist;
     int hist_len, n, width;
+    int need;  // only the most recent `need` samples will be read by the next push: older entries are not copied
 };
 __global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) {
     const CarryJob& job = jobs[blockIdx.y];
+    const int first = (job.hist_len - job.need) * job.width;
     const int total = job.hist_len * job.width;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (int e = first + blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int i = e / job.width, c = e % job.width;
         const long long s = (long long)job.n + i;  // index into old_hist ++ data
         job.new_hist[e] = (s < job.hist_len) ? job.old_hist[s * job.width + c] : job.data[(s - job.hist_len) * job.width + c];
     }
 }
-
 
 // =====================================================================================================================
 // Register-blocked kernels (round-1 optimisation of the measured bottleneck).
@@ -654,7 +743,7 @@ struct Front2Job {
 // evaluated once per block and VFO in double precision.  ptab[j] is applied to the stage-1 output; P_tile is constant over the
 // tile, so by linearity it is applied AFTER stage 2 (T2 instead of 256 complex multiplies per VFO).
 template <int VT, int K1S, int LGD1S>  // K1S > 0: stage-1 geometry known at compile time (fully unrolled)
-__global__ __launch_bounds__(256) void vfo_front2_kernel(IqSrc src, const Front2Job* __restrict__ jobs) {
+__global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Front2Job* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float2, smem2)
     const Front2Job& job = jobs[blockIdx.y];
     constexpr int tile = 256;  // stage-1 outputs computed per block (one per work-item); blockDim.x == 256
@@ -665,10 +754,13 @@ __global__ __launch_bounds__(256) void vfo_front2_kernel(IqSrc src, const Front2
     const int K2 = job.ntaps2, lgD2 = job.log2_decim2, D2 = 1 << lgD2;
     const int extra = (K1 - 1 + D1 - 1) >> lgD1;
     const int pitch = tile + extra + 1;
-    float2* xs = smem2;                    // [D1][pitch] de-interleaved IQ tile
-    float2* s1 = smem2 + D1 * pitch;       // [VT][tile + 1] stage-1 outputs of this tile
+    // LDS is used twice: first as the [D1][pitch] de-interleaved IQ tile, then (after a barrier) as the [VT][s1p] stage-1 output
+    // buffer — halving the footprint doubles the number of resident wavefronts that hide the tile-load latency.
     constexpr int s1p = tile + 16;         // row pitch; the slack absorbs stage-2 reads of (unused) lanes past the tile
-    float2* ptile = s1 + VT * s1p;         // [VT] tile phasors
+    const int region = max(D1 * pitch, VT * s1p);
+    float2* xs = smem2;
+    float2* s1 = smem2;
+    float2* ptile = smem2 + region;        // [VT] tile phasors
     // first stage-1 output index this block needs (relative to the push's stage-1 output sequence; may be negative)
     const int i1_0 = job.off2 + j2_0 * D2 - (K2 - 1);
     const long long base = (long long)job.off1 + (long long)i1_0 * D1 - (K1 - 1);
@@ -703,8 +795,11 @@ __global__ __launch_bounds__(256) void vfo_front2_kernel(IqSrc src, const Front2
 #pragma unroll
         for (int v = 0; v < VT; v++) {
             const float2 t = pt[v];
-            s1[v * s1p + j] = make_float2(fmaf(acc[v].x, t.x, -(acc[v].y * t.y)), fmaf(acc[v].x, t.y, acc[v].y * t.x));
+            acc[v] = make_float2(fmaf(acc[v].x, t.x, -(acc[v].y * t.y)), fmaf(acc[v].x, t.y, acc[v].y * t.x));
         }
+        __syncthreads();  // every work-item is done reading the IQ tile: the region becomes the stage-1 buffer
+#pragma unroll
+        for (int v = 0; v < VT; v++) { s1[v * s1p + j] = acc[v]; }
     }
     __syncthreads();
     // stage 2: out2[j2] = P_tile * sum_k taps2[k] * s1[(j2 - j2_0) * D2 + k]; 256/VT lanes per VFO, outputs strided by that
