@@ -79,6 +79,15 @@ def cpu_baseline(sr, nvfo, fft_size, block):
     }
 
 
+# kernel family (sdrpp_kernel_family_name) -> kernel-name prefixes as rocprofv3 reports them
+FAMILY_KERNELS = {
+    "fft_pass1": ["fft_pass1_kernel"], "fft_pass2": ["fft_pass2_kernel"], "fft_single": ["fft_single_kernel"], "zoom_palette": ["zoom_palette_kernel"],
+    "vfo_stage1": ["vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
+    "vfo_decim": ["vfo_firb_kernel<2, false, false>"], "vfo_poly": ["vfo_polyb_kernel", "vfo_poly_kernel"],
+    "vfo_fir": ["vfo_firb_kernel"], "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,8 +217,14 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+            # rocprofv3 --pmc runs, tools/rocpd_summary.py); only quoted when the profile was taken on this very workload
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                prof = json.load(open(pmc))
+                meta = prof.get("_meta", {})
+                if int(meta.get("push", 0)) == push and int(meta.get("cfg", 0)) == cfg and int(meta.get("nvfo", -1)) == nvfo:
+                    hits = [v["hbm_bytes_per_launch"] for k, v in prof.items() if k != "_meta" and any(k.startswith(pfx) for pfx in FAMILY_KERNELS[dom])]
+                    traffic = round(sum(hits)) if hits else None
             except Exception:
                 traffic = None
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),

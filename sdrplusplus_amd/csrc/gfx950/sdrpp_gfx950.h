@@ -19,4 +19,33 @@ __device__ __forceinline__ UniformF32 as_uniform(const void* ptr) {
     return u;
 }
 
+// Pointers fetched from a job table in memory have no known address space, so the compiler falls back to FLAT accesses — which
+// count against BOTH the vector-memory and the LDS wait counters (every LDS wait then also waits for L2/HBM).  These helpers
+// state that the pointer is device global memory, which restores global_load / global_store.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float global_load_f32(const float* p, long long i) { return ((const float __attribute__((address_space(1)))*)(uintptr_t)p)[i]; }
+__device__ __forceinline__ float2 global_load_f32x2(const float2* p, long long i) {
+    const f32x2 v = ((const f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i];
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float2 v) {
+    f32x2 t;
+    t.x = v.x;
+    t.y = v.y;
+    ((f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i] = t;
+}
+
+// FP32 matrix core: D(32x32) += A(32x2) * B(2x32), v_mfma_f32_32x32x2_f32, 64 cycles per instruction.  Lane l supplies
+// A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; it receives, in register r, D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31].
+// Numerically the result is the k-ordered fmaf chain d = fmaf(A[i][1], B[1][j], fmaf(A[i][0], B[0][j], c)) — plain f32, one
+// rounding per product-accumulate, which is what keeps the CPU test emulator and the hardware bit-identical.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { z[i] = 0.0f; }
+    return z;
+}
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
 }  // namespace sdrpp_k

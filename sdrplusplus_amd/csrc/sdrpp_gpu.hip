@@ -553,6 +553,17 @@ int front2_t2(int K1, int D1, int K2, int D2, int vt) {
 }
 
 
+// Matrix-core front kernel (composite stage 1 + 2 filter, 128 outputs per tile, up to 32 VFOs per job): usable?  Picks the
+// prefetch depth of the template variant.
+bool frontcm_ok(int K1, int lgD1, int K2, int lgD2, int* pf) {
+    const int K = K1 + (K2 - 1) * (1 << lgD1), lgD = lgD1 + lgD2;
+    if (K < 9 || lgD < 1 || lgD > 4) { return false; }
+    const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
+    if (nsamp > 9 * 256) { return false; }
+    *pf = nsamp <= 5 * 256 ? 5 : 9;
+    return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU (the register budget allows no more)
+}
+
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
     const int n_in = (int)count;
@@ -696,8 +707,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     });
     struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
     struct F2Launch { int vt; std::vector<Front2Job> jobs; int max_blocks = 0; size_t lds = 0; };
+    struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; };
     S1Launch s1l[4];
     F2Launch f2l[4];
+    FCMLaunch fcm[2];  // [PF == 9]
     const int vts[4] = { 8, 4, 2, 1 };
     for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
     size_t i = 0;
@@ -705,6 +718,91 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         size_t j = i;
         while (j < s1.size() && same(s1[j], s1[i])) { j++; }
         size_t g = i;
+        // ---- matrix-core path: >= 17 fused VFOs of one geometry -> jobs of up to 32 VFOs, stages 1 + 2 as one composite FIR ----
+        int m_pf = 0;
+        const bool m_ok = s1[i].fused && frontcm_ok(s1[i].K, s1[i].lgD, s1[i].K2, s1[i].lgD2, &m_pf);
+        while (m_ok && j - g >= 17) {
+            const int vt = (int)std::min<size_t>(j - g, SDRPP_FCM_VT);
+            const S1Member& h = s1[g];
+            const int D1 = 1 << h.lgD;
+            const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
+            const int NP = (K + 1) / 2, NP4 = (NP + 3) / 4 * 4;
+            std::string key = "M";
+            for (int m = 0; m < vt; m++) {
+                char b[64];
+                snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
+                key += b;
+            }
+            float2* d_taps = nullptr;
+            auto it = c->s1_tap_cache.find(key);
+            if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
+            else {
+                // [NP4][64] floats (= NP4 * 32 float2; rows >= NP are zero padding) followed by [32][TILE] float2
+                std::vector<float2> host((size_t)NP4 * 32 + (size_t)SDRPP_FCM_VT * SDRPP_FCM_TILE, make_float2(0.0f, 0.0f));
+                float* at = reinterpret_cast<float*>(host.data());
+                std::vector<double> h12((size_t)K);
+                const double kc = 0.5 * (double)(K - 1);
+                for (int m = 0; m < vt; m++) {
+                    const Vfo& vv = *s1[g + m].v;
+                    // composite taps h12 = h1 (*) upsample(h2, D1) in double precision (both are linear phase, so is h12)
+                    std::fill(h12.begin(), h12.end(), 0.0);
+                    for (int k2 = 0; k2 < h.K2; k2++) {
+                        for (int k1 = 0; k1 < h.K; k1++) { h12[(size_t)k2 * D1 + k1] += (double)vv.staps[1][(size_t)k2] * (double)vv.staps[0][(size_t)k1]; }
+                    }
+                    for (int pz = 0; pz < NP; pz++) {
+                        double t = ((double)pz - kc) * vv.theta;  // modulation centred on the filter: g[K-1-k] = conj(g[k])
+                        t -= std::rint(t);
+                        const double a = 2.0 * 3.14159265358979323846 * t;
+                        double gr = h12[(size_t)pz] * std::cos(a), gi = h12[(size_t)pz] * std::sin(a);
+                        if ((K & 1) && pz == NP - 1) { gr = h12[(size_t)pz]; gi = 0.0; }
+                        at[(size_t)pz * 64 + m] = (float)gr;
+                        at[(size_t)pz * 64 + 32 + m] = (float)-gi;
+                    }
+                }
+                for (int m = 0; m < SDRPP_FCM_VT; m++) {
+                    const double step = m < vt ? s1[g + m].v->theta * (double)(1 << lgD) : 0.0;
+                    for (int jj = 0; jj < SDRPP_FCM_TILE; jj++) {
+                        double tt = step * (double)jj;
+                        tt -= std::rint(tt);
+                        const double a = 2.0 * 3.14159265358979323846 * tt;
+                        host[(size_t)NP4 * 32 + (size_t)m * SDRPP_FCM_TILE + jj] = make_float2((float)std::cos(a), (float)std::sin(a));
+                    }
+                }
+                if (c->s1_tap_cache.size() > 4096) {
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
+                    c->s1_tap_cache.clear();
+                }
+                int rc = dev_alloc(c, &d_taps, host.size());
+                if (rc) { return rc; }
+                HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                c->s1_tap_cache[key] = d_taps;
+            }
+            FrontCMJob job{};
+            job.nv = vt;
+            job.ntaps = K;
+            job.log2_decim = lgD;
+            job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1);
+            job.nout = h.nout2;
+            job.min_idx = h.min_idx;
+            const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
+            // one resident round: 256 CUs x 3 blocks (a second, partly filled round would cost as much as the first)
+            job.tiles_per_block = std::max(1, (ntiles + 767) / 768);
+            job.atab = reinterpret_cast<const float*>(d_taps);
+            job.ptab = d_taps + (size_t)NP4 * 32;
+            for (int m = 0; m < SDRPP_FCM_VT; m++) {
+                Vfo* v = s1[g + std::min(m, vt - 1)].v;
+                job.theta[m] = v->theta;
+                job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
+                job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
+            }
+            FCMLaunch& L = fcm[m_pf == 9 ? 1 : 0];
+            L.jobs.push_back(job);
+            L.max_blocks = std::max(L.max_blocks, (ntiles + job.tiles_per_block - 1) / job.tiles_per_block);
+            L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
+            g += (size_t)vt;
+        }
         while (g < j) {
             const size_t left = j - g;
             int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
@@ -816,6 +914,13 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
     }
+    FrontCMJob* d_fcm[2] = {};
+    for (int k = 0; k < 2; k++) {
+        if (!fcm[k].jobs.empty()) {
+            d_fcm[k] = arena_push(c, fcm[k].jobs);
+            if (!d_fcm[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
+    }
     RotJob* d_rot = arena_push(c, rot);
     FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
@@ -884,6 +989,15 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             case 2: launch(c, vfo_front2_kernel<2, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
             default: launch(c, vfo_front2_kernel<1, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
             }
+        }
+        for (int k = 0; k < 2; k++) {
+            if (fcm[k].jobs.empty() || fcm[k].max_blocks == 0) { continue; }
+            const dim3 grid((unsigned)fcm[k].max_blocks, (unsigned)fcm[k].jobs.size());
+            bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
+            for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
+            if (k == 1 && all_132_4) { launch(c, vfo_frontcm_kernel<9, 132, 4>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            else if (k == 1) { launch(c, vfo_frontcm_kernel<9, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            else { launch(c, vfo_frontcm_kernel<5, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
         }
         if (!rot.empty() && max_rot > 0) {
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);

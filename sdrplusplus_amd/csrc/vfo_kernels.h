@@ -834,4 +834,216 @@ __global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Fro
     }
 }
 
+// =====================================================================================================================
+// Matrix-core front end for banks of >= 17 VFOs that share one decimation geometry.
+//
+// Stage 1 (translation + first decimating FIR) and stage 2 (second decimating FIR) are both linear and time invariant up to the
+// NCO phasor, so their cascade is ONE decimating FIR with the composite taps h12 = h1 (*) upsample(h2, D1), K = K1 + (K2-1)*D1
+// taps, decimation D = D1*D2 — again linear phase, so the tap-pair form of stage1_accumulate applies:
+//     y[v][n] = sum_p  gr[v][p] * sr[p][n] - gi[v][p] * di[p][n]          (real part; sr/di = pair sums / differences of the IQ tile)
+//               sum_p  gr[v][p] * si[p][n] + gi[v][p] * dr[p][n]          (imaginary part)
+// which is a matrix product with M = 32 VFOs, N = 32 consecutive outputs and K = 2 per tap pair: exactly one
+// v_mfma_f32_32x32x2_f32 per tap pair and component.  Evaluating the cascade at its OUTPUT rate costs ~1.3x the multiply-adds of
+// the two-stage form, but they run on the otherwise idle matrix cores at 4x the VALU rate, and the intermediate stream, its LDS
+// buffer, the second filter loop and two of the barriers disappear: the kernel is a pure LDS -> MFMA stream.
+//   A operand (taps):  [pair][64] table in LDS; lane l supplies (l < 32 ? gr : -gi) of VFO l & 31.
+//   B operand (data):  the IQ tile lives in two skewed planes (index i + i / D: a lane stride of D samples becomes the odd stride
+//                      D + 1, conflict free); lanes 0-31 read the real plane where lanes 32-63 read the imaginary one, four
+//                      ds_read_b32 (two ds_read2_b32 when the geometry is a template constant) per pair.
+//   D (results):       lane l holds output n = l & 31 of 16 VFOs; NCO phasor = tile phasor (double precision, once per tile and
+//                      VFO) x in-tile table entry (registers, loaded once per block); stores are coalesced along n.
+// A block walks over `tiles_per_block` consecutive tiles and prefetches the next IQ tile into registers while the matrix cores
+// work on the current one.  Rounding differs from the two-stage reference only in the order of the f32 accumulations (the
+// intermediate stream is never rounded to f32) — far inside the 1e-5 RMS bar, see tests/test_parity_vfo.py.
+// =====================================================================================================================
+#define SDRPP_FCM_VT 32
+#define SDRPP_FCM_TILE 128
+struct FrontCMJob {
+    int nv;
+    int ntaps;        // composite K
+    int log2_decim;   // log2(D1 * D2)
+    int off;          // push-relative IQ index of tap 0 of output 0 (negative: history)
+    int nout;         // outputs of this push (= stage-2 outputs)
+    int min_idx;      // IQ samples before this push-relative index read as zero
+    int tiles_per_block;
+    const float* atab;    // [npad][64]: lane l -> (l < 32 ? gr : -gi) of VFO l & 31 (0 for unused VFO slots and padding rows)
+    const float2* ptab;   // [32][SDRPP_FCM_TILE] exp(j*2*pi*theta_v*D*n): NCO advance inside a tile
+    double theta[SDRPP_FCM_VT];
+    double phi0[SDRPP_FCM_VT];
+    float2* out[SDRPP_FCM_VT];
+};
+
+// floats per skewed IQ plane; == 32 (mod 64) so that the two planes sit on complementary halves of the 64 LDS banks
+__host__ __device__ inline int frontcm_plane(int nsamp, int lgD) {
+    const int sk = nsamp + (nsamp >> lgD) + 1;
+    return ((sk + 31) / 64) * 64 + 32;
+}
+// LDS map (float offsets): [IQ planes XR, XI | tap operand table | tile phasors (double buffered)]
+struct FCMLayout { int pl, a_off, pt_off, total; };
+__host__ __device__ inline FCMLayout frontcm_layout(int K, int lgD) {
+    FCMLayout L;
+    const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
+    const int np4 = ((((K + 1) >> 1) + 3) >> 2) << 2;
+    L.pl = frontcm_plane(nsamp, lgD);
+    L.a_off = 2 * L.pl;
+    L.pt_off = L.a_off + np4 * 64;
+    L.total = L.pt_off + 2 * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // + the 32 output pointers
+    return L;
+}
+
+// PF: IQ samples prefetched per work-item (>= ceil(nsamp / 256)); KS > 0: geometry known at compile time (fully unrolled matrix
+// loop: every LDS offset is an immediate, the pair reads fuse into ds_read2_b32 and no scalar index arithmetic is left)
+template <int PF, int KS, int LGDS>
+__global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    const FrontCMJob& job = jobs[blockIdx.y];
+    constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
+    const int K = (KS > 0) ? KS : job.ntaps, lgD = (KS > 0) ? LGDS : job.log2_decim, D = 1 << lgD;
+    const int NP = (K + 1) >> 1, NP4 = ((NP + 3) >> 2) << 2;
+    const bool odd = (K & 1) != 0;
+    const int nsamp = (tile - 1) * D + K;
+    const FCMLayout L = frontcm_layout(K, lgD);
+    float* XR = smemf;
+    float* XI = smemf + L.pl;
+    float* AL = smemf + L.a_off;
+    float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off);  // [2][VT]
+    float2** outp = reinterpret_cast<float2**>(smemf + L.pt_off + 2 * VT * 2);  // [VT]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
+    const int tile0 = blockIdx.x * job.tiles_per_block;
+    if (tile0 * tile >= job.nout) { return; }
+    int ntl = (job.nout - tile0 * tile + tile - 1) / tile;  // tiles this block really has
+    if (ntl > job.tiles_per_block) { ntl = job.tiles_per_block; }
+
+    auto tile_base = [&](int tb) -> long long { return (long long)job.off + (long long)tb * tile * D; };
+    float2 pf[PF];
+    auto fetch = [&](long long base) {
+        if (base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur) {
+            const float2* p = src.cur + base;
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = tid + q * 256;
+                pf[q] = (sidx < nsamp) ? p[sidx] : make_float2(0.0f, 0.0f);
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = tid + q * 256;
+                const long long gi = base + sidx;
+                pf[q] = (sidx < nsamp && gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
+            }
+        }
+    };
+    auto planes_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int sidx = tid + q * 256;
+            if (sidx < nsamp) {
+                const int idx = sidx + (sidx >> lgD);
+                XR[idx] = pf[q].x;
+                XI[idx] = pf[q].y;
+            }
+        }
+    };
+    auto tile_phasor = [&](int tb, int slot) {
+        if (tid < VT && tid < job.nv) {
+            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[tid], job.phi0[tid]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            ptile[slot * VT + tid] = make_float2(cs, sn);
+        }
+    };
+
+    // ---- prologue: first IQ tile, the tap operand table and this lane's slice of the in-tile NCO table ----
+    fetch(tile_base(tile0));
+    for (int i = tid; i < NP4 * 64; i += 256) { AL[i] = global_load_f32(job.atab, i); }
+    if (tid < VT) { outp[tid] = job.out[tid]; }
+    const int n = wv * 32 + jl;  // output (within the tile) whose B column / D column this lane holds
+    float2 pt[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        pt[r] = global_load_f32x2(job.ptab, v * tile + n);
+    }
+    planes_store();
+    tile_phasor(tile0, 0);
+    if (ntl > 1) { fetch(tile_base(tile0 + 1)); }
+    __syncthreads();
+
+    const float sgn = hi ? -1.0f : 1.0f;
+    const float* P1 = hi ? XI : XR;
+    const float* P2 = hi ? XR : XI;
+    const int ib = n * D + n;  // skewed index of IQ sample n * D
+    for (int it = 0; it < ntl; it++) {
+        const int tb = tile0 + it;
+        f32x16 accR = mfma_zero(), accI = mfma_zero();
+        // operands of pair p: B = (sums | differences) of the two IQ samples the pair touches, A = its tap column
+        auto operands = [&](int p, float& a_re, float& bre, float& bim) {
+            const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
+            const int kb = K - 1 - pe;
+            const int ia = ib + pe + (pe >> lgD), ibb = ib + kb + (kb >> lgD);
+            const float a1 = P1[ia], a2 = P2[ia];
+            float b1 = P1[ibb], b2 = P2[ibb];
+            if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }  // centre tap of an odd filter: a "pair" with itself
+            bre = fmaf(sgn, b1, a1);  // lanes 0-31: sr = a.re + b.re   lanes 32-63: di = a.im - b.im
+            bim = fmaf(sgn, b2, a2);  // lanes 0-31: si = a.im + b.im   lanes 32-63: dr = a.re - b.re
+            a_re = AL[p * 64 + lane];  // (gr, -gi)
+        };
+        if constexpr (KS > 0) {
+            constexpr int NPS = (KS + 1) / 2;
+            float a_c, br_c, bi_c;
+            operands(0, a_c, br_c, bi_c);
+#pragma unroll
+            for (int p = 0; p < NPS; p++) {
+                float a_n = 0.0f, br_n = 0.0f, bi_n = 0.0f;
+                if (p + 1 < NPS) { operands(p + 1, a_n, br_n, bi_n); }  // one pair ahead of the matrix core
+                accR = mfma_32x32x2(a_c, br_c, accR);
+                accI = mfma_32x32x2(hi ? -a_c : a_c, bi_c, accI);  // (gr, +gi)
+                a_c = a_n;
+                br_c = br_n;
+                bi_c = bi_n;
+            }
+        }
+        else {
+            float a_c, br_c, bi_c;
+            operands(0, a_c, br_c, bi_c);
+            for (int p0 = 0; p0 < NP4; p0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    float a_n, br_n, bi_n;
+                    operands(p0 + u + 1 < NP4 ? p0 + u + 1 : NP4 - 1, a_n, br_n, bi_n);
+                    accR = mfma_32x32x2(a_c, br_c, accR);
+                    accI = mfma_32x32x2(hi ? -a_c : a_c, bi_c, accI);
+                    a_c = a_n;
+                    br_c = br_n;
+                    bi_c = bi_n;
+                }
+            }
+        }
+        __syncthreads();  // A: every wavefront is done with the IQ planes
+        if (it + 1 < ntl) {
+            planes_store();  // next tile (its loads were issued one tile ago)
+            tile_phasor(tb + 1, (it + 1) & 1);
+            if (it + 2 < ntl) { fetch(tile_base(tb + 2)); }
+        }
+        // ---- NCO: tile phasor x in-tile advance, then coalesced stores (lanes = consecutive outputs of one VFO) ----
+        {
+            const int j0 = tb * tile;
+            const bool live = j0 + n < job.nout;
+            const float2* pq = ptile + (it & 1) * VT;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (v < job.nv && live) {
+                    const float2 P = pq[v];
+                    const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                    global_store_f32x2(outp[v], j0 + n, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+                }
+            }
+        }
+        __syncthreads();  // B: next IQ planes and tile phasors visible
+    }
+}
+
 }  // namespace sdrpp_k

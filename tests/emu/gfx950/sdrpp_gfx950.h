@@ -8,4 +8,26 @@ struct UniformF32 {
     float operator[](int i) const { return p[i]; }
 };
 static inline UniformF32 as_uniform(const void* ptr) { return UniformF32{ (const float*)ptr }; }
+static inline float global_load_f32(const float* p, long long i) { return p[i]; }
+static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
+static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
+// v_mfma_f32_32x32x2_f32 emulated with a 64-lane rendezvous (hipemu::wave_exchange): same lane <-> element maps, same fmaf chain.
+struct f32x16 {
+    float v[16];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+static inline f32x16 mfma_zero() { f32x16 z; for (int i = 0; i < 16; i++) { z.v[i] = 0.0f; } return z; }
+static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    const float* ab = hipemu::wave_exchange(a, b);  // ab[lane * 2 + {0: a, 1: b}] of all 64 lanes of this wavefront
+    const int lane = hipemu::lane_id(), j = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float d = c.v[r];
+        d = fmaf(ab[(i) * 2], ab[(j) * 2 + 1], d);            // k = 0: A from lane i, B from lane j
+        d = fmaf(ab[(i + 32) * 2], ab[(j + 32) * 2 + 1], d);  // k = 1: lanes i + 32 / j + 32
+        c.v[r] = d;
+    }
+    return c;
+}
 }

@@ -46,12 +46,19 @@ namespace hipemu {
         int cur = -1;
         std::function<void()> body;
         alignas(64) char dynshared[160 * 1024];
+        // barrier / wavefront rendezvous bookkeeping (reset per block)
+        int nthreads = 0, ndone = 0, bar_arrived = 0;
+        unsigned bar_gen = 0;
+        std::vector<unsigned> wx_gen;              // per work-item: number of wave exchanges done
+        std::vector<unsigned long long> wx_count;  // [wave][parity]: deposits so far
+        std::vector<float> wx_buf;                 // [wave][parity][64][2]
     };
     inline State& S() { static State s; return s; }
     inline void trampoline() {
         State& s = S();
         s.body();
         s.done[s.cur] = 1;
+        s.ndone++;
         swapcontext(&s.ctx[s.cur], &s.sched);
     }
     inline void set_tid(int i) {
@@ -70,6 +77,14 @@ namespace hipemu {
             for (size_t i = old; i < (size_t)nthreads; i++) { s.stacks[i] = (char*)malloc(STK); }
         }
         s.done.assign(nthreads, 0);
+        s.nthreads = nthreads;
+        s.ndone = 0;
+        s.bar_arrived = 0;
+        s.bar_gen = 0;
+        const int nwaves = (nthreads + 63) / 64;
+        s.wx_gen.assign(nthreads, 0u);
+        s.wx_count.assign((size_t)nwaves * 2, 0ull);
+        s.wx_buf.assign((size_t)nwaves * 2 * 128, 0.0f);
         for (int i = 0; i < nthreads; i++) {
             getcontext(&s.ctx[i]);
             s.ctx[i].uc_stack.ss_sp = s.stacks[i];
@@ -89,12 +104,44 @@ namespace hipemu {
             }
         }
     }
-    inline void syncthreads() {
+    inline void yield() {
         State& s = S();
         int me = s.cur;
         swapcontext(&s.ctx[me], &s.sched);
         s.cur = me;
         set_tid(me);
+    }
+    // workgroup barrier: released when every work-item that has not exited has arrived (exited wavefronts do not take part,
+    // as on the hardware)
+    inline void syncthreads() {
+        State& s = S();
+        const unsigned gen = s.bar_gen;
+        s.bar_arrived++;
+        while (s.bar_gen == gen) {
+            if (s.bar_arrived >= s.nthreads - s.ndone) {
+                s.bar_gen++;
+                s.bar_arrived = 0;
+                break;
+            }
+            yield();
+        }
+    }
+    inline int lane_id() { State& s = S(); return s.cur & 63; }
+    // all 64 lanes of a wavefront deposit (a, b) and get a view of everybody's values (double buffered by parity: a lane can be at
+    // most one exchange ahead of the slowest lane of its wavefront)
+    inline const float* wave_exchange(float a, float b) {
+        State& s = S();
+        const int me = s.cur, w = me >> 6, lane = me & 63;
+        const unsigned g = s.wx_gen[me]++;
+        const int par = (int)(g & 1u);
+        float* buf = &s.wx_buf[((size_t)w * 2 + par) * 128];
+        buf[lane * 2] = a;
+        buf[lane * 2 + 1] = b;
+        unsigned long long& cnt = s.wx_count[(size_t)w * 2 + par];
+        cnt++;
+        const unsigned long long want = 64ull * ((unsigned long long)(g >> 1) + 1ull);
+        while (cnt < want) { yield(); }
+        return buf;
     }
 }
 #define threadIdx (hipemu::S().tIdx)

@@ -67,6 +67,34 @@ def test_cfg3_wfm_bank(backend):
     ctx.close()
 
 
+@pytest.mark.parametrize("nv", [20, 33])
+def test_matrix_core_front_bank(backend, nv):
+    """>= 17 VFOs of one geometry take the MFMA fused-front kernel (jobs of up to 32 VFOs; 20 -> one partly filled job,
+    33 -> one full job + the VALU kernel for the last one; more would leave the +-5 MHz band).  Uneven pushes exercise history, tile and push boundaries."""
+    from sdrplusplus_amd import workloads
+
+    sr = 10e6
+    pushes = [50000, 1031, 20000, 7, 33333]
+    x = workloads.synth(3, sum(pushes), seed=11, nvfo=nv)
+    plan = workloads.vfo_plan(3, nv)
+    ctx, vids, chains, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan], max(pushes))
+    worst_audio, worst_if, pos = 0.0, 0.0, 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        ctx.push(blk)
+        for vid, ch in zip(vids, chains):
+            oi, oa = ch.process(blk)
+            gi, ga = ctx.vfo_read_if(vid), ctx.vfo_read(vid)
+            assert gi.shape == oi.shape and ga.shape == oa.shape
+            if len(oa):
+                worst_audio = max(worst_audio, rms(ga - oa))
+                worst_if = max(worst_if, rms(gi - oi) / max(rms(oi), 1e-9))
+    assert worst_audio < 1e-5, worst_audio
+    assert worst_if < 2e-3, worst_if
+    ctx.close()
+
+
 def test_if_tight_with_exact_phase_steps(backend):
     """Offsets at multiples of sr/8: NCO and reference recursion are both exact, what is left is fp32 summation order."""
     sr, B = 10e6, 50000

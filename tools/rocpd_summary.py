@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--json")
     ap.add_argument("--title", default="rocprofv3 summary")
+    ap.add_argument("--meta", nargs="*", default=[], help="key=value pairs stored under _meta in the JSON (e.g. push=4194304 cfg=3)")
     a = ap.parse_args()
     lines = ["# " + a.title, "", "## kernel trace (`rocprofv3 --kernel-trace --stats`), product kernels only", "",
              "| kernel | calls | total us | avg us | min us | max us |", "|---|---:|---:|---:|---:|---:|"]
@@ -74,6 +75,7 @@ def main():
     else:
         sys.stdout.write(text)
     if a.json:
+        traffic["_meta"] = dict(kv.split("=", 1) for kv in a.meta)
         json.dump(traffic, open(a.json, "w"), indent=1)
 
 
