@@ -82,9 +82,9 @@ def cpu_baseline(sr, nvfo, fft_size, block):
 # kernel family (sdrpp_kernel_family_name) -> kernel-name prefixes as rocprofv3 reports them
 FAMILY_KERNELS = {
     "fft_pass1": ["fft_pass1_kernel"], "fft_pass2": ["fft_pass2_kernel"], "fft_single": ["fft_single_kernel"], "zoom_palette": ["zoom_palette_kernel"],
-    "vfo_stage1": ["vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
-    "vfo_decim": ["vfo_firb_kernel<2, false, false>"], "vfo_poly": ["vfo_polyb_kernel", "vfo_poly_kernel"],
-    "vfo_fir": ["vfo_firb_kernel"], "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
+    "vfo_stage1": ["vfo_frontcm_kernel", "vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
+    "vfo_decim": ["vfo_toep_kernel<2, 2, false>", "vfo_firb_kernel<2, false, false>"], "vfo_poly": ["vfo_toep_kernel<2, 2, false>", "vfo_polyb_kernel", "vfo_poly_kernel"],
+    "vfo_fir": ["vfo_toep_kernel<1, 2, true>", "vfo_toep_kernel<2, 2, false>", "vfo_firb_kernel"], "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
 }
 
 
@@ -192,28 +192,56 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (HIP events around every launch of the family, on the launch stream) ----
-    K1, D1, K2, D2 = 44, 8, 12, 2  # cfg 3 plan (ratio 32): fir_32_8 (44 taps, /8) fused with fir_4_2 (12 taps, /2)
-    bytes_per_launch = {  # compulsory HBM bytes of ONE launch of each kernel family (DESIGN.md "Kernels")
-        "vfo_stage1": push * (8 + nvfo * 8.0 / (D1 * D2)),
-        "fft_pass1": push * (8 + 8),
-        "fft_pass2": push * (8 + 4),
-        "vfo_decim": push * nvfo * (8.0 / 16 + 8.0 / 32),
-        "vfo_poly": push * nvfo * (8.0 / 32 + 8.0 / 40),
-        "vfo_fir": push * nvfo * (8.0 / 40 * 2 + 8.0 / 40 * 2),
-        "zoom_palette": push * 4.0,
-    }
+    # geometry of the VFO chain (all VFOs of cfg 3 share it): decimation plan, resampler, channel / audio filters
+    geo = None
+    if nvfo:
+        from sdrplusplus_amd import radio
+        m0, r0, b0, c0, _ = info["plan"][0]
+        d0, _keep = radio.vfo_desc(sr, r0, b0, c0, m0)
+        st = [(int(d0.stage_decim[i]), int(d0.stage_ntaps[i])) for i in range(d0.n_stages)]
+        geo = dict(stages=st, interp=int(d0.interp), decim=int(d0.decim), resamp_ntaps=int(d0.resamp_ntaps), chan_ntaps=int(d0.chan_ntaps), audio_ntaps=int(d0.audio_ntaps))
+    matrix_front = bool(geo) and nvfo >= 17 and len(geo["stages"]) >= 2      # vfo_frontcm_kernel: stages 1+2 as one composite FIR on the MFMA pipe
+    matrix_fir = not os.environ.get("SDRPP_GPU_VALU_FIR")                      # vfo_toep_kernel for the filters behind the front end
+    bytes_per_launch = {"fft_pass1": push * (8 + 8), "fft_pass2": push * (8 + 4), "zoom_palette": push * 4.0}  # compulsory HBM bytes of ONE launch per family
     flops_per_launch = {
-        # executed useful flops: 4 FMA per tap PAIR (linear-phase pairing) + phasor + stage 2 (complex data, real taps)
-        "vfo_stage1": push * nvfo * (((K1 + 1) // 2) * 8.0 / D1 + 8.0 / D1 + K2 * 4.0 / (D1 * D2)),
         "fft_pass1": push * (3 * 2 * 8 + 8 + 2),   # 8 radix-2 stages x 6 FMA per butterfly (3 per point) + window + twiddle
         "fft_pass2": push * (3 * 2 * 8 + 12),
     }
+    bound_of = {"fft_pass1": "hbm", "fft_pass2": "hbm", "fft_single": "hbm", "zoom_palette": "hbm", "carry_misc": "hbm"}
+    if geo:
+        (D1, K1) = geo["stages"][0]
+        fused = len(geo["stages"]) >= 2
+        D2, K2 = geo["stages"][1] if fused else (1, 1)
+        Kc, Dc = K1 + (K2 - 1) * D1, D1 * D2
+        n_front = push / Dc
+        bytes_per_launch["vfo_stage1"] = push * 8 + nvfo * n_front * 8
+        if matrix_front:   # composite filter at its output rate: tap PAIRS x (2 matrix rows x re/im) + NCO (two complex products)
+            flops_per_launch["vfo_stage1"] = nvfo * n_front * (((Kc + 1) // 2) * 8.0 + 16.0)
+        else:              # two-stage VALU form: 4 FMA per stage-1 tap pair, phasor, stage 2 on complex data with real taps
+            flops_per_launch["vfo_stage1"] = push * nvfo * (((K1 + 1) // 2) * 8.0 / D1 + 8.0 / D1 + K2 * 4.0 / Dc)
+        bound_of["vfo_stage1"] = "mfma" if matrix_front else "fp32_valu"
+        n, fl, by = n_front, 0.0, 0.0
+        for (Ds, Ks) in geo["stages"][2:]:
+            by += nvfo * (n * 8 + n / Ds * 8)
+            n /= Ds
+            fl += nvfo * n * Ks * 4.0
+        bytes_per_launch["vfo_decim"], flops_per_launch["vfo_decim"] = by, fl
+        if geo["interp"] != geo["decim"]:
+            tpp = -(-geo["resamp_ntaps"] // geo["interp"])
+            n_out = n * geo["interp"] / geo["decim"]
+            bytes_per_launch["vfo_poly"] = nvfo * (n * 8 + n_out * 8)
+            flops_per_launch["vfo_poly"] = nvfo * n_out * tpp * 4.0
+            n = n_out
+        # channel filter (complex) + discriminator/audio low-pass (real in, stereo out)
+        bytes_per_launch["vfo_fir"] = nvfo * n * ((16 if geo["chan_ntaps"] else 0) + 8 + 8)
+        flops_per_launch["vfo_fir"] = nvfo * n * (geo["chan_ntaps"] * 4.0 + geo["audio_ntaps"] * 2.0)
+        for f in ("vfo_decim", "vfo_poly", "vfo_fir"):
+            bound_of[f] = "mfma" if matrix_fir else "fp32_valu"
     kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}  # dominant family only, measured inside the timed region
     roof = None
     roof_valu = None
     if dom is not None and dom in bytes_per_launch and cfg == 3:
         dur = kernel_ms[dom] * 1e-3
-        ach = bytes_per_launch[dom] / dur / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -227,10 +255,20 @@ def main():
                     traffic = round(sum(hits)) if hits else None
             except Exception:
                 traffic = None
-        roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch[dom], "avg_launch_ms": round(kernel_ms[dom], 4),
-                "note": "this kernel is FP32-VALU-bound (no dense contraction, MFMA unused): see roofline_valu" if dom.startswith("vfo") else ""}
-        if dom in flops_per_launch:
+        bound = bound_of.get(dom, "hbm")
+        gbs = bytes_per_launch[dom] / dur / 1e9
+        if bound != "mfma" or dom not in flops_per_launch:  # HBM roofline (+ roofline_valu below for the FP32-VALU kernels)
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch[dom], "avg_launch_ms": round(kernel_ms[dom], 4)}
+        else:
+            # FP32 filter-bank kernels: the floor is the FP32 multiply-add rate (matrix pipe = vector pipe = 157.3 TFLOP/s on MI355X);
+            # `achieved` counts the ALGORITHMIC flops of the filters (DESIGN.md "Kernels"), not the zero band of the Toeplitz tiles
+            tf = flops_per_launch[dom] / dur / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / VALU_PEAK_TFLOPS, 5), "traffic": traffic, "algorithmic_flops_per_launch": flops_per_launch[dom],
+                    "algorithmic_bytes_per_launch": bytes_per_launch[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 4),
+                    "note": "family = all launches of this kind in one push (e.g. vfo_fir = channel filter + discriminator/audio low-pass)"}
+        if dom in flops_per_launch and roof["bound"] == "hbm":
             tf = flops_per_launch[dom] / dur / 1e12
             roof_valu = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 5)}
     # FFT 8 in + 4 out, VFO outputs at their IF rates; the IQ read is shared by both branches

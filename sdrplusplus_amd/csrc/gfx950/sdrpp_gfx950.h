@@ -24,6 +24,7 @@ __device__ __forceinline__ UniformF32 as_uniform(const void* ptr) {
 // state that the pointer is device global memory, which restores global_load / global_store.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float global_load_f32(const float* p, long long i) { return ((const float __attribute__((address_space(1)))*)(uintptr_t)p)[i]; }
+__device__ __forceinline__ int global_load_i32(const int* p, long long i) { return ((const int __attribute__((address_space(1)))*)(uintptr_t)p)[i]; }
 __device__ __forceinline__ float2 global_load_f32x2(const float2* p, long long i) {
     const f32x2 v = ((const f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i];
     return make_float2(v.x, v.y);
@@ -33,6 +34,20 @@ __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float
     t.x = v.x;
     t.y = v.y;
     ((f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i] = t;
+}
+
+// Scheduling fence: the instruction scheduler does not move anything across it.  Used to keep LDS reads issued two steps ahead
+// of the matrix instructions that consume them (left alone, the scheduler sinks them next to their use and the wave then
+// waits out the full LDS latency in front of every v_mfma).
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// Wavefront-level synchronisation of LDS traffic: the 64 lanes of a wavefront run in lock step and its LDS operations complete in
+// order, so no hardware barrier is needed for one lane to read what another lane of the SAME wavefront wrote — only the compiler
+// must be kept from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // FP32 matrix core: D(32x32) += A(32x2) * B(2x32), v_mfma_f32_32x32x2_f32, 64 cycles per instruction.  Lane l supplies
@@ -47,5 +62,16 @@ __device__ __forceinline__ f32x16 mfma_zero() {
     return z;
 }
 __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// D(16x16) += A(16x4) * B(4x16), v_mfma_f32_16x16x4_f32, 32 cycles per instruction (same FLOP rate as the 32x32x2 form).  Lane l
+// supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; register r receives D[i = 4 * (l >> 4) + r][j = l & 15];
+// numerically d = fmaf(A[i][3], B[3][j], fmaf(A[i][2], B[2][j], fmaf(A[i][1], B[1][j], fmaf(A[i][0], B[0][j], c)))).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma4_zero() {
+    f32x4 z;
+    z[0] = 0.0f; z[1] = 0.0f; z[2] = 0.0f; z[3] = 0.0f;
+    return z;
+}
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 }  // namespace sdrpp_k

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -42,6 +43,16 @@ struct Stream {
     int n = 0;
 };
 
+// Tap tables of the matrix-core FIR kernel (vfo_toep_kernel): zero-padded taps + per-lane base indices (one set per carried
+// resampler phase).
+struct ToepTab {
+    float* d_tl = nullptr;
+    int* d_lb = nullptr;  // [nvar][64]
+    int tl_len = 0, nsteps = 0, s_in = 0, rows = 0, nvar = 0;
+    int kind = 0;  // 1 decimator, 2 resampler, 4 channel filter, 8 audio low-pass
+    bool ok = false;
+};
+
 struct Vfo {
     int id = 0;
     sdrpp_vfo_desc d{};
@@ -73,6 +84,7 @@ struct Vfo {
     // streams: 0..nstages-1 decimator outputs (index 0 also used by the rotate-only path), then poly, chan, dem, out
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
+    ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
 };
 
 struct TimingPair { hipEvent_t a, b; int family; };
@@ -99,6 +111,7 @@ struct sdrpp_ctx {
 
     // job arena
     char* arena_host[kArenaSlots] = {};
+    char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
     hipEvent_t arena_ev[kArenaSlots] = {};
     bool arena_used[kArenaSlots] = {};
     char* arena_dev = nullptr;
@@ -250,9 +263,18 @@ T* arena_push(sdrpp_ctx* c, const std::vector<T>& v, T** host_copy = nullptr) {
     c->arena_off = off + bytes;
     return (T*)(c->arena_dev + off);
 }
+// The job tables of one push (a few tens of KB) travel from the pinned host slot to the device arena through a tiny copy KERNEL
+// that reads the pinned (device-mapped) host memory directly.  hipMemcpyAsync is avoided on purpose: above ~16 KB the runtime's
+// staged copy path was measured to block the enqueuing thread for up to 8 ms every few pushes (tools/hosttime.py,
+// SDRPP_GPU_HOSTPROF=1), which starved the GPU; a kernel launch costs ~7 us of host time, always.
+__global__ __launch_bounds__(256) void arena_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) { dst[i] = src[i]; }
+}
 int arena_commit(sdrpp_ctx* c) {
     if (c->arena_off == 0) { return SDRPP_OK; }
-    HIPCHK(c, hipMemcpyAsync(c->arena_dev, c->arena_host[c->arena_slot], c->arena_off, hipMemcpyHostToDevice, c->stream));
+    const int n16 = (int)((c->arena_off + 15) / 16);
+    hipLaunchKernelGGL(arena_upload_kernel, dim3((unsigned)std::min((n16 + 255) / 256, 64)), dim3(256), 0, c->stream,
+                       (const uint4*)c->arena_host_dev[c->arena_slot], (uint4*)c->arena_dev, n16);
     return SDRPP_OK;
 }
 int arena_end(sdrpp_ctx* c) {
@@ -346,6 +368,79 @@ int upload_blocked(sdrpp_ctx* c, float** dst, const float* h, int K, int D, int*
     return upload(c, dst, t.data(), t.size());
 }
 
+void toep_free(ToepTab& T) {
+    dev_free(T.d_tl);
+    dev_free(T.d_lb);
+    const int kind = T.kind;
+    T = ToepTab{};
+    T.kind = kind;
+}
+int toep_upload(sdrpp_ctx* c, ToepTab& T, const std::vector<float>& tl, const std::vector<int>& lb) {
+    dev_free(T.d_tl);
+    dev_free(T.d_lb);
+    T.ok = false;
+    int rc = upload(c, &T.d_tl, tl.data(), tl.size());
+    if (rc) { return rc; }
+    rc = upload(c, &T.d_lb, lb.data(), lb.size());
+    if (rc) { return rc; }
+    T.tl_len = (int)tl.size();
+    T.nvar = (int)lb.size() / 64;
+    // usable only if four wavefront windows (two planes each) + the tap table fit the block's LDS budget (1/3 of a CU) — very
+    // long filters stay on the register-blocked VALU kernels
+    const int span = (2 * 16 - 1) * T.s_in + 4 * T.nsteps, pl = (span + 8) & ~3;
+    T.ok = ((size_t)((T.tl_len + 3) & ~3) + (size_t)4 * 2 * pl) * sizeof(float) <= (size_t)(160 * 1024 / 3);
+    // A/B switch for benchmarking: SDRPP_GPU_VALU_FIR=<mask> keeps the register-blocked VALU kernels (1: decimators, 2: resampler,
+    // 4: channel filter, 8: audio low-pass; 15 = all)
+    if (const char* e = getenv("SDRPP_GPU_VALU_FIR")) {
+        if (atoi(e) & T.kind) { T.ok = false; }
+    }
+    return SDRPP_OK;
+}
+// FIR decimating by D: tile = 15 outputs, window offset k' = D * m + k  ->  B[k'][m] = h[k' - D * m]
+int toep_build_fir(sdrpp_ctx* c, ToepTab& T, const float* h, int K, int D) {
+    const int rows = 15, padl = (rows - 1) * D, kp = K + padl, nsteps = (kp + 3) / 4;
+    const int mainlen = padl + 4 * nsteps + 4, zb = mainlen;
+    std::vector<float> tl((size_t)mainlen + 4 * (size_t)nsteps + 4, 0.0f);
+    for (int k = 0; k < K; k++) { tl[(size_t)padl + k] = h[k]; }
+    std::vector<int> lb(64);
+    for (int lane = 0; lane < 64; lane++) {
+        const int m = lane & 15, kk = lane >> 4;
+        lb[(size_t)lane] = (m < rows) ? padl - D * m + kk : zb + kk;
+    }
+    T.nsteps = nsteps;
+    T.s_in = rows * D;
+    T.rows = rows;
+    return toep_upload(c, T, tl, lb);
+}
+// Polyphase resampler L/M (bank[phase][tpp], polyphase_resampler.h:75-93): tile = CY whole phase cycles (CY * L <= 15 outputs,
+// CY * M inputs); output (cy, r) uses phase (phase0 + r*M) % L at window offset cy*M + (phase0 + r*M) / L.  One lane-base set
+// per carried phase0.
+int toep_build_poly(sdrpp_ctx* c, ToepTab& T, const std::vector<float>& bank, int L, int M, int tpp) {
+    const int cy_n = 15 / L;
+    if (cy_n < 1) { return SDRPP_OK; }  // T.ok stays false: the VALU kernels handle it
+    const int rows = cy_n * L, omax = ((L - 1) + (L - 1) * M) / L, shift_max = (cy_n - 1) * M + omax;
+    const int kp = shift_max + tpp, nsteps = (kp + 3) / 4, padp = shift_max, row = padp + 4 * nsteps + 4, zb = L * row;
+    std::vector<float> tl((size_t)zb + 4 * (size_t)nsteps + 4, 0.0f);
+    for (int ph = 0; ph < L; ph++) {
+        for (int q = 0; q < tpp; q++) { tl[(size_t)ph * row + (size_t)padp + q] = bank[(size_t)ph * tpp + q]; }
+    }
+    std::vector<int> lb((size_t)L * 64);
+    for (int ph0 = 0; ph0 < L; ph0++) {
+        for (int lane = 0; lane < 64; lane++) {
+            const int m = lane & 15, kk = lane >> 4;
+            if (m < rows) {
+                const int cy = m / L, r = m % L, A = ph0 + r * M;
+                lb[(size_t)ph0 * 64 + lane] = (A % L) * row + padp - (cy * M + A / L) + kk;
+            }
+            else { lb[(size_t)ph0 * 64 + lane] = zb + kk; }
+        }
+    }
+    T.nsteps = nsteps;
+    T.s_in = cy_n * M;
+    T.rows = rows;
+    return toep_upload(c, T, tl, lb);
+}
+
 void build_modtaps(Vfo& v) {
     // g[k] = h[k] * exp(j*2*pi*(k - kc)*theta), kc = (K-1)/2, for the first (K+1)/2 taps; the other half is the conjugate
     // mirror (stage1_accumulate).  An odd K has a real centre tap.
@@ -371,6 +466,10 @@ void vfo_free(Vfo& v) {
     dev_free(v.d_chan);
     dev_free(v.d_audio);
     dev_free(v.d_state);
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { toep_free(v.tp_stage[i]); }
+    toep_free(v.tp_poly);
+    toep_free(v.tp_chan);
+    toep_free(v.tp_audio);
     for (auto& s : v.st) { stream_free(s); }
     v.st.clear();
 }
@@ -417,8 +516,36 @@ inline int poly_nout(int n, int poff, int pphase, int L, int M) {
     return (int)((need + M - 1) / M);
 }
 
+// Host-side enqueue profiler (SDRPP_GPU_HOSTPROF=1): wall time spent inside named sections of the push path, printed when the
+// context is destroyed.  Diagnostic only.
+struct HostProf {
+    struct Acc { double total = 0.0, mx = 0.0; long n = 0; };
+    std::map<std::string, Acc> acc;
+    bool on = getenv("SDRPP_GPU_HOSTPROF") != nullptr;
+    void add(const char* name, double us) {
+        Acc& a = acc[name];
+        a.total += us;
+        a.mx = std::max(a.mx, us);
+        a.n++;
+    }
+    void report() {
+        if (!on) { return; }
+        for (auto& kv : acc) { fprintf(stderr, "[sdrpp hostprof] %-28s n=%6ld avg %8.1f us max %9.1f us\n", kv.first.c_str(), kv.second.n, kv.second.total / (double)kv.second.n, kv.second.mx); }
+    }
+};
+HostProf g_hostprof;
+struct HostScope {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostScope(const char* n) : name(n) { if (g_hostprof.on) { t0 = std::chrono::steady_clock::now(); } }
+    ~HostScope() {
+        if (g_hostprof.on) { g_hostprof.add(name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+    }
+};
+
 template <class K, class... A>
 void launch(sdrpp_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+    HostScope hs("launch");
     hipLaunchKernelGGL(kernel, grid, block, lds, c->launch_stream, args...);
 }
 
@@ -553,15 +680,15 @@ int front2_t2(int K1, int D1, int K2, int D2, int vt) {
 }
 
 
-// Matrix-core front kernel (composite stage 1 + 2 filter, 128 outputs per tile, up to 32 VFOs per job): usable?  Picks the
-// prefetch depth of the template variant.
+// Matrix-core front kernel (composite stage 1 + 2 filter, one 32-output x 32-VFO tile per wavefront step): usable?  Picks the
+// prefetch depth (IQ samples per lane) of the template variant.
 bool frontcm_ok(int K1, int lgD1, int K2, int lgD2, int* pf) {
     const int K = K1 + (K2 - 1) * (1 << lgD1), lgD = lgD1 + lgD2;
-    if (K < 9 || lgD < 1 || lgD > 4) { return false; }
+    if (K < 9 || lgD < 1 || lgD > 5) { return false; }
     const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
-    if (nsamp > 9 * 256) { return false; }
-    *pf = nsamp <= 5 * 256 ? 5 : 9;
-    return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU (the register budget allows no more)
+    if (nsamp > 16 * 64) { return false; }
+    *pf = nsamp <= 6 * 64 ? 6 : (nsamp <= 10 * 64 ? 10 : 16);
+    return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU
 }
 
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
@@ -578,6 +705,24 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<PreJob> pre;
     std::vector<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
+    // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
+    std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
+    auto toep_job = [](const ToepTab& T, int var, StreamIn in, float* out, int base0, int nout, float inv_dev) {
+        ToepJob j{};
+        j.in = in;
+        j.out = out;
+        j.tl = T.d_tl;
+        j.lbase = T.d_lb + (size_t)var * 64;
+        j.tl_len = T.tl_len;
+        j.nsteps = T.nsteps;
+        j.s_in = T.s_in;
+        j.rows = T.rows;
+        j.base0 = base0;
+        j.nout = nout;
+        j.mt_per_wave = 1;
+        j.inv_deviation = inv_dev;
+        return j;
+    };
     int max_rot = 0;
 
     for (auto& kv : c->vfos) {
@@ -621,7 +766,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 Stream* nxt = &v.st[(size_t)v.i_first + s];
                 const int Ds = v.d.stage_decim[s];
                 const int no = decim_nout(cur->n, v.soff[s], Ds);
-                lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] });
+                if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
+                else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
                 v.soff[s] = v.soff[s] + no * Ds - cur->n;
                 nxt->n = no;
                 cur = nxt;
@@ -630,7 +776,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (v.i_poly >= 0) {
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
-            if (v.d_cyc) {
+            if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
+            else if (v.d_cyc) {
                 polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
             }
@@ -645,7 +792,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp });
+            if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
+            else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
             cur = nxt;
         }
@@ -655,8 +803,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
-            FirBJob jb{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation };
-            audio_fm.push_back(jb);
+            if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
+            else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
         }
         else if (v.d.demod == SDRPP_DEMOD_AM) {
@@ -665,7 +813,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!v.d.am_carrier_agc) { pre.push_back(PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
             seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc });
             dem.n = nif;
-            audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp });
+            if (v.tp_audio.ok) { t_audio.push_back(toep_job(v.tp_audio, 0, stream_in(dem), out.data, -(v.audio_ntaps - 1), nif, 0.0f)); }
+            else { audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp }); }
             out.n = nif;
         }
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
@@ -710,7 +859,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; };
     S1Launch s1l[4];
     F2Launch f2l[4];
-    FCMLaunch fcm[2];  // [PF == 9]
+    FCMLaunch fcm[3];  // PF 6 / 10 / 16
     const int vts[4] = { 8, 4, 2, 1 };
     for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
     size_t i = 0;
@@ -787,8 +936,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             job.nout = h.nout2;
             job.min_idx = h.min_idx;
             const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
-            // one resident round: 256 CUs x 3 blocks (a second, partly filled round would cost as much as the first)
-            job.tiles_per_block = std::max(1, (ntiles + 767) / 768);
+            // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first)
+            job.tiles_per_wave = std::max(1, (ntiles + 3071) / 3072);
             job.atab = reinterpret_cast<const float*>(d_taps);
             job.ptab = d_taps + (size_t)NP4 * 32;
             for (int m = 0; m < SDRPP_FCM_VT; m++) {
@@ -797,9 +946,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
                 job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
             }
-            FCMLaunch& L = fcm[m_pf == 9 ? 1 : 0];
+            FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
             L.jobs.push_back(job);
-            L.max_blocks = std::max(L.max_blocks, (ntiles + job.tiles_per_block - 1) / job.tiles_per_block);
+            L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
             L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
             g += (size_t)vt;
         }
@@ -914,12 +1063,51 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
     }
-    FrontCMJob* d_fcm[2] = {};
-    for (int k = 0; k < 2; k++) {
+    FrontCMJob* d_fcm[3] = {};
+    for (int k = 0; k < 3; k++) {
         if (!fcm[k].jobs.empty()) {
             d_fcm[k] = arena_push(c, fcm[k].jobs);
             if (!d_fcm[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
+    }
+    // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
+    struct ToepPlan { int grid_x = 0; size_t lds = 0; };
+    auto toep_plan = [&](std::vector<ToepJob>& jobs, int npl) {
+        ToepPlan P;
+        if (jobs.empty()) { return P; }
+        const int G = 2;
+        int mtw = 1;
+        for (; mtw < 16; mtw++) {  // one resident round: <= 256 CUs x 4 blocks of four wavefronts (each job padded to whole blocks)
+            size_t blocks = 0;
+            for (auto& jb : jobs) { blocks += (size_t)((jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows) + 4 * mtw - 1) / (size_t)(4 * mtw); }
+            if (blocks <= 1024) { break; }
+        }
+        for (auto& jb : jobs) {
+            jb.mt_per_wave = mtw;
+            const int nmt = (jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows);
+            P.grid_x = std::max(P.grid_x, (nmt + 4 * mtw - 1) / (4 * mtw));
+            const int span = (G * 16 - 1) * jb.s_in + 4 * jb.nsteps, pl = (span + 8) & ~3;
+            P.lds = std::max(P.lds, ((size_t)((jb.tl_len + 3) & ~3) + (size_t)4 * npl * pl) * sizeof(float));
+        }
+        return P;
+    };
+    ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
+    ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
+    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+        tp_lvl[s] = toep_plan(t_lvl[s], 2);
+        d_t_lvl[s] = arena_push(c, t_lvl[s]);
+        if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    }
+    const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
+    ToepJob* d_t_poly = arena_push(c, t_poly);
+    ToepJob* d_t_chan = arena_push(c, t_chan);
+    ToepJob* d_t_audio = arena_push(c, t_audio);
+    ToepJob* d_t_audio_fm = arena_push(c, t_audio_fm);
+    if ((!t_poly.empty() && !d_t_poly) || (!t_chan.empty() && !d_t_chan) || (!t_audio.empty() && !d_t_audio) || (!t_audio_fm.empty() && !d_t_audio_fm)) {
+        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
+    }
+    if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
+        return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS");
     }
     RotJob* d_rot = arena_push(c, rot);
     FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
@@ -943,7 +1131,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
         if (!lvl[s].empty() && !d_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
-    int rc = arena_commit(c);
+    int rc;
+    {
+        HostScope hs("arena_commit (H2D)");
+        rc = arena_commit(c);
+    }
     if (rc) { return rc; }
 
     // ---- launches ----
@@ -990,14 +1182,15 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             default: launch(c, vfo_front2_kernel<1, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
             }
         }
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             if (fcm[k].jobs.empty() || fcm[k].max_blocks == 0) { continue; }
             const dim3 grid((unsigned)fcm[k].max_blocks, (unsigned)fcm[k].jobs.size());
             bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
             for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
-            if (k == 1 && all_132_4) { launch(c, vfo_frontcm_kernel<9, 132, 4>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
-            else if (k == 1) { launch(c, vfo_frontcm_kernel<9, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
-            else { launch(c, vfo_frontcm_kernel<5, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            if (k == 1 && all_132_4) { launch(c, vfo_frontcm_kernel<10, 132, 4>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            else if (k == 0) { launch(c, vfo_frontcm_kernel<6, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            else if (k == 1) { launch(c, vfo_frontcm_kernel<10, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            else { launch(c, vfo_frontcm_kernel<16, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
         }
         if (!rot.empty() && max_rot > 0) {
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
@@ -1032,12 +1225,24 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         else { launch(c, vfo_firb_kernel<1, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         return SDRPP_OK;
     };
+    auto launch_toep = [&](std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
+        if (jobs.empty() || P.grid_x == 0) { return; }
+        const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
+        if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+        else if (width == 2) { launch(c, vfo_toep_kernel<2, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+        else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    };
     {
         FamilyTimer t(c, F_DECIM);
         for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+            launch_toep(t_lvl[s], d_t_lvl[s], tp_lvl[s], 2, false);
             rc = launch_fir(lvl[s], d_lvl[s], 2, false);
             if (rc) { return rc; }
         }
+    }
+    if (!t_poly.empty()) {
+        FamilyTimer t(c, F_POLY);
+        launch_toep(t_poly, d_t_poly, tp_poly, 2, false);
     }
     if (!poly.empty()) {
         FamilyTimer t(c, F_POLY);
@@ -1076,6 +1281,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     {
         FamilyTimer t(c, F_FIR);
+        launch_toep(t_chan, d_t_chan, tp_chan, 2, false);
         rc = launch_fir(chan, d_chan, 2, false);
         if (rc) { return rc; }
     }
@@ -1095,6 +1301,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     {
         FamilyTimer t(c, F_FIR);
+        launch_toep(t_audio, d_t_audio, tp_audio, 1, false);
+        launch_toep(t_audio_fm, d_t_audio_fm, tp_audio_fm, 1, true);
         rc = launch_fir(audio, d_audio, 1, true);
         if (rc) { return rc; }
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
@@ -1137,17 +1345,24 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     }
     int rc = ensure_iq_hist(c, need_hist);
     if (rc) { return rc; }
-    rc = arena_begin(c);
+    {
+        HostScope hs("arena_begin (backpressure)");
+        rc = arena_begin(c);
+    }
     if (rc) { return rc; }
     IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
     // fork: the FFT branch goes to its own stream and overlaps the VFO bank; both only read the IQ buffers
     const bool fork = c->fft_on && !c->vfos.empty();
     if (fork) {
+        HostScope hs("fork events");
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->fft_stream, c->ev_fork, 0));
         c->launch_stream = c->fft_stream;
     }
-    rc = do_fft(c, src, count);
+    {
+        HostScope hs("do_fft");
+        rc = do_fft(c, src, count);
+    }
     c->launch_stream = c->stream;
     if (rc) { return rc; }
     if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->fft_stream)); }
@@ -1176,9 +1391,11 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
         launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
     }
     else {
+        HostScope hs("do_vfos");
         rc = do_vfos(c, src, count, carry);
         if (rc) { return rc; }
     }
+    HostScope hs2("join + arena_end");
     if (fork) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     c->iq_cur ^= 1;
     rc = arena_end(c);
@@ -1242,7 +1459,8 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         return SDRPP_ERR_NO_DEVICE;
     }
     for (int i = 0; i < kArenaSlots; i++) {
-        if (hipHostMalloc((void**)&c->arena_host[i], kArenaBytes, hipHostMallocDefault) != hipSuccess || hipEventCreate(&c->arena_ev[i]) != hipSuccess) {
+        if (hipHostMalloc((void**)&c->arena_host[i], kArenaBytes, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c->arena_host_dev[i], c->arena_host[i], 0) != hipSuccess || hipEventCreate(&c->arena_ev[i]) != hipSuccess) {
             sdrpp_destroy(c);
             return SDRPP_ERR_NOMEM;
         }
@@ -1259,6 +1477,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     if (!c) { return SDRPP_OK; }
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    g_hostprof.report();
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
     c->vfos.clear();
     for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
@@ -1487,6 +1706,11 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         if (rc) { return rc; }
         rc = upload(c, &v->d_staps_nat[s], v->staps[s].data(), v->staps[s].size());
         if (rc) { return rc; }
+        if (s >= 1) {
+            v->tp_stage[s].kind = 1;
+            rc = toep_build_fir(c, v->tp_stage[s], v->staps[s].data(), (int)v->staps[s].size(), d->stage_decim[s]);
+            if (rc) { return rc; }
+        }
         cap = cap / (size_t)d->stage_decim[s] + 2;
         const int hist = (s + 1 < d->n_stages) ? d->stage_ntaps[s + 1] - 1 : hist_after_decim();
         if (add_stream(2, hist, cap) < 0) { return SDRPP_ERR_NOMEM; }
@@ -1503,6 +1727,9 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         const int tot = d->interp * tpp;
         for (int i = 0; i < tot; i++) { bank[(size_t)((d->interp - 1) - (i % d->interp)) * tpp + (size_t)(i / d->interp)] = (i < d->resamp_ntaps) ? v->rtaps[(size_t)i] : 0.0f; }  // polyphase_bank.h:31-34
         rc = upload(c, &v->d_bank, bank.data(), bank.size());
+        if (rc) { return rc; }
+        v->tp_poly.kind = 2;
+        rc = toep_build_poly(c, v->tp_poly, bank, d->interp, d->decim, tpp);
         if (rc) { return rc; }
         if (d->interp <= 8) {  // register-blocked kernel: per carried phase, taps of one full phase cycle
             const int L = d->interp, M = d->decim, lmax = (L <= 4) ? 4 : 8, rows = tpp + M;
@@ -1530,6 +1757,9 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         v->ctaps_chan.assign(d->chan_taps, d->chan_taps + d->chan_ntaps);
         rc = upload_blocked(c, &v->d_chan, v->ctaps_chan.data(), (int)v->ctaps_chan.size(), 1, &v->chan_kp);
         if (rc) { return rc; }
+        v->tp_chan.kind = 4;
+        rc = toep_build_fir(c, v->tp_chan, v->ctaps_chan.data(), (int)v->ctaps_chan.size(), 1);
+        if (rc) { return rc; }
         v->chan_ntaps = d->chan_ntaps;
     }
     v->d.chan_taps = nullptr;
@@ -1542,6 +1772,9 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             v->ataps.assign(at, at + an);
             v->audio_ntaps = an;
             rc = upload_blocked(c, &v->d_audio, v->ataps.data(), (int)v->ataps.size(), 1, &v->audio_kp);
+            if (rc) { return rc; }
+            v->tp_audio.kind = 8;
+            rc = toep_build_fir(c, v->tp_audio, v->ataps.data(), (int)v->ataps.size(), 1);
             if (rc) { return rc; }
             if (!fm) {  // AM: the sequential envelope/AGC kernel writes a real stream for the low-pass; FM demodulates inside the FIR kernel
                 v->i_dem = add_stream(1, std::max(an - 1, 1), cap);
@@ -1607,7 +1840,12 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     v.ctaps_chan.assign(taps, taps + n);
     v.chan_ntaps = n;
     v.d.chan_ntaps = n;
-    if (n > 0) { return upload_blocked(c, &v.d_chan, v.ctaps_chan.data(), n, 1, &v.chan_kp); }
+    if (n > 0) {
+        int rc = upload_blocked(c, &v.d_chan, v.ctaps_chan.data(), n, 1, &v.chan_kp);
+        if (rc) { return rc; }
+        v.tp_chan.kind = 4;
+        return toep_build_fir(c, v.tp_chan, v.ctaps_chan.data(), n, 1);
+    }
     return SDRPP_OK;
 }
 

@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Fro
 // intermediate stream is never rounded to f32) — far inside the 1e-5 RMS bar, see tests/test_parity_vfo.py.
 // =====================================================================================================================
 #define SDRPP_FCM_VT 32
-#define SDRPP_FCM_TILE 128
+#define SDRPP_FCM_TILE 32   // outputs per wavefront tile (the N of the matrix instruction)
 struct FrontCMJob {
     int nv;
     int ntaps;        // composite K
@@ -865,9 +865,9 @@ struct FrontCMJob {
     int off;          // push-relative IQ index of tap 0 of output 0 (negative: history)
     int nout;         // outputs of this push (= stage-2 outputs)
     int min_idx;      // IQ samples before this push-relative index read as zero
-    int tiles_per_block;
+    int tiles_per_wave;
     const float* atab;    // [npad][64]: lane l -> (l < 32 ? gr : -gi) of VFO l & 31 (0 for unused VFO slots and padding rows)
-    const float2* ptab;   // [32][SDRPP_FCM_TILE] exp(j*2*pi*theta_v*D*n): NCO advance inside a tile
+    const float2* ptab;   // [32][32] exp(j*2*pi*theta_v*D*n): NCO advance inside a tile
     double theta[SDRPP_FCM_VT];
     double phi0[SDRPP_FCM_VT];
     float2* out[SDRPP_FCM_VT];
@@ -878,21 +878,25 @@ __host__ __device__ inline int frontcm_plane(int nsamp, int lgD) {
     const int sk = nsamp + (nsamp >> lgD) + 1;
     return ((sk + 31) / 64) * 64 + 32;
 }
-// LDS map (float offsets): [IQ planes XR, XI | tap operand table | tile phasors (double buffered)]
-struct FCMLayout { int pl, a_off, pt_off, total; };
+// LDS map (float offsets): [4 wavefronts x (XR, XI planes) | tap operand table | 4 x 32 tile phasors | 32 output pointers]
+struct FCMLayout { int pl, a_off, pt_off, out_off, total; };
 __host__ __device__ inline FCMLayout frontcm_layout(int K, int lgD) {
     FCMLayout L;
     const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
     const int np4 = ((((K + 1) >> 1) + 3) >> 2) << 2;
     L.pl = frontcm_plane(nsamp, lgD);
-    L.a_off = 2 * L.pl;
+    L.a_off = 4 * 2 * L.pl;
     L.pt_off = L.a_off + np4 * 64;
-    L.total = L.pt_off + 2 * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // + the 32 output pointers
+    L.out_off = L.pt_off + 4 * SDRPP_FCM_VT * 2;
+    L.total = L.out_off + SDRPP_FCM_VT * 2;
     return L;
 }
 
-// PF: IQ samples prefetched per work-item (>= ceil(nsamp / 256)); KS > 0: geometry known at compile time (fully unrolled matrix
-// loop: every LDS offset is an immediate, the pair reads fuse into ds_read2_b32 and no scalar index arithmetic is left)
+// Every WAVEFRONT is an independent tile engine: it owns two skewed IQ planes in LDS, walks over `tiles_per_wave` consecutive
+// 32-output tiles and never meets a workgroup barrier after the prologue (the four wavefronts of a block only share the tap
+// table), so the matrix pipe of a SIMD always has several unsynchronised wavefronts to pick from.
+// PF: IQ samples prefetched per lane (>= ceil(nsamp / 64)); KS > 0: geometry known at compile time (fully unrolled matrix loop:
+// every LDS offset is an immediate, the pair reads fuse into ds_read2_b32 and no scalar index arithmetic is left)
 template <int PF, int KS, int LGDS>
 __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemf)
@@ -903,16 +907,22 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
     const bool odd = (K & 1) != 0;
     const int nsamp = (tile - 1) * D + K;
     const FCMLayout L = frontcm_layout(K, lgD);
-    float* XR = smemf;
-    float* XI = smemf + L.pl;
-    float* AL = smemf + L.a_off;
-    float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off);  // [2][VT]
-    float2** outp = reinterpret_cast<float2**>(smemf + L.pt_off + 2 * VT * 2);  // [VT]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
-    const int tile0 = blockIdx.x * job.tiles_per_block;
+    float* XR = smemf + wv * 2 * L.pl;
+    float* XI = XR + L.pl;
+    float* AL = smemf + L.a_off;
+    float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off) + wv * VT;  // [VT], private to the wavefront
+    float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);        // [VT]
+
+    // ---- block prologue: tap operand table and output pointers (the only workgroup barrier of the kernel) ----
+    for (int i = tid; i < NP4 * 64; i += 256) { AL[i] = global_load_f32(job.atab, i); }
+    if (tid < VT) { outp[tid] = job.out[tid]; }
+    __syncthreads();
+
+    const int tile0 = (blockIdx.x * 4 + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
-    int ntl = (job.nout - tile0 * tile + tile - 1) / tile;  // tiles this block really has
-    if (ntl > job.tiles_per_block) { ntl = job.tiles_per_block; }
+    int ntl = (job.nout - tile0 * tile + tile - 1) / tile;  // tiles this wavefront really has
+    if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
 
     auto tile_base = [&](int tb) -> long long { return (long long)job.off + (long long)tb * tile * D; };
     float2 pf[PF];
@@ -921,14 +931,14 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
             const float2* p = src.cur + base;
 #pragma unroll
             for (int q = 0; q < PF; q++) {
-                const int sidx = tid + q * 256;
+                const int sidx = lane + q * 64;
                 pf[q] = (sidx < nsamp) ? p[sidx] : make_float2(0.0f, 0.0f);
             }
         }
         else {
 #pragma unroll
             for (int q = 0; q < PF; q++) {
-                const int sidx = tid + q * 256;
+                const int sidx = lane + q * 64;
                 const long long gi = base + sidx;
                 pf[q] = (sidx < nsamp && gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
             }
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
     auto planes_store = [&]() {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const int sidx = tid + q * 256;
+            const int sidx = lane + q * 64;
             if (sidx < nsamp) {
                 const int idx = sidx + (sidx >> lgD);
                 XR[idx] = pf[q].x;
@@ -945,67 +955,80 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
             }
         }
     };
-    auto tile_phasor = [&](int tb, int slot) {
-        if (tid < VT && tid < job.nv) {
-            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[tid], job.phi0[tid]);
+    auto tile_phasor = [&](int tb) {
+        if (lane < VT && lane < job.nv) {
+            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);
-            ptile[slot * VT + tid] = make_float2(cs, sn);
+            ptile[lane] = make_float2(cs, sn);
         }
     };
 
-    // ---- prologue: first IQ tile, the tap operand table and this lane's slice of the in-tile NCO table ----
-    fetch(tile_base(tile0));
-    for (int i = tid; i < NP4 * 64; i += 256) { AL[i] = global_load_f32(job.atab, i); }
-    if (tid < VT) { outp[tid] = job.out[tid]; }
-    const int n = wv * 32 + jl;  // output (within the tile) whose B column / D column this lane holds
+    // ---- wavefront prologue: this lane's slice of the in-tile NCO table, first IQ tile ----
     float2 pt[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        pt[r] = global_load_f32x2(job.ptab, v * tile + n);
+        pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
     }
-    planes_store();
-    tile_phasor(tile0, 0);
-    if (ntl > 1) { fetch(tile_base(tile0 + 1)); }
-    __syncthreads();
+    fetch(tile_base(tile0));
 
     const float sgn = hi ? -1.0f : 1.0f;
     const float* P1 = hi ? XI : XR;
     const float* P2 = hi ? XR : XI;
-    const int ib = n * D + n;  // skewed index of IQ sample n * D
+    const int ib = jl * D + jl;  // skewed index of IQ sample jl * D
     for (int it = 0; it < ntl; it++) {
         const int tb = tile0 + it;
+        planes_store();   // registers -> this wavefront's planes (the previous tile's reads are complete: wave_sync below)
+        tile_phasor(tb);
+        if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop
+        wave_sync();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
-        // operands of pair p: B = (sums | differences) of the two IQ samples the pair touches, A = its tap column
-        auto operands = [&](int p, float& a_re, float& bre, float& bim) {
-            const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
-            const int kb = K - 1 - pe;
-            const int ia = ib + pe + (pe >> lgD), ibb = ib + kb + (kb >> lgD);
-            const float a1 = P1[ia], a2 = P2[ia];
-            float b1 = P1[ibb], b2 = P2[ibb];
-            if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }  // centre tap of an odd filter: a "pair" with itself
-            bre = fmaf(sgn, b1, a1);  // lanes 0-31: sr = a.re + b.re   lanes 32-63: di = a.im - b.im
-            bim = fmaf(sgn, b2, a2);  // lanes 0-31: si = a.im + b.im   lanes 32-63: dr = a.re - b.re
-            a_re = AL[p * 64 + lane];  // (gr, -gi)
-        };
         if constexpr (KS > 0) {
+            // software pipeline: the LDS reads of pair p + 2 are issued (and fenced) two pairs = four matrix instructions ahead of
+            // their use, so the wave never waits out an LDS latency in front of a v_mfma
             constexpr int NPS = (KS + 1) / 2;
-            float a_c, br_c, bi_c;
-            operands(0, a_c, br_c, bi_c);
+            float ra[3], r1a[3], r1b[3], r2a[3], r2b[3];
+            auto issue = [&](int p, int slot) {
+                const int kb = K - 1 - p;
+                const int ia = ib + p + (p >> lgD), ibb = ib + kb + (kb >> lgD);
+                ra[slot] = AL[p * 64 + lane];
+                r1a[slot] = P1[ia];
+                r1b[slot] = P1[ibb];
+                r2a[slot] = P2[ia];
+                r2b[slot] = P2[ibb];
+            };
+            issue(0, 0);
+            if (NPS > 1) { issue(1, 1); }
 #pragma unroll
             for (int p = 0; p < NPS; p++) {
-                float a_n = 0.0f, br_n = 0.0f, bi_n = 0.0f;
-                if (p + 1 < NPS) { operands(p + 1, a_n, br_n, bi_n); }  // one pair ahead of the matrix core
-                accR = mfma_32x32x2(a_c, br_c, accR);
-                accI = mfma_32x32x2(hi ? -a_c : a_c, bi_c, accI);  // (gr, +gi)
-                a_c = a_n;
-                br_c = br_n;
-                bi_c = bi_n;
+                if (p + 2 < NPS) { issue(p + 2, (p + 2) % 3); }
+                sched_fence();
+                const int sl = p % 3;
+                float b1 = r1b[sl], b2 = r2b[sl];
+                if ((KS & 1) && p == NPS - 1) { b1 = 0.0f; b2 = 0.0f; }  // centre tap of an odd filter: a "pair" with itself
+                const float bre = fmaf(sgn, b1, r1a[sl]);  // lanes 0-31: sr = a.re + b.re   lanes 32-63: di = a.im - b.im
+                const float bim = fmaf(sgn, b2, r2a[sl]);  // lanes 0-31: si = a.im + b.im   lanes 32-63: dr = a.re - b.re
+                const float a_re = ra[sl];                 // (gr, -gi)
+                accR = mfma_32x32x2(a_re, bre, accR);
+                accI = mfma_32x32x2(hi ? -a_re : a_re, bim, accI);  // (gr, +gi)
+                sched_fence();
             }
         }
         else {
+            // operands of pair p: B = (sums | differences) of the two IQ samples the pair touches, A = its tap column
+            auto operands = [&](int p, float& a_re, float& bre, float& bim) {
+                const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
+                const int kb = K - 1 - pe;
+                const int ia = ib + pe + (pe >> lgD), ibb = ib + kb + (kb >> lgD);
+                const float a1 = P1[ia], a2 = P2[ia];
+                float b1 = P1[ibb], b2 = P2[ibb];
+                if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
+                bre = fmaf(sgn, b1, a1);
+                bim = fmaf(sgn, b2, a2);
+                a_re = AL[p * 64 + lane];
+            };
             float a_c, br_c, bi_c;
             operands(0, a_c, br_c, bi_c);
             for (int p0 = 0; p0 < NP4; p0 += 4) {
@@ -1021,28 +1044,187 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
                 }
             }
         }
-        __syncthreads();  // A: every wavefront is done with the IQ planes
-        if (it + 1 < ntl) {
-            planes_store();  // next tile (its loads were issued one tile ago)
-            tile_phasor(tb + 1, (it + 1) & 1);
-            if (it + 2 < ntl) { fetch(tile_base(tb + 2)); }
-        }
         // ---- NCO: tile phasor x in-tile advance, then coalesced stores (lanes = consecutive outputs of one VFO) ----
         {
             const int j0 = tb * tile;
-            const bool live = j0 + n < job.nout;
-            const float2* pq = ptile + (it & 1) * VT;
+            const bool live = j0 + jl < job.nout;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (v < job.nv && live) {
-                    const float2 P = pq[v];
+                    const float2 P = ptile[v];
                     const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
-                    global_store_f32x2(outp[v], j0 + n, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+                    global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
                 }
             }
         }
-        __syncthreads();  // B: next IQ planes and tile phasors visible
+        wave_sync();  // every lane is done with the planes and tile phasors before the next tile overwrites them
+    }
+}
+
+// =====================================================================================================================
+// Per-stream FIR work on the matrix cores ("Toeplitz" form).  Any of the per-VFO filters behind the front end — a decimating
+// FIR, the channel filter, the audio low-pass (optionally with the FM discriminator fused into the load), the polyphase
+// resampler — computes   out[q * rows + m] = sum_k  B[k][m] * x[base + q * s_in + k]   for consecutive "tiles" q:
+// every tile applies the same small banded matrix B (k = input offset inside the tile window, m = output inside the tile:
+// B[k][m] = h[k - D * m] for a FIR decimating by D, bank[phase_m][k - shift_m] for the resampler) to a window of the stream.
+// Sixteen tiles side by side are one v_mfma_f32_16x16x4_f32 chain: A[i = tile][k] = x[base + i * s_in + k] (data, one LDS read
+// per lane and step), B from a zero-padded tap table through a per-lane base index (one LDS read), D[i = tile][j = m].
+// Only 15 of the 16 matrix columns are used per tile (rows = 15 for FIRs): s_in = 15 * D is then odd or 2 (mod 4), so the
+// 16 lanes that read 16 different tiles fall on different LDS banks without any address skew and every offset is an immediate.
+// Efficiency = K / (K + (rows - 1) * D) of the matrix work (the band), at 4x the VALU FMA rate and no register-blocked tap loop.
+// A WAVEFRONT is an independent engine (private LDS window, no workgroup barriers after the tap table is loaded); G groups of
+// 16 tiles share the B operand.
+// =====================================================================================================================
+struct ToepJob {
+    StreamIn in;
+    float* out;
+    const float* tl;       // [tl_len] zero-padded tap table
+    const int* lbase;      // [64] per-lane base index into tl (includes the lane's k = lane >> 4)
+    int tl_len, nsteps;    // matrix steps (4 input offsets each)
+    int s_in, rows;        // input samples / outputs per tile
+    int base0;             // stream index of window offset 0 of tile 0
+    int nout;
+    int mt_per_wave;       // macro tiles (G * 16 tiles) per wavefront
+    float inv_deviation;   // QUAD only
+};
+
+template <int WIDTH, int G, bool QUAD>
+__global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemt)
+    const ToepJob& job = jobs[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nsteps = job.nsteps, s_in = job.s_in, rows = job.rows;
+    const int span = (G * 16 - 1) * s_in + 4 * nsteps;  // window of one macro tile
+    const int pl = (span + 8) & ~3;
+    constexpr int NPL = (WIDTH == 2 || QUAD) ? 2 : 1;
+    const int tl_pad = (job.tl_len + 3) & ~3;
+    float* TLs = smemt;
+    float* XR = smemt + tl_pad + wv * NPL * pl;
+    float* XI = XR + pl;  // imaginary plane, or the phase scratch of the fused discriminator
+    for (int i = tid; i < job.tl_len; i += 256) { TLs[i] = global_load_f32(job.tl, i); }
+    __syncthreads();  // the only workgroup barrier
+    const int omt = G * 16 * rows;  // outputs per macro tile
+    const int mt0 = (blockIdx.x * 4 + wv) * job.mt_per_wave;
+    const int c = lane & 15, kk = lane >> 4;
+    const float* Bp = TLs + global_load_i32(job.lbase, lane);
+    const float* Ar = XR + c * s_in + kk;
+    const float* Ai = XI + c * s_in + kk;
+    // window fetch: all loads of a macro tile are in flight together (registers), and the NEXT window is fetched while the matrix
+    // cores work on the current one.  A window longer than PF * 64 samples (very long filters) is loaded in place, unpipelined.
+    constexpr int PF = 18;
+    constexpr bool CPLX_IN = (WIDTH == 2) || QUAD;
+    const int cnt = QUAD ? span + 1 : span;  // QUAD needs one more sample in front: d[i] uses x[i - 1]
+    const bool piped = cnt <= PF * 64;
+    float2 pf2[CPLX_IN ? PF : 1];
+    float pf1[CPLX_IN ? 1 : PF];
+    auto fetch = [&](int mt) {
+        const int lo = job.base0 + mt * G * 16 * s_in - (QUAD ? 1 : 0);
+        const bool inside = lo >= 0 && lo + cnt <= job.in.n;  // all but the first and last macro tiles: no history / end tests
+        if constexpr (CPLX_IN) {
+            if (inside) {
+                const float2* src2 = reinterpret_cast<const float2*>(job.in.data) + lo;
+#pragma unroll
+                for (int q = 0; q < PF; q++) {
+                    const int s = q * 64 + lane;
+                    pf2[q] = (s < cnt) ? global_load_f32x2(src2, s) : make_float2(0.0f, 0.0f);
+                }
+            }
+            else {
+#pragma unroll
+                for (int q = 0; q < PF; q++) {
+                    const int s = q * 64 + lane;
+                    pf2[q] = (s < cnt) ? stream_load2(job.in, lo + s) : make_float2(0.0f, 0.0f);
+                }
+            }
+        }
+        else {
+            if (inside) {
+#pragma unroll
+                for (int q = 0; q < PF; q++) {
+                    const int s = q * 64 + lane;
+                    pf1[q] = (s < cnt) ? global_load_f32(job.in.data + lo, s) : 0.0f;
+                }
+            }
+            else {
+#pragma unroll
+                for (int q = 0; q < PF; q++) {
+                    const int s = q * 64 + lane;
+                    pf1[q] = (s < cnt) ? stream_load1(job.in, lo + s) : 0.0f;
+                }
+            }
+        }
+    };
+    auto window_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int s = q * 64 + lane;
+            if (s < cnt) {
+                if constexpr (QUAD) { XI[s] = atan2f(pf2[q].y, pf2[q].x); }
+                else if constexpr (WIDTH == 2) {
+                    XR[s] = pf2[q].x;
+                    XI[s] = pf2[q].y;
+                }
+                else { XR[s] = pf1[q]; }
+            }
+        }
+    };
+    if (piped && mt0 * omt < job.nout) { fetch(mt0); }
+    for (int it = 0; it < job.mt_per_wave; it++) {
+        const int mt = mt0 + it;
+        const int obase = mt * omt;
+        if (obase >= job.nout) { break; }
+        if (piped) {
+            window_store();
+            if (it + 1 < job.mt_per_wave && (mt + 1) * omt < job.nout) { fetch(mt + 1); }
+        }
+        else {
+            const int lo = job.base0 + mt * G * 16 * s_in - (QUAD ? 1 : 0);
+            for (int s = lane; s < cnt; s += 64) {
+                if constexpr (QUAD) {
+                    const float2 x = stream_load2(job.in, lo + s);
+                    XI[s] = atan2f(x.y, x.x);
+                }
+                else if constexpr (WIDTH == 2) {
+                    const float2 x = stream_load2(job.in, lo + s);
+                    XR[s] = x.x;
+                    XI[s] = x.y;
+                }
+                else { XR[s] = stream_load1(job.in, lo + s); }
+            }
+        }
+        if constexpr (QUAD) {
+            // quadrature.h:39-46 fused into the load: d[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation
+            wave_sync();
+            for (int s = lane; s < span; s += 64) { XR[s] = normalize_phase(XI[s + 1] - XI[s]) * job.inv_deviation; }
+        }
+        wave_sync();
+        f32x4 accR[G], accI[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) { accR[g] = mfma4_zero(); accI[g] = mfma4_zero(); }
+        for (int t = 0; t < nsteps; t++) {
+            const float b = Bp[4 * t];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                accR[g] = mfma_16x16x4(Ar[g * 16 * s_in + 4 * t], b, accR[g]);
+                if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(Ai[g * 16 * s_in + 4 * t], b, accI[g]); }
+            }
+        }
+        // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r
+        if (c < rows) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int o = obase + (g * 16 + 4 * kk + r) * rows + c;
+                    if (o < job.nout) {
+                        if constexpr (WIDTH == 2) { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(accR[g][r], accI[g][r])); }
+                        else { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(accR[g][r], accR[g][r])); }  // mono -> stereo
+                    }
+                }
+            }
+        }
+        wave_sync();  // the next macro tile overwrites the window
     }
 }
 

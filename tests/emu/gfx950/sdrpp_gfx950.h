@@ -9,8 +9,11 @@ struct UniformF32 {
 };
 static inline UniformF32 as_uniform(const void* ptr) { return UniformF32{ (const float*)ptr }; }
 static inline float global_load_f32(const float* p, long long i) { return p[i]; }
+static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
+static inline void sched_fence() {}
+static inline void wave_sync() { hipemu::wave_exchange(0.0f, 0.0f); }  // fibers run lane by lane: a real 64-lane rendezvous
 // v_mfma_f32_32x32x2_f32 emulated with a 64-lane rendezvous (hipemu::wave_exchange): same lane <-> element maps, same fmaf chain.
 struct f32x16 {
     float v[16];
@@ -26,6 +29,23 @@ static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
         float d = c.v[r];
         d = fmaf(ab[(i) * 2], ab[(j) * 2 + 1], d);            // k = 0: A from lane i, B from lane j
         d = fmaf(ab[(i + 32) * 2], ab[(j + 32) * 2 + 1], d);  // k = 1: lanes i + 32 / j + 32
+        c.v[r] = d;
+    }
+    return c;
+}
+struct f32x4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+static inline f32x4 mfma4_zero() { f32x4 z; for (int i = 0; i < 4; i++) { z.v[i] = 0.0f; } return z; }
+static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    const float* ab = hipemu::wave_exchange(a, b);
+    const int lane = hipemu::lane_id(), j = lane & 15, g = lane >> 4;
+    for (int r = 0; r < 4; r++) {
+        const int i = 4 * g + r;
+        float d = c.v[r];
+        for (int k = 0; k < 4; k++) { d = fmaf(ab[(i + 16 * k) * 2], ab[(j + 16 * k) * 2 + 1], d); }  // A from lane i + 16k, B from lane j + 16k
         c.v[r] = d;
     }
     return c;

@@ -32,6 +32,7 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{ x, y }; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{ x, y, z, w }; }
 static inline int2 make_int2(int x, int y) { return int2{ x, y }; }
@@ -161,6 +162,8 @@ typedef struct hipemuEvent { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
+#define hipHostMallocMapped 2
+static inline int hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
 static inline hipError_t hipGetLastError() { return 0; }
