@@ -93,9 +93,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--push", type=int, default=1 << 22, help="complex samples per step (multiple of the FFT size)")
+    ap.add_argument("--push", type=int, default=1 << 24, help="complex samples per step (multiple of the FFT size); 2^24 = 1.7 s of the 10 MS/s stream per GPU and step")
     ap.add_argument("--nvfo", type=int, default=32)
-    ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 32 MiB > the 256 MiB MALL)")
+    ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 128 MiB at the default push: never resident in the 256 MiB MALL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fft-only", action="store_true", help="BASELINE cfg2 (no VFOs) instead of cfg3")
     ap.add_argument("--cfg", type=int, default=0, help="explicit BASELINE config: 2 (FFT only), 3 (headline), 4 (61.44 MS/s, 128 mixed VFOs, 2^20-pt FFT)")
@@ -155,7 +155,12 @@ def main():
     torch.cuda.synchronize()
     fam_all = ctx.timing_read()
     kernel_ms_all = {k: v[0] / ncal for k, v in fam_all.items() if v[0] > 0}
-    dom = max(kernel_ms_all, key=kernel_ms_all.get) if kernel_ms_all else None
+    # dominant family = the longest one on the CRITICAL stream: with VFOs present the FFT branch runs on a second stream as filler
+    # behind the VFO bank (its launches stretch while they wait for CUs, which says nothing about the kernels themselves), so only
+    # the VFO-bank families compete; FFT-only runs (cfg 2) have just the FFT families
+    filler = {"fft_pass1", "fft_pass2", "fft_single", "zoom_palette"} if nvfo else set()
+    cand = {k: v for k, v in kernel_ms_all.items() if k not in filler} or kernel_ms_all
+    dom = max(cand, key=cand.get) if cand else None
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -298,7 +303,13 @@ def main():
                 out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out))
+    try:  # C stdio of anything loaded into this process goes out BEFORE the JSON line, which must be the last line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

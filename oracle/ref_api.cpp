@@ -16,6 +16,15 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <cmath>
+#include <string>
+#include <algorithm>
+
+// RationalResampler::reconfigure (rational_resampler.h:162) printf()s a status line on every retune; inside a test / benchmark
+// process that stdout noise lands after bench.py's JSON line.  The reference is compiled unmodified, so the call is routed to a
+// no-op here (all standard headers that declare printf are included above this point).
+static inline int sdrpp_ref_quiet_printf(const char*, ...) { return 0; }
+#define printf(...) sdrpp_ref_quiet_printf(__VA_ARGS__)
 
 #include <dsp/channel/rx_vfo.h>
 #include <dsp/demod/broadcast_fm.h>
@@ -34,6 +43,8 @@
 
 using dsp::complex_t;
 using dsp::stereo_t;
+
+#undef printf
 
 extern "C" {
 
