@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--nvfo", type=int, default=32)
     ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 128 MiB at the default push: never resident in the 256 MiB MALL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload)")
     ap.add_argument("--fft-only", action="store_true", help="BASELINE cfg2 (no VFOs) instead of cfg3")
     ap.add_argument("--cfg", type=int, default=0, help="explicit BASELINE config: 2 (FFT only), 3 (headline), 4 (61.44 MS/s, 128 mixed VFOs, 2^20-pt FFT)")
     args = ap.parse_args()
@@ -134,6 +135,13 @@ def main():
     ctx = capi.Context(local, max_push=push)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
     info = workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo)
+    af_keep = []
+    if args.af and nvfo:
+        from sdrplusplus_amd import radio
+        for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
+            a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
+            ctx.vfo_set_af(vid, a_, k_)
+            af_keep.append(k_)
     lines_per_push = push // N
     lines = torch.empty((lines_per_push, 1024), dtype=torch.float32, device=device)
     gathered = [torch.empty_like(lines) for _ in range(world)] if (dist is not None and rank == 0) else None
@@ -289,7 +297,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg%d: %.2f MS/s-format synthetic IQ, %d-pt dense FFT + log-power waterfall%s" % (cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, "WFM" if cfg == 3 else "NFM/AM/USB")) if nvfo else ""),
                    "samples_per_step_per_gpu": push, "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
-                   "input_batches_rotated": args.nbuf, "device": ctx.device_info()},
+                   "input_batches_rotated": args.nbuf, "af_chain": bool(args.af and nvfo), "device": ctx.device_info()},
         "roofline": roof, "roofline_valu": roof_valu, "roofline_path": roof_path,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
         "kernel_ms_note": "per-family HIP-event times from an untimed calibration pass (FFT branch and VFO bank run on two streams and overlap, so the "

@@ -69,6 +69,8 @@ void sdrpp_design_phase_delta(double offset_hz, double sample_rate, float* re, f
  * (power_decimator.h:29-31; 8192 for the reference's tables).  Returns tap count (0 if no polyphase stage). */
 int sdrpp_design_resampler(double in_sr, double out_sr, int max_ratio, int* mode, int* predec_ratio, int* interp, int* decim,
                            float* taps, int max);
+/* filter/deephasis.h:90-93: alpha = dt / (tau + dt), dt = 1.0f / samplerate (float arithmetic as in the reference). */
+float sdrpp_design_deemphasis_alpha(double tau, double sample_rate);
 /* gui/widgets/waterfall.cpp:891-894 (view -> bin window) */
 void sdrpp_design_waterfall_view(double view_offset, double view_bandwidth, double whole_bandwidth, int raw_fft_size,
                                  int* draw_data_start, int* draw_data_size);
@@ -152,6 +154,32 @@ int sdrpp_vfo_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
 /* Device pointers: demodulated audio (or IF in RAW mode) and the complex IF stream (RxVFO::out) of the last push. */
 int sdrpp_vfo_device_buffers(sdrpp_ctx* ctx, int id, const float** out, int* n_out, const float** if_out, int* n_if);
 
+/* ---- radio AF chain behind a demodulating VFO (decoder_modules/radio/src/radio_module.h:98-110, 540-547) ------
+ * RationalResampler<stereo_t> (demodulator AF rate -> audio rate: power-of-two pre-decimation plan + L/M polyphase,
+ * rational_resampler.h:80-165) -> FIR<stereo_t,float> high-pass (radio_module.h:103,597; optional) -> Deemphasis<stereo_t>
+ * (filter/deephasis.h:58-77; optional).  Attached to an existing VFO; its output replaces nothing: the demodulator output
+ * (sdrpp_vfo_read) stays available, the AF output has its own accessors. */
+typedef struct sdrpp_af_desc {
+    int n_stages;                                     /* PowerDecimator stages of the pre-decimation plan (0: ratio 1)        */
+    int stage_decim[SDRPP_MAX_DECIM_STAGES];
+    int stage_ntaps[SDRPP_MAX_DECIM_STAGES];
+    const float* stage_taps[SDRPP_MAX_DECIM_STAGES];
+    int interp, decim;                                /* polyphase L/M; interp == decim -> stage absent                         */
+    int resamp_ntaps;
+    const float* resamp_taps;                         /* already scaled by interp (sdrpp_design_resampler)                      */
+    int hpf_ntaps;                                    /* 0 = high-pass block disabled                                           */
+    const float* hpf_taps;
+    float deemph_alpha;                               /* 0 = de-emphasis block disabled (sdrpp_design_deemphasis_alpha)         */
+} sdrpp_af_desc;
+/* afChain.enableBlock / setAudioSampleRate (radio_module.h:540-547, 585-600).  af == NULL detaches.  Arrays are copied; the chain
+ * starts from cleared state.  Only for VFOs with a demodulator (demod != RAW). */
+int sdrpp_vfo_set_af(sdrpp_ctx* ctx, int id, const sdrpp_af_desc* af);
+/* AF output of the most recent push: stereo frames at the audio rate (what afChain.out swap()s to the sink stream). */
+int sdrpp_vfo_af_count(sdrpp_ctx* ctx, int id);
+int sdrpp_vfo_af_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
+int sdrpp_vfo_af_device_buffer(sdrpp_ctx* ctx, int id, const float** out, int* n_out);
+int sdrpp_abi_sizeof_af_desc(void);
+
 /* ---- data path ------------------------------------------------------------------------------------------------------------ */
 /* One block of IQ, as Splitter::run hands to every bound stream (splitter.h:46-61).  Host pointer: copied H2D first.
  * Device pointer: read in place (must stay valid until the next sdrpp_sync / stream synchronisation).  Runs the FFT
@@ -166,7 +194,7 @@ int sdrpp_push_int16(sdrpp_ctx* ctx, const int16_t* iq_host, int64_t count);
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.
  * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc */
-#define SDRPP_NUM_KERNEL_FAMILIES 10
+#define SDRPP_NUM_KERNEL_FAMILIES 11
 /* on = 0: off; 1: every family; 1 | (family_bitmask << 1): only the selected families (each timed launch costs two event
  * records on its stream, so a throughput run instruments just the kernel it reports). */
 int sdrpp_timing_enable(sdrpp_ctx* ctx, int on);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libsdrpp_gpu.so")
 
 MAX_DECIM_STAGES = 4
-NUM_KERNEL_FAMILIES = 10
+NUM_KERNEL_FAMILIES = 11  # SDRPP_NUM_KERNEL_FAMILIES (checked against the header in tests/test_capi_host.py)
 
 DEMOD_RAW, DEMOD_WFM, DEMOD_NFM, DEMOD_AM, DEMOD_USB, DEMOD_LSB, DEMOD_DSB = -1, 0, 1, 2, 3, 4, 5
 
@@ -58,6 +58,24 @@ class VfoDesc(C.Structure):
     ]
 
 
+class AfDesc(C.Structure):
+    """struct sdrpp_af_desc (include/sdrpp_gpu.h): the radio AF chain behind a demodulating VFO."""
+
+    _fields_ = [
+        ("n_stages", C.c_int),
+        ("stage_decim", C.c_int * MAX_DECIM_STAGES),
+        ("stage_ntaps", C.c_int * MAX_DECIM_STAGES),
+        ("stage_taps", c_float_p * MAX_DECIM_STAGES),
+        ("interp", C.c_int),
+        ("decim", C.c_int),
+        ("resamp_ntaps", C.c_int),
+        ("resamp_taps", c_float_p),
+        ("hpf_ntaps", C.c_int),
+        ("hpf_taps", c_float_p),
+        ("deemph_alpha", C.c_float),
+    ]
+
+
 class SdrppError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("sdrpp error %d: %s" % (code, msg))
@@ -95,6 +113,15 @@ def load():
     sz = C.c_int()
     if L.sdrpp_abi_version(C.byref(sz)) != 1 or sz.value != C.sizeof(VfoDesc):
         raise ImportError("sdrpp_vfo_desc layout mismatch: library %d bytes, binding %d" % (sz.value, C.sizeof(VfoDesc)))
+    L.sdrpp_abi_sizeof_af_desc.argtypes = []
+    if L.sdrpp_abi_sizeof_af_desc() != C.sizeof(AfDesc):
+        raise ImportError("sdrpp_af_desc layout mismatch: library %d bytes, binding %d" % (L.sdrpp_abi_sizeof_af_desc(), C.sizeof(AfDesc)))
+    L.sdrpp_design_deemphasis_alpha.restype = C.c_float
+    L.sdrpp_design_deemphasis_alpha.argtypes = [C.c_double, C.c_double]
+    L.sdrpp_vfo_set_af.argtypes = [vp, C.c_int, C.POINTER(AfDesc)]
+    L.sdrpp_vfo_af_count.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_af_read.argtypes = [vp, C.c_int, c_float_p, C.c_int]
+    L.sdrpp_vfo_af_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p]
     for f in (L.sdrpp_design_low_pass, L.sdrpp_design_high_pass):
         f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, c_float_p, C.c_int]
     L.sdrpp_design_fft_window.argtypes = [C.c_int, C.c_int, c_float_p]
@@ -136,7 +163,8 @@ def load():
 EXPORTED_SYMBOLS = [
     "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
-    "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view",
+    "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
+    "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
@@ -190,6 +218,10 @@ def design_resampler(in_sr, out_sr, max_ratio=8192):
     if n > 0:
         L.sdrpp_design_resampler(in_sr, out_sr, max_ratio, C.byref(mode), C.byref(predec), C.byref(interp), C.byref(decim), taps.ctypes.data_as(c_float_p), n)
     return dict(mode=mode.value, predec=predec.value, interp=interp.value, decim=decim.value, taps=taps[:n])
+
+
+def design_deemphasis_alpha(tau, sample_rate):
+    return float(load().sdrpp_design_deemphasis_alpha(tau, sample_rate))
 
 
 def design_waterfall_view(view_offset, view_bandwidth, whole_bandwidth, raw_fft_size):
@@ -307,6 +339,19 @@ class Context:
         n = self.vfo_out_count(vid)
         out = np.empty((max(n, 1), 2), dtype=np.float32)
         got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
+        return out[:got]
+
+    def vfo_set_af(self, vid, af_desc, keepalive=None):
+        """Attach (or, with None, detach) the radio AF chain: resampler -> high-pass -> de-emphasis (sdrpp_vfo_set_af)."""
+        self._chk(self.L.sdrpp_vfo_set_af(self.h, vid, C.byref(af_desc) if af_desc is not None else None))
+
+    def vfo_af_count(self, vid):
+        return self._chk(self.L.sdrpp_vfo_af_count(self.h, vid))
+
+    def vfo_af_read(self, vid):
+        n = self.vfo_af_count(vid)
+        out = np.empty((max(n, 1), 2), dtype=np.float32)
+        got = self._chk(self.L.sdrpp_vfo_af_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
         return out[:got]
 
     def vfo_device_buffers(self, vid):

@@ -86,6 +86,11 @@ void sdrpp_design_phase_delta(double offset_hz, double sample_rate, float* re, f
     *im = (float)std::sin(w);
 }
 
+float sdrpp_design_deemphasis_alpha(double tau, double sample_rate) {
+    const float dt = 1.0f / sample_rate;  // deephasis.h:91-92: float dt = 1.0f / _samplerate; alpha = dt / (_tau + dt);
+    return (float)(dt / (tau + dt));
+}
+
 int sdrpp_design_resampler(double in_sr, double out_sr, int max_ratio, int* mode, int* predec_ratio, int* interp, int* decim,
                            float* taps, int max) {
     // rational_resampler.h:120-165.  Note the reference clamps the POWER against the maximum RATIO (line 122); kept.

@@ -29,9 +29,9 @@ constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4
 constexpr size_t kScratchBytes = 64u << 20;
 constexpr int kMaxLds = 64 * 1024;
 
-enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC };
+enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF };
 const char* kFamilyNames[SDRPP_NUM_KERNEL_FAMILIES] = { "fft_pass1", "fft_pass2", "fft_single", "zoom_palette", "vfo_stage1",
-                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc" };
+                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain" };
 
 struct Stream {
     int width = 2;
@@ -85,6 +85,27 @@ struct Vfo {
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
+    // radio AF chain (sdrpp_vfo_set_af): RationalResampler<stereo_t> -> high-pass -> de-emphasis, fed by st[i_out]
+    struct Af {
+        bool on = false;
+        int n_stages = 0, decim_s[SDRPP_MAX_DECIM_STAGES] = { 1, 1, 1, 1 };
+        std::vector<float> staps[SDRPP_MAX_DECIM_STAGES], rtaps, htaps;
+        float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+        int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_hpf;
+        int interp = 1, decim = 1, tpp = 0;
+        float* d_bank = nullptr;
+        float* d_hpf = nullptr;
+        int hpf_kp = 0;
+        float alpha = 0.0f;
+        float2* d_last = nullptr;  // Deemphasis::lastOut
+        float4* d_seg = nullptr;   // per-segment affine maps of the de-emphasis scan
+        int seg_cap = 0;
+        int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        int pphase = 0, poff = 0;
+        int i_stage0 = -1, i_poly = -1, i_hpf = -1, i_deemp = -1, i_last = -1;  // indices into st (i_last: where the AF output is)
+        int base = -1;  // first AF stream in st (they are appended behind the VFO's own streams)
+    } af;
 };
 
 struct TimingPair { hipEvent_t a, b; int family; };
@@ -470,6 +491,16 @@ void vfo_free(Vfo& v) {
     toep_free(v.tp_poly);
     toep_free(v.tp_chan);
     toep_free(v.tp_audio);
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
+        dev_free(v.af.d_staps[i]);
+        toep_free(v.af.tp_stage[i]);
+    }
+    toep_free(v.af.tp_poly);
+    toep_free(v.af.tp_hpf);
+    dev_free(v.af.d_bank);
+    dev_free(v.af.d_hpf);
+    dev_free(v.af.d_last);
+    dev_free(v.af.d_seg);
     for (auto& s : v.st) { stream_free(s); }
     v.st.clear();
 }
@@ -481,6 +512,10 @@ int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.soff[i] = 0; }
     v.pphase = 0;
     v.poff = 0;
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.af.soff[i] = 0; }
+    v.af.pphase = 0;
+    v.af.poff = 0;
+    if (v.af.d_last) { HIPCHK(c, hipMemsetAsync(v.af.d_last, 0, sizeof(float2), c->stream)); }
     for (auto& s : v.st) {
         for (int i = 0; i < 2; i++) {
             if (s.hist[i]) { HIPCHK(c, hipMemsetAsync(s.hist[i], 0, (size_t)std::max(s.hist_len, 1) * s.width * sizeof(float), c->stream)); }
@@ -707,6 +742,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
     std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
+    // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
+    std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
+    std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
+    std::vector<PolyJob> af_poly;
+    std::vector<DeempJob> af_deemp;
     auto toep_job = [](const ToepTab& T, int var, StreamIn in, float* out, int base0, int nout, float inv_dev) {
         ToepJob j{};
         j.in = in;
@@ -826,6 +866,47 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             out.n = nif;
             double p2 = v.phi2 + (double)nif * v.theta2;
             v.phi2 = p2 - std::floor(p2);
+        }
+        if (v.af.on && v.i_out >= 0) {  // radio AF chain on the demodulator's stereo output
+            Vfo::Af& a = v.af;
+            Stream* acur = &v.st[(size_t)v.i_out];
+            for (int s = 0; s < a.n_stages; s++) {
+                Stream* nxt = &v.st[(size_t)a.i_stage0 + s];
+                const int Ds = a.decim_s[s], K = (int)a.staps[s].size();
+                const int no = decim_nout(acur->n, a.soff[s], Ds);
+                if (a.tp_stage[s].ok) { t_af_lvl[s].push_back(toep_job(a.tp_stage[s], 0, stream_in(*acur), nxt->data, a.soff[s] - (K - 1), no, 0.0f)); }
+                else { af_lvl[s].push_back(FirBJob{ stream_in(*acur), nxt->data, a.d_staps[s], K, ilog2(Ds), a.soff[s], no, a.s_kp[s] }); }
+                a.soff[s] = a.soff[s] + no * Ds - acur->n;
+                nxt->n = no;
+                acur = nxt;
+            }
+            if (a.i_poly >= 0) {
+                Stream* nxt = &v.st[(size_t)a.i_poly];
+                const int no = poly_nout(acur->n, a.poff, a.pphase, a.interp, a.decim);
+                if (a.tp_poly.ok) { t_af_poly.push_back(toep_job(a.tp_poly, a.pphase, stream_in(*acur), nxt->data, a.poff - (a.tpp - 1), no, 0.0f)); }
+                else { af_poly.push_back(PolyJob{ stream_in(*acur), (float2*)nxt->data, a.d_bank, a.interp, a.decim, a.tpp, a.pphase, a.poff, no }); }
+                const long long A = (long long)a.pphase + (long long)no * a.decim;
+                a.pphase = (int)(A % a.interp);
+                a.poff = a.poff + (int)(A / a.interp) - acur->n;
+                nxt->n = no;
+                acur = nxt;
+            }
+            if (a.i_hpf >= 0) {
+                Stream* nxt = &v.st[(size_t)a.i_hpf];
+                const int K = (int)a.htaps.size();
+                if (a.tp_hpf.ok) { t_af_hpf.push_back(toep_job(a.tp_hpf, 0, stream_in(*acur), nxt->data, -(K - 1), acur->n, 0.0f)); }
+                else { af_hpf.push_back(FirBJob{ stream_in(*acur), nxt->data, a.d_hpf, K, 0, 0, acur->n, a.hpf_kp }); }
+                nxt->n = acur->n;
+                acur = nxt;
+            }
+            if (a.i_deemp >= 0) {
+                Stream* nxt = &v.st[(size_t)a.i_deemp];
+                af_deemp.push_back(DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last, a.d_seg,
+                                             std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG) });
+                nxt->n = acur->n;
+                acur = nxt;
+            }
+            a.i_last = (int)(acur - &v.st[0]);
         }
         double p = v.phi + (double)n_in * v.theta;
         v.phi = p - std::floor(p);
@@ -1109,6 +1190,25 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS");
     }
+    ToepPlan tp_af_lvl[SDRPP_MAX_DECIM_STAGES];
+    ToepJob* d_t_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
+    FirBJob* d_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
+    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
+        tp_af_lvl[s] = toep_plan(t_af_lvl[s], 2);
+        d_t_af_lvl[s] = arena_push(c, t_af_lvl[s]);
+        d_af_lvl[s] = arena_push(c, af_lvl[s]);
+        if ((!t_af_lvl[s].empty() && !d_t_af_lvl[s]) || (!af_lvl[s].empty() && !d_af_lvl[s])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    }
+    const ToepPlan tp_af_poly = toep_plan(t_af_poly, 2), tp_af_hpf = toep_plan(t_af_hpf, 2);
+    ToepJob* d_t_af_poly = arena_push(c, t_af_poly);
+    ToepJob* d_t_af_hpf = arena_push(c, t_af_hpf);
+    PolyJob* d_af_poly = arena_push(c, af_poly);
+    FirBJob* d_af_hpf = arena_push(c, af_hpf);
+    DeempJob* d_af_deemp = arena_push(c, af_deemp);
+    if ((!t_af_poly.empty() && !d_t_af_poly) || (!t_af_hpf.empty() && !d_t_af_hpf) || (!af_poly.empty() && !d_af_poly) || (!af_hpf.empty() && !d_af_hpf) ||
+        (!af_deemp.empty() && !d_af_deemp)) {
+        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
+    }
     RotJob* d_rot = arena_push(c, rot);
     FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
@@ -1225,6 +1325,35 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         else { launch(c, vfo_firb_kernel<1, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
         return SDRPP_OK;
     };
+    // resamplers with many phases (L > 8, e.g. 96/125): cycle-major kernel — one LDS window serves all L phases of up to 64 cycles;
+    // a filter whose single cycle does not fit falls back to the per-output kernel
+    auto launch_polyc = [&](std::vector<PolyJob>& jobs, PolyJob* d_jobs) -> int {
+        if (jobs.empty()) { return SDRPP_OK; }
+        const int cap2 = kMaxLds / (int)sizeof(float2);
+        bool fits = true;
+        int max_nout = 0, max_tiles = 0;
+        for (auto& jb : jobs) {
+            max_nout = std::max(max_nout, jb.nout);
+            const int ct = std::min(64, (cap2 - jb.tpp - jb.decim) / jb.decim);
+            if (ct < 1) { fits = false; continue; }
+            const int ncyc = (jb.nout + jb.interp - 1) / jb.interp;
+            max_tiles = std::max(max_tiles, (ncyc + ct - 1) / ct);
+        }
+        if (max_nout == 0) { return SDRPP_OK; }
+        if (fits) {
+            launch(c, vfo_polyc_kernel, dim3((unsigned)max_tiles, (unsigned)jobs.size()), dim3(256), (size_t)kMaxLds, (const PolyJob*)d_jobs, cap2);
+            return SDRPP_OK;
+        }
+        size_t lds = 0;
+        const int tile = 256;
+        for (auto& jb : jobs) {
+            const size_t ns = (size_t)((long long)tile * jb.decim / jb.interp) + jb.tpp + 4;
+            lds = std::max(lds, ns * sizeof(float2));
+        }
+        if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
+        launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
+        return SDRPP_OK;
+    };
     auto launch_toep = [&](std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
         if (jobs.empty() || P.grid_x == 0) { return; }
         const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
@@ -1246,16 +1375,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     if (!poly.empty()) {
         FamilyTimer t(c, F_POLY);
-        int max_nout = 0;
-        size_t lds = 0;
-        const int tile = 256;
-        for (auto& jb : poly) {
-            max_nout = std::max(max_nout, jb.nout);
-            const size_t ns = (size_t)((long long)tile * jb.decim / jb.interp) + jb.tpp + 4;
-            lds = std::max(lds, ns * sizeof(float2));
-        }
-        if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
-        if (max_nout > 0) { launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)poly.size()), dim3(tile), lds, (const PolyJob*)d_poly); }
+        rc = launch_polyc(poly, d_poly);
+        if (rc) { return rc; }
     }
     for (int li = 0; li < 4; li++) {
         if (polyb[li].empty()) { continue; }
@@ -1307,6 +1428,32 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (rc) { return rc; }
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
         if (rc) { return rc; }
+    }
+    bool any_af = !af_deemp.empty() || !af_poly.empty() || !t_af_poly.empty() || !af_hpf.empty() || !t_af_hpf.empty();
+    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { any_af = any_af || !af_lvl[s].empty() || !t_af_lvl[s].empty(); }
+    if (any_af) {
+        FamilyTimer t(c, F_AF);
+        for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
+            launch_toep(t_af_lvl[s], d_t_af_lvl[s], tp_af_lvl[s], 2, false);
+            rc = launch_fir(af_lvl[s], d_af_lvl[s], 2, false);
+            if (rc) { return rc; }
+        }
+        launch_toep(t_af_poly, d_t_af_poly, tp_af_poly, 2, false);
+        rc = launch_polyc(af_poly, d_af_poly);
+        if (rc) { return rc; }
+        launch_toep(t_af_hpf, d_t_af_hpf, tp_af_hpf, 2, false);
+        rc = launch_fir(af_hpf, d_af_hpf, 2, false);
+        if (rc) { return rc; }
+        if (!af_deemp.empty()) {
+            int max_seg = 0;
+            for (auto& jb : af_deemp) { max_seg = std::max(max_seg, jb.nseg); }
+            if (max_seg > 0) {
+                const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.size());
+                launch(c, vfo_deemph_kernel<0>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
+                launch(c, vfo_deemph_kernel<1>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
+                launch(c, vfo_deemph_state_kernel, dim3(((unsigned)af_deemp.size() + 63) / 64), dim3(64), 0, (const DeempJob*)d_af_deemp, (int)af_deemp.size());
+            }
+        }
     }
     if (!carry.empty()) {
         FamilyTimer t(c, F_MISC);
@@ -1848,6 +1995,153 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     }
     return SDRPP_OK;
 }
+
+static void af_detach(Vfo& v) {
+    Vfo::Af& a = v.af;
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
+        dev_free(a.d_staps[i]);
+        toep_free(a.tp_stage[i]);
+    }
+    toep_free(a.tp_poly);
+    toep_free(a.tp_hpf);
+    dev_free(a.d_bank);
+    dev_free(a.d_hpf);
+    dev_free(a.d_last);
+    dev_free(a.d_seg);
+    if (a.base >= 0) {
+        for (size_t i = (size_t)a.base; i < v.st.size(); i++) { stream_free(v.st[i]); }
+        v.st.resize((size_t)a.base);
+    }
+    a = Vfo::Af{};
+}
+
+int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Vfo& v = *it->second;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    af_detach(v);
+    if (!af) { return SDRPP_OK; }
+    if (v.d.demod == SDRPP_DEMOD_RAW || v.i_out < 0) { return fail(c, SDRPP_ERR_UNSUPPORTED, "the AF chain needs a demodulating VFO"); }
+    if (af->n_stages < 0 || af->n_stages > SDRPP_MAX_DECIM_STAGES) { return fail(c, SDRPP_ERR_INVALID, "af n_stages %d", af->n_stages); }
+    for (int s = 0; s < af->n_stages; s++) {
+        if (!is_pow2(af->stage_decim[s]) || af->stage_ntaps[s] <= 0 || !af->stage_taps[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "af stage %d: decimation must be a power of two with taps", s); }
+    }
+    const bool has_poly = af->interp != af->decim;
+    if (has_poly && (af->interp <= 0 || af->decim <= 0 || af->resamp_ntaps <= 0 || !af->resamp_taps)) { return fail(c, SDRPP_ERR_INVALID, "bad af polyphase description"); }
+    if (af->hpf_ntaps < 0 || af->hpf_ntaps > kChanHistCap + 1 || (af->hpf_ntaps > 0 && !af->hpf_taps)) { return fail(c, SDRPP_ERR_INVALID, "bad af high-pass description"); }
+    Vfo::Af& a = v.af;
+    a.base = (int)v.st.size();
+    a.n_stages = af->n_stages;
+    a.interp = has_poly ? af->interp : 1;
+    a.decim = has_poly ? af->decim : 1;
+    a.tpp = has_poly ? (af->resamp_ntaps + af->interp - 1) / af->interp : 0;
+    a.alpha = af->deemph_alpha;
+    int rc;
+    // history a stream must keep = (taps - 1) of its consumer; `stage` = first block that can be the consumer
+    // (0..n_stages-1 decimators, n_stages polyphase, n_stages+1 high-pass; de-emphasis needs none)
+    auto need_of = [&](int stage) -> int {
+        if (stage < a.n_stages) { return af->stage_ntaps[stage] - 1; }
+        if (stage <= a.n_stages && has_poly) { return a.tpp - 1; }
+        if (stage <= a.n_stages + 1 && af->hpf_ntaps > 0) { return af->hpf_ntaps - 1; }
+        return 0;
+    };
+    rc = stream_grow_hist(c, v.st[(size_t)v.i_out], need_of(0));
+    if (rc) { return rc; }
+    size_t cap = v.st[(size_t)v.i_out].cap;
+    auto add_stream = [&](int hist, size_t capn) -> int {
+        v.st.emplace_back();
+        int r = stream_alloc(c, v.st.back(), 2, hist, capn);
+        return r ? -1 : (int)v.st.size() - 1;
+    };
+    for (int s = 0; s < a.n_stages; s++) {
+        a.decim_s[s] = af->stage_decim[s];
+        a.staps[s].assign(af->stage_taps[s], af->stage_taps[s] + af->stage_ntaps[s]);
+        rc = upload_blocked(c, &a.d_staps[s], a.staps[s].data(), (int)a.staps[s].size(), a.decim_s[s], &a.s_kp[s]);
+        if (rc) { return rc; }
+        a.tp_stage[s].kind = 1;
+        rc = toep_build_fir(c, a.tp_stage[s], a.staps[s].data(), (int)a.staps[s].size(), a.decim_s[s]);
+        if (rc) { return rc; }
+        cap = cap / (size_t)a.decim_s[s] + 2;
+        const int idx = add_stream(need_of(s + 1), cap);
+        if (idx < 0) { return SDRPP_ERR_NOMEM; }
+        if (s == 0) { a.i_stage0 = idx; }
+    }
+    if (has_poly) {
+        a.rtaps.assign(af->resamp_taps, af->resamp_taps + af->resamp_ntaps);
+        std::vector<float> bank((size_t)a.interp * a.tpp, 0.0f);
+        const int tot = a.interp * a.tpp;
+        for (int i = 0; i < tot; i++) { bank[(size_t)((a.interp - 1) - (i % a.interp)) * a.tpp + (size_t)(i / a.interp)] = (i < af->resamp_ntaps) ? a.rtaps[(size_t)i] : 0.0f; }  // polyphase_bank.h:31-34
+        rc = upload(c, &a.d_bank, bank.data(), bank.size());
+        if (rc) { return rc; }
+        a.tp_poly.kind = 2;
+        rc = toep_build_poly(c, a.tp_poly, bank, a.interp, a.decim, a.tpp);
+        if (rc) { return rc; }
+        cap = cap * (size_t)a.interp / (size_t)a.decim + 4;
+        a.i_poly = add_stream(need_of(a.n_stages + 1), cap);
+        if (a.i_poly < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    if (af->hpf_ntaps > 0) {
+        a.htaps.assign(af->hpf_taps, af->hpf_taps + af->hpf_ntaps);
+        rc = upload_blocked(c, &a.d_hpf, a.htaps.data(), (int)a.htaps.size(), 1, &a.hpf_kp);
+        if (rc) { return rc; }
+        a.tp_hpf.kind = 4;
+        rc = toep_build_fir(c, a.tp_hpf, a.htaps.data(), (int)a.htaps.size(), 1);
+        if (rc) { return rc; }
+        a.i_hpf = add_stream(0, cap);
+        if (a.i_hpf < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    if (a.alpha != 0.0f) {
+        rc = dev_alloc(c, &a.d_last, 1);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(a.d_last, 0, sizeof(float2)));
+        a.seg_cap = (int)(cap / SDRPP_DEEMP_SEG) + 2;
+        rc = dev_alloc(c, &a.d_seg, (size_t)a.seg_cap);
+        if (rc) { return rc; }
+        a.i_deemp = add_stream(0, cap);
+        if (a.i_deemp < 0) { return SDRPP_ERR_NOMEM; }
+    }
+    a.i_last = v.i_out;
+    a.on = true;
+    return SDRPP_OK;
+}
+
+static Stream* af_stream(Vfo& v) { return (v.af.on && v.af.i_last >= 0) ? &v.st[(size_t)v.af.i_last] : nullptr; }
+
+int sdrpp_vfo_af_count(sdrpp_ctx* c, int id) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = af_stream(*it->second);
+    if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no AF chain", id); }
+    return s->n;
+}
+
+int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
+    if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = af_stream(*it->second);
+    if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no AF chain", id); }
+    const int n = std::min(max, s->n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n > 0) { HIPCHK(c, hipMemcpy(dst, s->data, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
+    return n;
+}
+
+int sdrpp_vfo_af_device_buffer(sdrpp_ctx* c, int id, const float** out, int* n_out) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = af_stream(*it->second);
+    if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no AF chain", id); }
+    if (out) { *out = s->data; }
+    if (n_out) { *n_out = s->n; }
+    return SDRPP_OK;
+}
+
+int sdrpp_abi_sizeof_af_desc(void) { return (int)sizeof(sdrpp_af_desc); }
 
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }

@@ -1228,4 +1228,141 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
     }
 }
 
+// =====================================================================================================================
+// AF chain: Deemphasis<stereo_t> (filter/deephasis.h:58-77): y[i] = alpha * x[i] + (1 - alpha) * y[i-1] per channel, state carried
+// across pushes.  A first-order linear recurrence: one workgroup per VFO walks the push in super chunks of 256 * 8 frames; every
+// work-item runs the recursion over its 8 frames from a zero carry, the chunk-end values are combined with a workgroup scan of
+// the affine maps (m, a): y_end = m * y_in + a, and each work-item then re-runs the reference's exact expression from its true
+// carry-in.  Only the carry-in differs in rounding from the sequential loop (~1e-7 relative; the filter is contractive).
+// =====================================================================================================================
+struct DeempJob {
+    const float2* in;
+    float2* out;
+    int n;
+    float alpha;
+    float2* state;    // lastOut (deephasis.h:72-73), device resident
+    float4* seg;      // [nseg] scratch: per segment (m, a.l, a.r, -): y_end = m * y_in + a
+    int nseg;         // segments of SDRPP_DEEMP_SEG frames
+};
+#define SDRPP_DEEMP_C 16
+#define SDRPP_DEEMP_SEG (256 * SDRPP_DEEMP_C)
+
+// Workgroup-wide composition of the per-work-item affine maps (Hillis-Steele): on return sm_m/sm_a[t] hold the map of work-items
+// 0..t applied in order: (m2, a2) o (m1, a1) = (m2*m1, a2 + m2*a1).
+__device__ __forceinline__ void deemph_block_scan(float* sm_m, float2* sm_a, int t, float m, float2 e) {
+    sm_m[t] = m;
+    sm_a[t] = e;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        float pm = 1.0f;
+        float2 pa = make_float2(0.0f, 0.0f);
+        const bool has = t >= d;
+        if (has) {
+            pm = sm_m[t - d];
+            pa = sm_a[t - d];
+        }
+        __syncthreads();
+        if (has) {
+            const float mm = sm_m[t];
+            const float2 aa = sm_a[t];
+            sm_m[t] = mm * pm;
+            sm_a[t] = make_float2(aa.x + mm * pa.x, aa.y + mm * pa.y);
+        }
+        __syncthreads();
+    }
+}
+
+// PASS 0: segment maps from a zero carry (grid: x = segment, y = VFO).  PASS 1: every segment composes the maps of the segments
+// before it onto the carried state (a few dozen multiply-adds), then each work-item re-runs the reference's exact expression from
+// its true carry-in; the last segment stores the new state.
+template <int PASS>
+__global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restrict__ jobs) {
+    __shared__ float sm_m[256];
+    __shared__ float2 sm_a[256];
+    const DeempJob& job = jobs[blockIdx.y];
+    const int sg = blockIdx.x;
+    if (sg >= job.nseg) { return; }
+    constexpr int C = SDRPP_DEEMP_C;
+    const int t = threadIdx.x;
+    const float alpha = job.alpha, beta = 1.0f - alpha;
+    const int i0 = sg * SDRPP_DEEMP_SEG + t * C;
+    float2 x[C];
+    float2 e = make_float2(0.0f, 0.0f);
+    float m = 1.0f;
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        const bool ok = i0 + j < job.n;
+        x[j] = ok ? job.in[i0 + j] : make_float2(0.0f, 0.0f);
+        if (ok) {
+            e.x = (alpha * x[j].x) + (beta * e.x);
+            e.y = (alpha * x[j].y) + (beta * e.y);
+            m *= beta;
+        }
+    }
+    deemph_block_scan(sm_m, sm_a, t, m, e);
+    if constexpr (PASS == 0) {
+        if (t == 255) { job.seg[sg] = make_float4(sm_m[255], sm_a[255].x, sm_a[255].y, 0.0f); }
+    }
+    else {
+        float2 c0 = *job.state;  // carry into the push, then through the earlier segments (uniform: every work-item does the same)
+        for (int q = 0; q < sg; q++) {
+            const float4 g = job.seg[q];
+            c0 = make_float2(g.y + g.x * c0.x, g.z + g.x * c0.y);
+        }
+        float2 y = c0;
+        if (t > 0) { y = make_float2(sm_a[t - 1].x + sm_m[t - 1] * c0.x, sm_a[t - 1].y + sm_m[t - 1] * c0.y); }
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            if (i0 + j < job.n) {
+                y.x = (alpha * x[j].x) + (beta * y.x);  // deephasis.h:66-69, same expression
+                y.y = (alpha * x[j].y) + (beta * y.y);
+                job.out[i0 + j] = y;
+            }
+        }
+        // the new lastOut is stored by vfo_deemph_state_kernel once every segment (they run concurrently and all read the old
+        // state) is done
+    }
+}
+// lastOut = out[n-1] (deephasis.h:72-73), after all segments are done
+__global__ void vfo_deemph_state_kernel(const DeempJob* __restrict__ jobs, int njobs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < njobs && jobs[i].n > 0) { *jobs[i].state = jobs[i].out[jobs[i].n - 1]; }
+}
+
+// =====================================================================================================================
+// Polyphase resampler with many phases (the AF chain's 96/125): cycle-major.  A tile = CT whole phase cycles (CT * L outputs,
+// CT * M inputs); lane j owns cycle j, a wavefront walks over phases r = w, w + 4, ...: within a wavefront the phase — hence
+// the tap row — is uniform (scalar loads) and all L phases reuse ONE LDS window of CT * M + tpp input samples.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void vfo_polyc_kernel(const PolyJob* __restrict__ jobs, int cap2) {
+    HIP_DYNAMIC_SHARED(float2, xsc)
+    const PolyJob& job = jobs[blockIdx.y];
+    const int L = job.interp, M = job.decim, tpp = job.tpp;
+    int CT = (cap2 - tpp - M) / M;  // cycles per tile: window (CT - 1) * M + o_max + tpp <= cap2, o_max <= M
+    if (CT > 64) { CT = 64; }
+    const int c0 = blockIdx.x * CT;
+    if ((long long)c0 * L >= job.nout) { return; }
+    const int first = job.off0 + c0 * M - (tpp - 1);
+    const int nwin = CT * M + M + tpp;
+    for (int s = threadIdx.x; s < nwin; s += 256) { xsc[s] = stream_load2(job.in, first + s); }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv; r < L; r += 4) {
+        const int A = job.phase0 + r * M, ph = A % L, o = A / L;
+        const UniformF32 taps = as_uniform(job.bank + (size_t)ph * tpp);
+        const float2* xp = xsc + lane * M + o;
+        float2 acc = make_float2(0.0f, 0.0f);
+        if (lane < CT) {
+            for (int k = 0; k < tpp; k++) {
+                const float h = taps[k];
+                const float2 x = xp[k];
+                acc.x = fmaf(h, x.x, acc.x);
+                acc.y = fmaf(h, x.y, acc.y);
+            }
+            const long long n = (long long)(c0 + lane) * L + r;
+            if (n < job.nout) { global_store_f32x2(job.out, n, acc); }
+        }
+    }
+}
+
 }  // namespace sdrpp_k

@@ -217,11 +217,19 @@ public:
     void reset();                                             // rx_vfo.h:79-87
     // Radio-module demodulator fused behind this VFO (decoder_modules/radio/src/demodulators/*.h defaults).
     void attachDemod(Demod mode, bool lowPass = true, double agcAttack = 50.0, double agcDecay = 5.0, bool carrierAgc = false);
+    // The radio module's AF chain behind the demodulator (radio_module.h:98-110, 540-547): RationalResampler<stereo_t> to
+    // `audioSamplerate`, optional highPass(300, 100) FIR, optional Deemphasis(tau) (tau <= 0: off).  With the chain attached `audio`
+    // carries its output (what afChain.out hands to the sink stream); afRate = the demodulator's getAFSampleRate() (= IF rate for
+    // every analog demodulator of the radio module).  detachAF() puts the demodulator output back on `audio`.
+    void attachAF(double audioSamplerate = 48000.0, double deempTau = 50e-6, bool highPass = false);
+    void detachAF();
 
     double inSamplerate = 0, outSamplerate = 0, bandwidth = 0, offset = 0;
     Demod demod = Demod::RAW;
     bool lowPass = true, carrierAgc = false;
     double agcAttack = 50.0, agcDecay = 5.0;
+    bool afOn = false, afHighPass = false;
+    double afAudioRate = 48000.0, afDeempTau = 50e-6;
 
 private:
     friend class IQFrontEnd;
@@ -341,7 +349,8 @@ public:
                 if (n > 0 && !v->out.swap(n)) { return -1; }
             }
             else {
-                int n = sdrpp_vfo_read(ctx, v->id, (float*)v->audio.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE);
+                int n = v->afOn ? sdrpp_vfo_af_read(ctx, v->id, (float*)v->audio.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE)
+                                : sdrpp_vfo_read(ctx, v->id, (float*)v->audio.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE);
                 if (n > 0 && !v->audio.swap(n)) { return -1; }
             }
         }
@@ -435,6 +444,44 @@ private:
         }
         int rc = sdrpp_vfo_add(ctx, &d, &v.id);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] vfo_add: ") + sdrpp_last_error(ctx)); }
+        if (v.afOn && v.demod != Demod::RAW) { applyAF(v); }
+    }
+
+    // radio_module.h:98-110: resamp.init(NULL, afRate, audioRate); hpTaps = highPass(300, 100, audioRate); deemp.init(NULL, tau, audioRate)
+    void applyAF(RxVFO& v) {
+        sdrpp_af_desc a;
+        memset(&a, 0, sizeof(a));
+        int mode = 0, predec = 1, interp = 1, decim = 1;
+        int nt = sdrpp_design_resampler(v.outSamplerate, v.afAudioRate, _plans.maxRatio, &mode, &predec, &interp, &decim, nullptr, 0);
+        std::vector<float> rtaps((size_t)(nt > 0 ? nt : 1));
+        if (nt > 0) { sdrpp_design_resampler(v.outSamplerate, v.afAudioRate, _plans.maxRatio, &mode, &predec, &interp, &decim, rtaps.data(), nt); }
+        const std::vector<DecimStage>* st = nullptr;
+        if ((mode == 0 || mode == 1) && predec > 1) {
+            auto it = _plans.plans.find(predec);
+            if (it == _plans.plans.end()) { throw std::runtime_error("[sdrpp_gpu::IQFrontEnd] no decimation plan for ratio " + std::to_string(predec)); }
+            st = &it->second;
+        }
+        a.n_stages = st ? (int)st->size() : 0;
+        for (int i = 0; i < a.n_stages; i++) {
+            a.stage_decim[i] = (*st)[(size_t)i].decimation;
+            a.stage_ntaps[i] = (int)(*st)[(size_t)i].taps.size();
+            a.stage_taps[i] = (*st)[(size_t)i].taps.data();
+        }
+        a.interp = (mode == 0 || mode == 2) ? interp : 1;
+        a.decim = (mode == 0 || mode == 2) ? decim : 1;
+        a.resamp_ntaps = (mode == 0 || mode == 2) ? nt : 0;
+        a.resamp_taps = rtaps.data();
+        std::vector<float> htaps;
+        if (v.afHighPass) {
+            int n = sdrpp_design_high_pass(300.0, 100.0, v.afAudioRate, 0, nullptr, 0);
+            htaps.resize((size_t)n);
+            sdrpp_design_high_pass(300.0, 100.0, v.afAudioRate, 0, htaps.data(), n);
+            a.hpf_ntaps = n;
+            a.hpf_taps = htaps.data();
+        }
+        a.deemph_alpha = v.afDeempTau > 0.0 ? sdrpp_design_deemphasis_alpha(v.afDeempTau, v.afAudioRate) : 0.0f;
+        int rc = sdrpp_vfo_set_af(ctx, v.id, &a);
+        if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] vfo_set_af: ") + sdrpp_last_error(ctx)); }
     }
 
     dsp::stream<dsp::complex_t>* _in = nullptr;
@@ -496,6 +543,24 @@ inline void RxVFO::attachDemod(Demod mode, bool lp, double att, double dec, bool
     agcDecay = dec;
     carrierAgc = carrier;
     fe->rebuild(*this);
+    fe->tempStart();
+}
+
+inline void RxVFO::attachAF(double audioSamplerate, double deempTau, bool highPass) {
+    std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
+    fe->tempStop();  // radio_module.h:589 afChain.stop() ... :600 afChain.start()
+    afOn = true;
+    afAudioRate = audioSamplerate;
+    afDeempTau = deempTau;
+    afHighPass = highPass;
+    if (demod != Demod::RAW && id >= 0) { fe->applyAF(*this); }
+    fe->tempStart();
+}
+inline void RxVFO::detachAF() {
+    std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
+    fe->tempStop();
+    afOn = false;
+    if (id >= 0) { sdrpp_vfo_set_af(fe->ctx, id, nullptr); }
     fe->tempStart();
 }
 

@@ -149,3 +149,35 @@ def describe(desc):
         predec *= desc.stage_decim[i]
     return dict(predec=predec, interp=desc.interp, decim=desc.decim, rtaps=desc.resamp_ntaps, chan_taps=desc.chan_ntaps,
                 audio_taps=desc.audio_ntaps, stages=[(desc.stage_decim[i], desc.stage_ntaps[i]) for i in range(desc.n_stages)])
+
+
+def af_desc(af_rate, audio_rate=48000.0, deemp_tau=50e-6, high_pass=False):
+    """sdrpp_af_desc for the radio module's AF chain (radio_module.h:98-110): RationalResampler<stereo_t>(af_rate -> audio_rate),
+    optional highPass(300, 100, audio_rate) FIR, optional Deemphasis(tau, audio_rate) (tau None/0 = off).
+    Returns (desc, keepalive)."""
+    a = capi.AfDesc()
+    keep = []
+    rs = capi.design_resampler(af_rate, audio_rate, plans().max_ratio)
+    stages = plans().stages(rs["predec"]) if rs["mode"] in (0, 1) else []
+    a.n_stages = len(stages)
+    for i, (dec, taps) in enumerate(stages):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        keep.append(t)
+        a.stage_decim[i] = dec
+        a.stage_ntaps[i] = len(t)
+        a.stage_taps[i] = _fp(t)
+    if rs["mode"] in (0, 2):
+        rt = np.ascontiguousarray(rs["taps"], dtype=np.float32)
+        keep.append(rt)
+        a.interp, a.decim = rs["interp"], rs["decim"]
+        a.resamp_ntaps = len(rt)
+        a.resamp_taps = _fp(rt)
+    else:
+        a.interp, a.decim, a.resamp_ntaps = 1, 1, 0
+    if high_pass:
+        ht = capi.design_high_pass(300.0, 100.0, audio_rate)
+        keep.append(ht)
+        a.hpf_ntaps = len(ht)
+        a.hpf_taps = _fp(ht)
+    a.deemph_alpha = capi.design_deemphasis_alpha(deemp_tau, audio_rate) if deemp_tau else 0.0
+    return a, keep

@@ -52,12 +52,18 @@ int main(int argc, char** argv) {
     sdrpp_gpu::RxVFO* wfm = fe.addVFO("radio", 250000.0, 150000.0, 300000.0);
     if (!raw || !wfm) { return 1; }
     wfm->attachDemod(sdrpp_gpu::Demod::WFM);
+    // a second radio instance with the AF chain (48 kHz, 50 us de-emphasis) behind its demodulator (radio_module.h:98-110)
+    sdrpp_gpu::RxVFO* wfmAf = fe.addVFO("radio_af", 250000.0, 150000.0, 300000.0);
+    if (!wfmAf) { return 1; }
+    wfmAf->attachDemod(sdrpp_gpu::Demod::WFM);
+    wfmAf->attachAF(48000.0, 50e-6, false);
     if (fe.addVFO("raw", 1.0, 1.0, 0.0) != nullptr) { fprintf(stderr, "duplicate VFO name accepted\n"); return 1; }
     fe.removeVFO("nope");  // logs, like the reference
 
-    std::vector<float> ifOut, audioOut;
+    std::vector<float> ifOut, audioOut, afOut;
     std::thread t1(drain<dsp::complex_t>, &raw->out, &ifOut);
     std::thread t2(drain<dsp::stereo_t>, &wfm->audio, &audioOut);
+    std::thread t3(drain<dsp::stereo_t>, &wfmAf->audio, &afOut);
     fe.start();
     size_t pos = 0;
     int blk = 0;
@@ -73,8 +79,10 @@ int main(int argc, char** argv) {
     fe.stop();
     raw->out.stopReader();
     wfm->audio.stopReader();
+    wfmAf->audio.stopReader();
     t1.join();
     t2.join();
+    t3.join();
     auto dump = [&](const char* name, const std::vector<float>& v) {
         std::ofstream o(outdir + "/" + name, std::ios::binary);
         o.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));
@@ -82,6 +90,7 @@ int main(int argc, char** argv) {
     dump("lines.f32", lines.all);
     dump("if.f32", ifOut);
     dump("audio.f32", audioOut);
+    dump("af.f32", afOut);
     printf("blocks %d lines %d (acquire %d release %d) if %zu audio %zu\n", blk, (int)(lines.all.size() / (size_t)fftSize), lines.acquired, lines.released, ifOut.size() / 2, audioOut.size() / 2);
     return (lines.acquired == lines.released) ? 0 : 1;
 }

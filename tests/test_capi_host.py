@@ -99,3 +99,15 @@ def test_emulator_is_never_the_default():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle/" not in text.replace("oracle/_ref", "").replace("test oracle", "") or f in ("__init__.py",), "product file %s references the oracle" % f
+
+
+def test_binding_constants_match_header():
+    """Buffers handed to sdrpp_timing_read are sized from these constants: they must track include/sdrpp_gpu.h."""
+    import re
+    from sdrplusplus_amd import capi
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdrpp_gpu.h")).read()
+    assert int(re.search(r"#define\s+SDRPP_NUM_KERNEL_FAMILIES\s+(\d+)", hdr).group(1)) == capi.NUM_KERNEL_FAMILIES
+    assert int(re.search(r"#define\s+SDRPP_MAX_DECIM_STAGES\s+(\d+)", hdr).group(1)) == capi.MAX_DECIM_STAGES
+    names = [capi.load().sdrpp_kernel_family_name(i).decode() for i in range(capi.NUM_KERNEL_FAMILIES)]
+    assert len(set(names)) == capi.NUM_KERNEL_FAMILIES and "?" not in names

@@ -51,10 +51,13 @@ def test_threaded_graph_matches_oracle():
         lines = np.fromfile(os.path.join(tmp, "lines.f32"), np.float32).reshape(-1, N)
         ifs = np.fromfile(os.path.join(tmp, "if.f32"), np.float32).view(np.complex64)
         audio = np.fromfile(os.path.join(tmp, "audio.f32"), np.float32).reshape(-1, 2)
+        af = np.fromfile(os.path.join(tmp, "af.f32"), np.float32).reshape(-1, 2)
     nz, skip = capi.design_reshape_params(sr, N, rate)
     spec = S.OracleSpectrum(N, nz, skip, capi.design_fft_window(2, nz))
     raw = S.OracleChain(sr, 250e3, 150e3, sr / 8, None)
     wfm = S.OracleChain(sr, 250e3, 150e3, 300e3, S.MODES["WFM"])
+    from test_parity_vfo import _OracleAf
+    oaf, of = _OracleAf(250e3, 48000.0, 50e-6, False), []
     ol, oi, oa = [], [], []
     for b in range(nblk):
         blk = x[b * B:(b + 1) * B]
@@ -63,9 +66,12 @@ def test_threaded_graph_matches_oracle():
         ol.append(spec.push(blk))
         oi.append(raw.process(blk)[0])
         oa.append(wfm.process(blk)[1])
-    ol, oi, oa = np.concatenate(ol), np.concatenate(oi), np.concatenate(oa)
+        of.append(oaf.process(oa[-1]))
+    ol, oi, oa, of = np.concatenate(ol), np.concatenate(oi), np.concatenate(oa), np.concatenate(of)
     assert lines.shape == ol.shape and np.array_equal(lines, ol)
     assert audio.shape == oa.shape and np.sqrt(np.mean((audio - oa) ** 2)) < 1e-5
+    # RxVFO::attachAF: resampler to 48 kHz + 50 us de-emphasis behind the demodulator, delivered on the same `audio` stream
+    assert af.shape == of.shape and np.sqrt(np.mean((af - of) ** 2)) < 1e-5
     # setOffset() is called by the source thread right after it handed over the third block, i.e. asynchronously to the worker
     # (exactly like a GUI retune in SDR++): it takes effect from block 2 or 3.  Blocks 0-1 are therefore compared tightly.
     assert ifs.shape == oi.shape

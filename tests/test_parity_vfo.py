@@ -288,3 +288,86 @@ def test_am_carrier_agc_and_fm_without_lowpass(backend):
             ga = ctx.vfo_read(vid)
             assert ga.shape == oa.shape and rms(ga - oa) <= _audio_tol(oa)
     ctx.close()
+
+
+class _OracleAf:
+    """The radio module's AF chain on the oracle: RationalResampler<stereo_t> -> optional highPass(300,100) FIR -> optional Deemphasis
+    (radio_module.h:98-110); each piece is pinned bit-exactly to the reference in test_oracle_vs_reference.py."""
+
+    def __init__(self, af_rate, audio_rate, tau, high_pass):
+        import ctypes as C
+        from sdrplusplus_amd import capi
+
+        self.o = S.oracle()
+        self.rs = self.o.orc_resampler_create(S.plans_handle(), float(af_rate), float(audio_rate), 2)
+        self.ratio = float(audio_rate) / float(af_rate)
+        self.hp = None
+        if high_pass:
+            self.hp_taps = capi.design_high_pass(300.0, 100.0, audio_rate)
+            self.hp = self.o.orc_fir_create(S._fp(self.hp_taps), len(self.hp_taps), 1, 2)
+        self.de = self.o.orc_deemp_create(float(tau), float(audio_rate)) if tau else None
+
+    def process(self, audio):
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        out = np.empty((int(len(a) * max(1.0, self.ratio)) + 64, 2), np.float32)  # the AF resampler may interpolate (15 k -> 48 k)
+        n = self.o.orc_resampler_process(self.rs, len(a), S._fp(a), S._fp(out)) if len(a) else 0
+        y = np.ascontiguousarray(out[:n])
+        if self.hp is not None and n:
+            z = np.empty_like(y)
+            self.o.orc_fir_process(self.hp, n, S._fp(y), S._fp(z))
+            y = z
+        if self.de is not None and n:
+            z = np.empty_like(y)
+            self.o.orc_deemp_process(self.de, n, S._fp(y), S._fp(z))
+            y = z
+        return y
+
+
+@pytest.mark.parametrize("mode,high_pass,tau", [("WFM", False, 50e-6), ("NFM", True, None), ("AM", False, 75e-6)])
+def test_af_chain(backend, mode, high_pass, tau):
+    """demodulator output -> AF resampler to 48 kHz -> [high-pass 300 Hz, 1824 taps] -> [de-emphasis] on the
+    device (sdrpp_vfo_set_af) against the oracle chain, over uneven pushes; the demodulator output itself stays readable."""
+    from sdrplusplus_amd import radio, workloads
+
+    sr = 10e6 if mode == "WFM" else 2.4e6
+    pushes = [50000, 12000, 7, 30011, 50000] if mode == "WFM" else [48000, 12000, 7, 30011, 48000]
+    if_rate, bw = radio.RADIO_DEFAULTS[mode]
+    if mode == "WFM":  # cfg 3 content: listen to one of its FM carriers
+        x = workloads.synth(3, sum(pushes), seed=21, nvfo=4)
+        offset = workloads.vfo_plan(3, 4)[1][3]
+    else:              # a carrier with 1 kHz AM and 700 Hz FM (+ a little noise) where this VFO listens
+        offset = 250e3
+        rng = np.random.default_rng(21)
+        n = np.arange(sum(pushes))
+        dev = 2.0 if mode == "NFM" else 0.0
+        tone = 0.2 * (1.0 + 0.3 * np.sin(2 * np.pi * 1000.0 * n / sr)) * np.exp(2j * np.pi * offset * n / sr + 1j * dev * np.sin(2 * np.pi * 700.0 * n / sr))
+        x = (tone + 0.002 * (rng.standard_normal(len(n)) + 1j * rng.standard_normal(len(n)))).astype(np.complex64)
+    ctx, vids, chains, _ = _setup(sr, [(mode, offset)], max(pushes))
+    a, keep = radio.af_desc(if_rate, 48000.0, tau, high_pass)
+    ctx.vfo_set_af(vids[0], a, keep)
+    oaf = _OracleAf(if_rate, 48000.0, tau, high_pass)
+    worst, worst_dem, pos, total = 0.0, 0.0, 0, 0
+    for npush in pushes:
+        blk = x[pos:pos + npush]
+        pos += npush
+        ctx.push(blk)
+        _, oa = chains[0].process(blk)
+        ref = oaf.process(oa)
+        got = ctx.vfo_af_read(vids[0])
+        dem = ctx.vfo_read(vids[0])
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert dem.shape == oa.shape
+        total += len(ref)
+        if len(ref):
+            worst = max(worst, rms(got - ref) / max(1.0, rms(ref)))
+        if len(oa):
+            worst_dem = max(worst_dem, rms(dem - oa) / max(1.0, rms(oa)))
+    assert total > 0
+    assert worst < 1e-5, worst
+    assert worst_dem < 1e-5, worst_dem
+    # detach: the VFO keeps running without the chain
+    ctx.vfo_set_af(vids[0], None)
+    ctx.push(x[:5000])
+    with pytest.raises(Exception):
+        ctx.vfo_af_count(vids[0])
+    ctx.close()
