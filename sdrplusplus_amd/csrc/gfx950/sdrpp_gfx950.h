@@ -50,6 +50,17 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave-uniform helpers: value of lane `src` (src uniform across the wavefront: v_readlane_b32), and the maximum over all 64 lanes.
+__device__ __forceinline__ float wave_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_xor(v, d, 64);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
 // FP32 matrix core: D(32x32) += A(32x2) * B(2x32), v_mfma_f32_32x32x2_f32, 64 cycles per instruction.  Lane l supplies
 // A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; it receives, in register r, D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31].
 // Numerically the result is the k-ordered fmaf chain d = fmaf(A[i][1], B[1][j], fmaf(A[i][0], B[0][j], c)) — plain f32, one

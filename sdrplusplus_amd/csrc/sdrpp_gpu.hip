@@ -941,6 +941,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     S1Launch s1l[4];
     F2Launch f2l[4];
     FCMLaunch fcm[3];  // PF 6 / 10 / 16
+    FCMLaunch fcl;     // long first stages (vfo_frontcl_kernel)
     const int vts[4] = { 8, 4, 2, 1 };
     for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
     size_t i = 0;
@@ -950,14 +951,26 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         size_t g = i;
         // ---- matrix-core path: >= 17 fused VFOs of one geometry -> jobs of up to 32 VFOs, stages 1 + 2 as one composite FIR ----
         int m_pf = 0;
-        const bool m_ok = s1[i].fused && frontcm_ok(s1[i].K, s1[i].lgD, s1[i].K2, s1[i].lgD2, &m_pf);
-        while (m_ok && j - g >= 17) {
+        const bool m_fused = s1[i].fused && frontcm_ok(s1[i].K, s1[i].lgD, s1[i].K2, s1[i].lgD2, &m_pf);
+        // ... or a long first stage on its own (decimation >= 32: no fusion, vfo_frontcl_kernel)
+        const bool m_long = !m_fused && !s1[i].fused && s1[i].lgD >= 5 && s1[i].K >= 9 && (size_t)frontcl_lds_floats(s1[i].K, s1[i].lgD) * 4 <= (size_t)kMaxLds;
+        const bool m_ok = m_fused || m_long;
+        // worth it from 17 VFOs against the fused VALU kernel (8 VFOs per work-item); a long first stage has no good VALU form (its
+        // per-VFO windows do not fit LDS), there the matrix kernel pays off from 2 VFOs on
+        const size_t m_min = m_long ? 2 : 17;
+        while (m_ok && j - g >= m_min) {
             const int vt = (int)std::min<size_t>(j - g, SDRPP_FCM_VT);
-            const S1Member& h = s1[g];
+            S1Member h = s1[g];
+            if (m_long) {  // the "composite" is the first stage alone
+                h.K2 = 1;
+                h.lgD2 = 0;
+                h.off2 = 0;
+                h.nout2 = h.nout;
+            }
             const int D1 = 1 << h.lgD;
             const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
             const int NP = (K + 1) / 2, NP4 = (NP + 3) / 4 * 4;
-            std::string key = "M";
+            std::string key = m_long ? "L" : "M";
             for (int m = 0; m < vt; m++) {
                 char b[64];
                 snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
@@ -977,7 +990,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                     // composite taps h12 = h1 (*) upsample(h2, D1) in double precision (both are linear phase, so is h12)
                     std::fill(h12.begin(), h12.end(), 0.0);
                     for (int k2 = 0; k2 < h.K2; k2++) {
-                        for (int k1 = 0; k1 < h.K; k1++) { h12[(size_t)k2 * D1 + k1] += (double)vv.staps[1][(size_t)k2] * (double)vv.staps[0][(size_t)k1]; }
+                        const double w2 = m_long ? 1.0 : (double)vv.staps[1][(size_t)k2];
+                        for (int k1 = 0; k1 < h.K; k1++) { h12[(size_t)k2 * D1 + k1] += w2 * (double)vv.staps[0][(size_t)k1]; }
                     }
                     for (int pz = 0; pz < NP; pz++) {
                         double t = ((double)pz - kc) * vv.theta;  // modulation centred on the filter: g[K-1-k] = conj(g[k])
@@ -1017,20 +1031,30 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             job.nout = h.nout2;
             job.min_idx = h.min_idx;
             const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
-            // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first)
-            job.tiles_per_wave = std::max(1, (ntiles + 3071) / 3072);
+            // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
+            // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
+            const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD) * 4))) : 0;
+            const int resident = m_long ? 256 * long_blocks * 2 : 3072;
+            job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
             job.atab = reinterpret_cast<const float*>(d_taps);
             job.ptab = d_taps + (size_t)NP4 * 32;
             for (int m = 0; m < SDRPP_FCM_VT; m++) {
                 Vfo* v = s1[g + std::min(m, vt - 1)].v;
                 job.theta[m] = v->theta;
                 job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
-                job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
+                job.out[m] = (float2*)v->st[(size_t)v->i_first + (m_long ? 0 : 1)].data;
             }
-            FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
-            L.jobs.push_back(job);
-            L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
-            L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
+            if (m_long) {
+                fcl.jobs.push_back(job);
+                fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + 2 * job.tiles_per_wave - 1) / (2 * job.tiles_per_wave));
+                fcl.lds = std::max(fcl.lds, (size_t)frontcl_lds_floats(K, lgD) * 4);
+            }
+            else {
+                FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
+                L.jobs.push_back(job);
+                L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
+                L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
+            }
             g += (size_t)vt;
         }
         while (g < j) {
@@ -1144,6 +1168,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
     }
+    FrontCMJob* d_fcl = arena_push(c, fcl.jobs);
+    if (!fcl.jobs.empty() && !d_fcl) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     FrontCMJob* d_fcm[3] = {};
     for (int k = 0; k < 3; k++) {
         if (!fcm[k].jobs.empty()) {
@@ -1292,6 +1318,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             else if (k == 1) { launch(c, vfo_frontcm_kernel<10, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
             else { launch(c, vfo_frontcm_kernel<16, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
         }
+        if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
+            launch(c, vfo_frontcl_kernel, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl);
+        }
         if (!rot.empty() && max_rot > 0) {
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
         }
@@ -1418,7 +1447,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             for (auto& q : pre) { mx = std::max(mx, q.n); }
             if (mx > 0) { launch(c, vfo_demod_pre_kernel, dim3(std::min((mx + 255) / 256, 1024), (unsigned)pre.size()), dim3(256), 0, (const PreJob*)d_pre); }
         }
-        if (!seq.empty()) { launch(c, vfo_sequential_kernel, dim3(((unsigned)seq.size() + 63) / 64), dim3(64), 0, (const SeqJob*)d_seq, (int)seq.size()); }
+        if (!seq.empty()) { launch(c, vfo_sequential_kernel, dim3((unsigned)seq.size()), dim3(64), 0, (const SeqJob*)d_seq, (int)seq.size()); }
     }
     {
         FamilyTimer t(c, F_FIR);

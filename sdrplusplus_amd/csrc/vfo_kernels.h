@@ -426,89 +426,125 @@ __device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
     return gain;
 }
 
-// One work-item per VFO: only the recursions (DC blocker, AGC) are left here.
+// One WAVEFRONT per VFO: only the recursions (DC blocker, AGC) are left here.  The lanes fetch 64 consecutive samples with one
+// coalesced load; every lane then evaluates the same (uniform) recursion, taking sample i from lane i with v_readlane — a
+// one-work-item loop over global memory pays ~1 us of load latency per sample.  The AGC's look-ahead to the end of the push
+// (agc.h:91-104) is a wave-wide max reduction where it is a plain maximum, and the same chunked loop where it has to re-run the
+// DC blocker forward (AM, audio AGC).
 __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __restrict__ jobs, int njobs) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int id = blockIdx.x;
     if (id >= njobs) { return; }
     const SeqJob job = jobs[id];
+    const int lane = threadIdx.x;
+    const int n = job.n;
     if (job.mode == 2) {
         AgcState agc = *job.agc;
         AgcState cagc = *job.carrier_agc;
         float off = *job.dc_offset;
-        for (int i = 0; i < job.n; i++) {
-            float mag;
-            if (job.carrier_mode) {
-                float2 x = job.in[i];
-                float inAmp = sqrtf((x.x * x.x) + (x.y * x.y));
-                float gain = agc_gain(cagc, inAmp);
-                if (inAmp * gain > cagc.max_output_amp) {
-                    float maxAmp = 0.0f;
-                    for (int j = i; j < job.n; j++) {
-                        const float2 y = job.in[j];
-                        const float a = sqrtf((y.x * y.x) + (y.y * y.y));
-                        if (a > maxAmp) { maxAmp = a; }
+        for (int base = 0; base < n; base += 64) {
+            const int cnt = (n - base < 64) ? n - base : 64;
+            float2 xin = make_float2(0.0f, 0.0f);
+            float pv = 0.0f;
+            if (lane < cnt) {
+                if (job.carrier_mode) { xin = job.in[base + lane]; }
+                else { pv = job.pre[base + lane]; }
+            }
+            const float amp_l = sqrtf((xin.x * xin.x) + (xin.y * xin.y));  // carrier mode: |x| of this lane's sample
+            float outv = 0.0f;
+            for (int i = 0; i < cnt; i++) {
+                float mag;
+                if (job.carrier_mode) {
+                    float2 x = make_float2(wave_bcast(xin.x, i), wave_bcast(xin.y, i));
+                    const float inAmp = wave_bcast(amp_l, i);
+                    float gain = agc_gain(cagc, inAmp);
+                    if (inAmp * gain > cagc.max_output_amp) {
+                        float m = (lane >= i && lane < cnt) ? amp_l : 0.0f;  // rest of this chunk, then the rest of the push
+                        for (int b2 = base + 64 + lane; b2 < n; b2 += 64) {
+                            const float2 y = job.in[b2];
+                            const float a = sqrtf((y.x * y.x) + (y.y * y.y));
+                            if (a > m) { m = a; }
+                        }
+                        cagc.amp = wave_max(m);
+                        const float g = cagc.set_point / cagc.amp;
+                        gain = (cagc.max_gain < g) ? cagc.max_gain : g;
                     }
-                    cagc.amp = maxAmp;
-                    const float g = cagc.set_point / cagc.amp;
-                    gain = (cagc.max_gain < g) ? cagc.max_gain : g;
+                    x.x = x.x * gain;
+                    x.y = x.y * gain;
+                    mag = sqrtf((x.x * x.x) + (x.y * x.y));
                 }
-                x.x = x.x * gain;
-                x.y = x.y * gain;
-                mag = sqrtf((x.x * x.x) + (x.y * x.y));
-            }
-            else {
-                mag = job.pre[i];
-            }
-            float v = mag - off;
-            off += v * job.dc_rate;
-            if (!job.carrier_mode) {
-                // audio AGC sees the DC-blocked envelope; its look-ahead needs the not-yet-computed future samples of the same
-                // recursion, so it re-runs the DC blocker forward from the current state (exactly what the reference's
-                // in-place buffer holds at that moment).
-                float inAmp = fabsf(v);
-                float gain = agc_gain(agc, inAmp);
-                if (inAmp * gain > agc.max_output_amp) {
-                    float maxAmp = inAmp;
-                    float o2 = off;
-                    for (int j = i + 1; j < job.n; j++) {
-                        const float v2 = job.pre[j] - o2;
-                        o2 += v2 * job.dc_rate;
-                        const float a2 = fabsf(v2);
-                        if (a2 > maxAmp) { maxAmp = a2; }
+                else {
+                    mag = wave_bcast(pv, i);
+                }
+                float v = mag - off;
+                off += v * job.dc_rate;
+                if (!job.carrier_mode) {
+                    // audio AGC sees the DC-blocked envelope; its look-ahead needs the not-yet-computed future samples of the same
+                    // recursion, so it re-runs the DC blocker forward from the current state (exactly what the reference's
+                    // in-place buffer holds at that moment).
+                    const float inAmp = fabsf(v);
+                    float gain = agc_gain(agc, inAmp);
+                    if (inAmp * gain > agc.max_output_amp) {
+                        float maxAmp = inAmp;
+                        float o2 = off;
+                        for (int j = i + 1; j < cnt; j++) {
+                            const float v2 = wave_bcast(pv, j) - o2;
+                            o2 += v2 * job.dc_rate;
+                            const float a2 = fabsf(v2);
+                            if (a2 > maxAmp) { maxAmp = a2; }
+                        }
+                        for (int b2 = base + 64; b2 < n; b2 += 64) {
+                            const int c2 = (n - b2 < 64) ? n - b2 : 64;
+                            const float q = (lane < c2) ? job.pre[b2 + lane] : 0.0f;
+                            for (int j = 0; j < c2; j++) {
+                                const float v2 = wave_bcast(q, j) - o2;
+                                o2 += v2 * job.dc_rate;
+                                const float a2 = fabsf(v2);
+                                if (a2 > maxAmp) { maxAmp = a2; }
+                            }
+                        }
+                        agc.amp = maxAmp;
+                        const float g = agc.set_point / agc.amp;
+                        gain = (agc.max_gain < g) ? agc.max_gain : g;
                     }
-                    agc.amp = maxAmp;
-                    const float g = agc.set_point / agc.amp;
-                    gain = (agc.max_gain < g) ? agc.max_gain : g;
+                    v = v * gain;
                 }
-                v = v * gain;
+                if (lane == i) { outv = v; }
             }
-            job.pre[i] = v;
+            if (lane < cnt) { job.pre[base + lane] = outv; }
         }
-        *job.agc = agc;
-        *job.carrier_agc = cagc;
-        *job.dc_offset = off;
+        if (lane == 0) {
+            *job.agc = agc;
+            *job.carrier_agc = cagc;
+            *job.dc_offset = off;
+        }
     }
     else {
         AgcState agc = *job.agc;
         float2* out = reinterpret_cast<float2*>(job.out);
-        for (int i = 0; i < job.n; i++) {
-            const float re = job.pre[i];
-            float inAmp = fabsf(re);
-            float gain = agc_gain(agc, inAmp);
-            if (inAmp * gain > agc.max_output_amp) {
-                float maxAmp = inAmp;
-                for (int j = i + 1; j < job.n; j++) {
-                    const float a2 = fabsf(job.pre[j]);
-                    if (a2 > maxAmp) { maxAmp = a2; }
+        for (int base = 0; base < n; base += 64) {
+            const int cnt = (n - base < 64) ? n - base : 64;
+            const float pv = (lane < cnt) ? job.pre[base + lane] : 0.0f;
+            float outv = 0.0f;
+            for (int i = 0; i < cnt; i++) {
+                const float re = wave_bcast(pv, i);
+                const float inAmp = fabsf(re);
+                float gain = agc_gain(agc, inAmp);
+                if (inAmp * gain > agc.max_output_amp) {
+                    float m = (lane >= i && lane < cnt) ? fabsf(pv) : 0.0f;
+                    for (int b2 = base + 64 + lane; b2 < n; b2 += 64) {
+                        const float a2 = fabsf(job.pre[b2]);
+                        if (a2 > m) { m = a2; }
+                    }
+                    agc.amp = wave_max(m);
+                    const float g = agc.set_point / agc.amp;
+                    gain = (agc.max_gain < g) ? agc.max_gain : g;
                 }
-                agc.amp = maxAmp;
-                const float g = agc.set_point / agc.amp;
-                gain = (agc.max_gain < g) ? agc.max_gain : g;
+                const float v = re * gain;
+                if (lane == i) { outv = v; }
             }
-            const float v = re * gain;
-            out[i] = make_float2(v, v);
+            if (lane < cnt) { out[base + lane] = make_float2(outv, outv); }
         }
-        *job.agc = agc;
+        if (lane == 0) { *job.agc = agc; }
     }
 }
 
@@ -1059,6 +1095,122 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
             }
         }
         wave_sync();  // every lane is done with the planes and tile phasors before the next tile overwrites them
+    }
+}
+
+// Long first stages (decimation by 32 or 64 with 143...726 taps: the plans for narrow channels in a very wide capture, e.g. cfg 4's
+// 61.44 MS/s -> 60 kS/s) use the same matrix formulation with the first stage alone as the "composite" filter, in a leaner
+// shape: 2 wavefronts per block (a wavefront's two IQ planes are ~20 KB), the IQ window goes straight from global memory to the
+// planes (no register staging: it would need ~70 VGPRs), and the tap operand — up to 363 pairs x 64 lanes — streams from
+// global memory / L2 through a four-deep register ring instead of living in LDS.
+__host__ __device__ inline int frontcl_lds_floats(int K, int lgD) {
+    const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
+    return 2 * 2 * frontcm_plane(nsamp, lgD) + 2 * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // 2 waves x 2 planes + tile phasors + pointers
+}
+__global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    const FrontCMJob& job = jobs[blockIdx.y];
+    constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
+    const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
+    const int NP = (K + 1) >> 1, NP4 = ((NP + 3) >> 2) << 2;
+    const bool odd = (K & 1) != 0;
+    const int nsamp = (tile - 1) * D + K;
+    const int pl = frontcm_plane(nsamp, lgD);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
+    float* XR = smemf + wv * 2 * pl;
+    float* XI = XR + pl;
+    float2* ptile = reinterpret_cast<float2*>(smemf + 4 * pl) + wv * VT;
+    float2** outp = reinterpret_cast<float2**>(smemf + 4 * pl + 2 * VT * 2);
+    if (tid < VT) { outp[tid] = job.out[tid]; }
+    __syncthreads();  // the only workgroup barrier
+    const int tile0 = (blockIdx.x * 2 + wv) * job.tiles_per_wave;
+    if (tile0 * tile >= job.nout) { return; }
+    int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
+    if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
+    float2 pt[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
+    }
+    const float sgn = hi ? -1.0f : 1.0f;
+    const float* P1 = hi ? XI : XR;
+    const float* P2 = hi ? XR : XI;
+    const int ib = jl * D + jl;
+    for (int it = 0; it < ntl; it++) {
+        const int tb = tile0 + it;
+        const long long base = (long long)job.off + (long long)tb * tile * D;
+        // ---- IQ window -> skewed planes (eight loads in flight per lane) ----
+        {
+            const bool inside = base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur;
+            for (int s0 = 0; s0 < nsamp; s0 += 64 * 8) {
+                float2 tmp[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int sidx = s0 + q * 64 + lane;
+                    if (inside) { tmp[q] = (sidx < nsamp) ? src.cur[base + sidx] : make_float2(0.0f, 0.0f); }
+                    else {
+                        const long long gi = base + sidx;
+                        tmp[q] = (sidx < nsamp && gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int sidx = s0 + q * 64 + lane;
+                    if (sidx < nsamp) {
+                        const int idx = sidx + (sidx >> lgD);
+                        XR[idx] = tmp[q].x;
+                        XI[idx] = tmp[q].y;
+                    }
+                }
+            }
+        }
+        if (lane < VT && lane < job.nv) {
+            double ph = fma((double)base + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            ptile[lane] = make_float2(cs, sn);
+        }
+        wave_sync();
+        f32x16 accR = mfma_zero(), accI = mfma_zero();
+        {
+            // tap operand ring: four pairs ahead, coalesced 256-byte rows of the [pair][64] table (rows >= NP are zero padding)
+            float aq[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { aq[u] = global_load_f32(job.atab, u * 64 + lane); }
+            for (int p0 = 0; p0 < NP4; p0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int p = p0 + u;
+                    const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
+                    const int kb = K - 1 - pe;
+                    const int ia = ib + pe + (pe >> lgD), ibb = ib + kb + (kb >> lgD);
+                    const float a1 = P1[ia], a2 = P2[ia];
+                    float b1 = P1[ibb], b2 = P2[ibb];
+                    if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
+                    const float bre = fmaf(sgn, b1, a1), bim = fmaf(sgn, b2, a2);
+                    const float a_re = aq[u];
+                    aq[u] = global_load_f32(job.atab, (p + 4 < NP4 ? p + 4 : p) * 64 + lane);
+                    accR = mfma_32x32x2(a_re, bre, accR);
+                    accI = mfma_32x32x2(hi ? -a_re : a_re, bim, accI);
+                }
+            }
+        }
+        {
+            const int j0 = tb * tile;
+            const bool live = j0 + jl < job.nout;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (v < job.nv && live) {
+                    const float2 P = ptile[v];
+                    const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                    global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+                }
+            }
+        }
+        wave_sync();
     }
 }
 

@@ -13,6 +13,13 @@ static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
 static inline void sched_fence() {}
+static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
+static inline float wave_max(float v) {
+    const float* ab = hipemu::wave_exchange(v, 0.0f);
+    float m = ab[0];
+    for (int l = 1; l < 64; l++) { m = (ab[l * 2] > m) ? ab[l * 2] : m; }
+    return m;
+}
 static inline void wave_sync() { hipemu::wave_exchange(0.0f, 0.0f); }  // fibers run lane by lane: a real 64-lane rendezvous
 // v_mfma_f32_32x32x2_f32 emulated with a 64-lane rendezvous (hipemu::wave_exchange): same lane <-> element maps, same fmaf chain.
 struct f32x16 {

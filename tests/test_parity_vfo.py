@@ -95,6 +95,35 @@ def test_matrix_core_front_bank(backend, nv):
     ctx.close()
 
 
+def test_long_first_stage_bank(backend):
+    """cfg 4 geometry (61.44 MS/s; plans 1024 / 4096 / 2048 with a /64 first stage of 257 / 400 / 329 taps): 18 VFOs per mode take
+    the matrix-core kernel for long first stages (vfo_frontcl_kernel), the stages behind it the Toeplitz kernels."""
+    from sdrplusplus_amd import workloads
+
+    sr, nv = 61.44e6, 54
+    pushes = [307200, 100003, 204397]
+    x = workloads.synth(4, sum(pushes), seed=13, nvfo=nv)
+    plan = workloads.vfo_plan(4, nv)
+    ctx, vids, chains, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan], max(pushes))
+    worst = {"NFM": 0.0, "AM": 0.0, "USB": 0.0}
+    pos = 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        ctx.push(blk)
+        for (mode, _, _, _, _), vid, ch in zip(plan, vids, chains):
+            oi, oa = ch.process(blk)
+            gi, ga = ctx.vfo_read_if(vid), ctx.vfo_read(vid)
+            assert gi.shape == oi.shape and ga.shape == oa.shape
+            if len(oa) and mode != "USB":  # SSB at arbitrary offsets is drift-limited (see the module docstring); its IF is checked instead
+                worst[mode] = max(worst[mode], rms(ga - oa) / max(1.0, rms(oa)))
+            if len(oi) and mode == "USB":
+                worst[mode] = max(worst[mode], rms(gi - oi) / max(rms(oi), 1e-9))
+    assert worst["NFM"] < 1e-5 and worst["AM"] < 1e-5, worst
+    assert worst["USB"] < 2e-3, worst  # IF: dominated by the reference rotator's own drift
+    ctx.close()
+
+
 def test_if_tight_with_exact_phase_steps(backend):
     """Offsets at multiples of sr/8: NCO and reference recursion are both exact, what is left is fp32 summation order."""
     sr, B = 10e6, 50000
