@@ -180,6 +180,19 @@ int sdrpp_vfo_af_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
 int sdrpp_vfo_af_device_buffer(sdrpp_ctx* ctx, int id, const float** out, int* n_out);
 int sdrpp_abi_sizeof_af_desc(void);
 
+/* ---- IQFrontEnd pre-processing chain (core/src/signal_path/iq_frontend.cpp:32-39, setDecimation /
+ *      setDCBlocking / setInvertIQ :105-130): PowerDecimator<complex_t> (stages of the plan for the ratio, power_decimator.h:93-111)
+ *      -> DCBlocker<complex_t> (dc_rate = genDCBlockRate(effectiveSr) = 50 / effectiveSr, iq_frontend.h:55-57; 0 = block disabled)
+ *      -> Conjugate.  Runs on the device in front of the FFT branch and the VFO bank: every later stage sees the pre-processed
+ *      stream at the effective sample rate (FFT framing, VFO descriptors are the caller's, designed at that rate).  max_push of
+ *      sdrpp_create counts RAW samples.  n_stages = 0, dc_rate = 0, conjugate = 0 removes the chain.  State starts cleared. */
+int sdrpp_preproc_configure(sdrpp_ctx* ctx, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps,
+                            float dc_rate, int conjugate);
+/* The pre-processed samples of the most recent push — what Splitter hands to streams bound with bindIQStream (iq_frontend.cpp:132-138). */
+int sdrpp_preproc_out_count(sdrpp_ctx* ctx);
+int sdrpp_preproc_read(sdrpp_ctx* ctx, float* dst_host, int max);
+int sdrpp_preproc_device_buffer(sdrpp_ctx* ctx, const float** iq, int* n);
+
 /* ---- data path ------------------------------------------------------------------------------------------------------------ */
 /* One block of IQ, as Splitter::run hands to every bound stream (splitter.h:46-61).  Host pointer: copied H2D first.
  * Device pointer: read in place (must stay valid until the next sdrpp_sync / stream synchronisation).  Runs the FFT

@@ -1059,6 +1059,37 @@ void orc_deemp_process(orc_deemp* d, int count, const float* in, float* out) {
     d->lastR = out[2 * (count - 1) + 1];
 }
 
+/* IQFrontEnd pre-processing chain (core/src/signal_path/iq_frontend.cpp:32-39): PowerDecimator<complex_t> (enabled when the ratio
+ * is > 1) -> DCBlocker<complex_t> (dsp/correction/dc_blocker.h:54-60, rate genDCBlockRate(effectiveSr) = 50 / effectiveSr,
+ * iq_frontend.h:55-57) -> Conjugate (dsp/math/conjugate.h:12-15, volk_32fc_conjugate_32fc).  SURVEY.md 8f row 2. */
+typedef struct { orc_powdec dec; int dc_on, conj_on; float rate, offRe, offIm; } orc_preproc;
+orc_preproc* orc_preproc_create(const orc_plans* plans, int ratio, int dcBlocking, double dcRate, int conjugate) {
+    orc_preproc* p = (orc_preproc*)calloc(1, sizeof(orc_preproc));
+    powdec_init(&p->dec, plans, ratio, 2);
+    p->dc_on = dcBlocking;
+    p->rate = (float)dcRate; /* DCBlocker::init(in, double rate) stores a float _rate (dc_blocker.h:13-27) */
+    p->conj_on = conjugate;
+    return p;
+}
+void orc_preproc_destroy(orc_preproc* p) { if (p) { powdec_free(&p->dec); free(p); } }
+/* out must hold `count` complex samples; returns the number produced */
+int orc_preproc_process(orc_preproc* p, int count, const float* in, float* out) {
+    int n = powdec_process(&p->dec, count, in, out, 2);
+    if (p->dc_on) {
+        for (int i = 0; i < n; i++) { /* out[i] = in[i] - offset; offset += out[i] * _rate (complex_t operators, types.h) */
+            const float re = out[2 * i] - p->offRe, im = out[2 * i + 1] - p->offIm;
+            out[2 * i] = re;
+            out[2 * i + 1] = im;
+            p->offRe += re * p->rate;
+            p->offIm += im * p->rate;
+        }
+    }
+    if (p->conj_on) {
+        for (int i = 0; i < n; i++) { out[2 * i + 1] = -out[2 * i + 1]; }
+    }
+    return n;
+}
+
 /* source_modules/file_source/src/main.cpp:162: volk_16i_s32f_convert_32f(out, in, 32768.0f, 2*count) */
 void orc_int16_to_float(const int16_t* in, float* out, int n) {
     const float iScalar = 1.0f / 32768.0f;

@@ -33,6 +33,9 @@ static inline int sdrpp_ref_quiet_printf(const char*, ...) { return 0; }
 #include <dsp/demod/ssb.h>
 #include <dsp/filter/deephasis.h>
 #include <dsp/multirate/rational_resampler.h>
+#include <dsp/multirate/power_decimator.h>
+#include <dsp/correction/dc_blocker.h>
+#include <dsp/math/conjugate.h>
 #include <dsp/taps/low_pass.h>
 #include <dsp/taps/high_pass.h>
 #include <dsp/window/nuttall.h>
@@ -134,6 +137,39 @@ int ref_demod_process(void* h, int count, const float* in, float* out) {
     if (d->nfm) { return d->nfm->process(count, cin, (stereo_t*)out); }
     if (d->am) { return d->am->process(count, cin, (stereo_t*)out); }
     return d->ssb->process(count, cin, (stereo_t*)out);
+}
+
+// ---- IQFrontEnd pre-processing chain (iq_frontend.cpp:32-39): PowerDecimator -> DCBlocker -> Conjugate, process() level -------------
+struct RefPreproc {
+    dsp::multirate::PowerDecimator<complex_t> decim;
+    dsp::correction::DCBlocker<complex_t> dcBlock;
+    int ratio, dc, conj;
+    complex_t* work;
+};
+void* ref_preproc_create(int ratio, int dcBlocking, double dcRate, int conjugate) {
+    RefPreproc* p = new RefPreproc;
+    p->decim.init(NULL, ratio);
+    p->dcBlock.init(NULL, dcRate);
+    p->ratio = ratio;
+    p->dc = dcBlocking;
+    p->conj = conjugate;
+    p->work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
+    return p;
+}
+void ref_preproc_destroy(void* h) {
+    RefPreproc* p = (RefPreproc*)h;
+    dsp::buffer::free(p->work);
+    delete p;
+}
+// count <= STREAM_BUFFER_SIZE; the chain enables the decimator only for ratio > 1 (iq_frontend.cpp:37)
+int ref_preproc_process(void* h, int count, const float* in, float* out) {
+    RefPreproc* p = (RefPreproc*)h;
+    int n = count;
+    if (p->ratio > 1) { n = p->decim.process(count, (const complex_t*)in, (complex_t*)out); }
+    else { memcpy(out, in, sizeof(complex_t) * (size_t)count); }
+    if (p->dc) { p->dcBlock.process(n, (complex_t*)out, (complex_t*)out); }
+    if (p->conj) { dsp::math::Conjugate::process(n, (complex_t*)out, (complex_t*)out); }
+    return n;
 }
 
 // ---- RationalResampler<stereo_t/complex_t> and Deemphasis (AF chain, radio_module.h:102-110) ----------------------------------

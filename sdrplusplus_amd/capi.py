@@ -118,6 +118,10 @@ def load():
         raise ImportError("sdrpp_af_desc layout mismatch: library %d bytes, binding %d" % (L.sdrpp_abi_sizeof_af_desc(), C.sizeof(AfDesc)))
     L.sdrpp_design_deemphasis_alpha.restype = C.c_float
     L.sdrpp_design_deemphasis_alpha.argtypes = [C.c_double, C.c_double]
+    L.sdrpp_preproc_configure.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_float, C.c_int]
+    L.sdrpp_preproc_out_count.argtypes = [vp]
+    L.sdrpp_preproc_read.argtypes = [vp, c_float_p, C.c_int]
+    L.sdrpp_preproc_device_buffer.argtypes = [vp, C.POINTER(vp), c_int_p]
     L.sdrpp_vfo_set_af.argtypes = [vp, C.c_int, C.POINTER(AfDesc)]
     L.sdrpp_vfo_af_count.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_af_read.argtypes = [vp, C.c_int, c_float_p, C.c_int]
@@ -164,6 +168,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
+    "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
@@ -339,6 +344,21 @@ class Context:
         n = self.vfo_out_count(vid)
         out = np.empty((max(n, 1), 2), dtype=np.float32)
         got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
+        return out[:got]
+
+    def preproc_configure(self, stages=(), dc_rate=0.0, conjugate=False):
+        """IQFrontEnd pre-processing chain: `stages` = [(decimation, taps)] of the PowerDecimator plan, dc_rate (0 = off), conjugate."""
+        n = len(stages)
+        dec = (C.c_int * max(n, 1))(*[int(d) for d, _ in stages])
+        nt = (C.c_int * max(n, 1))(*[len(t) for _, t in stages])
+        arrs = [np.ascontiguousarray(t, dtype=np.float32) for _, t in stages]
+        ptrs = (c_float_p * max(n, 1))(*[a.ctypes.data_as(c_float_p) for a in arrs])
+        self._chk(self.L.sdrpp_preproc_configure(self.h, n, dec, nt, ptrs, float(dc_rate), int(bool(conjugate))))
+
+    def preproc_read(self):
+        n = self._chk(self.L.sdrpp_preproc_out_count(self.h))
+        out = np.empty(max(n, 1), dtype=np.complex64)
+        got = self._chk(self.L.sdrpp_preproc_read(self.h, out.view(np.float32).ctypes.data_as(c_float_p), n))
         return out[:got]
 
     def vfo_set_af(self, vid, af_desc, keepalive=None):

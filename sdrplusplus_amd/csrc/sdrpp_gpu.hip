@@ -130,6 +130,28 @@ struct sdrpp_ctx {
     int iq_hist_cap = 0;              // samples of history kept
     int iq_cur = 0;
 
+    // IQFrontEnd pre-processing chain (sdrpp_preproc_configure): PowerDecimator -> DCBlocker -> Conjugate on the wideband stream,
+    // in front of the FFT branch and the VFO bank (iq_frontend.cpp:32-39)
+    struct Pre {
+        bool on = false;
+        int n_stages = 0, decim_s[SDRPP_MAX_DECIM_STAGES] = { 1, 1, 1, 1 };
+        std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
+        ToepTab tp[SDRPP_MAX_DECIM_STAGES];
+        float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+        int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        float dc_rate = 0.0f;
+        int conj = 0;
+        Stream raw;               // history of the caller's buffer (data stays the caller's)
+        std::vector<Stream> st;   // decimator stage outputs
+        Stream out;               // DC blocker / conjugate output
+        float2* d_off = nullptr;  // DCBlocker::offset
+        float4* d_seg = nullptr;
+        int seg_cap = 0;
+        const float* last = nullptr;  // what the chain handed on for the most recent push
+        int last_n = 0;
+    } pre;
+
     // job arena
     char* arena_host[kArenaSlots] = {};
     char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
@@ -726,6 +748,53 @@ bool frontcm_ok(int K1, int lgD1, int K2, int lgD2, int* pf) {
     return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU
 }
 
+// ---- matrix-core FIR launches (vfo_toep_kernel): job construction, per-list planning (macro tiles per wavefront, grid, LDS), launch ----
+ToepJob toep_job(const ToepTab& T, int var, StreamIn in, float* out, int base0, int nout, float inv_dev) {
+    ToepJob j{};
+    j.in = in;
+    j.out = out;
+    j.tl = T.d_tl;
+    j.lbase = T.d_lb + (size_t)var * 64;
+    j.tl_len = T.tl_len;
+    j.nsteps = T.nsteps;
+    j.s_in = T.s_in;
+    j.rows = T.rows;
+    j.base0 = base0;
+    j.nout = nout;
+    j.mt_per_wave = 1;
+    j.inv_deviation = inv_dev;
+    return j;
+}
+
+struct ToepPlan { int grid_x = 0; size_t lds = 0; };
+ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
+    ToepPlan P;
+    if (jobs.empty()) { return P; }
+    const int G = 2;
+    int mtw = 1;
+    for (; mtw < 16; mtw++) {  // one resident round: <= 256 CUs x 4 blocks of four wavefronts (each job padded to whole blocks)
+        size_t blocks = 0;
+        for (auto& jb : jobs) { blocks += (size_t)((jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows) + 4 * mtw - 1) / (size_t)(4 * mtw); }
+        if (blocks <= 1024) { break; }
+    }
+    for (auto& jb : jobs) {
+        jb.mt_per_wave = mtw;
+        const int nmt = (jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows);
+        P.grid_x = std::max(P.grid_x, (nmt + 4 * mtw - 1) / (4 * mtw));
+        const int span = (G * 16 - 1) * jb.s_in + 4 * jb.nsteps, pl = (span + 8) & ~3;
+        P.lds = std::max(P.lds, ((size_t)((jb.tl_len + 3) & ~3) + (size_t)4 * npl * pl) * sizeof(float));
+    }
+    return P;
+}
+
+void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
+    if (jobs.empty() || P.grid_x == 0) { return; }
+    const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
+    if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    else if (width == 2) { launch(c, vfo_toep_kernel<2, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+}
+
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
     const int n_in = (int)count;
@@ -747,22 +816,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
     std::vector<PolyJob> af_poly;
     std::vector<DeempJob> af_deemp;
-    auto toep_job = [](const ToepTab& T, int var, StreamIn in, float* out, int base0, int nout, float inv_dev) {
-        ToepJob j{};
-        j.in = in;
-        j.out = out;
-        j.tl = T.d_tl;
-        j.lbase = T.d_lb + (size_t)var * 64;
-        j.tl_len = T.tl_len;
-        j.nsteps = T.nsteps;
-        j.s_in = T.s_in;
-        j.rows = T.rows;
-        j.base0 = base0;
-        j.nout = nout;
-        j.mt_per_wave = 1;
-        j.inv_deviation = inv_dev;
-        return j;
-    };
     int max_rot = 0;
 
     for (auto& kv : c->vfos) {
@@ -902,7 +955,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (a.i_deemp >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_deemp];
                 af_deemp.push_back(DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last, a.d_seg,
-                                             std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG) });
+                                             std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG), 0 });
                 nxt->n = acur->n;
                 acur = nxt;
             }
@@ -1178,26 +1231,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
     }
     // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
-    struct ToepPlan { int grid_x = 0; size_t lds = 0; };
-    auto toep_plan = [&](std::vector<ToepJob>& jobs, int npl) {
-        ToepPlan P;
-        if (jobs.empty()) { return P; }
-        const int G = 2;
-        int mtw = 1;
-        for (; mtw < 16; mtw++) {  // one resident round: <= 256 CUs x 4 blocks of four wavefronts (each job padded to whole blocks)
-            size_t blocks = 0;
-            for (auto& jb : jobs) { blocks += (size_t)((jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows) + 4 * mtw - 1) / (size_t)(4 * mtw); }
-            if (blocks <= 1024) { break; }
-        }
-        for (auto& jb : jobs) {
-            jb.mt_per_wave = mtw;
-            const int nmt = (jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows);
-            P.grid_x = std::max(P.grid_x, (nmt + 4 * mtw - 1) / (4 * mtw));
-            const int span = (G * 16 - 1) * jb.s_in + 4 * jb.nsteps, pl = (span + 8) & ~3;
-            P.lds = std::max(P.lds, ((size_t)((jb.tl_len + 3) & ~3) + (size_t)4 * npl * pl) * sizeof(float));
-        }
-        return P;
-    };
     ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
@@ -1383,24 +1416,17 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
         return SDRPP_OK;
     };
-    auto launch_toep = [&](std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
-        if (jobs.empty() || P.grid_x == 0) { return; }
-        const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
-        if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-        else if (width == 2) { launch(c, vfo_toep_kernel<2, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-        else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-    };
     {
         FamilyTimer t(c, F_DECIM);
         for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
-            launch_toep(t_lvl[s], d_t_lvl[s], tp_lvl[s], 2, false);
+            launch_toep(c, t_lvl[s], d_t_lvl[s], tp_lvl[s], 2, false);
             rc = launch_fir(lvl[s], d_lvl[s], 2, false);
             if (rc) { return rc; }
         }
     }
     if (!t_poly.empty()) {
         FamilyTimer t(c, F_POLY);
-        launch_toep(t_poly, d_t_poly, tp_poly, 2, false);
+        launch_toep(c, t_poly, d_t_poly, tp_poly, 2, false);
     }
     if (!poly.empty()) {
         FamilyTimer t(c, F_POLY);
@@ -1431,7 +1457,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     {
         FamilyTimer t(c, F_FIR);
-        launch_toep(t_chan, d_t_chan, tp_chan, 2, false);
+        launch_toep(c, t_chan, d_t_chan, tp_chan, 2, false);
         rc = launch_fir(chan, d_chan, 2, false);
         if (rc) { return rc; }
     }
@@ -1451,8 +1477,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     {
         FamilyTimer t(c, F_FIR);
-        launch_toep(t_audio, d_t_audio, tp_audio, 1, false);
-        launch_toep(t_audio_fm, d_t_audio_fm, tp_audio_fm, 1, true);
+        launch_toep(c, t_audio, d_t_audio, tp_audio, 1, false);
+        launch_toep(c, t_audio_fm, d_t_audio_fm, tp_audio_fm, 1, true);
         rc = launch_fir(audio, d_audio, 1, true);
         if (rc) { return rc; }
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
@@ -1463,14 +1489,14 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if (any_af) {
         FamilyTimer t(c, F_AF);
         for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-            launch_toep(t_af_lvl[s], d_t_af_lvl[s], tp_af_lvl[s], 2, false);
+            launch_toep(c, t_af_lvl[s], d_t_af_lvl[s], tp_af_lvl[s], 2, false);
             rc = launch_fir(af_lvl[s], d_af_lvl[s], 2, false);
             if (rc) { return rc; }
         }
-        launch_toep(t_af_poly, d_t_af_poly, tp_af_poly, 2, false);
+        launch_toep(c, t_af_poly, d_t_af_poly, tp_af_poly, 2, false);
         rc = launch_polyc(af_poly, d_af_poly);
         if (rc) { return rc; }
-        launch_toep(t_af_hpf, d_t_af_hpf, tp_af_hpf, 2, false);
+        launch_toep(c, t_af_hpf, d_t_af_hpf, tp_af_hpf, 2, false);
         rc = launch_fir(af_hpf, d_af_hpf, 2, false);
         if (rc) { return rc; }
         if (!af_deemp.empty()) {
@@ -1478,9 +1504,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             for (auto& jb : af_deemp) { max_seg = std::max(max_seg, jb.nseg); }
             if (max_seg > 0) {
                 const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.size());
-                launch(c, vfo_deemph_kernel<0>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
-                launch(c, vfo_deemph_kernel<1>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
-                launch(c, vfo_deemph_state_kernel, dim3(((unsigned)af_deemp.size() + 63) / 64), dim3(64), 0, (const DeempJob*)d_af_deemp, (int)af_deemp.size());
+                launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
+                launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
+                launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.size() + 63) / 64), dim3(64), 0, (const DeempJob*)d_af_deemp, (int)af_deemp.size());
             }
         }
     }
@@ -1504,6 +1530,94 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     return SDRPP_OK;
 }
 
+// ---- IQFrontEnd pre-processing chain: one push ------------------------------------------------------------------------------------
+// Decimator stages run on the matrix-core FIR kernel (register-blocked VALU kernel for tap counts it does not cover), the DC
+// blocker as a two-level scan (vfo_deemph_kernel<1, *>), the conjugate inside its store (or alone).  On return *d_iq / *count
+// describe the pre-processed stream; the raw and stage histories are carried for the next push.
+int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
+    sdrpp_ctx::Pre& P = c->pre;
+    const int n_in = (int)*count;
+    std::vector<ToepJob> tj[SDRPP_MAX_DECIM_STAGES];
+    std::vector<FirBJob> fj[SDRPP_MAX_DECIM_STAGES];
+    std::vector<CarryJob> carry;
+    std::vector<DeempJob> dc;
+    P.raw.data = const_cast<float*>(*d_iq);
+    P.raw.n = n_in;
+    Stream* cur = &P.raw;
+    for (int s = 0; s < P.n_stages; s++) {
+        Stream* nxt = &P.st[(size_t)s];
+        const int D = P.decim_s[s], K = (int)P.staps[s].size();
+        const int no = decim_nout(cur->n, P.soff[s], D);
+        if ((size_t)no > nxt->cap) { return fail(c, SDRPP_ERR_INVALID, "pre-processing stage %d: %d outputs exceed the capacity", s, no); }
+        if (P.tp[s].ok) { tj[s].push_back(toep_job(P.tp[s], 0, stream_in(*cur), nxt->data, P.soff[s] - (K - 1), no, 0.0f)); }
+        else { fj[s].push_back(FirBJob{ stream_in(*cur), nxt->data, P.d_staps[s], K, ilog2(D), P.soff[s], no, P.s_kp[s] }); }
+        P.soff[s] = P.soff[s] + no * D - cur->n;
+        nxt->n = no;
+        if (cur->hist_len > 0) { carry.push_back(CarryJob{ cur->data, cur->hist[cur->cur], cur->hist[cur->cur ^ 1], cur->hist_len, cur->n, 2, cur->hist_len }); }
+        cur = nxt;
+    }
+    const int n_out = cur->n;
+    const float* result = cur->data;
+    if (P.dc_rate != 0.0f) {
+        const int nseg = std::min(P.seg_cap, (n_out + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG);
+        dc.push_back(DeempJob{ (const float2*)cur->data, (float2*)P.out.data, n_out, P.dc_rate, P.d_off, P.d_seg, nseg, P.conj });
+        result = P.out.data;
+    }
+    else if (P.conj) { result = P.out.data; }
+    // job tables
+    ToepPlan tp[SDRPP_MAX_DECIM_STAGES];
+    ToepJob* d_tj[SDRPP_MAX_DECIM_STAGES] = {};
+    FirBJob* d_fj[SDRPP_MAX_DECIM_STAGES] = {};
+    for (int s = 0; s < P.n_stages; s++) {
+        tp[s] = toep_plan(tj[s], 2);
+        d_tj[s] = arena_push(c, tj[s]);
+        d_fj[s] = arena_push(c, fj[s]);
+        if ((!tj[s].empty() && !d_tj[s]) || (!fj[s].empty() && !d_fj[s])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    }
+    DeempJob* d_dc = arena_push(c, dc);
+    CarryJob* d_carry = arena_push(c, carry);
+    if ((!dc.empty() && !d_dc) || (!carry.empty() && !d_carry)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    int rc = arena_commit(c);
+    if (rc) { return rc; }
+    {
+        FamilyTimer t(c, F_MISC);
+        for (int s = 0; s < P.n_stages; s++) {
+            launch_toep(c, tj[s], d_tj[s], tp[s], 2, false);
+            for (auto& jb : fj[s]) {  // register-blocked fallback (one job): largest work-group whose window fits
+                const int R = SDRPP_FIR_R;
+                int threads = 256;
+                auto lds_for = [&](int nt) { return (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * 2 * 4; };
+                while (threads >= 32 && lds_for(threads) > (size_t)kMaxLds) { threads >>= 1; }
+                if (threads < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "pre-processing FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+                if (jb.nout > 0) { launch(c, vfo_firb_kernel<2, false>, dim3((unsigned)((jb.nout + threads * R - 1) / (threads * R)), 1), dim3(threads), lds_for(threads), (const FirBJob*)d_fj[s]); }
+            }
+        }
+        if (!dc.empty() && dc[0].nseg > 0) {
+            const dim3 grid((unsigned)dc[0].nseg, 1);
+            launch(c, vfo_deemph_kernel<1, 0>, grid, dim3(256), 0, (const DeempJob*)d_dc);
+            launch(c, vfo_deemph_kernel<1, 1>, grid, dim3(256), 0, (const DeempJob*)d_dc);
+            launch(c, vfo_deemph_state_kernel<1>, dim3(1), dim3(64), 0, (const DeempJob*)d_dc, 1);
+        }
+        else if (dc.empty() && P.conj && n_out > 0) {
+            launch(c, iq_conjugate_kernel, dim3((unsigned)std::min((n_out + 255) / 256, 4096)), dim3(256), 0, (const float2*)cur->data, (float2*)P.out.data, n_out);
+        }
+        if (!carry.empty()) {
+            int mx = 0;
+            for (auto& k : carry) { mx = std::max(mx, k.need * k.width); }
+            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+        }
+    }
+    if (P.raw.hist_len > 0) { P.raw.cur ^= 1; }
+    for (int s = 0; s + 1 < P.n_stages; s++) {
+        if (P.st[(size_t)s].hist_len > 0) { P.st[(size_t)s].cur ^= 1; }
+    }
+    P.last = result;
+    P.last_n = n_out;
+    *d_iq = result;
+    *count = n_out;
+    return SDRPP_OK;
+}
+
 int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     if (count == 0) {  // an empty block produces nothing (and changes no state)
         c->n_lines = 0;
@@ -1511,6 +1625,23 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
             for (auto& s : kv.second->st) { s.n = 0; }
         }
         return SDRPP_OK;
+    }
+    int rc0;
+    {
+        HostScope hs("arena_begin (backpressure)");
+        rc0 = arena_begin(c);
+    }
+    if (rc0) { return rc0; }
+    if (c->pre.on) {
+        rc0 = run_preproc(c, &d_iq, &count);
+        if (rc0) { return rc0; }
+        if (count == 0) {  // the decimator swallowed the whole block (offset carried): nothing reaches the FFT / VFOs
+            c->n_lines = 0;
+            for (auto& kv : c->vfos) {
+                for (auto& s : kv.second->st) { s.n = 0; }
+            }
+            return arena_end(c);
+        }
     }
     int need_hist = 1;
     if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
@@ -1520,11 +1651,6 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
         if (d.n_stages > 1) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }  // fused front
     }
     int rc = ensure_iq_hist(c, need_hist);
-    if (rc) { return rc; }
-    {
-        HostScope hs("arena_begin (backpressure)");
-        rc = arena_begin(c);
-    }
     if (rc) { return rc; }
     IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
     // fork: the FFT branch goes to its own stream and overlaps the VFO bank; both only read the IQ buffers
@@ -1649,11 +1775,27 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
     return SDRPP_OK;
 }
 
+static void preproc_free(sdrpp_ctx* c) {
+    sdrpp_ctx::Pre& P = c->pre;
+    for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
+        dev_free(P.d_staps[i]);
+        toep_free(P.tp[i]);
+    }
+    P.raw.data = nullptr;  // the caller's buffer, never owned
+    stream_free(P.raw);
+    for (auto& s : P.st) { stream_free(s); }
+    stream_free(P.out);
+    dev_free(P.d_off);
+    dev_free(P.d_seg);
+    P = sdrpp_ctx::Pre{};
+}
+
 int sdrpp_destroy(sdrpp_ctx* c) {
     if (!c) { return SDRPP_OK; }
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
+    preproc_free(c);
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
     c->vfos.clear();
     for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
@@ -1833,6 +1975,83 @@ int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoom
     if (zoomed) { *zoomed = c->d_zoomed; }
     if (index) { *index = c->d_index; }
     if (n_lines) { *n_lines = c->n_lines; }
+    return SDRPP_OK;
+}
+
+int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps, float dc_rate, int conjugate) {
+    if (!c || n_stages < 0 || n_stages > SDRPP_MAX_DECIM_STAGES) { return SDRPP_ERR_INVALID; }
+    for (int s = 0; s < n_stages; s++) {
+        if (!stage_decim || !stage_ntaps || !stage_taps || !is_pow2(stage_decim[s]) || stage_ntaps[s] <= 0 || !stage_taps[s]) {
+            return fail(c, SDRPP_ERR_UNSUPPORTED, "pre-processing stage %d: decimation must be a power of two with taps", s);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    preproc_free(c);
+    if (n_stages == 0 && dc_rate == 0.0f && !conjugate) { return SDRPP_OK; }  // chain fully disabled: pushes go straight through
+    sdrpp_ctx::Pre& P = c->pre;
+    P.n_stages = n_stages;
+    P.dc_rate = dc_rate;
+    P.conj = conjugate ? 1 : 0;
+    int rc;
+    size_t cap = (size_t)c->max_push;
+    if (n_stages > 0) {
+        P.raw.width = 2;
+        P.raw.hist_len = stage_ntaps[0] - 1;
+        for (int i = 0; i < 2; i++) {
+            rc = dev_alloc(c, &P.raw.hist[i], (size_t)std::max(P.raw.hist_len, 1) * 2);
+            if (rc) { return rc; }
+            HIPCHK(c, hipMemset(P.raw.hist[i], 0, (size_t)std::max(P.raw.hist_len, 1) * 2 * sizeof(float)));
+        }
+    }
+    P.st.resize((size_t)n_stages);
+    for (int s = 0; s < n_stages; s++) {
+        P.decim_s[s] = stage_decim[s];
+        P.staps[s].assign(stage_taps[s], stage_taps[s] + stage_ntaps[s]);
+        rc = upload_blocked(c, &P.d_staps[s], P.staps[s].data(), (int)P.staps[s].size(), P.decim_s[s], &P.s_kp[s]);
+        if (rc) { return rc; }
+        P.tp[s].kind = 1;
+        rc = toep_build_fir(c, P.tp[s], P.staps[s].data(), (int)P.staps[s].size(), P.decim_s[s]);
+        if (rc) { return rc; }
+        cap = cap / (size_t)P.decim_s[s] + 2;
+        rc = stream_alloc(c, P.st[(size_t)s], 2, (s + 1 < n_stages) ? stage_ntaps[s + 1] - 1 : 0, cap);
+        if (rc) { return rc; }
+    }
+    if (dc_rate != 0.0f || conjugate) {
+        rc = stream_alloc(c, P.out, 2, 0, cap);
+        if (rc) { return rc; }
+    }
+    if (dc_rate != 0.0f) {
+        rc = dev_alloc(c, &P.d_off, 1);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(P.d_off, 0, sizeof(float2)));
+        P.seg_cap = (int)(cap / SDRPP_DEEMP_SEG) + 2;
+        rc = dev_alloc(c, &P.d_seg, (size_t)P.seg_cap + 1);
+        if (rc) { return rc; }
+    }
+    P.on = true;
+    return SDRPP_OK;
+}
+
+int sdrpp_preproc_out_count(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
+    return c->pre.last_n;
+}
+
+int sdrpp_preproc_read(sdrpp_ctx* c, float* dst, int max) {
+    if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
+    const int n = std::min(max, c->pre.last_n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n > 0) { HIPCHK(c, hipMemcpy(dst, c->pre.last, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
+    return n;
+}
+
+int sdrpp_preproc_device_buffer(sdrpp_ctx* c, const float** iq, int* n) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
+    if (iq) { *iq = c->pre.last; }
+    if (n) { *n = c->pre.last_n; }
     return SDRPP_OK;
 }
 
@@ -2126,7 +2345,7 @@ int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
         if (rc) { return rc; }
         HIPCHK(c, hipMemset(a.d_last, 0, sizeof(float2)));
         a.seg_cap = (int)(cap / SDRPP_DEEMP_SEG) + 2;
-        rc = dev_alloc(c, &a.d_seg, (size_t)a.seg_cap);
+        rc = dev_alloc(c, &a.d_seg, (size_t)a.seg_cap + 1);
         if (rc) { return rc; }
         a.i_deemp = add_stream(0, cap);
         if (a.i_deemp < 0) { return SDRPP_ERR_NOMEM; }

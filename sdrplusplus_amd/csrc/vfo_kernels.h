@@ -1391,10 +1391,11 @@ struct DeempJob {
     const float2* in;
     float2* out;
     int n;
-    float alpha;
-    float2* state;    // lastOut (deephasis.h:72-73), device resident
-    float4* seg;      // [nseg] scratch: per segment (m, a.l, a.r, -): y_end = m * y_in + a
+    float alpha;      // KIND 0: de-emphasis alpha; KIND 1: DC-blocker rate
+    float2* state;    // KIND 0: lastOut (deephasis.h:72-73); KIND 1: offset (dc_blocker.h:57), device resident
+    float4* seg;      // [nseg] scratch: per segment (m, a.l, a.r, -): state_end = m * state_in + a
     int nseg;         // segments of SDRPP_DEEMP_SEG frames
+    int conj;         // KIND 1: negate the imaginary part of the output (dsp/math/conjugate.h) after the DC blocker
 };
 #define SDRPP_DEEMP_C 16
 #define SDRPP_DEEMP_SEG (256 * SDRPP_DEEMP_C)
@@ -1424,10 +1425,14 @@ __device__ __forceinline__ void deemph_block_scan(float* sm_m, float2* sm_a, int
     }
 }
 
-// PASS 0: segment maps from a zero carry (grid: x = segment, y = VFO).  PASS 1: every segment composes the maps of the segments
+// First-order recurrences over a two-channel stream as a two-level scan.
+//   KIND 0  Deemphasis<stereo_t>:   y[i] = alpha * x[i] + (1 - alpha) * y[i-1]                       (state = y)
+//   KIND 1  DCBlocker<complex_t>:   out[i] = x[i] - off;  off += out[i] * rate   [then optional conj]  (state = off)
+// Both states evolve by an affine map per sample (slope 1 - alpha / 1 - rate).
+// PASS 0: segment maps from a zero state (grid: x = segment, y = job).  PASS 1: every segment composes the maps of the segments
 // before it onto the carried state (a few dozen multiply-adds), then each work-item re-runs the reference's exact expression from
-// its true carry-in; the last segment stores the new state.
-template <int PASS>
+// its true carry-in; vfo_deemph_state_kernel stores the new state.
+template <int KIND, int PASS>
 __global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restrict__ jobs) {
     __shared__ float sm_m[256];
     __shared__ float2 sm_a[256];
@@ -1446,8 +1451,14 @@ __global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restr
         const bool ok = i0 + j < job.n;
         x[j] = ok ? job.in[i0 + j] : make_float2(0.0f, 0.0f);
         if (ok) {
-            e.x = (alpha * x[j].x) + (beta * e.x);
-            e.y = (alpha * x[j].y) + (beta * e.y);
+            if constexpr (KIND == 0) {
+                e.x = (alpha * x[j].x) + (beta * e.x);
+                e.y = (alpha * x[j].y) + (beta * e.y);
+            }
+            else {
+                e.x += (x[j].x - e.x) * alpha;
+                e.y += (x[j].y - e.y) * alpha;
+            }
             m *= beta;
         }
     }
@@ -1466,19 +1477,43 @@ __global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restr
 #pragma unroll
         for (int j = 0; j < C; j++) {
             if (i0 + j < job.n) {
-                y.x = (alpha * x[j].x) + (beta * y.x);  // deephasis.h:66-69, same expression
-                y.y = (alpha * x[j].y) + (beta * y.y);
-                job.out[i0 + j] = y;
+                if constexpr (KIND == 0) {
+                    y.x = (alpha * x[j].x) + (beta * y.x);  // deephasis.h:66-69, same expression
+                    y.y = (alpha * x[j].y) + (beta * y.y);
+                    job.out[i0 + j] = y;
+                }
+                else {
+                    const float2 o = make_float2(x[j].x - y.x, x[j].y - y.y);  // dc_blocker.h:56-57
+                    y.x += o.x * alpha;
+                    y.y += o.y * alpha;
+                    job.out[i0 + j] = make_float2(o.x, job.conj ? -o.y : o.y);
+                }
             }
         }
-        // the new lastOut is stored by vfo_deemph_state_kernel once every segment (they run concurrently and all read the old
-        // state) is done
+        if constexpr (KIND == 1) {
+            // the offset after the last sample is not an output: the last segment's last live work-item keeps it for the state kernel
+            if (sg == job.nseg - 1 && i0 < job.n && i0 + C >= job.n) { job.seg[job.nseg] = make_float4(0.0f, y.x, y.y, 0.0f); }
+        }
     }
 }
 // lastOut = out[n-1] (deephasis.h:72-73), after all segments are done
+template <int KIND>
 __global__ void vfo_deemph_state_kernel(const DeempJob* __restrict__ jobs, int njobs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < njobs && jobs[i].n > 0) { *jobs[i].state = jobs[i].out[jobs[i].n - 1]; }
+    if (i < njobs && jobs[i].n > 0) {
+        if constexpr (KIND == 0) { *jobs[i].state = jobs[i].out[jobs[i].n - 1]; }
+        else {
+            const float4 g = jobs[i].seg[jobs[i].nseg];
+            *jobs[i].state = make_float2(g.y, g.z);
+        }
+    }
+}
+// Conjugate alone (dsp/math/conjugate.h:12-15)
+__global__ __launch_bounds__(256) void iq_conjugate_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 x = in[i];
+        out[i] = make_float2(x.x, -x.y);
+    }
 }
 
 // =====================================================================================================================

@@ -248,15 +248,17 @@ public:
         if (ctx) { sdrpp_destroy(ctx); }
     }
 
-    // iq_frontend.h:23 — decimRatio / dcBlocking / buffering belong to the pre-processing chain, which stays on the host
-    // side of the boundary (all disabled by default, iq_frontend.cpp:36-39); only decimRatio == 1 && !dcBlocking is accepted.
+    // iq_frontend.h:23 — decimRatio / dcBlocking configure the pre-processing chain (PowerDecimator -> DCBlocker -> Conjugate,
+    // iq_frontend.cpp:32-39), which runs on the device in front of the FFT branch and the VFO bank; `buffering` (the
+    // SampleFrameBuffer in front of it) is a host-side hand-off and has no device counterpart.
     void init(dsp::stream<dsp::complex_t>* in, double sampleRate, bool buffering, int decimRatio, bool dcBlocking, int fftSize, double fftRate,
               FFTWindow fftWindow, float* (*acquireFFTBuffer)(void* ctx), void (*releaseFFTBuffer)(void* ctx), void* fftCtx, int device = 0,
               const DecimPlans* plans = nullptr) {
         (void)buffering;
-        if (decimRatio != 1 || dcBlocking) { throw std::runtime_error("[sdrpp_gpu::IQFrontEnd] front-end decimation / DC blocking stay on the host chain"); }
         _in = in;
         _sampleRate = sampleRate;
+        _decimRatio = decimRatio;
+        _dcBlocking = dcBlocking;
         _fftSize = fftSize;
         _fftRate = fftRate;
         _fftWindow = fftWindow;
@@ -267,23 +269,41 @@ public:
         int rc = sdrpp_create(device, SDRPP_GPU_MAX_BLOCK, &ctx);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] ") + sdrpp_strerror(rc)); }
         registerInput(_in);
+        updatePreproc();
         updateFFTPath();
         _init = true;
     }
+
+    // iq_frontend.cpp:105-130: the effective sample rate changes with the decimation; every VFO and the FFT framing follow it
+    void setDecimation(int ratio) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        tempStop();
+        _decimRatio = ratio;
+        updatePreproc();
+        for (auto& kv : vfos) {
+            kv.second->inSamplerate = getEffectiveSamplerate();
+            rebuild(*kv.second);
+        }
+        updateFFTPath();
+        tempStart();
+    }
+    void setDCBlocking(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _dcBlocking = enabled; updatePreproc(); tempStart(); }
+    void setInvertIQ(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _invertIQ = enabled; updatePreproc(); tempStart(); }
 
     void setSampleRate(double sampleRate) {
         std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
         tempStop();
         _sampleRate = sampleRate;
+        updatePreproc();  // the DC blocker's rate follows the effective sample rate (iq_frontend.cpp:85-86)
         for (auto& kv : vfos) {
-            kv.second->inSamplerate = sampleRate;
+            kv.second->inSamplerate = getEffectiveSamplerate();
             rebuild(*kv.second);
         }
         updateFFTPath();
         tempStart();
     }
     double getSampleRate() { return _sampleRate; }
-    double getEffectiveSamplerate() { return _sampleRate; }
+    double getEffectiveSamplerate() { return _sampleRate / (double)_decimRatio; }
     void setFFTSize(int size) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftSize = size; updateFFTPath(); tempStart(); }
     void setFFTRate(double rate) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftRate = rate; updateFFTPath(); tempStart(); }
     void setFFTWindow(FFTWindow w) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftWindow = w; updateFFTPath(); tempStart(); }
@@ -299,7 +319,7 @@ public:
         RxVFO* v = new RxVFO;
         v->fe = this;
         v->name = name;
-        v->inSamplerate = _sampleRate;
+        v->inSamplerate = getEffectiveSamplerate();
         v->outSamplerate = sampleRate;
         v->bandwidth = bandwidth;
         v->offset = offset;
@@ -363,9 +383,28 @@ public:
 private:
     friend class RxVFO;
 
+    void updatePreproc() {  // iq_frontend.cpp:32-39: decim enabled for ratio > 1, dcBlock rate genDCBlockRate(effectiveSr), conjugate
+        int dec[SDRPP_MAX_DECIM_STAGES] = { 0 }, nt[SDRPP_MAX_DECIM_STAGES] = { 0 };
+        const float* tp[SDRPP_MAX_DECIM_STAGES] = { nullptr };
+        int n = 0;
+        if (_decimRatio > 1) {
+            auto it = _plans.plans.find(_decimRatio);
+            if (it == _plans.plans.end()) { throw std::runtime_error("[sdrpp_gpu::IQFrontEnd] no decimation plan for ratio " + std::to_string(_decimRatio)); }
+            for (auto& st : it->second) {
+                dec[n] = st.decimation;
+                nt[n] = (int)st.taps.size();
+                tp[n] = st.taps.data();
+                n++;
+            }
+        }
+        const float rate = _dcBlocking ? (float)(50.0 / getEffectiveSamplerate()) : 0.0f;  // iq_frontend.h:55-57
+        int rc = sdrpp_preproc_configure(ctx, n, dec, nt, tp, rate, _invertIQ ? 1 : 0);
+        if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] ") + sdrpp_last_error(ctx)); }
+    }
+
     void updateFFTPath() {  // iq_frontend.cpp:269-309
         int skip = 0, nz = 0;
-        sdrpp_design_reshape_params(_sampleRate, _fftSize, _fftRate, &skip, &nz);
+        sdrpp_design_reshape_params(getEffectiveSamplerate(), _fftSize, _fftRate, &skip, &nz);
         std::vector<float> w((size_t)nz);
         sdrpp_design_fft_window((int)_fftWindow, nz, w.data());
         int rc = sdrpp_fft_configure(ctx, _fftSize, nz, skip, w.data());
@@ -490,6 +529,8 @@ private:
     std::map<std::string, RxVFO*> vfos;
     double _sampleRate = 0, _fftRate = 20.0;
     int _fftSize = 65536;
+    int _decimRatio = 1;
+    bool _dcBlocking = false, _invertIQ = false;
     FFTWindow _fftWindow = NUTTALL;
     float* (*_acquire)(void*) = nullptr;
     void (*_release)(void*) = nullptr;

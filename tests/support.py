@@ -81,6 +81,10 @@ def oracle():
         L.orc_deemp_create.argtypes = [C.c_double, C.c_double]
         L.orc_deemp_destroy.argtypes = [C.c_void_p]
         L.orc_deemp_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.orc_preproc_create.restype = C.c_void_p
+        L.orc_preproc_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.orc_preproc_destroy.argtypes = [C.c_void_p]
+        L.orc_preproc_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.orc_int16_to_float.argtypes = [C.POINTER(C.c_int16), c_float_p, C.c_int]
         L.orc_fir_create.restype = C.c_void_p
         L.orc_fir_create.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int]
@@ -130,6 +134,10 @@ def ref(fast=False):
         L.ref_deemp_create.argtypes = [C.c_double, C.c_double]
         L.ref_deemp_destroy.argtypes = [C.c_void_p]
         L.ref_deemp_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
+        L.ref_preproc_create.restype = C.c_void_p
+        L.ref_preproc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+        L.ref_preproc_destroy.argtypes = [C.c_void_p]
+        L.ref_preproc_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.ref_frontend_create.restype = C.c_void_p
         L.ref_frontend_create.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int]
         L.ref_frontend_feed.argtypes = [C.c_void_p, c_float_p, C.c_longlong, C.c_int, C.c_int, C.c_int]
@@ -282,3 +290,23 @@ def oracle_rxvfo_info(chain):
 
 
 MODES = {"WFM": 0, "NFM": 1, "AM": 2, "USB": 3, "LSB": 4, "DSB": 5}
+
+
+class OraclePreproc:
+    """IQFrontEnd pre-processing chain on the oracle (orc_preproc_*): PowerDecimator -> DCBlocker -> Conjugate."""
+
+    def __init__(self, ratio, dc_blocking, dc_rate, conjugate):
+        self.o = oracle()
+        self.h = self.o.orc_preproc_create(plans_handle(), int(ratio), int(bool(dc_blocking)), float(dc_rate), int(bool(conjugate)))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.empty(len(x) + 8, np.complex64)
+        n = self.o.orc_preproc_process(self.h, len(x), _fp(x.view(np.float32)), _fp(out.view(np.float32))) if len(x) else 0
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            self.o.orc_preproc_destroy(self.h)
+        except Exception:
+            pass

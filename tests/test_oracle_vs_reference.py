@@ -126,3 +126,25 @@ def test_af_resampler_and_deemphasis_bit_exact():
     assert np.array_equal(oa, ra)
     o.orc_deemp_destroy(od)
     r.ref_deemp_destroy(rd)
+
+
+@pytest.mark.parametrize("ratio,dc,conj", [(1, True, False), (2, True, True), (8, False, True), (64, True, False)])
+def test_preproc_chain_bit_exact(ratio, dc, conj):
+    """'next' row 2: IQFrontEnd's pre-processing chain (iq_frontend.cpp:32-39) = PowerDecimator<complex_t> -> DCBlocker<complex_t>
+    -> Conjugate, restated in oracle.c, against the reference classes block by block (uneven blocks exercise the stage offsets)."""
+    o, r = S.oracle(), S.ref()
+    x = (_noise(60000, 9) + np.complex64(0.25 - 0.125j)).astype(np.complex64)
+    rate = 50.0 / (2.4e6 / ratio)  # genDCBlockRate(effectiveSr), iq_frontend.h:55-57
+    oh = o.orc_preproc_create(S.plans_handle(), ratio, int(dc), rate, int(conj))
+    rh = r.ref_preproc_create(ratio, int(dc), rate, int(conj))
+    pos = 0
+    for n in (12000, 7, 20001, 27992):
+        blk = np.ascontiguousarray(x[pos:pos + n])
+        pos += n
+        oo = np.empty(n + 8, np.complex64)
+        ro = np.empty(n + 8, np.complex64)
+        no = o.orc_preproc_process(oh, n, S._fp(blk.view(np.float32)), S._fp(oo.view(np.float32)))
+        nr = r.ref_preproc_process(rh, n, S._fp(blk.view(np.float32)), S._fp(ro.view(np.float32)))
+        assert no == nr and np.array_equal(oo[:no].view(np.uint32), ro[:nr].view(np.uint32))
+    o.orc_preproc_destroy(oh)
+    r.ref_preproc_destroy(rh)

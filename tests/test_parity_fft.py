@@ -6,6 +6,11 @@ import pytest
 import support as S
 
 
+def rms(a):
+    a = np.asarray(a)
+    return float(np.sqrt(np.mean(np.abs(a) ** 2))) if a.size else 0.0
+
+
 def _ctx(max_push):
     from sdrplusplus_amd import capi
 
@@ -147,4 +152,69 @@ def test_int16_ingest_matches_file_source_conversion(backend):
     raw, _, _ = ctx.fft_read(zoomed=False)
     ol = S.OracleSpectrum(4096, nz, skip, w).push(xc)
     assert len(ol) == 2 and np.array_equal(raw, ol)
+    ctx.close()
+
+
+@pytest.mark.parametrize("ratio,dc,conj", [(2, True, False), (8, True, True), (1, True, True), (4, False, False), (1, False, True)])
+def test_preproc_chain(backend, ratio, dc, conj):
+    """IQFrontEnd's pre-processing chain (decimation / DC blocking / invert IQ, iq_frontend.cpp:32-39) on the
+    device in front of everything else.  Checked: the pre-processed stream itself (what bindIQStream consumers get) against the
+    oracle chain (bit-exactly pinned to the reference in test_oracle_vs_reference.py), the waterfall lines computed from it, and a
+    WFM VFO designed at the effective sample rate — over uneven pushes."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr = 2.4e6 * ratio  # effective rate 2.4 MS/s after the chain (cfg 1 geometry behind it)
+    eff = sr / ratio
+    pushes = [24000 * ratio, 1001, 7 * ratio, 36000 * ratio + 3, 12000 * ratio]
+    rng = np.random.default_rng(ratio * 10 + dc * 2 + conj)
+    n = np.arange(sum(pushes))
+    sign = -1.0 if conj else 1.0  # the conjugate mirrors the spectrum: put the FM carrier where it lands at +300 kHz afterwards
+    x = (0.2 * np.exp(1j * (2 * np.pi * sign * 300e3 * n / sr + sign * 3.0 * np.sin(2 * np.pi * 1000.0 * n / sr))) + (0.05 + 0.03j)
+         + 0.01 * (rng.standard_normal(len(n)) + 1j * rng.standard_normal(len(n)))).astype(np.complex64)
+    ctx = capi.Context(0, max_push=max(pushes))
+    stages = radio.plans().stages(ratio) if ratio > 1 else []
+    rate = 50.0 / eff if dc else 0.0
+    ctx.preproc_configure(stages, rate, conj)
+    N = 4096
+    w = capi.design_fft_window(2, N)
+    ctx.fft_configure(N, N, 0, w)
+    d, keep = radio.vfo_desc(eff, 250e3, 150e3, 300e3, "WFM")
+    vid = ctx.vfo_add(d, keep)
+    opre = S.OraclePreproc(ratio, dc, rate, conj)
+    spec = S.OracleSpectrum(N, N, 0, w)
+    chain = S.OracleChain(eff, 250e3, 150e3, 300e3, S.MODES["WFM"])
+    pos, worst_pre, worst_audio, worst_db, nlines = 0, 0.0, 0.0, 0.0, 0
+    for npush in pushes:
+        blk = x[pos:pos + npush]
+        pos += npush
+        ctx.push(blk)
+        ref = opre.process(blk)
+        got = ctx.preproc_read()
+        assert got.shape == ref.shape
+        if len(ref):
+            worst_pre = max(worst_pre, rms(got - ref) / max(rms(ref), 1e-9))
+        # downstream: oracle fed with the ORACLE's pre-processed stream (the reference graph), device fed by its own
+        raw, _, _ = ctx.fft_read(zoomed=False)
+        ol = spec.push(ref)
+        assert raw.shape == ol.shape
+        if ol.size:
+            strong = ol > -100.0  # bins above the noise floor of the test signal: dB of a ~1e-6-relative different input
+            worst_db = max(worst_db, float(np.max(np.abs(raw - ol)[strong])))
+            nlines += len(ol)
+        _, oa = chain.process(ref)
+        ga = ctx.vfo_read(vid)
+        assert ga.shape == oa.shape
+        if len(oa):
+            worst_audio = max(worst_audio, rms(ga - oa))
+    assert nlines > 0
+    # conjugate alone is exact; the decimator differs by summation order (~1e-7).  The DC blocker is a very slow float32 integrator
+    # (rate 2e-5): the reference's sequential running sum carries its own rounding drift (~1e-5 of the DC level, quasi-systematic),
+    # which a parallel evaluation — chunk-local partial sums, i.e. a MORE accurate sum — cannot and does not reproduce (DESIGN.md 5)
+    assert worst_pre < (1e-9 if (ratio == 1 and not dc) else (2e-4 if dc else 2e-6)), worst_pre
+    assert worst_audio < 1e-5, worst_audio
+    assert worst_db < (0.05 if dc else 5e-3), worst_db  # -100 dB bins next to a -14 dB carrier feel a 1e-7-relative input change as ~1e-3 dB
+    ctx.preproc_configure([], 0.0, False)  # chain removed: the raw stream goes straight through again
+    ctx.push(x[:N])
+    with pytest.raises(Exception):
+        ctx.preproc_read()
     ctx.close()
