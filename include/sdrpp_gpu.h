@@ -180,6 +180,19 @@ int sdrpp_vfo_af_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
 int sdrpp_vfo_af_device_buffer(sdrpp_ctx* ctx, int id, const float** out, int* n_out);
 int sdrpp_abi_sizeof_af_desc(void);
 
+/* ---- WaterFall display state around the raw-line history (core/src/gui/widgets/waterfall.cpp) ---------------
+ * The last `height` raw dB lines stay resident in HBM in the reference's ring order (getFFTBuffer :875-886), so a zoom / pan /
+ * level change re-renders the whole waterfall on the device (updateWaterfallFb :600-631) instead of re-reading host memory, and
+ * the FFT trace's smoothing and peak hold (pushFFT :913-939) run per new line next to the zoom that already does.
+ * Needs sdrpp_fft_configure first (and sdrpp_fft_set_view for the trace); re-configuring the FFT size invalidates it. */
+int sdrpp_wf_configure(sdrpp_ctx* ctx, int height);                              /* waterfallHeight lines kept; 0 removes          */
+int sdrpp_wf_set_smoothing(sdrpp_ctx* ctx, int enabled, float speed);            /* setFFTSmoothing + setFFTSmoothingSpeed :1166-1194 */
+int sdrpp_wf_set_hold(sdrpp_ctx* ctx, int enabled, float speed);                 /* setFFTHold + setFFTHoldSpeed :1153-1164          */
+/* latestFFT (after smoothing) and latestFFTHold of the current view: data_width floats each (NULL to skip); returns data_width */
+int sdrpp_wf_latest(sdrpp_ctx* ctx, float* latest, float* hold);
+/* updateWaterfallFb: palette indices [height][data_width], newest line first, rows beyond the stored lines = -1 (opaque black). */
+int sdrpp_wf_raster(sdrpp_ctx* ctx, int draw_data_start, int draw_data_size, int data_width, float wf_min, float wf_max, int32_t* dst_host, int* n_lines);
+
 /* ---- IQFrontEnd pre-processing chain (core/src/signal_path/iq_frontend.cpp:32-39, setDecimation /
  *      setDCBlocking / setInvertIQ :105-130): PowerDecimator<complex_t> (stages of the plan for the ratio, power_decimator.h:93-111)
  *      -> DCBlocker<complex_t> (dc_rate = genDCBlockRate(effectiveSr) = 50 / effectiveSr, iq_frontend.h:55-57; 0 = block disabled)

@@ -1059,6 +1059,99 @@ void orc_deemp_process(orc_deemp* d, int count, const float* in, float* out) {
     d->lastR = out[2 * (count - 1) + 1];
 }
 
+/* WaterFall display state around the raw-line ring (gui/widgets/waterfall.cpp, waterfallVisible == true):
+ *   getFFTBuffer  :875-886   currentFFTLine--, wrap, fftLines = min(fftLines + 1, waterfallHeight); the handler writes the raw line there
+ *   pushFFT       :888-941   doZoom of that line -> latestFFT; palette index row; FFT smoothing (:913-920, three separately rounded
+ *                            VOLK passes); FFT hold (:935-939, starts at index 1)
+ *   updateWaterfallFb :600-631  re-zoom of every stored line, newest first, rows beyond fftLines opaque black (returned as -1)
+ *   setFFTSmoothing :1166-1188 (buffer starts as a copy of latestFFT), setFFTSmoothingSpeed :1190-1194, setFFTHold :1153-1160 (-1000) */
+typedef struct {
+    int height, N, dataWidth;
+    float* raw;       /* [height][N] */
+    int currentFFTLine, fftLines;
+    float* latest;    /* [dataWidth] */
+    float* smoothing; /* NULL = off */
+    float* hold;
+    int holdOn;
+    float alpha, beta, holdSpeed;
+} orc_wf;
+orc_wf* orc_wf_create(int height, int N, int dataWidth) {
+    orc_wf* w = (orc_wf*)calloc(1, sizeof(orc_wf));
+    w->height = height;
+    w->N = N;
+    w->dataWidth = dataWidth;
+    w->raw = (float*)calloc((size_t)height * N, sizeof(float));
+    w->latest = (float*)calloc((size_t)dataWidth, sizeof(float));
+    w->hold = (float*)calloc((size_t)dataWidth, sizeof(float));
+    return w;
+}
+void orc_wf_destroy(orc_wf* w) {
+    if (!w) { return; }
+    free(w->raw);
+    free(w->latest);
+    free(w->smoothing);
+    free(w->hold);
+    free(w);
+}
+void orc_wf_set_smoothing(orc_wf* w, int enabled, float speed) {
+    free(w->smoothing);
+    w->smoothing = NULL;
+    if (enabled) {
+        w->smoothing = (float*)malloc(sizeof(float) * (size_t)w->dataWidth);
+        memcpy(w->smoothing, w->latest, sizeof(float) * (size_t)w->dataWidth);
+    }
+    w->alpha = speed;
+    w->beta = 1.0f - speed;
+}
+void orc_wf_set_hold(orc_wf* w, int enabled, float speed) {
+    w->holdOn = enabled;
+    if (enabled) {
+        for (int i = 0; i < w->dataWidth; i++) { w->hold[i] = -1000.0; }
+    }
+    w->holdSpeed = speed;
+}
+/* one finished raw line: index row of the new top line goes to idx[dataWidth] */
+void orc_wf_push(orc_wf* w, const float* line, int drawDataStart, int drawDataSize, float wmin, float wmax, int32_t* idx) {
+    w->currentFFTLine--;
+    w->fftLines++;
+    w->currentFFTLine = ((w->currentFFTLine + w->height) % w->height);
+    if (w->fftLines > w->height) { w->fftLines = w->height; }
+    float* slot = &w->raw[(size_t)w->currentFFTLine * w->N];
+    memcpy(slot, line, sizeof(float) * (size_t)w->N);
+    orc_do_zoom(drawDataStart, drawDataSize, w->N, w->dataWidth, slot, w->latest);
+    orc_palette_index(w->latest, w->dataWidth, wmin, wmax, idx);
+    if (w->smoothing) {
+        for (int i = 0; i < w->dataWidth; i++) { w->latest[i] = w->latest[i] * w->alpha; }
+        for (int i = 0; i < w->dataWidth; i++) { w->smoothing[i] = w->smoothing[i] * w->beta; }
+        for (int i = 0; i < w->dataWidth; i++) { w->smoothing[i] = w->smoothing[i] + w->latest[i]; }
+        memcpy(w->latest, w->smoothing, sizeof(float) * (size_t)w->dataWidth);
+    }
+    if (w->holdOn) {
+        for (int i = 1; i < w->dataWidth; i++) {
+            const float a = w->latest[i], b = w->hold[i] - w->holdSpeed;
+            w->hold[i] = (a < b) ? b : a; /* std::max<float>(a, b) */
+        }
+    }
+}
+void orc_wf_latest(const orc_wf* w, float* latest, float* hold) {
+    if (latest) { memcpy(latest, w->latest, sizeof(float) * (size_t)w->dataWidth); }
+    if (hold) { memcpy(hold, w->hold, sizeof(float) * (size_t)w->dataWidth); }
+}
+/* fb[height][dataWidth]: palette indices, -1 where the reference writes opaque black; returns the number of stored lines */
+int orc_wf_raster(const orc_wf* w, int drawDataStart, int drawDataSize, float wmin, float wmax, int32_t* fb) {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)w->dataWidth);
+    const int count = (w->fftLines < w->height) ? w->fftLines : w->height;
+    for (int i = 0; i < count; i++) {
+        orc_do_zoom(drawDataStart, drawDataSize, w->N, w->dataWidth, &w->raw[(size_t)((i + w->currentFFTLine) % w->height) * w->N], tmp);
+        orc_palette_index(tmp, w->dataWidth, wmin, wmax, &fb[(size_t)i * w->dataWidth]);
+    }
+    for (int i = count; i < w->height; i++) {
+        for (int j = 0; j < w->dataWidth; j++) { fb[(size_t)i * w->dataWidth + j] = -1; }
+    }
+    free(tmp);
+    return count;
+}
+
 /* IQFrontEnd pre-processing chain (core/src/signal_path/iq_frontend.cpp:32-39): PowerDecimator<complex_t> (enabled when the ratio
  * is > 1) -> DCBlocker<complex_t> (dsp/correction/dc_blocker.h:54-60, rate genDCBlockRate(effectiveSr) = 50 / effectiveSr,
  * iq_frontend.h:55-57) -> Conjugate (dsp/math/conjugate.h:12-15, volk_32fc_conjugate_32fc).  SURVEY.md 8f row 2. */

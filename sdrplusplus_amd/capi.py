@@ -118,6 +118,11 @@ def load():
         raise ImportError("sdrpp_af_desc layout mismatch: library %d bytes, binding %d" % (L.sdrpp_abi_sizeof_af_desc(), C.sizeof(AfDesc)))
     L.sdrpp_design_deemphasis_alpha.restype = C.c_float
     L.sdrpp_design_deemphasis_alpha.argtypes = [C.c_double, C.c_double]
+    L.sdrpp_wf_configure.argtypes = [vp, C.c_int]
+    L.sdrpp_wf_set_smoothing.argtypes = [vp, C.c_int, C.c_float]
+    L.sdrpp_wf_set_hold.argtypes = [vp, C.c_int, C.c_float]
+    L.sdrpp_wf_latest.argtypes = [vp, c_float_p, c_float_p]
+    L.sdrpp_wf_raster.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_int32_p, c_int_p]
     L.sdrpp_preproc_configure.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_float, C.c_int]
     L.sdrpp_preproc_out_count.argtypes = [vp]
     L.sdrpp_preproc_read.argtypes = [vp, c_float_p, C.c_int]
@@ -168,6 +173,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
+    "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster",
     "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
@@ -345,6 +351,27 @@ class Context:
         out = np.empty((max(n, 1), 2), dtype=np.float32)
         got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
         return out[:got]
+
+    def wf_configure(self, height):
+        self._chk(self.L.sdrpp_wf_configure(self.h, int(height)))
+
+    def wf_set_smoothing(self, enabled, speed=0.1):
+        self._chk(self.L.sdrpp_wf_set_smoothing(self.h, int(bool(enabled)), float(speed)))
+
+    def wf_set_hold(self, enabled, speed=60.0):
+        self._chk(self.L.sdrpp_wf_set_hold(self.h, int(bool(enabled)), float(speed)))
+
+    def wf_latest(self, data_width):
+        a = np.empty(data_width, np.float32)
+        b = np.empty(data_width, np.float32)
+        self._chk(self.L.sdrpp_wf_latest(self.h, a.ctypes.data_as(c_float_p), b.ctypes.data_as(c_float_p)))
+        return a, b
+
+    def wf_raster(self, height, draw_start, draw_size, data_width, wf_min, wf_max):
+        fb = np.empty((height, data_width), np.int32)
+        n = C.c_int()
+        self._chk(self.L.sdrpp_wf_raster(self.h, int(draw_start), int(draw_size), int(data_width), float(wf_min), float(wf_max), fb.ctypes.data_as(c_int32_p), C.byref(n)))
+        return fb, n.value
 
     def preproc_configure(self, stages=(), dc_rate=0.0, conjugate=False):
         """IQFrontEnd pre-processing chain: `stages` = [(decimation, taps)] of the PowerDecimator plan, dc_rate (0 = off), conjugate."""

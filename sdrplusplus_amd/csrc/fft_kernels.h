@@ -414,6 +414,45 @@ __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restri
     }
 }
 
+// ---- WaterFall display state (waterfall.cpp:875-941): raw-line ring, FFT trace smoothing / hold -----------------------------------------
+// getFFTBuffer (:875-886): every new line moves currentFFTLine one slot DOWN (mod height) and is written there.  Line f of this
+// push (0 = oldest) therefore lands in slot (cur0 - 1 - f) mod H; when a push brings more than H lines only the last H survive.
+__global__ __launch_bounds__(256) void wf_ring_store_kernel(const float* __restrict__ lines, int nframes, int fft_size, float* __restrict__ ring, int height, int cur0) {
+    const int f = blockIdx.y;
+    if (f < nframes - height) { return; }
+    int slot = (cur0 - 1 - f) % height;
+    if (slot < 0) { slot += height; }
+    const float4* src = reinterpret_cast<const float4*>(lines + (size_t)f * fft_size);
+    float4* dst = reinterpret_cast<float4*>(ring + (size_t)slot * fft_size);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fft_size / 4; i += gridDim.x * blockDim.x) { dst[i] = src[i]; }
+}
+// pushFFT tail (:913-939), one work-item per pixel walking over the new lines in order: smoothing = three separately rounded passes
+// (latest *= alpha; buf *= beta; buf += latest; latest = buf), hold[i] = max(latest[i], hold[i] - speed) for i >= 1.
+__global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__ zoomed, int nframes, int data_width, float* __restrict__ latest,
+                                                      float* __restrict__ smooth, float alpha, float beta, float* __restrict__ hold, float hold_speed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= data_width) { return; }
+    float s = smooth ? smooth[j] : 0.0f;
+    float h = hold ? hold[j] : 0.0f;
+    float l = 0.0f;
+    for (int f = 0; f < nframes; f++) {
+        l = zoomed[(size_t)f * data_width + j];
+        if (smooth) {
+            l = l * alpha;
+            s = s * beta;
+            s = s + l;
+            l = s;
+        }
+        if (hold && j >= 1) {
+            const float b = h - hold_speed;
+            h = (l < b) ? b : l;
+        }
+    }
+    latest[j] = l;
+    if (smooth) { smooth[j] = s; }
+    if (hold) { hold[j] = h; }
+}
+
 // int16 IQ -> float (file_source/main.cpp:162: volk_16i_s32f_convert_32f(out, in, 32768.0f, n))
 __global__ __launch_bounds__(256) void int16_to_float_kernel(const int16_t* __restrict__ in, float* __restrict__ out, long long n) {
     const float inv = 1.0f / 32768.0f;

@@ -152,6 +152,19 @@ struct sdrpp_ctx {
         int last_n = 0;
     } pre;
 
+    // WaterFall display state (sdrpp_wf_*): raw-line ring in HBM, FFT trace smoothing / hold
+    struct Wf {
+        int height = 0;
+        float* d_ring = nullptr;  // [height][fft_size]
+        int cur = 0, lines = 0;   // currentFFTLine, fftLines (waterfall.cpp:879-882)
+        int width = 0;            // data_width the trace arrays were sized for
+        float* d_latest = nullptr;
+        float* d_smooth = nullptr;  // nullptr = smoothing off
+        float* d_hold = nullptr;
+        bool hold_on = false, have_latest = false;
+        float alpha = 0.0f, beta = 1.0f, hold_speed = 0.0f;
+    } wf;
+
     // job arena
     char* arena_host[kArenaSlots] = {};
     char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
@@ -689,6 +702,33 @@ int ensure_zoom(sdrpp_ctx* c, size_t lines) {
     return SDRPP_OK;
 }
 
+// latestFFT / smoothing / hold arrays follow the view's data width (WaterFall::onResize reallocates them)
+int wf_ensure_trace(sdrpp_ctx* c) {
+    sdrpp_ctx::Wf& W = c->wf;
+    if (W.width == c->data_width && W.d_latest) { return SDRPP_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool had_smooth = W.d_smooth != nullptr;
+    dev_free(W.d_latest);
+    dev_free(W.d_smooth);
+    dev_free(W.d_hold);
+    W.width = c->data_width;
+    W.have_latest = false;
+    if (W.width <= 0) { return SDRPP_OK; }
+    int rc = dev_alloc(c, &W.d_latest, (size_t)W.width);
+    if (rc) { return rc; }
+    HIPCHK(c, hipMemset(W.d_latest, 0, (size_t)W.width * sizeof(float)));
+    rc = dev_alloc(c, &W.d_hold, (size_t)W.width);
+    if (rc) { return rc; }
+    std::vector<float> init((size_t)W.width, -1000.0f);  // setFFTHold, waterfall.cpp:1153-1160
+    HIPCHK(c, hipMemcpy(W.d_hold, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (had_smooth) {
+        rc = dev_alloc(c, &W.d_smooth, (size_t)W.width);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemset(W.d_smooth, 0, (size_t)W.width * sizeof(float)));
+    }
+    return SDRPP_OK;
+}
+
 int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
     c->n_lines = 0;
     if (!c->fft_on) { return SDRPP_OK; }
@@ -714,6 +754,21 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             FamilyTimer t(c, F_ZOOM);
             launch(c, zoom_palette_kernel, dim3((c->data_width + SDRPP_ZPX - 1) / SDRPP_ZPX, (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, c->fft_size, c->data_width,
                    (const int32_t*)c->d_zstart, (const int32_t*)c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index);
+            if (c->wf.height > 0) {  // FFT trace: latestFFT after smoothing / hold (pushFFT, waterfall.cpp:913-939)
+                int rc2 = wf_ensure_trace(c);
+                if (rc2) { return rc2; }
+                launch(c, wf_trace_kernel, dim3((unsigned)(c->data_width + 255) / 256), dim3(256), 0, (const float*)c->d_zoomed, (int)nframes, c->data_width, c->wf.d_latest, c->wf.d_smooth,
+                       c->wf.alpha, c->wf.beta, c->wf.hold_on ? c->wf.d_hold : (float*)nullptr, c->wf.hold_speed);
+                c->wf.have_latest = true;
+            }
+        }
+        if (c->wf.height > 0) {  // raw lines into the ring (getFFTBuffer, waterfall.cpp:875-886)
+            FamilyTimer t(c, F_ZOOM);
+            launch(c, wf_ring_store_kernel, dim3((unsigned)std::max(1, std::min(c->fft_size / 1024, 64)), (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, (int)nframes, c->fft_size,
+                   c->wf.d_ring, c->wf.height, c->wf.cur);
+            const long long nc = (long long)c->wf.cur - nframes;
+            c->wf.cur = (int)(((nc % c->wf.height) + c->wf.height) % c->wf.height);
+            c->wf.lines = (int)std::min<int64_t>((int64_t)c->wf.lines + nframes, c->wf.height);
         }
         c->fft_next += nframes;
     }
@@ -1775,6 +1830,115 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
     return SDRPP_OK;
 }
 
+// ---- WaterFall display state ----------------------------------------------------------------------------------
+static void wf_free(sdrpp_ctx* c) {
+    dev_free(c->wf.d_ring);
+    dev_free(c->wf.d_latest);
+    dev_free(c->wf.d_smooth);
+    dev_free(c->wf.d_hold);
+    c->wf = sdrpp_ctx::Wf{};
+}
+
+int sdrpp_wf_configure(sdrpp_ctx* c, int height) {
+    if (!c || height < 0) { return SDRPP_ERR_INVALID; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    wf_free(c);
+    if (height == 0) { return SDRPP_OK; }
+    if (!c->fft_on) { return fail(c, SDRPP_ERR_INVALID, "configure the FFT first (sdrpp_fft_configure)"); }
+    int rc = dev_alloc(c, &c->wf.d_ring, (size_t)height * c->fft_size);
+    if (rc) { return rc; }
+    HIPCHK(c, hipMemset(c->wf.d_ring, 0, (size_t)height * c->fft_size * sizeof(float)));
+    c->wf.height = height;
+    return SDRPP_OK;
+}
+
+int sdrpp_wf_set_smoothing(sdrpp_ctx* c, int enabled, float speed) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    int rc = wf_ensure_trace(c);
+    if (rc) { return rc; }
+    sdrpp_ctx::Wf& W = c->wf;
+    dev_free(W.d_smooth);  // setFFTSmoothing (waterfall.cpp:1166-1188): the buffer is re-created as a copy of latestFFT
+    if (enabled && W.width > 0) {
+        rc = dev_alloc(c, &W.d_smooth, (size_t)W.width);
+        if (rc) { return rc; }
+        HIPCHK(c, hipMemcpy(W.d_smooth, W.d_latest, (size_t)W.width * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    W.alpha = speed;  // setFFTSmoothingSpeed (:1190-1194)
+    W.beta = 1.0f - speed;
+    return SDRPP_OK;
+}
+
+int sdrpp_wf_set_hold(sdrpp_ctx* c, int enabled, float speed) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    int rc = wf_ensure_trace(c);
+    if (rc) { return rc; }
+    sdrpp_ctx::Wf& W = c->wf;
+    W.hold_on = enabled != 0;
+    if (W.hold_on && W.width > 0) {  // setFFTHold (:1153-1160)
+        std::vector<float> init((size_t)W.width, -1000.0f);
+        HIPCHK(c, hipMemcpy(W.d_hold, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    W.hold_speed = speed;
+    return SDRPP_OK;
+}
+
+int sdrpp_wf_latest(sdrpp_ctx* c, float* latest, float* hold) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    sdrpp_ctx::Wf& W = c->wf;
+    if (W.height <= 0 || W.width <= 0 || !W.d_latest) { return fail(c, SDRPP_ERR_INVALID, "no waterfall trace yet"); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (latest) { HIPCHK(c, hipMemcpy(latest, W.d_latest, (size_t)W.width * sizeof(float), hipMemcpyDeviceToHost)); }
+    if (hold) { HIPCHK(c, hipMemcpy(hold, W.d_hold, (size_t)W.width * sizeof(float), hipMemcpyDeviceToHost)); }
+    return W.width;
+}
+
+// updateWaterfallFb (waterfall.cpp:600-631): every stored line re-zoomed with a NEW view, newest first
+int sdrpp_wf_raster(sdrpp_ctx* c, int draw_start, int draw_size, int data_width, float wf_min, float wf_max, int32_t* dst_host, int* n_lines) {
+    if (!c || !dst_host || data_width <= 0) { return SDRPP_ERR_INVALID; }
+    sdrpp_ctx::Wf& W = c->wf;
+    if (W.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    const int count = std::min(W.lines, W.height);
+    std::vector<int32_t> zs, zc;
+    sdrpp_host::zoomTable(draw_start, draw_size, c->fft_size, data_width, zs, zc);
+    int32_t *d_zs = nullptr, *d_zc = nullptr, *d_idx = nullptr;
+    float* d_zm = nullptr;
+    int rc = upload(c, &d_zs, zs.data(), zs.size());
+    if (!rc) { rc = upload(c, &d_zc, zc.data(), zc.size()); }
+    if (!rc) { rc = dev_alloc(c, &d_zm, (size_t)std::max(count, 1) * data_width); }
+    if (!rc) { rc = dev_alloc(c, &d_idx, (size_t)std::max(count, 1) * data_width); }
+    if (!rc && count > 0) {
+        // display row i = ring slot (i + cur) mod H: two contiguous runs of slots
+        const int first = std::min(count, W.height - W.cur);
+        const dim3 gx((unsigned)(data_width + SDRPP_ZPX - 1) / SDRPP_ZPX);
+        hipLaunchKernelGGL(zoom_palette_kernel, dim3(gx.x, (unsigned)first), dim3(256), 0, c->stream, (const float*)(W.d_ring + (size_t)W.cur * c->fft_size), c->fft_size, data_width,
+                           (const int32_t*)d_zs, (const int32_t*)d_zc, wf_min, wf_max, d_zm, d_idx);
+        if (count > first) {
+            hipLaunchKernelGGL(zoom_palette_kernel, dim3(gx.x, (unsigned)(count - first)), dim3(256), 0, c->stream, (const float*)W.d_ring, c->fft_size, data_width, (const int32_t*)d_zs,
+                               (const int32_t*)d_zc, wf_min, wf_max, d_zm + (size_t)first * data_width, d_idx + (size_t)first * data_width);
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) { e = hipMemcpy(dst_host, d_idx, (size_t)count * data_width * sizeof(int32_t), hipMemcpyDeviceToHost); }
+        if (e != hipSuccess) { rc = fail(c, SDRPP_ERR_HIP, "waterfall raster failed: %s", hipGetErrorString(e)); }
+    }
+    dev_free(d_zs);
+    dev_free(d_zc);
+    dev_free(d_zm);
+    dev_free(d_idx);
+    if (rc) { return rc; }
+    for (size_t i = (size_t)count * data_width; i < (size_t)W.height * data_width; i++) { dst_host[i] = -1; }  // (uint32_t)255 << 24 in the reference
+    if (n_lines) { *n_lines = count; }
+    return SDRPP_OK;
+}
+
 static void preproc_free(sdrpp_ctx* c) {
     sdrpp_ctx::Pre& P = c->pre;
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
@@ -1796,6 +1960,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
     preproc_free(c);
+    wf_free(c);
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
     c->vfos.clear();
     for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
@@ -1856,6 +2021,8 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
     if (!is_pow2(fft_size) || fft_size < 1024 || fft_size > (1 << 20)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft_size %d: need a power of two in [1024, 1048576]", fft_size); }
     if (nz <= 0 || nz > fft_size || skip < 0) { return fail(c, SDRPP_ERR_INVALID, "bad framing nz=%d skip=%d", nz, skip); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    if (c->wf.height > 0 && fft_size != c->fft_size) { wf_free(c); }  // the line history holds lines of the old size (setRawFFTSize reallocates rawFFTs)
     c->fft_on = false;
     const int m = ilog2(fft_size);
     int rc = upload(c, &c->d_window, window, (size_t)nz);

@@ -218,3 +218,96 @@ def test_preproc_chain(backend, ratio, dc, conj):
     with pytest.raises(Exception):
         ctx.preproc_read()
     ctx.close()
+
+
+class _OracleWf:
+    def __init__(self, height, N, width):
+        import ctypes as C
+
+        self.C = C
+        self.o = S.oracle()
+        o = self.o
+        o.orc_wf_create.restype = C.c_void_p
+        o.orc_wf_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        o.orc_wf_destroy.argtypes = [C.c_void_p]
+        o.orc_wf_set_smoothing.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        o.orc_wf_set_hold.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        o.orc_wf_push.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_float, C.c_float, ip]
+        o.orc_wf_latest.argtypes = [C.c_void_p, fp, fp]
+        o.orc_wf_raster.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, ip]
+        self.h = o.orc_wf_create(height, N, width)
+        self.height, self.N, self.width = height, N, width
+
+    def push(self, line, start, size, wmin, wmax):
+        C = self.C
+        idx = np.empty(self.width, np.int32)
+        line = np.ascontiguousarray(line, np.float32)
+        self.o.orc_wf_push(self.h, line.ctypes.data_as(C.POINTER(C.c_float)), start, size, wmin, wmax, idx.ctypes.data_as(C.POINTER(C.c_int32)))
+        return idx
+
+    def latest(self):
+        C = self.C
+        a, b = np.empty(self.width, np.float32), np.empty(self.width, np.float32)
+        self.o.orc_wf_latest(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)))
+        return a, b
+
+    def raster(self, start, size, wmin, wmax):
+        C = self.C
+        fb = np.empty((self.height, self.width), np.int32)
+        n = self.o.orc_wf_raster(self.h, start, size, wmin, wmax, fb.ctypes.data_as(C.POINTER(C.c_int32)))
+        return fb, n
+
+
+def test_waterfall_history_trace_and_raster(backend):
+    """the raw-line ring in HBM (getFFTBuffer order), the FFT trace's smoothing / hold per new line (pushFFT) and
+    the full re-raster after a view change (updateWaterfallFb) — all integer / max / separately rounded float work: bit-exact against
+    the oracle restatement of waterfall.cpp.  The ring wraps (height 5, 12 lines), pushes bring 0, 1 and several lines."""
+    from sdrplusplus_amd import capi, workloads
+
+    sr, N, W, H = 10e6, 4096, 600, 5
+    x = workloads.synth(2, N * 12 + 1000, seed=31)
+    ctx = capi.Context(0, max_push=N * 5)
+    w = capi.design_fft_window(2, N)
+    ctx.fft_configure(N, N, 0, w)
+    start, size = capi.design_waterfall_view(1.0e6, 4.0e6, sr, N)
+    wmin, wmax = -110.0, -10.0
+    ctx.fft_set_view(start, size, W, wmin, wmax)
+    ctx.wf_configure(H)
+    spec = S.OracleSpectrum(N, N, 0, w)
+    owf = _OracleWf(H, N, W)
+    pos, step = 0, 0
+    for npush in [N // 2, N, N * 3 + 17, 100, N * 5, N * 2]:
+        if step == 2:   # switched on mid-stream: the smoothing buffer starts as a copy of the current trace
+            ctx.wf_set_smoothing(True, 0.25)
+            owf.o.orc_wf_set_smoothing(owf.h, 1, 0.25)
+        if step == 3:
+            ctx.wf_set_hold(True, 1.5)
+            owf.o.orc_wf_set_hold(owf.h, 1, 1.5)
+        blk = x[pos:pos + npush]
+        pos += npush
+        step += 1
+        ctx.push(blk)
+        lines = spec.push(blk)
+        raw, zoomed, index = ctx.fft_read()
+        assert raw.shape == lines.shape and np.array_equal(raw, lines)
+        for k, ln in enumerate(lines):
+            oidx = owf.push(ln, start, size, wmin, wmax)
+            assert np.array_equal(index[k], oidx)
+        if len(lines):
+            gl, gh = ctx.wf_latest(W)
+            ol, oh = owf.latest()
+            assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
+            if step > 3:
+                assert np.array_equal(gh.view(np.uint32), oh.view(np.uint32))
+        # re-raster with the current view and with a zoomed-in one (the GUI's pan / zoom): every stored line, newest first
+        for vo, vb in ((1.0e6, 4.0e6), (-2.0e6, 1.0e6)):
+            s2, z2 = capi.design_waterfall_view(vo, vb, sr, N)
+            gfb, gn = ctx.wf_raster(H, s2, z2, W, wmin, wmax)
+            ofb, on = owf.raster(s2, z2, wmin, wmax)
+            assert gn == on and np.array_equal(gfb, ofb)
+    assert gn == H  # the ring wrapped
+    ctx.wf_configure(0)
+    with pytest.raises(Exception):
+        ctx.wf_raster(H, start, size, W, wmin, wmax)
+    ctx.close()
