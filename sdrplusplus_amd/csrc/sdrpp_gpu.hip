@@ -18,6 +18,7 @@
 #include "fft_kernels.h"
 #include "host_design.h"
 #include "vfo_kernels.h"
+#include "chain_kernels.h"
 
 using namespace sdrpp_k;
 
@@ -51,6 +52,8 @@ struct ToepTab {
     int tl_len = 0, nsteps = 0, s_in = 0, rows = 0, nvar = 0;
     int kind = 0;  // 1 decimator, 2 resampler, 4 channel filter, 8 audio low-pass
     bool ok = false;
+    std::vector<float> h_tl;  // host copies (the fused back-end kernel concatenates the tables of its four stages)
+    std::vector<int> h_lb;
 };
 
 struct Vfo {
@@ -85,6 +88,17 @@ struct Vfo {
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
+    // fused back end (vfo_chain_kernel): last decimator -> resampler -> channel filter -> discriminator + audio low-pass
+    struct Chain {
+        bool ok = false;
+        int stage = 0;             // index of the (only) separate decimator stage
+        float* d_tl = nullptr;     // concatenated tap tables
+        int* d_lb = nullptr;       // [interp][4][64]
+        int tl_off[4] = { 0, 0, 0, 0 }, tl_len = 0;
+        int nsteps[4], s_in[4], rows[4], groups[4], slab_out[4];
+        int hist[4] = { 0, 0, 0, 0 };
+        int warm = 2;
+    } chain;
     // radio AF chain (sdrpp_vfo_set_af): RationalResampler<stereo_t> -> high-pass -> de-emphasis, fed by st[i_out]
     struct Af {
         bool on = false;
@@ -441,6 +455,8 @@ int toep_upload(sdrpp_ctx* c, ToepTab& T, const std::vector<float>& tl, const st
     if (rc) { return rc; }
     T.tl_len = (int)tl.size();
     T.nvar = (int)lb.size() / 64;
+    T.h_tl = tl;
+    T.h_lb = lb;
     // usable only if four wavefront windows (two planes each) + the tap table fit the block's LDS budget (1/3 of a CU) — very
     // long filters stay on the register-blocked VALU kernels
     const int span = (2 * 16 - 1) * T.s_in + 4 * T.nsteps, pl = (span + 8) & ~3;
@@ -526,6 +542,8 @@ void vfo_free(Vfo& v) {
     toep_free(v.tp_poly);
     toep_free(v.tp_chan);
     toep_free(v.tp_audio);
+    dev_free(v.chain.d_tl);
+    dev_free(v.chain.d_lb);
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
         dev_free(v.af.d_staps[i]);
         toep_free(v.af.tp_stage[i]);
@@ -803,6 +821,102 @@ bool frontcm_ok(int K1, int lgD1, int K2, int lgD2, int* pf) {
     return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU
 }
 
+// SDRPP_CHAIN_PROF builds only: per-wavefront cycle counters of one workgroup of the fused back end, printed at destroy
+long long* chain_prof_buffer(sdrpp_ctx* c) {
+#ifdef SDRPP_CHAIN_PROF
+    static long long* buf = nullptr;
+    if (!buf) { (void)hipMalloc((void**)&buf, 32 * sizeof(long long)); (void)hipMemset(buf, 0, 32 * sizeof(long long)); }
+    (void)c;
+    return buf;
+#else
+    (void)c;
+    return nullptr;
+#endif
+}
+
+// ---- fused back end (vfo_chain_kernel): static per-VFO set-up -------------------------------------------------------------------------
+// Eligible: [front end] -> exactly one separate decimator -> polyphase resampler -> channel filter -> FM discriminator + audio
+// low-pass, every stage with a matrix-core tap table, slab sizes integral (960 IF samples per slab).
+int chain_static_stage(const Vfo& v) {
+    const sdrpp_vfo_desc& d = v.d;
+    if (d.n_stages < 1) { return -1; }
+    const bool fused = d.n_stages >= 2 && front2_t2(d.stage_ntaps[0], d.stage_decim[0], d.stage_ntaps[1], d.stage_decim[1], 8) > 0;
+    const int first_sep = fused ? 2 : 1;
+    return (d.n_stages - first_sep == 1) ? first_sep : -1;
+}
+int chain_build(sdrpp_ctx* c, Vfo& v) {
+    Vfo::Chain& ch = v.chain;
+    dev_free(ch.d_tl);
+    dev_free(ch.d_lb);
+    ch.ok = false;
+    // Opt-in (SDRPP_GPU_CHAIN=1): correct (tests/test_parity_vfo.py::test_fused_back_end) but, as measured in round 1, 3.5x SLOWER than
+    // the four separate launches — one stage per wavefront leaves 1-2 wavefronts per SIMD, every LDS/global latency is exposed and
+    // the stage-0 loads are not prefetched.  Kept as the starting point of the fused back end.
+    if (!getenv("SDRPP_GPU_CHAIN")) { return SDRPP_OK; }
+    const int s = chain_static_stage(v);
+    const bool fm = v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM;
+    if (s < 0 || !fm || v.i_poly < 0 || v.chan_ntaps <= 0 || !v.tp_stage[s].ok || !v.tp_poly.ok || !v.tp_chan.ok || !v.tp_audio.ok) { return SDRPP_OK; }
+    const ToepTab* T[4] = { &v.tp_stage[s], &v.tp_poly, &v.tp_chan, &v.tp_audio };
+    const int L = v.d.interp, M = v.d.decim, A = SDRPP_CHAIN_SLAB;
+    if (T[0]->rows != 15 || T[2]->rows != 15 || T[3]->rows != 15 || T[1]->rows % L != 0) { return SDRPP_OK; }
+    if (A % (16 * T[1]->rows) != 0 || ((long long)A * M) % L != 0) { return SDRPP_OK; }
+    const int slab0 = (int)((long long)A * M / L);
+    if (slab0 % (16 * 15) != 0) { return SDRPP_OK; }
+    ch.stage = s;
+    ch.slab_out[0] = slab0;
+    ch.slab_out[1] = ch.slab_out[2] = ch.slab_out[3] = A;
+    int off = 0;
+    for (int k = 0; k < 4; k++) {
+        ch.nsteps[k] = T[k]->nsteps;
+        ch.s_in[k] = T[k]->s_in;
+        ch.rows[k] = T[k]->rows;
+        ch.groups[k] = ch.slab_out[k] / (16 * T[k]->rows);
+        ch.tl_off[k] = off;
+        off += (T[k]->tl_len + 3) & ~3;
+    }
+    ch.tl_len = off;
+    // history in front of each consumer's slab: the last tile's window must end inside [history | slab]
+    for (int k = 1; k < 4; k++) {
+        const int tiles = ch.groups[k] * 16;
+        ch.hist[k] = std::max(0, ch.s_in[k] * (tiles - 1) + 4 * ch.nsteps[k] - ch.slab_out[k - 1]);
+    }
+    // the resampler's tiles start on phase-cycle boundaries: its output alignment C[1] must be a multiple of L (see do_vfos)
+    {
+        const int c2 = -(v.audio_ntaps - 1) + ch.hist[3];
+        const int c1 = -(v.chan_ntaps - 1) + c2 + ch.hist[2];
+        ch.hist[2] += ((-c1 % L) + L) % L;
+    }
+    ch.warm = (ch.hist[1] * L / M + ch.hist[2] + ch.hist[3] + 64 < A) ? 2 : 3;
+    // tables
+    std::vector<float> tl((size_t)ch.tl_len, 0.0f);
+    for (int k = 0; k < 4; k++) { std::copy(T[k]->h_tl.begin(), T[k]->h_tl.end(), tl.begin() + ch.tl_off[k]); }
+    std::vector<int> lb((size_t)L * 4 * 64);
+    for (int ph = 0; ph < L; ph++) {
+        for (int k = 0; k < 4; k++) {
+            const int var = (k == 1) ? ph : 0;
+            for (int l = 0; l < 64; l++) { lb[((size_t)ph * 4 + k) * 64 + l] = T[k]->h_lb[(size_t)var * 64 + l]; }
+        }
+    }
+    ChainJob probe{};
+    probe.tl_len = ch.tl_len;
+    for (int k = 0; k < 4; k++) {
+        probe.nsteps[k] = ch.nsteps[k];
+        probe.s_in[k] = ch.s_in[k];
+        probe.hist[k] = ch.hist[k];
+        probe.slab_out[k] = ch.slab_out[k];
+    }
+    if ((size_t)chain_layout(probe).total * sizeof(float) > (size_t)kMaxLds) { return SDRPP_OK; }
+    int rc = upload(c, &ch.d_tl, tl.data(), tl.size());
+    if (rc) { return rc; }
+    rc = upload(c, &ch.d_lb, lb.data(), lb.size());
+    if (rc) { return rc; }
+    // the kernel re-runs `warm` slabs in front of every chunk from the INPUT stream: keep that much of it
+    rc = stream_grow_hist(c, v.st[(size_t)v.i_first + s - 1], (ch.warm + 1) * ch.slab_out[0] * v.d.stage_decim[s] + v.d.stage_ntaps[s] + 64);
+    if (rc) { return rc; }
+    ch.ok = true;
+    return SDRPP_OK;
+}
+
 // ---- matrix-core FIR launches (vfo_toep_kernel): job construction, per-list planning (macro tiles per wavefront, grid, LDS), launch ----
 ToepJob toep_job(const ToepTab& T, int var, StreamIn in, float* out, int base0, int nout, float inv_dev) {
     ToepJob j{};
@@ -866,6 +980,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
     std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
+    std::vector<ChainJob> chainj;  // fused back end (vfo_chain_kernel)
     // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
     std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
     std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
@@ -876,6 +991,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     for (auto& kv : c->vfos) {
         Vfo& v = *kv.second;
         Stream* cur = &v.st[(size_t)v.i_first];
+        // fused back end: the four per-stage launches below become one ChainJob (same integer state, same streams)
+        bool use_chain = false;
+        ChainJob cj{};
+        int cj_poly_base0 = 0;
         if (v.d.n_stages == 0) {
             rot.push_back(RotJob{ v.theta, v.phi, (float2*)cur->data, n_in });
             cur->n = n_in;
@@ -910,11 +1029,17 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 nxt->n = mem.nout2;
                 cur = nxt;
             }
+            use_chain = v.chain.ok && first_sep == v.chain.stage;
             for (int s = first_sep; s < v.d.n_stages; s++) {
                 Stream* nxt = &v.st[(size_t)v.i_first + s];
                 const int Ds = v.d.stage_decim[s];
                 const int no = decim_nout(cur->n, v.soff[s], Ds);
-                if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
+                if (use_chain) {
+                    cj.in = stream_in(*cur);
+                    cj.in0_base = (long long)v.soff[s] - (v.d.stage_ntaps[s] - 1);
+                    cj.d0 = Ds;
+                }
+                else if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
                 else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
                 v.soff[s] = v.soff[s] + no * Ds - cur->n;
                 nxt->n = no;
@@ -924,7 +1049,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (v.i_poly >= 0) {
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
-            if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
+            if (use_chain) {
+                cj_poly_base0 = v.poff - (v.tpp - 1);
+                cj.lb = v.chain.d_lb + (size_t)v.pphase * 4 * 64;
+            }
+            else if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
             else if (v.d_cyc) {
                 polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
@@ -940,7 +1069,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
+            if (use_chain) { cj.if_out = nxt->data; }
+            else if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
             else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
             cur = nxt;
@@ -951,7 +1081,34 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
-            if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
+            if (use_chain) {
+                const Vfo::Chain& ch = v.chain;
+                const int L = v.d.interp, M = v.d.decim;
+                cj.audio_out = out.data;
+                cj.n_if = nif;
+                cj.tl = ch.d_tl;
+                cj.tl_len = ch.tl_len;
+                for (int k = 0; k < 4; k++) {
+                    cj.tl_off[k] = ch.tl_off[k];
+                    cj.nsteps[k] = ch.nsteps[k];
+                    cj.s_in[k] = ch.s_in[k];
+                    cj.rows[k] = ch.rows[k];
+                    cj.groups[k] = ch.groups[k];
+                    cj.hist[k] = ch.hist[k];
+                    cj.slab_out[k] = ch.slab_out[k];
+                }
+                // output alignment, consumer by consumer (chain_kernels.h): C[s-1] = base0[s] + ratio * C[s] + hist[s]
+                cj.C[3] = 0;
+                cj.C[2] = -(v.audio_ntaps - 1) + cj.C[3] + ch.hist[3];
+                cj.C[1] = -(v.chan_ntaps - 1) + cj.C[2] + ch.hist[2];  // a multiple of L by construction (chain_build)
+                cj.C[0] = cj_poly_base0 + (int)((long long)cj.C[1] * M / L) + ch.hist[1];
+                const int need = nif - std::min(0, cj.C[2]);
+                cj.nslabs = (need + SDRPP_CHAIN_SLAB - 1) / SDRPP_CHAIN_SLAB;
+                cj.warm = ch.warm;
+                cj.inv_deviation = v.d.inv_deviation;
+                if (cj.nslabs > 0) { chainj.push_back(cj); }
+            }
+            else if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
             else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
         }
@@ -1304,6 +1461,23 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS");
     }
+    // fused back end: time chunks per VFO so that ~2 workgroups per CU are resident (the warm-up slabs of a chunk are pure
+    // overhead, so no more chunks than that), at least `8 * warm` slabs per chunk
+    int chain_chunks = 0;
+    size_t chain_lds = 0;
+    if (!chainj.empty()) {
+        int max_slabs = 0;
+        for (auto& j : chainj) { max_slabs = std::max(max_slabs, j.nslabs); }
+        int per_vfo = std::max(1, 512 / (int)chainj.size());
+        per_vfo = std::min(per_vfo, std::max(1, max_slabs / 16));
+        for (auto& j : chainj) {
+            j.slabs_per_block = (j.nslabs + per_vfo - 1) / per_vfo;
+            chain_chunks = std::max(chain_chunks, (j.nslabs + j.slabs_per_block - 1) / j.slabs_per_block);
+            chain_lds = std::max(chain_lds, (size_t)chain_layout(j).total * sizeof(float));
+        }
+    }
+    ChainJob* d_chainj = arena_push(c, chainj);
+    if (!chainj.empty() && !d_chainj) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepPlan tp_af_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     FirBJob* d_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
@@ -1471,6 +1645,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
         return SDRPP_OK;
     };
+    if (!chainj.empty() && chain_chunks > 0) {
+        FamilyTimer t(c, F_FIR);
+        launch(c, vfo_chain_kernel, dim3((unsigned)chain_chunks, (unsigned)chainj.size()), dim3(256), chain_lds, (const ChainJob*)d_chainj, (long long*)chain_prof_buffer(c));
+    }
     {
         FamilyTimer t(c, F_DECIM);
         for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
@@ -1959,6 +2137,15 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
+#ifdef SDRPP_CHAIN_PROF
+    {
+        long long h[32];
+        if (hipMemcpy(h, chain_prof_buffer(c), sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[sdrpp chain prof] iterations %lld (last launch, workgroup (1, 0)); cycles per wavefront: work / barrier wait / stage-0 load / stage-0 mfma\n", h[16]);
+            for (int s = 0; s < 4; s++) { fprintf(stderr, "[sdrpp chain prof]   stage %d: %lld / %lld / %lld / %lld\n", s, h[s * 4], h[s * 4 + 1], h[s * 4 + 2], h[s * 4 + 3]); }
+        }
+    }
+#endif
     preproc_free(c);
     wf_free(c);
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
@@ -2357,6 +2544,8 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     v->theta2 = sdrpp_host::turnsPerSample(d->ssb_phase_delta_re, d->ssb_phase_delta_im);
     if (d->demod < SDRPP_DEMOD_USB) { v->theta2 = 0.0; }
     v->modtaps_dirty = true;
+    rc = chain_build(c, *v);
+    if (rc) { return rc; }
     rc = vfo_reset_state(c, *v);
     if (rc) { return rc; }
     *id = v->id;
@@ -2406,9 +2595,10 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
         int rc = upload_blocked(c, &v.d_chan, v.ctaps_chan.data(), n, 1, &v.chan_kp);
         if (rc) { return rc; }
         v.tp_chan.kind = 4;
-        return toep_build_fir(c, v.tp_chan, v.ctaps_chan.data(), n, 1);
+        rc = toep_build_fir(c, v.tp_chan, v.ctaps_chan.data(), n, 1);
+        if (rc) { return rc; }
     }
-    return SDRPP_OK;
+    return chain_build(c, v);  // the fused back end follows the new filter (or steps aside when it is switched off)
 }
 
 static void af_detach(Vfo& v) {

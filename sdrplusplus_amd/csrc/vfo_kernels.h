@@ -1354,12 +1354,37 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
         f32x4 accR[G], accI[G];
 #pragma unroll
         for (int g = 0; g < G; g++) { accR[g] = mfma4_zero(); accI[g] = mfma4_zero(); }
-        for (int t = 0; t < nsteps; t++) {
-            const float b = Bp[4 * t];
+        // operands of four steps are fetched together (up to 20 independent ds_reads, one wait) in front of their matrix instructions
+        {
+            constexpr int U = 4;
+            int t0 = 0;
+            for (; t0 + U <= nsteps; t0 += U) {
+                float b[U], xr[U][G], xi[U][G];
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                accR[g] = mfma_16x16x4(Ar[g * 16 * s_in + 4 * t], b, accR[g]);
-                if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(Ai[g * 16 * s_in + 4 * t], b, accI[g]); }
+                for (int u = 0; u < U; u++) {
+                    b[u] = Bp[4 * (t0 + u)];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        xr[u][g] = Ar[g * 16 * s_in + 4 * (t0 + u)];
+                        if constexpr (WIDTH == 2) { xi[u][g] = Ai[g * 16 * s_in + 4 * (t0 + u)]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        accR[g] = mfma_16x16x4(xr[u][g], b[u], accR[g]);
+                        if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(xi[u][g], b[u], accI[g]); }
+                    }
+                }
+            }
+            for (; t0 < nsteps; t0++) {
+                const float b = Bp[4 * t0];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    accR[g] = mfma_16x16x4(Ar[g * 16 * s_in + 4 * t0], b, accR[g]);
+                    if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(Ai[g * 16 * s_in + 4 * t0], b, accI[g]); }
+                }
             }
         }
         // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r

@@ -95,6 +95,35 @@ def test_matrix_core_front_bank(backend, nv):
     ctx.close()
 
 
+def test_fused_back_end(backend, monkeypatch):
+    """Opt-in fused back end (SDRPP_GPU_CHAIN=1, vfo_chain_kernel): last decimator -> resampler -> channel filter -> discriminator +
+    audio low-pass as a 4-wavefront software pipeline over LDS double buffers.  Same results as the separate launches; uneven
+    pushes exercise the warm-up slabs, chunk boundaries and the output alignment constants."""
+    from sdrplusplus_amd import workloads
+
+    monkeypatch.setenv("SDRPP_GPU_CHAIN", "1")
+    sr, nv = 10e6, 3
+    pushes = [50000, 1031, 200000, 7, 33333]
+    x = workloads.synth(3, sum(pushes), seed=17, nvfo=nv)
+    plan = workloads.vfo_plan(3, nv)
+    ctx, vids, chains, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan], max(pushes))
+    worst_audio, worst_if, pos = 0.0, 0.0, 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        ctx.push(blk)
+        for vid, ch in zip(vids, chains):
+            oi, oa = ch.process(blk)
+            gi, ga = ctx.vfo_read_if(vid), ctx.vfo_read(vid)
+            assert gi.shape == oi.shape and ga.shape == oa.shape
+            if len(oa):
+                worst_audio = max(worst_audio, rms(ga - oa))
+                worst_if = max(worst_if, rms(gi - oi) / max(rms(oi), 1e-9))
+    assert worst_audio < 1e-5, worst_audio
+    assert worst_if < 2e-3, worst_if
+    ctx.close()
+
+
 def test_long_first_stage_bank(backend):
     """cfg 4 geometry (61.44 MS/s; plans 1024 / 4096 / 2048 with a /64 first stage of 257 / 400 / 329 taps): 18 VFOs per mode take
     the matrix-core kernel for long first stages (vfo_frontcl_kernel), the stages behind it the Toeplitz kernels."""
