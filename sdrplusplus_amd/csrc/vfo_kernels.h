@@ -1354,9 +1354,10 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
         f32x4 accR[G], accI[G];
 #pragma unroll
         for (int g = 0; g < G; g++) { accR[g] = mfma4_zero(); accI[g] = mfma4_zero(); }
-        // operands of four steps are fetched together (up to 20 independent ds_reads, one wait) in front of their matrix instructions
+        // operands of four (complex) / eight (real) steps are fetched together (20-24 independent ds_reads, one wait) in front of
+        // their matrix instructions
         {
-            constexpr int U = 4;
+            constexpr int U = (WIDTH == 2) ? 4 : 8;
             int t0 = 0;
             for (; t0 + U <= nsteps; t0 += U) {
                 float b[U], xr[U][G], xi[U][G];
