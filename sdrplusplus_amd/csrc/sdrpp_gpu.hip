@@ -973,7 +973,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<PolyJob> poly;
     std::vector<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
     std::vector<FirBJob> chan;
-    std::vector<QuadJob> quad;
     std::vector<SeqJob> seq;
     std::vector<PreJob> pre;
     std::vector<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
@@ -1503,7 +1502,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     PolyJob* d_poly = arena_push(c, poly);
     PolyBJob* d_polyb[4] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]), arena_push(c, polyb[2]), arena_push(c, polyb[3]) };
     FirBJob* d_chan = arena_push(c, chan);
-    QuadJob* d_quad = arena_push(c, quad);
     SeqJob* d_seq = arena_push(c, seq);
     PreJob* d_pre = arena_push(c, pre);
     if (!pre.empty() && !d_pre) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
@@ -1512,7 +1510,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if (!audio_fm.empty() && !d_audio_fm) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     CarryJob* d_carry = arena_push(c, carry);
     if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1]) || (!polyb[2].empty() && !d_polyb[2]) || (!polyb[3].empty() && !d_polyb[3])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!quad.empty() && !d_quad) || (!seq.empty() && !d_seq) ||
+    if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!seq.empty() && !d_seq) ||
         (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
     }
@@ -1694,13 +1692,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         rc = launch_fir(chan, d_chan, 2, false);
         if (rc) { return rc; }
     }
-    if (!quad.empty() || !seq.empty()) {
+    if (!pre.empty() || !seq.empty()) {
         FamilyTimer t(c, F_DEMOD);
-        if (!quad.empty()) {
-            int mx = 0;
-            for (auto& q : quad) { mx = std::max(mx, q.n); }
-            if (mx > 0) { launch(c, vfo_quadrature_kernel, dim3(std::min((mx + 255) / 256, 4096), (unsigned)quad.size()), dim3(256), 0, (const QuadJob*)d_quad); }
-        }
         if (!pre.empty()) {
             int mx = 0;
             for (auto& q : pre) { mx = std::max(mx, q.n); }

@@ -247,58 +247,6 @@ __global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob
 }
 
 // =====================================================================================================================
-// Generic (decimating) FIR with real taps on complex / stereo (WIDTH 2) or real (WIDTH 1) streams.
-//   out[j] = sum_k taps[k] * in[off0 + j*D + k - (K-1)]      (decimating_fir.h:51-61, fir.h:67-77)
-// STEREO: WIDTH 1 input, output written as {v, v} (convert::MonoToStereo / LRToStereo(x, x)).
-// =====================================================================================================================
-struct FirJob {
-    StreamIn in;
-    float* out;
-    const float* taps;
-    int ntaps, log2_decim, off0, nout;
-};
-
-template <int WIDTH, bool STEREO>
-__global__ __launch_bounds__(256) void vfo_fir_kernel(const FirJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    const FirJob& job = jobs[blockIdx.y];
-    const int tile = blockDim.x;
-    const int j0 = blockIdx.x * tile;
-    if (j0 >= job.nout) { return; }
-    const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
-    const int extra = (K - 1 + D - 1) >> lgD;
-    const int pitch = tile + extra + 1;
-    const int nsamp = (tile - 1) * D + K;
-    const int base = job.off0 + j0 * D - (K - 1);
-    const int j = threadIdx.x;
-    const UniformF32 taps = as_uniform(job.taps);  // wave-uniform -> scalar loads
-    if constexpr (WIDTH == 2) {
-        float2* xs = reinterpret_cast<float2*>(smem);
-        for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = stream_load2(job.in, base + s); }
-        __syncthreads();
-        float2 acc = make_float2(0.0f, 0.0f);
-        for (int k = 0; k < K; k++) {
-            const float2 x = xs[(k & (D - 1)) * pitch + (k >> lgD) + j];
-            const float h = taps[k];
-            acc.x = fmaf(h, x.x, acc.x);
-            acc.y = fmaf(h, x.y, acc.y);
-        }
-        if (j0 + j < job.nout) { reinterpret_cast<float2*>(job.out)[j0 + j] = acc; }
-    }
-    else {
-        float* xs = smem;
-        for (int s = threadIdx.x; s < nsamp; s += tile) { xs[(s & (D - 1)) * pitch + (s >> lgD)] = stream_load1(job.in, base + s); }
-        __syncthreads();
-        float acc = 0.0f;
-        for (int k = 0; k < K; k++) { acc = fmaf(taps[k], xs[(k & (D - 1)) * pitch + (k >> lgD) + j], acc); }
-        if (j0 + j < job.nout) {
-            if constexpr (STEREO) { reinterpret_cast<float2*>(job.out)[j0 + j] = make_float2(acc, acc); }
-            else { job.out[j0 + j] = acc; }
-        }
-    }
-}
-
-// =====================================================================================================================
 // Polyphase rational resampler (polyphase_resampler.h:75-93):
 //   A_n = phase0 + n*M;  out[n] = sum_k bank[A_n mod L][k] * in[offset0 + A_n div L + k - (tpp-1)]
 // bank[(L-1) - (i mod L)][i div L] = taps[i] (polyphase_bank.h:31-34) is laid out [phase][tpp] on the host.
@@ -342,29 +290,14 @@ __global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict
 }
 
 // =====================================================================================================================
-// FM discriminator (quadrature.h:39-46): out[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation
+// FM discriminator (quadrature.h:39-46): out[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation — fused into the loads
+// of the audio low-pass kernels (QUAD); this is its phase wrap.
 // =====================================================================================================================
-struct QuadJob {
-    StreamIn in;  // complex IF stream, hist_len >= 1
-    float* out;
-    float inv_deviation;
-    int n;
-};
 __device__ __forceinline__ float normalize_phase(float d) {
     const float FL_PI = 3.1415926535f;  // math/constants.h:4, math/normalize_phase.h:6-9
     if (d > FL_PI) { d -= 2.0f * FL_PI; }
     else if (d <= -FL_PI) { d += 2.0f * FL_PI; }
     return d;
-}
-__global__ __launch_bounds__(256) void vfo_quadrature_kernel(const QuadJob* __restrict__ jobs) {
-    const QuadJob& job = jobs[blockIdx.y];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
-        const float2 c = stream_load2(job.in, i);
-        const float2 p = stream_load2(job.in, i - 1);
-        const float cp = atan2f(c.y, c.x);
-        const float pp = atan2f(p.y, p.x);
-        job.out[i] = normalize_phase(cp - pp) * job.inv_deviation;
-    }
 }
 
 // =====================================================================================================================
