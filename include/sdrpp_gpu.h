@@ -180,6 +180,16 @@ int sdrpp_vfo_af_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
 int sdrpp_vfo_af_device_buffer(sdrpp_ctx* ctx, int id, const float** out, int* n_out);
 int sdrpp_abi_sizeof_af_desc(void);
 
+/* ---- sink-side sample packing: float -> int16 / int8 on the device, before the copy to the host -----------------
+ * `which`: 0 = what sdrpp_vfo_read returns (demodulator output, or the IF in RAW mode), 1 = the complex IF (RxVFO::out), 2 = the AF
+ * chain output.  pcm_type follows dsp/compression/pcm_type.h: 0 = I8, 1 = I16, 2 = F32.
+ * sdrpp_vfo_read_pcm: VOLK's volk_32f_s32f_convert_16i / _8i with the caller's scale (the recorder writes int16 WAV with 32767,
+ *   utils/wav.cpp:166); returns frames.  sdrpp_vfo_read_compressed: one SDR++-server frame exactly as
+ *   SampleStreamCompressor::process builds it (sample_stream_compressor.h:30-62): [u16 0][u16 pcm_type][f32 scaler][data], scaler =
+ *   the largest VALUE of the block, data scaled by 128 / scaler or 32768 / scaler; returns bytes (0 for an empty block). */
+int sdrpp_vfo_read_pcm(sdrpp_ctx* ctx, int id, int which, int pcm_type, float scale, void* dst_host, int max_frames);
+int sdrpp_vfo_read_compressed(sdrpp_ctx* ctx, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes);
+
 /* ---- WaterFall display state around the raw-line history (core/src/gui/widgets/waterfall.cpp) ---------------
  * The last `height` raw dB lines stay resident in HBM in the reference's ring order (getFFTBuffer :875-886), so a zoom / pan /
  * level change re-renders the whole waterfall on the device (updateWaterfallFb :600-631) instead of re-reading host memory, and

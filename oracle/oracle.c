@@ -1059,6 +1059,54 @@ void orc_deemp_process(orc_deemp* d, int count, const float* in, float* out) {
     d->lastR = out[2 * (count - 1) + 1];
 }
 
+/* Sink-side sample packing.
+ *   dsp/compression/sample_stream_compressor.h:30-62 (SDR++ server wire format): [u16 0][u16 pcmType][f32 scaler][data];
+ *     F32: scaler 0, raw copy; I8 / I16: scaler = value at volk_32f_index_max_32u (the largest VALUE, not magnitude), samples
+ *     converted with scale 128 / scaler resp. 32768 / scaler.
+ *   utils/wav.cpp:166 (recorder, int16 WAV): volk_32f_s32f_convert_16i(buf, samples, 32767.0f, n).
+ * VOLK generic conversions: r = x * scalar, clamped to the integer range, rintf, cast. */
+void orc_convert_16i(const float* in, float scalar, int n, int16_t* out) {
+    for (int i = 0; i < n; i++) {
+        float r = in[i] * scalar;
+        if (r > 32767.0f) { r = 32767.0f; }
+        else if (r < -32768.0f) { r = -32768.0f; }
+        out[i] = (int16_t)rintf(r);
+    }
+}
+void orc_convert_8i(const float* in, float scalar, int n, int8_t* out) {
+    for (int i = 0; i < n; i++) {
+        float r = in[i] * scalar;
+        if (r > 127.0f) { r = 127.0f; }
+        else if (r < -128.0f) { r = -128.0f; }
+        out[i] = (int8_t)rintf(r);
+    }
+}
+/* pcmType: 0 I8, 1 I16, 2 F32 (dsp/compression/pcm_type.h); in: count complex samples; returns bytes written */
+int orc_compress(int count, int pcmType, const float* in, uint8_t* out) {
+    uint16_t* compressionType = (uint16_t*)out;
+    uint16_t* sampleType = (uint16_t*)&out[2];
+    float* scaler = (float*)&out[4];
+    void* dataBuf = &out[8];
+    *compressionType = 0;
+    *sampleType = (uint16_t)pcmType;
+    if (pcmType == 2) {
+        *scaler = 0;
+        memcpy(dataBuf, in, (size_t)count * 8);
+        return 8 + count * 8;
+    }
+    float maxVal = in[0];
+    for (int i = 1; i < count * 2; i++) {
+        if (in[i] > maxVal) { maxVal = in[i]; }
+    }
+    *scaler = maxVal;
+    if (pcmType == 0) {
+        orc_convert_8i(in, 128.0f / maxVal, count * 2, (int8_t*)dataBuf);
+        return 8 + count * 2;
+    }
+    orc_convert_16i(in, 32768.0f / maxVal, count * 2, (int16_t*)dataBuf);
+    return 8 + count * 4;
+}
+
 /* WaterFall display state around the raw-line ring (gui/widgets/waterfall.cpp, waterfallVisible == true):
  *   getFFTBuffer  :875-886   currentFFTLine--, wrap, fftLines = min(fftLines + 1, waterfallHeight); the handler writes the raw line there
  *   pushFFT       :888-941   doZoom of that line -> latestFFT; palette index row; FFT smoothing (:913-920, three separately rounded

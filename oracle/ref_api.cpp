@@ -36,6 +36,7 @@ static inline int sdrpp_ref_quiet_printf(const char*, ...) { return 0; }
 #include <dsp/multirate/power_decimator.h>
 #include <dsp/correction/dc_blocker.h>
 #include <dsp/math/conjugate.h>
+#include <dsp/compression/sample_stream_compressor.h>
 #include <dsp/taps/low_pass.h>
 #include <dsp/taps/high_pass.h>
 #include <dsp/window/nuttall.h>
@@ -137,6 +138,11 @@ int ref_demod_process(void* h, int count, const float* in, float* out) {
     if (d->nfm) { return d->nfm->process(count, cin, (stereo_t*)out); }
     if (d->am) { return d->am->process(count, cin, (stereo_t*)out); }
     return d->ssb->process(count, cin, (stereo_t*)out);
+}
+
+// ---- server wire format: SampleStreamCompressor::process (sample_stream_compressor.h:30-62) ---------------------------------------------
+int ref_compress(int count, int pcmType, const float* in, unsigned char* out) {
+    return dsp::compression::SampleStreamCompressor::process(count, (dsp::compression::PCMType)pcmType, (const complex_t*)in, (uint8_t*)out);
 }
 
 // ---- IQFrontEnd pre-processing chain (iq_frontend.cpp:32-39): PowerDecimator -> DCBlocker -> Conjugate, process() level -------------

@@ -118,6 +118,8 @@ def load():
         raise ImportError("sdrpp_af_desc layout mismatch: library %d bytes, binding %d" % (L.sdrpp_abi_sizeof_af_desc(), C.sizeof(AfDesc)))
     L.sdrpp_design_deemphasis_alpha.restype = C.c_float
     L.sdrpp_design_deemphasis_alpha.argtypes = [C.c_double, C.c_double]
+    L.sdrpp_vfo_read_pcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int]
+    L.sdrpp_vfo_read_compressed.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int]
     L.sdrpp_wf_configure.argtypes = [vp, C.c_int]
     L.sdrpp_wf_set_smoothing.argtypes = [vp, C.c_int, C.c_float]
     L.sdrpp_wf_set_hold.argtypes = [vp, C.c_int, C.c_float]
@@ -173,6 +175,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
+    "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed",
     "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster",
     "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
@@ -351,6 +354,17 @@ class Context:
         out = np.empty((max(n, 1), 2), dtype=np.float32)
         got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
         return out[:got]
+
+    def vfo_read_pcm(self, vid, which, pcm_type, scale, max_frames):
+        dt = np.int16 if pcm_type == 1 else np.int8
+        out = np.empty((max(max_frames, 1), 2), dtype=dt)
+        got = self._chk(self.L.sdrpp_vfo_read_pcm(self.h, vid, which, pcm_type, float(scale), out.ctypes.data_as(C.c_void_p), max_frames))
+        return out[:got]
+
+    def vfo_read_compressed(self, vid, which, pcm_type, max_frames):
+        buf = np.empty(8 + max(max_frames, 1) * 8, dtype=np.uint8)
+        got = self._chk(self.L.sdrpp_vfo_read_compressed(self.h, vid, which, pcm_type, buf.ctypes.data_as(C.POINTER(C.c_uint8)), len(buf)))
+        return buf[:got]
 
     def wf_configure(self, height):
         self._chk(self.L.sdrpp_wf_configure(self.h, int(height)))

@@ -453,6 +453,38 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__
     if (hold) { hold[j] = h; }
 }
 
+// ---- sink-side sample packing: f32 -> int16 / int8 on the device, so the D2H copy carries 2 or 1 byte per value ----
+// VOLK generic conversion (volk_32f_s32f_convert_16i / _8i): r = x * scalar, clamp to the integer range, rintf (round half to even), cast.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_convert_kernel(const float* __restrict__ in, float scalar, long long n, T* __restrict__ out) {
+    constexpr float hi = sizeof(T) == 2 ? 32767.0f : 127.0f, lo = sizeof(T) == 2 ? -32768.0f : -128.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float r = in[i] * scalar;
+        if (r > hi) { r = hi; }
+        else if (r < lo) { r = lo; }
+        out[i] = (T)rintf(r);
+    }
+}
+// largest VALUE of a float array (volk_32f_index_max_32u as SampleStreamCompressor uses it: only the value matters); partial[blockIdx.x]
+__global__ __launch_bounds__(256) void pack_max_kernel(const float* __restrict__ in, long long n, float* __restrict__ partial) {
+    __shared__ float sm[256];
+    float m = __uint_as_float(0xff800000u);  // -inf; `src[i] > max` never lets a NaN win, like the reference loop (whose seed is src[0])
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = in[i];
+        if (v > m) { m = v; }
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            const float o = sm[threadIdx.x + d];
+            if (o > sm[threadIdx.x]) { sm[threadIdx.x] = o; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[blockIdx.x] = sm[0]; }
+}
+
 // int16 IQ -> float (file_source/main.cpp:162: volk_16i_s32f_convert_32f(out, in, 32768.0f, n))
 __global__ __launch_bounds__(256) void int16_to_float_kernel(const int16_t* __restrict__ in, float* __restrict__ out, long long n) {
     const float inv = 1.0f / 32768.0f;

@@ -179,6 +179,9 @@ struct sdrpp_ctx {
         float alpha = 0.0f, beta = 1.0f, hold_speed = 0.0f;
     } wf;
 
+    char* d_pack = nullptr;  // scratch of the packed-sample reads (sdrpp_vfo_read_pcm / _compressed)
+    size_t pack_cap = 0;
+
     // job arena
     char* arena_host[kArenaSlots] = {};
     char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
@@ -2141,6 +2144,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
 #endif
     preproc_free(c);
     wf_free(c);
+    dev_free(c->d_pack);
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
     c->vfos.clear();
     for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
@@ -2740,6 +2744,88 @@ int sdrpp_vfo_af_device_buffer(sdrpp_ctx* c, int id, const float** out, int* n_o
 }
 
 int sdrpp_abi_sizeof_af_desc(void) { return (int)sizeof(sdrpp_af_desc); }
+
+// ---- sink-side sample packing ----------------------------------------------------------------------------------
+static Stream* pick_stream(sdrpp_ctx* c, Vfo& v, int which) {
+    (void)c;
+    if (which == 0) { return (v.d.demod == SDRPP_DEMOD_RAW) ? &v.st[(size_t)v.i_if] : &v.st[(size_t)v.i_out]; }
+    if (which == 1) { return &v.st[(size_t)v.i_if]; }
+    if (which == 2) { return (v.af.on && v.af.i_last >= 0) ? &v.st[(size_t)v.af.i_last] : nullptr; }
+    return nullptr;
+}
+static int pack_scratch(sdrpp_ctx* c, size_t bytes) {
+    if (bytes <= c->pack_cap) { return SDRPP_OK; }
+    dev_free(c->d_pack);
+    c->pack_cap = 0;
+    int rc = dev_alloc(c, &c->d_pack, bytes + 1024);
+    if (rc) { return rc; }
+    c->pack_cap = bytes + 1024;
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scale, void* dst_host, int max_frames) {
+    if (!c || !dst_host || max_frames < 0 || (pcm_type != 0 && pcm_type != 1)) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = pick_stream(c, *it->second, which);
+    if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no such stream (%d)", id, which); }
+    const int n = std::min(max_frames, s->n);
+    if (n == 0) { return 0; }
+    const long long nv = (long long)n * 2;
+    const size_t esz = pcm_type == 1 ? 2 : 1;
+    int rc = pack_scratch(c, (size_t)nv * esz);
+    if (rc) { return rc; }
+    const dim3 grid((unsigned)std::min<long long>((nv + 255) / 256, 4096));
+    if (pcm_type == 1) { hipLaunchKernelGGL(pack_convert_kernel<int16_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, scale, nv, (int16_t*)c->d_pack); }
+    else { hipLaunchKernelGGL(pack_convert_kernel<int8_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, scale, nv, (int8_t*)c->d_pack); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst_host, c->d_pack, (size_t)nv * esz, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes) {
+    if (!c || !dst_host || pcm_type < 0 || pcm_type > 2) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Stream* s = pick_stream(c, *it->second, which);
+    if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no such stream (%d)", id, which); }
+    const int n = s->n;
+    const long long nv = (long long)n * 2;
+    const size_t esz = pcm_type == 2 ? 4 : (pcm_type == 1 ? 2 : 1);
+    const size_t total = 8 + (size_t)nv * esz;
+    if (n == 0) { return 0; }  // the reference block does not swap an empty frame (sample_stream_compressor.h:70-73)
+    if ((size_t)max_bytes < total) { return fail(c, SDRPP_ERR_INVALID, "compressed frame needs %zu bytes", total); }
+    uint16_t hdr[2] = { 0, (uint16_t)pcm_type };
+    memcpy(dst_host, hdr, 4);
+    float scaler = 0.0f;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (pcm_type == 2) {
+        memcpy(dst_host + 4, &scaler, 4);
+        HIPCHK(c, hipMemcpy(dst_host + 8, s->data, (size_t)nv * 4, hipMemcpyDeviceToHost));
+        return (int)total;
+    }
+    int rc = pack_scratch(c, (size_t)nv * esz + 256 * sizeof(float));
+    if (rc) { return rc; }
+    float* d_part = (float*)(c->d_pack);
+    char* d_data = c->d_pack + 256 * sizeof(float);
+    const int nb = (int)std::min<long long>((nv + 255) / 256, 256);
+    hipLaunchKernelGGL(pack_max_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, (const float*)s->data, nv, d_part);
+    float part[256];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(part, d_part, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost));
+    float maxVal = part[0];
+    for (int i = 1; i < nb; i++) {
+        if (part[i] > maxVal) { maxVal = part[i]; }
+    }
+    scaler = maxVal;
+    memcpy(dst_host + 4, &scaler, 4);
+    const dim3 grid((unsigned)std::min<long long>((nv + 255) / 256, 4096));
+    if (pcm_type == 1) { hipLaunchKernelGGL(pack_convert_kernel<int16_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, 32768.0f / maxVal, nv, (int16_t*)d_data); }
+    else { hipLaunchKernelGGL(pack_convert_kernel<int8_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, 128.0f / maxVal, nv, (int8_t*)d_data); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst_host + 8, d_data, (size_t)nv * esz, hipMemcpyDeviceToHost));
+    return (int)total;
+}
 
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }

@@ -148,3 +148,18 @@ def test_preproc_chain_bit_exact(ratio, dc, conj):
         assert no == nr and np.array_equal(oo[:no].view(np.uint32), ro[:nr].view(np.uint32))
     o.orc_preproc_destroy(oh)
     r.ref_preproc_destroy(rh)
+
+
+@pytest.mark.parametrize("pcm", [0, 1, 2])
+def test_sample_stream_compressor_bit_exact(pcm):
+    """'next' row 4: the SDR++-server frame (SampleStreamCompressor::process, sample_stream_compressor.h:30-62) restated in oracle.c
+    against the reference's own static function."""
+    o, r = S.oracle(), S.ref()
+    for seed, n in ((1, 1000), (2, 7), (3, 4096)):
+        x = np.ascontiguousarray(_noise(n, seed, 0.3))
+        a = np.zeros(8 + n * 8 + 16, np.uint8)
+        b = np.zeros_like(a)
+        u8 = C.POINTER(C.c_uint8)
+        na = o.orc_compress(n, pcm, S._fp(x.view(np.float32)), a.ctypes.data_as(u8))
+        nb = r.ref_compress(n, pcm, S._fp(x.view(np.float32)), b.ctypes.data_as(u8))
+        assert na == nb and np.array_equal(a[:na], b[:nb])

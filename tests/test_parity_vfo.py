@@ -429,3 +429,39 @@ def test_af_chain(backend, mode, high_pass, tau):
     with pytest.raises(Exception):
         ctx.vfo_af_count(vids[0])
     ctx.close()
+
+
+def test_packed_reads(backend):
+    """int16 / int8 conversion and the SDR++-server frame built on the device from the VFO's streams — bit-exact
+    against the oracle restatement (pinned to the reference's SampleStreamCompressor) applied to what the plain float reads return."""
+    import ctypes as C
+    from sdrplusplus_amd import radio, workloads
+
+    sr = 10e6
+    x = workloads.synth(3, 60000, seed=41, nvfo=4)
+    plan = workloads.vfo_plan(3, 4)
+    ctx, vids, _, _ = _setup(sr, [(plan[1][0], plan[1][3])], 60000)
+    a, keep = radio.af_desc(250e3, 48000.0, 50e-6, False)
+    ctx.vfo_set_af(vids[0], a, keep)
+    ctx.push(x)
+    o = S.oracle()
+    floats = {0: ctx.vfo_read(vids[0]), 1: ctx.vfo_read_if(vids[0]).view(np.float32).reshape(-1, 2), 2: ctx.vfo_af_read(vids[0])}
+    u8, fp = C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    for which, f in floats.items():
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        n = len(f)
+        assert n > 0
+        # recorder-style int16 (utils/wav.cpp:166) and int8 with an explicit scale
+        for pcm, scale, dt, conv in ((1, 32767.0, np.int16, o.orc_convert_16i), (0, 100.0, np.int8, o.orc_convert_8i)):
+            got = ctx.vfo_read_pcm(vids[0], which, pcm, scale, n)
+            ref = np.empty(n * 2, dt)
+            conv.argtypes = [fp, C.c_float, C.c_int, C.c_void_p]
+            conv(f.ctypes.data_as(fp), scale, n * 2, ref.ctypes.data_as(C.c_void_p))
+            assert got.shape == (n, 2) and np.array_equal(got.reshape(-1), ref)
+        # server frames
+        for pcm in (0, 1, 2):
+            got = ctx.vfo_read_compressed(vids[0], which, pcm, n)
+            ref = np.zeros(8 + n * 8 + 16, np.uint8)
+            nb = o.orc_compress(n, pcm, f.ctypes.data_as(fp), ref.ctypes.data_as(u8))
+            assert len(got) == nb and np.array_equal(got, ref[:nb])
+    ctx.close()
