@@ -200,6 +200,9 @@ int sdrpp_wf_set_smoothing(sdrpp_ctx* ctx, int enabled, float speed);           
 int sdrpp_wf_set_hold(sdrpp_ctx* ctx, int enabled, float speed);                 /* setFFTHold + setFFTHoldSpeed :1153-1164          */
 /* latestFFT (after smoothing) and latestFFTHold of the current view: data_width floats each (NULL to skip); returns data_width */
 int sdrpp_wf_latest(sdrpp_ctx* ctx, float* latest, float* hold);
+/* calculateVFOSignalInfo (:558-598) on the newest stored line: strength = max dB inside the VFO, snr = strength - mean of the two
+ * half-bandwidth side bands.  Returns 1, or 0 while no line is stored. */
+int sdrpp_wf_signal_info(sdrpp_ctx* ctx, double center_offset, double bandwidth, double whole_bandwidth, float* strength, float* snr);
 /* updateWaterfallFb: palette indices [height][data_width], newest line first, rows beyond the stored lines = -1 (opaque black). */
 int sdrpp_wf_raster(sdrpp_ctx* ctx, int draw_data_start, int draw_data_size, int data_width, float wf_min, float wf_max, int32_t* dst_host, int* n_lines);
 

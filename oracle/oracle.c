@@ -1181,6 +1181,35 @@ void orc_wf_push(orc_wf* w, const float* line, int drawDataStart, int drawDataSi
         }
     }
 }
+/* calculateVFOSignalInfo (waterfall.cpp:558-598) on the newest stored line: strength = max over the VFO's bins, snr = max - mean of the
+ * two side bands (one bandwidth wide in total), accumulated in double in bin order.  Returns 0 when no line is stored. */
+int orc_wf_signal_info(const orc_wf* w, double centerOffset, double bandwidth, double wholeBandwidth, float* strength, float* snr) {
+    if (w->fftLines <= 0) { return 0; }
+    const float* fftLine = &w->raw[(size_t)w->currentFFTLine * w->N];
+    const int rawFFTSize = w->N;
+    double vfoMinSizeFreq = centerOffset - bandwidth;
+    double vfoMinFreq = centerOffset - (bandwidth / 2.0);
+    double vfoMaxFreq = centerOffset + (bandwidth / 2.0);
+    double vfoMaxSizeFreq = centerOffset + bandwidth;
+    int off[4];
+    const double f[4] = { vfoMinSizeFreq, vfoMinFreq, vfoMaxFreq, vfoMaxSizeFreq };
+    for (int i = 0; i < 4; i++) {
+        int v = (int)(((f[i] / (wholeBandwidth / 2.0)) * (double)(rawFFTSize / 2)) + (rawFFTSize / 2));
+        off[i] = v < 0 ? 0 : (v > rawFFTSize ? rawFFTSize : v); /* std::clamp<int>(.., 0, rawFFTSize) */
+    }
+    double avg = 0;
+    float max = -INFINITY;
+    int avgCount = 0;
+    for (int i = off[0]; i < off[1]; i++) { avg += fftLine[i]; avgCount++; }
+    for (int i = off[2] + 1; i < off[3]; i++) { avg += fftLine[i]; avgCount++; }
+    avg /= (double)(avgCount);
+    for (int i = off[1]; i <= off[2]; i++) {
+        if (fftLine[i] > max) { max = fftLine[i]; }
+    }
+    *strength = max;
+    *snr = max - avg;
+    return 1;
+}
 void orc_wf_latest(const orc_wf* w, float* latest, float* hold) {
     if (latest) { memcpy(latest, w->latest, sizeof(float) * (size_t)w->dataWidth); }
     if (hold) { memcpy(hold, w->hold, sizeof(float) * (size_t)w->dataWidth); }

@@ -124,6 +124,7 @@ def load():
     L.sdrpp_wf_set_smoothing.argtypes = [vp, C.c_int, C.c_float]
     L.sdrpp_wf_set_hold.argtypes = [vp, C.c_int, C.c_float]
     L.sdrpp_wf_latest.argtypes = [vp, c_float_p, c_float_p]
+    L.sdrpp_wf_signal_info.argtypes = [vp, C.c_double, C.c_double, C.c_double, c_float_p, c_float_p]
     L.sdrpp_wf_raster.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_int32_p, c_int_p]
     L.sdrpp_preproc_configure.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_float, C.c_int]
     L.sdrpp_preproc_out_count.argtypes = [vp]
@@ -176,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
     "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed",
-    "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster",
+    "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster", "sdrpp_wf_signal_info",
     "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
@@ -380,6 +381,11 @@ class Context:
         b = np.empty(data_width, np.float32)
         self._chk(self.L.sdrpp_wf_latest(self.h, a.ctypes.data_as(c_float_p), b.ctypes.data_as(c_float_p)))
         return a, b
+
+    def wf_signal_info(self, center_offset, bandwidth, whole_bandwidth):
+        a, b = C.c_float(), C.c_float()
+        ok = self._chk(self.L.sdrpp_wf_signal_info(self.h, center_offset, bandwidth, whole_bandwidth, C.byref(a), C.byref(b)))
+        return (a.value, b.value) if ok else None
 
     def wf_raster(self, height, draw_start, draw_size, data_width, wf_min, wf_max):
         fb = np.empty((height, data_width), np.int32)

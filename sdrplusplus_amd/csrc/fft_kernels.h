@@ -453,6 +453,37 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__
     if (hold) { hold[j] = h; }
 }
 
+// calculateVFOSignalInfo (waterfall.cpp:558-598) on one raw line: out[0] = max over [o1, o2], out[1] = max - mean of [o0, o1) and (o2, o3)
+// (double accumulation; a tree instead of the reference's bin order: the double sums agree to ~1e-13 relative, the float snr to 1 ulp).
+__global__ __launch_bounds__(256) void wf_signal_info_kernel(const float* __restrict__ line, int o0, int o1, int o2, int o3, float* __restrict__ out) {
+    __shared__ double ssum[256];
+    __shared__ float smax[256];
+    double acc = 0.0;
+    float m = __uint_as_float(0xff800000u);
+    for (int i = o0 + threadIdx.x; i < o1; i += 256) { acc += (double)line[i]; }
+    for (int i = o2 + 1 + threadIdx.x; i < o3; i += 256) { acc += (double)line[i]; }
+    for (int i = o1 + threadIdx.x; i <= o2; i += 256) {
+        const float v = line[i];
+        if (v > m) { m = v; }
+    }
+    ssum[threadIdx.x] = acc;
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + d];
+            if (smax[threadIdx.x + d] > smax[threadIdx.x]) { smax[threadIdx.x] = smax[threadIdx.x + d]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int cnt = (o1 > o0 ? o1 - o0 : 0) + (o3 > o2 + 1 ? o3 - (o2 + 1) : 0);
+        const double avg = ssum[0] / (double)cnt;
+        out[0] = smax[0];
+        out[1] = (float)((double)smax[0] - avg);
+    }
+}
+
 // ---- sink-side sample packing: f32 -> int16 / int8 on the device, so the D2H copy carries 2 or 1 byte per value ----
 // VOLK generic conversion (volk_32f_s32f_convert_16i / _8i): r = x * scalar, clamp to the integer range, rintf (round half to even), cast.
 template <typename T>

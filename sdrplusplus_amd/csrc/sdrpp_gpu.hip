@@ -2827,6 +2827,33 @@ int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, uns
     return (int)total;
 }
 
+// calculateVFOSignalInfo (waterfall.cpp:558-598) on the newest line of the history ring
+int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, double whole_bandwidth, float* strength, float* snr) {
+    if (!c || !strength || !snr) { return SDRPP_ERR_INVALID; }
+    sdrpp_ctx::Wf& W = c->wf;
+    if (W.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
+    if (W.lines <= 0) { return 0; }  // the reference returns false: nothing to measure yet
+    const int N = c->fft_size;
+    const double f[4] = { center_offset - bandwidth, center_offset - (bandwidth / 2.0), center_offset + (bandwidth / 2.0), center_offset + bandwidth };
+    int off[4];
+    for (int i = 0; i < 4; i++) {
+        const int v = (int)(((f[i] / (whole_bandwidth / 2.0)) * (double)(N / 2)) + (N / 2));
+        off[i] = std::min(std::max(v, 0), N);
+    }
+    if (off[2] >= N) { off[2] = N - 1; }  // the reference reads fftLine[rawFFTSize] here; clamp to the last bin
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
+    int rc = pack_scratch(c, 64);
+    if (rc) { return rc; }
+    hipLaunchKernelGGL(wf_signal_info_kernel, dim3(1), dim3(256), 0, c->stream, (const float*)(W.d_ring + (size_t)W.cur * N), off[0], off[1], off[2], off[3], (float*)c->d_pack);
+    float out[2];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_pack, sizeof(out), hipMemcpyDeviceToHost));
+    *strength = out[0];
+    *snr = out[1];
+    return 1;
+}
+
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }
     auto it = c->vfos.find(id);

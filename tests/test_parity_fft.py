@@ -236,6 +236,7 @@ class _OracleWf:
         o.orc_wf_push.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_float, C.c_float, ip]
         o.orc_wf_latest.argtypes = [C.c_void_p, fp, fp]
         o.orc_wf_raster.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, ip]
+        o.orc_wf_signal_info.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, fp, fp]
         self.h = o.orc_wf_create(height, N, width)
         self.height, self.N, self.width = height, N, width
 
@@ -251,6 +252,12 @@ class _OracleWf:
         a, b = np.empty(self.width, np.float32), np.empty(self.width, np.float32)
         self.o.orc_wf_latest(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)))
         return a, b
+
+    def signal_info(self, centre, bw, whole):
+        C = self.C
+        a, b = C.c_float(), C.c_float()
+        ok = self.o.orc_wf_signal_info(self.h, centre, bw, whole, C.byref(a), C.byref(b))
+        return (a.value, b.value) if ok else None
 
     def raster(self, start, size, wmin, wmax):
         C = self.C
@@ -300,6 +307,13 @@ def test_waterfall_history_trace_and_raster(backend):
             assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32))
             if step > 3:
                 assert np.array_equal(gh.view(np.uint32), oh.view(np.uint32))
+        # SNR meter of a "selected VFO" on the newest line (calculateVFOSignalInfo): max exact, the double-precision mean to 1e-5 dB
+        # (in-band VFOs: one reaching past +sr/2 makes the reference read one bin beyond the line; the device clamps)
+        for centre, bw in ((1.0e6, 200e3), (-3.0e6, 12.5e3), (4.0e6, 400e3)):
+            gi, oi = ctx.wf_signal_info(centre, bw, sr), owf.signal_info(centre, bw, sr)
+            assert (gi is None) == (oi is None)
+            if gi is not None:
+                assert gi[0] == oi[0] and abs(gi[1] - oi[1]) < 1e-5
         # re-raster with the current view and with a zoomed-in one (the GUI's pan / zoom): every stored line, newest first
         for vo, vb in ((1.0e6, 4.0e6), (-2.0e6, 1.0e6)):
             s2, z2 = capi.design_waterfall_view(vo, vb, sr, N)
