@@ -978,10 +978,10 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
                 float b1 = r1b[sl], b2 = r2b[sl];
                 if ((KS & 1) && p == NPS - 1) { b1 = 0.0f; b2 = 0.0f; }  // centre tap of an odd filter: a "pair" with itself
                 const float bre = fmaf(sgn, b1, r1a[sl]);  // lanes 0-31: sr = a.re + b.re   lanes 32-63: di = a.im - b.im
-                const float bim = fmaf(sgn, b2, r2a[sl]);  // lanes 0-31: si = a.im + b.im   lanes 32-63: dr = a.re - b.re
-                const float a_re = ra[sl];                 // (gr, -gi)
+                const float bim = fmaf(sgn, r2a[sl], b2);  // lanes 0-31: si = a.im + b.im   lanes 32-63: -dr = b.re - a.re
+                const float a_re = ra[sl];                 // (gr, -gi): with -dr in the B operand the SAME tap operand serves both products
                 accR = mfma_32x32x2(a_re, bre, accR);
-                accI = mfma_32x32x2(hi ? -a_re : a_re, bim, accI);  // (gr, +gi)
+                accI = mfma_32x32x2(a_re, bim, accI);
                 sched_fence();
             }
         }
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
                 float b1 = P1[ibb], b2 = P2[ibb];
                 if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
                 bre = fmaf(sgn, b1, a1);
-                bim = fmaf(sgn, b2, a2);
+                bim = fmaf(sgn, a2, b2);  // lanes 32-63: -dr, so that the (gr, -gi) tap operand serves the imaginary part too
                 a_re = AL[p * 64 + lane];
             };
             float a_c, br_c, bi_c;
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
                     float a_n, br_n, bi_n;
                     operands(p0 + u + 1 < NP4 ? p0 + u + 1 : NP4 - 1, a_n, br_n, bi_n);
                     accR = mfma_32x32x2(a_c, br_c, accR);
-                    accI = mfma_32x32x2(hi ? -a_c : a_c, bi_c, accI);
+                    accI = mfma_32x32x2(a_c, bi_c, accI);
                     a_c = a_n;
                     br_c = br_n;
                     bi_c = bi_n;
@@ -1122,11 +1122,11 @@ __global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const Front
                     const float a1 = P1[ia], a2 = P2[ia];
                     float b1 = P1[ibb], b2 = P2[ibb];
                     if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
-                    const float bre = fmaf(sgn, b1, a1), bim = fmaf(sgn, b2, a2);
+                    const float bre = fmaf(sgn, b1, a1), bim = fmaf(sgn, a2, b2);  // lanes 32-63: di and -dr
                     const float a_re = aq[u];
                     aq[u] = global_load_f32(job.atab, (p + 4 < NP4 ? p + 4 : p) * 64 + lane);
                     accR = mfma_32x32x2(a_re, bre, accR);
-                    accI = mfma_32x32x2(hi ? -a_re : a_re, bim, accI);
+                    accI = mfma_32x32x2(a_re, bim, accI);
                 }
             }
         }
