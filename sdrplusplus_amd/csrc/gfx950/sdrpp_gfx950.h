@@ -29,6 +29,13 @@ __device__ __forceinline__ float2 global_load_f32x2(const float2* p, long long i
     const f32x2 v = ((const f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i];
     return make_float2(v.x, v.y);
 }
+// four consecutive floats (two complex samples) that are only 8-byte aligned: one global_load_dwordx4 (global memory accesses
+// need dword alignment only)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 global_load_f32x4_unaligned(const float* p, long long i) {
+    const f32x4_a4 v = *((const f32x4_a4 __attribute__((address_space(1)))*)(uintptr_t)(p + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float2 v) {
     f32x2 t;
     t.x = v.x;

@@ -1195,18 +1195,48 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
     const float* Bp = TLs + global_load_i32(job.lbase, lane);
     const float* Ar = XR + c * s_in + kk;
     const float* Ai = XI + c * s_in + kk;
+    // complex streams keep the window INTERLEAVED (re, im) in the same 2 * pl floats: samples arrive two at a time (one dwordx4
+    // load, one ds_write_b128) and one ds_read_b64 feeds both matrix products — every vector instruction saved here is matrix
+    // issue time won back (VALU / LDS-address instructions issued between v_mfma's delay them)
+    constexpr bool ILV = (WIDTH == 2) && !QUAD;
+    float2* X2 = reinterpret_cast<float2*>(XR);
+    const float2* A2 = X2 + c * s_in + kk;
     // window fetch: all loads of a macro tile are in flight together (registers), and the NEXT window is fetched while the matrix
     // cores work on the current one.  A window longer than PF * 64 samples (very long filters) is loaded in place, unpipelined.
     constexpr int PF = 18;
+    constexpr int PF4 = 9;  // interleaved mode: sample PAIRS per lane
     constexpr bool CPLX_IN = (WIDTH == 2) || QUAD;
     const int cnt = QUAD ? span + 1 : span;  // QUAD needs one more sample in front: d[i] uses x[i - 1]
-    const bool piped = cnt <= PF * 64;
-    float2 pf2[CPLX_IN ? PF : 1];
+    const int npair = (cnt + 1) >> 1;
+    const bool piped = ILV ? (npair <= PF4 * 64) : (cnt <= PF * 64);
+    float2 pf2[(CPLX_IN && !ILV) ? PF : 1];
     float pf1[CPLX_IN ? 1 : PF];
+    float4 pf4[ILV ? PF4 : 1];
     auto fetch = [&](int mt) {
         const int lo = job.base0 + mt * G * 16 * s_in - (QUAD ? 1 : 0);
         const bool inside = lo >= 0 && lo + cnt <= job.in.n;  // all but the first and last macro tiles: no history / end tests
-        if constexpr (CPLX_IN) {
+        if constexpr (ILV) {
+            if (inside) {  // (an odd window reads one sample past its end: inside the stream's allocation slack, never used)
+#pragma unroll
+                for (int q = 0; q < PF4; q++) {
+                    const int e = q * 64 + lane;
+                    pf4[q] = (e < npair) ? global_load_f32x4_unaligned(job.in.data, 2ll * (lo + 2 * e)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            else {
+#pragma unroll
+                for (int q = 0; q < PF4; q++) {
+                    const int e = q * 64 + lane;
+                    float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
+                    if (e < npair) {
+                        a = stream_load2(job.in, lo + 2 * e);
+                        b = stream_load2(job.in, lo + 2 * e + 1);
+                    }
+                    pf4[q] = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+        }
+        else if constexpr (CPLX_IN) {
             if (inside) {
                 const float2* src2 = reinterpret_cast<const float2*>(job.in.data) + lo;
 #pragma unroll
@@ -1241,6 +1271,15 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
         }
     };
     auto window_store = [&]() {
+        if constexpr (ILV) {
+            float4* X4 = reinterpret_cast<float4*>(XR);
+#pragma unroll
+            for (int q = 0; q < PF4; q++) {
+                const int e = q * 64 + lane;
+                if (e < npair) { X4[e] = pf4[q]; }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
             const int s = q * 64 + lane;
@@ -1270,11 +1309,7 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                     const float2 x = stream_load2(job.in, lo + s);
                     XI[s] = atan2f(x.y, x.x);
                 }
-                else if constexpr (WIDTH == 2) {
-                    const float2 x = stream_load2(job.in, lo + s);
-                    XR[s] = x.x;
-                    XI[s] = x.y;
-                }
+                else if constexpr (WIDTH == 2) { X2[s] = stream_load2(job.in, lo + s); }
                 else { XR[s] = stream_load1(job.in, lo + s); }
             }
         }
@@ -1299,8 +1334,15 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                     b[u] = Bp[4 * (t0 + u)];
 #pragma unroll
                     for (int g = 0; g < G; g++) {
-                        xr[u][g] = Ar[g * 16 * s_in + 4 * (t0 + u)];
-                        if constexpr (WIDTH == 2) { xi[u][g] = Ai[g * 16 * s_in + 4 * (t0 + u)]; }
+                        if constexpr (ILV) {
+                            const float2 a = A2[g * 16 * s_in + 4 * (t0 + u)];
+                            xr[u][g] = a.x;
+                            xi[u][g] = a.y;
+                        }
+                        else {
+                            xr[u][g] = Ar[g * 16 * s_in + 4 * (t0 + u)];
+                            if constexpr (WIDTH == 2) { xi[u][g] = Ai[g * 16 * s_in + 4 * (t0 + u)]; }
+                        }
                     }
                 }
 #pragma unroll
@@ -1316,8 +1358,15 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                 const float b = Bp[4 * t0];
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    accR[g] = mfma_16x16x4(Ar[g * 16 * s_in + 4 * t0], b, accR[g]);
-                    if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(Ai[g * 16 * s_in + 4 * t0], b, accI[g]); }
+                    if constexpr (ILV) {
+                        const float2 a = A2[g * 16 * s_in + 4 * t0];
+                        accR[g] = mfma_16x16x4(a.x, b, accR[g]);
+                        accI[g] = mfma_16x16x4(a.y, b, accI[g]);
+                    }
+                    else {
+                        accR[g] = mfma_16x16x4(Ar[g * 16 * s_in + 4 * t0], b, accR[g]);
+                        if constexpr (WIDTH == 2) { accI[g] = mfma_16x16x4(Ai[g * 16 * s_in + 4 * t0], b, accI[g]); }
+                    }
                 }
             }
         }

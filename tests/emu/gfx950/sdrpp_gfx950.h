@@ -11,6 +11,7 @@ static inline UniformF32 as_uniform(const void* ptr) { return UniformF32{ (const
 static inline float global_load_f32(const float* p, long long i) { return p[i]; }
 static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
+static inline float4 global_load_f32x4_unaligned(const float* p, long long i) { return make_float4(p[i], p[i + 1], p[i + 2], p[i + 3]); }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
 static inline void sched_fence() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
