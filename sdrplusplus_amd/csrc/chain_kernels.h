@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void vfo_chain_kernel(const ChainJob* __restri
                             else if (st == 2) {
                                 const long long gi = o0 + o;
                                 if (gi >= lo2 && gi < hi2) { global_store_f32x2(if_out, gi, make_float2(aR[r], aI[r])); }
-                                phase[1 + o] = atan2f(aI[r], aR[r]);  // quadrature.h:39-46: discriminator on the IF
+                                phase[1 + o] = fm_phase(aI[r], aR[r]);  // quadrature.h:39-46: discriminator on the IF
                             }
                             else {
                                 const long long gi = o0 + o;

@@ -43,6 +43,9 @@ __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float
     ((f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i] = t;
 }
 
+// 1 / x to 1 ulp (v_rcp_f32); x must be a normal number
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Scheduling fence: the instruction scheduler does not move anything across it.  Used to keep LDS reads issued two steps ahead
 // of the matrix instructions that consume them (left alone, the scheduler sinks them next to their use and the wave then
 // waits out the full LDS latency in front of every v_mfma).

@@ -293,6 +293,29 @@ __global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict
 // FM discriminator (quadrature.h:39-46): out[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation — fused into the loads
 // of the audio low-pass kernels (QUAD); this is its phase wrap.
 // =====================================================================================================================
+// atan2f for the discriminator: |error| < 3e-7 rad (libm's is ~1 ulp = 2.4e-7 at pi) in ~23 vector instructions instead of the
+// ~53 of the library routine — the phase of every IF sample is taken on the way into the audio low-pass, which made this the
+// largest single cost of that kernel.  Octant reduction to z = min/max in [0, 1], odd polynomial z * P(z^2) of degree 17
+// (least-squares fit on Chebyshev nodes, weighted by z; max error 8.9e-8 in float arithmetic), then the usual reflections.
+__device__ __forceinline__ float fm_phase(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.17549435e-38f), mn = fminf(ax, ay);  // (0, 0) -> z = 0 -> phase 0 like atan2f
+    const float z = mn * fast_rcp(mx);
+    const float w = z * z;
+    float p = 0.0023981390986591578f;
+    p = fmaf(p, w, -0.014152348041534424f);
+    p = fmaf(p, w, 0.03934541344642639f);
+    p = fmaf(p, w, -0.07194384187459946f);
+    p = fmaf(p, w, 0.10477539151906967f);
+    p = fmaf(p, w, -0.1415480673313141f);
+    p = fmaf(p, w, 0.19984884560108185f);
+    p = fmaf(p, w, -0.33332523703575134f);
+    p = fmaf(p, w, 0.9999998807907104f);
+    float r = z * p;
+    r = (ay > ax) ? 1.57079632679489662f - r : r;
+    r = (x < 0.0f) ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+}
 __device__ __forceinline__ float normalize_phase(float d) {
     const float FL_PI = 3.1415926535f;  // math/constants.h:4, math/normalize_phase.h:6-9
     if (d > FL_PI) { d -= 2.0f * FL_PI; }
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict
         float* phase = smem + ncomp;  // phase[i] = atan2f(x[base - 1 + i]), i = 0 .. nvalid
         for (int s = threadIdx.x; s <= nvalid; s += nthreads) {
             const float2 x = stream_load2(job.in, base - 1 + s);
-            phase[s] = atan2f(x.y, x.x);
+            phase[s] = fm_phase(x.y, x.x);
         }
         __syncthreads();
         for (int s = threadIdx.x; s < ncomp; s += nthreads) {
@@ -1284,7 +1307,7 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
         for (int q = 0; q < PF; q++) {
             const int s = q * 64 + lane;
             if (s < cnt) {
-                if constexpr (QUAD) { XI[s] = atan2f(pf2[q].y, pf2[q].x); }
+                if constexpr (QUAD) { XI[s] = fm_phase(pf2[q].y, pf2[q].x); }
                 else if constexpr (WIDTH == 2) {
                     XR[s] = pf2[q].x;
                     XI[s] = pf2[q].y;
@@ -1307,7 +1330,7 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
             for (int s = lane; s < cnt; s += 64) {
                 if constexpr (QUAD) {
                     const float2 x = stream_load2(job.in, lo + s);
-                    XI[s] = atan2f(x.y, x.x);
+                    XI[s] = fm_phase(x.y, x.x);
                 }
                 else if constexpr (WIDTH == 2) { X2[s] = stream_load2(job.in, lo + s); }
                 else { XR[s] = stream_load1(job.in, lo + s); }
