@@ -375,36 +375,39 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
 
 // ---- doZoom max-decimation + palette index (waterfall.cpp:65-90, 899-905) -------------------------------------------------------------
 // The float32 running index of doZoom is evaluated on the host once per view change (sdrpp_host::zoomTable: first bin and bin
-// count of every pixel).  A block owns ZPX = 64 consecutive pixels of one line, four work-items per pixel: each scans a quarter
-// of the pixel's bin range with the reference's comparison (`if (in > max) max = in`, -inf start, so a NaN never wins), then the
-// four partial maxima meet in LDS.  max is order independent: the result is bit-identical to the sequential scan.
-#define SDRPP_ZPX 64
+// count of every pixel).  TP consecutive work-items share a pixel and walk its bin range with stride TP, so the lanes of a wavefront
+// read consecutive bins (the host picks TP = 16 / 4 / 1 from the bins-per-pixel of the view); each keeps the reference's comparison
+// (`if (in > max) max = in`, -inf start, so a NaN never wins) and the partial maxima meet in LDS.  max is order independent: the
+// result is bit-identical to the sequential scan.
+template <int TP>
 __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
                                                           const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
                                                           float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index) {
-    __shared__ float part[SDRPP_ZPX * 4];
+    constexpr int PPB = 256 / TP;  // pixels per block
+    __shared__ float part[PPB * (TP + 1)];
     const int line = blockIdx.y;
-    const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const int px = blockIdx.x * SDRPP_ZPX + p;
+    const int p = threadIdx.x / TP, q = threadIdx.x % TP;
+    const int px = blockIdx.x * PPB + p;
     const float* in = lines + (size_t)line * fft_size;
     float m = __uint_as_float(0xff800000u);  // -inf
     if (px < data_width) {
-        const int s = zstart[px], n = zcount[px];
-        const int chunk = (n + 3) >> 2;
-        const int b0 = s + q * chunk;
-        const int b1 = min(s + n, b0 + chunk);
-        for (int b = b0; b < b1; b++) {
+        const int s = zstart[px], e = s + zcount[px];
+        for (int b = s + q; b < e; b += TP) {
             const float v = in[b];
             if (v > m) { m = v; }
         }
     }
-    part[threadIdx.x] = m;
-    __syncthreads();
+    if constexpr (TP > 1) {
+        part[p * (TP + 1) + q] = m;
+        __syncthreads();
+    }
     if (q == 0 && px < data_width) {
+        if constexpr (TP > 1) {
 #pragma unroll
-        for (int i = 1; i < 4; i++) {
-            const float v = part[threadIdx.x + i];
-            if (v > m) { m = v; }
+            for (int i = 1; i < TP; i++) {
+                const float v = part[p * (TP + 1) + i];
+                if (v > m) { m = v; }
+            }
         }
         zoomed[(size_t)line * data_width + px] = m;
         const float range = wf_max - wf_min;
