@@ -1200,7 +1200,7 @@ struct ToepJob {
 template <int WIDTH, int G, bool QUAD>
 __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemt)
-    const ToepJob& job = jobs[blockIdx.y];
+    const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nsteps = job.nsteps, s_in = job.s_in, rows = job.rows;
     const int span = (G * 16 - 1) * s_in + 4 * nsteps;  // window of one macro tile
@@ -1213,7 +1213,9 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
     for (int i = tid; i < job.tl_len; i += 256) { TLs[i] = global_load_f32(job.tl, i); }
     __syncthreads();  // the only workgroup barrier
     const int omt = G * 16 * rows;  // outputs per macro tile
-    const int mt0 = (blockIdx.x * 4 + wv) * job.mt_per_wave;
+    // macro tiles are dealt out CYCLICALLY: round `it` of wavefront w works on tile w + it * (wavefronts of this job), so at any
+    // moment the wavefronts of a job stream through one contiguous region of its input and output
+    const int mt0 = blockIdx.x * 4 + wv, mts = gridDim.x * 4;
     const int c = lane & 15, kk = lane >> 4;
     const float* Bp = TLs + global_load_i32(job.lbase, lane);
     const float* Ar = XR + c * s_in + kk;
@@ -1316,16 +1318,27 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
             }
         }
     };
-    if (piped && mt0 * omt < job.nout) { fetch(mt0); }
+    // quadrature.h:39-46 fused into the load: d[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation
+    auto discriminate = [&]() {
+        if constexpr (QUAD) {
+            wave_sync();
+            for (int s = lane; s < span; s += 64) { XR[s] = normalize_phase(XI[s + 1] - XI[s]) * job.inv_deviation; }
+        }
+    };
+    // Order of one round of the pipelined path: matrix work on window t | window t+1 from registers to LDS | loads of window t+2 |
+    // stores of the outputs of t.  The only wait for global memory (in front of the LDS writes) then covers loads and stores that
+    // were issued one whole round earlier, never the stores just issued.
+    if (piped && mt0 * omt < job.nout) {
+        fetch(mt0);
+        window_store();
+        if (1 < job.mt_per_wave && (mt0 + mts) * omt < job.nout) { fetch(mt0 + mts); }
+        discriminate();
+    }
     for (int it = 0; it < job.mt_per_wave; it++) {
-        const int mt = mt0 + it;
+        const int mt = mt0 + it * mts;
         const int obase = mt * omt;
         if (obase >= job.nout) { break; }
-        if (piped) {
-            window_store();
-            if (it + 1 < job.mt_per_wave && (mt + 1) * omt < job.nout) { fetch(mt + 1); }
-        }
-        else {
+        if (!piped) {
             const int lo = job.base0 + mt * G * 16 * s_in - (QUAD ? 1 : 0);
             for (int s = lane; s < cnt; s += 64) {
                 if constexpr (QUAD) {
@@ -1335,11 +1348,7 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                 else if constexpr (WIDTH == 2) { X2[s] = stream_load2(job.in, lo + s); }
                 else { XR[s] = stream_load1(job.in, lo + s); }
             }
-        }
-        if constexpr (QUAD) {
-            // quadrature.h:39-46 fused into the load: d[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation
-            wave_sync();
-            for (int s = lane; s < span; s += 64) { XR[s] = normalize_phase(XI[s + 1] - XI[s]) * job.inv_deviation; }
+            discriminate();
         }
         wave_sync();
         f32x4 accR[G], accI[G];
@@ -1393,6 +1402,13 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                 }
             }
         }
+        if (piped && it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout) {
+            wave_sync();  // every lane has read its operands of this window
+            window_store();
+            if (it + 2 < job.mt_per_wave && (mt + 2 * mts) * omt < job.nout) { fetch(mt + 2 * mts); }
+            discriminate();
+            sched_fence();
+        }
         // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r
         if (c < rows) {
 #pragma unroll
@@ -1407,7 +1423,7 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                 }
             }
         }
-        wave_sync();  // the next macro tile overwrites the window
+        if (!piped) { wave_sync(); }  // the next macro tile overwrites the window
     }
 }
 
