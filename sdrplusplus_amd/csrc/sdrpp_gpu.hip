@@ -956,10 +956,12 @@ ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
     if (jobs.empty()) { return P; }
     const int G = 2;
     int mtw = 1;
-    for (; mtw < 16; mtw++) {  // one resident round: <= 256 CUs x 4 blocks of four wavefronts (each job padded to whole blocks)
+    // about two resident rounds (256 CUs x 4 blocks of four wavefronts, each job padded to whole blocks): alone the kernels do not
+    // care (1 024 ... 8 192 blocks measured equal), but blocks that end let the FFT branch's blocks in — 2.5 % on the whole step
+    for (; mtw < 16; mtw++) {
         size_t blocks = 0;
         for (auto& jb : jobs) { blocks += (size_t)((jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows) + 4 * mtw - 1) / (size_t)(4 * mtw); }
-        if (blocks <= 1024) { break; }
+        if (blocks <= 2048) { break; }
     }
     for (auto& jb : jobs) {
         jb.mt_per_wave = mtw;
