@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict
 // FM discriminator (quadrature.h:39-46): out[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation — fused into the loads
 // of the audio low-pass kernels (QUAD); this is its phase wrap.
 // =====================================================================================================================
-// atan2f for the discriminator: |error| < 3e-7 rad (libm's is ~1 ulp = 2.4e-7 at pi) in ~23 vector instructions instead of the
+// atan2f for the discriminator: |error| <= 3e-7 rad against double precision (tests/host_cpp/test_device_math.cpp; libm's is ~1 ulp = 2.4e-7 at pi) in ~23 vector instructions instead of the
 // ~53 of the library routine — the phase of every IF sample is taken on the way into the audio low-pass, which made this the
 // largest single cost of that kernel.  Octant reduction to z = min/max in [0, 1], odd polynomial z * P(z^2) of degree 17
 // (least-squares fit on Chebyshev nodes, weighted by z; max error 8.9e-8 in float arithmetic), then the usual reflections.

@@ -25,6 +25,18 @@ def test_host_mirror_compiles_standalone():
         assert os.path.exists(_build(tmp))
 
 
+def test_device_math_helpers():
+    """fm_phase (the discriminator's polynomial atan2) against double-precision atan2 over 2.5 M points, normalize_phase's range:
+    the kernel header compiled for the host against the emulator's headers (tests/host_cpp/test_device_math.cpp)."""
+    emu = os.path.join(ROOT, "tests", "emu")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_device_math")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-I" + emu, "-I" + os.path.join(emu, "gfx950"), "-I" + CSRC, "-o", exe,
+                        os.path.join(ROOT, "tests", "host_cpp", "test_device_math.cpp"), "-lm"], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/core/src/dsp"), reason="needs the reference tree")
 def test_host_mirror_compiles_inside_sdrpp_tree():
     """-DSDRPP_GPU_USE_SDRPP_DSP: the blocks derive from the reference's own dsp::block and use its dsp::stream<T> and plans.h."""
