@@ -88,6 +88,8 @@ struct Vfo {
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
+    // two-stage launches (vfo_toep2_kernel, SDRPP_GPU_FUSE): last decimator -> resampler; channel filter -> discriminator -> audio low-pass
+    bool fuse_dp = false, fuse_ca = false;
     // fused back end (vfo_chain_kernel): last decimator -> resampler -> channel filter -> discriminator + audio low-pass
     struct Chain {
         bool ok = false;
@@ -981,6 +983,82 @@ void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, cons
     else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
 }
 
+// ---- two filters per launch (vfo_toep2_kernel; opt-in: SDRPP_GPU_FUSE=1 pairs last decimator + resampler, =2 channel filter +
+// discriminator/audio low-pass, =3 both) ----
+// A pair can be fused when stage B consumes 480 stage-A outputs per macro tile (s_in 15), its window overlap fits the kernel's
+// carry registers and the block's LDS fits; the input stream of stage A then has to remember what the pre-roll of a wavefront
+// reaches back to.
+bool toep2_fits(int mode, const ToepTab& A, const ToepTab& B, int* lookback_outputs) {
+    if (!A.ok || !B.ok || A.rows != 15 || B.s_in != 15) { return false; }
+    const int spanB = 31 * B.s_in + 4 * B.nsteps, carry = std::max(0, spanB - 32 * B.s_in), need = carry + (mode == 1 ? 1 : 0);
+    if (need > 512) { return false; }
+    const size_t lds = ((size_t)((A.tl_len + 3) & ~3) + (size_t)((B.tl_len + 3) & ~3) + (size_t)4 * sdrpp_k::toep2_wave_floats(mode, A.s_in, A.nsteps, B.s_in, B.nsteps)) * sizeof(float);
+    if (lds > (size_t)kMaxLds) { return false; }
+    *lookback_outputs = 240 * ((need + 239) / 240) - carry;  // stage-A outputs in front of stage B's first window offset
+    return true;
+}
+int fuse_build(sdrpp_ctx* c, Vfo& v) {
+    static const int fuse = getenv("SDRPP_GPU_FUSE") ? atoi(getenv("SDRPP_GPU_FUSE")) : 0;
+    v.fuse_dp = v.fuse_ca = false;
+    if (!fuse || v.chain.ok) { return SDRPP_OK; }
+    int back = 0;
+    const int sl = v.d.n_stages - 1;
+    if ((fuse & 1) && sl >= 1 && v.i_poly >= 0 && toep2_fits(0, v.tp_stage[sl], v.tp_poly, &back)) {
+        const int dA = v.d.stage_decim[sl];
+        int rc = stream_grow_hist(c, v.st[(size_t)v.i_first + sl - 1], (v.d.stage_ntaps[sl] - 1) + dA * ((v.tpp - 1) + back + 2) + 4);
+        if (rc) { return rc; }
+        v.fuse_dp = true;
+    }
+    const bool fm = v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM;
+    if ((fuse & 2) && fm && v.i_chan >= 0 && v.chan_ntaps > 0 && toep2_fits(1, v.tp_chan, v.tp_audio, &back)) {
+        const int idx = (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1;
+        int rc = stream_grow_hist(c, v.st[(size_t)idx], (v.chan_ntaps - 1) + (v.audio_ntaps - 1) + back + 4);
+        if (rc) { return rc; }
+        v.fuse_ca = true;
+    }
+    return SDRPP_OK;
+}
+sdrpp_k::Toep2Job toep2_job(const ToepTab& A, const ToepTab& B, int varB, StreamIn in, float* out, int base0A, int base0B, int nout, float inv_dev) {
+    sdrpp_k::Toep2Job j{};
+    j.in = in;
+    j.out = out;
+    j.tlA = A.d_tl;
+    j.lbaseA = A.d_lb;
+    j.tl_lenA = A.tl_len;
+    j.nstepsA = A.nsteps;
+    j.s_inA = A.s_in;
+    j.tlB = B.d_tl;
+    j.lbaseB = B.d_lb + (size_t)varB * 64;
+    j.tl_lenB = B.tl_len;
+    j.nstepsB = B.nsteps;
+    j.s_inB = B.s_in;
+    j.rowsB = B.rows;
+    j.base0A = base0A;
+    j.base0B = base0B;
+    j.nout = nout;
+    j.mt_per_wave = 4;
+    j.inv_deviation = inv_dev;
+    return j;
+}
+// Wavefronts walk CONSECUTIVE macro tiles (at least four each, so that the pre-roll chain stays below 10 % of their work).
+ToepPlan toep2_plan(std::vector<sdrpp_k::Toep2Job>& jobs, int mode) {
+    ToepPlan P;
+    if (jobs.empty()) { return P; }
+    int mtw = 4;
+    for (; mtw < 64; mtw++) {
+        size_t blocks = 0;
+        for (auto& jb : jobs) { blocks += (size_t)((jb.nout + 32 * jb.rowsB - 1) / (32 * jb.rowsB) + 4 * mtw - 1) / (size_t)(4 * mtw); }
+        if (blocks <= 2048) { break; }
+    }
+    for (auto& jb : jobs) {
+        jb.mt_per_wave = mtw;
+        const int nmt = (jb.nout + 32 * jb.rowsB - 1) / (32 * jb.rowsB);
+        P.grid_x = std::max(P.grid_x, (nmt + 4 * mtw - 1) / (4 * mtw));
+        P.lds = std::max(P.lds, ((size_t)((jb.tl_lenA + 3) & ~3) + (size_t)((jb.tl_lenB + 3) & ~3) + (size_t)4 * sdrpp_k::toep2_wave_floats(mode, jb.s_inA, jb.nstepsA, jb.s_inB, jb.nstepsB)) * sizeof(float));
+    }
+    return P;
+}
+
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
     const int n_in = (int)count;
@@ -997,6 +1075,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
     std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
     std::vector<ChainJob> chainj;  // fused back end (vfo_chain_kernel)
+    std::vector<sdrpp_k::Toep2Job> t2_dp, t2_ca;  // two filters per launch (vfo_toep2_kernel)
+    std::vector<Stream*> ghost;                    // streams that such a launch keeps on the CU: nothing to carry
     // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
     std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
     std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
@@ -1009,6 +1089,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         Stream* cur = &v.st[(size_t)v.i_first];
         // fused back end: the four per-stage launches below become one ChainJob (same integer state, same streams)
         bool use_chain = false;
+        bool f2_pending = false, f1_pending = false;
+        StreamIn f2_in{}, f1_in{};
+        int f2_base0A = 0;
         ChainJob cj{};
         int cj_poly_base0 = 0;
         if (v.d.n_stages == 0) {
@@ -1055,6 +1138,12 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                     cj.in0_base = (long long)v.soff[s] - (v.d.stage_ntaps[s] - 1);
                     cj.d0 = Ds;
                 }
+                else if (v.fuse_dp && s == v.d.n_stages - 1 && v.tp_stage[s].ok && v.tp_poly.ok) {
+                    f2_in = stream_in(*cur);
+                    f2_base0A = v.soff[s] - (v.d.stage_ntaps[s] - 1);
+                    f2_pending = true;
+                    ghost.push_back(nxt);
+                }
                 else if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
                 else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
                 v.soff[s] = v.soff[s] + no * Ds - cur->n;
@@ -1068,6 +1157,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (use_chain) {
                 cj_poly_base0 = v.poff - (v.tpp - 1);
                 cj.lb = v.chain.d_lb + (size_t)v.pphase * 4 * 64;
+            }
+            else if (f2_pending) {
+                t2_dp.push_back(toep2_job(v.tp_stage[v.d.n_stages - 1], v.tp_poly, v.pphase, f2_in, nxt->data, f2_base0A, v.poff - (v.tpp - 1), no, 0.0f));
             }
             else if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
             else if (v.d_cyc) {
@@ -1086,6 +1178,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
             if (use_chain) { cj.if_out = nxt->data; }
+            else if (v.fuse_ca && v.tp_chan.ok && v.tp_audio.ok) {
+                f1_in = stream_in(*cur);
+                f1_pending = true;
+                ghost.push_back(nxt);
+            }
             else if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
             else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
@@ -1123,6 +1220,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 cj.warm = ch.warm;
                 cj.inv_deviation = v.d.inv_deviation;
                 if (cj.nslabs > 0) { chainj.push_back(cj); }
+            }
+            else if (f1_pending) {
+                t2_ca.push_back(toep2_job(v.tp_chan, v.tp_audio, 0, f1_in, out.data, -(v.chan_ntaps - 1), -(v.audio_ntaps - 1), nif, v.d.inv_deviation));
             }
             else if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
             else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
@@ -1192,6 +1292,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         double p = v.phi + (double)n_in * v.theta;
         v.phi = p - std::floor(p);
         v.seen += n_in;
+        for (Stream* g : ghost) { g->n = 0; }  // never materialised
+        ghost.clear();
         // history carries for every stream that has a consumer with memory
         for (auto& s : v.st) {
             if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len }); }
@@ -1467,6 +1569,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
     const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
+    const ToepPlan tp2_dp = toep2_plan(t2_dp, 0), tp2_ca = toep2_plan(t2_ca, 1);
+    sdrpp_k::Toep2Job* d_t2_dp = arena_push(c, t2_dp);
+    sdrpp_k::Toep2Job* d_t2_ca = arena_push(c, t2_ca);
+    if ((!t2_dp.empty() && !d_t2_dp) || (!t2_ca.empty() && !d_t2_ca)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepJob* d_t_poly = arena_push(c, t_poly);
     ToepJob* d_t_chan = arena_push(c, t_chan);
     ToepJob* d_t_audio = arena_push(c, t_audio);
@@ -1676,6 +1782,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         FamilyTimer t(c, F_POLY);
         launch_toep(c, t_poly, d_t_poly, tp_poly, 2, false);
     }
+    if (!t2_dp.empty()) {  // last decimator + resampler in one launch
+        FamilyTimer t(c, F_POLY);
+        launch(c, vfo_toep2_kernel<0>, dim3((unsigned)tp2_dp.grid_x, (unsigned)t2_dp.size()), dim3(256), tp2_dp.lds, (const sdrpp_k::Toep2Job*)d_t2_dp);
+    }
     if (!poly.empty()) {
         FamilyTimer t(c, F_POLY);
         rc = launch_polyc(poly, d_poly);
@@ -1726,6 +1836,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (rc) { return rc; }
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
         if (rc) { return rc; }
+    }
+    if (!t2_ca.empty()) {  // channel filter + discriminator + audio low-pass in one launch
+        FamilyTimer t(c, F_FIR);
+        launch(c, vfo_toep2_kernel<1>, dim3((unsigned)tp2_ca.grid_x, (unsigned)t2_ca.size()), dim3(256), tp2_ca.lds, (const sdrpp_k::Toep2Job*)d_t2_ca);
     }
     bool any_af = !af_deemp.empty() || !af_poly.empty() || !t_af_poly.empty() || !af_hpf.empty() || !t_af_hpf.empty();
     for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { any_af = any_af || !af_lvl[s].empty() || !t_af_lvl[s].empty(); }
@@ -2554,6 +2668,8 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     v->modtaps_dirty = true;
     rc = chain_build(c, *v);
     if (rc) { return rc; }
+    rc = fuse_build(c, *v);
+    if (rc) { return rc; }
     rc = vfo_reset_state(c, *v);
     if (rc) { return rc; }
     *id = v->id;
@@ -2606,7 +2722,9 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
         rc = toep_build_fir(c, v.tp_chan, v.ctaps_chan.data(), n, 1);
         if (rc) { return rc; }
     }
-    return chain_build(c, v);  // the fused back end follows the new filter (or steps aside when it is switched off)
+    int rc2 = chain_build(c, v);  // the fused back end follows the new filter (or steps aside when it is switched off)
+    if (rc2) { return rc2; }
+    return fuse_build(c, v);
 }
 
 static void af_detach(Vfo& v) {

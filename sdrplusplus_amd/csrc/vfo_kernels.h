@@ -1428,6 +1428,279 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
 }
 
 // =====================================================================================================================
+// Two consecutive per-VFO filters in ONE launch, the stream between them never leaving the CU (SDRPP_GPU_FUSE, opt-in):
+//   MODE 0   decimating FIR (stage A)  ->  FIR / polyphase resampler (stage B)           e.g. last decimator -> resampler
+//   MODE 1   FIR (stage A) -> FM discriminator -> real FIR (stage B), mono -> stereo     channel filter -> demodulator -> audio low-pass
+// Both stages are the banded-Toeplitz products of vfo_toep_kernel with the same tables, so every output is the same k-ordered fmaf
+// chain (zero taps add exact zeros): results are bit-identical to the two separate launches.  A wavefront walks CONSECUTIVE macro
+// tiles of stage B; each needs 32 * s_inB = 480 new stage-A outputs — exactly two matrix chains — which it computes from the input
+// window (prefetched a round ahead as in vfo_toep_kernel) straight into the stage-B window in LDS; the `carry` outputs that window
+// shares with the previous macro tile are moved to its front, and only the first macro tile of a wavefront recomputes them
+// (one or two extra chains per wavefront and launch).  What it saves is the HBM round trip of the intermediate stream and one
+// launch; the algorithmic work is unchanged.
+// =====================================================================================================================
+struct Toep2Job {
+    StreamIn in;            // input stream of stage A (complex)
+    float* out;             // output of stage B
+    const float* tlA;       // stage A: tap table / lane bases / geometry as in ToepJob (rows = 15, s_inA = 15 * decimation)
+    const int* lbaseA;
+    int tl_lenA, nstepsA, s_inA;
+    const float* tlB;       // stage B
+    const int* lbaseB;
+    int tl_lenB, nstepsB, s_inB, rowsB;
+    int base0A;             // stage-A INPUT index of window offset 0 of stage-A output 0 of this push
+    int base0B;             // stage-A OUTPUT index of window offset 0 of stage-B tile 0 (MODE 1: index of the discriminator output)
+    int nout;               // stage-B outputs of this push
+    int mt_per_wave;
+    float inv_deviation;    // MODE 1
+};
+
+// G (<= 2) chains of 16 tiles: acc[g] += window(tile, k) * taps(k, m).  CPLX: interleaved complex window (one ds_read_b64 feeds both products)
+template <bool CPLX>
+__device__ __forceinline__ void toep_chains(const float* Bp, const float* Aw, int s_in, int nsteps, int nch, f32x4 (&accR)[2], f32x4 (&accI)[2]) {
+    const float2* A2 = reinterpret_cast<const float2*>(Aw);
+    constexpr int U = CPLX ? 4 : 8;
+    int t0 = 0;
+    for (; t0 + U <= nsteps; t0 += U) {
+        float b[U], xr[U][2], xi[U][2];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            b[u] = Bp[4 * (t0 + u)];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                if (g < nch) {
+                    if constexpr (CPLX) {
+                        const float2 a = A2[g * 16 * s_in + 4 * (t0 + u)];
+                        xr[u][g] = a.x;
+                        xi[u][g] = a.y;
+                    }
+                    else { xr[u][g] = Aw[g * 16 * s_in + 4 * (t0 + u)]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                if (g < nch) {
+                    accR[g] = mfma_16x16x4(xr[u][g], b[u], accR[g]);
+                    if constexpr (CPLX) { accI[g] = mfma_16x16x4(xi[u][g], b[u], accI[g]); }
+                }
+            }
+        }
+    }
+    for (; t0 < nsteps; t0++) {
+        const float b = Bp[4 * t0];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if (g < nch) {
+                if constexpr (CPLX) {
+                    const float2 a = A2[g * 16 * s_in + 4 * t0];
+                    accR[g] = mfma_16x16x4(a.x, b, accR[g]);
+                    accI[g] = mfma_16x16x4(a.y, b, accI[g]);
+                }
+                else { accR[g] = mfma_16x16x4(Aw[g * 16 * s_in + 4 * t0], b, accR[g]); }
+            }
+        }
+    }
+}
+
+// LDS floats of one wavefront: stage-A input window (interleaved complex) + stage-B window (MODE 0: interleaved complex;
+// MODE 1: phases + discriminator output).  Shared by the kernel and the host's launch planning.
+__host__ __device__ inline int toep2_wave_floats(int mode, int s_inA, int nstepsA, int s_inB, int nstepsB) {
+    const int spanA = 31 * s_inA + 4 * nstepsA, spanB = 31 * s_inB + 4 * nstepsB;
+    const int carry = spanB > 32 * s_inB ? spanB - 32 * s_inB : 0;
+    const int plA = (spanA + 8) & ~3, plB = (carry + 32 * s_inB + 12) & ~3;
+    return 2 * plA + 2 * plB;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void vfo_toep2_kernel(const Toep2Job* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemt2)
+    const Toep2Job job = jobs[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nA = job.nstepsA, sA = job.s_inA, nB = job.nstepsB, sB = job.s_inB, rowsB = job.rowsB;
+    const int dA = sA / 15;                      // decimation of stage A
+    const int newB = 32 * sB;                    // stage-A outputs one macro tile of stage B consumes (= 480: two chains; the host checks)
+    const int spanA = 31 * sA + 4 * nA;          // input window of two stage-A chains
+    const int spanA1 = 15 * sA + 4 * nA;         // ... of one chain (pre-roll)
+    const int spanB = 31 * sB + 4 * nB;          // stage-B window
+    const int carry = spanB > newB ? spanB - newB : 0;
+    const int plA = (spanA + 8) & ~3, plB = (carry + newB + 12) & ~3;
+    const int tlA_pad = (job.tl_lenA + 3) & ~3, tlB_pad = (job.tl_lenB + 3) & ~3;
+    float* TLA = smemt2;
+    float* TLB = smemt2 + tlA_pad;
+    float* XA = smemt2 + tlA_pad + tlB_pad + wv * (2 * plA + 2 * plB);  // stage-A input window, interleaved (re, im)
+    float* WB = XA + 2 * plA;                                        // MODE 0: stage-B window, interleaved; MODE 1: phases PH
+    float* XR = WB + plB;                                            // MODE 1: discriminator output (stage-B window)
+    for (int i = tid; i < job.tl_lenA; i += 256) { TLA[i] = global_load_f32(job.tlA, i); }
+    for (int i = tid; i < job.tl_lenB; i += 256) { TLB[i] = global_load_f32(job.tlB, i); }
+    __syncthreads();  // the only workgroup barrier
+    const int c = lane & 15, kk = lane >> 4;
+    const float* BpA = TLA + global_load_i32(job.lbaseA, lane);
+    const float* BpB = TLB + global_load_i32(job.lbaseB, lane);
+    float2* XA2 = reinterpret_cast<float2*>(XA);
+    float2* WB2 = reinterpret_cast<float2*>(WB);
+    const float* AwA = XA + 2 * (c * sA + kk);
+    const float* AwB = (MODE == 0) ? WB + 2 * (c * sB + kk) : XR + (c * sB + kk);
+    const int omt = 32 * rowsB;                                       // stage-B outputs per macro tile
+    const int nmt = (job.nout + omt - 1) / omt;
+    const int mt_first = (blockIdx.x * 4 + wv) * job.mt_per_wave;
+    if (mt_first >= nmt) { return; }
+    const int mt_end = min(nmt, mt_first + job.mt_per_wave);
+    constexpr int EXTRA = (MODE == 1) ? 1 : 0;                        // MODE 1 keeps one more phase in front: d[i] uses x[i - 1]
+    // stage-A output index (IF sample index in MODE 1) of the first NEW sample of macro tile mt, and where it lands in the window
+    auto new0 = [&](int mt) { return job.base0B - EXTRA + mt * newB + carry + EXTRA; };
+    // store two (or one) chains of stage-A results: lane holds outputs (g * 16 + 4 * kk + r) * 15 + c of the chain group
+    auto put = [&](const f32x4 (&aR)[2], const f32x4 (&aI)[2], int nch, int w0) {
+        if (c < 15) {
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                if (g < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int w = w0 + (g * 16 + 4 * kk + r) * 15 + c;
+                        if (w >= 0) {
+                            if constexpr (MODE == 0) { WB2[w] = make_float2(aR[g][r], aI[g][r]); }
+                            else { WB[w] = fm_phase(aI[g][r], aR[g][r]); }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // ---- pre-roll: the `carry` (+1) stage-A outputs in front of the first macro tile, one chain of 240 at a time ----
+    {
+        const int need = carry + EXTRA;
+        const int npre = (need + 239) / 240;
+        for (int q = 0; q < npre; q++) {
+            const int a0 = new0(mt_first) - 240 * (npre - q);         // first stage-A output of this chain
+            const int lo = job.base0A + dA * a0;
+            wave_sync();
+            for (int s = lane; s < spanA1; s += 64) { XA2[s] = stream_load2(job.in, lo + s); }
+            wave_sync();
+            f32x4 aR[2] = { mfma4_zero(), mfma4_zero() }, aI[2] = { mfma4_zero(), mfma4_zero() };
+            toep_chains<true>(BpA, AwA, sA, nA, 1, aR, aI);
+            put(aR, aI, 1, need - 240 * (npre - q));
+        }
+    }
+    // ---- steady state: input windows prefetched into registers a round ahead ----
+    constexpr int PF4 = 9;  // sample pairs per lane: windows up to 1152 samples are pipelined, longer ones are loaded in place
+    const int npair = (spanA + 1) >> 1;
+    const bool piped = npair <= PF4 * 64;
+    float4 pf4[PF4];
+    auto fetch = [&](int mt) {
+        const int lo = job.base0A + dA * new0(mt);
+        const bool inside = lo >= 0 && lo + spanA + 1 <= job.in.n;
+        if (inside) {
+#pragma unroll
+            for (int q = 0; q < PF4; q++) {
+                const int e = q * 64 + lane;
+                pf4[q] = (e < npair) ? global_load_f32x4_unaligned(job.in.data, 2ll * (lo + 2 * e)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < PF4; q++) {
+                const int e = q * 64 + lane;
+                float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
+                if (e < npair) {
+                    a = stream_load2(job.in, lo + 2 * e);
+                    b = stream_load2(job.in, lo + 2 * e + 1);
+                }
+                pf4[q] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+    };
+    auto window_store = [&]() {
+        float4* X4 = reinterpret_cast<float4*>(XA);
+#pragma unroll
+        for (int q = 0; q < PF4; q++) {
+            const int e = q * 64 + lane;
+            if (e < npair) { X4[e] = pf4[q]; }
+        }
+    };
+    if (piped) {
+        fetch(mt_first);
+        wave_sync();
+        window_store();
+        if (mt_first + 1 < mt_end) { fetch(mt_first + 1); }
+    }
+    for (int mt = mt_first; mt < mt_end; mt++) {
+        if (!piped) {
+            const int lo = job.base0A + dA * new0(mt);
+            wave_sync();
+            for (int s = lane; s < spanA; s += 64) { XA2[s] = stream_load2(job.in, lo + s); }
+        }
+        wave_sync();
+        // stage A: 480 new outputs
+        f32x4 aR[2] = { mfma4_zero(), mfma4_zero() }, aI[2] = { mfma4_zero(), mfma4_zero() };
+        toep_chains<true>(BpA, AwA, sA, nA, 2, aR, aI);
+        // the part of the stage-B window shared with the previous macro tile moves to the front (read all, then write)
+        if (mt > mt_first && carry + EXTRA > 0) {
+            const int ncar = carry + EXTRA;
+            if constexpr (MODE == 0) {
+                float2 t[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int s = q * 64 + lane;
+                    t[q] = (s < ncar) ? WB2[newB + s] : make_float2(0.0f, 0.0f);
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int s = q * 64 + lane;
+                    if (s < ncar) { WB2[s] = t[q]; }
+                }
+            }
+            else {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int s = q * 64 + lane;
+                    t[q] = (s < ncar) ? WB[newB + s] : 0.0f;
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int s = q * 64 + lane;
+                    if (s < ncar) { WB[s] = t[q]; }
+                }
+            }
+        }
+        put(aR, aI, 2, carry + EXTRA);
+        if constexpr (MODE == 1) {
+            // quadrature.h:39-46: d[i] = normalizePhase(phase[i] - phase[i-1]) * invDeviation
+            wave_sync();
+            for (int s = lane; s < spanB; s += 64) { XR[s] = normalize_phase(WB[s + 1] - WB[s]) * job.inv_deviation; }
+        }
+        wave_sync();
+        // stage B on the window
+        f32x4 bR[2] = { mfma4_zero(), mfma4_zero() }, bI[2] = { mfma4_zero(), mfma4_zero() };
+        toep_chains<MODE == 0>(BpB, AwB, sB, nB, 2, bR, bI);
+        if (piped && mt + 1 < mt_end) {
+            window_store();  // stage A has consumed its window
+            if (mt + 2 < mt_end) { fetch(mt + 2); }
+            sched_fence();
+        }
+        if (c < rowsB) {
+            const int obase = mt * omt;
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int o = obase + (g * 16 + 4 * kk + r) * rowsB + c;
+                    if (o < job.nout) {
+                        if constexpr (MODE == 0) { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(bR[g][r], bI[g][r])); }
+                        else { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(bR[g][r], bR[g][r])); }  // mono -> stereo
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
 // AF chain: Deemphasis<stereo_t> (filter/deephasis.h:58-77): y[i] = alpha * x[i] + (1 - alpha) * y[i-1] per channel, state carried
 // across pushes.  A first-order linear recurrence: one workgroup per VFO walks the push in super chunks of 256 * 8 frames; every
 // work-item runs the recursion over its 8 frames from a zero carry, the chunk-end values are combined with a workgroup scan of

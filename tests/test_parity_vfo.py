@@ -465,3 +465,25 @@ def test_packed_reads(backend):
             nb = o.orc_compress(n, pcm, f.ctypes.data_as(fp), ref.ctypes.data_as(u8))
             assert len(got) == nb and np.array_equal(got, ref[:nb])
     ctx.close()
+
+
+@pytest.mark.parametrize("fuse", [1, 2, 3])
+def test_two_stage_launches_bit_identical(backend, fuse, tmp_path):
+    """SDRPP_GPU_FUSE (opt-in): last decimator + resampler and/or channel filter + discriminator + audio low-pass in one launch each
+    (vfo_toep2_kernel), the stream between them kept in LDS — the same matrix chains on the same tables, so the audio of every VFO
+    must be bit-identical to the separate launches, across ragged pushes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for f in (0, fuse):
+        out = str(tmp_path / ("fuse%d.npz" % f))
+        env = dict(os.environ, SDRPP_GPU_FUSE=str(f))
+        subprocess.run([sys.executable, os.path.join(root, "tests", "fuse_scenario.py"), out, "18"], check=True, env=env)
+        res[f] = np.load(out)
+    assert len(res[0].files) == 18
+    for k in res[0].files:
+        assert res[0][k].shape == res[fuse][k].shape and res[0][k].shape[0] > 8000
+        assert np.array_equal(res[0][k], res[fuse][k]), k
