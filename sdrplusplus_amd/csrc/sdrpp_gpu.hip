@@ -1782,7 +1782,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         FamilyTimer t(c, F_POLY);
         launch_toep(c, t_poly, d_t_poly, tp_poly, 2, false);
     }
-    if (!t2_dp.empty()) {  // last decimator + resampler in one launch
+    if (!t2_dp.empty() && tp2_dp.grid_x > 0) {  // last decimator + resampler in one launch (no launch for a push too short to produce outputs)
         FamilyTimer t(c, F_POLY);
         launch(c, vfo_toep2_kernel<0>, dim3((unsigned)tp2_dp.grid_x, (unsigned)t2_dp.size()), dim3(256), tp2_dp.lds, (const sdrpp_k::Toep2Job*)d_t2_dp);
     }
@@ -1837,7 +1837,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
         if (rc) { return rc; }
     }
-    if (!t2_ca.empty()) {  // channel filter + discriminator + audio low-pass in one launch
+    if (!t2_ca.empty() && tp2_ca.grid_x > 0) {  // channel filter + discriminator + audio low-pass in one launch
         FamilyTimer t(c, F_FIR);
         launch(c, vfo_toep2_kernel<1>, dim3((unsigned)tp2_ca.grid_x, (unsigned)t2_ca.size()), dim3(256), tp2_ca.lds, (const sdrpp_k::Toep2Job*)d_t2_ca);
     }
