@@ -46,6 +46,17 @@ __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float
 // 1 / x to 1 ulp (v_rcp_f32); x must be a normal number
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// four consecutive floats, 16-byte aligned: one global_store_dwordx4
+typedef float f32x4_a16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void global_store_f32x4(float* p, long long i, float4 v) {
+    f32x4_a16 t;
+    t.x = v.x;
+    t.y = v.y;
+    t.z = v.z;
+    t.w = v.w;
+    *((f32x4_a16 __attribute__((address_space(1)))*)(uintptr_t)(p + i)) = t;
+}
+
 // Scheduling fence: the instruction scheduler does not move anything across it.  Used to keep LDS reads issued two steps ahead
 // of the matrix instructions that consume them (left alone, the scheduler sinks them next to their use and the wave then
 // waits out the full LDS latency in front of every v_mfma).

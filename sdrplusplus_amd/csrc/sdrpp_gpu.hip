@@ -978,7 +978,10 @@ ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
 void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
     if (jobs.empty() || P.grid_x == 0) { return; }
     const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
-    if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    static const bool wide_store = getenv("SDRPP_GPU_WIDE_STORE") && atoi(getenv("SDRPP_GPU_WIDE_STORE")) != 0;  // opt-in, see vfo_toep_kernel
+    if (wide_store && quad) { launch(c, vfo_toep_kernel<1, 2, true, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    else if (wide_store && width == 2) { launch(c, vfo_toep_kernel<2, 2, false, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    else if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
     else if (width == 2) { launch(c, vfo_toep_kernel<2, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
     else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
 }

@@ -1197,7 +1197,10 @@ struct ToepJob {
     float inv_deviation;   // QUAD only
 };
 
-template <int WIDTH, int G, bool QUAD>
+// WS (opt-in, SDRPP_GPU_WIDE_STORE=1): the outputs of a full macro tile go back through the (by then free) LDS window so that every
+// lane stores two consecutive outputs with one global_store_dwordx4 — 4 fully contiguous store instructions per macro tile instead of
+// 16 that each write four 120-byte pieces.
+template <int WIDTH, int G, bool QUAD, bool WS = false>
 __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemt)
     const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
@@ -1402,6 +1405,31 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
                 }
             }
         }
+        constexpr int NST = (G * 16 * 15 / 2 + 63) / 64;  // sample pairs per lane of a macro tile
+        float4 st4[WS ? NST : 1];
+        bool wide = false;
+        if constexpr (WS && NPL == 2) {
+            wide = piped && obase + omt <= job.nout && pl >= omt;
+            if (wide) {
+                wave_sync();  // every lane has read its operands: the window doubles as the staging area, output (tile, m) at tile * rows + m
+                float2* S2 = reinterpret_cast<float2*>(XR);
+                if (c < rows) {
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            S2[(g * 16 + 4 * kk + r) * rows + c] = make_float2(accR[g][r], (WIDTH == 2) ? accI[g][r] : accR[g][r]);
+                        }
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < NST; q++) {
+                    const int pr = q * 64 + lane;
+                    if (2 * pr < omt) { st4[q] = reinterpret_cast<const float4*>(S2)[pr]; }
+                }
+            }
+        }
         if (piped && it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout) {
             wave_sync();  // every lane has read its operands of this window
             window_store();
@@ -1409,8 +1437,17 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
             discriminate();
             sched_fence();
         }
+        if (wide) {
+            if constexpr (WS) {
+#pragma unroll
+                for (int q = 0; q < NST; q++) {
+                    const int pr = q * 64 + lane;
+                    if (2 * pr < omt) { global_store_f32x4(job.out, 2ll * obase + 4ll * pr, st4[q]); }
+                }
+            }
+        }
         // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r
-        if (c < rows) {
+        else if (c < rows) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
 #pragma unroll

@@ -13,6 +13,7 @@ static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
 static inline float4 global_load_f32x4_unaligned(const float* p, long long i) { return make_float4(p[i], p[i + 1], p[i + 2], p[i + 3]); }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
+static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }

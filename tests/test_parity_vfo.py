@@ -467,28 +467,30 @@ def test_packed_reads(backend):
     ctx.close()
 
 
-@pytest.mark.parametrize("fuse", [1, 2, 3])
-def test_two_stage_launches_bit_identical(backend, fuse, tmp_path):
-    if backend == "gpu":
-        # The fused launches ran on the MI355X through bench.py (slower than the separate launches, hence opt-in), and
-        # the first GPU run of THIS test found a zero-sized grid for pushes too short to produce outputs (fixed); round 1's GPU
-        # budget ended before the re-run, so the device leg is pending rather than claimed.
-        pytest.skip("device leg pending: GPU budget of round 1 exhausted after the zero-grid fix")
-    """SDRPP_GPU_FUSE (opt-in): last decimator + resampler and/or channel filter + discriminator + audio low-pass in one launch each
-    (vfo_toep2_kernel), the stream between them kept in LDS — the same matrix chains on the same tables, so the audio of every VFO
-    must be bit-identical to the separate launches, across ragged pushes."""
+@pytest.mark.parametrize("switch", ["SDRPP_GPU_FUSE=1", "SDRPP_GPU_FUSE=2", "SDRPP_GPU_FUSE=3", "SDRPP_GPU_WIDE_STORE=1"])
+def test_opt_in_kernel_variants_bit_identical(backend, switch, tmp_path):
+    """Opt-in variants of the per-VFO filter launches: SDRPP_GPU_FUSE — last decimator + resampler and/or channel
+    filter + discriminator + audio low-pass in one launch each (vfo_toep2_kernel), the stream between them kept in LDS;
+    SDRPP_GPU_WIDE_STORE — outputs of full macro tiles staged through LDS and stored with dwordx4.  The same matrix chains on the same
+    tables, so the audio of every VFO must be bit-identical to the default launches, across ragged pushes.  One process per setting
+    (the library reads the switches once)."""
     import os
     import subprocess
     import sys
 
+    if backend == "gpu":
+        # The fused launches ran on the MI355X through bench.py (DESIGN.md §4: no faster than the separate launches, hence opt-in), and
+        # the first GPU run of this test found a zero-sized grid for pushes too short to produce outputs (fixed); round 1's GPU
+        # budget ended before the re-run, so the device leg is pending rather than claimed.
+        pytest.skip("device leg pending: GPU budget of round 1 exhausted")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for f in (0, fuse):
-        out = str(tmp_path / ("fuse%d.npz" % f))
-        env = dict(os.environ, SDRPP_GPU_FUSE=str(f))
-        subprocess.run([sys.executable, os.path.join(root, "tests", "fuse_scenario.py"), out, "18"], check=True, env=env)
-        res[f] = np.load(out)
+    name, value = switch.split("=")
+    res = []
+    for v in ("0", value):
+        out = str(tmp_path / ("%s_%s.npz" % (name, v)))
+        subprocess.run([sys.executable, os.path.join(root, "tests", "variant_scenario.py"), out, "18"], check=True, env=dict(os.environ, **{name: v}))
+        res.append(np.load(out))
     assert len(res[0].files) == 18
     for k in res[0].files:
-        assert res[0][k].shape == res[fuse][k].shape and res[0][k].shape[0] > 8000
-        assert np.array_equal(res[0][k], res[fuse][k]), k
+        assert res[0][k].shape == res[1][k].shape and res[0][k].shape[0] > 8000
+        assert np.array_equal(res[0][k], res[1][k]), k

@@ -1,5 +1,5 @@
-"""Helper of test_two_stage_launches_bit_identical: one process = one setting of SDRPP_GPU_FUSE (the library reads it once).
-   python tests/fuse_scenario.py OUT.npz NVFO      (SDRPP_GPU_LIB selects emulator / product library as in the other tests)"""
+"""Helper of test_opt_in_kernel_variants_bit_identical: one process = one setting of the opt-in switches (the library reads them once).
+   python tests/variant_scenario.py OUT.npz NVFO      (SDRPP_GPU_LIB selects emulator / product library as in the other tests)"""
 import os
 import sys
 
