@@ -1201,7 +1201,7 @@ struct ToepJob {
 // lane stores two consecutive outputs with one global_store_dwordx4 — 4 fully contiguous store instructions per macro tile instead of
 // 16 that each write four 120-byte pieces.
 template <int WIDTH, int G, bool QUAD, bool WS = false>
-__global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemt)
     const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1447,6 +1447,21 @@ __global__ __launch_bounds__(256) void vfo_toep_kernel(const ToepJob* __restrict
             }
         }
         // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r
+        else if (obase + omt <= job.nout) {
+            // full macro tile (all but the last one of a stream): no per-output bound tests, one lane offset for all sixteen stores and
+            // a wave-uniform base per store (scalar address arithmetic instead of ~12 vector instructions and a branch per store)
+            if (c < rows) {
+                float2* const ob = reinterpret_cast<float2*>(job.out) + obase;
+                const int lofs = 4 * kk * rows + c;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        global_store_f32x2(ob + (g * 16 + r) * rows, lofs, make_float2(accR[g][r], (WIDTH == 2) ? accI[g][r] : accR[g][r]));
+                    }
+                }
+            }
+        }
         else if (c < rows) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
