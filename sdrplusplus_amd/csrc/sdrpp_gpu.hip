@@ -1064,6 +1064,16 @@ ToepPlan toep2_plan(std::vector<sdrpp_k::Toep2Job>& jobs, int mode) {
 
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
+#ifdef SDRPP_TOEP_KNOCK
+    {   // diagnostic build: SDRPP_TOEP_KNOCK=<mask> (1: no stores, 2: no loads, 4: no matrix loop) in vfo_toep_kernel
+        static bool once = false;
+        if (!once) {
+            once = true;
+            const int m = getenv("SDRPP_TOEP_KNOCK") ? atoi(getenv("SDRPP_TOEP_KNOCK")) : 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_toep_knock), &m, sizeof(int));
+        }
+    }
+#endif
     const int n_in = (int)count;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;

@@ -1197,6 +1197,12 @@ struct ToepJob {
     float inv_deviation;   // QUAD only
 };
 
+// -DSDRPP_TOEP_KNOCK builds only (`make knock`, diagnostic, results are WRONG by design): g_toep_knock bit 0 drops the output stores,
+// bit 1 the window loads, bit 2 the matrix loop — the timing of what is left shows what each part costs.
+#ifdef SDRPP_TOEP_KNOCK
+__device__ int g_toep_knock;
+#endif
+
 // WS (opt-in, SDRPP_GPU_WIDE_STORE=1): the outputs of a full macro tile go back through the (by then free) LDS window so that every
 // lane stores two consecutive outputs with one global_store_dwordx4 — 4 fully contiguous store instructions per macro tile instead of
 // 16 that each write four 120-byte pieces.
@@ -1205,6 +1211,9 @@ __global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob
     HIP_DYNAMIC_SHARED(float, smemt)
     const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef SDRPP_TOEP_KNOCK
+    const int knock = g_toep_knock;
+#endif
     const int nsteps = job.nsteps, s_in = job.s_in, rows = job.rows;
     const int span = (G * 16 - 1) * s_in + 4 * nsteps;  // window of one macro tile
     const int pl = (span + 8) & ~3;
@@ -1241,6 +1250,9 @@ __global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob
     float pf1[CPLX_IN ? 1 : PF];
     float4 pf4[ILV ? PF4 : 1];
     auto fetch = [&](int mt) {
+#ifdef SDRPP_TOEP_KNOCK
+        if (knock & 2) { return; }
+#endif
         const int lo = job.base0 + mt * G * 16 * s_in - (QUAD ? 1 : 0);
         const bool inside = lo >= 0 && lo + cnt <= job.in.n;  // all but the first and last macro tiles: no history / end tests
         if constexpr (ILV) {
@@ -1362,6 +1374,9 @@ __global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob
         {
             constexpr int U = (WIDTH == 2) ? 4 : 8;
             int t0 = 0;
+#ifdef SDRPP_TOEP_KNOCK
+            if (knock & 4) { t0 = nsteps; }
+#endif
             for (; t0 + U <= nsteps; t0 += U) {
                 float b[U], xr[U][G], xi[U][G];
 #pragma unroll
@@ -1437,6 +1452,9 @@ __global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob
             discriminate();
             sched_fence();
         }
+#ifdef SDRPP_TOEP_KNOCK
+        if ((knock & 1) && accR[0][0] != 123.456f) { continue; }
+#endif
         if (wide) {
             if constexpr (WS) {
 #pragma unroll

@@ -23,3 +23,9 @@ for sw in "SDRPP_GPU_FUSE=0" "SDRPP_GPU_WIDE_STORE=1"; do
     echo "-- $sw"
     env $sw python tools/vfo_only_time.py 16777216 32 10 2>&1 | tail -1
 done
+echo "== knock-out builds of the Toeplitz kernel (1: no stores, 2: no loads, 4: no matrix loop; DESIGN.md section 4)"
+make -C sdrplusplus_amd/csrc -s knock
+for m in 0 1 2 3 4 7; do
+    echo "-- mask $m"
+    SDRPP_TOEP_KNOCK=$m SDRPP_GPU_LIB=$PWD/sdrplusplus_amd/csrc/libsdrpp_gpu_knock.so python tools/vfo_only_time.py 16777216 32 10 2>&1 | tail -1
+done
