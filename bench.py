@@ -83,8 +83,8 @@ def cpu_baseline(sr, nvfo, fft_size, block):
 FAMILY_KERNELS = {
     "fft_pass1": ["fft_pass1_kernel"], "fft_pass2": ["fft_pass2_kernel"], "fft_single": ["fft_single_kernel"], "zoom_palette": ["zoom_palette_kernel"],
     "vfo_stage1": ["vfo_frontcm_kernel", "vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
-    "vfo_decim": ["vfo_toep_kernel<2, 2, false>", "vfo_firb_kernel<2, false, false>"], "vfo_poly": ["vfo_toep_kernel<2, 2, false>", "vfo_toep2_kernel<0>", "vfo_polyb_kernel", "vfo_poly_kernel"],
-    "vfo_fir": ["vfo_toep_kernel<1, 2, true>", "vfo_toep_kernel<2, 2, false>", "vfo_toep2_kernel<1>", "vfo_firb_kernel"], "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
+    "vfo_decim": ["vfo_toep_kernel<2, 2, false>", "vfo_firb_kernel<2, false, false>"], "vfo_poly": ["vfo_toep_kernel<2, 2, false>", "vfo_polyb_kernel", "vfo_poly_kernel"],
+    "vfo_fir": ["vfo_toep_kernel<1, 2, true>", "vfo_toep_kernel<2, 2, false>", "vfo_firb_kernel"], "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
 }
 
 

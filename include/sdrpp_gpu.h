@@ -75,6 +75,26 @@ float sdrpp_design_deemphasis_alpha(double tau, double sample_rate);
 void sdrpp_design_waterfall_view(double view_offset, double view_bandwidth, double whole_bandwidth, int raw_fft_size,
                                  int* draw_data_start, int* draw_data_size);
 
+/* ---- what in the reference depends on how its stream is cut into blocks ---------------------------------------------------------------
+ * Two operations of the path are block-size dependent in the reference: loop::AGC's look-ahead on clipping scans to the end of the
+ * CURRENT block (agc.h:91-104; AM and SSB demodulators), and VOLK's rotator renormalises its phase at the end of every call
+ * (frequency_xlator.h:43-50).  ref_block > 0: every push is treated as consecutive reference blocks of `ref_block` input samples (the
+ * last one may be shorter), whatever the push size — e.g. sample_rate / 200 for a file source (file_source/src/main.cpp:157) — and the
+ * block ends are carried through the decimators / resampler down to the demodulator's rate.  0 (default): one push = one block. */
+int sdrpp_set_reference_block(sdrpp_ctx* ctx, int ref_block);
+/* NCO of the frequency translations (RxVFO's xlator, SSB's second xlator).
+ *   SDRPP_NCO_CLOSED_FORM (default): phase = arg(phaseDelta) * n evaluated in float64, folded into the first filter's taps; exact
+ *     frequency, no drift.  FM / AM outputs agree with the reference to ~1e-7; the raw IF and an SSB product detector additionally see
+ *     the reference rotator's own rounding drift (1e-10 .. 2e-9 rad per sample, linear in time), which this mode does not have.
+ *   SDRPP_NCO_REFERENCE_ROTATOR: the reference's float recursion itself (VOLK generic rotator2: phase *= phaseDelta in float, renormalised
+ *     every 512 samples and at the end of every block), one lane per VFO at the full input rate, then the plan's stages as plain FIRs.
+ *     Reproduces the reference's phase sequence — IF and SSB parity ~1e-7 for any run length — at a few times real time instead of
+ *     thousands: a parity mode.  Set sdrpp_set_reference_block as well: the renormalisation points are the reference's block ends.
+ * Can only be changed while the context has no VFO. */
+#define SDRPP_NCO_CLOSED_FORM 0
+#define SDRPP_NCO_REFERENCE_ROTATOR 1
+int sdrpp_set_nco_mode(sdrpp_ctx* ctx, int mode);
+
 /* ---- FFT -> log-power -> waterfall line (replaces Reshaper + Handler + IQFrontEnd::handler, iq_frontend.cpp:248-309,
  *      and WaterFall::pushFFT's doZoom + palette index, waterfall.cpp:65-90, 889-906) --------------------------------------- */
 /* fft_size: power of two 1024..1048576.  Frame k covers stream samples [k*(nz+skip), k*(nz+skip)+nz) since the last
@@ -141,8 +161,11 @@ typedef struct sdrpp_vfo_desc {
 int sdrpp_vfo_add(sdrpp_ctx* ctx, const sdrpp_vfo_desc* desc, int* id);
 int sdrpp_vfo_remove(sdrpp_ctx* ctx, int id);
 int sdrpp_vfo_count(sdrpp_ctx* ctx);
-/* RxVFO::setOffset (rx_vfo.h:72-77): only phaseDelta changes, phase stays continuous. */
+/* RxVFO::setOffset (rx_vfo.h:72-77): only phaseDelta changes, phase stays continuous; the samples already inside the first
+ * decimator's delay line keep their old rotation (the first outputs after the change are handed over sample-exactly). */
 int sdrpp_vfo_set_phase_delta(sdrpp_ctx* ctx, int id, float re, float im);
+/* SSB::setBandwidth / setMode (ssb.h:44-62, 106-117): the second translation's increment follows bandwidth / 2; phase continuous. */
+int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* ctx, int id, float re, float im);
 /* RxVFO::setBandwidth (rx_vfo.h:60-70): swap the channel-filter taps, history kept (fir.h:31-52). n = 0 bypasses. */
 int sdrpp_vfo_set_channel_taps(sdrpp_ctx* ctx, int id, const float* taps, int n);
 /* RxVFO::reset + demod reset: clears histories, NCO phase and loop states. */

@@ -419,15 +419,20 @@ void orc_palette_index(const float* zoomed, int n, float waterfallMin, float wat
  * =================================================================================================================== */
 
 /* ---- FrequencyXlator (dsp/channel/frequency_xlator.h) + VOLK rotator2 generic ---------------------------------- */
-typedef struct { float pr, pi, dr, di; } orc_xlator;
+/* `ideal` (TEST SWITCH, never the pinned configuration): the float recursion is replaced by a float64 NCO at exactly
+ * arg(phaseDelta_f32) per sample — same float phaseDelta, same float complex product, everything behind the xlator unchanged —
+ * so a comparison against it isolates what the recursion's own rounding (drift, amplitude saw-tooth) contributes. */
+typedef struct { float pr, pi, dr, di; int ideal; double theta, acc; } orc_xlator;
 
 static void xlator_set_offset(orc_xlator* x, double offset, double samplerate) {
     const double o = hz_to_rads(offset, samplerate);
     x->dr = (float)cos(o); /* frequency_xlator.h:17,28: lv_cmake(cos(offset), sin(offset)) */
     x->di = (float)sin(o);
+    x->theta = atan2((double)x->di, (double)x->dr) / (2.0 * DB_M_PI); /* turns per sample of the STORED float phaseDelta */
 }
 static void xlator_init(orc_xlator* x, double offset, double samplerate) {
     x->pr = 1.0f; x->pi = 0.0f;
+    x->ideal = 0; x->acc = 0.0;
     xlator_set_offset(x, offset, samplerate);
 }
 static void rot_norm(float* pr, float* pi) {
@@ -436,6 +441,19 @@ static void rot_norm(float* pr, float* pi) {
     *pi = *pi / h;
 }
 static void xlator_process(orc_xlator* x, int count, const float* in, float* out) {
+    if (x->ideal) {
+        for (int k = 0; k < count; k++) {
+            double ph = x->acc + x->theta * (double)k;
+            ph -= floor(ph);
+            const float pr = (float)cos(2.0 * DB_M_PI * ph), pi = (float)sin(2.0 * DB_M_PI * ph);
+            const float xr = in[2 * k], xi = in[2 * k + 1];
+            out[2 * k] = (xr * pr) - (xi * pi);
+            out[2 * k + 1] = (xr * pi) + (xi * pr);
+        }
+        x->acc += x->theta * (double)count;
+        x->acc -= floor(x->acc);
+        return;
+    }
     float pr = x->pr, pi = x->pi;
     const float dr = x->dr, di = x->di;
     int k = 0, i;
@@ -802,6 +820,8 @@ void orc_rxvfo_info(const orc_rxvfo* v, int* mode, int* predec, int* interp, int
     *tapsPerPhase = v->rs.res.tapsPerPhase; *chanTaps = v->chanTaps; *filterNeeded = v->filterNeeded;
 }
 void orc_rxvfo_phase_delta(const orc_rxvfo* v, float* dr, float* di) { *dr = v->xl.dr; *di = v->xl.di; }
+/* test switch, see orc_xlator */
+void orc_rxvfo_set_ideal_nco(orc_rxvfo* v, int on) { v->xl.ideal = on; }
 
 /* ===================================================================================================================
  * 5. Demodulators
@@ -988,6 +1008,7 @@ void orc_demod_destroy(orc_demod* d) {
     free(d->tmp); free(d->tmp2); free(d);
 }
 int orc_demod_audio_taps(const orc_demod* d) { return d->audioTaps; }
+void orc_demod_set_ideal_nco(orc_demod* d, int on) { d->xl.ideal = on; } /* SSB second translation; test switch, see orc_xlator */
 
 /* in: count complex IF samples; out: count stereo_t samples (l, r interleaved). */
 int orc_demod_process(orc_demod* d, int count, const float* in, float* out) {
@@ -1282,5 +1303,6 @@ orc_xlator* orc_xlator_create(double offset, double samplerate) {
     return x;
 }
 void orc_xlator_destroy(orc_xlator* x) { free(x); }
+void orc_xlator_set_ideal(orc_xlator* x, int on) { x->ideal = on; }
 void orc_xlator_process(orc_xlator* x, int count, const float* in, float* out) { xlator_process(x, count, in, out); }
 void orc_xlator_state(const orc_xlator* x, float* pr, float* pi, float* dr, float* di) { *pr = x->pr; *pi = x->pi; *dr = x->dr; *di = x->di; }

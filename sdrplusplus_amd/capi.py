@@ -157,6 +157,9 @@ def load():
     L.sdrpp_vfo_set_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.sdrpp_vfo_set_channel_taps.argtypes = [vp, C.c_int, c_float_p, C.c_int]
     L.sdrpp_vfo_reset.argtypes = [vp, C.c_int]
+    L.sdrpp_set_reference_block.argtypes = [vp, C.c_int]
+    L.sdrpp_set_nco_mode.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_set_ssb_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.sdrpp_vfo_out_count.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_read.argtypes = [vp, C.c_int, c_float_p, C.c_int]
     L.sdrpp_vfo_device_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), c_int_p, C.POINTER(vp), c_int_p]
@@ -183,6 +186,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -288,6 +292,14 @@ class Context:
     def sync(self):
         self._chk(self.L.sdrpp_sync(self.h))
 
+    def set_reference_block(self, ref_block):
+        """Every push = consecutive reference blocks of `ref_block` samples (AGC look-ahead, rotator renormalisation); 0 = one push, one block."""
+        self._chk(self.L.sdrpp_set_reference_block(self.h, int(ref_block)))
+
+    def set_nco_mode(self, mode):
+        """0 closed-form NCO (default), 1 the reference's float rotator recursion (parity mode).  Only while no VFO exists."""
+        self._chk(self.L.sdrpp_set_nco_mode(self.h, int(mode)))
+
     # FFT branch
     def fft_configure(self, fft_size, nz, skip, window):
         w = np.ascontiguousarray(window, dtype=np.float32)
@@ -343,6 +355,9 @@ class Context:
     def vfo_set_channel_taps(self, vid, taps):
         t = np.ascontiguousarray(taps, dtype=np.float32)
         self._chk(self.L.sdrpp_vfo_set_channel_taps(self.h, vid, t.ctypes.data_as(c_float_p), len(t)))
+
+    def vfo_set_ssb_phase_delta(self, vid, re, im):
+        self._chk(self.L.sdrpp_vfo_set_ssb_phase_delta(self.h, vid, re, im))
 
     def vfo_reset(self, vid):
         self._chk(self.L.sdrpp_vfo_reset(self.h, vid))
@@ -441,6 +456,10 @@ class Context:
     def push(self, iq):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         self._chk(self.L.sdrpp_push(self.h, iq.view(np.float32).ctypes.data_as(c_float_p), len(iq)))
+
+    def push_host_ptr(self, host_ptr, count):
+        """sdrpp_push from a raw host address (e.g. pinned memory the caller owns)."""
+        self._chk(self.L.sdrpp_push(self.h, C.cast(C.c_void_p(host_ptr), c_float_p), int(count)))
 
     def push_int16(self, iq_i16):
         a = np.ascontiguousarray(iq_i16, dtype=np.int16)

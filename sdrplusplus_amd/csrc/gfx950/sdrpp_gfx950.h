@@ -73,6 +73,11 @@ __device__ __forceinline__ void wave_sync() {
 
 // Wave-uniform helpers: value of lane `src` (src uniform across the wavefront: v_readlane_b32), and the maximum over all 64 lanes.
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d, 64); }
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {

@@ -18,7 +18,6 @@
 #include "fft_kernels.h"
 #include "host_design.h"
 #include "vfo_kernels.h"
-#include "chain_kernels.h"
 
 using namespace sdrpp_k;
 
@@ -52,8 +51,6 @@ struct ToepTab {
     int tl_len = 0, nsteps = 0, s_in = 0, rows = 0, nvar = 0;
     int kind = 0;  // 1 decimator, 2 resampler, 4 channel filter, 8 audio low-pass
     bool ok = false;
-    std::vector<float> h_tl;  // host copies (the fused back-end kernel concatenates the tables of its four stages)
-    std::vector<int> h_lb;
 };
 
 struct Vfo {
@@ -88,19 +85,18 @@ struct Vfo {
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
-    // two-stage launches (vfo_toep2_kernel, SDRPP_GPU_FUSE): last decimator -> resampler; channel filter -> discriminator -> audio low-pass
-    bool fuse_dp = false, fuse_ca = false;
-    // fused back end (vfo_chain_kernel): last decimator -> resampler -> channel filter -> discriminator + audio low-pass
-    struct Chain {
-        bool ok = false;
-        int stage = 0;             // index of the (only) separate decimator stage
-        float* d_tl = nullptr;     // concatenated tap tables
-        int* d_lb = nullptr;       // [interp][4][64]
-        int tl_off[4] = { 0, 0, 0, 0 }, tl_len = 0;
-        int nsteps[4], s_in[4], rows[4], groups[4], slab_out[4];
-        int hist[4] = { 0, 0, 0, 0 };
-        int warm = 2;
-    } chain;
+    // front end as one filter (what the fused translate + filter kernels evaluate): stages 0 (+ 1) of the plan
+    bool fused_front = false;      // stages 0 and 1 run as one composite filter (front2_t2 > 0)
+    bool no_fuse = false;          // stage-1 taps are not linear phase: the composite forms do not apply
+    unsigned long long tap_hash = 0;  // of the stage-0 / stage-1 taps: only VFOs with identical taps share a front-end job
+    float* d_h12 = nullptr;        // composite (or stage-0) taps, real, natural order — used by the retune hand-over kernel
+    int h12_K = 0, h12_lgD = 0;
+    // RxVFO::setOffset hand-over (closed-form NCO): retune points whose old-increment samples a filter window can still reach
+    struct Retune { long long pos; double theta_before; };  // pos: input samples consumed (Vfo::seen) when the increment changed
+    std::vector<Retune> recs;
+    // reference-rotator mode (sdrpp_set_nco_mode): rotated full-rate stream + persistent float phases (main xlator, SSB xlator)
+    int i_rot = -1;
+    float2* d_rot = nullptr;
     // radio AF chain (sdrpp_vfo_set_af): RationalResampler<stereo_t> -> high-pass -> de-emphasis, fed by st[i_out]
     struct Af {
         bool on = false;
@@ -213,6 +209,11 @@ struct sdrpp_ctx {
     float* d_zoomed = nullptr;
     int32_t* d_index = nullptr;
     size_t zoom_cap = 0;
+
+    // reference block structure / NCO flavour (sdrpp_set_reference_block, sdrpp_set_nco_mode)
+    int ref_block = 0;             // 0: one push = one reference block
+    int nco_exact = 0;             // 1: the reference's float rotator recursion instead of the closed-form NCO
+    std::vector<int> vfo_bounds;   // reference-block ends (cumulative sample counts) of the current push at the VFO bank's input
 
     // VFOs
     std::map<int, std::unique_ptr<Vfo>> vfos;
@@ -460,8 +461,6 @@ int toep_upload(sdrpp_ctx* c, ToepTab& T, const std::vector<float>& tl, const st
     if (rc) { return rc; }
     T.tl_len = (int)tl.size();
     T.nvar = (int)lb.size() / 64;
-    T.h_tl = tl;
-    T.h_lb = lb;
     // usable only if four wavefront windows (two planes each) + the tap table fit the block's LDS budget (1/3 of a CU) — very
     // long filters stay on the register-blocked VALU kernels
     const int span = (2 * 16 - 1) * T.s_in + 4 * T.nsteps, pl = (span + 8) & ~3;
@@ -543,12 +542,12 @@ void vfo_free(Vfo& v) {
     dev_free(v.d_chan);
     dev_free(v.d_audio);
     dev_free(v.d_state);
+    dev_free(v.d_h12);
+    dev_free(v.d_rot);
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { toep_free(v.tp_stage[i]); }
     toep_free(v.tp_poly);
     toep_free(v.tp_chan);
     toep_free(v.tp_audio);
-    dev_free(v.chain.d_tl);
-    dev_free(v.chain.d_lb);
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) {
         dev_free(v.af.d_staps[i]);
         toep_free(v.af.tp_stage[i]);
@@ -567,6 +566,7 @@ int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     v.phi = 0.0;
     v.phi2 = 0.0;
     v.seen = 0;
+    v.recs.clear();
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.soff[i] = 0; }
     v.pphase = 0;
     v.poff = 0;
@@ -597,6 +597,8 @@ int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     memcpy(blob + sizeof(st), &zero, sizeof(float));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(v.d_state, blob, sizeof(blob), hipMemcpyHostToDevice));
+    const float2 unit[2] = { make_float2(1.0f, 0.0f), make_float2(1.0f, 0.0f) };  // frequency_xlator.h:21: phase = (1, 0)
+    HIPCHK(c, hipMemcpy(v.d_rot, unit, sizeof(unit), hipMemcpyHostToDevice));
     return SDRPP_OK;
 }
 
@@ -607,6 +609,15 @@ inline int poly_nout(int n, int poff, int pphase, int L, int M) {
     if (n <= poff) { return 0; }
     const long long need = (long long)L * (n - poff) - pphase;  // A_m >= L*(n - poff)
     return (int)((need + M - 1) / M);
+}
+
+// Reference-block ends (cumulative counts) carried through a stage: outputs produced once the first `b` inputs are in.  Evaluate
+// with the stage's state BEFORE the push updates it.
+void bounds_decim(std::vector<int>& b, int off, int D) {
+    for (auto& x : b) { x = decim_nout(x, off, D); }
+}
+void bounds_poly(std::vector<int>& b, int poff, int pphase, int L, int M) {
+    for (auto& x : b) { x = poly_nout(x, poff, pphase, L, M); }
 }
 
 // Host-side enqueue profiler (SDRPP_GPU_HOSTPROF=1): wall time spent inside named sections of the push path, printed when the
@@ -813,7 +824,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
 }
 
 // ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
-struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; };
+struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; unsigned long long taph; };
 
 // Stage-2 outputs per block of the fused front kernel (0 = do not fuse: the recomputed overlap would dominate or LDS would overflow).
 int front2_t2(int K1, int D1, int K2, int D2, int vt) {
@@ -836,102 +847,6 @@ bool frontcm_ok(int K1, int lgD1, int K2, int lgD2, int* pf) {
     if (nsamp > 16 * 64) { return false; }
     *pf = nsamp <= 6 * 64 ? 6 : (nsamp <= 10 * 64 ? 10 : 16);
     return (size_t)frontcm_layout(K, lgD).total * 4 <= (size_t)(160 * 1024 / 3);  // three blocks per CU
-}
-
-// SDRPP_CHAIN_PROF builds only: per-wavefront cycle counters of one workgroup of the fused back end, printed at destroy
-long long* chain_prof_buffer(sdrpp_ctx* c) {
-#ifdef SDRPP_CHAIN_PROF
-    static long long* buf = nullptr;
-    if (!buf) { (void)hipMalloc((void**)&buf, 32 * sizeof(long long)); (void)hipMemset(buf, 0, 32 * sizeof(long long)); }
-    (void)c;
-    return buf;
-#else
-    (void)c;
-    return nullptr;
-#endif
-}
-
-// ---- fused back end (vfo_chain_kernel): static per-VFO set-up -------------------------------------------------------------------------
-// Eligible: [front end] -> exactly one separate decimator -> polyphase resampler -> channel filter -> FM discriminator + audio
-// low-pass, every stage with a matrix-core tap table, slab sizes integral (960 IF samples per slab).
-int chain_static_stage(const Vfo& v) {
-    const sdrpp_vfo_desc& d = v.d;
-    if (d.n_stages < 1) { return -1; }
-    const bool fused = d.n_stages >= 2 && front2_t2(d.stage_ntaps[0], d.stage_decim[0], d.stage_ntaps[1], d.stage_decim[1], 8) > 0;
-    const int first_sep = fused ? 2 : 1;
-    return (d.n_stages - first_sep == 1) ? first_sep : -1;
-}
-int chain_build(sdrpp_ctx* c, Vfo& v) {
-    Vfo::Chain& ch = v.chain;
-    dev_free(ch.d_tl);
-    dev_free(ch.d_lb);
-    ch.ok = false;
-    // Opt-in (SDRPP_GPU_CHAIN=1): correct (tests/test_parity_vfo.py::test_fused_back_end) but, as measured in round 1, 3.5x SLOWER than
-    // the four separate launches — one stage per wavefront leaves 1-2 wavefronts per SIMD, every LDS/global latency is exposed and
-    // the stage-0 loads are not prefetched.  Kept as the starting point of the fused back end.
-    if (!getenv("SDRPP_GPU_CHAIN")) { return SDRPP_OK; }
-    const int s = chain_static_stage(v);
-    const bool fm = v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM;
-    if (s < 0 || !fm || v.i_poly < 0 || v.chan_ntaps <= 0 || !v.tp_stage[s].ok || !v.tp_poly.ok || !v.tp_chan.ok || !v.tp_audio.ok) { return SDRPP_OK; }
-    const ToepTab* T[4] = { &v.tp_stage[s], &v.tp_poly, &v.tp_chan, &v.tp_audio };
-    const int L = v.d.interp, M = v.d.decim, A = SDRPP_CHAIN_SLAB;
-    if (T[0]->rows != 15 || T[2]->rows != 15 || T[3]->rows != 15 || T[1]->rows % L != 0) { return SDRPP_OK; }
-    if (A % (16 * T[1]->rows) != 0 || ((long long)A * M) % L != 0) { return SDRPP_OK; }
-    const int slab0 = (int)((long long)A * M / L);
-    if (slab0 % (16 * 15) != 0) { return SDRPP_OK; }
-    ch.stage = s;
-    ch.slab_out[0] = slab0;
-    ch.slab_out[1] = ch.slab_out[2] = ch.slab_out[3] = A;
-    int off = 0;
-    for (int k = 0; k < 4; k++) {
-        ch.nsteps[k] = T[k]->nsteps;
-        ch.s_in[k] = T[k]->s_in;
-        ch.rows[k] = T[k]->rows;
-        ch.groups[k] = ch.slab_out[k] / (16 * T[k]->rows);
-        ch.tl_off[k] = off;
-        off += (T[k]->tl_len + 3) & ~3;
-    }
-    ch.tl_len = off;
-    // history in front of each consumer's slab: the last tile's window must end inside [history | slab]
-    for (int k = 1; k < 4; k++) {
-        const int tiles = ch.groups[k] * 16;
-        ch.hist[k] = std::max(0, ch.s_in[k] * (tiles - 1) + 4 * ch.nsteps[k] - ch.slab_out[k - 1]);
-    }
-    // the resampler's tiles start on phase-cycle boundaries: its output alignment C[1] must be a multiple of L (see do_vfos)
-    {
-        const int c2 = -(v.audio_ntaps - 1) + ch.hist[3];
-        const int c1 = -(v.chan_ntaps - 1) + c2 + ch.hist[2];
-        ch.hist[2] += ((-c1 % L) + L) % L;
-    }
-    ch.warm = (ch.hist[1] * L / M + ch.hist[2] + ch.hist[3] + 64 < A) ? 2 : 3;
-    // tables
-    std::vector<float> tl((size_t)ch.tl_len, 0.0f);
-    for (int k = 0; k < 4; k++) { std::copy(T[k]->h_tl.begin(), T[k]->h_tl.end(), tl.begin() + ch.tl_off[k]); }
-    std::vector<int> lb((size_t)L * 4 * 64);
-    for (int ph = 0; ph < L; ph++) {
-        for (int k = 0; k < 4; k++) {
-            const int var = (k == 1) ? ph : 0;
-            for (int l = 0; l < 64; l++) { lb[((size_t)ph * 4 + k) * 64 + l] = T[k]->h_lb[(size_t)var * 64 + l]; }
-        }
-    }
-    ChainJob probe{};
-    probe.tl_len = ch.tl_len;
-    for (int k = 0; k < 4; k++) {
-        probe.nsteps[k] = ch.nsteps[k];
-        probe.s_in[k] = ch.s_in[k];
-        probe.hist[k] = ch.hist[k];
-        probe.slab_out[k] = ch.slab_out[k];
-    }
-    if ((size_t)chain_layout(probe).total * sizeof(float) > (size_t)kMaxLds) { return SDRPP_OK; }
-    int rc = upload(c, &ch.d_tl, tl.data(), tl.size());
-    if (rc) { return rc; }
-    rc = upload(c, &ch.d_lb, lb.data(), lb.size());
-    if (rc) { return rc; }
-    // the kernel re-runs `warm` slabs in front of every chunk from the INPUT stream: keep that much of it
-    rc = stream_grow_hist(c, v.st[(size_t)v.i_first + s - 1], (ch.warm + 1) * ch.slab_out[0] * v.d.stage_decim[s] + v.d.stage_ntaps[s] + 64);
-    if (rc) { return rc; }
-    ch.ok = true;
-    return SDRPP_OK;
 }
 
 // ---- matrix-core FIR launches (vfo_toep_kernel): job construction, per-list planning (macro tiles per wavefront, grid, LDS), launch ----
@@ -986,82 +901,6 @@ void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, cons
     else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
 }
 
-// ---- two filters per launch (vfo_toep2_kernel; opt-in: SDRPP_GPU_FUSE=1 pairs last decimator + resampler, =2 channel filter +
-// discriminator/audio low-pass, =3 both) ----
-// A pair can be fused when stage B consumes 480 stage-A outputs per macro tile (s_in 15), its window overlap fits the kernel's
-// carry registers and the block's LDS fits; the input stream of stage A then has to remember what the pre-roll of a wavefront
-// reaches back to.
-bool toep2_fits(int mode, const ToepTab& A, const ToepTab& B, int* lookback_outputs) {
-    if (!A.ok || !B.ok || A.rows != 15 || B.s_in != 15) { return false; }
-    const int spanB = 31 * B.s_in + 4 * B.nsteps, carry = std::max(0, spanB - 32 * B.s_in), need = carry + (mode == 1 ? 1 : 0);
-    if (need > 512) { return false; }
-    const size_t lds = ((size_t)((A.tl_len + 3) & ~3) + (size_t)((B.tl_len + 3) & ~3) + (size_t)4 * sdrpp_k::toep2_wave_floats(mode, A.s_in, A.nsteps, B.s_in, B.nsteps)) * sizeof(float);
-    if (lds > (size_t)kMaxLds) { return false; }
-    *lookback_outputs = 240 * ((need + 239) / 240) - carry;  // stage-A outputs in front of stage B's first window offset
-    return true;
-}
-int fuse_build(sdrpp_ctx* c, Vfo& v) {
-    static const int fuse = getenv("SDRPP_GPU_FUSE") ? atoi(getenv("SDRPP_GPU_FUSE")) : 0;
-    v.fuse_dp = v.fuse_ca = false;
-    if (!fuse || v.chain.ok) { return SDRPP_OK; }
-    int back = 0;
-    const int sl = v.d.n_stages - 1;
-    if ((fuse & 1) && sl >= 1 && v.i_poly >= 0 && toep2_fits(0, v.tp_stage[sl], v.tp_poly, &back)) {
-        const int dA = v.d.stage_decim[sl];
-        int rc = stream_grow_hist(c, v.st[(size_t)v.i_first + sl - 1], (v.d.stage_ntaps[sl] - 1) + dA * ((v.tpp - 1) + back + 2) + 4);
-        if (rc) { return rc; }
-        v.fuse_dp = true;
-    }
-    const bool fm = v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM;
-    if ((fuse & 2) && fm && v.i_chan >= 0 && v.chan_ntaps > 0 && toep2_fits(1, v.tp_chan, v.tp_audio, &back)) {
-        const int idx = (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1;
-        int rc = stream_grow_hist(c, v.st[(size_t)idx], (v.chan_ntaps - 1) + (v.audio_ntaps - 1) + back + 4);
-        if (rc) { return rc; }
-        v.fuse_ca = true;
-    }
-    return SDRPP_OK;
-}
-sdrpp_k::Toep2Job toep2_job(const ToepTab& A, const ToepTab& B, int varB, StreamIn in, float* out, int base0A, int base0B, int nout, float inv_dev) {
-    sdrpp_k::Toep2Job j{};
-    j.in = in;
-    j.out = out;
-    j.tlA = A.d_tl;
-    j.lbaseA = A.d_lb;
-    j.tl_lenA = A.tl_len;
-    j.nstepsA = A.nsteps;
-    j.s_inA = A.s_in;
-    j.tlB = B.d_tl;
-    j.lbaseB = B.d_lb + (size_t)varB * 64;
-    j.tl_lenB = B.tl_len;
-    j.nstepsB = B.nsteps;
-    j.s_inB = B.s_in;
-    j.rowsB = B.rows;
-    j.base0A = base0A;
-    j.base0B = base0B;
-    j.nout = nout;
-    j.mt_per_wave = 4;
-    j.inv_deviation = inv_dev;
-    return j;
-}
-// Wavefronts walk CONSECUTIVE macro tiles (at least four each, so that the pre-roll chain stays below 10 % of their work).
-ToepPlan toep2_plan(std::vector<sdrpp_k::Toep2Job>& jobs, int mode) {
-    ToepPlan P;
-    if (jobs.empty()) { return P; }
-    int mtw = 4;
-    for (; mtw < 64; mtw++) {
-        size_t blocks = 0;
-        for (auto& jb : jobs) { blocks += (size_t)((jb.nout + 32 * jb.rowsB - 1) / (32 * jb.rowsB) + 4 * mtw - 1) / (size_t)(4 * mtw); }
-        if (blocks <= 2048) { break; }
-    }
-    for (auto& jb : jobs) {
-        jb.mt_per_wave = mtw;
-        const int nmt = (jb.nout + 32 * jb.rowsB - 1) / (32 * jb.rowsB);
-        P.grid_x = std::max(P.grid_x, (nmt + 4 * mtw - 1) / (4 * mtw));
-        P.lds = std::max(P.lds, ((size_t)((jb.tl_lenA + 3) & ~3) + (size_t)((jb.tl_lenB + 3) & ~3) + (size_t)4 * sdrpp_k::toep2_wave_floats(mode, jb.s_inA, jb.nstepsA, jb.s_inB, jb.nstepsB)) * sizeof(float));
-    }
-    return P;
-}
-
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
 #ifdef SDRPP_TOEP_KNOCK
@@ -1077,7 +916,12 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     const int n_in = (int)count;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;
-    std::vector<FirBJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 1..3 used
+    std::vector<FirBJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 0 only in reference-rotator mode (stage 0 as a plain FIR)
+    std::vector<RotXJob> rotx;                          // reference-rotator mode: full-rate float recursion, one lane per VFO
+    std::vector<SsbRotXJob> ssbx;
+    std::vector<RetuneJob> retune;                      // closed-form NCO: first outputs after a setOffset
+    const std::vector<int>& fb = c->vfo_bounds;         // reference-block ends of this push (at least one entry: n_in)
+    const bool blocks = fb.size() > 1;
     std::vector<PolyJob> poly;
     std::vector<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
     std::vector<FirBJob> chan;
@@ -1087,9 +931,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
     std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
-    std::vector<ChainJob> chainj;  // fused back end (vfo_chain_kernel)
-    std::vector<sdrpp_k::Toep2Job> t2_dp, t2_ca;  // two filters per launch (vfo_toep2_kernel)
-    std::vector<Stream*> ghost;                    // streams that such a launch keeps on the CU: nothing to carry
     // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
     std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
     std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
@@ -1100,14 +941,21 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     for (auto& kv : c->vfos) {
         Vfo& v = *kv.second;
         Stream* cur = &v.st[(size_t)v.i_first];
-        // fused back end: the four per-stage launches below become one ChainJob (same integer state, same streams)
-        bool use_chain = false;
-        bool f2_pending = false, f1_pending = false;
-        StreamIn f2_in{}, f1_in{};
-        int f2_base0A = 0;
-        ChainJob cj{};
-        int cj_poly_base0 = 0;
-        if (v.d.n_stages == 0) {
+        // reference-block ends carried stage by stage down to the demodulator's rate, for the block-dependent operations there
+        // (AGC look-ahead, SSB rotator calls)
+        const bool agc_mode = v.d.demod == SDRPP_DEMOD_AM || (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB);
+        const bool need_bnd = agc_mode && (blocks || c->nco_exact);
+        std::vector<int> bnd;
+        if (need_bnd) { bnd = fb; }
+        int first_sep = 0;  // first decimator stage that runs as its own FIR launch
+        if (c->nco_exact) {
+            // the reference's own data flow: rotate at the full rate (float recursion), then every stage of the plan as a plain FIR
+            Stream* tgt = (v.d.n_stages == 0) ? cur : &v.st[(size_t)v.i_rot];
+            rotx.push_back(RotXJob{ (float2*)tgt->data, v.d_rot, v.d.phase_delta_re, v.d.phase_delta_im });
+            tgt->n = n_in;
+            cur = tgt;
+        }
+        else if (v.d.n_stages == 0) {
             rot.push_back(RotJob{ v.theta, v.phi, (float2*)cur->data, n_in });
             cur->n = n_in;
             max_rot = std::max(max_rot, n_in);
@@ -1117,10 +965,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int nout = decim_nout(n_in, v.soff[0], D);
             if (v.modtaps_dirty) { build_modtaps(v); }
             const int K0 = v.d.stage_ntaps[0];
-            S1Member mem{ &v, K0, ilog2(D), v.soff[0], nout, v.phi, 0, 0, 0, 0, 0, 0 };
+            S1Member mem{ &v, K0, ilog2(D), v.soff[0], nout, v.phi, 0, 0, 0, 0, 0, 0, v.tap_hash };
             int need = K0 - 1;
-            int first_sep = 1;  // first stage that runs as its own FIR launch
-            if (v.d.n_stages >= 2 && front2_t2(K0, D, v.d.stage_ntaps[1], v.d.stage_decim[1], 8) > 0) {
+            first_sep = 1;
+            if (need_bnd) { bounds_decim(bnd, v.soff[0], D); }
+            if (v.fused_front) {
                 const int D2 = v.d.stage_decim[1];
                 mem.fused = 1;
                 mem.K2 = v.d.stage_ntaps[1];
@@ -1129,9 +978,54 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 mem.nout2 = decim_nout(nout, v.soff[1], D2);
                 need = K0 - 1 + D * (mem.K2 - 1);
                 first_sep = 2;
+                if (need_bnd) { bounds_decim(bnd, v.soff[1], D2); }
             }
             mem.min_idx = (v.seen >= need) ? -need : -(int)v.seen;  // older samples predate this VFO: zero
             s1.push_back(mem);
+            // setOffset hand-over: outputs whose window still reaches in front of the latest retune point are recomputed with the
+            // piecewise phase (vfo_retune_fix_kernel); retune points no window can reach any more are forgotten
+            {
+                const int D1 = D, Kc = v.h12_K;
+                const int off = mem.fused ? mem.off0 + (mem.off2 - (mem.K2 - 1)) * D1 - (K0 - 1) : mem.off0 - (K0 - 1);
+                const int nout_f = mem.fused ? mem.nout2 : nout;
+                while (!v.recs.empty() && v.recs.front().pos - v.seen <= (long long)off) { v.recs.erase(v.recs.begin()); }
+                while (v.recs.size() > SDRPP_RETUNE_MAX_SEG - 1) { v.recs.erase(v.recs.begin()); }
+                if (!v.recs.empty() && nout_f > 0) {
+                    const long long r_last = v.recs.back().pos - v.seen;  // push-relative, <= 0
+                    const long long Dc = 1ll << v.h12_lgD;
+                    const int nfix = (int)std::min<long long>((long long)nout_f, (r_last - off + Dc - 1) / Dc);  // outputs m with off + m * Dc < r_last
+                    if (nfix > 0) {
+                        RetuneJob rj{};
+                        rj.out = (float2*)v.st[(size_t)v.i_first + (mem.fused ? 1 : 0)].data;
+                        rj.taps = v.d_h12;
+                        rj.K = Kc;
+                        rj.log2_decim = v.h12_lgD;
+                        rj.off = off;
+                        rj.nfix = nfix;
+                        rj.min_idx = mem.min_idx;
+                        const int nr = (int)v.recs.size();
+                        rj.nseg = nr + 1;
+                        // segment q >= 1 starts at retune point q - 1 and runs with the increment that was in effect from there on (the
+                        // newest with the current one); segment 0 = everything in front of the oldest remembered point, anchored there.
+                        // Phases are continuous across the points, evaluated backwards from the current phase.
+                        double P = v.phi + v.theta * (double)r_last;  // phase at the newest point
+                        for (int q = nr; q >= 1; q--) {
+                            const long long Sq = v.recs[(size_t)q - 1].pos - v.seen;
+                            rj.start[q] = (int)std::max<long long>(Sq, -2000000000ll);
+                            rj.theta[q] = (q == nr) ? v.theta : v.recs[(size_t)q].theta_before;
+                            rj.phi[q] = P - std::floor(P);
+                            if (q >= 2) {  // phase at the start of the segment in front: back along ITS increment
+                                const long long Sp = v.recs[(size_t)q - 2].pos - v.seen;
+                                P = P + v.recs[(size_t)q - 1].theta_before * (double)(Sp - Sq);
+                            }
+                        }
+                        rj.start[0] = rj.start[1];
+                        rj.theta[0] = v.recs[0].theta_before;
+                        rj.phi[0] = rj.phi[1];
+                        retune.push_back(rj);
+                    }
+                }
+            }
             v.soff[0] = v.soff[0] + nout * D - n_in;
             cur->n = nout;
             if (mem.fused) {
@@ -1141,40 +1035,23 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 nxt->n = mem.nout2;
                 cur = nxt;
             }
-            use_chain = v.chain.ok && first_sep == v.chain.stage;
-            for (int s = first_sep; s < v.d.n_stages; s++) {
-                Stream* nxt = &v.st[(size_t)v.i_first + s];
-                const int Ds = v.d.stage_decim[s];
-                const int no = decim_nout(cur->n, v.soff[s], Ds);
-                if (use_chain) {
-                    cj.in = stream_in(*cur);
-                    cj.in0_base = (long long)v.soff[s] - (v.d.stage_ntaps[s] - 1);
-                    cj.d0 = Ds;
-                }
-                else if (v.fuse_dp && s == v.d.n_stages - 1 && v.tp_stage[s].ok && v.tp_poly.ok) {
-                    f2_in = stream_in(*cur);
-                    f2_base0A = v.soff[s] - (v.d.stage_ntaps[s] - 1);
-                    f2_pending = true;
-                    ghost.push_back(nxt);
-                }
-                else if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
-                else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
-                v.soff[s] = v.soff[s] + no * Ds - cur->n;
-                nxt->n = no;
-                cur = nxt;
-            }
+        }
+        for (int s = first_sep; s < v.d.n_stages; s++) {
+            Stream* nxt = &v.st[(size_t)v.i_first + s];
+            const int Ds = v.d.stage_decim[s];
+            const int no = decim_nout(cur->n, v.soff[s], Ds);
+            if (need_bnd) { bounds_decim(bnd, v.soff[s], Ds); }
+            if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
+            else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
+            v.soff[s] = v.soff[s] + no * Ds - cur->n;
+            nxt->n = no;
+            cur = nxt;
         }
         if (v.i_poly >= 0) {
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
-            if (use_chain) {
-                cj_poly_base0 = v.poff - (v.tpp - 1);
-                cj.lb = v.chain.d_lb + (size_t)v.pphase * 4 * 64;
-            }
-            else if (f2_pending) {
-                t2_dp.push_back(toep2_job(v.tp_stage[v.d.n_stages - 1], v.tp_poly, v.pphase, f2_in, nxt->data, f2_base0A, v.poff - (v.tpp - 1), no, 0.0f));
-            }
-            else if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
+            if (need_bnd) { bounds_poly(bnd, v.poff, v.pphase, v.d.interp, v.d.decim); }
+            if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
             else if (v.d_cyc) {
                 polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
@@ -1190,13 +1067,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            if (use_chain) { cj.if_out = nxt->data; }
-            else if (v.fuse_ca && v.tp_chan.ok && v.tp_audio.ok) {
-                f1_in = stream_in(*cur);
-                f1_pending = true;
-                ghost.push_back(nxt);
-            }
-            else if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
+            if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
             else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
             cur = nxt;
@@ -1205,39 +1076,15 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         const int nif = cur->n;
         AgcState* agc = (AgcState*)v.d_state;
         float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
+        const int* d_bnd = nullptr;
+        if (need_bnd) {
+            d_bnd = arena_push(c, bnd);
+            if (!d_bnd) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
+        const int nbnd = need_bnd ? (int)bnd.size() : 0;
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
-            if (use_chain) {
-                const Vfo::Chain& ch = v.chain;
-                const int L = v.d.interp, M = v.d.decim;
-                cj.audio_out = out.data;
-                cj.n_if = nif;
-                cj.tl = ch.d_tl;
-                cj.tl_len = ch.tl_len;
-                for (int k = 0; k < 4; k++) {
-                    cj.tl_off[k] = ch.tl_off[k];
-                    cj.nsteps[k] = ch.nsteps[k];
-                    cj.s_in[k] = ch.s_in[k];
-                    cj.rows[k] = ch.rows[k];
-                    cj.groups[k] = ch.groups[k];
-                    cj.hist[k] = ch.hist[k];
-                    cj.slab_out[k] = ch.slab_out[k];
-                }
-                // output alignment, consumer by consumer (chain_kernels.h): C[s-1] = base0[s] + ratio * C[s] + hist[s]
-                cj.C[3] = 0;
-                cj.C[2] = -(v.audio_ntaps - 1) + cj.C[3] + ch.hist[3];
-                cj.C[1] = -(v.chan_ntaps - 1) + cj.C[2] + ch.hist[2];  // a multiple of L by construction (chain_build)
-                cj.C[0] = cj_poly_base0 + (int)((long long)cj.C[1] * M / L) + ch.hist[1];
-                const int need = nif - std::min(0, cj.C[2]);
-                cj.nslabs = (need + SDRPP_CHAIN_SLAB - 1) / SDRPP_CHAIN_SLAB;
-                cj.warm = ch.warm;
-                cj.inv_deviation = v.d.inv_deviation;
-                if (cj.nslabs > 0) { chainj.push_back(cj); }
-            }
-            else if (f1_pending) {
-                t2_ca.push_back(toep2_job(v.tp_chan, v.tp_audio, 0, f1_in, out.data, -(v.chan_ntaps - 1), -(v.audio_ntaps - 1), nif, v.d.inv_deviation));
-            }
-            else if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
+            if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
             else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
         }
@@ -1245,7 +1092,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
             if (!v.d.am_carrier_agc) { pre.push_back(PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
-            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc });
+            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, d_bnd, nbnd });
             dem.n = nif;
             if (v.tp_audio.ok) { t_audio.push_back(toep_job(v.tp_audio, 0, stream_in(dem), out.data, -(v.audio_ntaps - 1), nif, 0.0f)); }
             else { audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp }); }
@@ -1254,8 +1101,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            pre.push_back(PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 });
-            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0 });
+            if (c->nco_exact) { ssbx.push_back(SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
+            else { pre.push_back(PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 }); }
+            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0, d_bnd, nbnd });
             dem.n = 0;  // scratch only
             out.n = nif;
             double p2 = v.phi2 + (double)nif * v.theta2;
@@ -1305,8 +1153,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         double p = v.phi + (double)n_in * v.theta;
         v.phi = p - std::floor(p);
         v.seen += n_in;
-        for (Stream* g : ghost) { g->n = 0; }  // never materialised
-        ghost.clear();
         // history carries for every stream that has a consumer with memory
         for (auto& s : v.st) {
             if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len }); }
@@ -1316,7 +1162,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     // ---- stage 1 (optionally fused with stage 2): group VFOs with identical geometry, VT per job ----
     auto same = [](const S1Member& a, const S1Member& b) {
         return a.fused == b.fused && a.K == b.K && a.lgD == b.lgD && a.off0 == b.off0 && a.nout == b.nout && a.min_idx == b.min_idx && a.K2 == b.K2 &&
-               a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2;
+               a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2 && a.taph == b.taph;
     };
     std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
         if (a.fused != b.fused) { return a.fused < b.fused; }
@@ -1329,6 +1175,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (a.lgD2 != b.lgD2) { return a.lgD2 < b.lgD2; }
         if (a.off2 != b.off2) { return a.off2 < b.off2; }
         if (a.nout2 != b.nout2) { return a.nout2 < b.nout2; }
+        if (a.taph != b.taph) { return a.taph < b.taph; }
         return a.v->id < b.v->id;
     });
     struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
@@ -1574,18 +1421,19 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
     }
     // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
+    RotXJob* d_rotx = arena_push(c, rotx);
+    SsbRotXJob* d_ssbx = arena_push(c, ssbx);
+    RetuneJob* d_retune = arena_push(c, retune);
+    const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
+    if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!ssbx.empty() && !d_ssbx) || (!retune.empty() && !d_retune)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
         tp_lvl[s] = toep_plan(t_lvl[s], 2);
         d_t_lvl[s] = arena_push(c, t_lvl[s]);
         if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
     const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
-    const ToepPlan tp2_dp = toep2_plan(t2_dp, 0), tp2_ca = toep2_plan(t2_ca, 1);
-    sdrpp_k::Toep2Job* d_t2_dp = arena_push(c, t2_dp);
-    sdrpp_k::Toep2Job* d_t2_ca = arena_push(c, t2_ca);
-    if ((!t2_dp.empty() && !d_t2_dp) || (!t2_ca.empty() && !d_t2_ca)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepJob* d_t_poly = arena_push(c, t_poly);
     ToepJob* d_t_chan = arena_push(c, t_chan);
     ToepJob* d_t_audio = arena_push(c, t_audio);
@@ -1593,26 +1441,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if ((!t_poly.empty() && !d_t_poly) || (!t_chan.empty() && !d_t_chan) || (!t_audio.empty() && !d_t_audio) || (!t_audio_fm.empty() && !d_t_audio_fm)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
     }
-    if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
+    if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[0].lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS");
     }
-    // fused back end: time chunks per VFO so that ~2 workgroups per CU are resident (the warm-up slabs of a chunk are pure
-    // overhead, so no more chunks than that), at least `8 * warm` slabs per chunk
-    int chain_chunks = 0;
-    size_t chain_lds = 0;
-    if (!chainj.empty()) {
-        int max_slabs = 0;
-        for (auto& j : chainj) { max_slabs = std::max(max_slabs, j.nslabs); }
-        int per_vfo = std::max(1, 512 / (int)chainj.size());
-        per_vfo = std::min(per_vfo, std::max(1, max_slabs / 16));
-        for (auto& j : chainj) {
-            j.slabs_per_block = (j.nslabs + per_vfo - 1) / per_vfo;
-            chain_chunks = std::max(chain_chunks, (j.nslabs + j.slabs_per_block - 1) / j.slabs_per_block);
-            chain_lds = std::max(chain_lds, (size_t)chain_layout(j).total * sizeof(float));
-        }
-    }
-    ChainJob* d_chainj = arena_push(c, chainj);
-    if (!chainj.empty() && !d_chainj) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepPlan tp_af_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     FirBJob* d_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
@@ -1634,7 +1465,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     RotJob* d_rot = arena_push(c, rot);
     FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
+    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
     PolyJob* d_poly = arena_push(c, poly);
     PolyBJob* d_polyb[4] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]), arena_push(c, polyb[2]), arena_push(c, polyb[3]) };
     FirBJob* d_chan = arena_push(c, chan);
@@ -1650,7 +1481,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
     }
-    for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
         if (!lvl[s].empty() && !d_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
     int rc;
@@ -1663,6 +1494,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     // ---- launches ----
     {
         FamilyTimer t(c, F_S1);
+        if (!rotx.empty() && n_in > 0) {
+            launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size());
+        }
         for (int k = 0; k < 4; k++) {
             if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }
             bool direct = true;  // every job of the class decimates by >= 32: stream from global memory, no LDS tile
@@ -1720,6 +1554,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (!rot.empty() && max_rot > 0) {
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
         }
+        if (!retune.empty()) {
+            int mx = 0;
+            for (auto& r : retune) { mx = std::max(mx, r.nfix); }
+            launch(c, vfo_retune_fix_kernel, dim3((unsigned)mx, (unsigned)retune.size()), dim3(64), 0, src, (const RetuneJob*)d_retune);
+        }
     }
     auto launch_fir = [&](std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) -> int {
         if (jobs.empty()) { return SDRPP_OK; }
@@ -1734,8 +1573,17 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             max_nout = std::max(max_nout, jb.nout);
             int nt = 256;
             while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
-            if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+            if (nt < 32) {
+                if (width != 2 || quad || stereo) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+                threads = 0;  // complex stream: the untiled kernel takes the whole list
+                break;
+            }
             threads = std::min(threads, nt);
+        }
+        if (threads == 0) {
+            for (auto& jb : jobs) { max_nout = std::max(max_nout, jb.nout); }
+            if (max_nout > 0) { launch(c, vfo_fir_direct_kernel, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
+            return SDRPP_OK;
         }
         if (max_nout == 0) { return SDRPP_OK; }
         // enough blocks to load-balance 256 CUs: shrink the tile while the grid has fewer than ~8 blocks per CU
@@ -1779,13 +1627,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
         return SDRPP_OK;
     };
-    if (!chainj.empty() && chain_chunks > 0) {
-        FamilyTimer t(c, F_FIR);
-        launch(c, vfo_chain_kernel, dim3((unsigned)chain_chunks, (unsigned)chainj.size()), dim3(256), chain_lds, (const ChainJob*)d_chainj, (long long*)chain_prof_buffer(c));
-    }
     {
         FamilyTimer t(c, F_DECIM);
-        for (int s = 1; s < SDRPP_MAX_DECIM_STAGES; s++) {
+        for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
             launch_toep(c, t_lvl[s], d_t_lvl[s], tp_lvl[s], 2, false);
             rc = launch_fir(lvl[s], d_lvl[s], 2, false);
             if (rc) { return rc; }
@@ -1794,10 +1638,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     if (!t_poly.empty()) {
         FamilyTimer t(c, F_POLY);
         launch_toep(c, t_poly, d_t_poly, tp_poly, 2, false);
-    }
-    if (!t2_dp.empty() && tp2_dp.grid_x > 0) {  // last decimator + resampler in one launch (no launch for a push too short to produce outputs)
-        FamilyTimer t(c, F_POLY);
-        launch(c, vfo_toep2_kernel<0>, dim3((unsigned)tp2_dp.grid_x, (unsigned)t2_dp.size()), dim3(256), tp2_dp.lds, (const sdrpp_k::Toep2Job*)d_t2_dp);
     }
     if (!poly.empty()) {
         FamilyTimer t(c, F_POLY);
@@ -1832,8 +1672,9 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         rc = launch_fir(chan, d_chan, 2, false);
         if (rc) { return rc; }
     }
-    if (!pre.empty() || !seq.empty()) {
+    if (!pre.empty() || !seq.empty() || !ssbx.empty()) {
         FamilyTimer t(c, F_DEMOD);
+        if (!ssbx.empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx.size()), dim3(64), 0, (const SsbRotXJob*)d_ssbx); }
         if (!pre.empty()) {
             int mx = 0;
             for (auto& q : pre) { mx = std::max(mx, q.n); }
@@ -1849,10 +1690,6 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (rc) { return rc; }
         rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
         if (rc) { return rc; }
-    }
-    if (!t2_ca.empty() && tp2_ca.grid_x > 0) {  // channel filter + discriminator + audio low-pass in one launch
-        FamilyTimer t(c, F_FIR);
-        launch(c, vfo_toep2_kernel<1>, dim3((unsigned)tp2_ca.grid_x, (unsigned)t2_ca.size()), dim3(256), tp2_ca.lds, (const sdrpp_k::Toep2Job*)d_t2_ca);
     }
     bool any_af = !af_deemp.empty() || !af_poly.empty() || !t_af_poly.empty() || !af_hpf.empty() || !t_af_hpf.empty();
     for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { any_af = any_af || !af_lvl[s].empty() || !t_af_lvl[s].empty(); }
@@ -1919,6 +1756,7 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
         const int D = P.decim_s[s], K = (int)P.staps[s].size();
         const int no = decim_nout(cur->n, P.soff[s], D);
         if ((size_t)no > nxt->cap) { return fail(c, SDRPP_ERR_INVALID, "pre-processing stage %d: %d outputs exceed the capacity", s, no); }
+        bounds_decim(c->vfo_bounds, P.soff[s], D);  // the reference's blocks behind this stage
         if (P.tp[s].ok) { tj[s].push_back(toep_job(P.tp[s], 0, stream_in(*cur), nxt->data, P.soff[s] - (K - 1), no, 0.0f)); }
         else { fj[s].push_back(FirBJob{ stream_in(*cur), nxt->data, P.d_staps[s], K, ilog2(D), P.soff[s], no, P.s_kp[s] }); }
         P.soff[s] = P.soff[s] + no * D - cur->n;
@@ -2002,6 +1840,14 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
         rc0 = arena_begin(c);
     }
     if (rc0) { return rc0; }
+    {   // the reference's blocks inside this push (sdrpp_set_reference_block): ends as cumulative sample counts
+        std::vector<int>& B = c->vfo_bounds;
+        B.clear();
+        if (c->ref_block > 0) {
+            for (int64_t e = c->ref_block; e < count; e += c->ref_block) { B.push_back((int)e); }
+        }
+        B.push_back((int)count);
+    }
     if (c->pre.on) {
         rc0 = run_preproc(c, &d_iq, &count);
         if (rc0) { return rc0; }
@@ -2271,15 +2117,6 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
-#ifdef SDRPP_CHAIN_PROF
-    {
-        long long h[32];
-        if (hipMemcpy(h, chain_prof_buffer(c), sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "[sdrpp chain prof] iterations %lld (last launch, workgroup (1, 0)); cycles per wavefront: work / barrier wait / stage-0 load / stage-0 mfma\n", h[16]);
-            for (int s = 0; s < 4; s++) { fprintf(stderr, "[sdrpp chain prof]   stage %d: %lld / %lld / %lld / %lld\n", s, h[s * 4], h[s * 4 + 1], h[s * 4 + 2], h[s * 4 + 3]); }
-        }
-    }
-#endif
     preproc_free(c);
     wf_free(c);
     dev_free(c->d_pack);
@@ -2590,7 +2427,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         if (rc) { return rc; }
         rc = upload(c, &v->d_staps_nat[s], v->staps[s].data(), v->staps[s].size());
         if (rc) { return rc; }
-        if (s >= 1) {
+        if (s >= 1 || c->nco_exact) {  // stage 0 runs as a plain FIR only behind the reference rotator
             v->tp_stage[s].kind = 1;
             rc = toep_build_fir(c, v->tp_stage[s], v->staps[s].data(), (int)v->staps[s].size(), d->stage_decim[s]);
             if (rc) { return rc; }
@@ -2603,6 +2440,40 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         if (add_stream(2, hist_after_decim(), cap) < 0) { return SDRPP_ERR_NOMEM; }
     }
     v->i_first = 0;
+    {   // the front end as one filter: fusion decision (geometry only), tap identity, composite taps for the retune hand-over
+        unsigned long long hsh = 1469598103934665603ull;  // FNV-1a over the taps of stages 0 and 1
+        for (int s = 0; s < std::min(d->n_stages, 2); s++) {
+            for (float t : v->staps[s]) {
+                unsigned u;
+                memcpy(&u, &t, 4);
+                hsh = (hsh ^ u) * 1099511628211ull;
+            }
+        }
+        v->tap_hash = hsh;
+        if (d->n_stages >= 2) {  // the composite forms pair taps k and K-1-k: stage 1 must be linear phase as well
+            const std::vector<float>& h2 = v->staps[1];
+            for (size_t k = 0; k < h2.size() / 2; k++) { v->no_fuse = v->no_fuse || (h2[k] != h2[h2.size() - 1 - k]); }
+        }
+        v->fused_front = !c->nco_exact && !v->no_fuse && d->n_stages >= 2 && front2_t2(d->stage_ntaps[0], d->stage_decim[0], d->stage_ntaps[1], d->stage_decim[1], 8) > 0;
+        if (d->n_stages >= 1 && !c->nco_exact) {
+            const int K0 = d->stage_ntaps[0], D1 = d->stage_decim[0], K2 = v->fused_front ? d->stage_ntaps[1] : 1;
+            const int K = K0 + (K2 - 1) * D1;
+            std::vector<double> h12((size_t)K, 0.0);
+            for (int k2 = 0; k2 < K2; k2++) {
+                const double w2 = v->fused_front ? (double)v->staps[1][(size_t)k2] : 1.0;
+                for (int k1 = 0; k1 < K0; k1++) { h12[(size_t)k2 * D1 + k1] += w2 * (double)v->staps[0][(size_t)k1]; }
+            }
+            std::vector<float> hf(h12.begin(), h12.end());
+            rc = upload(c, &v->d_h12, hf.data(), hf.size());
+            if (rc) { return rc; }
+            v->h12_K = K;
+            v->h12_lgD = ilog2(D1) + (v->fused_front ? ilog2(d->stage_decim[1]) : 0);
+        }
+        if (c->nco_exact && d->n_stages >= 1) {  // reference-rotator mode: the rotated full-rate stream feeds stage 0
+            v->i_rot = add_stream(2, d->stage_ntaps[0] - 1, (size_t)c->max_push);
+            if (v->i_rot < 0) { return SDRPP_ERR_NOMEM; }
+        }
+    }
     if (has_poly) {
         v->rtaps.assign(d->resamp_taps, d->resamp_taps + d->resamp_ntaps);
         v->d.resamp_taps = nullptr;
@@ -2675,14 +2546,12 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     v->d.audio_taps = nullptr;
     rc = dev_alloc(c, &v->d_state, 2 * sizeof(AgcState) + sizeof(float));
     if (rc) { return rc; }
+    rc = dev_alloc(c, &v->d_rot, 2);
+    if (rc) { return rc; }
     v->theta = sdrpp_host::turnsPerSample(d->phase_delta_re, d->phase_delta_im);
     v->theta2 = sdrpp_host::turnsPerSample(d->ssb_phase_delta_re, d->ssb_phase_delta_im);
     if (d->demod < SDRPP_DEMOD_USB) { v->theta2 = 0.0; }
     v->modtaps_dirty = true;
-    rc = chain_build(c, *v);
-    if (rc) { return rc; }
-    rc = fuse_build(c, *v);
-    if (rc) { return rc; }
     rc = vfo_reset_state(c, *v);
     if (rc) { return rc; }
     *id = v->id;
@@ -2707,9 +2576,16 @@ int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
+    const double th = sdrpp_host::turnsPerSample(re, im);
+    // the samples already in the first decimator's delay line stay rotated with the old increment (rx_vfo.h:72-77 only swaps
+    // phaseDelta): remember where it changed so the first outputs of the next pushes can be handed over exactly (do_vfos)
+    if (!c->nco_exact && v.d.n_stages > 0 && th != v.theta) {
+        if (!v.recs.empty() && v.recs.back().pos == v.seen) { /* retuned twice between pushes: the older increment stays the one before */ }
+        else { v.recs.push_back(Vfo::Retune{ v.seen, v.theta }); }
+    }
     v.d.phase_delta_re = re;
     v.d.phase_delta_im = im;
-    v.theta = sdrpp_host::turnsPerSample(re, im);
+    v.theta = th;
     v.modtaps_dirty = true;
     return SDRPP_OK;
 }
@@ -2735,9 +2611,7 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
         rc = toep_build_fir(c, v.tp_chan, v.ctaps_chan.data(), n, 1);
         if (rc) { return rc; }
     }
-    int rc2 = chain_build(c, v);  // the fused back end follows the new filter (or steps aside when it is switched off)
-    if (rc2) { return rc2; }
-    return fuse_build(c, v);
+    return SDRPP_OK;
 }
 
 static void af_detach(Vfo& v) {
@@ -2994,6 +2868,31 @@ int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, d
     *strength = out[0];
     *snr = out[1];
     return 1;
+}
+
+int sdrpp_set_reference_block(sdrpp_ctx* c, int ref_block) {
+    if (!c || ref_block < 0) { return SDRPP_ERR_INVALID; }
+    c->ref_block = ref_block;
+    return SDRPP_OK;
+}
+
+int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
+    if (!c || (mode != SDRPP_NCO_CLOSED_FORM && mode != SDRPP_NCO_REFERENCE_ROTATOR)) { return SDRPP_ERR_INVALID; }
+    if (!c->vfos.empty() && mode != c->nco_exact) { return fail(c, SDRPP_ERR_INVALID, "the NCO mode can only change while no VFO exists (it decides how a VFO's front end is built)"); }
+    c->nco_exact = mode;
+    return SDRPP_OK;
+}
+
+int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    auto it = c->vfos.find(id);
+    if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
+    Vfo& v = *it->second;
+    if (v.d.demod < SDRPP_DEMOD_USB) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no SSB demodulator", id); }
+    v.d.ssb_phase_delta_re = re;
+    v.d.ssb_phase_delta_im = im;
+    v.theta2 = sdrpp_host::turnsPerSample(re, im);  // the translation is sample-wise: nothing to hand over, the phase stays continuous
+    return SDRPP_OK;
 }
 
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {

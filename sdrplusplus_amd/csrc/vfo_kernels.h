@@ -247,6 +247,162 @@ __global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob
 }
 
 // =====================================================================================================================
+// Reference-rotator mode (sdrpp_set_nco_mode(ctx, 1); parity runs against the reference's CPU path).
+//
+// The reference's FrequencyXlator (frequency_xlator.h:43-50) calls VOLK's rotator2 once per block: out[i] = in[i] * phase;
+// phase *= phaseDelta in float, phase /= |phase| after every 512 samples and at the end of a call with a remainder.  That phase
+// sequence drifts from arg(phaseDelta) * i by its own rounding (1e-10 .. 2e-9 rad/sample) and its modulus saw-tooths by up to
+// 512 ulp; a product detector (SSB) and the raw IF see both.  The recursion is a strictly sequential float chain, so exactly
+// reproducing it costs one dependent complex multiply per input sample and VFO: here ONE LANE per VFO walks the push, all lanes of
+// a wavefront share the input samples (64 at a time, one coalesced load, v_readlane broadcast) and the 64 x 64 tile of rotated
+// samples goes through LDS so that the stores are coalesced rows.  The rotated stream then feeds the first decimator as a plain
+// FIR (the fused translate + filter kernels cannot be used: their NCO is folded into the taps).  ~50 cycles per sample: a few
+// times real time at 10 MS/s — a parity mode, not the throughput path.
+// `bounds` = cumulative sample counts at which the reference's blocks end inside this push (strictly what its rotator calls saw).
+// =====================================================================================================================
+struct RotXJob {
+    float2* out;    // rotated samples of this push
+    float2* state;  // persistent phase (re, im)
+    float dr, di;   // phaseDelta (frequency_xlator.h:17)
+};
+__device__ __forceinline__ void rotator_norm(float& pr, float& pi) {
+    // hypotf as glibc evaluates it for floats: sqrt in double of the exactly representable squares' sum, rounded once to float
+    const double h2 = ((double)pr * (double)pr) + ((double)pi * (double)pi);
+    const float h = (float)sqrt(h2);
+    pr = pr / h;
+    pi = pi / h;
+}
+__global__ __launch_bounds__(64) void vfo_rotate_exact_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds, int nb) {
+    HIP_DYNAMIC_SHARED(float2, rot_tile)  // [64 samples][65]: column = VFO (lane)
+    const int lane = threadIdx.x;
+    const int jid = (int)blockIdx.x * 64 + lane;
+    const bool live = jid < njobs;
+    const RotXJob job = jobs[live ? jid : njobs - 1];
+    float pr = job.state->x, pi = job.state->y;
+    const float dr = job.dr, di = job.di;
+    const int nrows = min(64, njobs - (int)blockIdx.x * 64);
+    int b0 = 0;
+    for (int blk = 0; blk < nb; blk++) {
+        const int b1 = bounds[blk];
+        int since = 0;  // samples since the start of this call (block)
+        for (int base = b0; base < b1; base += 64) {
+            const int cnt = min(64, b1 - base);
+            const float2 xv = (lane < cnt) ? src.cur[base + lane] : make_float2(0.0f, 0.0f);
+            for (int i = 0; i < cnt; i++) {
+                const float xr = wave_bcast(xv.x, i), xi = wave_bcast(xv.y, i);
+                rot_tile[i * 65 + lane] = make_float2((xr * pr) - (xi * pi), (xr * pi) + (xi * pr));
+                const float nr = (pr * dr) - (pi * di);
+                const float ni = (pr * di) + (pi * dr);
+                pr = nr;
+                pi = ni;
+                since++;
+                if ((since & 511) == 0) { rotator_norm(pr, pi); }
+            }
+            wave_sync();
+            for (int r = 0; r < nrows; r++) {
+                float2* o = jobs[(int)blockIdx.x * 64 + r].out;
+                if (lane < cnt) { o[base + lane] = rot_tile[lane * 65 + r]; }
+            }
+            wave_sync();
+        }
+        if ((since & 511) != 0) { rotator_norm(pr, pi); }
+        b0 = b1;
+    }
+    if (live) { *job.state = make_float2(pr, pi); }
+}
+
+// SSB's second translation (ssb.h:78, a FrequencyXlator at the IF rate) in reference-rotator mode: one wavefront per VFO, every lane
+// evaluates the same (uniform) recursion, lane i keeps Re{x[i] * phase} of sample i of the 64-sample chunk.
+struct SsbRotXJob {
+    const float2* in;
+    float* out;     // Re{} of the rotated samples (ComplexToReal, ssb.h:81-88)
+    float2* state;
+    float dr, di;
+    const int* bounds;
+    int nb;
+};
+__global__ __launch_bounds__(64) void vfo_ssb_rotate_exact_kernel(const SsbRotXJob* __restrict__ jobs) {
+    const SsbRotXJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    float pr = job.state->x, pi = job.state->y;
+    int b0 = 0;
+    for (int blk = 0; blk < job.nb; blk++) {
+        const int b1 = job.bounds[blk];
+        int since = 0;
+        for (int base = b0; base < b1; base += 64) {
+            const int cnt = min(64, b1 - base);
+            const float2 xv = (lane < cnt) ? job.in[base + lane] : make_float2(0.0f, 0.0f);
+            float mine = 0.0f;
+            for (int i = 0; i < cnt; i++) {
+                const float xr = wave_bcast(xv.x, i), xi = wave_bcast(xv.y, i);
+                const float re = (xr * pr) - (xi * pi);
+                if (lane == i) { mine = re; }
+                const float nr = (pr * job.dr) - (pi * job.di);
+                const float ni = (pr * job.di) + (pi * job.dr);
+                pr = nr;
+                pi = ni;
+                since++;
+                if ((since & 511) == 0) { rotator_norm(pr, pi); }
+            }
+            if (lane < cnt) { job.out[base + lane] = mine; }
+        }
+        if ((since & 511) != 0) { rotator_norm(pr, pi); }
+        b0 = b1;
+    }
+    if (lane == 0) { *job.state = make_float2(pr, pi); }
+}
+
+// =====================================================================================================================
+// Retune hand-over of the closed-form NCO (RxVFO::setOffset, rx_vfo.h:72-77).  In the reference only phaseDelta changes: the
+// samples already in the first decimator's delay line stay rotated with the OLD increment, the phase is continuous.  The fused
+// translate + filter kernels rotate a whole filter window with ONE increment, so the first outputs after a retune — those whose
+// window still reaches in front of the retune point — are recomputed here sample by sample with a piecewise phase
+//     phase(n) = seg[s].phi + seg[s].theta * (n - seg[s].start),  seg[s].start <= n < seg[s + 1].start   (turns, push-relative n)
+// and overwrite what the front kernel wrote.  A handful of outputs per retuned VFO; later stages are linear and need nothing.
+// =====================================================================================================================
+#define SDRPP_RETUNE_MAX_SEG 4
+struct RetuneJob {
+    float2* out;          // first-stage (or composite) output stream of this push
+    const float* taps;    // [K] real taps of the (composite) filter
+    int K, log2_decim;
+    int off;              // push-relative IQ index of tap 0 of output 0
+    int nfix;             // outputs 0 .. nfix-1 are recomputed
+    int min_idx;          // IQ samples before this index read as zero
+    int nseg;
+    int start[SDRPP_RETUNE_MAX_SEG];  // ascending; segment 0 covers everything before start[1]
+    double theta[SDRPP_RETUNE_MAX_SEG];
+    double phi[SDRPP_RETUNE_MAX_SEG];
+};
+__global__ __launch_bounds__(64) void vfo_retune_fix_kernel(IqSrc src, const RetuneJob* __restrict__ jobs) {
+    const RetuneJob& job = jobs[blockIdx.y];
+    const int m = (int)blockIdx.x;
+    if (m >= job.nfix) { return; }
+    const int lane = threadIdx.x;
+    const long long i0 = (long long)job.off + ((long long)m << job.log2_decim);
+    float ar = 0.0f, ai = 0.0f;
+    for (int k = lane; k < job.K; k += 64) {
+        const long long n = i0 + k;
+        if (n < job.min_idx) { continue; }
+        int s = 0;
+        for (int q = 1; q < job.nseg; q++) {
+            if (n >= job.start[q]) { s = q; }
+        }
+        double ph = fma((double)(n - job.start[s]), job.theta[s], job.phi[s]);
+        ph -= rint(ph);
+        float sn, cs;
+        sincospif(2.0f * (float)ph, &sn, &cs);
+        const float2 x = iq_load_clamped(src, n);
+        const float h = job.taps[k];
+        const float rr = (x.x * cs) - (x.y * sn), ri = (x.x * sn) + (x.y * cs);
+        ar = fmaf(h, rr, ar);
+        ai = fmaf(h, ri, ai);
+    }
+    ar = wave_sum(ar);
+    ai = wave_sum(ai);
+    if (lane == 0) { job.out[m] = make_float2(ar, ai); }
+}
+
+// =====================================================================================================================
 // Polyphase rational resampler (polyphase_resampler.h:75-93):
 //   A_n = phase0 + n*M;  out[n] = sum_k bank[A_n mod L][k] * in[offset0 + A_n div L + k - (tpp-1)]
 // bank[(L-1) - (i mod L)][i div L] = taps[i] (polyphase_bank.h:31-34) is laid out [phase][tpp] on the host.
@@ -327,7 +483,7 @@ __device__ __forceinline__ float normalize_phase(float d) {
 // Sequential tails at IF rate — one work-item per VFO, exactly the reference's per-sample recursions:
 //   AM  (am.h:101-131): [carrier AGC] -> |x| -> DC blocker (dc_blocker.h:54-60) -> [audio AGC] -> (LPF runs afterwards as a FIR job)
 //   SSB (ssb.h:77-92) : second translation (closed-form NCO) -> Re{} -> AGC (agc.h:70-109) -> {v, v}
-// The AGC look-ahead on clipping scans to the end of the push (the reference scans to the end of its block).
+// The AGC look-ahead on clipping scans to the end of the reference block (SeqJob::bounds; without them: to the end of the push).
 // =====================================================================================================================
 struct AgcState {
     float set_point, attack, inv_attack, decay, inv_decay, max_gain, max_output_amp, amp;
@@ -367,6 +523,10 @@ struct SeqJob {
     float* dc_offset;  // persistent
     float dc_rate;
     int carrier_mode;
+    // reference blocks inside this push (cumulative sample counts; nullptr: the push is one block).  loop::AGC's look-ahead on
+    // clipping scans to the end of the CURRENT BLOCK (agc.h:91-104), so its result depends on how the reference cut the stream.
+    const int* bounds;
+    int nb;
 };
 
 __device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
@@ -392,12 +552,15 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
     if (id >= njobs) { return; }
     const SeqJob job = jobs[id];
     const int lane = threadIdx.x;
-    const int n = job.n;
+    const int nblk = job.bounds ? job.nb : 1;
     if (job.mode == 2) {
         AgcState agc = *job.agc;
         AgcState cagc = *job.carrier_agc;
         float off = *job.dc_offset;
-        for (int base = 0; base < n; base += 64) {
+        int blk_lo = 0;
+        for (int blk = 0; blk < nblk; blk++) {
+        const int n = job.bounds ? job.bounds[blk] : job.n;  // end of this reference block
+        for (int base = blk_lo; base < n; base += 64) {
             const int cnt = (n - base < 64) ? n - base : 64;
             float2 xin = make_float2(0.0f, 0.0f);
             float pv = 0.0f;
@@ -468,6 +631,8 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
             }
             if (lane < cnt) { job.pre[base + lane] = outv; }
         }
+        blk_lo = n;
+        }
         if (lane == 0) {
             *job.agc = agc;
             *job.carrier_agc = cagc;
@@ -477,7 +642,10 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
     else {
         AgcState agc = *job.agc;
         float2* out = reinterpret_cast<float2*>(job.out);
-        for (int base = 0; base < n; base += 64) {
+        int blk_lo = 0;
+        for (int blk = 0; blk < nblk; blk++) {
+        const int n = job.bounds ? job.bounds[blk] : job.n;
+        for (int base = blk_lo; base < n; base += 64) {
             const int cnt = (n - base < 64) ? n - base : 64;
             const float pv = (lane < cnt) ? job.pre[base + lane] : 0.0f;
             float outv = 0.0f;
@@ -499,6 +667,8 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
                 if (lane == i) { outv = v; }
             }
             if (lane < cnt) { out[base + lane] = make_float2(outv, outv); }
+        }
+        blk_lo = n;
         }
         if (lane == 0) { *job.agc = agc; }
     }
@@ -547,6 +717,25 @@ struct FirBJob {
     int ntaps, log2_decim, off0, nout, kp_pad;
     float inv_deviation;  // QUAD only
 };
+
+// Decimating FIR on a complex stream whose window fits neither the matrix-core table nor an LDS tile (decimation 32 / 64 with hundreds
+// of taps as a PLAIN filter: only in reference-rotator mode, where the first stage cannot be fused with the translation).  One output
+// per work-item straight from global memory, k-ordered fmaf chain.  Correctness path of a parity mode, not tuned.
+__global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __restrict__ jobs) {
+    const FirBJob& job = jobs[blockIdx.y];
+    const int D = 1 << job.log2_decim, kp = job.kp_pad;
+    for (int j = (int)(blockIdx.x * blockDim.x + threadIdx.x); j < job.nout; j += (int)(gridDim.x * blockDim.x)) {
+        const int i0 = job.off0 + (j << job.log2_decim) - (job.ntaps - 1);
+        float2 acc = make_float2(0.0f, 0.0f);
+        for (int k = 0; k < job.ntaps; k++) {
+            const float h = job.taps[(size_t)(k & (D - 1)) * kp + (size_t)(k >> job.log2_decim)];
+            const float2 x = stream_load2(job.in, i0 + k);
+            acc.x = fmaf(h, x.x, acc.x);
+            acc.y = fmaf(h, x.y, acc.y);
+        }
+        reinterpret_cast<float2*>(job.out)[j] = acc;
+    }
+}
 
 // QUAD (WIDTH 1, decimation 1): the input stream is the complex IF and the FM discriminator (quadrature.h:39-46) runs while the
 // tile is loaded — d[i] = normalizePhase(atan2f(x[i]) - atan2f(x[i-1])) * invDeviation — so the demodulated stream never goes
@@ -1494,279 +1683,6 @@ __global__ __launch_bounds__(256, WS ? 3 : 5) void vfo_toep_kernel(const ToepJob
             }
         }
         if (!piped) { wave_sync(); }  // the next macro tile overwrites the window
-    }
-}
-
-// =====================================================================================================================
-// Two consecutive per-VFO filters in ONE launch, the stream between them never leaving the CU (SDRPP_GPU_FUSE, opt-in):
-//   MODE 0   decimating FIR (stage A)  ->  FIR / polyphase resampler (stage B)           e.g. last decimator -> resampler
-//   MODE 1   FIR (stage A) -> FM discriminator -> real FIR (stage B), mono -> stereo     channel filter -> demodulator -> audio low-pass
-// Both stages are the banded-Toeplitz products of vfo_toep_kernel with the same tables, so every output is the same k-ordered fmaf
-// chain (zero taps add exact zeros): results are bit-identical to the two separate launches.  A wavefront walks CONSECUTIVE macro
-// tiles of stage B; each needs 32 * s_inB = 480 new stage-A outputs — exactly two matrix chains — which it computes from the input
-// window (prefetched a round ahead as in vfo_toep_kernel) straight into the stage-B window in LDS; the `carry` outputs that window
-// shares with the previous macro tile are moved to its front, and only the first macro tile of a wavefront recomputes them
-// (one or two extra chains per wavefront and launch).  What it saves is the HBM round trip of the intermediate stream and one
-// launch; the algorithmic work is unchanged.
-// =====================================================================================================================
-struct Toep2Job {
-    StreamIn in;            // input stream of stage A (complex)
-    float* out;             // output of stage B
-    const float* tlA;       // stage A: tap table / lane bases / geometry as in ToepJob (rows = 15, s_inA = 15 * decimation)
-    const int* lbaseA;
-    int tl_lenA, nstepsA, s_inA;
-    const float* tlB;       // stage B
-    const int* lbaseB;
-    int tl_lenB, nstepsB, s_inB, rowsB;
-    int base0A;             // stage-A INPUT index of window offset 0 of stage-A output 0 of this push
-    int base0B;             // stage-A OUTPUT index of window offset 0 of stage-B tile 0 (MODE 1: index of the discriminator output)
-    int nout;               // stage-B outputs of this push
-    int mt_per_wave;
-    float inv_deviation;    // MODE 1
-};
-
-// G (<= 2) chains of 16 tiles: acc[g] += window(tile, k) * taps(k, m).  CPLX: interleaved complex window (one ds_read_b64 feeds both products)
-template <bool CPLX>
-__device__ __forceinline__ void toep_chains(const float* Bp, const float* Aw, int s_in, int nsteps, int nch, f32x4 (&accR)[2], f32x4 (&accI)[2]) {
-    const float2* A2 = reinterpret_cast<const float2*>(Aw);
-    constexpr int U = CPLX ? 4 : 8;
-    int t0 = 0;
-    for (; t0 + U <= nsteps; t0 += U) {
-        float b[U], xr[U][2], xi[U][2];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            b[u] = Bp[4 * (t0 + u)];
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                if (g < nch) {
-                    if constexpr (CPLX) {
-                        const float2 a = A2[g * 16 * s_in + 4 * (t0 + u)];
-                        xr[u][g] = a.x;
-                        xi[u][g] = a.y;
-                    }
-                    else { xr[u][g] = Aw[g * 16 * s_in + 4 * (t0 + u)]; }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                if (g < nch) {
-                    accR[g] = mfma_16x16x4(xr[u][g], b[u], accR[g]);
-                    if constexpr (CPLX) { accI[g] = mfma_16x16x4(xi[u][g], b[u], accI[g]); }
-                }
-            }
-        }
-    }
-    for (; t0 < nsteps; t0++) {
-        const float b = Bp[4 * t0];
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            if (g < nch) {
-                if constexpr (CPLX) {
-                    const float2 a = A2[g * 16 * s_in + 4 * t0];
-                    accR[g] = mfma_16x16x4(a.x, b, accR[g]);
-                    accI[g] = mfma_16x16x4(a.y, b, accI[g]);
-                }
-                else { accR[g] = mfma_16x16x4(Aw[g * 16 * s_in + 4 * t0], b, accR[g]); }
-            }
-        }
-    }
-}
-
-// LDS floats of one wavefront: stage-A input window (interleaved complex) + stage-B window (MODE 0: interleaved complex;
-// MODE 1: phases + discriminator output).  Shared by the kernel and the host's launch planning.
-__host__ __device__ inline int toep2_wave_floats(int mode, int s_inA, int nstepsA, int s_inB, int nstepsB) {
-    const int spanA = 31 * s_inA + 4 * nstepsA, spanB = 31 * s_inB + 4 * nstepsB;
-    const int carry = spanB > 32 * s_inB ? spanB - 32 * s_inB : 0;
-    const int plA = (spanA + 8) & ~3, plB = (carry + 32 * s_inB + 12) & ~3;
-    return 2 * plA + 2 * plB;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void vfo_toep2_kernel(const Toep2Job* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smemt2)
-    const Toep2Job job = jobs[blockIdx.y];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nA = job.nstepsA, sA = job.s_inA, nB = job.nstepsB, sB = job.s_inB, rowsB = job.rowsB;
-    const int dA = sA / 15;                      // decimation of stage A
-    const int newB = 32 * sB;                    // stage-A outputs one macro tile of stage B consumes (= 480: two chains; the host checks)
-    const int spanA = 31 * sA + 4 * nA;          // input window of two stage-A chains
-    const int spanA1 = 15 * sA + 4 * nA;         // ... of one chain (pre-roll)
-    const int spanB = 31 * sB + 4 * nB;          // stage-B window
-    const int carry = spanB > newB ? spanB - newB : 0;
-    const int plA = (spanA + 8) & ~3, plB = (carry + newB + 12) & ~3;
-    const int tlA_pad = (job.tl_lenA + 3) & ~3, tlB_pad = (job.tl_lenB + 3) & ~3;
-    float* TLA = smemt2;
-    float* TLB = smemt2 + tlA_pad;
-    float* XA = smemt2 + tlA_pad + tlB_pad + wv * (2 * plA + 2 * plB);  // stage-A input window, interleaved (re, im)
-    float* WB = XA + 2 * plA;                                        // MODE 0: stage-B window, interleaved; MODE 1: phases PH
-    float* XR = WB + plB;                                            // MODE 1: discriminator output (stage-B window)
-    for (int i = tid; i < job.tl_lenA; i += 256) { TLA[i] = global_load_f32(job.tlA, i); }
-    for (int i = tid; i < job.tl_lenB; i += 256) { TLB[i] = global_load_f32(job.tlB, i); }
-    __syncthreads();  // the only workgroup barrier
-    const int c = lane & 15, kk = lane >> 4;
-    const float* BpA = TLA + global_load_i32(job.lbaseA, lane);
-    const float* BpB = TLB + global_load_i32(job.lbaseB, lane);
-    float2* XA2 = reinterpret_cast<float2*>(XA);
-    float2* WB2 = reinterpret_cast<float2*>(WB);
-    const float* AwA = XA + 2 * (c * sA + kk);
-    const float* AwB = (MODE == 0) ? WB + 2 * (c * sB + kk) : XR + (c * sB + kk);
-    const int omt = 32 * rowsB;                                       // stage-B outputs per macro tile
-    const int nmt = (job.nout + omt - 1) / omt;
-    const int mt_first = (blockIdx.x * 4 + wv) * job.mt_per_wave;
-    if (mt_first >= nmt) { return; }
-    const int mt_end = min(nmt, mt_first + job.mt_per_wave);
-    constexpr int EXTRA = (MODE == 1) ? 1 : 0;                        // MODE 1 keeps one more phase in front: d[i] uses x[i - 1]
-    // stage-A output index (IF sample index in MODE 1) of the first NEW sample of macro tile mt, and where it lands in the window
-    auto new0 = [&](int mt) { return job.base0B - EXTRA + mt * newB + carry + EXTRA; };
-    // store two (or one) chains of stage-A results: lane holds outputs (g * 16 + 4 * kk + r) * 15 + c of the chain group
-    auto put = [&](const f32x4 (&aR)[2], const f32x4 (&aI)[2], int nch, int w0) {
-        if (c < 15) {
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                if (g < nch) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int w = w0 + (g * 16 + 4 * kk + r) * 15 + c;
-                        if (w >= 0) {
-                            if constexpr (MODE == 0) { WB2[w] = make_float2(aR[g][r], aI[g][r]); }
-                            else { WB[w] = fm_phase(aI[g][r], aR[g][r]); }
-                        }
-                    }
-                }
-            }
-        }
-    };
-    // ---- pre-roll: the `carry` (+1) stage-A outputs in front of the first macro tile, one chain of 240 at a time ----
-    {
-        const int need = carry + EXTRA;
-        const int npre = (need + 239) / 240;
-        for (int q = 0; q < npre; q++) {
-            const int a0 = new0(mt_first) - 240 * (npre - q);         // first stage-A output of this chain
-            const int lo = job.base0A + dA * a0;
-            wave_sync();
-            for (int s = lane; s < spanA1; s += 64) { XA2[s] = stream_load2(job.in, lo + s); }
-            wave_sync();
-            f32x4 aR[2] = { mfma4_zero(), mfma4_zero() }, aI[2] = { mfma4_zero(), mfma4_zero() };
-            toep_chains<true>(BpA, AwA, sA, nA, 1, aR, aI);
-            put(aR, aI, 1, need - 240 * (npre - q));
-        }
-    }
-    // ---- steady state: input windows prefetched into registers a round ahead ----
-    constexpr int PF4 = 9;  // sample pairs per lane: windows up to 1152 samples are pipelined, longer ones are loaded in place
-    const int npair = (spanA + 1) >> 1;
-    const bool piped = npair <= PF4 * 64;
-    float4 pf4[PF4];
-    auto fetch = [&](int mt) {
-        const int lo = job.base0A + dA * new0(mt);
-        const bool inside = lo >= 0 && lo + spanA + 1 <= job.in.n;
-        if (inside) {
-#pragma unroll
-            for (int q = 0; q < PF4; q++) {
-                const int e = q * 64 + lane;
-                pf4[q] = (e < npair) ? global_load_f32x4_unaligned(job.in.data, 2ll * (lo + 2 * e)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
-        else {
-#pragma unroll
-            for (int q = 0; q < PF4; q++) {
-                const int e = q * 64 + lane;
-                float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
-                if (e < npair) {
-                    a = stream_load2(job.in, lo + 2 * e);
-                    b = stream_load2(job.in, lo + 2 * e + 1);
-                }
-                pf4[q] = make_float4(a.x, a.y, b.x, b.y);
-            }
-        }
-    };
-    auto window_store = [&]() {
-        float4* X4 = reinterpret_cast<float4*>(XA);
-#pragma unroll
-        for (int q = 0; q < PF4; q++) {
-            const int e = q * 64 + lane;
-            if (e < npair) { X4[e] = pf4[q]; }
-        }
-    };
-    if (piped) {
-        fetch(mt_first);
-        wave_sync();
-        window_store();
-        if (mt_first + 1 < mt_end) { fetch(mt_first + 1); }
-    }
-    for (int mt = mt_first; mt < mt_end; mt++) {
-        if (!piped) {
-            const int lo = job.base0A + dA * new0(mt);
-            wave_sync();
-            for (int s = lane; s < spanA; s += 64) { XA2[s] = stream_load2(job.in, lo + s); }
-        }
-        wave_sync();
-        // stage A: 480 new outputs
-        f32x4 aR[2] = { mfma4_zero(), mfma4_zero() }, aI[2] = { mfma4_zero(), mfma4_zero() };
-        toep_chains<true>(BpA, AwA, sA, nA, 2, aR, aI);
-        // the part of the stage-B window shared with the previous macro tile moves to the front (read all, then write)
-        if (mt > mt_first && carry + EXTRA > 0) {
-            const int ncar = carry + EXTRA;
-            if constexpr (MODE == 0) {
-                float2 t[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int s = q * 64 + lane;
-                    t[q] = (s < ncar) ? WB2[newB + s] : make_float2(0.0f, 0.0f);
-                }
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int s = q * 64 + lane;
-                    if (s < ncar) { WB2[s] = t[q]; }
-                }
-            }
-            else {
-                float t[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int s = q * 64 + lane;
-                    t[q] = (s < ncar) ? WB[newB + s] : 0.0f;
-                }
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int s = q * 64 + lane;
-                    if (s < ncar) { WB[s] = t[q]; }
-                }
-            }
-        }
-        put(aR, aI, 2, carry + EXTRA);
-        if constexpr (MODE == 1) {
-            // quadrature.h:39-46: d[i] = normalizePhase(phase[i] - phase[i-1]) * invDeviation
-            wave_sync();
-            for (int s = lane; s < spanB; s += 64) { XR[s] = normalize_phase(WB[s + 1] - WB[s]) * job.inv_deviation; }
-        }
-        wave_sync();
-        // stage B on the window
-        f32x4 bR[2] = { mfma4_zero(), mfma4_zero() }, bI[2] = { mfma4_zero(), mfma4_zero() };
-        toep_chains<MODE == 0>(BpB, AwB, sB, nB, 2, bR, bI);
-        if (piped && mt + 1 < mt_end) {
-            window_store();  // stage A has consumed its window
-            if (mt + 2 < mt_end) { fetch(mt + 2); }
-            sched_fence();
-        }
-        if (c < rowsB) {
-            const int obase = mt * omt;
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int o = obase + (g * 16 + 4 * kk + r) * rowsB + c;
-                    if (o < job.nout) {
-                        if constexpr (MODE == 0) { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(bR[g][r], bI[g][r])); }
-                        else { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(bR[g][r], bR[g][r])); }  // mono -> stereo
-                    }
-                }
-            }
-        }
     }
 }
 

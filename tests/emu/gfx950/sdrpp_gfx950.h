@@ -17,6 +17,14 @@ static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = 
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
+static inline float wave_sum(float v) {  // same butterfly order as the device's shfl_xor reduction
+    float cur = v;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float* ab = hipemu::wave_exchange(cur, 0.0f);
+        cur = cur + ab[(hipemu::lane_id() ^ d) * 2];
+    }
+    return cur;
+}
 static inline float wave_max(float v) {
     const float* ab = hipemu::wave_exchange(v, 0.0f);
     float m = ab[0];

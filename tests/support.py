@@ -67,6 +67,9 @@ def oracle():
         L.orc_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.orc_rxvfo_info.argtypes = [C.c_void_p] + [c_int_p] * 8
         L.orc_rxvfo_phase_delta.argtypes = [C.c_void_p, c_float_p, c_float_p]
+        L.orc_rxvfo_set_ideal_nco.argtypes = [C.c_void_p, C.c_int]
+        L.orc_demod_set_ideal_nco.argtypes = [C.c_void_p, C.c_int]
+        L.orc_xlator_set_ideal.argtypes = [C.c_void_p, C.c_int]
         L.orc_demod_create.restype = C.c_void_p
         L.orc_demod_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
         L.orc_demod_destroy.argtypes = [C.c_void_p]
@@ -225,7 +228,9 @@ def oracle_palette_index(zoomed, wmin, wmax):
 class _Chain:
     """RxVFO + demodulator pair driven block by block, backed by either the oracle or the compiled reference."""
 
-    def __init__(self, lib, prefix, in_sr, out_sr, bw, offset, mode, low_pass=True, agc_attack=50.0, agc_decay=5.0, carrier_agc=False):
+    def __init__(self, lib, prefix, in_sr, out_sr, bw, offset, mode, low_pass=True, agc_attack=50.0, agc_decay=5.0, carrier_agc=False, ideal_nco=False):
+        """ideal_nco (oracle only, a TEST SWITCH): both frequency translations use a float64 NCO at arg(phaseDelta_f32) instead of the
+        float recursion; everything else is the pinned restatement.  Isolates what the recursion's rounding contributes."""
         self.lib, self.p = lib, prefix
         g = lambda name: getattr(lib, prefix + name)
         if prefix == "orc_":
@@ -235,6 +240,11 @@ class _Chain:
         self.dem = None
         if mode is not None:
             self.dem = g("demod_create")(mode, bw, out_sr, int(low_pass), agc_attack, agc_decay, int(carrier_agc))
+        if ideal_nco:
+            assert prefix == "orc_", "the ideal-NCO switch exists in the oracle only"
+            lib.orc_rxvfo_set_ideal_nco(self.vfo, 1)
+            if self.dem is not None:
+                lib.orc_demod_set_ideal_nco(self.dem, 1)
 
     def vfo_process(self, iq):
         iq = c64(iq)
