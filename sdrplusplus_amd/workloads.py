@@ -84,17 +84,18 @@ def to_int16_wav_samples(x):
     return np.clip(np.rint(v * 32767.0 * 0.5), -32768, 32767).astype(np.int16)
 
 
-def setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=None, window_kind=2, wf_min=-120.0, wf_max=0.0):
-    """Configure a capi.Context for a BASELINE configuration.  Returns dict(vids, plan, nz, skip, fft)."""
+def setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=None, window_kind=2, wf_min=-120.0, wf_max=0.0, fft=True):
+    """Configure a capi.Context for a BASELINE configuration (fft=False: VFO bank only).  Returns dict(vids, plan, nz, skip, fft)."""
     c = CFG[cfg]
     sr, N = c["sr"], c["fft"]
     if dense_fft and c["fft_rate"] is None:
         nz, skip = N, 0  # every sample transformed (headline framing)
     else:
         nz, skip = capi.design_reshape_params(sr, N, c["fft_rate"] or 20.0)
-    ctx.fft_configure(N, nz, skip, capi.design_fft_window(window_kind, nz))
     start, size = capi.design_waterfall_view(0.0, sr, sr, N)  # full view
-    ctx.fft_set_view(start, size, data_width, wf_min, wf_max)
+    if fft:
+        ctx.fft_configure(N, nz, skip, capi.design_fft_window(window_kind, nz))
+        ctx.fft_set_view(start, size, data_width, wf_min, wf_max)
     vids = []
     plan = vfo_plan(cfg, nvfo)
     for mode, if_rate, bw, centre, _ in plan:
