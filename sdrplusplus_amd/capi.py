@@ -158,6 +158,7 @@ def load():
     L.sdrpp_vfo_set_channel_taps.argtypes = [vp, C.c_int, c_float_p, C.c_int]
     L.sdrpp_vfo_reset.argtypes = [vp, C.c_int]
     L.sdrpp_set_reference_block.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_read_many.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int64, C.POINTER(C.c_int64), c_int_p]
     L.sdrpp_set_nco_mode.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_set_ssb_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.sdrpp_vfo_out_count.argtypes = [vp, C.c_int]
@@ -186,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
-    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -370,6 +371,18 @@ class Context:
         out = np.empty((max(n, 1), 2), dtype=np.float32)
         got = self._chk(self.L.sdrpp_vfo_read(self.h, vid, out.ctypes.data_as(c_float_p), n))
         return out[:got]
+
+    def vfo_read_many(self, vids, which=None):
+        """Outputs of many VFOs with one device-to-host copy -> list of [n, 2] float32 arrays (views into one buffer)."""
+        n = len(vids)
+        ids = (C.c_int * max(n, 1))(*[int(v) for v in vids])
+        wh = (C.c_int * max(n, 1))(*[int(w) for w in which]) if which is not None else None
+        total = sum(self.vfo_out_count(v) for v in vids) if which is None else self.max_push * n
+        buf = np.empty((max(total, 1), 2), dtype=np.float32)
+        offs = (C.c_int64 * max(n, 1))()
+        cnts = (C.c_int * max(n, 1))()
+        self._chk(self.L.sdrpp_vfo_read_many(self.h, n, ids, wh, buf.ctypes.data_as(c_float_p), len(buf), offs, cnts))
+        return [buf[offs[i]:offs[i] + cnts[i]] for i in range(n)]
 
     def vfo_read_pcm(self, vid, which, pcm_type, scale, max_frames):
         dt = np.int16 if pcm_type == 1 else np.int8

@@ -179,6 +179,10 @@ struct sdrpp_ctx {
 
     char* d_pack = nullptr;  // scratch of the packed-sample reads (sdrpp_vfo_read_pcm / _compressed)
     size_t pack_cap = 0;
+    float2* d_gather = nullptr;     // sdrpp_vfo_read_many: packed outputs + job table
+    size_t gather_cap = 0;          // samples
+    GatherJob* d_gather_jobs = nullptr;
+    int gather_jobs_cap = 0;
 
     // job arena
     char* arena_host[kArenaSlots] = {};
@@ -2120,6 +2124,8 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     preproc_free(c);
     wf_free(c);
     dev_free(c->d_pack);
+    dev_free(c->d_gather);
+    dev_free(c->d_gather_jobs);
     for (auto& kv : c->vfos) { vfo_free(*kv.second); }
     c->vfos.clear();
     for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
@@ -2920,6 +2926,47 @@ int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (n > 0) { HIPCHK(c, hipMemcpy(dst, s->data, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
     return n;
+}
+
+int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, float* dst_host, int64_t max_samples, int64_t* offsets, int* counts) {
+    if (!c || n < 0 || (n > 0 && (!ids || !dst_host || !offsets || !counts)) || max_samples < 0) { return SDRPP_ERR_INVALID; }
+    std::vector<GatherJob> jobs;
+    int64_t total = 0;
+    int mx = 0;
+    for (int i = 0; i < n; i++) {
+        auto it = c->vfos.find(ids[i]);
+        if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", ids[i]); }
+        Stream* s = pick_stream(c, *it->second, which ? which[i] : 0);
+        if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no such stream (%d)", ids[i], which ? which[i] : 0); }
+        offsets[i] = total;
+        counts[i] = s->n;
+        if (s->n > 0) { jobs.push_back(GatherJob{ (const float2*)s->data, (long long)total, s->n }); }
+        mx = std::max(mx, s->n);
+        total += s->n;
+    }
+    if (total > max_samples) { return fail(c, SDRPP_ERR_INVALID, "the outputs need room for %lld samples", (long long)total); }
+    if (total == 0) { return 0; }
+    if ((size_t)total > c->gather_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_gather);
+        c->gather_cap = 0;
+        int rc = dev_alloc(c, &c->d_gather, (size_t)total + 4096);
+        if (rc) { return rc; }
+        c->gather_cap = (size_t)total + 4096;
+    }
+    if ((int)jobs.size() > c->gather_jobs_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_gather_jobs);
+        c->gather_jobs_cap = 0;
+        int rc = dev_alloc(c, &c->d_gather_jobs, jobs.size() + 64);
+        if (rc) { return rc; }
+        c->gather_jobs_cap = (int)jobs.size() + 64;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_gather_jobs, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)jobs.size()), dim3(256), 0, c->stream, (const GatherJob*)c->d_gather_jobs, c->d_gather);
+    HIPCHK(c, hipMemcpyAsync(dst_host, c->d_gather, (size_t)total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps `jobs` alive until the upload has been consumed
+    return (int)std::min<int64_t>(total, 0x7fffffff);
 }
 
 int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out, const float** if_out, int* n_if) {

@@ -697,6 +697,20 @@ __global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__
 }
 
 // =====================================================================================================================
+// Output gather (sdrpp_vfo_read_many): the per-VFO output blocks of one push packed back to back, so that the host gets all of them
+// with ONE device-to-host copy instead of one small copy (and stream synchronisation) per VFO.
+// =====================================================================================================================
+struct GatherJob {
+    const float2* src;
+    long long dst_off;  // samples
+    int n;
+};
+__global__ __launch_bounds__(256) void gather_kernel(const GatherJob* __restrict__ jobs, float2* __restrict__ dst) {
+    const GatherJob job = jobs[blockIdx.y];
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < job.n; i += (int)(gridDim.x * blockDim.x)) { dst[job.dst_off + i] = job.src[i]; }
+}
+
+// =====================================================================================================================
 // Register-blocked kernels (round-1 optimisation of the measured bottleneck).
 //
 // The generic FIR above issues one ds_read per two FMAs and is LDS-bound at ~10 TFLOP/s.  Here every work-item computes

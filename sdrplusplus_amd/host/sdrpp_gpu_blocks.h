@@ -1,25 +1,23 @@
 // Host-side C++ mirror of the reference's plugin/operator surface for the hot path, on top of the C-ABI
-// (include/sdrpp_gpu.h).  Header-only, like the reference's DSP library.
-//
-// Two ways to use it:
-//   * inside an SDR++ tree: compile with -DSDRPP_GPU_USE_SDRPP_DSP and SDR++'s core/src on the include path — the blocks
-//     then derive from the real dsp::block and speak the real dsp::stream<T> (core/src/dsp/block.h, stream.h);
-//   * stand-alone (tests, other hosts): the minimal `dsp::stream<T>` / `dsp::block` below reproduce the reference's
-//     contract — double-buffered swap()/read()/flush(), stopWriter/stopReader, one worker thread per block running
-//     `while (run() >= 0)`, tempStop/tempStart around reconfiguration (block.h:46-94, stream.h:43-116).
+// (include/sdrpp_gpu.h).  Header-only, like the reference's DSP library, and written against SDR++'s own block / stream headers:
+// compile with SDR++'s core/src on the include path — the blocks derive from the real dsp::block and speak the real dsp::stream<T>
+// (core/src/dsp/block.h, stream.h, types.h).  (tests/host_cpp/standalone holds a small test double of those three headers so the
+// mirror can also be built and run on a machine without the SDR++ tree.)
 //
 // Blocks:
-//   sdrpp_gpu::IQFrontEnd  — same public API as the reference's IQFrontEnd (core/src/signal_path/iq_frontend.h:12-49):
-//       init(in, sampleRate, buffering, decimRatio, dcBlocking, fftSize, fftRate, fftWindow, acquireFFTBuffer,
-//       releaseFFTBuffer, fftCtx), setFFTSize/Rate/Window, setSampleRate, addVFO/removeVFO, start/stop,
-//       getEffectiveSamplerate.  One worker thread replaces inBuf + Splitter + Reshaper + Handler + every RxVFO thread:
-//       it reads a block from the input stream, hands it to sdrpp_push (one H2D copy, all kernels), then delivers the
-//       finished dB lines through the same acquire/release callback pair (iq_frontend.cpp:258-266) and swaps every VFO's
-//       output stream.
-//   sdrpp_gpu::RxVFO — what addVFO returns: public `out` stream + setOffset / setBandwidth / setOutSamplerate / reset with
-//       the reference's meaning (core/src/dsp/channel/rx_vfo.h:38-87).  With a demodulator attached (attachDemod) the
+//   sdrpp_gpu::IQFrontEnd  — the public API of the reference's IQFrontEnd (core/src/signal_path/iq_frontend.h:12-49), call for call:
+//       init(in, sampleRate, buffering, decimRatio, dcBlocking, fftSize, fftRate, fftWindow, acquireFFTBuffer, releaseFFTBuffer,
+//       fftCtx), setInput, setSampleRate / getSampleRate, setBuffering, setDecimation, setInvertIQ, setDCBlocking,
+//       bindIQStream / unbindIQStream, addVFO / removeVFO, setFFTSize / Rate / Window, flushInputBuffer, start / stop,
+//       getEffectiveSamplerate.  One worker replaces inBuf + preproc + Splitter + Reshaper + Handler + every RxVFO thread: it takes
+//       a block from the input stream (directly, or through a 32-slot frame buffer when buffering is on — frame_buffer.h:51-98),
+//       hands it to sdrpp_push (one H2D copy, all kernels), delivers the finished dB lines through the acquire / release callback
+//       pair (iq_frontend.cpp:258-266), the pre-processed IQ to every stream bound with bindIQStream (Splitter::run,
+//       routing/splitter.h:46-61) and one block on every VFO's output stream (all VFO outputs arrive in ONE D2H copy).
+//   sdrpp_gpu::RxVFO — what addVFO returns: public `out` stream + setInSamplerate / setOutSamplerate / setBandwidth / setOffset /
+//       reset with the reference's meaning (core/src/dsp/channel/rx_vfo.h:38-87).  With a demodulator attached (attachDemod) the
 //       demodulated audio is delivered on `audio` (dsp::stream<stereo_t>), which is what radio's Demodulator::getOutput()
-//       returns (decoder_modules/radio/src/demod.h:60).
+//       returns (decoder_modules/radio/src/demod.h:60); sdrpp_gpu_radio.h wraps that as a demod::Demodulator.
 #pragma once
 #include <atomic>
 #include <cassert>
@@ -38,119 +36,14 @@
 
 #include "../../include/sdrpp_gpu.h"
 
-#ifdef SDRPP_GPU_USE_SDRPP_DSP
 #include <dsp/block.h>
 #include <dsp/stream.h>
 #include <dsp/types.h>
+#if defined(__has_include)
+#if __has_include(<dsp/multirate/decim/plans.h>)
 #include <dsp/multirate/decim/plans.h>
-#define SDRPP_GPU_STREAM_BUFFER_SIZE STREAM_BUFFER_SIZE
-#else
-#define SDRPP_GPU_STREAM_BUFFER_SIZE 1000000  // STREAM_BUFFER_SIZE, core/src/dsp/stream.h:9
-namespace dsp {
-struct complex_t { float re, im; };
-struct stereo_t { float l, r; };
-
-class untyped_stream {
-public:
-    virtual ~untyped_stream() {}
-    virtual void stopWriter() {}
-    virtual void clearWriteStop() {}
-    virtual void stopReader() {}
-    virtual void clearReadStop() {}
-};
-
-// Same hand-off protocol as the reference's stream<T>: the producer fills writeBuf and calls swap(n) (blocks until the
-// consumer has flushed the previous block; false when stopped); the consumer calls read() (-1 when stopped), uses
-// readBuf[0..n) and calls flush().  The two pointers are exchanged on every swap.
-template <class T>
-class stream : public untyped_stream {
-public:
-    stream() {
-        writeBuf = (T*)aligned_alloc(64, sizeof(T) * SDRPP_GPU_STREAM_BUFFER_SIZE);
-        readBuf = (T*)aligned_alloc(64, sizeof(T) * SDRPP_GPU_STREAM_BUFFER_SIZE);
-    }
-    ~stream() override { free(writeBuf); free(readBuf); }
-    bool swap(int size) {
-        {
-            std::unique_lock<std::mutex> lck(swapMtx);
-            swapCV.wait(lck, [this] { return canSwap || writerStop; });
-            if (writerStop) { return false; }
-            dataSize = size;
-            std::swap(writeBuf, readBuf);
-            canSwap = false;
-        }
-        { std::lock_guard<std::mutex> lck(rdyMtx); dataReady = true; }
-        rdyCV.notify_all();
-        return true;
-    }
-    int read() {
-        std::unique_lock<std::mutex> lck(rdyMtx);
-        rdyCV.wait(lck, [this] { return dataReady || readerStop; });
-        return readerStop ? -1 : dataSize;
-    }
-    void flush() {
-        { std::lock_guard<std::mutex> lck(rdyMtx); dataReady = false; }
-        { std::lock_guard<std::mutex> lck(swapMtx); canSwap = true; }
-        swapCV.notify_all();
-    }
-    void stopWriter() override { { std::lock_guard<std::mutex> lck(swapMtx); writerStop = true; } swapCV.notify_all(); }
-    void clearWriteStop() override { writerStop = false; }
-    void stopReader() override { { std::lock_guard<std::mutex> lck(rdyMtx); readerStop = true; } rdyCV.notify_all(); }
-    void clearReadStop() override { readerStop = false; }
-    T* writeBuf;
-    T* readBuf;
-private:
-    std::mutex swapMtx, rdyMtx;
-    std::condition_variable swapCV, rdyCV;
-    bool canSwap = true, dataReady = false, readerStop = false, writerStop = false;
-    int dataSize = 0;
-};
-
-class block {
-public:
-    virtual ~block() {}
-    virtual void start() {
-        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
-        if (running) { return; }
-        running = true;
-        doStart();
-    }
-    virtual void stop() {
-        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
-        if (!running) { return; }
-        doStop();
-        running = false;
-    }
-    void tempStart() {
-        if (!tempStopDepth || --tempStopDepth) { return; }
-        if (tempStopped) { doStart(); tempStopped = false; }
-    }
-    void tempStop() {
-        if (tempStopDepth++) { return; }
-        if (running && !tempStopped) { doStop(); tempStopped = true; }
-    }
-    virtual int run() = 0;
-protected:
-    void doStart() { workerThread = std::thread([this] { while (run() >= 0) {} }); }
-    void doStop() {
-        for (auto* in : inputs) { in->stopReader(); }
-        for (auto* out : outputs) { out->stopWriter(); }
-        if (workerThread.joinable()) { workerThread.join(); }
-        for (auto* in : inputs) { in->clearReadStop(); }
-        for (auto* out : outputs) { out->clearWriteStop(); }
-    }
-    void registerInput(untyped_stream* s) { inputs.push_back(s); }
-    void registerOutput(untyped_stream* s) { outputs.push_back(s); }
-    void unregisterOutput(untyped_stream* s) {
-        for (size_t i = 0; i < outputs.size(); i++) { if (outputs[i] == s) { outputs.erase(outputs.begin() + (long)i); break; } }
-    }
-    std::recursive_mutex ctrlMtx;
-    std::vector<untyped_stream*> inputs, outputs;
-    bool running = false, tempStopped = false;
-    int tempStopDepth = 0;
-    std::thread workerThread;
-};
-}  // namespace dsp
+#define SDRPP_GPU_HAVE_SDRPP_PLANS 1
+#endif
 #endif
 
 namespace sdrpp_gpu {
@@ -162,7 +55,7 @@ class DecimPlans {
 public:
     std::map<int, std::vector<DecimStage>> plans;
     int maxRatio = 1;
-#ifdef SDRPP_GPU_USE_SDRPP_DSP
+#ifdef SDRPP_GPU_HAVE_SDRPP_PLANS
     DecimPlans() {
         using namespace dsp::multirate::decim;
         for (unsigned i = 0; i < plans_len; i++) {
@@ -211,12 +104,16 @@ public:
     dsp::stream<dsp::complex_t> out;   // RxVFO::out (IF); delivered when no demodulator is attached
     dsp::stream<dsp::stereo_t> audio;  // demodulator output (radio's Demodulator::getOutput()) when attached
 
+    void setInSamplerate(double inSamplerate);                // rx_vfo.h:38-43
     void setOffset(double offset);                            // rx_vfo.h:72-77
     void setBandwidth(double bandwidth);                      // rx_vfo.h:60-70
     void setOutSamplerate(double outSamplerate, double bandwidth);  // rx_vfo.h:45-58
     void reset();                                             // rx_vfo.h:79-87
     // Radio-module demodulator fused behind this VFO (decoder_modules/radio/src/demodulators/*.h defaults).
     void attachDemod(Demod mode, bool lowPass = true, double agcAttack = 50.0, double agcDecay = 5.0, bool carrierAgc = false);
+    // demod::Demodulator::setBandwidth of the fused demodulator (FM deviation = bw / 2, NFM / AM audio low-pass, SSB's second
+    // translation: fm.h:47-58, am.h:62-72, ssb.h:44-62); RxVFO::setBandwidth stays the channel filter only, as in the reference
+    void setDemodBandwidth(double bandwidth);
     // The radio module's AF chain behind the demodulator (radio_module.h:98-110, 540-547): RationalResampler<stereo_t> to
     // `audioSamplerate`, optional highPass(300, 100) FIR, optional Deemphasis(tau) (tau <= 0: off).  With the chain attached `audio`
     // carries its output (what afChain.out hands to the sink stream); afRate = the demodulator's getAFSampleRate() (= IF rate for
@@ -225,6 +122,7 @@ public:
     void detachAF();
 
     double inSamplerate = 0, outSamplerate = 0, bandwidth = 0, offset = 0;
+    double demodBandwidth = 0;  // 0: follows `bandwidth`
     Demod demod = Demod::RAW;
     bool lowPass = true, carrierAgc = false;
     double agcAttack = 50.0, agcDecay = 5.0;
@@ -243,20 +141,25 @@ public:
     enum FFTWindow { RECTANGULAR, BLACKMAN, NUTTALL };  // iq_frontend.h:18-22
 
     ~IQFrontEnd() override {
-        if (_init) { stop(); }
+        if (_block_init) {
+            stop();
+            _block_init = false;  // dsp::block's destructor has nothing left to stop
+        }
         for (auto& kv : vfos) { delete kv.second; }
         if (ctx) { sdrpp_destroy(ctx); }
+        for (int i = 0; i < FRAME_SLOTS; i++) { free(frames[i]); }
+        free(frameStage);
     }
 
-    // iq_frontend.h:23 — decimRatio / dcBlocking configure the pre-processing chain (PowerDecimator -> DCBlocker -> Conjugate,
-    // iq_frontend.cpp:32-39), which runs on the device in front of the FFT branch and the VFO bank; `buffering` (the
-    // SampleFrameBuffer in front of it) is a host-side hand-off and has no device counterpart.
+    // iq_frontend.h:23.  decimRatio / dcBlocking configure the pre-processing chain (PowerDecimator -> DCBlocker -> Conjugate,
+    // iq_frontend.cpp:32-39), which runs on the device in front of the FFT branch and the VFO bank; `buffering` puts the 32-slot
+    // SampleFrameBuffer in front of it (iq_frontend.cpp:29-30, frame_buffer.h).  `device` / `plans` are additions with defaults.
     void init(dsp::stream<dsp::complex_t>* in, double sampleRate, bool buffering, int decimRatio, bool dcBlocking, int fftSize, double fftRate,
               FFTWindow fftWindow, float* (*acquireFFTBuffer)(void* ctx), void (*releaseFFTBuffer)(void* ctx), void* fftCtx, int device = 0,
               const DecimPlans* plans = nullptr) {
-        (void)buffering;
         _in = in;
         _sampleRate = sampleRate;
+        _buffering = buffering;
         _decimRatio = decimRatio;
         _dcBlocking = dcBlocking;
         _fftSize = fftSize;
@@ -271,7 +174,26 @@ public:
         registerInput(_in);
         updatePreproc();
         updateFFTPath();
-        _init = true;
+        _block_init = true;
+    }
+
+    // iq_frontend.cpp:72-74 -> SampleFrameBuffer::setInput (frame_buffer.h:36-44)
+    void setInput(dsp::stream<dsp::complex_t>* in) {
+        assert(_block_init);
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        tempStop();
+        unregisterInput(_in);
+        _in = in;
+        registerInput(_in);
+        tempStart();
+    }
+
+    // iq_frontend.cpp:101-103: inBuf.bypass = !enabled — takes effect with the next block, no restart
+    void setBuffering(bool enabled) { _buffering = enabled; }
+    // iq_frontend.cpp:200-202 -> SampleFrameBuffer::flush (frame_buffer.h:46-49): drop what is queued
+    void flushInputBuffer() {
+        std::unique_lock<std::mutex> lck(frameMtx);
+        frameRead = frameWrite;
     }
 
     // iq_frontend.cpp:105-130: the effective sample rate changes with the decimation; every VFO and the FFT framing follow it
@@ -280,33 +202,47 @@ public:
         tempStop();
         _decimRatio = ratio;
         updatePreproc();
-        for (auto& kv : vfos) {
-            kv.second->inSamplerate = getEffectiveSamplerate();
-            rebuild(*kv.second);
-        }
+        for (auto& kv : vfos) { kv.second->setInSamplerate(getEffectiveSamplerate()); }
         updateFFTPath();
         tempStart();
     }
     void setDCBlocking(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _dcBlocking = enabled; updatePreproc(); tempStart(); }
     void setInvertIQ(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _invertIQ = enabled; updatePreproc(); tempStart(); }
 
-    void setSampleRate(double sampleRate) {
+    void setSampleRate(double sampleRate) {  // iq_frontend.cpp:76-99
         std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
         tempStop();
         _sampleRate = sampleRate;
         updatePreproc();  // the DC blocker's rate follows the effective sample rate (iq_frontend.cpp:85-86)
-        for (auto& kv : vfos) {
-            kv.second->inSamplerate = getEffectiveSamplerate();
-            rebuild(*kv.second);
-        }
+        for (auto& kv : vfos) { kv.second->setInSamplerate(getEffectiveSamplerate()); }
         updateFFTPath();
         tempStart();
     }
-    double getSampleRate() { return _sampleRate; }
-    double getEffectiveSamplerate() { return _sampleRate / (double)_decimRatio; }
+    double getSampleRate() { return _sampleRate / (double)_decimRatio; }           // iq_frontend.h:27
+    double getEffectiveSamplerate() { return _sampleRate / (double)_decimRatio; }  // iq_frontend.cpp:244-246
     void setFFTSize(int size) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftSize = size; updateFFTPath(); tempStart(); }
     void setFFTRate(double rate) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftRate = rate; updateFFTPath(); tempStart(); }
     void setFFTWindow(FFTWindow w) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _fftWindow = w; updateFFTPath(); tempStart(); }
+
+    // iq_frontend.cpp:132-138 -> Splitter::bindStream / unbindStream (routing/splitter.h:14-44): every bound stream receives each
+    // block of the PRE-PROCESSED IQ (recorder, iq_exporter).  Same exceptions as the Splitter.
+    void bindIQStream(dsp::stream<dsp::complex_t>* stream) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        if (std::find(iqStreams.begin(), iqStreams.end(), stream) != iqStreams.end()) { throw std::runtime_error("[Splitter] Tried to bind stream to that is already bound"); }
+        tempStop();
+        registerOutput(stream);
+        iqStreams.push_back(stream);
+        tempStart();
+    }
+    void unbindIQStream(dsp::stream<dsp::complex_t>* stream) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        auto sit = std::find(iqStreams.begin(), iqStreams.end(), stream);
+        if (sit == iqStreams.end()) { throw std::runtime_error("[Splitter] Tried to unbind stream to that isn't bound"); }
+        tempStop();
+        iqStreams.erase(sit);
+        unregisterOutput(stream);
+        tempStart();
+    }
 
     // iq_frontend.cpp:140-160: duplicate names are rejected with NULL
     RxVFO* addVFO(std::string name, double sampleRate, double bandwidth, double offset) {
@@ -345,13 +281,99 @@ public:
         vfos.erase(it);
         tempStart();
     }
+    // The VFO whose `out` stream this is (NULL if none): how a demod::Demodulator-shaped adaptor (sdrpp_gpu_radio.h), which is handed
+    // `&vfo->out` as its input stream exactly like a CPU demodulator, finds the channel it is fused into.
+    RxVFO* vfoOfStream(dsp::stream<dsp::complex_t>* stream) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        for (auto& kv : vfos) {
+            if (&kv.second->out == stream) { return kv.second; }
+        }
+        return nullptr;
+    }
+    // Parity switch (not in the reference): run the reference's float rotator recursion on the device instead of the closed-form NCO
+    // (sdrpp_set_nco_mode).  Rebuilds every VFO.
+    void setReferenceRotator(bool enabled) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        tempStop();
+        for (auto& kv : vfos) {
+            if (kv.second->id >= 0) { sdrpp_vfo_remove(ctx, kv.second->id); kv.second->id = -1; }
+        }
+        sdrpp_set_nco_mode(ctx, enabled ? SDRPP_NCO_REFERENCE_ROTATOR : SDRPP_NCO_CLOSED_FORM);
+        for (auto& kv : vfos) { rebuild(*kv.second); }
+        tempStart();
+    }
 
-    // One block in -> FFT lines through acquire/release, one block out on every VFO stream.
+    // Worker of the block: one block from the input stream -> processed at once (bypass, the file source's setting:
+    // file_source/src/main.cpp:74) or queued in the 32-slot frame buffer and processed by the second worker
+    // (SampleFrameBuffer::run / worker, frame_buffer.h:51-98; same index arithmetic, so an overrun drops a whole lap like the reference).
     int run() override {
         int count = _in->read();
         if (count < 0) { return -1; }
-        int rc = sdrpp_push(ctx, (const float*)_in->readBuf, count);
+        if (!_buffering) {
+            const int rc = process((const dsp::complex_t*)_in->readBuf, count);
+            _in->flush();
+            return rc < 0 ? -1 : count;
+        }
+        {
+            std::lock_guard<std::mutex> lck(frameMtx);
+            if (!frames[frameWrite]) { frames[frameWrite] = (dsp::complex_t*)malloc(sizeof(dsp::complex_t) * STREAM_BUFFER_SIZE); }
+            memcpy(frames[frameWrite], _in->readBuf, (size_t)count * sizeof(dsp::complex_t));
+            frameSizes[frameWrite] = count;
+            frameWrite = (frameWrite + 1) % FRAME_SLOTS;
+        }
+        frameCnd.notify_all();
         _in->flush();
+        return count;
+    }
+
+    sdrpp_ctx* context() { return ctx; }
+    static constexpr int64_t SDRPP_GPU_MAX_BLOCK = 1000000;
+
+protected:
+    // dsp::block hooks: the frame-buffer worker lives and dies with the block's own worker (SampleFrameBuffer::doStart / doStop,
+    // frame_buffer.h:105-124)
+    void doStart() override {
+        stopFrameWorker = false;
+        workerThread = std::thread(&IQFrontEnd::workerLoop, this);
+        frameThread = std::thread(&IQFrontEnd::frameWorker, this);
+    }
+    void doStop() override {
+        for (auto& in : inputs) { in->stopReader(); }
+        for (auto& out : outputs) { out->stopWriter(); }
+        {
+            std::lock_guard<std::mutex> lck(frameMtx);
+            stopFrameWorker = true;
+        }
+        frameCnd.notify_all();
+        if (workerThread.joinable()) { workerThread.join(); }
+        if (frameThread.joinable()) { frameThread.join(); }
+        for (auto& in : inputs) { in->clearReadStop(); }
+        for (auto& out : outputs) { out->clearWriteStop(); }
+    }
+
+private:
+    friend class RxVFO;
+    static constexpr int FRAME_SLOTS = 32;  // TEST_BUFFER_SIZE, frame_buffer.h:3
+
+    void frameWorker() {
+        while (true) {
+            int count;
+            {
+                std::unique_lock<std::mutex> lck(frameMtx);
+                frameCnd.wait(lck, [this]() { return (((frameWrite - frameRead + FRAME_SLOTS) % FRAME_SLOTS) > 0) || stopFrameWorker; });
+                if (stopFrameWorker) { break; }
+                count = frameSizes[frameRead];
+                if (!frameStage) { frameStage = (dsp::complex_t*)malloc(sizeof(dsp::complex_t) * STREAM_BUFFER_SIZE); }
+                memcpy(frameStage, frames[frameRead], (size_t)count * sizeof(dsp::complex_t));  // under the lock, like the reference's copy into out.writeBuf
+                frameRead = (frameRead + 1) % FRAME_SLOTS;
+            }
+            if (process(frameStage, count) < 0) { break; }
+        }
+    }
+
+    // One block in -> FFT lines through acquire/release, the pre-processed IQ on every bound stream, one block out on every VFO stream.
+    int process(const dsp::complex_t* data, int count) {
+        int rc = sdrpp_push(ctx, (const float*)data, count);
         if (rc) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
             return -1;
@@ -362,26 +384,59 @@ public:
             if (buf) { sdrpp_fft_read(ctx, i, 1, buf, nullptr, nullptr); }
             if (_release) { _release(_fftCtx); }
         }
+        if (!iqStreams.empty()) {  // Splitter::run: copy to every bound stream, then swap (blocking on the slowest consumer)
+            const bool pre = _decimRatio > 1 || _dcBlocking || _invertIQ;
+            for (auto* st : iqStreams) {
+                int n = count;
+                if (pre) { n = sdrpp_preproc_read(ctx, (float*)st->writeBuf, STREAM_BUFFER_SIZE); }
+                else { memcpy(st->writeBuf, data, (size_t)count * sizeof(dsp::complex_t)); }
+                if (n < 0) { return -1; }
+                if (n > 0 && !st->swap(n)) { return -1; }
+            }
+        }
+        // every VFO's block with ONE device-to-host copy, then the per-stream hand-offs
+        const int nv = (int)vfos.size();
+        if (nv == 0) { return count; }
+        ids.resize((size_t)nv);
+        which.resize((size_t)nv);
+        offs.resize((size_t)nv);
+        cnts.resize((size_t)nv);
+        int k = 0;
+        for (auto& kv : vfos) {
+            ids[(size_t)k] = kv.second->id;
+            which[(size_t)k] = (kv.second->demod != Demod::RAW && kv.second->afOn) ? 2 : 0;
+            k++;
+        }
+        if (gather.size() < (size_t)2 * STREAM_BUFFER_SIZE) { gather.resize((size_t)2 * STREAM_BUFFER_SIZE); }
+        int total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
+        if (total == SDRPP_ERR_INVALID) {  // more than the staging holds (very many VFOs at a high output rate): size it and retry once
+            long long need = 0;
+            for (auto& kv : vfos) { need += std::max(sdrpp_vfo_out_count(ctx, kv.second->id), sdrpp_vfo_af_count(ctx, kv.second->id)); }
+            gather.resize((size_t)2 * (size_t)(need + 1024));
+            total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
+        }
+        if (total < 0) {
+            fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] reading the VFO outputs failed: %s\n", sdrpp_last_error(ctx));
+            return -1;
+        }
+        k = 0;
         for (auto& kv : vfos) {
             RxVFO* v = kv.second;
+            const int n = cnts[(size_t)k];
+            const float* src = gather.data() + 2 * (size_t)offs[(size_t)k];
+            k++;
+            if (n <= 0) { continue; }
             if (v->demod == Demod::RAW) {
-                int n = sdrpp_vfo_read(ctx, v->id, (float*)v->out.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE);
-                if (n > 0 && !v->out.swap(n)) { return -1; }
+                memcpy(v->out.writeBuf, src, (size_t)n * sizeof(dsp::complex_t));
+                if (!v->out.swap(n)) { return -1; }
             }
             else {
-                int n = v->afOn ? sdrpp_vfo_af_read(ctx, v->id, (float*)v->audio.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE)
-                                : sdrpp_vfo_read(ctx, v->id, (float*)v->audio.writeBuf, SDRPP_GPU_STREAM_BUFFER_SIZE);
-                if (n > 0 && !v->audio.swap(n)) { return -1; }
+                memcpy(v->audio.writeBuf, src, (size_t)n * sizeof(dsp::stereo_t));
+                if (!v->audio.swap(n)) { return -1; }
             }
         }
         return count;
     }
-
-    sdrpp_ctx* context() { return ctx; }
-    static constexpr int64_t SDRPP_GPU_MAX_BLOCK = 1000000;
-
-private:
-    friend class RxVFO;
 
     void updatePreproc() {  // iq_frontend.cpp:32-39: decim enabled for ratio > 1, dcBlock rate genDCBlockRate(effectiveSr), conjugate
         int dec[SDRPP_MAX_DECIM_STAGES] = { 0 }, nt[SDRPP_MAX_DECIM_STAGES] = { 0 };
@@ -466,19 +521,20 @@ private:
             d.audio_ntaps = n;
             d.audio_taps = ataps.data();
         };
+        const double dbw = v.demodBandwidth > 0.0 ? v.demodBandwidth : v.bandwidth;  // the demodulator's own bandwidth (Demodulator::setBandwidth)
         if (v.demod == Demod::WFM) {
-            d.inv_deviation = (float)(1.0 / (twoPi * ((v.bandwidth / 2.0) / v.outSamplerate)));
+            d.inv_deviation = (float)(1.0 / (twoPi * ((dbw / 2.0) / v.outSamplerate)));
             if (v.lowPass) { lp(15000.0, 4000.0); }
         }
         else if (v.demod == Demod::NFM) {
-            d.inv_deviation = (float)(1.0 / (twoPi * ((v.bandwidth / 2.0) / v.outSamplerate)));
-            if (v.lowPass) { lp(v.bandwidth / 2.0, (v.bandwidth / 2.0) * 0.1); }
+            d.inv_deviation = (float)(1.0 / (twoPi * ((dbw / 2.0) / v.outSamplerate)));
+            if (v.lowPass) { lp(dbw / 2.0, (dbw / 2.0) * 0.1); }
         }
         else if (v.demod == Demod::AM) {
-            lp(v.bandwidth / 2.0, (v.bandwidth / 2.0) * 0.1);
+            lp(dbw / 2.0, (dbw / 2.0) * 0.1);
         }
         else if (v.demod == Demod::USB || v.demod == Demod::LSB || v.demod == Demod::DSB) {
-            const double tr = v.demod == Demod::USB ? v.bandwidth / 2.0 : (v.demod == Demod::LSB ? -v.bandwidth / 2.0 : 0.0);
+            const double tr = v.demod == Demod::USB ? dbw / 2.0 : (v.demod == Demod::LSB ? -dbw / 2.0 : 0.0);
             sdrpp_design_phase_delta(tr, v.outSamplerate, &d.ssb_phase_delta_re, &d.ssb_phase_delta_im);
         }
         int rc = sdrpp_vfo_add(ctx, &d, &v.id);
@@ -531,13 +587,49 @@ private:
     int _fftSize = 65536;
     int _decimRatio = 1;
     bool _dcBlocking = false, _invertIQ = false;
+    std::atomic<bool> _buffering{ false };
+    // SampleFrameBuffer state (frame_buffer.h:100-134)
+    dsp::complex_t* frames[FRAME_SLOTS] = {};
+    int frameSizes[FRAME_SLOTS] = {};
+    int frameWrite = 0, frameRead = 0;
+    dsp::complex_t* frameStage = nullptr;
+    std::mutex frameMtx;
+    std::condition_variable frameCnd;
+    std::thread frameThread;
+    bool stopFrameWorker = false;
+    // bound IQ consumers (Splitter::streams) and the staging of the batched VFO read
+    std::vector<dsp::stream<dsp::complex_t>*> iqStreams;
+    std::vector<int> ids, which, cnts;
+    std::vector<int64_t> offs;
+    std::vector<float> gather;
     FFTWindow _fftWindow = NUTTALL;
     float* (*_acquire)(void*) = nullptr;
     void (*_release)(void*) = nullptr;
     void* _fftCtx = nullptr;
-    bool _init = false;
 };
 
+inline void RxVFO::setInSamplerate(double sr) {  // rx_vfo.h:38-43: xlator offset and resampler follow the new input rate
+    std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
+    fe->tempStop();
+    inSamplerate = sr;
+    fe->rebuild(*this);
+    fe->tempStart();
+}
+inline void RxVFO::setDemodBandwidth(double bw) {
+    std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
+    demodBandwidth = bw;
+    if (demod == Demod::RAW) { return; }
+    if (demod == Demod::USB || demod == Demod::LSB) {  // ssb.h:44-50, 106-117: only the second translation follows the bandwidth — no restart
+        float re, im;
+        sdrpp_design_phase_delta(demod == Demod::USB ? bw / 2.0 : -bw / 2.0, outSamplerate, &re, &im);
+        sdrpp_vfo_set_ssb_phase_delta(fe->ctx, id, re, im);
+        return;
+    }
+    if (demod == Demod::DSB) { return; }
+    fe->tempStop();
+    fe->rebuild(*this);
+    fe->tempStart();
+}
 inline void RxVFO::setOffset(double off) {
     std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
     offset = off;

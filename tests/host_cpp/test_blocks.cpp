@@ -1,13 +1,20 @@
 // Drives the C++ host mirror (sdrplusplus_amd/host/sdrpp_gpu_blocks.h) the way SDR++ drives IQFrontEnd: a source thread
 // swap()s IQ blocks into a dsp::stream, the front end delivers dB lines through acquire/release callbacks and per-VFO blocks
 // on dsp::streams read by sink threads.  Outputs are written to files and compared with the oracle by tests/test_host_cpp.py.
-//   usage: test_blocks <plans.bin> <iq.f32> <sample_rate> <block> <fft_size> <fft_rate> <outdir>
+//   usage: test_blocks <plans.bin> <iq.f32> <sample_rate> <block> <fft_size> <fft_rate> <outdir> [buffered|bypass]
+// Built three ways by tests/test_host_cpp.py: against the test double of dsp::block / dsp::stream (tests/host_cpp/standalone), against
+// the reference's REAL headers (-I<sdrpp>/core/src, oracle/_ref/test_blocks_ref), and with -DSDRPP_GPU_TEST_DEMOD_IFACE against the
+// radio module's demod::Demodulator interface (extracted from the reference at build time, oracle/_ref/demod_iface.h).
 #include <cstdio>
 #include <fstream>
 #include <string>
 #include <thread>
 #include <vector>
 #include "../../sdrplusplus_amd/host/sdrpp_gpu_blocks.h"
+#ifdef SDRPP_GPU_TEST_DEMOD_IFACE
+#include "demod_iface.h"  // namespace demod { class Demodulator { ... }; } as declared by decoder_modules/radio/src/demod.h
+#include "../../sdrplusplus_amd/host/sdrpp_gpu_radio.h"
+#endif
 
 struct LineSink {
     int fftSize;
@@ -42,16 +49,48 @@ int main(int argc, char** argv) {
     const int block = atoi(argv[4]), fftSize = atoi(argv[5]);
     const double fftRate = atof(argv[6]);
     const std::string outdir = argv[7];
+    const bool buffered = argc > 8 && std::string(argv[8]) == "buffered";
     const size_t nsamp = iq.size() / 2;
 
-    dsp::stream<dsp::complex_t> src;
+    dsp::stream<dsp::complex_t> src, src2;  // the second one takes over half way (IQFrontEnd::setInput, source.cpp:29,57)
     LineSink lines{ fftSize };
     sdrpp_gpu::IQFrontEnd fe;
-    fe.init(&src, sr, false, 1, false, fftSize, fftRate, sdrpp_gpu::IQFrontEnd::NUTTALL, acquire, release, &lines, 0, &plans);
+    fe.init(&src, sr, buffered, 1, false, fftSize, fftRate, sdrpp_gpu::IQFrontEnd::NUTTALL, acquire, release, &lines, 0, &plans);
+    if (fe.getSampleRate() != sr || fe.getEffectiveSamplerate() != sr) { fprintf(stderr, "getSampleRate\n"); return 1; }
     sdrpp_gpu::RxVFO* raw = fe.addVFO("raw", 250000.0, 150000.0, sr / 8);
     sdrpp_gpu::RxVFO* wfm = fe.addVFO("radio", 250000.0, 150000.0, 300000.0);
     if (!raw || !wfm) { return 1; }
+#ifdef SDRPP_GPU_TEST_DEMOD_IFACE
+    // the radio module's view: a demod::Demodulator that was handed the VFO's output stream (radio_module.h:455-473)
+    sdrpp_gpu::FusedDemodulator<demod::Demodulator, sdrpp_gpu::Demod::WFM> gpuWfm(&fe);
+    demod::Demodulator* dm = &gpuWfm;
+    dm->init("radio", nullptr, &wfm->out, 150000.0, 48000.0);
+    dm->start();
+    if (dm->getOutput() != &wfm->audio || dm->getIFSampleRate() != 250000.0 || std::string(dm->getName()) != "WFM" || dm->getVFOReference() != 1) {
+        fprintf(stderr, "Demodulator adaptor\n");
+        return 1;
+    }
+    {   // an input that is no VFO output cannot be fused
+        dsp::stream<dsp::complex_t> stray;
+        bool threw = false;
+        sdrpp_gpu::FusedDemodulator<demod::Demodulator, sdrpp_gpu::Demod::NFM> bad(&fe);
+        try { bad.init("x", nullptr, &stray, 12500.0, 48000.0); } catch (const std::runtime_error&) { threw = true; }
+        if (!threw) { fprintf(stderr, "stray input accepted\n"); return 1; }
+    }
+#else
     wfm->attachDemod(sdrpp_gpu::Demod::WFM);
+#endif
+    // a consumer of the (pre-processed) wideband IQ, like the recorder's baseband tap (recorder/src/main.cpp:209,229)
+    dsp::stream<dsp::complex_t> iqTap;
+    fe.bindIQStream(&iqTap);
+    {
+        bool threw = false;
+        try { fe.bindIQStream(&iqTap); } catch (const std::runtime_error&) { threw = true; }  // Splitter::bindStream, splitter.h:18-20
+        dsp::stream<dsp::complex_t> other;
+        bool threw2 = false;
+        try { fe.unbindIQStream(&other); } catch (const std::runtime_error&) { threw2 = true; }
+        if (!threw || !threw2) { fprintf(stderr, "bind/unbind error behaviour\n"); return 1; }
+    }
     // a second radio instance with the AF chain (48 kHz, 50 us de-emphasis) behind its demodulator (radio_module.h:98-110)
     sdrpp_gpu::RxVFO* wfmAf = fe.addVFO("radio_af", 250000.0, 150000.0, 300000.0);
     if (!wfmAf) { return 1; }
@@ -60,26 +99,38 @@ int main(int argc, char** argv) {
     if (fe.addVFO("raw", 1.0, 1.0, 0.0) != nullptr) { fprintf(stderr, "duplicate VFO name accepted\n"); return 1; }
     fe.removeVFO("nope");  // logs, like the reference
 
-    std::vector<float> ifOut, audioOut, afOut;
+    std::vector<float> ifOut, audioOut, afOut, tapOut;
+    std::thread t0(drain<dsp::complex_t>, &iqTap, &tapOut);
     std::thread t1(drain<dsp::complex_t>, &raw->out, &ifOut);
     std::thread t2(drain<dsp::stereo_t>, &wfm->audio, &audioOut);
     std::thread t3(drain<dsp::stereo_t>, &wfmAf->audio, &afOut);
     fe.start();
+    fe.flushInputBuffer();  // nothing queued yet: a no-op that must not disturb the indices (main_window.cpp:679,689)
     size_t pos = 0;
     int blk = 0;
+    const int nblocks = (int)(nsamp / (size_t)block);
+    dsp::stream<dsp::complex_t>* cur = &src;
     while (pos + (size_t)block <= nsamp) {
-        memcpy(src.writeBuf, &iq[2 * pos], sizeof(float) * 2 * (size_t)block);
-        if (!src.swap(block)) { break; }
+        memcpy(cur->writeBuf, &iq[2 * pos], sizeof(float) * 2 * (size_t)block);
+        if (!cur->swap(block)) { break; }
         pos += (size_t)block;
         blk++;
         if (blk == 3) { raw->setOffset(-sr / 4); }  // retune while running (phase-continuous)
+        if (blk == nblocks / 2) {  // change of source: everything handed over so far must have been consumed first
+            std::this_thread::sleep_for(std::chrono::milliseconds(buffered ? 1500 : 300));
+            fe.setInput(&src2);
+            cur = &src2;
+        }
     }
     // let the last block drain: a final empty swap is not part of the reference protocol, so wait on the line/audio counts instead
-    std::this_thread::sleep_for(std::chrono::milliseconds(300));
+    std::this_thread::sleep_for(std::chrono::milliseconds(buffered ? 1500 : 300));
     fe.stop();
+    fe.unbindIQStream(&iqTap);
+    iqTap.stopReader();
     raw->out.stopReader();
     wfm->audio.stopReader();
     wfmAf->audio.stopReader();
+    t0.join();
     t1.join();
     t2.join();
     t3.join();
@@ -91,6 +142,7 @@ int main(int argc, char** argv) {
     dump("if.f32", ifOut);
     dump("audio.f32", audioOut);
     dump("af.f32", afOut);
+    dump("iq_tap.f32", tapOut);
     printf("blocks %d lines %d (acquire %d release %d) if %zu audio %zu\n", blk, (int)(lines.all.size() / (size_t)fftSize), lines.acquired, lines.released, ifOut.size() / 2, audioOut.size() / 2);
     return (lines.acquired == lines.released) ? 0 : 1;
 }

@@ -13,57 +13,46 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sdrplusplus_amd", "csrc")
 
 
-def _build(tmp):
-    exe = os.path.join(tmp, "test_blocks")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_blocks.cpp"), "-L" + CSRC, "-lsdrpp_gpu",
-                    "-Wl,-rpath," + CSRC, "-lpthread"], check=True)
+EMU = os.path.join(ROOT, "tests", "emu")
+REF = "/root/reference"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "test_blocks_ref")
+
+
+def _build(tmp, lib="product", headers="standalone"):
+    """tests/host_cpp/test_blocks.cpp against the test double of dsp::block / dsp::stream or against the reference's REAL headers
+    (+ the radio module's demod::Demodulator interface, extracted by oracle/Makefile), linked with the product library or — for runs
+    on a machine without a GPU — with the CPU emulator build of the same sources (tests/emu)."""
+    exe = os.path.join(tmp, "test_blocks_%s_%s" % (lib, headers))
+    cmd = ["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_blocks.cpp")]
+    if headers == "reference":
+        cmd += ["-DSDRPP_GPU_TEST_DEMOD_IFACE", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + REF + "/core/src", "-I" + os.path.join(ROOT, "oracle", "_ref")]
+    else:
+        cmd += ["-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone")]
+    if lib == "emu":
+        subprocess.run(["make", "-C", EMU, "-s"], check=True)
+        cmd += ["-L" + EMU, "-l:libsdrpp_gpu_emu.so", "-Wl,-rpath," + EMU]
+    else:
+        cmd += ["-L" + CSRC, "-lsdrpp_gpu", "-Wl,-rpath," + CSRC]
+    subprocess.run(cmd + ["-lpthread"], check=True)
     return exe
 
 
-def test_host_mirror_compiles_standalone():
-    with tempfile.TemporaryDirectory() as tmp:
-        assert os.path.exists(_build(tmp))
-
-
-def test_device_math_helpers():
-    """fm_phase (the discriminator's polynomial atan2) against double-precision atan2 over 2.5 M points, normalize_phase's range:
-    the kernel header compiled for the host against the emulator's headers (tests/host_cpp/test_device_math.cpp)."""
-    emu = os.path.join(ROOT, "tests", "emu")
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = os.path.join(tmp, "test_device_math")
-        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-I" + emu, "-I" + os.path.join(emu, "gfx950"), "-I" + CSRC, "-o", exe,
-                        os.path.join(ROOT, "tests", "host_cpp", "test_device_math.cpp"), "-lm"], check=True)
-        r = subprocess.run([exe], capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout + r.stderr
-
-
-@pytest.mark.skipif(not os.path.isdir("/root/reference/core/src/dsp"), reason="needs the reference tree")
-def test_host_mirror_compiles_inside_sdrpp_tree():
-    """-DSDRPP_GPU_USE_SDRPP_DSP: the blocks derive from the reference's own dsp::block and use its dsp::stream<T> and plans.h."""
-    src = '#define SDRPP_GPU_USE_SDRPP_DSP\n#include "sdrplusplus_amd/host/sdrpp_gpu_blocks.h"\nint main() { sdrpp_gpu::DecimPlans p; sdrpp_gpu::IQFrontEnd fe; return p.maxRatio == 8192 ? 0 : 1; }\n'
-    with tempfile.TemporaryDirectory() as tmp:
-        f = os.path.join(tmp, "t.cpp")
-        open(f, "w").write(src)
-        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + ROOT, "-I" + os.path.join(ROOT, "oracle", "shim"), "-I/root/reference/core/src", f], check=True)
-
-
-@pytest.mark.gpu
-def test_threaded_graph_matches_oracle():
+def _run_graph_and_check(exe, mode, tmp):
+    """Source thread -> IQFrontEnd -> sink threads (the way SDR++ drives it), 12 blocks of cfg 1, outputs against the oracle."""
     from sdrplusplus_amd import capi, workloads
 
     sr, B, N, rate = 2.4e6, 12000, 4096, 100.0
     nblk = 12
     x = workloads.synth(1, B * nblk, seed=5)
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = _build(tmp)
-        x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
-        r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), str(N), str(rate), tmp],
-                           capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0, r.stdout + r.stderr
-        lines = np.fromfile(os.path.join(tmp, "lines.f32"), np.float32).reshape(-1, N)
-        ifs = np.fromfile(os.path.join(tmp, "if.f32"), np.float32).view(np.complex64)
-        audio = np.fromfile(os.path.join(tmp, "audio.f32"), np.float32).reshape(-1, 2)
-        af = np.fromfile(os.path.join(tmp, "af.f32"), np.float32).reshape(-1, 2)
+    x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
+    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), str(N), str(rate), tmp, mode],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = np.fromfile(os.path.join(tmp, "lines.f32"), np.float32).reshape(-1, N)
+    ifs = np.fromfile(os.path.join(tmp, "if.f32"), np.float32).view(np.complex64)
+    audio = np.fromfile(os.path.join(tmp, "audio.f32"), np.float32).reshape(-1, 2)
+    af = np.fromfile(os.path.join(tmp, "af.f32"), np.float32).reshape(-1, 2)
+    tap = np.fromfile(os.path.join(tmp, "iq_tap.f32"), np.float32).view(np.complex64)
     nz, skip = capi.design_reshape_params(sr, N, rate)
     spec = S.OracleSpectrum(N, nz, skip, capi.design_fft_window(2, nz))
     raw = S.OracleChain(sr, 250e3, 150e3, sr / 8, None)
@@ -84,8 +73,62 @@ def test_threaded_graph_matches_oracle():
     assert audio.shape == oa.shape and np.sqrt(np.mean((audio - oa) ** 2)) < 1e-5
     # RxVFO::attachAF: resampler to 48 kHz + 50 us de-emphasis behind the demodulator, delivered on the same `audio` stream
     assert af.shape == of.shape and np.sqrt(np.mean((af - of) ** 2)) < 1e-5
+    # bindIQStream: every block of the (here un-pre-processed) wideband IQ, bit for bit, across the setInput() change of source
+    assert tap.shape == x.shape and np.array_equal(tap, x)
     # setOffset() is called by the source thread right after it handed over the third block, i.e. asynchronously to the worker
-    # (exactly like a GUI retune in SDR++): it takes effect from block 2 or 3.  Blocks 0-1 are therefore compared tightly.
+    # (exactly like a GUI retune in SDR++): it takes effect from block 2 or 3 on (later still when the frame buffer queues blocks).
+    # Blocks 0-1 are therefore compared tightly.
     assert ifs.shape == oi.shape
+    if mode == "buffered":
+        return  # the source runs up to 32 blocks ahead of the worker: where the asynchronous retune lands is not defined
     n2 = 2 * 1250 - 10
     assert np.sqrt(np.mean(np.abs(ifs[:n2] - oi[:n2]) ** 2)) / np.sqrt(np.mean(np.abs(oi[:n2]) ** 2)) < 5e-6
+
+
+@pytest.mark.parametrize("mode", ["bypass", "buffered"])
+def test_host_mirror_threaded_graph_on_the_emulator(mode):
+    """The C++ mirror built against the test double of dsp::block / dsp::stream, linked with the CPU emulator build of the library:
+    source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
+    flushInputBuffer, retune while running.  A logic check of the host code; the device leg is test_threaded_graph_matches_oracle."""
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/core/src/dsp"), reason="needs the reference tree")
+def test_host_mirror_links_and_runs_against_the_reference_headers():
+    """The same source compiled against SDR++'s REAL core/src/dsp/block.h, stream.h, types.h, multirate/decim/plans.h and the radio
+    module's demod::Demodulator interface (decoder_modules/radio/src/demod.h, cut out at build time), LINKED and RUN (CPU emulator
+    library): IQFrontEnd derives from the real dsp::block, speaks the real dsp::stream<T>, FusedDemodulator overrides every pure
+    virtual of the real interface."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/demod_iface.h"], check=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp)
+
+
+def test_device_math_helpers():
+    """fm_phase (the discriminator's polynomial atan2) against double-precision atan2 over 2.5 M points, normalize_phase's range:
+    the kernel header compiled for the host against the emulator's headers (tests/host_cpp/test_device_math.cpp)."""
+    emu = os.path.join(ROOT, "tests", "emu")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_device_math")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-I" + emu, "-I" + os.path.join(emu, "gfx950"), "-I" + CSRC, "-o", exe,
+                        os.path.join(ROOT, "tests", "host_cpp", "test_device_math.cpp"), "-lm"], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bypass", "buffered"])
+def test_threaded_graph_matches_oracle(mode):
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_graph_and_check(_build(tmp), mode, tmp)
+
+
+@pytest.mark.gpu
+def test_reference_header_build_runs_on_the_device():
+    """oracle/_ref/test_blocks_ref: the host mirror compiled HERE against the reference's real dsp headers + Demodulator interface (the
+    GPU box has no reference tree; the binary travels like the other oracle/_ref files), linked with the product library."""
+    if not os.path.exists(REF_BIN):
+        pytest.skip("oracle/_ref/test_blocks_ref not built (needs the reference tree at build time)")
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_graph_and_check(REF_BIN, "bypass", tmp)
