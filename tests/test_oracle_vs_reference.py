@@ -163,3 +163,98 @@ def test_sample_stream_compressor_bit_exact(pcm):
         na = o.orc_compress(n, pcm, S._fp(x.view(np.float32)), a.ctypes.data_as(u8))
         nb = r.ref_compress(n, pcm, S._fp(x.view(np.float32)), b.ctypes.data_as(u8))
         assert na == nb and np.array_equal(a[:na], b[:nb])
+
+
+# ---- waterfall widget arithmetic: oracle.c's restatement vs the reference's own functions, cut out of gui/widgets/waterfall.cpp at build
+#      time (oracle/Makefile: _ref/waterfall_extract.inc + oracle/ref_waterfall.cpp) ----
+def _refwf():
+    import os
+    path = os.path.join(S.ORACLE_DIR, "_ref", "libsdrpp_refwf.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libsdrpp_refwf.so not built")
+    L = C.CDLL(path)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.ref_do_zoom.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
+    L.ref_wf_create.restype = C.c_void_p
+    L.ref_wf_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ref_wf_destroy.argtypes = [C.c_void_p]
+    L.ref_wf_set_view.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float]
+    L.ref_wf_set_smoothing.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    L.ref_wf_set_hold.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    L.ref_wf_push.argtypes = [C.c_void_p, fp, ip]
+    L.ref_wf_latest.argtypes = [C.c_void_p, fp, fp]
+    L.ref_wf_signal_info.argtypes = [C.c_void_p, C.c_double, C.c_double, fp, fp]
+    L.ref_wf_raster.argtypes = [C.c_void_p, ip]
+    return L
+
+
+@pytest.mark.parametrize("case", [(0, 65536, 65536, 1024), (1000, 30000, 65536, 600), (4000, 90, 4096, 600), (-5, 4096, 4096, 333), (60000, 9000, 65536, 1920),
+                                  (0, 1 << 20, 1 << 20, 1024)])
+def test_do_zoom_bit_exact(case):
+    """doZoom (waterfall.cpp:65-90) incl. its quirks: float running index, ceil window, clip at the end of the line, offset < 0 -> 0,
+    width clamp 524288, bins repeated when zoomed past one bin per pixel."""
+    offset, width, n_in, n_out = case
+    L = _refwf()
+    r = np.random.default_rng(n_in + n_out)
+    line = (r.standard_normal(n_in) * 20.0 - 80.0).astype(np.float32)
+    a = S.oracle_do_zoom(offset, width, n_out, line)
+    b = np.empty(n_out, np.float32)
+    L.ref_do_zoom(offset, width, n_in, n_out, S._fp(line), S._fp(b))
+    assert np.array_equal(a, b)
+
+
+def test_waterfall_push_trace_raster_signal_info_bit_exact():
+    """WaterFall::getFFTBuffer / pushFFT (ring order, zoom, palette index, smoothing as three separately rounded VOLK passes, hold from
+    index 1), updateWaterfallFb (full re-raster, opaque rows), calculateVFOSignalInfo and the smoothing / hold setters: the oracle's
+    restatement (oracle.c section 7) against the reference's own function bodies, bit for bit, over a wrapping ring and view changes."""
+    from test_parity_fft import _OracleWf
+    from sdrplusplus_amd import capi
+
+    L = _refwf()
+    sr, N, W, H = 10e6, 4096, 600, 5
+    r = np.random.default_rng(5)
+    owf = _OracleWf(H, N, W)
+    h = L.ref_wf_create(H, N, W)
+    view = (1.0e6, 4.0e6)
+    wmin, wmax = -110.0, -10.0
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    assert owf.signal_info(0.5e6, 200e3, sr) is None
+    sa, sb = C.c_float(), C.c_float()
+    assert L.ref_wf_signal_info(h, 0.5e6, 200e3, C.byref(sa), C.byref(sb)) == 0
+    for step in range(13):
+        if step == 4:
+            owf.o.orc_wf_set_smoothing(owf.h, 1, 0.25)
+            L.ref_wf_set_smoothing(h, 1, 0.25)
+        if step == 6:
+            owf.o.orc_wf_set_hold(owf.h, 1, 1.5)
+            L.ref_wf_set_hold(h, 1, 1.5)
+        if step == 9:
+            view, wmin, wmax = (-2.0e6, 1.5e6), -90.0, -20.0
+        if step == 11:
+            owf.o.orc_wf_set_smoothing(owf.h, 0, 0.25)
+            L.ref_wf_set_smoothing(h, 0, 0.25)
+        start, size = capi.design_waterfall_view(view[0], view[1], sr, N)
+        L.ref_wf_set_view(h, view[0], view[1], sr, wmin, wmax)
+        line = (r.standard_normal(N) * 15.0 - 70.0 + 30.0 * np.exp(-((np.arange(N) - 2300.0) / 40.0) ** 2)).astype(np.float32)
+        oi = owf.push(line, start, size, wmin, wmax)
+        ri = np.empty(W, np.int32)
+        L.ref_wf_push(h, line.ctypes.data_as(fp), ri.ctypes.data_as(ip))
+        assert np.array_equal(oi, ri), step
+        ol, oh = owf.latest()
+        rl, rh = np.empty(W, np.float32), np.empty(W, np.float32)
+        L.ref_wf_latest(h, rl.ctypes.data_as(fp), rh.ctypes.data_as(fp))
+        assert np.array_equal(ol, rl), step
+        if step >= 6:
+            assert np.array_equal(oh[1:], rh[1:]), step  # index 0 is never touched by the hold loop (starts at 1) on either side
+        for centre, bw in ((0.55e6, 200e3), (-4.9e6, 300e3), (4.99e6, 50e3)):
+            assert L.ref_wf_signal_info(h, centre, bw, C.byref(sa), C.byref(sb)) == 1
+            os_, on_ = owf.signal_info(centre, bw, sr)
+            if centre > 4.9e6:
+                continue  # the reference reads fftLine[rawFFTSize] (one past the line) for a VFO touching the upper edge: not comparable
+            assert (os_, on_) == (sa.value, sb.value), (step, centre)
+        ofb, on = owf.raster(start, size, wmin, wmax)
+        rfb = np.empty((H, W), np.int32)
+        rn = L.ref_wf_raster(h, rfb.ctypes.data_as(ip))
+        assert on == rn == min(step + 1, H)
+        assert np.array_equal(ofb[:on], rfb[:rn]) and np.all(rfb[rn:] == -1), step
+    L.ref_wf_destroy(h)
