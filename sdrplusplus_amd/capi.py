@@ -4,8 +4,8 @@ The library is the product: every data-path call runs hand-written HIP kernels o
 fallback — `Context()` raises `SdrppError` (SDRPP_ERR_NO_DEVICE) when no GPU is present, and importing this module
 raises `ImportError` when the shared library has not been built (`python -c "import __graft_entry__ as g; g.build()"`).
 
-Tests may point SDRPP_GPU_LIB at the fiber-emulator build (tests/emu) to exercise host logic without a GPU; nothing in
-this package does so on its own.
+The library that is loaded is always DEFAULT_LIB below — no environment override.  (The test suite's CPU legs assign
+`capi.DEFAULT_LIB` themselves to run host logic against the fiber-emulator build in tests/emu; nothing in this package does.)
 """
 import ctypes as C
 import os
@@ -87,7 +87,7 @@ _lib_path = None
 
 
 def lib_path():
-    return os.environ.get("SDRPP_GPU_LIB", DEFAULT_LIB)
+    return DEFAULT_LIB
 
 
 def load():
@@ -265,6 +265,7 @@ class Context:
         self._keep = []  # numpy arrays referenced by descriptors during vfo_add
         self.fft_size = 0
         self.data_width = 0
+        self.wf_height = 0
 
     def _chk(self, rc):
         if rc < 0:
@@ -397,6 +398,7 @@ class Context:
 
     def wf_configure(self, height):
         self._chk(self.L.sdrpp_wf_configure(self.h, int(height)))
+        self.wf_height = int(height)  # sdrpp_wf_raster always fills height x data_width entries: size the buffer from THIS value
 
     def wf_set_smoothing(self, enabled, speed=0.1):
         self._chk(self.L.sdrpp_wf_set_smoothing(self.h, int(bool(enabled)), float(speed)))
@@ -415,8 +417,8 @@ class Context:
         ok = self._chk(self.L.sdrpp_wf_signal_info(self.h, center_offset, bandwidth, whole_bandwidth, C.byref(a), C.byref(b)))
         return (a.value, b.value) if ok else None
 
-    def wf_raster(self, height, draw_start, draw_size, data_width, wf_min, wf_max):
-        fb = np.empty((height, data_width), np.int32)
+    def wf_raster(self, draw_start, draw_size, data_width, wf_min, wf_max):
+        fb = np.empty((self.wf_height, data_width), np.int32)
         n = C.c_int()
         self._chk(self.L.sdrpp_wf_raster(self.h, int(draw_start), int(draw_size), int(data_width), float(wf_min), float(wf_max), fb.ctypes.data_as(c_int32_p), C.byref(n)))
         return fb, n.value

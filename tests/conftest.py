@@ -41,15 +41,10 @@ def backend(request):
     path."""
     from sdrplusplus_amd import capi
 
-    old = os.environ.get("SDRPP_GPU_LIB")
     if request.param == "emu":
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s"], check=True)
-        os.environ["SDRPP_GPU_LIB"] = EMU_LIB
+        capi.DEFAULT_LIB = EMU_LIB  # test-only: the product binding itself has no override
     else:
-        os.environ.pop("SDRPP_GPU_LIB", None)
-        assert capi.lib_path() == REAL_LIB
+        capi.DEFAULT_LIB = REAL_LIB
     yield request.param
-    if old is None:
-        os.environ.pop("SDRPP_GPU_LIB", None)
-    else:
-        os.environ["SDRPP_GPU_LIB"] = old
+    capi.DEFAULT_LIB = REAL_LIB

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _real_capi():
     from sdrplusplus_amd import capi
 
-    os.environ.pop("SDRPP_GPU_LIB", None)
+    capi.DEFAULT_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", "libsdrpp_gpu.so")
     return capi
 
 

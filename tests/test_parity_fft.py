@@ -317,11 +317,11 @@ def test_waterfall_history_trace_and_raster(backend):
         # re-raster with the current view and with a zoomed-in one (the GUI's pan / zoom): every stored line, newest first
         for vo, vb in ((1.0e6, 4.0e6), (-2.0e6, 1.0e6)):
             s2, z2 = capi.design_waterfall_view(vo, vb, sr, N)
-            gfb, gn = ctx.wf_raster(H, s2, z2, W, wmin, wmax)
+            gfb, gn = ctx.wf_raster(s2, z2, W, wmin, wmax)
             ofb, on = owf.raster(s2, z2, wmin, wmax)
             assert gn == on and np.array_equal(gfb, ofb)
     assert gn == H  # the ring wrapped
     ctx.wf_configure(0)
     with pytest.raises(Exception):
-        ctx.wf_raster(H, start, size, W, wmin, wmax)
+        ctx.wf_raster(start, size, W, wmin, wmax)
     ctx.close()

@@ -610,7 +610,8 @@ def test_opt_in_kernel_variants_bit_identical(backend, switch, tmp_path):
     res = []
     for v in ("0", value):
         out = str(tmp_path / ("%s_%s.npz" % (name, v)))
-        subprocess.run([sys.executable, os.path.join(root, "tests", "variant_scenario.py"), out, "18"], check=True, env=dict(os.environ, **{name: v}))
+        from sdrplusplus_amd import capi
+        subprocess.run([sys.executable, os.path.join(root, "tests", "variant_scenario.py"), out, "18", capi.lib_path()], check=True, env=dict(os.environ, **{name: v}))
         res.append(np.load(out))
     assert len(res[0].files) == 18
     for k in res[0].files:

@@ -1,5 +1,5 @@
 """Helper of test_opt_in_kernel_variants_bit_identical: one process = one setting of the opt-in switches (the library reads them once).
-   python tests/variant_scenario.py OUT.npz NVFO      (SDRPP_GPU_LIB selects emulator / product library as in the other tests)"""
+   python tests/variant_scenario.py OUT.npz NVFO [LIBRARY]      (LIBRARY: the emulator build for the CPU leg of the test)"""
 import os
 import sys
 
@@ -9,6 +9,8 @@ import numpy as np
 from sdrplusplus_amd import capi, radio, workloads
 
 nv = int(sys.argv[2])
+if len(sys.argv) > 3:
+    capi.DEFAULT_LIB = sys.argv[3]
 sizes = [65536, 50000, 1000, 131072, 7, 90001]  # ragged pushes: windows, carries and the resampler phase straddle every cut
 ctx = capi.Context(0, max_push=max(sizes))
 vids = []

@@ -6,6 +6,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 import torch
 from sdrplusplus_amd import capi, radio, workloads
 
+if os.environ.get("SDRPP_GPU_LIB"):  # experimental builds of the library (a switch of this TOOL, not of the binding)
+    capi.DEFAULT_LIB = os.environ["SDRPP_GPU_LIB"]
 push = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 24
 nvfo = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
