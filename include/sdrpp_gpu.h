@@ -20,6 +20,7 @@
 #ifndef SDRPP_GPU_H
 #define SDRPP_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -257,6 +258,21 @@ int sdrpp_push_device(sdrpp_ctx* ctx, const float* iq_dev, int64_t count);
 /* file_source path (source_modules/file_source/src/main.cpp:154-167): interleaved int16 IQ converted on the device
  * (x / 32768), halving the PCIe bytes.  Host pointer. */
 int sdrpp_push_int16(sdrpp_ctx* ctx, const int16_t* iq_host, int64_t count);
+
+/* Page-locked host memory for buffers that are pushed from (the copy out of pageable memory is staged by the runtime and about three
+ * times slower); NULL on failure.  The host blocks allocate their frame-buffer slots with it. */
+void* sdrpp_host_alloc(size_t bytes);
+void sdrpp_host_free(void* p);
+/* Deferred processing: sdrpp_push* only stage the samples (the H2D copy runs, the caller's buffer is free on return) and the next call
+ * that observes results — sdrpp_sync, any *_lines / *_read* / *_count / *_device_buffer(s) / sdrpp_wf_* call — or changes the
+ * configuration processes everything staged since the previous one as ONE pass over the device.  The results then cover ALL those
+ * pushes, concatenated (lines, VFO blocks); every staged push still counts as a reference block of its own for the block-dependent
+ * operations (sdrpp_set_reference_block), so the output is what pushing and reading block by block gives — only the launch sequence is
+ * paid once per pass instead of once per block.  This is how a host that drains a queue of blocks (IQFrontEnd with buffering on) keeps
+ * up at the reference's block size (sample_rate / 200), where a pass is launch-bound.  At most max_push samples can be staged:
+ * a push beyond that returns SDRPP_ERR_INVALID (observe first).  Off (default): every push is processed at once. */
+int sdrpp_set_deferred(sdrpp_ctx* ctx, int on);
+int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed */
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.

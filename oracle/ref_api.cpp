@@ -322,4 +322,67 @@ double ref_bench_cfg3(const float* iq, long long totalSamples, int blockSize, do
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// Any BASELINE configuration: per VFO its own IF rate / bandwidth / offset / radio demodulator (REF_* mode; < 0: none, RxVFO only),
+// plus (fftSize > 0) one windowed FFT + log-power per `fftSize` samples.  cfg 2 = nVfo 0; cfg 4 = 128 VFOs NFM / AM / USB at 61.44 MS/s
+// with the 2^20-point FFT evaluated directly (the reference's own Reshaper cannot carry a 2^20-sample frame).
+// Same threading as ref_bench_cfg3.  Returns seconds of wall time for repeat * totalSamples input samples.
+double ref_bench_cfg(const float* iq, long long totalSamples, int blockSize, double inSR, int nVfo, const double* offsets, const double* ifRates,
+                     const double* bandwidths, const int* modes, int fftSize, int nthreads, int repeat) {
+    std::vector<dsp::channel::RxVFO*> vfos((size_t)nVfo);
+    std::vector<void*> dem((size_t)nVfo, (void*)NULL);
+    for (int v = 0; v < nVfo; v++) {
+        vfos[v] = new dsp::channel::RxVFO;
+        vfos[v]->init(NULL, inSR, ifRates[v], bandwidths[v], offsets[v]);
+        if (modes[v] >= 0) { dem[v] = ref_demod_create(modes[v], bandwidths[v], ifRates[v], 1, 50.0, 5.0, 0); }
+    }
+    std::vector<float> window((size_t)(fftSize > 0 ? fftSize : 1));
+    fftwf_complex *fin = NULL, *fout = NULL;
+    fftwf_plan plan = NULL;
+    std::vector<float> db((size_t)(fftSize > 0 ? fftSize : 1));
+    if (fftSize > 0) {
+        for (int i = 0; i < fftSize; i++) { window[i] = dsp::window::nuttall(i, fftSize) * ((i % 2) ? -1.0f : 1.0f); }
+        fin = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+        fout = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+        plan = fftwf_plan_dft_1d(fftSize, fin, fout, FFTW_FORWARD, FFTW_ESTIMATE);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) {
+        th.emplace_back([&, t]() {
+            complex_t* work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
+            stereo_t* audio = dsp::buffer::alloc<stereo_t>(STREAM_BUFFER_SIZE);
+            for (int rep = 0; rep < repeat; rep++)
+            for (long long pos = 0; pos + blockSize <= totalSamples; pos += blockSize) {
+                const complex_t* blk = (const complex_t*)(iq + 2 * pos);
+                for (int v = t; v < nVfo; v += nthreads) {
+                    int n = vfos[v]->process(blockSize, blk, work);
+                    if (dem[v]) { ref_demod_process(dem[v], n, (const float*)work, (float*)audio); }
+                }
+            }
+            if (t == 0 && fftSize > 0) {
+                for (int rep = 0; rep < repeat; rep++)
+                for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
+                    volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
+                    fftwf_execute(plan);
+                    volk_32fc_s32f_power_spectrum_32f(db.data(), (lv_32fc_t*)fout, fftSize, fftSize);
+                }
+            }
+            dsp::buffer::free(work);
+            dsp::buffer::free(audio);
+        });
+    }
+    for (auto& x : th) { x.join(); }
+    auto t1 = std::chrono::steady_clock::now();
+    for (int v = 0; v < nVfo; v++) {
+        delete vfos[v];
+        if (dem[v]) { ref_demod_destroy(dem[v]); }
+    }
+    if (plan) {
+        fftwf_destroy_plan(plan);
+        fftwf_free(fin);
+        fftwf_free(fout);
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
 } // extern "C"

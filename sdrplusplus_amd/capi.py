@@ -158,6 +158,13 @@ def load():
     L.sdrpp_vfo_set_channel_taps.argtypes = [vp, C.c_int, c_float_p, C.c_int]
     L.sdrpp_vfo_reset.argtypes = [vp, C.c_int]
     L.sdrpp_set_reference_block.argtypes = [vp, C.c_int]
+    L.sdrpp_set_deferred.argtypes = [vp, C.c_int]
+    L.sdrpp_host_alloc.restype = vp
+    L.sdrpp_host_alloc.argtypes = [C.c_size_t]
+    L.sdrpp_host_free.restype = None
+    L.sdrpp_host_free.argtypes = [vp]
+    L.sdrpp_pending.restype = C.c_int64
+    L.sdrpp_pending.argtypes = [vp]
     L.sdrpp_vfo_read_many.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int64, C.POINTER(C.c_int64), c_int_p]
     L.sdrpp_set_nco_mode.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_set_ssb_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
@@ -187,7 +194,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
-    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -297,6 +304,13 @@ class Context:
     def set_reference_block(self, ref_block):
         """Every push = consecutive reference blocks of `ref_block` samples (AGC look-ahead, rotator renormalisation); 0 = one push, one block."""
         self._chk(self.L.sdrpp_set_reference_block(self.h, int(ref_block)))
+
+    def set_deferred(self, on):
+        """Pushes are only staged; the next observing call processes them as one pass (results cover all of them)."""
+        self._chk(self.L.sdrpp_set_deferred(self.h, int(bool(on))))
+
+    def pending(self):
+        return int(self.L.sdrpp_pending(self.h))
 
     def set_nco_mode(self, mode):
         """0 closed-form NCO (default), 1 the reference's float rotator recursion (parity mode).  Only while no VFO exists."""

@@ -135,9 +135,20 @@ struct sdrpp_ctx {
     std::string err;
     std::string devinfo;
 
-    // input
-    float* iq_stage = nullptr;        // H2D landing buffer (max_push complex)
-    int16_t* iq_stage16 = nullptr;
+    // input: landing buffers of host pushes / of a deferred pass (max_push complex each), ping-pong per pass so that the copies of the
+    // next pass overlap the kernels of the current one; copies run on their own stream and are host-synchronised (the caller's
+    // buffer is free again when sdrpp_push returns, like a dsp::stream read buffer after flush())
+    float* iq_land[2] = { nullptr, nullptr };
+    int16_t* iq_land16[2] = { nullptr, nullptr };
+    hipEvent_t land_ev[2] = { nullptr, nullptr };   // recorded behind the pass that read the buffer
+    bool land_used[2] = { false, false };
+    int land_cur = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    // deferred processing (sdrpp_set_deferred): pushes are only staged; the next observing call processes them as ONE pass
+    bool deferred = false;
+    int64_t pending = 0;
+    std::vector<int> pend_ends;       // cumulative end of every staged push
     float* iq_hist[2] = { nullptr, nullptr };
     int iq_hist_cap = 0;              // samples of history kept
     int iq_cur = 0;
@@ -223,7 +234,7 @@ struct sdrpp_ctx {
     std::map<int, std::unique_ptr<Vfo>> vfos;
     int next_id = 1;
     // cached stage-1 job tap arrays, keyed by membership signature
-    std::map<std::string, float2*> s1_tap_cache;
+    std::map<std::string, float2*> s1_tap_cache;  // key = 16 raw bytes: two independent 64-bit hashes of (kind, member ids, increments)
 
     // timing
     bool timing = false;
@@ -830,6 +841,25 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
 // ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
 struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; unsigned long long taph; };
 
+// Cache key of a front-end job's tap operand: membership (VFO ids) and NCO increments, as two independent 64-bit hashes (the job
+// tables are rebuilt on every push: formatting 32 ids and doubles into a string cost more host time than the launch itself)
+std::string member_key(char kind, const S1Member* m, int n) {
+    unsigned long long h1 = 1469598103934665603ull ^ (unsigned char)kind, h2 = 0x9e3779b97f4a7c15ull + (unsigned char)kind;
+    for (int i = 0; i < n; i++) {
+        unsigned long long tb;
+        memcpy(&tb, &m[i].v->theta, 8);
+        const unsigned long long id = (unsigned long long)(unsigned)m[i].v->id;
+        h1 = (h1 ^ id) * 1099511628211ull;
+        h1 = (h1 ^ tb) * 1099511628211ull;
+        h2 ^= id + 0x9e3779b97f4a7c15ull + (h2 << 6) + (h2 >> 2);
+        h2 ^= tb + 0x9e3779b97f4a7c15ull + (h2 << 6) + (h2 >> 2);
+    }
+    char raw[16];
+    memcpy(raw, &h1, 8);
+    memcpy(raw + 8, &h2, 8);
+    return std::string(raw, 16);
+}
+
 // Stage-2 outputs per block of the fused front kernel (0 = do not fuse: the recomputed overlap would dominate or LDS would overflow).
 int front2_t2(int K1, int D1, int K2, int D2, int vt) {
     const int tile = 256;
@@ -1217,12 +1247,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int D1 = 1 << h.lgD;
             const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
             const int NP = (K + 1) / 2, NP4 = (NP + 3) / 4 * 4;
-            std::string key = m_long ? "L" : "M";
-            for (int m = 0; m < vt; m++) {
-                char b[64];
-                snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
-                key += b;
-            }
+            const std::string key = member_key(m_long ? 'L' : 'M', &s1[g], vt);
             float2* d_taps = nullptr;
             auto it = c->s1_tap_cache.find(key);
             if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
@@ -1309,12 +1334,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
             const int vt = vts[li];
             // tap array for this membership (cached on the device)
-            std::string key;
-            for (int m = 0; m < vt; m++) {
-                char b[64];
-                snprintf(b, sizeof(b), "%d:%.17g;", s1[g + m].v->id, s1[g + m].v->theta);
-                key += b;
-            }
+            const std::string key = member_key('V', &s1[g], vt);
             float2* d_taps = nullptr;
             auto it = c->s1_tap_cache.find(key);
             if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
@@ -1723,13 +1743,18 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     if (!carry.empty()) {
         FamilyTimer t(c, F_MISC);
-        // job 0 = the shared IQ stream (can be a whole FFT frame long): its own grid; the per-VFO histories are a few hundred samples
+        // job 0 = the shared IQ stream (up to a whole FFT frame long), the per-VFO histories are a few hundred samples: a long IQ carry
+        // gets its own wide grid, otherwise one launch serves all jobs (every block strides over its job)
         const int iq_elems = carry[0].need * carry[0].width;
-        launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
-        if (carry.size() > 1) {
-            int mx = 0;
-            for (size_t k = 1; k < carry.size(); k++) { mx = std::max(mx, carry[k].need * carry[k].width); }
+        int mx = 0;
+        for (size_t k = 1; k < carry.size(); k++) { mx = std::max(mx, carry[k].need * carry[k].width); }
+        if (iq_elems > 16384 && carry.size() > 1) {
+            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
             launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)carry.size() - 1), dim3(256), 0, (const CarryJob*)(d_carry + 1));
+        }
+        else {
+            mx = std::max(mx, iq_elems);
+            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 1023) / 1024, 2048)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
         }
     }
     // flip the ping-pong side of every carried stream
@@ -1830,7 +1855,8 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
     return SDRPP_OK;
 }
 
-int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
+// `push_ends`: cumulative ends of the pushes a deferred pass combines (nullptr: the pass is one push)
+int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vector<int>* push_ends = nullptr) {
     if (count == 0) {  // an empty block produces nothing (and changes no state)
         c->n_lines = 0;
         for (auto& kv : c->vfos) {
@@ -1845,12 +1871,18 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
     }
     if (rc0) { return rc0; }
     {   // the reference's blocks inside this push (sdrpp_set_reference_block): ends as cumulative sample counts
+        // every push is at least one block of its own; with a reference block size it is cut further
         std::vector<int>& B = c->vfo_bounds;
         B.clear();
-        if (c->ref_block > 0) {
-            for (int64_t e = c->ref_block; e < count; e += c->ref_block) { B.push_back((int)e); }
+        const std::vector<int> whole{ (int)count };
+        int64_t lo = 0;
+        for (int e : (push_ends ? *push_ends : whole)) {
+            if (c->ref_block > 0) {
+                for (int64_t q = lo + c->ref_block; q < e; q += c->ref_block) { B.push_back((int)q); }
+            }
+            if (e > lo || B.empty()) { B.push_back(e); }
+            lo = e;
         }
-        B.push_back((int)count);
     }
     if (c->pre.on) {
         rc0 = run_preproc(c, &d_iq, &count);
@@ -1932,7 +1964,16 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count) {
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
+// every call that observes results or changes the configuration first processes what deferred pushes have staged
+#define FLUSH_PENDING(c)                          \
+    do {                                          \
+        int frc_ = flush_pending(c);              \
+        if (frc_) { return frc_; }                \
+    } while (0)
+
 extern "C" {
+
+int flush_pending(sdrpp_ctx* c);  // deferred pushes -> one pass (defined with the data path below; internal, not part of the ABI header)
 
 const char* sdrpp_strerror(int code) {
     switch (code) {
@@ -1987,7 +2028,12 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
             return SDRPP_ERR_NOMEM;
         }
     }
-    if (dev_alloc(c, &c->arena_dev, kArenaBytes) != SDRPP_OK || dev_alloc(c, &c->iq_stage, (size_t)max_push * 2 + 32) != SDRPP_OK) {
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_copy) != hipSuccess ||
+        hipEventCreate(&c->land_ev[0]) != hipSuccess || hipEventCreate(&c->land_ev[1]) != hipSuccess) {
+        sdrpp_destroy(c);
+        return SDRPP_ERR_NO_DEVICE;
+    }
+    if (dev_alloc(c, &c->arena_dev, kArenaBytes) != SDRPP_OK || dev_alloc(c, &c->iq_land[0], (size_t)max_push * 2 + 32) != SDRPP_OK) {
         sdrpp_destroy(c);
         return SDRPP_ERR_NOMEM;
     }
@@ -2006,6 +2052,7 @@ static void wf_free(sdrpp_ctx* c) {
 
 int sdrpp_wf_configure(sdrpp_ctx* c, int height) {
     if (!c || height < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
     wf_free(c);
@@ -2020,6 +2067,7 @@ int sdrpp_wf_configure(sdrpp_ctx* c, int height) {
 
 int sdrpp_wf_set_smoothing(sdrpp_ctx* c, int enabled, float speed) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
@@ -2039,6 +2087,7 @@ int sdrpp_wf_set_smoothing(sdrpp_ctx* c, int enabled, float speed) {
 
 int sdrpp_wf_set_hold(sdrpp_ctx* c, int enabled, float speed) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->fft_stream) { HIPCHK(c, hipStreamSynchronize(c->fft_stream)); }
@@ -2056,6 +2105,7 @@ int sdrpp_wf_set_hold(sdrpp_ctx* c, int enabled, float speed) {
 
 int sdrpp_wf_latest(sdrpp_ctx* c, float* latest, float* hold) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
     if (W.height <= 0 || W.width <= 0 || !W.d_latest) { return fail(c, SDRPP_ERR_INVALID, "no waterfall trace yet"); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2067,6 +2117,7 @@ int sdrpp_wf_latest(sdrpp_ctx* c, float* latest, float* hold) {
 // updateWaterfallFb (waterfall.cpp:600-631): every stored line re-zoomed with a NEW view, newest first
 int sdrpp_wf_raster(sdrpp_ctx* c, int draw_start, int draw_size, int data_width, float wf_min, float wf_max, int32_t* dst_host, int* n_lines) {
     if (!c || !dst_host || data_width <= 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
     if (W.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2136,8 +2187,13 @@ int sdrpp_destroy(sdrpp_ctx* c) {
         if (c->arena_ev[i]) { (void)hipEventDestroy(c->arena_ev[i]); }
     }
     dev_free(c->arena_dev);
-    dev_free(c->iq_stage);
-    dev_free(c->iq_stage16);
+    for (int i = 0; i < 2; i++) {
+        dev_free(c->iq_land[i]);
+        dev_free(c->iq_land16[i]);
+        if (c->land_ev[i]) { (void)hipEventDestroy(c->land_ev[i]); }
+    }
+    if (c->ev_copy) { (void)hipEventDestroy(c->ev_copy); }
+    if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); }
     dev_free(c->iq_hist[0]);
     dev_free(c->iq_hist[1]);
     dev_free(c->d_window);
@@ -2162,6 +2218,7 @@ const char* sdrpp_last_error(const sdrpp_ctx* c) { return c ? c->err.c_str() : "
 
 int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     c->launch_stream = c->stream;
@@ -2170,6 +2227,7 @@ int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
 
 int sdrpp_sync(sdrpp_ctx* c) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SDRPP_OK;
 }
@@ -2183,6 +2241,7 @@ int sdrpp_device_info(sdrpp_ctx* c, char* buf, int buflen) {
 // ---- FFT ---------------------------------------------------------------------------------------------------------------------
 int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const float* window) {
     if (!c || !window) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (!is_pow2(fft_size) || fft_size < 1024 || fft_size > (1 << 20)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft_size %d: need a power of two in [1024, 1048576]", fft_size); }
     if (nz <= 0 || nz > fft_size || skip < 0) { return fail(c, SDRPP_ERR_INVALID, "bad framing nz=%d skip=%d", nz, skip); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2245,6 +2304,7 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
 
 int sdrpp_fft_disable(sdrpp_ctx* c) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->fft_on = false;
     c->n_lines = 0;
@@ -2253,6 +2313,7 @@ int sdrpp_fft_disable(sdrpp_ctx* c) {
 
 int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float wf_min, float wf_max) {
     if (!c || data_width < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->view_start = start;
     c->view_size = size;
@@ -2272,10 +2333,15 @@ int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float 
     return ensure_zoom(c, c->lines_cap);
 }
 
-int sdrpp_fft_lines(sdrpp_ctx* c) { return c ? c->n_lines : SDRPP_ERR_INVALID; }
+int sdrpp_fft_lines(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
+    return c->n_lines;
+}
 
 int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
     if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (first >= c->n_lines) { return 0; }
     n = std::min(n, c->n_lines - first);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2292,6 +2358,7 @@ int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, in
 
 int sdrpp_fft_copy_device(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
     if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (first >= c->n_lines) { return 0; }
     n = std::min(n, c->n_lines - first);
     if (raw) { HIPCHK(c, hipMemcpyAsync(raw, c->d_lines + (size_t)first * c->fft_size, (size_t)n * c->fft_size * sizeof(float), hipMemcpyDeviceToDevice, c->stream)); }
@@ -2303,6 +2370,7 @@ int sdrpp_fft_copy_device(sdrpp_ctx* c, int first, int n, float* raw, float* zoo
 
 int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoomed, const int32_t** index, int* n_lines) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (raw) { *raw = c->d_lines; }
     if (zoomed) { *zoomed = c->d_zoomed; }
     if (index) { *index = c->d_index; }
@@ -2312,6 +2380,7 @@ int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoom
 
 int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps, float dc_rate, int conjugate) {
     if (!c || n_stages < 0 || n_stages > SDRPP_MAX_DECIM_STAGES) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     for (int s = 0; s < n_stages; s++) {
         if (!stage_decim || !stage_ntaps || !stage_taps || !is_pow2(stage_decim[s]) || stage_ntaps[s] <= 0 || !stage_taps[s]) {
             return fail(c, SDRPP_ERR_UNSUPPORTED, "pre-processing stage %d: decimation must be a power of two with taps", s);
@@ -2366,12 +2435,14 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
 
 int sdrpp_preproc_out_count(sdrpp_ctx* c) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
     return c->pre.last_n;
 }
 
 int sdrpp_preproc_read(sdrpp_ctx* c, float* dst, int max) {
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
     const int n = std::min(max, c->pre.last_n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2381,6 +2452,7 @@ int sdrpp_preproc_read(sdrpp_ctx* c, float* dst, int max) {
 
 int sdrpp_preproc_device_buffer(sdrpp_ctx* c, const float** iq, int* n) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
     if (iq) { *iq = c->pre.last; }
     if (n) { *n = c->pre.last_n; }
@@ -2390,6 +2462,7 @@ int sdrpp_preproc_device_buffer(sdrpp_ctx* c, const float** iq, int* n) {
 // ---- VFOs ----------------------------------------------------------------------------------------------------------------------
 int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     if (!c || !d || !id) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (d->n_stages < 0 || d->n_stages > SDRPP_MAX_DECIM_STAGES) { return fail(c, SDRPP_ERR_INVALID, "n_stages %d", d->n_stages); }
     for (int s = 0; s < d->n_stages; s++) {
         if (!is_pow2(d->stage_decim[s]) || d->stage_ntaps[s] <= 0 || !d->stage_taps[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage %d: decimation must be a power of two with taps", s); }
@@ -2567,6 +2640,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
 
 int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2579,6 +2653,7 @@ int sdrpp_vfo_count(sdrpp_ctx* c) { return c ? (int)c->vfos.size() : SDRPP_ERR_I
 
 int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
@@ -2598,6 +2673,7 @@ int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
 
 int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     if (!c || n < 0 || n > kChanHistCap + 1 || (n > 0 && !taps)) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
@@ -2641,6 +2717,7 @@ static void af_detach(Vfo& v) {
 
 int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
@@ -2735,6 +2812,7 @@ static Stream* af_stream(Vfo& v) { return (v.af.on && v.af.i_last >= 0) ? &v.st[
 
 int sdrpp_vfo_af_count(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = af_stream(*it->second);
@@ -2744,6 +2822,7 @@ int sdrpp_vfo_af_count(sdrpp_ctx* c, int id) {
 
 int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = af_stream(*it->second);
@@ -2756,6 +2835,7 @@ int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
 
 int sdrpp_vfo_af_device_buffer(sdrpp_ctx* c, int id, const float** out, int* n_out) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = af_stream(*it->second);
@@ -2787,6 +2867,7 @@ static int pack_scratch(sdrpp_ctx* c, size_t bytes) {
 
 int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scale, void* dst_host, int max_frames) {
     if (!c || !dst_host || max_frames < 0 || (pcm_type != 0 && pcm_type != 1)) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = pick_stream(c, *it->second, which);
@@ -2807,6 +2888,7 @@ int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scal
 
 int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes) {
     if (!c || !dst_host || pcm_type < 0 || pcm_type > 2) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = pick_stream(c, *it->second, which);
@@ -2852,6 +2934,7 @@ int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, uns
 // calculateVFOSignalInfo (waterfall.cpp:558-598) on the newest line of the history ring
 int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, double whole_bandwidth, float* strength, float* snr) {
     if (!c || !strength || !snr) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
     if (W.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
     if (W.lines <= 0) { return 0; }  // the reference returns false: nothing to measure yet
@@ -2878,12 +2961,14 @@ int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, d
 
 int sdrpp_set_reference_block(sdrpp_ctx* c, int ref_block) {
     if (!c || ref_block < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     c->ref_block = ref_block;
     return SDRPP_OK;
 }
 
 int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
     if (!c || (mode != SDRPP_NCO_CLOSED_FORM && mode != SDRPP_NCO_REFERENCE_ROTATOR)) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     if (!c->vfos.empty() && mode != c->nco_exact) { return fail(c, SDRPP_ERR_INVALID, "the NCO mode can only change while no VFO exists (it decides how a VFO's front end is built)"); }
     c->nco_exact = mode;
     return SDRPP_OK;
@@ -2891,6 +2976,7 @@ int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
 
 int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
@@ -2903,6 +2989,7 @@ int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
 
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     return vfo_reset_state(c, *it->second);
@@ -2912,6 +2999,7 @@ static Stream* out_stream(Vfo& v) { return (v.d.demod == SDRPP_DEMOD_RAW) ? &v.s
 
 int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     return out_stream(*it->second)->n;
@@ -2919,6 +3007,7 @@ int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
 
 int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Stream* s = out_stream(*it->second);
@@ -2930,6 +3019,7 @@ int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
 
 int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, float* dst_host, int64_t max_samples, int64_t* offsets, int* counts) {
     if (!c || n < 0 || (n > 0 && (!ids || !dst_host || !offsets || !counts)) || max_samples < 0) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     std::vector<GatherJob> jobs;
     int64_t total = 0;
     int mx = 0;
@@ -2971,6 +3061,7 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
 
 int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out, const float** if_out, int* n_if) {
     if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     Vfo& v = *it->second;
@@ -2983,35 +3074,121 @@ int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out
 }
 
 // ---- data path --------------------------------------------------------------------------------------------------------------------
+// Landing buffer of the pass being assembled (allocated on first use of the second one; waits until the pass that last read it is done)
+static int landing_acquire(sdrpp_ctx* c, bool need16) {
+    const int b = c->land_cur;
+    if (!c->iq_land[b]) {
+        int rc = dev_alloc(c, &c->iq_land[b], (size_t)c->max_push * 2 + 32);
+        if (rc) { return rc; }
+    }
+    if (need16 && !c->iq_land16[b]) {
+        int rc = dev_alloc(c, &c->iq_land16[b], (size_t)c->max_push * 2 + 32);
+        if (rc) { return rc; }
+    }
+    if (c->pending == 0 && c->land_used[b]) {
+        HIPCHK(c, hipEventSynchronize(c->land_ev[b]));
+        c->land_used[b] = false;
+    }
+    return SDRPP_OK;
+}
+// the pass over what has been staged: kernels enqueued, landing buffer marked busy until they are done, the other one becomes current
+static int landing_process(sdrpp_ctx* c, int64_t count, const std::vector<int>* ends) {
+    const int b = c->land_cur;
+    int rc = push_common(c, c->iq_land[b], count, ends);
+    (void)hipEventRecord(c->land_ev[b], c->stream);
+    c->land_used[b] = true;
+    c->land_cur ^= 1;
+    return rc;
+}
+int flush_pending(sdrpp_ctx* c) {
+    if (c->pending == 0) { return SDRPP_OK; }
+    const int64_t n = c->pending;
+    c->pending = 0;  // cleared first: push_common's own helpers may call observing functions
+    std::vector<int> ends;
+    ends.swap(c->pend_ends);
+    return landing_process(c, n, &ends);
+}
+static int push_args_ok(sdrpp_ctx* c, const void* p, int64_t count) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if ((!p && count > 0) || count < 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push); }
+    if (c->deferred && c->pending + count > c->max_push) {
+        return fail(c, SDRPP_ERR_INVALID, "deferred pushes hold %lld samples, %lld more exceed max_push %lld: observe the results first", (long long)c->pending, (long long)count, (long long)c->max_push);
+    }
+    return SDRPP_OK;
+}
+
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
-    if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return c ? fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push) : SDRPP_ERR_INVALID; }
-    if (count == 0) { return push_common(c, nullptr, 0); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the landing buffer is single: the previous push must have consumed it
-    HIPCHK(c, hipMemcpyAsync(c->iq_stage, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    return push_common(c, c->iq_stage, count);
+    int rc = push_args_ok(c, iq_host, count);
+    if (rc) { return rc; }
+    if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
+    rc = landing_acquire(c, false);
+    if (rc) { return rc; }
+    float* land = c->iq_land[c->land_cur] + 2 * c->pending;
+    HIPCHK(c, hipMemcpyAsync(land, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_copy));  // the caller's buffer is free again; the kernels of the previous pass keep running meanwhile
+    if (c->deferred) {
+        c->pending += count;
+        c->pend_ends.push_back((int)c->pending);
+        return SDRPP_OK;
+    }
+    return landing_process(c, count, nullptr);
 }
 
 int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
-    if (!c || (!iq_dev && count > 0) || count < 0 || count > c->max_push) { return c ? fail(c, SDRPP_ERR_INVALID, "push of %lld samples (max %lld)", (long long)count, (long long)c->max_push) : SDRPP_ERR_INVALID; }
-    return push_common(c, iq_dev, count);
+    int rc = push_args_ok(c, iq_dev, count);
+    if (rc) { return rc; }
+    if (!c->deferred) { return push_common(c, iq_dev, count); }  // read in place
+    if (count == 0) { return SDRPP_OK; }
+    rc = landing_acquire(c, false);
+    if (rc) { return rc; }
+    HIPCHK(c, hipMemcpyAsync(c->iq_land[c->land_cur] + 2 * c->pending, iq_dev, (size_t)count * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    c->pending += count;
+    c->pend_ends.push_back((int)c->pending);
+    return SDRPP_OK;
 }
 
 int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
-    if (!c || (!iq_host && count > 0) || count < 0 || count > c->max_push) { return SDRPP_ERR_INVALID; }
-    if (count == 0) { return push_common(c, nullptr, 0); }
-    if (!c->iq_stage16) {
-        int rc = dev_alloc(c, &c->iq_stage16, (size_t)c->max_push * 2);
-        if (rc) { return rc; }
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->iq_stage16, iq_host, (size_t)count * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    int rc = push_args_ok(c, iq_host, count);
+    if (rc) { return rc; }
+    if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
+    rc = landing_acquire(c, true);
+    if (rc) { return rc; }
+    const int b = c->land_cur;
+    int16_t* land16 = c->iq_land16[b] + 2 * c->pending;
+    HIPCHK(c, hipMemcpyAsync(land16, iq_host, (size_t)count * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_copy));
     {
         FamilyTimer t(c, F_MISC);
         const long long n = (long long)count * 2;
-        launch(c, int16_to_float_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, (const int16_t*)c->iq_stage16, c->iq_stage, n);
+        launch(c, int16_to_float_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, (const int16_t*)land16, c->iq_land[b] + 2 * c->pending, n);
     }
-    return push_common(c, c->iq_stage, count);
+    if (c->deferred) {
+        c->pending += count;
+        c->pend_ends.push_back((int)c->pending);
+        return SDRPP_OK;
+    }
+    return landing_process(c, count, nullptr);
 }
+
+// page-locked host memory for buffers the caller pushes from (an H2D copy from pageable memory is staged by the runtime: ~3x slower)
+void* sdrpp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { return nullptr; }
+    return p;
+}
+void sdrpp_host_free(void* p) {
+    if (p) { (void)hipHostFree(p); }
+}
+
+int sdrpp_set_deferred(sdrpp_ctx* c, int on) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    int rc = flush_pending(c);
+    c->deferred = on != 0;
+    return rc;
+}
+int64_t sdrpp_pending(sdrpp_ctx* c) { return c ? c->pending : SDRPP_ERR_INVALID; }
 
 // ---- measurement ---------------------------------------------------------------------------------------------------------------------
 int sdrpp_timing_enable(sdrpp_ctx* c, int on) {

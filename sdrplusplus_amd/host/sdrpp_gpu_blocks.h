@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -147,8 +148,7 @@ public:
         }
         for (auto& kv : vfos) { delete kv.second; }
         if (ctx) { sdrpp_destroy(ctx); }
-        for (int i = 0; i < FRAME_SLOTS; i++) { free(frames[i]); }
-        free(frameStage);
+        for (int i = 0; i < FRAME_SLOTS; i++) { sdrpp_host_free(frames[i]); }
     }
 
     // iq_frontend.h:23.  decimRatio / dcBlocking configure the pre-processing chain (PowerDecimator -> DCBlocker -> Conjugate,
@@ -171,6 +171,7 @@ public:
         if (plans) { _plans = *plans; }
         int rc = sdrpp_create(device, SDRPP_GPU_MAX_BLOCK, &ctx);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] ") + sdrpp_strerror(rc)); }
+        sdrpp_set_deferred(ctx, 1);  // blocks are staged by stage() and processed by the first read of deliver(): one block or a whole backlog
         registerInput(_in);
         updatePreproc();
         updateFFTPath();
@@ -290,6 +291,17 @@ public:
         }
         return nullptr;
     }
+    // Control calls that do not restart the worker in the reference (RxVFO::setOffset, SSB's translation) reach the context through the
+    // worker: the C-ABI context belongs to one thread at a time.  While the worker runs they are queued and applied in front of the next
+    // block (where the reference's mutexes let them in as well); otherwise they are applied at once.  Call with ctrlMtx held.
+    void control(std::function<void()> op) {
+        if (running && !tempStopped) {
+            std::lock_guard<std::mutex> lck(ctlMtx);
+            ctlOps.push_back(std::move(op));
+        }
+        else { op(); }
+    }
+
     // Parity switch (not in the reference): run the reference's float rotator recursion on the device instead of the closed-form NCO
     // (sdrpp_set_nco_mode).  Rebuilds every VFO.
     void setReferenceRotator(bool enabled) {
@@ -310,13 +322,18 @@ public:
         int count = _in->read();
         if (count < 0) { return -1; }
         if (!_buffering) {
-            const int rc = process((const dsp::complex_t*)_in->readBuf, count);
+            drainControl();
+            int rc = stage((const dsp::complex_t*)_in->readBuf, count);  // the H2D copy is complete on return: the stream buffer is free
             _in->flush();
+            if (rc >= 0) { rc = deliver((const dsp::complex_t*)nullptr, count); }
             return rc < 0 ? -1 : count;
         }
         {
             std::lock_guard<std::mutex> lck(frameMtx);
-            if (!frames[frameWrite]) { frames[frameWrite] = (dsp::complex_t*)malloc(sizeof(dsp::complex_t) * STREAM_BUFFER_SIZE); }
+            if (!frames[frameWrite]) {  // page-locked: the copy to the device runs straight out of the slot
+                frames[frameWrite] = (dsp::complex_t*)sdrpp_host_alloc(sizeof(dsp::complex_t) * STREAM_BUFFER_SIZE);
+                if (!frames[frameWrite]) { throw std::runtime_error("[sdrpp_gpu::IQFrontEnd] cannot allocate a frame-buffer slot"); }
+            }
             memcpy(frames[frameWrite], _in->readBuf, (size_t)count * sizeof(dsp::complex_t));
             frameSizes[frameWrite] = count;
             frameWrite = (frameWrite + 1) % FRAME_SLOTS;
@@ -355,30 +372,65 @@ private:
     friend class RxVFO;
     static constexpr int FRAME_SLOTS = 32;  // TEST_BUFFER_SIZE, frame_buffer.h:3
 
+    // Second worker (SampleFrameBuffer::worker, frame_buffer.h:76-98).  The reference hands the queued frames on one by one; here
+    // EVERYTHING that is queued goes to the device as one deferred pass (every frame still a block of its own for the block-dependent
+    // operations), so a backlog is worked off at large-batch speed instead of launch-bound frame by frame.  With consumers of the
+    // wideband IQ bound (bindIQStream) the frames are handed on one by one, as those consumers receive them block-wise.
     void frameWorker() {
         while (true) {
-            int count;
+            int staged = 0, last = 0;
             {
                 std::unique_lock<std::mutex> lck(frameMtx);
                 frameCnd.wait(lck, [this]() { return (((frameWrite - frameRead + FRAME_SLOTS) % FRAME_SLOTS) > 0) || stopFrameWorker; });
                 if (stopFrameWorker) { break; }
-                count = frameSizes[frameRead];
-                if (!frameStage) { frameStage = (dsp::complex_t*)malloc(sizeof(dsp::complex_t) * STREAM_BUFFER_SIZE); }
-                memcpy(frameStage, frames[frameRead], (size_t)count * sizeof(dsp::complex_t));  // under the lock, like the reference's copy into out.writeBuf
-                frameRead = (frameRead + 1) % FRAME_SLOTS;
+                lck.unlock();
+                drainControl();  // may run a pass (a retune first processes what is staged): not under the producer's lock
+                lck.lock();
+                // under the lock, like the reference's copy into out.writeBuf: the copy to the device is complete when stage() returns
+                while (((frameWrite - frameRead + FRAME_SLOTS) % FRAME_SLOTS) > 0) {
+                    const int count = frameSizes[frameRead];
+                    if (staged > 0 && ((int64_t)staged + count > SDRPP_GPU_MAX_BLOCK || !iqStreams.empty())) { break; }
+                    if (!iqStreams.empty()) {  // the bound consumers need this block's samples after the lock is gone
+                        tapCopy.assign(frames[frameRead], frames[frameRead] + count);
+                    }
+                    if (stage(frames[frameRead], count) < 0) { return; }
+                    frameRead = (frameRead + 1) % FRAME_SLOTS;
+                    staged += count;
+                    last = count;
+                }
             }
-            if (process(frameStage, count) < 0) { break; }
+            if (deliver(iqStreams.empty() ? nullptr : tapCopy.data(), last) < 0) { break; }
         }
     }
 
-    // One block in -> FFT lines through acquire/release, the pre-processed IQ on every bound stream, one block out on every VFO stream.
-    int process(const dsp::complex_t* data, int count) {
+    void drainControl() {
+        std::vector<std::function<void()>> ops;
+        {
+            std::lock_guard<std::mutex> lck(ctlMtx);
+            ops.swap(ctlOps);
+        }
+        for (auto& op : ops) { op(); }
+    }
+
+    // one block to the device (copy only; the kernels run with the first read of deliver())
+    int stage(const dsp::complex_t* data, int count) {
         int rc = sdrpp_push(ctx, (const float*)data, count);
         if (rc) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
             return -1;
         }
-        const int nlines = sdrpp_fft_lines(ctx);
+        if (!_buffering && !iqStreams.empty()) { tapCopy.assign(data, data + count); }
+        return count;
+    }
+
+    // everything staged -> FFT lines through acquire/release, the pre-processed IQ on every bound stream, one block out on every VFO stream
+    int deliver(const dsp::complex_t* data, int count) {
+        if (!data && !iqStreams.empty()) { data = tapCopy.data(); }
+        const int nlines = sdrpp_fft_lines(ctx);  // first observing call: processes what is staged
+        if (nlines < 0) {
+            fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] processing failed: %s\n", sdrpp_last_error(ctx));
+            return -1;
+        }
         for (int i = 0; i < nlines; i++) {
             float* buf = _acquire ? _acquire(_fftCtx) : nullptr;  // may be NULL: still paired with release (iq_frontend.cpp:258-266)
             if (buf) { sdrpp_fft_read(ctx, i, 1, buf, nullptr, nullptr); }
@@ -411,7 +463,7 @@ private:
         int total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
         if (total == SDRPP_ERR_INVALID) {  // more than the staging holds (very many VFOs at a high output rate): size it and retry once
             long long need = 0;
-            for (auto& kv : vfos) { need += std::max(sdrpp_vfo_out_count(ctx, kv.second->id), sdrpp_vfo_af_count(ctx, kv.second->id)); }
+            for (auto& kv : vfos) { need += std::max(sdrpp_vfo_out_count(ctx, kv.second->id), kv.second->afOn ? sdrpp_vfo_af_count(ctx, kv.second->id) : 0); }
             gather.resize((size_t)2 * (size_t)(need + 1024));
             total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
         }
@@ -592,7 +644,9 @@ private:
     dsp::complex_t* frames[FRAME_SLOTS] = {};
     int frameSizes[FRAME_SLOTS] = {};
     int frameWrite = 0, frameRead = 0;
-    dsp::complex_t* frameStage = nullptr;
+    std::vector<dsp::complex_t> tapCopy;  // the block the bound IQ consumers are about to receive
+    std::mutex ctlMtx;
+    std::vector<std::function<void()>> ctlOps;
     std::mutex frameMtx;
     std::condition_variable frameCnd;
     std::thread frameThread;
@@ -622,7 +676,9 @@ inline void RxVFO::setDemodBandwidth(double bw) {
     if (demod == Demod::USB || demod == Demod::LSB) {  // ssb.h:44-50, 106-117: only the second translation follows the bandwidth — no restart
         float re, im;
         sdrpp_design_phase_delta(demod == Demod::USB ? bw / 2.0 : -bw / 2.0, outSamplerate, &re, &im);
-        sdrpp_vfo_set_ssb_phase_delta(fe->ctx, id, re, im);
+        IQFrontEnd* f = fe;
+        RxVFO* self = this;
+        fe->control([f, self, re, im]() { sdrpp_vfo_set_ssb_phase_delta(f->ctx, self->id, re, im); });
         return;
     }
     if (demod == Demod::DSB) { return; }
@@ -635,7 +691,9 @@ inline void RxVFO::setOffset(double off) {
     offset = off;
     float re, im;
     sdrpp_design_phase_delta(-offset, inSamplerate, &re, &im);
-    sdrpp_vfo_set_phase_delta(fe->ctx, id, re, im);  // phase stays continuous, no restart (rx_vfo.h:72-77)
+    IQFrontEnd* f = fe;
+    RxVFO* self = this;
+    fe->control([f, self, re, im]() { sdrpp_vfo_set_phase_delta(f->ctx, self->id, re, im); });  // phase stays continuous, no restart (rx_vfo.h:72-77)
 }
 inline void RxVFO::setBandwidth(double bw) {
     std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);

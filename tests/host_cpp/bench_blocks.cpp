@@ -1,0 +1,104 @@
+// Throughput of the hot path THROUGH the C++ host mirror, measured the way SDR++'s SpeedTester measures a graph
+// (core/src/dsp/bench/speed_tester.h:31-92): an unthrottled source thread swap()s fixed-size IQ blocks into the front end's input
+// stream (back-pressured by the stream hand-off), sink threads read() / flush() every output stream, and the rate is samples
+// ingested per wall second.  Workload = BASELINE cfg 3 (65536-point FFT, nvfo WFM VFOs 300 kHz apart) at the block size given.
+//   usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered 0|1>
+// Prints one JSON object.  Built by bench.py against tests/host_cpp/standalone (the test double of dsp::block / dsp::stream).
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../sdrplusplus_amd/host/sdrpp_gpu_blocks.h"
+
+static std::atomic<long long> g_lines{ 0 };
+static std::vector<float> g_line;
+static float* acquire(void*) { return g_line.data(); }
+static void release(void*) { g_lines++; }
+
+int main(int argc, char** argv) {
+    if (argc < 8) {
+        fprintf(stderr, "usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered>\n");
+        return 2;
+    }
+    sdrpp_gpu::DecimPlans plans;
+    if (!plans.load(argv[1])) {
+        fprintf(stderr, "cannot load plans\n");
+        return 1;
+    }
+    const double sr = atof(argv[2]);
+    const int block = atoi(argv[3]), fftSize = atoi(argv[4]), nvfo = atoi(argv[5]);
+    const double seconds = atof(argv[6]);
+    const bool buffered = atoi(argv[7]) != 0;
+    g_line.assign((size_t)fftSize, 0.0f);
+
+    // four distinct blocks of tones + FM carriers (content does not change the work)
+    std::vector<std::vector<dsp::complex_t>> blocks(4, std::vector<dsp::complex_t>((size_t)block));
+    for (int b = 0; b < 4; b++) {
+        for (int i = 0; i < block; i++) {
+            const double t = (double)(b * block + i) / sr;
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < nvfo; k += 4) {
+                const double f = (k - (nvfo - 1) / 2.0) * 300e3;
+                const double ph = 2.0 * M_PI * f * t + 50.0 * std::sin(2.0 * M_PI * 1000.0 * t);
+                re += 0.05 * std::cos(ph);
+                im += 0.05 * std::sin(ph);
+            }
+            blocks[(size_t)b][(size_t)i] = { (float)re, (float)im };
+        }
+    }
+
+    dsp::stream<dsp::complex_t> src;
+    sdrpp_gpu::IQFrontEnd fe;
+    fe.init(&src, sr, buffered, 1, false, fftSize, sr / (double)fftSize /* dense framing */, sdrpp_gpu::IQFrontEnd::NUTTALL, acquire, release, nullptr, 0, &plans);
+    std::vector<sdrpp_gpu::RxVFO*> vfos;
+    for (int k = 0; k < nvfo; k++) {
+        sdrpp_gpu::RxVFO* v = fe.addVFO("vfo" + std::to_string(k), 250000.0, 150000.0, (k - (nvfo - 1) / 2.0) * 300e3);
+        if (!v) { return 1; }
+        v->attachDemod(sdrpp_gpu::Demod::WFM);
+        vfos.push_back(v);
+    }
+    std::atomic<long long> audioFrames{ 0 };
+    std::vector<std::thread> sinks;
+    for (auto* v : vfos) {
+        sinks.emplace_back([v, &audioFrames]() {
+            while (true) {
+                int n = v->audio.read();
+                if (n < 0) { break; }
+                audioFrames += n;
+                v->audio.flush();
+            }
+        });
+    }
+    fe.start();
+    std::atomic<bool> stop{ false };
+    std::atomic<long long> fed{ 0 };
+    std::thread source([&]() {
+        int b = 0;
+        while (!stop) {
+            memcpy(src.writeBuf, blocks[(size_t)(b++ & 3)].data(), sizeof(dsp::complex_t) * (size_t)block);
+            if (!src.swap(block)) { break; }
+            fed += block;
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(500));  // warm-up
+    const long long f0 = fed, a0 = audioFrames, l0 = g_lines;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    const long long f1 = fed, a1 = audioFrames, l1 = g_lines;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stop = true;
+    src.stopWriter();
+    source.join();
+    fe.stop();
+    for (auto* v : vfos) { v->audio.stopReader(); }
+    for (auto& t : sinks) { t.join(); }
+    // the frame buffer does not back-pressure its producer (an overrun drops a lap, like the reference's): count what came OUT
+    const double processed = nvfo > 0 ? ((double)(a1 - a0) / nvfo) * (sr / 250000.0) : (double)(l1 - l0) * fftSize;
+    printf("{\"block\": %d, \"buffered\": %s, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f}\n", block,
+           buffered ? "true" : "false", nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt);
+    return 0;
+}

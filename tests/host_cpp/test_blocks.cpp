@@ -1,7 +1,7 @@
 // Drives the C++ host mirror (sdrplusplus_amd/host/sdrpp_gpu_blocks.h) the way SDR++ drives IQFrontEnd: a source thread
 // swap()s IQ blocks into a dsp::stream, the front end delivers dB lines through acquire/release callbacks and per-VFO blocks
 // on dsp::streams read by sink threads.  Outputs are written to files and compared with the oracle by tests/test_host_cpp.py.
-//   usage: test_blocks <plans.bin> <iq.f32> <sample_rate> <block> <fft_size> <fft_rate> <outdir> [buffered|bypass]
+//   usage: test_blocks <plans.bin> <iq.f32> <sample_rate> <block> <fft_size> <fft_rate> <outdir> [buffered|bypass] [drain_ms]
 // Built three ways by tests/test_host_cpp.py: against the test double of dsp::block / dsp::stream (tests/host_cpp/standalone), against
 // the reference's REAL headers (-I<sdrpp>/core/src, oracle/_ref/test_blocks_ref), and with -DSDRPP_GPU_TEST_DEMOD_IFACE against the
 // radio module's demod::Demodulator interface (extracted from the reference at build time, oracle/_ref/demod_iface.h).
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
     const double fftRate = atof(argv[6]);
     const std::string outdir = argv[7];
     const bool buffered = argc > 8 && std::string(argv[8]) == "buffered";
+    const int drainMs = argc > 9 ? atoi(argv[9]) : (buffered ? 1500 : 300);  // time to let handed-over blocks drain (the CPU emulator needs seconds)
     const size_t nsamp = iq.size() / 2;
 
     dsp::stream<dsp::complex_t> src, src2;  // the second one takes over half way (IQFrontEnd::setInput, source.cpp:29,57)
@@ -117,13 +118,13 @@ int main(int argc, char** argv) {
         blk++;
         if (blk == 3) { raw->setOffset(-sr / 4); }  // retune while running (phase-continuous)
         if (blk == nblocks / 2) {  // change of source: everything handed over so far must have been consumed first
-            std::this_thread::sleep_for(std::chrono::milliseconds(buffered ? 1500 : 300));
+            std::this_thread::sleep_for(std::chrono::milliseconds(drainMs));
             fe.setInput(&src2);
             cur = &src2;
         }
     }
     // let the last block drain: a final empty swap is not part of the reference protocol, so wait on the line/audio counts instead
-    std::this_thread::sleep_for(std::chrono::milliseconds(buffered ? 1500 : 300));
+    std::this_thread::sleep_for(std::chrono::milliseconds(drainMs));
     fe.stop();
     fe.unbindIQStream(&iqTap);
     iqTap.stopReader();

@@ -148,6 +148,9 @@ def ref(fast=False):
         L.ref_frontend_destroy.argtypes = [C.c_void_p]
         L.ref_bench_cfg3.restype = C.c_double
         L.ref_bench_cfg3.argtypes = [c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int]
+        L.ref_bench_cfg.restype = C.c_double
+        L.ref_bench_cfg.argtypes = [c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p,
+                                    C.c_int, C.c_int, C.c_int]
         _ref[fast] = L
     return _ref[fast]
 

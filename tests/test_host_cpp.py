@@ -37,7 +37,7 @@ def _build(tmp, lib="product", headers="standalone"):
     return exe
 
 
-def _run_graph_and_check(exe, mode, tmp):
+def _run_graph_and_check(exe, mode, tmp, drain_ms=None):
     """Source thread -> IQFrontEnd -> sink threads (the way SDR++ drives it), 12 blocks of cfg 1, outputs against the oracle."""
     from sdrplusplus_amd import capi, workloads
 
@@ -45,8 +45,8 @@ def _run_graph_and_check(exe, mode, tmp):
     nblk = 12
     x = workloads.synth(1, B * nblk, seed=5)
     x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
-    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), str(N), str(rate), tmp, mode],
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), str(N), str(rate), tmp, mode] +
+                       ([str(drain_ms)] if drain_ms else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = np.fromfile(os.path.join(tmp, "lines.f32"), np.float32).reshape(-1, N)
     ifs = np.fromfile(os.path.join(tmp, "if.f32"), np.float32).view(np.complex64)
@@ -91,7 +91,7 @@ def test_host_mirror_threaded_graph_on_the_emulator(mode):
     source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
     flushInputBuffer, retune while running.  A logic check of the host code; the device leg is test_threaded_graph_matches_oracle."""
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp)
+        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=4000)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/core/src/dsp"), reason="needs the reference tree")
@@ -102,7 +102,7 @@ def test_host_mirror_links_and_runs_against_the_reference_headers():
     virtual of the real interface."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/demod_iface.h"], check=True)
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp)
+        _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp, drain_ms=4000)
 
 
 def test_device_math_helpers():

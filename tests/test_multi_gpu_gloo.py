@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo processes, one independent IQ stream per rank, gather of waterfall lines to rank 0
 (the only exchange step of the path).  Line contents come from the oracle here — the point is the sharding / gather logic
-bench.py uses with RCCL on the GPU node."""
+bench.py uses with RCCL on the GPU node: test_stream_runner_protocol_gloo drives multi.StreamRunner — the very object whose
+step() / timed() bench.py calls — with a stub context."""
 import os
 import socket
 import sys
@@ -69,6 +70,67 @@ def test_two_streams_gather_lines_gloo():
         exp = np.stack([S.oracle_do_zoom(0, N, W, l) for l in lines])
         assert np.array_equal(got[r], exp)
     assert not np.array_equal(got[0], got[1])
+
+
+class _StubCtx:
+    """What StreamRunner needs of a context: push_device + fft_copy_device.  The 'lines' of push i are rank- and step-specific numbers."""
+
+    def __init__(self, rank, lines):
+        self.rank, self.lines, self.pushes = rank, lines, []
+
+    def push_device(self, ptr, count):
+        self.pushes.append((ptr, count))
+
+    def fft_copy_device(self, first, n, zoomed_ptr=None):
+        assert first == 0 and n == self.lines.shape[0] and zoomed_ptr == self.lines.data_ptr()
+        self.lines.fill_(1000.0 * self.rank + len(self.pushes))
+        return n
+
+
+def _runner_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdrplusplus_amd import multi
+
+    lines = torch.zeros((3, 16), dtype=torch.float32)
+    bufs = [torch.zeros(8), torch.ones(8)]
+    ctx = _StubCtx(rank, lines)
+    r = multi.StreamRunner(ctx, bufs, push=4, lines=lines)
+    assert (r.world, r.rank) == (world, rank)
+    for i in range(2):
+        r.step(i)
+    elapsed = r.timed(5, first=2)
+    assert elapsed > 0.0 and len(ctx.pushes) == 7
+    assert [p for p, _ in ctx.pushes] == [bufs[i % 2].data_ptr() for i in range(7)] and all(c == 4 for _, c in ctx.pushes)
+    if rank == 0:
+        q.put((elapsed, r.gathered.numpy().copy()))
+    else:
+        assert r.gathered is None
+        q.put((elapsed, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_runner_protocol_gloo():
+    """bench.py's per-rank protocol (multi.StreamRunner: step = push + copy out this rank's lines + gather on rank 0; timed = exactly K steps
+    between barriers, MAX over ranks) with world size 2 over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    times = [t for t, _ in res]
+    assert abs(times[0] - times[1]) < 1e-9  # the all-reduced maximum: identical on both ranks
+    got = [g for _, g in res if g is not None]
+    assert len(got) == 1 and got[0].shape == (2, 3, 16)
+    assert np.all(got[0][0] == 7.0) and np.all(got[0][1] == 1007.0)  # slot r = rank r's lines of the last (7th) push
 
 
 def test_stream_dealing():

@@ -617,3 +617,58 @@ def test_opt_in_kernel_variants_bit_identical(backend, switch, tmp_path):
     for k in res[0].files:
         assert res[0][k].shape == res[1][k].shape and res[0][k].shape[0] > 8000
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_deferred_pushes_equal_block_by_block(backend):
+    """sdrpp_set_deferred: pushes are staged and the next observing call processes them as ONE pass.  The result is the concatenation of
+    what pushing and reading block by block gives — including the block-dependent AGC look-ahead (bursts make it rescan), because every
+    staged push stays a reference block of its own — and the waterfall lines are bit-identical.  Configuration calls flush first."""
+    from sdrplusplus_amd import capi, radio
+
+    sr, B, nblk, N = 10e6, 50000, 8, 4096
+    n = B * nblk
+    t = np.arange(n) / sr
+    env = np.where((np.arange(n) // 37000) % 3 == 2, 1.0, 0.03)
+    specs = [("WFM", 1.35e6), ("AM", -2.5e6), ("USB", sr / 8), ("RAW", 2.0e6)]
+    r = np.random.default_rng(5)
+    x = (r.standard_normal(n) + 1j * r.standard_normal(n)) * 1e-3
+    x += 0.2 * np.exp(1j * (2 * np.pi * 1.35e6 * t + 30 * np.sin(2 * np.pi * 2000 * t)))
+    x += env * 0.3 * (1 + 0.5 * np.cos(2 * np.pi * 900 * t)) * np.exp(2j * np.pi * -2.5e6 * t)
+    x += env * 0.2 * (np.exp(2j * np.pi * (sr / 8 + 300) * t) + np.exp(2j * np.pi * (sr / 8 - 900) * t))
+    x = x.astype(np.complex64)
+    w = capi.design_fft_window(2, N)
+
+    def run(deferred, per_pass):
+        ctx = capi.Context(0, max_push=B * per_pass)
+        ctx.fft_configure(N, N, 1000, w)
+        ctx.set_deferred(deferred)
+        vids = []
+        for mode, off in specs:
+            if_rate, bw = radio.RADIO_DEFAULTS.get(mode, (250e3, 250e3))
+            d, keep = radio.vfo_desc(sr, if_rate, bw, off, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        lines, outs = [], [[] for _ in specs]
+        for b in range(nblk):
+            ctx.push(x[b * B:(b + 1) * B])
+            if deferred and (b + 1) % per_pass:
+                assert ctx.pending() == ((b % per_pass) + 1) * B
+                continue
+            lines.append(ctx.fft_read(zoomed=False)[0])  # observing call: processes what is staged
+            assert ctx.pending() == 0
+            for k, got in enumerate(ctx.vfo_read_many(vids)):
+                outs[k].append(got.copy())
+        if deferred:  # staging more than max_push is refused, the staged data stays intact
+            for _ in range(per_pass):
+                ctx.push(x[:B])
+            with pytest.raises(capi.SdrppError):
+                ctx.push(x[:B])
+            assert ctx.pending() == per_pass * B
+        ctx.close()
+        return np.concatenate(lines), [np.concatenate(o) for o in outs]
+
+    l0, o0 = run(False, 1)
+    l1, o1 = run(True, 4)
+    assert l0.shape == l1.shape and l0.shape[0] == n // (N + 1000) and np.array_equal(l0, l1)
+    for (mode, _), a, b in zip(specs, o0, o1):
+        assert a.shape == b.shape and len(a) > 100, mode
+        assert np.max(np.abs(a - b)) < 5e-6 * max(1.0, float(np.max(np.abs(a)))), (mode, float(np.max(np.abs(a - b))))
