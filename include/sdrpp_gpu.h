@@ -41,6 +41,7 @@ typedef struct sdrpp_ctx sdrpp_ctx;
 /* Replaces IQFrontEnd::init's allocation half (iq_frontend.cpp:17-71).  `max_push` = largest sample count one
  * sdrpp_push* call will carry (the reference's streams carry <= 1 000 000, core/src/dsp/stream.h:9; device-resident
  * callers may use larger batches). */
+int sdrpp_device_count(void);   /* usable devices (0: none — nothing here runs without one) */
 int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** ctx);
 int sdrpp_destroy(sdrpp_ctx* ctx);
 const char* sdrpp_strerror(int code);

@@ -1995,6 +1995,11 @@ int sdrpp_abi_version(int* sizeof_vfo_desc) {
 
 const char* sdrpp_kernel_family_name(int family) { return (family >= 0 && family < SDRPP_NUM_KERNEL_FAMILIES) ? kFamilyNames[family] : "?"; }
 
+int sdrpp_device_count(void) {
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess) ? n : 0;
+}
+
 int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
     if (!out || max_push <= 0 || max_push > ((int64_t)1 << 28)) { return SDRPP_ERR_INVALID; }
     *out = nullptr;
@@ -2478,7 +2483,16 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     if (d->chan_ntaps < 0 || d->chan_ntaps > kChanHistCap + 1) { return fail(c, SDRPP_ERR_UNSUPPORTED, "channel filter of %d taps (max %d)", d->chan_ntaps, kChanHistCap + 1); }
     if (d->demod < SDRPP_DEMOD_RAW || d->demod > SDRPP_DEMOD_DSB) { return fail(c, SDRPP_ERR_INVALID, "demod %d", d->demod); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    auto v = std::make_unique<Vfo>();
+    // every early return below gives the device allocations made so far back (vfo_free); only a fully built VFO is handed to the context
+    struct VfoFreer {
+        void operator()(Vfo* p) const {
+            if (p) {
+                vfo_free(*p);
+                delete p;
+            }
+        }
+    };
+    std::unique_ptr<Vfo, VfoFreer> v(new Vfo);
     v->id = c->next_id++;
     v->d = *d;
     int rc;
@@ -2633,8 +2647,9 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     v->modtaps_dirty = true;
     rc = vfo_reset_state(c, *v);
     if (rc) { return rc; }
-    *id = v->id;
-    c->vfos[v->id] = std::move(v);
+    const int vid = v->id;  // (the right-hand side of the assignment below is evaluated first)
+    *id = vid;
+    c->vfos[vid] = std::unique_ptr<Vfo>(v.release());
     return SDRPP_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define __global__
@@ -55,6 +56,7 @@ namespace hipemu {
         std::vector<float> wx_buf;                 // [wave][parity][64][2]
     };
     inline State& S() { static State s; return s; }
+    inline std::mutex& launch_mutex() { static std::mutex m; return m; }  // (a function-local static: ONE for all kernel templates)
     inline void trampoline() {
         State& s = S();
         s.body();
@@ -202,6 +204,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 
 template <typename... KArgs, typename... Args>
 static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, Args... args) {
+    std::lock_guard<std::mutex> launch_lck(hipemu::launch_mutex());  // one workgroup at a time PROCESS-wide: host threads take turns
     hipemu::State& s = hipemu::S();
     if (getenv("SDRPP_EMU_TRACE")) { fprintf(stderr, "[hipemu] launch grid=(%u,%u,%u) block=(%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z); }
     s.gDim = grid;

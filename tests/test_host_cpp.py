@@ -18,12 +18,12 @@ REF = "/root/reference"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "test_blocks_ref")
 
 
-def _build(tmp, lib="product", headers="standalone"):
+def _build(tmp, lib="product", headers="standalone", source="test_blocks.cpp"):
     """tests/host_cpp/test_blocks.cpp against the test double of dsp::block / dsp::stream or against the reference's REAL headers
     (+ the radio module's demod::Demodulator interface, extracted by oracle/Makefile), linked with the product library or — for runs
     on a machine without a GPU — with the CPU emulator build of the same sources (tests/emu)."""
-    exe = os.path.join(tmp, "test_blocks_%s_%s" % (lib, headers))
-    cmd = ["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_blocks.cpp")]
+    exe = os.path.join(tmp, "%s_%s_%s" % (source.split(".")[0], lib, headers))
+    cmd = ["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", source)]
     if headers == "reference":
         cmd += ["-DSDRPP_GPU_TEST_DEMOD_IFACE", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + REF + "/core/src", "-I" + os.path.join(ROOT, "oracle", "_ref")]
     else:
@@ -132,3 +132,40 @@ def test_reference_header_build_runs_on_the_device():
         pytest.skip("oracle/_ref/test_blocks_ref not built (needs the reference tree at build time)")
     with tempfile.TemporaryDirectory() as tmp:
         _run_graph_and_check(REF_BIN, "bypass", tmp)
+
+
+def _run_multi_and_check(exe, tmp, drain_ms):
+    """Two streams with different FM modulation through sdrpp_gpu::StreamBank: each stream's lines and audio match its OWN oracle."""
+    from sdrplusplus_amd import capi
+
+    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), tmp, str(drain_ms)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sr, B, N, nblk = 2.4e6, 12000, 4096, 6
+    nz, skip = capi.design_reshape_params(sr, N, 100.0)
+    t = np.arange(B * nblk, dtype=np.float64) / sr
+    for s in range(2):
+        ph = 2.0 * np.pi * 300e3 * t + (20.0 if s else 60.0) * np.sin(2.0 * np.pi * (1700.0 if s else 1000.0) * t)
+        amp = 0.2 if s else 0.4
+        x = np.empty(len(t), np.complex64)
+        x.real = (amp * np.cos(ph)).astype(np.float32)
+        x.imag = (amp * np.sin(ph)).astype(np.float32)
+        spec = S.OracleSpectrum(N, nz, skip, capi.design_fft_window(2, nz))
+        ch = S.OracleChain(sr, 250e3, 150e3, 300e3, S.MODES["WFM"])
+        ol = np.concatenate([spec.push(x[b * B:(b + 1) * B]) for b in range(nblk)])
+        oa = np.concatenate([ch.process(x[b * B:(b + 1) * B])[1] for b in range(nblk)])
+        lines = np.fromfile(os.path.join(tmp, "lines_%d.f32" % s), np.float32).reshape(-1, N)
+        audio = np.fromfile(os.path.join(tmp, "audio_%d.f32" % s), np.float32).reshape(-1, 2)
+        assert lines.shape == ol.shape and np.array_equal(lines, ol), s
+        assert audio.shape == oa.shape and np.sqrt(np.mean((audio - oa) ** 2)) < 1e-5, s
+
+
+def test_stream_bank_two_streams_on_the_emulator():
+    """sdrpp_gpu::StreamBank (one front end + worker per stream / device, one line handler): the C++ multi-device host, on the emulator."""
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_multi_and_check(_build(tmp, lib="emu", source="test_multi.cpp"), tmp, 4000)
+
+
+@pytest.mark.gpu
+def test_stream_bank_two_streams_on_the_device():
+    with tempfile.TemporaryDirectory() as tmp:
+        _run_multi_and_check(_build(tmp, source="test_multi.cpp"), tmp, 500)
