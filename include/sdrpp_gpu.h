@@ -99,7 +99,11 @@ int sdrpp_set_nco_mode(sdrpp_ctx* ctx, int mode);
 
 /* ---- FFT -> log-power -> waterfall line (replaces Reshaper + Handler + IQFrontEnd::handler, iq_frontend.cpp:248-309,
  *      and WaterFall::pushFFT's doZoom + palette index, waterfall.cpp:65-90, 889-906) --------------------------------------- */
-/* fft_size: power of two 1024..1048576.  Frame k covers stream samples [k*(nz+skip), k*(nz+skip)+nz) since the last
+/* Numerics: the reference links libfftw3f / libvolk, neither of which is part of its tree (unpinned distro packages), so "bit-exact" for
+ * this branch is defined against a fully specified float32 FFT + log2 that the test oracle and these kernels
+ * share operation for operation; against a float64 DFT it is accurate to < 4e-7 relative (tests/test_oracle_kat.py), i.e. palette
+ * indices agree with ANY correct FFT to +-1 of 10^6 levels.
+ * fft_size: power of two 1024..1048576.  Frame k covers stream samples [k*(nz+skip), k*(nz+skip)+nz) since the last
  * configure/reset (reshaper.h:101-128); fftIn[nz:fft_size] is zero (iq_frontend.cpp:301).  `window` has nz floats.
  * Reconfiguring drops the partial frame, like updateFFTPath's tempStop/tempStart. */
 int sdrpp_fft_configure(sdrpp_ctx* ctx, int fft_size, int nz, int skip, const float* window);

@@ -596,11 +596,12 @@ def test_packed_reads(backend):
     ctx.close()
 
 
-@pytest.mark.parametrize("switch", ["SDRPP_GPU_WIDE_STORE=1"])
+@pytest.mark.parametrize("switch", ["SDRPP_GPU_WIDE_STORE=1", "SDRPP_GPU_TOEP_DMA=1", "SDRPP_GPU_TOEP_DMA=2"])
 def test_opt_in_kernel_variants_bit_identical(backend, switch, tmp_path):
-    """Opt-in variant of the per-VFO filter launches: SDRPP_GPU_WIDE_STORE — outputs of full macro tiles staged through
-    LDS and stored with dwordx4.  The same matrix chains on the same tables, so the audio of every VFO must be bit-identical to the
-    default launches, across ragged pushes.  One process per setting (the library reads the switch once)."""
+    """Variants of the per-VFO filter launches: SDRPP_GPU_WIDE_STORE — outputs of full macro tiles staged through LDS and
+    stored with dwordx4; SDRPP_GPU_TOEP_DMA — windows loaded global -> LDS by LDS-DMA (one window refilled in place / two windows).  The
+    same matrix chains on the same tables, so the audio of every VFO must be bit-identical to the default launches, across ragged
+    pushes.  One process per setting (the library reads the switches once)."""
     import os
     import subprocess
     import sys
