@@ -36,13 +36,6 @@ __device__ __forceinline__ float4 global_load_f32x4_unaligned(const float* p, lo
     const f32x4_a4 v = *((const f32x4_a4 __attribute__((address_space(1)))*)(uintptr_t)(p + i));
     return make_float4(v.x, v.y, v.z, v.w);
 }
-// LDS-DMA: asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4), no VGPR in between.  The destination is
-// WAVE-UNIFORM base + 16 * lane (hardware rule); the source address is per lane.  Counted by vmcnt: wait_vmem_all() before the
-// ds_reads of the data (nothing else orders a read behind a pending DMA).
-__device__ __forceinline__ void global_load_lds_f32x4(const float* gsrc_lane, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)gsrc_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float2 v) {
     f32x2 t;
     t.x = v.x;

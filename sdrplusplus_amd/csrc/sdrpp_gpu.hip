@@ -901,13 +901,8 @@ ToepJob toep_job(const ToepTab& T, int var, StreamIn in, float* out, int base0, 
     return j;
 }
 
-// SDRPP_GPU_TOEP_DMA=1|2: LDS-DMA window loads in the complex-stream Toeplitz launches (vfo_toep_kernel's DMA parameter)
-int toep_dma_mode() {
-    static const int m = getenv("SDRPP_GPU_TOEP_DMA") ? atoi(getenv("SDRPP_GPU_TOEP_DMA")) : 0;
-    return m;
-}
-struct ToepPlan { int grid_x = 0; size_t lds = 0; int nw = 1; };
-ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl, bool ilv = false) {
+struct ToepPlan { int grid_x = 0; size_t lds = 0; };
+ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
     ToepPlan P;
     if (jobs.empty()) { return P; }
     const int G = 2;
@@ -926,29 +921,13 @@ ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl, bool ilv = false) {
         const int span = (G * 16 - 1) * jb.s_in + 4 * jb.nsteps, pl = (span + 8) & ~3;
         P.lds = std::max(P.lds, ((size_t)((jb.tl_len + 3) & ~3) + (size_t)4 * npl * pl) * sizeof(float));
     }
-    if (ilv && toep_dma_mode() == 2) {  // two windows per wavefront where the launch's largest job leaves room for them
-        size_t lds2 = 0;
-        for (auto& jb : jobs) {
-            const int span = (G * 16 - 1) * jb.s_in + 4 * jb.nsteps, pl = (span + 8) & ~3;
-            lds2 = std::max(lds2, ((size_t)((jb.tl_len + 3) & ~3) + (size_t)4 * 2 * npl * pl) * sizeof(float));
-        }
-        if (lds2 <= (size_t)kMaxLds) {
-            P.lds = lds2;
-            P.nw = 2;
-        }
-    }
     return P;
 }
 
 void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, const ToepPlan& P, int width, bool quad) {
     if (jobs.empty() || P.grid_x == 0) { return; }
     const dim3 grid((unsigned)P.grid_x, (unsigned)jobs.size());
-    static const bool wide_store = getenv("SDRPP_GPU_WIDE_STORE") && atoi(getenv("SDRPP_GPU_WIDE_STORE")) != 0;  // opt-in, see vfo_toep_kernel
-    if (wide_store && quad) { launch(c, vfo_toep_kernel<1, 2, true, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-    else if (wide_store && width == 2) { launch(c, vfo_toep_kernel<2, 2, false, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-    else if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-    else if (width == 2 && toep_dma_mode() > 0 && P.nw == 2) { launch(c, vfo_toep_kernel<2, 2, false, false, 2>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
-    else if (width == 2 && toep_dma_mode() > 0) { launch(c, vfo_toep_kernel<2, 2, false, false, 1>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
+    if (quad) { launch(c, vfo_toep_kernel<1, 2, true>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
     else if (width == 2) { launch(c, vfo_toep_kernel<2, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
     else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
 }
@@ -1471,11 +1450,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-        tp_lvl[s] = toep_plan(t_lvl[s], 2, true);
+        tp_lvl[s] = toep_plan(t_lvl[s], 2);
         d_t_lvl[s] = arena_push(c, t_lvl[s]);
         if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
-    const ToepPlan tp_poly = toep_plan(t_poly, 2, true), tp_chan = toep_plan(t_chan, 2, true), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
+    const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
     ToepJob* d_t_poly = arena_push(c, t_poly);
     ToepJob* d_t_chan = arena_push(c, t_chan);
     ToepJob* d_t_audio = arena_push(c, t_audio);
@@ -1490,12 +1469,12 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     ToepJob* d_t_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     FirBJob* d_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-        tp_af_lvl[s] = toep_plan(t_af_lvl[s], 2, true);
+        tp_af_lvl[s] = toep_plan(t_af_lvl[s], 2);
         d_t_af_lvl[s] = arena_push(c, t_af_lvl[s]);
         d_af_lvl[s] = arena_push(c, af_lvl[s]);
         if ((!t_af_lvl[s].empty() && !d_t_af_lvl[s]) || (!af_lvl[s].empty() && !d_af_lvl[s])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
-    const ToepPlan tp_af_poly = toep_plan(t_af_poly, 2, true), tp_af_hpf = toep_plan(t_af_hpf, 2, true);
+    const ToepPlan tp_af_poly = toep_plan(t_af_poly, 2), tp_af_hpf = toep_plan(t_af_hpf, 2);
     ToepJob* d_t_af_poly = arena_push(c, t_af_poly);
     ToepJob* d_t_af_hpf = arena_push(c, t_af_hpf);
     PolyJob* d_af_poly = arena_push(c, af_poly);
@@ -1824,7 +1803,7 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
     ToepJob* d_tj[SDRPP_MAX_DECIM_STAGES] = {};
     FirBJob* d_fj[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 0; s < P.n_stages; s++) {
-        tp[s] = toep_plan(tj[s], 2, true);
+        tp[s] = toep_plan(tj[s], 2);
         d_tj[s] = arena_push(c, tj[s]);
         d_fj[s] = arena_push(c, fj[s]);
         if ((!tj[s].empty() && !d_tj[s]) || (!fj[s].empty() && !d_fj[s])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }

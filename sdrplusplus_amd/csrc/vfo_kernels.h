@@ -1406,17 +1406,8 @@ struct ToepJob {
 __device__ int g_toep_knock;
 #endif
 
-// WS (opt-in, SDRPP_GPU_WIDE_STORE=1): the outputs of a full macro tile go back through the (by then free) LDS window so that every
-// lane stores two consecutive outputs with one global_store_dwordx4 — 4 fully contiguous store instructions per macro tile instead of
-// 16 that each write four 120-byte pieces.
-// DMA (complex streams only; SDRPP_GPU_TOEP_DMA): the window goes global -> LDS with LDS-DMA (global_load_lds_dwordx4) instead of
-// global -> VGPR -> ds_write: no staging registers, no ds_write pass, the loaded bytes never touch the register file the matrix
-// pipe is reading.  1: one window per wavefront, refilled in place right after its matrix loop (the wavefront then waits for its
-// own DMA at the top of the next round — the other wavefronts of the SIMD compute meanwhile); 2: two windows per wavefront, the
-// next one fills while the current one is multiplied (twice the LDS).  Outputs of a round are stored after the wait at the top
-// of the NEXT round, so that wait never covers stores just issued.  Same tables, same chains: bit-identical results.
-template <int WIDTH, int G, bool QUAD, bool WS = false, int DMA = 0>
-__global__ __launch_bounds__(256, WS ? 3 : (DMA ? 4 : 5)) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
+template <int WIDTH, int G, bool QUAD>
+__global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemt)
     const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1428,9 +1419,8 @@ __global__ __launch_bounds__(256, WS ? 3 : (DMA ? 4 : 5)) void vfo_toep_kernel(c
     const int pl = (span + 8) & ~3;
     constexpr int NPL = (WIDTH == 2 || QUAD) ? 2 : 1;
     const int tl_pad = (job.tl_len + 3) & ~3;
-    constexpr int NW = (DMA == 2) ? 2 : 1;  // LDS windows per wavefront
     float* TLs = smemt;
-    float* XR = smemt + tl_pad + wv * NW * NPL * pl;
+    float* XR = smemt + tl_pad + wv * NPL * pl;
     float* XI = XR + pl;  // imaginary plane, or the phase scratch of the fused discriminator
     for (int i = tid; i < job.tl_len; i += 256) { TLs[i] = global_load_f32(job.tl, i); }
     __syncthreads();  // the only workgroup barrier
@@ -1550,104 +1540,6 @@ __global__ __launch_bounds__(256, WS ? 3 : (DMA ? 4 : 5)) void vfo_toep_kernel(c
             for (int s = lane; s < span; s += 64) { XR[s] = normalize_phase(XI[s + 1] - XI[s]) * job.inv_deviation; }
         }
     };
-    if constexpr (DMA > 0 && ILV) {
-        // ---------------- LDS-DMA pipeline (see the template comment) ----------------
-        auto win = [&](int parity) -> float* { return XR + ((NW == 2) ? (parity & 1) * NPL * pl : 0); };
-        auto dma_fetch = [&](int mt, float* W) {
-            const int lo = job.base0 + mt * G * 16 * s_in;
-            if (lo >= 0 && lo + cnt <= job.in.n) {  // fully inside this push (global side: dword alignment suffices, as for global_load_dwordx4)
-                const float* g0 = job.in.data + 2ll * lo;
-                for (int q = 0; q * 64 < npair; q++) {
-                    const int e = q * 64 + lane;
-                    if (e < npair) { global_load_lds_f32x4(g0 + 4ll * e, W + q * 256); }
-                }
-            }
-            else {  // first / last macro tiles and odd starts: through registers
-                float4* W4 = reinterpret_cast<float4*>(W);
-                for (int e = lane; e < npair; e += 64) {
-                    const float2 a = stream_load2(job.in, lo + 2 * e), b = stream_load2(job.in, lo + 2 * e + 1);
-                    W4[e] = make_float4(a.x, a.y, b.x, b.y);
-                }
-            }
-        };
-        f32x4 accR[G], accI[G];
-        auto store_tile = [&](int obase) {
-            if (obase + omt <= job.nout) {
-                if (c < rows) {
-                    float2* const ob = reinterpret_cast<float2*>(job.out) + obase;
-                    const int lofs = 4 * kk * rows + c;
-#pragma unroll
-                    for (int g = 0; g < G; g++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) { global_store_f32x2(ob + (g * 16 + r) * rows, lofs, make_float2(accR[g][r], accI[g][r])); }
-                    }
-                }
-            }
-            else if (c < rows) {
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int o = obase + (g * 16 + 4 * kk + r) * rows + c;
-                        if (o < job.nout) { global_store_f32x2(reinterpret_cast<float2*>(job.out), o, make_float2(accR[g][r], accI[g][r])); }
-                    }
-                }
-            }
-        };
-        if (mt0 * omt < job.nout) { dma_fetch(mt0, win(0)); }
-        bool have_prev = false;
-        int prev_obase = 0;
-        for (int it = 0; it < job.mt_per_wave; it++) {
-            const int mt = mt0 + it * mts;
-            const int obase = mt * omt;
-            if (obase >= job.nout) { break; }
-            const bool more = it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout;
-            wait_vmem_all();  // this round's window has landed (and the stores of two rounds ago are done)
-            wave_sync();
-            if (have_prev) { store_tile(prev_obase); }
-            if (NW == 2 && more) { dma_fetch(mt + mts, win(it + 1)); }
-            const float2* A2w = reinterpret_cast<const float2*>(win(it)) + c * s_in + kk;
-#pragma unroll
-            for (int g = 0; g < G; g++) { accR[g] = mfma4_zero(); accI[g] = mfma4_zero(); }
-            constexpr int U = 4;
-            int t0 = 0;
-            for (; t0 + U <= nsteps; t0 += U) {
-                float b[U];
-                float2 a[U][G];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    b[u] = Bp[4 * (t0 + u)];
-#pragma unroll
-                    for (int g = 0; g < G; g++) { a[u][g] = A2w[g * 16 * s_in + 4 * (t0 + u)]; }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-#pragma unroll
-                    for (int g = 0; g < G; g++) {
-                        accR[g] = mfma_16x16x4(a[u][g].x, b[u], accR[g]);
-                        accI[g] = mfma_16x16x4(a[u][g].y, b[u], accI[g]);
-                    }
-                }
-            }
-            for (; t0 < nsteps; t0++) {
-                const float b = Bp[4 * t0];
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const float2 a = A2w[g * 16 * s_in + 4 * t0];
-                    accR[g] = mfma_16x16x4(a.x, b, accR[g]);
-                    accI[g] = mfma_16x16x4(a.y, b, accI[g]);
-                }
-            }
-            if (NW == 1 && more) {
-                wave_sync();  // every lane has read its operands: the window can be refilled in place
-                dma_fetch(mt + mts, win(0));
-            }
-            have_prev = true;
-            prev_obase = obase;
-        }
-        if (have_prev) { store_tile(prev_obase); }
-        return;
-    }
     // Order of one round of the pipelined path: matrix work on window t | window t+1 from registers to LDS | loads of window t+2 |
     // stores of the outputs of t.  The only wait for global memory (in front of the LDS writes) then covers loads and stores that
     // were issued one whole round earlier, never the stores just issued.
@@ -1728,31 +1620,6 @@ __global__ __launch_bounds__(256, WS ? 3 : (DMA ? 4 : 5)) void vfo_toep_kernel(c
                 }
             }
         }
-        constexpr int NST = (G * 16 * 15 / 2 + 63) / 64;  // sample pairs per lane of a macro tile
-        float4 st4[WS ? NST : 1];
-        bool wide = false;
-        if constexpr (WS && NPL == 2) {
-            wide = piped && obase + omt <= job.nout && pl >= omt;
-            if (wide) {
-                wave_sync();  // every lane has read its operands: the window doubles as the staging area, output (tile, m) at tile * rows + m
-                float2* S2 = reinterpret_cast<float2*>(XR);
-                if (c < rows) {
-#pragma unroll
-                    for (int g = 0; g < G; g++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            S2[(g * 16 + 4 * kk + r) * rows + c] = make_float2(accR[g][r], (WIDTH == 2) ? accI[g][r] : accR[g][r]);
-                        }
-                    }
-                }
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < NST; q++) {
-                    const int pr = q * 64 + lane;
-                    if (2 * pr < omt) { st4[q] = reinterpret_cast<const float4*>(S2)[pr]; }
-                }
-            }
-        }
         if (piped && it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout) {
             wave_sync();  // every lane has read its operands of this window
             window_store();
@@ -1763,17 +1630,8 @@ __global__ __launch_bounds__(256, WS ? 3 : (DMA ? 4 : 5)) void vfo_toep_kernel(c
 #ifdef SDRPP_TOEP_KNOCK
         if ((knock & 1) && accR[0][0] != 123.456f) { continue; }
 #endif
-        if (wide) {
-            if constexpr (WS) {
-#pragma unroll
-                for (int q = 0; q < NST; q++) {
-                    const int pr = q * 64 + lane;
-                    if (2 * pr < omt) { global_store_f32x4(job.out, 2ll * obase + 4ll * pr, st4[q]); }
-                }
-            }
-        }
         // D[i = tile][j = m]: this lane holds output m = lane & 15 of tiles 4 * (lane >> 4) + r
-        else if (obase + omt <= job.nout) {
+        if (obase + omt <= job.nout) {
             // full macro tile (all but the last one of a stream): no per-output bound tests, one lane offset for all sixteen stores and
             // a wave-uniform base per store (scalar address arithmetic instead of ~12 vector instructions and a branch per store)
             if (c < rows) {

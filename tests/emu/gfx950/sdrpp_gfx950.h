@@ -12,8 +12,6 @@ static inline float global_load_f32(const float* p, long long i) { return p[i]; 
 static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
 static inline float4 global_load_f32x4_unaligned(const float* p, long long i) { return make_float4(p[i], p[i + 1], p[i + 2], p[i + 3]); }
-static inline void global_load_lds_f32x4(const float* gsrc_lane, float* lds_wave_base) { memcpy(lds_wave_base + 4 * hipemu::lane_id(), gsrc_lane, 16); }
-static inline void wait_vmem_all() {}
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }

@@ -596,30 +596,6 @@ def test_packed_reads(backend):
     ctx.close()
 
 
-@pytest.mark.parametrize("switch", ["SDRPP_GPU_WIDE_STORE=1", "SDRPP_GPU_TOEP_DMA=1", "SDRPP_GPU_TOEP_DMA=2"])
-def test_opt_in_kernel_variants_bit_identical(backend, switch, tmp_path):
-    """Variants of the per-VFO filter launches: SDRPP_GPU_WIDE_STORE — outputs of full macro tiles staged through LDS and
-    stored with dwordx4; SDRPP_GPU_TOEP_DMA — windows loaded global -> LDS by LDS-DMA (one window refilled in place / two windows).  The
-    same matrix chains on the same tables, so the audio of every VFO must be bit-identical to the default launches, across ragged
-    pushes.  One process per setting (the library reads the switches once)."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name, value = switch.split("=")
-    res = []
-    for v in ("0", value):
-        out = str(tmp_path / ("%s_%s.npz" % (name, v)))
-        from sdrplusplus_amd import capi
-        subprocess.run([sys.executable, os.path.join(root, "tests", "variant_scenario.py"), out, "18", capi.lib_path()], check=True, env=dict(os.environ, **{name: v}))
-        res.append(np.load(out))
-    assert len(res[0].files) == 18
-    for k in res[0].files:
-        assert res[0][k].shape == res[1][k].shape and res[0][k].shape[0] > 8000
-        assert np.array_equal(res[0][k], res[1][k]), k
-
-
 def test_deferred_pushes_equal_block_by_block(backend):
     """sdrpp_set_deferred: pushes are staged and the next observing call processes them as ONE pass.  The result is the concatenation of
     what pushing and reading block by block gives — including the block-dependent AGC look-ahead (bursts make it rescan), because every
