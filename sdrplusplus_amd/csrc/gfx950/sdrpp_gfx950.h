@@ -73,6 +73,11 @@ __device__ __forceinline__ void wave_sync() {
 
 // Wave-uniform helpers: value of lane `src` (src uniform across the wavefront: v_readlane_b32), and the maximum over all 64 lanes.
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+// index of the first lane whose predicate holds, 64 if none (v_cmp + s_ff1)
+__device__ __forceinline__ int wave_first(bool pred) {
+    const unsigned long long m = __ballot(pred);
+    return m ? (int)__builtin_ctzll(m) : 64;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d, 64); }

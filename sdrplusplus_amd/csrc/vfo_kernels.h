@@ -542,6 +542,22 @@ __device__ __forceinline__ float agc_gain(AgcState& a, float inAmp) {
     return gain;
 }
 
+// loop::AGC's amplitude tracker alone (agc.h:79-83): the part of the recursion that is really sequential.  The gain — a division per
+// sample — depends on it but nothing depends on the gain, so it is taken out of the chain and evaluated for 64 samples at once.
+__device__ __forceinline__ float agc_track(float amp, float inAmp, const AgcState& a) {
+    if (inAmp != 0.0f) {
+        const bool up = inAmp > amp;
+        const float c1 = up ? a.inv_attack : a.inv_decay, c2 = up ? a.attack : a.decay;
+        amp = (amp * c1) + (inAmp * c2);
+    }
+    return amp;
+}
+__device__ __forceinline__ float agc_gain_of(float amp, float inAmp, const AgcState& a) {
+    if (inAmp == 0.0f) { return 1.0f; }
+    const float g = a.set_point / amp;
+    return (a.max_gain < g) ? a.max_gain : g;
+}
+
 // One WAVEFRONT per VFO: only the recursions (DC blocker, AGC) are left here.  The lanes fetch 64 consecutive samples with one
 // coalesced load; every lane then evaluates the same (uniform) recursion, taking sample i from lane i with v_readlane — a
 // one-work-item loop over global memory pays ~1 us of load latency per sample.  The AGC's look-ahead to the end of the push
@@ -570,14 +586,14 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
             }
             const float amp_l = sqrtf((xin.x * xin.x) + (xin.y * xin.y));  // carrier mode: |x| of this lane's sample
             float outv = 0.0f;
-            for (int i = 0; i < cnt; i++) {
-                float mag;
-                if (job.carrier_mode) {
+            if (job.carrier_mode) {
+                // carrier AGC on the complex IF (am.h:103-106), then envelope and DC blocker: sample by sample
+                for (int i = 0; i < cnt; i++) {
                     float2 x = make_float2(wave_bcast(xin.x, i), wave_bcast(xin.y, i));
                     const float inAmp = wave_bcast(amp_l, i);
                     float gain = agc_gain(cagc, inAmp);
                     if (inAmp * gain > cagc.max_output_amp) {
-                        float m = (lane >= i && lane < cnt) ? amp_l : 0.0f;  // rest of this chunk, then the rest of the push
+                        float m = (lane >= i && lane < cnt) ? amp_l : 0.0f;  // rest of this chunk, then the rest of the block
                         for (int b2 = base + 64 + lane; b2 < n; b2 += 64) {
                             const float2 y = job.in[b2];
                             const float a = sqrtf((y.x * y.x) + (y.y * y.y));
@@ -589,45 +605,66 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
                     }
                     x.x = x.x * gain;
                     x.y = x.y * gain;
-                    mag = sqrtf((x.x * x.x) + (x.y * x.y));
+                    const float mag = sqrtf((x.x * x.x) + (x.y * x.y));
+                    const float v = mag - off;
+                    off += v * job.dc_rate;
+                    if (lane == i) { outv = v; }
                 }
-                else {
-                    mag = wave_bcast(pv, i);
-                }
-                float v = mag - off;
-                off += v * job.dc_rate;
-                if (!job.carrier_mode) {
-                    // audio AGC sees the DC-blocked envelope; its look-ahead needs the not-yet-computed future samples of the same
-                    // recursion, so it re-runs the DC blocker forward from the current state (exactly what the reference's
-                    // in-place buffer holds at that moment).
-                    const float inAmp = fabsf(v);
-                    float gain = agc_gain(agc, inAmp);
-                    if (inAmp * gain > agc.max_output_amp) {
-                        float maxAmp = inAmp;
-                        float o2 = off;
-                        for (int j = i + 1; j < cnt; j++) {
-                            const float v2 = wave_bcast(pv, j) - o2;
+            }
+            else {
+                // envelope (already in `pre`) -> DC blocker -> audio AGC.  Sequential per chunk: only the DC blocker and the AGC's amplitude
+                // tracker (lane i keeps v, the tracker and the blocker's offset after sample i); gains and the clip test in one parallel step.
+                // A clip is handled at its sample as the reference does: the look-ahead needs the not-yet-computed future samples of the same
+                // recursion, so it re-runs the DC blocker forward to the end of the BLOCK from the state behind that sample (exactly what
+                // the reference's in-place buffer holds at that moment), and the scan restarts behind it.
+                int i0 = 0;
+                while (i0 < cnt) {
+                    float o = off, amp = agc.amp, my_v = 0.0f, my_amp = 0.0f, my_off = 0.0f;
+                    for (int i = i0; i < cnt; i++) {
+                        const float v = wave_bcast(pv, i) - o;
+                        o += v * job.dc_rate;
+                        amp = agc_track(amp, fabsf(v), agc);
+                        if (lane == i) {
+                            my_v = v;
+                            my_amp = amp;
+                            my_off = o;
+                        }
+                    }
+                    const bool mine = lane >= i0 && lane < cnt;
+                    const float a_l = fabsf(my_v);
+                    const float g_l = mine ? agc_gain_of(my_amp, a_l, agc) : 1.0f;
+                    const int f = wave_first(mine && (a_l * g_l > agc.max_output_amp));
+                    if (mine && lane < f) { outv = my_v * g_l; }
+                    if (f >= 64) {
+                        off = o;
+                        agc.amp = amp;
+                        break;
+                    }
+                    float maxAmp = wave_bcast(a_l, f);
+                    float o2 = wave_bcast(my_off, f);
+                    off = o2;
+                    for (int jn = f + 1; jn < cnt; jn++) {
+                        const float v2 = wave_bcast(pv, jn) - o2;
+                        o2 += v2 * job.dc_rate;
+                        const float a2 = fabsf(v2);
+                        if (a2 > maxAmp) { maxAmp = a2; }
+                    }
+                    for (int b2 = base + 64; b2 < n; b2 += 64) {
+                        const int c2 = (n - b2 < 64) ? n - b2 : 64;
+                        const float q = (lane < c2) ? job.pre[b2 + lane] : 0.0f;
+                        for (int jn = 0; jn < c2; jn++) {
+                            const float v2 = wave_bcast(q, jn) - o2;
                             o2 += v2 * job.dc_rate;
                             const float a2 = fabsf(v2);
                             if (a2 > maxAmp) { maxAmp = a2; }
                         }
-                        for (int b2 = base + 64; b2 < n; b2 += 64) {
-                            const int c2 = (n - b2 < 64) ? n - b2 : 64;
-                            const float q = (lane < c2) ? job.pre[b2 + lane] : 0.0f;
-                            for (int j = 0; j < c2; j++) {
-                                const float v2 = wave_bcast(q, j) - o2;
-                                o2 += v2 * job.dc_rate;
-                                const float a2 = fabsf(v2);
-                                if (a2 > maxAmp) { maxAmp = a2; }
-                            }
-                        }
-                        agc.amp = maxAmp;
-                        const float g = agc.set_point / agc.amp;
-                        gain = (agc.max_gain < g) ? agc.max_gain : g;
                     }
-                    v = v * gain;
+                    agc.amp = maxAmp;
+                    const float g = agc.set_point / agc.amp;
+                    const float gain = (agc.max_gain < g) ? agc.max_gain : g;
+                    if (lane == f) { outv = my_v * gain; }
+                    i0 = f + 1;
                 }
-                if (lane == i) { outv = v; }
             }
             if (lane < cnt) { job.pre[base + lane] = outv; }
         }
@@ -648,23 +685,36 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
         for (int base = blk_lo; base < n; base += 64) {
             const int cnt = (n - base < 64) ? n - base : 64;
             const float pv = (lane < cnt) ? job.pre[base + lane] : 0.0f;
+            const float a_l = fabsf(pv);
             float outv = 0.0f;
-            for (int i = 0; i < cnt; i++) {
-                const float re = wave_bcast(pv, i);
-                const float inAmp = fabsf(re);
-                float gain = agc_gain(agc, inAmp);
-                if (inAmp * gain > agc.max_output_amp) {
-                    float m = (lane >= i && lane < cnt) ? fabsf(pv) : 0.0f;
-                    for (int b2 = base + 64 + lane; b2 < n; b2 += 64) {
-                        const float a2 = fabsf(job.pre[b2]);
-                        if (a2 > m) { m = a2; }
-                    }
-                    agc.amp = wave_max(m);
-                    const float g = agc.set_point / agc.amp;
-                    gain = (agc.max_gain < g) ? agc.max_gain : g;
+            // Chunk of 64 samples: the amplitude tracker runs sequentially (uniform, ~10 instructions per sample), lane i keeps the value
+            // after sample i; gains and the clip test are then one parallel step.  A clip (rare: the start of a burst) is handled at its
+            // sample exactly as the reference does — amp = maximum over the rest of the BLOCK — and the scan restarts behind it.
+            int i0 = 0;
+            while (i0 < cnt) {
+                float amp = agc.amp, my_amp = 0.0f;
+                for (int i = i0; i < cnt; i++) {
+                    amp = agc_track(amp, wave_bcast(a_l, i), agc);
+                    if (lane == i) { my_amp = amp; }
                 }
-                const float v = re * gain;
-                if (lane == i) { outv = v; }
+                const bool mine = lane >= i0 && lane < cnt;
+                const float g_l = mine ? agc_gain_of(my_amp, a_l, agc) : 1.0f;
+                const int f = wave_first(mine && (a_l * g_l > agc.max_output_amp));
+                if (mine && lane < f) { outv = pv * g_l; }
+                if (f >= 64) {
+                    agc.amp = amp;
+                    break;
+                }
+                float m = (lane >= f && lane < cnt) ? a_l : 0.0f;  // rest of this chunk, then the rest of the block
+                for (int b2 = base + 64 + lane; b2 < n; b2 += 64) {
+                    const float a2 = fabsf(job.pre[b2]);
+                    if (a2 > m) { m = a2; }
+                }
+                agc.amp = wave_max(m);
+                const float g = agc.set_point / agc.amp;
+                const float gain = (agc.max_gain < g) ? agc.max_gain : g;
+                if (lane == f) { outv = pv * gain; }
+                i0 = f + 1;
             }
             if (lane < cnt) { out[base + lane] = make_float2(outv, outv); }
         }

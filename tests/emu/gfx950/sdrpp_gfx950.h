@@ -17,6 +17,13 @@ static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = 
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
+static inline int wave_first(bool pred) {
+    const float* ab = hipemu::wave_exchange(pred ? 1.0f : 0.0f, 0.0f);
+    for (int l = 0; l < 64; l++) {
+        if (ab[l * 2] != 0.0f) { return l; }
+    }
+    return 64;
+}
 static inline float wave_sum(float v) {  // same butterfly order as the device's shfl_xor reduction
     float cur = v;
     for (int d = 32; d >= 1; d >>= 1) {
