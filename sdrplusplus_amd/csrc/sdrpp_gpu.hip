@@ -1243,7 +1243,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             }
             const int D1 = 1 << h.lgD;
             const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
-            const int NP = (K + 1) / 2, NP4 = (NP + 3) / 4 * 4;
+            const int NP = (K + 1) / 2, NP4 = (NP + 7) / 8 * 8;  // rows of the tap operand table, zero padded (the kernels read 4 / 8 rows at a time)
             const std::string key = member_key(m_long ? 'L' : 'M', &s1[g], vt);
             float2* d_taps = nullptr;
             auto it = c->s1_tap_cache.find(key);
@@ -1570,7 +1570,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             else { launch(c, vfo_frontcm_kernel<16, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
         }
         if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
-            launch(c, vfo_frontcl_kernel, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl);
+            bool pf_ok = true;  // every window of the launch fits the register prefetch
+            for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
+            if (pf_ok) { launch(c, vfo_frontcl_kernel<SDRPP_FCL_PF>, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl); }
+            else { launch(c, vfo_frontcl_kernel<0>, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl); }
         }
         if (!rot.empty() && max_rot > 0) {
             launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);

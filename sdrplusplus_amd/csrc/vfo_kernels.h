@@ -1316,12 +1316,16 @@ __host__ __device__ inline int frontcl_lds_floats(int K, int lgD) {
     const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
     return 2 * 2 * frontcm_plane(nsamp, lgD) + 2 * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // 2 waves x 2 planes + tile phasors + pointers
 }
-__global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+// PF: IQ samples prefetched per lane into registers (covers windows of nsamp <= 64 * PF samples: PF = 38 -> first stages up to 448
+// taps at /64); PF = 0: longer windows are loaded in place, unpipelined.
+#define SDRPP_FCL_PF 38
+template <int PF>
+__global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemf)
     const FrontCMJob& job = jobs[blockIdx.y];
     constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
-    const int NP = (K + 1) >> 1, NP4 = ((NP + 3) >> 2) << 2;
+    const int NP = (K + 1) >> 1, NP8 = ((NP + 7) >> 3) << 3;
     const bool odd = (K & 1) != 0;
     const int nsamp = (tile - 1) * D + K;
     const int pl = frontcm_plane(nsamp, lgD);
@@ -1336,44 +1340,52 @@ __global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const Front
     if (tile0 * tile >= job.nout) { return; }
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
     if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
-    float2 pt[16];
+    // The window of a tile (up to 21 KB) is fetched into REGISTERS while the matrix cores work on the previous tile — only two
+    // wavefronts fit a SIMD (the planes fill the LDS), so the register file has room for it and nothing else would hide the load —
+    // and goes to the skewed planes between two matrix loops.
+    auto tile_base = [&](int tb) -> long long { return (long long)job.off + (long long)tb * tile * D; };
+    float2 pf[PF > 0 ? PF : 1];
+    bool pf_valid = false;  // wave-uniform: the registers hold the window of the next tile
+    auto fetch = [&](long long base) {  // windows fully inside this push only (all but the first and last tiles of a stream)
+        if constexpr (PF > 0) {
+            pf_valid = base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur;
+            if (pf_valid) {
+                const float2* p = src.cur + base + lane;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
-    }
+                for (int q = 0; q < PF; q++) { pf[q] = (q * 64 + lane < nsamp) ? global_load_f32x2(p, q * 64) : make_float2(0.0f, 0.0f); }
+            }
+        }
+    };
+    auto planes_store = [&](long long base) {
+        if (PF > 0 && pf_valid) {
+#pragma unroll
+            for (int q = 0; q < (PF > 0 ? PF : 1); q++) {
+                const int sidx = lane + q * 64;
+                if (sidx < nsamp) {
+                    const int idx = sidx + (sidx >> lgD);
+                    XR[idx] = pf[q].x;
+                    XI[idx] = pf[q].y;
+                }
+            }
+            return;
+        }
+        for (int sidx = lane; sidx < nsamp; sidx += 64) {  // history / end of the push / samples older than the VFO: in place, unpipelined
+            const long long gi = base + sidx;
+            const float2 v = (gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
+            const int idx = sidx + (sidx >> lgD);
+            XR[idx] = v.x;
+            XI[idx] = v.y;
+        }
+    };
+    fetch(tile_base(tile0));
     const float sgn = hi ? -1.0f : 1.0f;
     const float* P1 = hi ? XI : XR;
     const float* P2 = hi ? XR : XI;
     const int ib = jl * D + jl;
     for (int it = 0; it < ntl; it++) {
         const int tb = tile0 + it;
-        const long long base = (long long)job.off + (long long)tb * tile * D;
-        // ---- IQ window -> skewed planes (eight loads in flight per lane) ----
-        {
-            const bool inside = base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur;
-            for (int s0 = 0; s0 < nsamp; s0 += 64 * 8) {
-                float2 tmp[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int sidx = s0 + q * 64 + lane;
-                    if (inside) { tmp[q] = (sidx < nsamp) ? src.cur[base + sidx] : make_float2(0.0f, 0.0f); }
-                    else {
-                        const long long gi = base + sidx;
-                        tmp[q] = (sidx < nsamp && gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int sidx = s0 + q * 64 + lane;
-                    if (sidx < nsamp) {
-                        const int idx = sidx + (sidx >> lgD);
-                        XR[idx] = tmp[q].x;
-                        XI[idx] = tmp[q].y;
-                    }
-                }
-            }
-        }
+        const long long base = tile_base(tb);
+        planes_store(base);  // the previous tile's reads are complete (wave_sync at the end of the loop body)
         if (lane < VT && lane < job.nv) {
             double ph = fma((double)base + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
             ph -= rint(ph);
@@ -1381,16 +1393,19 @@ __global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const Front
             sincospif(2.0f * (float)ph, &sn, &cs);
             ptile[lane] = make_float2(cs, sn);
         }
+        pf_valid = false;
+        if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop (spreading these loads over the loop — vector memory
+                                                         // operations retire in order, the tap loads queue behind them — measured no faster)
         wave_sync();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
         {
-            // tap operand ring: four pairs ahead, coalesced 256-byte rows of the [pair][64] table (rows >= NP are zero padding)
-            float aq[4];
+            // tap operand ring: eight pairs ahead, coalesced 256-byte rows of the [pair][64] table (rows >= NP are zero padding)
+            float aq[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { aq[u] = global_load_f32(job.atab, u * 64 + lane); }
-            for (int p0 = 0; p0 < NP4; p0 += 4) {
+            for (int u = 0; u < 8; u++) { aq[u] = global_load_f32(job.atab, u * 64 + lane); }
+            for (int p0 = 0; p0 < NP8; p0 += 8) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     const int p = p0 + u;
                     const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
                     const int kb = K - 1 - pe;
@@ -1400,7 +1415,7 @@ __global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const Front
                     if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
                     const float bre = fmaf(sgn, b1, a1), bim = fmaf(sgn, a2, b2);  // lanes 32-63: di and -dr
                     const float a_re = aq[u];
-                    aq[u] = global_load_f32(job.atab, (p + 4 < NP4 ? p + 4 : p) * 64 + lane);
+                    aq[u] = global_load_f32(job.atab, (p + 8 < NP8 ? p + 8 : p) * 64 + lane);
                     accR = mfma_32x32x2(a_re, bre, accR);
                     accI = mfma_32x32x2(a_re, bim, accI);
                 }
@@ -1414,7 +1429,8 @@ __global__ __launch_bounds__(128) void vfo_frontcl_kernel(IqSrc src, const Front
                 const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (v < job.nv && live) {
                     const float2 P = ptile[v];
-                    const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                    const float2 T = global_load_f32x2(job.ptab, v * tile + jl);  // in-tile NCO advance (L2-resident table; keeping it in 32 registers would spill the prefetch)
+                    const float qr = fmaf(P.x, T.x, -(P.y * T.y)), qi = fmaf(P.x, T.y, P.y * T.x);
                     global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
                 }
             }
