@@ -37,6 +37,7 @@ struct Stream {
     int width = 2;
     int hist_len = 0;
     float* data = nullptr;
+    float* base = nullptr;  // the allocation `data` lives in (data = base + skew, see stream_alloc)
     size_t cap = 0;  // samples
     float* hist[2] = { nullptr, nullptr };
     int cur = 0;
@@ -381,8 +382,9 @@ int stream_alloc(sdrpp_ctx* c, Stream& s, int width, int hist_len, size_t cap) {
     s.cap = cap;
     s.cur = 0;
     s.n = 0;
-    int rc = dev_alloc(c, &s.data, (cap + 16) * width);
+    int rc = dev_alloc(c, &s.base, (cap + 16) * width);
     if (rc) { return rc; }
+    s.data = s.base;
     for (int i = 0; i < 2; i++) {
         rc = dev_alloc(c, &s.hist[i], (size_t)std::max(hist_len, 1) * width);
         if (rc) { return rc; }
@@ -391,7 +393,8 @@ int stream_alloc(sdrpp_ctx* c, Stream& s, int width, int hist_len, size_t cap) {
     return SDRPP_OK;
 }
 void stream_free(Stream& s) {
-    dev_free(s.data);
+    dev_free(s.base);
+    s.data = nullptr;
     dev_free(s.hist[0]);
     dev_free(s.hist[1]);
 }
@@ -2177,6 +2180,22 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
+#ifdef SDRPP_TOEP_PROF
+    {
+        unsigned long long h[4][8];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sdrpp_k::g_toep_prof), sizeof(h)) == hipSuccess) {
+            const char* names[4] = { "decimator", "resampler", "channel filter", "discriminator+audio" };
+            for (int k = 0; k < 4; k++) {
+                if (!h[k][5]) { continue; }
+                const double r = (double)h[k][5];
+                fprintf(stderr, "[sdrpp toep prof] %-20s rounds %llu, cycles per round: matrix %.0f | wait loads + regs->LDS %.0f | issue loads %.0f | discriminate %.0f | issue stores %.0f ; wavefront lifetime %.0f cycles, %.2f rounds per wavefront\n",
+                        names[k], h[k][5], h[k][0] / r, h[k][1] / r, h[k][2] / r, h[k][3] / r, h[k][4] / r, (double)h[k][6] / (double)h[k][7], r / (double)h[k][7]);
+            }
+            unsigned long long z[4][8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_toep_prof), z, sizeof(z));
+        }
+    }
+#endif
     preproc_free(c);
     wf_free(c);
     dev_free(c->d_pack);

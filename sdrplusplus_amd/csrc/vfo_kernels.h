@@ -1471,6 +1471,14 @@ struct ToepJob {
 #ifdef SDRPP_TOEP_KNOCK
 __device__ int g_toep_knock;
 #endif
+// -DSDRPP_TOEP_PROF builds only (`make prof`, diagnostic): shader-clock cycles every wavefront spends in the phases of a round of the
+// pipelined path, summed per launch kind (0 decimator, 1 resampler, 2 channel filter, 3 discriminator + audio low-pass):
+// [kind][0] matrix loop, [1] waiting for the next window's loads + registers -> LDS, [2] issuing the loads of the window after,
+// [3] discriminator, [4] issuing the output stores, [5] rounds, [6] whole wavefront lifetime, [7] wavefronts.  Printed at sdrpp_destroy.
+#ifdef SDRPP_TOEP_PROF
+__device__ unsigned long long g_toep_prof[4][8];
+#define TOEP_TICK() ((long long)__builtin_readcyclecounter())
+#endif
 
 template <int WIDTH, int G, bool QUAD>
 __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
@@ -1609,6 +1617,10 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
     // Order of one round of the pipelined path: matrix work on window t | window t+1 from registers to LDS | loads of window t+2 |
     // stores of the outputs of t.  The only wait for global memory (in front of the LDS writes) then covers loads and stores that
     // were issued one whole round earlier, never the stores just issued.
+#ifdef SDRPP_TOEP_PROF
+    long long tp_acc[5] = { 0, 0, 0, 0, 0 }, tp_rounds = 0;
+    const long long tp_birth = TOEP_TICK();
+#endif
     if (piped && mt0 * omt < job.nout) {
         fetch(mt0);
         window_store();
@@ -1632,6 +1644,9 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
             discriminate();
         }
         wave_sync();
+#ifdef SDRPP_TOEP_PROF
+        const long long tp0 = TOEP_TICK();
+#endif
         f32x4 accR[G], accI[G];
 #pragma unroll
         for (int g = 0; g < G; g++) { accR[g] = mfma4_zero(); accI[g] = mfma4_zero(); }
@@ -1686,12 +1701,28 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
                 }
             }
         }
+#ifdef SDRPP_TOEP_PROF
+        sched_fence();
+        const long long tp1 = TOEP_TICK();
+        long long tp2 = tp1, tp3 = tp1, tp4 = tp1;
+#endif
         if (piped && it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout) {
             wave_sync();  // every lane has read its operands of this window
             window_store();
+#ifdef SDRPP_TOEP_PROF
+            sched_fence();
+            tp2 = TOEP_TICK();
+#endif
             if (it + 2 < job.mt_per_wave && (mt + 2 * mts) * omt < job.nout) { fetch(mt + 2 * mts); }
+#ifdef SDRPP_TOEP_PROF
+            sched_fence();
+            tp3 = TOEP_TICK();
+#endif
             discriminate();
             sched_fence();
+#ifdef SDRPP_TOEP_PROF
+            tp4 = TOEP_TICK();
+#endif
         }
 #ifdef SDRPP_TOEP_KNOCK
         if ((knock & 1) && accR[0][0] != 123.456f) { continue; }
@@ -1726,7 +1757,26 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
             }
         }
         if (!piped) { wave_sync(); }  // the next macro tile overwrites the window
+#ifdef SDRPP_TOEP_PROF
+        sched_fence();
+        const long long tp5 = TOEP_TICK();
+        tp_acc[0] += tp1 - tp0;
+        tp_acc[1] += tp2 - tp1;
+        tp_acc[2] += tp3 - tp2;
+        tp_acc[3] += tp4 - tp3;
+        tp_acc[4] += tp5 - tp4;
+        tp_rounds++;
+#endif
     }
+#ifdef SDRPP_TOEP_PROF
+    if (lane == 0) {
+        const int kind = QUAD ? 3 : (s_in >= 30 ? 0 : (rows < 15 ? 1 : 2));
+        for (int k = 0; k < 5; k++) { atomicAdd(&g_toep_prof[kind][k], (unsigned long long)tp_acc[k]); }
+        atomicAdd(&g_toep_prof[kind][5], (unsigned long long)tp_rounds);
+        atomicAdd(&g_toep_prof[kind][6], (unsigned long long)(TOEP_TICK() - tp_birth));
+        atomicAdd(&g_toep_prof[kind][7], 1ull);
+    }
+#endif
 }
 
 // =====================================================================================================================
