@@ -42,7 +42,7 @@ FAMILY_KERNELS = {
     "vfo_stage1": ["vfo_frontcm_kernel", "vfo_frontcl_kernel", "vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
     "vfo_decim": ["vfo_toep_kernel<2, 2, false"], "vfo_poly": ["vfo_toep_kernel<2, 2, false", "vfo_polyc_kernel", "vfo_polyb_kernel", "vfo_poly_kernel"],
     "vfo_fir": ["vfo_toep_kernel<1, 2, true", "vfo_toep_kernel<2, 2, false", "vfo_toep_kernel<1, 2, false", "vfo_firb_kernel"],
-    "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"],
+    "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"], "vfo_pipe": ["vfo_pipe_kernel"],
 }
 
 
@@ -102,10 +102,12 @@ def cpu_baseline(base_cfg, nvfo, fft_size):
     }
 
 
-def algorithmic_work(push, plan, sr, nvfo):
+def algorithmic_work(push, plan, sr, nvfo, piped=False):
     """ALGORITHMIC flops / compulsory HBM bytes of ONE launch set of every kernel family for one push: real-tap FIR on
     complex data = 4 flop per tap and output; the fused front end in its tap-pair form (8 flop per pair and output + the NCO's two
-    complex products); real audio filter 2 flop per tap.  Families hold several launches (vfo_fir = channel filter + audio low-pass)."""
+    complex products); real audio filter 2 flop per tap.  Families hold several launches (vfo_fir = channel filter + audio low-pass).
+    piped: the FM back ends ran as the pipelined launch (family vfo_pipe = last decimator + resampler + channel filter + discriminator /
+    audio low-pass of those VFOs, compulsory bytes = front-end stream in, IF + audio out); their work leaves the other three families."""
     from sdrplusplus_amd import radio
 
     by = {"fft_pass1": push * 16.0, "fft_pass2": push * 12.0, "fft_single": push * 12.0, "zoom_palette": push * 4.0}
@@ -113,7 +115,7 @@ def algorithmic_work(push, plan, sr, nvfo):
     bound = {"fft_pass1": "hbm", "fft_pass2": "hbm", "fft_single": "hbm", "zoom_palette": "hbm", "carry_misc": "hbm", "demod": "hbm"}
     if not nvfo:
         return fl, by, bound
-    for f in ("vfo_stage1", "vfo_decim", "vfo_poly", "vfo_fir"):
+    for f in ("vfo_stage1", "vfo_decim", "vfo_poly", "vfo_fir", "vfo_pipe"):
         fl[f], by[f], bound[f] = 0.0, 0.0, "mfma"
     by["vfo_stage1"] += push * 8.0  # the IQ stream is read once for all VFOs of a front-end job
     cache = {}
@@ -134,25 +136,41 @@ def algorithmic_work(push, plan, sr, nvfo):
             n = n / Dc
             fl["vfo_stage1"] += n * (((Kc + 1) // 2) * 8.0 + 16.0)
             by["vfo_stage1"] += n * 8.0
-            for Ds, Ks in st[2 if fused else 1:]:
-                by["vfo_decim"] += n * 8 + n / Ds * 8
+            rest = st[2 if fused else 1:]
+            # (the pipelined launch takes the LAST decimator stage of an FM VFO whose plan has a resampler, a channel filter and an audio low-pass)
+            in_pipe = piped and g["fm"] and bool(rest) and g["interp"] != g["decim"] and g["interp"] <= 15 and g["chan"] and g["audio"]
+            for si, (Ds, Ks) in enumerate(rest):
+                fam = "vfo_pipe" if (in_pipe and si == len(rest) - 1) else "vfo_decim"
+                by[fam] += n * 8 + (0 if fam == "vfo_pipe" else n / Ds * 8)
                 n /= Ds
-                fl["vfo_decim"] += n * Ks * 4.0
+                fl[fam] += n * Ks * 4.0
         else:
+            in_pipe = False
             fl["vfo_stage1"] += n * 8.0
             by["vfo_stage1"] += n * 8.0
         if g["interp"] != g["decim"]:
             tpp = -(-g["rtaps"] // g["interp"])
             n_out = n * g["interp"] / g["decim"]
-            by["vfo_poly"] += n * 8 + n_out * 8
-            fl["vfo_poly"] += n_out * tpp * 4.0
+            if in_pipe:
+                fl["vfo_pipe"] += n_out * tpp * 4.0
+            else:
+                by["vfo_poly"] += n * 8 + n_out * 8
+                fl["vfo_poly"] += n_out * tpp * 4.0
             n = n_out
         if g["chan"]:
-            by["vfo_fir"] += n * 16
-            fl["vfo_fir"] += n * g["chan"] * 4.0
+            if in_pipe:
+                by["vfo_pipe"] += n * 8  # the IF stream (RxVFO output) is written
+                fl["vfo_pipe"] += n * g["chan"] * 4.0
+            else:
+                by["vfo_fir"] += n * 16
+                fl["vfo_fir"] += n * g["chan"] * 4.0
         if g["audio"]:
-            by["vfo_fir"] += n * (16 if g["fm"] else 12)
-            fl["vfo_fir"] += n * g["audio"] * 2.0
+            if in_pipe:
+                by["vfo_pipe"] += n * 8
+                fl["vfo_pipe"] += n * g["audio"] * 2.0
+            else:
+                by["vfo_fir"] += n * (16 if g["fm"] else 12)
+                fl["vfo_fir"] += n * g["audio"] * 2.0
     return fl, by, bound
 
 
@@ -367,7 +385,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel family (HIP events around its launches, on the launch stream, inside the timed region) ----
-    fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo)
+    fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo, piped=kernel_ms_all.get("vfo_pipe", 0) > 0)
     kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}
     roof = None
     if dom is not None and dom in kernel_ms and dom in by:
@@ -378,7 +396,7 @@ def main():
             tf = fl[dom] / dur / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5), "traffic": traffic,
                     "algorithmic_flops_per_launch": fl[dom], "algorithmic_bytes_per_launch": by[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 4),
-                    "note": "family = all launches of this kind in one push (vfo_fir = channel filters + discriminator / audio low-passes); peak = dense FP32 MFMA"}
+                    "note": "family = all launches of this kind in one push (vfo_fir = channel filters + discriminator / audio low-passes; vfo_pipe = the pipelined FM back ends: last decimator + resampler + channel filter + discriminator / audio low-pass in one launch); peak = dense FP32 MFMA"}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": by[dom], "avg_launch_ms": round(kernel_ms[dom], 4)}

@@ -96,6 +96,14 @@ int sdrpp_set_reference_block(sdrpp_ctx* ctx, int ref_block);
 #define SDRPP_NCO_CLOSED_FORM 0
 #define SDRPP_NCO_REFERENCE_ROTATOR 1
 int sdrpp_set_nco_mode(sdrpp_ctx* ctx, int mode);
+/* How the per-VFO filters behind the front end are launched for FM VFOs (WFM / NFM: last decimator -> resampler -> channel filter ->
+ * discriminator + audio low-pass; the chain of rx_vfo.h:20-66 + demod/broadcast_fm.h, demod/fm.h).
+ *   on (default): as ONE launch where that pays — the four stages run as a pipeline inside a workgroup, the streams between them stay in
+ *     LDS (csrc/pipe_kernels.h); the library decides push by push (large pushes and launch-bound small ones).
+ *   off: one launch per stage, intermediate streams in HBM.
+ * Results are bit-identical either way (same tap tables, same summation order); a switch for measurements and for the test that says so
+ * (on >= 2, a test hook: always pipelined, `on` segments per VFO). */
+int sdrpp_set_backend_pipeline(sdrpp_ctx* ctx, int on);
 
 /* ---- FFT -> log-power -> waterfall line (replaces Reshaper + Handler + IQFrontEnd::handler, iq_frontend.cpp:248-309,
  *      and WaterFall::pushFFT's doZoom + palette index, waterfall.cpp:65-90, 889-906) --------------------------------------- */
@@ -281,8 +289,9 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.
- * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc */
-#define SDRPP_NUM_KERNEL_FAMILIES 11
+ * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc,
+ * 10 af_chain, 11 vfo_pipe (pipelined FM back ends) */
+#define SDRPP_NUM_KERNEL_FAMILIES 12
 /* on = 0: off; 1: every family; 1 | (family_bitmask << 1): only the selected families (each timed launch costs two event
  * records on its stream, so a throughput run instruments just the kernel it reports). */
 int sdrpp_timing_enable(sdrpp_ctx* ctx, int on);

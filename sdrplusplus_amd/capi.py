@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libsdrpp_gpu.so")
 
 MAX_DECIM_STAGES = 4
-NUM_KERNEL_FAMILIES = 11  # SDRPP_NUM_KERNEL_FAMILIES (checked against the header in tests/test_capi_host.py)
+NUM_KERNEL_FAMILIES = 12  # SDRPP_NUM_KERNEL_FAMILIES (checked against the header in tests/test_capi_host.py)
 
 DEMOD_RAW, DEMOD_WFM, DEMOD_NFM, DEMOD_AM, DEMOD_USB, DEMOD_LSB, DEMOD_DSB = -1, 0, 1, 2, 3, 4, 5
 
@@ -167,6 +167,7 @@ def load():
     L.sdrpp_pending.argtypes = [vp]
     L.sdrpp_vfo_read_many.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int64, C.POINTER(C.c_int64), c_int_p]
     L.sdrpp_set_nco_mode.argtypes = [vp, C.c_int]
+    L.sdrpp_set_backend_pipeline.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_set_ssb_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.sdrpp_vfo_out_count.argtypes = [vp, C.c_int]
     L.sdrpp_vfo_read.argtypes = [vp, C.c_int, c_float_p, C.c_int]
@@ -194,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
-    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -315,6 +316,10 @@ class Context:
     def set_nco_mode(self, mode):
         """0 closed-form NCO (default), 1 the reference's float rotator recursion (parity mode).  Only while no VFO exists."""
         self._chk(self.L.sdrpp_set_nco_mode(self.h, int(mode)))
+
+    def set_backend_pipeline(self, on):
+        """FM back ends as one pipelined launch where that pays (default) / one launch per stage.  Bit-identical results."""
+        self._chk(self.L.sdrpp_set_backend_pipeline(self.h, int(on)))
 
     # FFT branch
     def fft_configure(self, fft_size, nz, skip, window):

@@ -71,8 +71,25 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Flags in LDS between the wavefronts of a workgroup (producer / consumer rings): a wavefront's LDS operations are carried out in
+// program order and the LDS serves one CU, so a flag written after the data (release) and read before it (acquire) is all the
+// ordering there is to it; a waiting wavefront sleeps 64 cycles between looks so that it does not take issue slots from the others.
+__device__ __forceinline__ void lds_flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_wait_ge(int* f, int need) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) { __builtin_amdgcn_s_sleep(1); }
+}
+
+// Issue priority of this wavefront among the wavefronts of its SIMD (s_setprio 0..3)
+__device__ __forceinline__ void wave_prio_high() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void wave_prio_low() { __builtin_amdgcn_s_setprio(0); }
+
 // Wave-uniform helpers: value of lane `src` (src uniform across the wavefront: v_readlane_b32), and the maximum over all 64 lanes.
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+// value of the lane to the left (lane 0: `first`)
+__device__ __forceinline__ float wave_shr1(float v, float first) {
+    const float r = __shfl_up(v, 1, 64);
+    return ((threadIdx.x & 63) == 0) ? first : r;
+}
 // index of the first lane whose predicate holds, 64 if none (v_cmp + s_ff1)
 __device__ __forceinline__ int wave_first(bool pred) {
     const unsigned long long m = __ballot(pred);

@@ -18,6 +18,7 @@
 #include "fft_kernels.h"
 #include "host_design.h"
 #include "vfo_kernels.h"
+#include "pipe_kernels.h"
 
 using namespace sdrpp_k;
 
@@ -29,9 +30,9 @@ constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4
 constexpr size_t kScratchBytes = 64u << 20;
 constexpr int kMaxLds = 64 * 1024;
 
-enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF };
+enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF, F_PIPE };
 const char* kFamilyNames[SDRPP_NUM_KERNEL_FAMILIES] = { "fft_pass1", "fft_pass2", "fft_single", "zoom_palette", "vfo_stage1",
-                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain" };
+                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain",  "vfo_pipe" };
 
 struct Stream {
     int width = 2;
@@ -229,6 +230,7 @@ struct sdrpp_ctx {
     // reference block structure / NCO flavour (sdrpp_set_reference_block, sdrpp_set_nco_mode)
     int ref_block = 0;             // 0: one push = one reference block
     int nco_exact = 0;             // 1: the reference's float rotator recursion instead of the closed-form NCO
+    int pipe_on = 1;               // FM back ends as one pipelined launch where that pays (sdrpp_set_backend_pipeline)
     std::vector<int> vfo_bounds;   // reference-block ends (cumulative sample counts) of the current push at the VFO bank's input
 
     // VFOs
@@ -935,6 +937,64 @@ void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, cons
     else { launch(c, vfo_toep_kernel<1, 2, false>, grid, dim3(256), P.lds, (const ToepJob*)d_jobs); }
 }
 
+// ---- pipelined FM back end (vfo_pipe_kernel) ----
+constexpr int kPipeG = 1;    // groups of 16 tiles per macro tile: one keeps a job's LDS at ~30 KB, five workgroups per CU
+constexpr int kPipeBpc = 5;  // workgroups per CU the kernel is built for (launch bounds, LDS share)
+// LDS layout of one job; false = does not fit / stage 0 not register-staged -> the VFO keeps its separate launches
+bool pipe_layout_try(PipeJob& J, int fifo_tiles, size_t* lds_bytes) {
+    const int G = kPipeG;
+    int off = 0;
+    auto take = [&](int nfloats) { const int o = off; off += (nfloats + 3) & ~3; return o; };
+    for (int s = 0; s < 4; s++) { J.tl_off[s] = take(J.st[s].tl_len); }
+    int W[4], span[4], omt[4];
+    for (int s = 0; s < 4; s++) {
+        W[s] = G * 16 * J.st[s].s_in;
+        span[s] = W[s] - J.st[s].s_in + 4 * J.st[s].nsteps;
+        omt[s] = G * 16 * J.st[s].rows;
+    }
+    if (((span[0] + 1) >> 1) > 9 * 64) { return false; }  // stage 0's window is register-staged: nine sample pairs per lane
+    J.win_off = take(2 * ((span[0] + 8) & ~3));
+    J.zero_lo = off;
+    for (int i = 0; i < 3; i++) {
+        // R >= W + h + what the producer writes at a time, a multiple of W: windows start at multiples of W, no stall cycle.  (i = 2:
+        // stage 3's own ring of discriminator outputs, which it fills a stage-2 macro tile at a time between two matrix loops.)
+        const int s = i + 1, h = span[s] - W[s];
+        if (h < 0) { return false; }
+        const int R = std::max(2, (W[s] + h + omt[i] + W[s] - 1) / W[s]) * W[s];
+        if (i < 2) {
+            J.ring_len[i] = R;
+            J.ring_mir[i] = h;
+            J.ring_off[i] = take(2 * (R + h));
+        }
+        else {
+            J.dring_len = R;
+            J.dring_mir = h;
+            J.dring_off = take(R + h);
+        }
+    }
+    J.ring_len[2] = fifo_tiles * omt[2];  // IF phases on their way to the discriminator's difference: a plain FIFO of whole stage-2 macro tiles
+    J.ring_mir[2] = 0;
+    J.ring_off[2] = take(J.ring_len[2]);
+    J.zero_hi = off;
+    J.flag_off = take(8);
+    *lds_bytes = (size_t)off * sizeof(float);
+    return *lds_bytes <= (size_t)(160 * 1024) / kPipeBpc;
+}
+bool pipe_layout(PipeJob& J, size_t* lds_bytes) { return pipe_layout_try(J, 2, lds_bytes) || pipe_layout_try(J, 1, lds_bytes); }
+// Segments per VFO, 0 = this push is better served by the separate launches.  A segment pays one warm-up macro tile per stage and the
+// pipeline's fill: with fewer than ~12 last-stage macro tiles per segment of a full grid the four launches win (measured: 1 M-sample
+// pushes of the 32-VFO bank, 2.6 tiles per segment, 14 % slower) — unless the push is so small that it is launch-bound anyway.
+int pipe_segments(const std::vector<PipeJob>& pipes, int forced) {
+    if (pipes.empty()) { return 0; }
+    int max_nmt = 1;
+    for (auto& pj : pipes) { max_nmt = std::max(max_nmt, (pj.st[3].nout + kPipeG * 16 * pj.st[3].rows - 1) / (kPipeG * 16 * pj.st[3].rows)); }
+    if (forced >= 2) { return std::min(forced, max_nmt); }
+    const int s_full = (256 * kPipeBpc + (int)pipes.size() - 1) / (int)pipes.size();
+    if (max_nmt >= 12 * s_full) { return s_full; }
+    if (max_nmt <= 16) { return 1; }
+    return 0;
+}
+
 int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
 #ifdef SDRPP_TOEP_KNOCK
@@ -965,6 +1025,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
     std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
+    std::vector<PipeJob> pipes;  // FM back ends that run as one pipelined launch
+    size_t pipe_lds = 0;
     // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
     std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
     std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
@@ -1070,12 +1132,31 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 cur = nxt;
             }
         }
+        // the FM back end as one pipelined launch: last decimator, resampler, channel filter, discriminator + audio low-pass all in
+        // their matrix form, and the pipeline's LDS layout fits
+        const int last_dec = v.d.n_stages - 1;
+        bool piped_be = c->pipe_on && (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) && last_dec >= first_sep && v.tp_stage[last_dec].ok &&
+                        v.i_poly >= 0 && v.tp_poly.ok && v.i_chan >= 0 && v.chan_ntaps > 0 && v.tp_chan.ok && v.tp_audio.ok;
+        PipeJob pj{};
+        size_t pj_lds = 0;
+        if (piped_be) {
+            pj.st[0] = toep_job(v.tp_stage[last_dec], 0, StreamIn{}, nullptr, 0, 0, 0.0f);
+            pj.st[1] = toep_job(v.tp_poly, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
+            pj.st[2] = toep_job(v.tp_chan, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
+            pj.st[3] = toep_job(v.tp_audio, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
+            piped_be = pipe_layout(pj, &pj_lds);
+        }
         for (int s = first_sep; s < v.d.n_stages; s++) {
             Stream* nxt = &v.st[(size_t)v.i_first + s];
             const int Ds = v.d.stage_decim[s];
             const int no = decim_nout(cur->n, v.soff[s], Ds);
             if (need_bnd) { bounds_decim(bnd, v.soff[s], Ds); }
-            if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
+            if (piped_be && s == last_dec) {
+                pj.st[0] = toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f);
+                pj.keep[0] = std::max(0, no - nxt->hist_len);
+                pj.dec_stage = s;
+            }
+            else if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
             else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
             v.soff[s] = v.soff[s] + no * Ds - cur->n;
             nxt->n = no;
@@ -1085,7 +1166,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
             if (need_bnd) { bounds_poly(bnd, v.poff, v.pphase, v.d.interp, v.d.decim); }
-            if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
+            if (piped_be) {
+                pj.st[1] = toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f);
+                pj.keep[1] = std::max(0, no - nxt->hist_len);
+            }
+            else if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
             else if (v.d_cyc) {
                 polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
@@ -1101,7 +1186,11 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
+            if (piped_be) {
+                pj.st[2] = toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f);
+                pj.keep[2] = 0;  // the IF stream is the RxVFO's output: all of it
+            }
+            else if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
             else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
             cur = nxt;
@@ -1118,7 +1207,12 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         const int nbnd = need_bnd ? (int)bnd.size() : 0;
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
-            if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
+            if (piped_be) {
+                pj.st[3] = toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation);
+                pipes.push_back(pj);
+                pipe_lds = std::max(pipe_lds, pj_lds);
+            }
+            else if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
             else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
         }
@@ -1450,6 +1544,18 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     RetuneJob* d_retune = arena_push(c, retune);
     const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
     if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!ssbx.empty() && !d_ssbx) || (!retune.empty() && !d_retune)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    const int pipe_seg = pipe_segments(pipes, c->pipe_on);
+    if (!pipes.empty() && pipe_seg == 0) {  // not this push: the same four jobs go to the separate launches
+        for (auto& pj : pipes) {
+            for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
+                if (pj.dec_stage == s) { t_lvl[s].push_back(pj.st[0]); }
+            }
+            t_poly.push_back(pj.st[1]);
+            t_chan.push_back(pj.st[2]);
+            t_audio_fm.push_back(pj.st[3]);
+        }
+        pipes.clear();
+    }
     ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
     ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
     for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
@@ -1458,6 +1564,8 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
     const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
+    PipeJob* d_pipes = arena_push(c, pipes);
+    if (!pipes.empty() && !d_pipes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     ToepJob* d_t_poly = arena_push(c, t_poly);
     ToepJob* d_t_chan = arena_push(c, t_chan);
     ToepJob* d_t_audio = arena_push(c, t_audio);
@@ -1661,6 +1769,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             rc = launch_fir(lvl[s], d_lvl[s], 2, false);
             if (rc) { return rc; }
         }
+    }
+    if (!pipes.empty()) {
+        FamilyTimer t(c, F_PIPE);
+        launch(c, vfo_pipe_kernel<kPipeG>, dim3((unsigned)pipe_seg, (unsigned)pipes.size()), dim3(256), pipe_lds, (const PipeJob*)d_pipes);
     }
     if (!t_poly.empty()) {
         FamilyTimer t(c, F_POLY);
@@ -2193,6 +2305,17 @@ int sdrpp_destroy(sdrpp_ctx* c) {
             }
             unsigned long long z[4][8] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_toep_prof), z, sizeof(z));
+        }
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sdrpp_k::g_pipe_prof), sizeof(h)) == hipSuccess) {
+            const char* names[4] = { "decimator", "resampler", "channel filter", "discriminator+audio" };
+            for (int k = 0; k < 4; k++) {
+                if (!h[k][5]) { continue; }
+                const double r = (double)h[k][5];
+                fprintf(stderr, "[sdrpp pipe prof] %-20s tiles %llu, cycles per tile: wait input %.0f | matrix %.0f | release / stage next %.0f | epilogue + wait space %.0f | write + publish %.0f ; wavefront lifetime %.0f cycles, %.2f tiles per wavefront\n",
+                        names[k], h[k][5], h[k][0] / r, h[k][1] / r, h[k][2] / r, h[k][3] / r, h[k][4] / r, (double)h[k][6] / (double)h[k][7], r / (double)h[k][7]);
+            }
+            unsigned long long z[4][8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_pipe_prof), z, sizeof(z));
         }
     }
 #endif
@@ -3000,6 +3123,11 @@ int sdrpp_set_reference_block(sdrpp_ctx* c, int ref_block) {
     return SDRPP_OK;
 }
 
+int sdrpp_set_backend_pipeline(sdrpp_ctx* c, int on) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    c->pipe_on = on < 0 ? 0 : on;
+    return SDRPP_OK;
+}
 int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
     if (!c || (mode != SDRPP_NCO_CLOSED_FORM && mode != SDRPP_NCO_REFERENCE_ROTATOR)) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);

@@ -16,7 +16,16 @@ static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] =
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
+static inline void lds_flag_set(int* f, int v) { *(volatile int*)f = v; }
+static inline void lds_flag_wait_ge(int* f, int need) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile
+static inline void wave_prio_high() {}
+static inline void wave_prio_low() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
+static inline float wave_shr1(float v, float first) {
+    const float* ab = hipemu::wave_exchange(v, 0.0f);
+    const int l = hipemu::lane_id();
+    return l == 0 ? first : ab[(l - 1) * 2];
+}
 static inline int wave_first(bool pred) {
     const float* ab = hipemu::wave_exchange(pred ? 1.0f : 0.0f, 0.0f);
     for (int l = 0; l < 64; l++) {

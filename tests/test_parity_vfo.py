@@ -649,3 +649,54 @@ def test_deferred_pushes_equal_block_by_block(backend):
     for (mode, _), a, b in zip(specs, o0, o1):
         assert a.shape == b.shape and len(a) > 100, mode
         assert np.max(np.abs(a - b)) < 5e-6 * max(1.0, float(np.max(np.abs(a)))), (mode, float(np.max(np.abs(a - b))))
+
+
+def test_pipelined_fm_back_end_is_bit_identical(backend):
+    """sdrpp_set_backend_pipeline: last decimator -> resampler -> channel filter -> discriminator + audio low-pass of an FM VFO as ONE
+    launch (csrc/pipe_kernels.h: four wavefronts = four stages, the streams between them in LDS rings) gives the BITS of the four
+    separate launches — audio and IF — over ragged pushes (history hand-over between pushes, one-sample pushes, pushes that end inside a
+    macro tile), alone in a workgroup and cut into segments with recomputed warm-up tiles (the forced segment counts), next to VFOs that
+    keep their separate launches (NFM's 16/25 resampler, AM).  Against the oracle the default (pipelined) path is what every other test
+    of this file runs."""
+    from sdrplusplus_amd import capi, radio
+
+    sr = 10e6
+    n = 420000 if backend == "emu" else 6000000
+    r = np.random.default_rng(5)
+    x = (r.standard_normal(n) + 1j * r.standard_normal(n)) * 0.05
+    t = np.arange(n)
+    x += 0.5 * np.exp(2j * np.pi * (1.35e6 / sr * t + 3.0 * np.sin(2 * np.pi * 3e3 / sr * t)))
+    x = x.astype(np.complex64)
+    cuts = [50000, 1, 7, 4096, 65536, 100, 50000, 131072, 333]
+    cuts.append(n - sum(cuts))
+    specs = [("WFM", 1.35e6), ("WFM", -2.0e6), ("NFM", 0.4e6), ("AM", -0.7e6)]
+
+    def run(mode):
+        ctx = capi.Context(0, max_push=max(cuts))
+        ctx.set_backend_pipeline(mode)
+        vids = []
+        for m, off in specs:
+            if_rate, bw = radio.RADIO_DEFAULTS.get(m, (250e3, 250e3))
+            d, keep = radio.vfo_desc(sr, if_rate, bw, off, m)
+            vids.append(ctx.vfo_add(d, keep))
+        pos, audio, ifs = 0, [[] for _ in vids], [[] for _ in vids]
+        ctx.timing_enable(True)
+        for c in cuts:
+            ctx.push(x[pos:pos + c])
+            pos += c
+            for k, v in enumerate(vids):
+                audio[k].append(ctx.vfo_read(v))
+                ifs[k].append(ctx.vfo_read_if(v))
+        launches = ctx.timing_read()["vfo_pipe"][1]
+        ctx.close()
+        return [np.concatenate(a) for a in audio], [np.concatenate(i) for i in ifs], launches
+
+    a0, i0, l0 = run(0)
+    assert l0 == 0
+    for mode in (1, 2, 5) if backend == "emu" else (1, 2, 7, 64):
+        a1, i1, l1 = run(mode)
+        assert l1 > 0, mode  # the pipelined launch really ran
+        for k, (m, _) in enumerate(specs):
+            assert a1[k].shape == a0[k].shape and i1[k].shape == i0[k].shape and len(a0[k]) > 500
+            assert np.array_equal(a1[k].view(np.uint32), a0[k].view(np.uint32)), (mode, m)
+            assert np.array_equal(i1[k].view(np.uint32), i0[k].view(np.uint32)), (mode, m)

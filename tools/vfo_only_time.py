@@ -14,6 +14,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 x = (torch.randn(push * 2, device="cuda:0", dtype=torch.float32) * 0.1)
 ctx = capi.Context(0, max_push=push)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("SDRPP_TOOL_PIPELINE"):  # 0: one launch per back-end stage
+    ctx.set_backend_pipeline(int(os.environ["SDRPP_TOOL_PIPELINE"]))
 for mode, if_rate, bw, centre, _ in workloads.vfo_plan(3, nvfo):
     d, keep = radio.vfo_desc(10e6, if_rate, bw, centre, mode)
     ctx.vfo_add(d, keep)
