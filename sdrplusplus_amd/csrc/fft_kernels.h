@@ -324,7 +324,7 @@ struct IdxRowPad {
 // grid.x = nframes * (N1 / R); block = (N2/16) * R work-items, t fastest (coalesced row reads).
 template <int LG2, int R>
 __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
-                                                                         float* __restrict__ out_db, int lg1, int nframes) {
+                                                                         float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
     constexpr int L2 = 1 << LG2;
     constexpr int TPF = L2 / 16;
     constexpr int PITCH = L2 + L2 / 16;
@@ -370,6 +370,20 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
         const int rr = e % R;
         dst[((size_t)k2 << lg1) + rr] = tile[k2 * (R + 1) + rr];
     }
+    // doZoom's maximum over the R consecutive bins k1 = r0 .. r0 + R - 1 of every k2, while the tile is in LDS: the zoom kernel then
+    // reads one value per aligned group of R bins instead of R (waterfall.cpp:65-90 takes a maximum, which does not care how it is split)
+    if (grp_max) {
+        float* gdst = grp_max + (((size_t)frame << (LG2 + lg1)) + r0) / R;
+        for (int k2 = threadIdx.x; k2 < L2; k2 += TPF * R) {
+            float m = __uint_as_float(0xff800000u);
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const float v = tile[k2 * (R + 1) + rr];
+                if (v > m) { m = v; }
+            }
+            gdst[((size_t)k2 << lg1) / R] = m;
+        }
+    }
     (void)nframes;
 }
 
@@ -382,7 +396,8 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
 template <int TP>
 __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
                                                           const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
-                                                          float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index) {
+                                                          float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index,
+                                                          const float* __restrict__ grp_max, int gsz) {
     constexpr int PPB = 256 / TP;  // pixels per block
     __shared__ float part[PPB * (TP + 1)];
     const int line = blockIdx.y;
@@ -392,9 +407,21 @@ __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restri
     float m = __uint_as_float(0xff800000u);  // -inf
     if (px < data_width) {
         const int s = zstart[px], e = s + zcount[px];
-        for (int b = s + q; b < e; b += TP) {
-            const float v = in[b];
-            if (v > m) { m = v; }
+        if (grp_max && e - s >= 2 * gsz) {
+            // pass 2 left the maximum of every aligned group of gsz bins: the pixel's range = ragged head + whole groups + ragged tail
+            const int a = ((s + gsz - 1) / gsz) * gsz, bnd = (e / gsz) * gsz;
+            const int nh = a - s, ng = (bnd - a) / gsz, nt = e - bnd;
+            const float* g = grp_max + (size_t)line * (fft_size / gsz) + a / gsz;
+            for (int i = q; i < nh + ng + nt; i += TP) {
+                const float v = (i < nh) ? in[s + i] : ((i < nh + ng) ? g[i - nh] : in[bnd + (i - nh - ng)]);
+                if (v > m) { m = v; }
+            }
+        }
+        else {
+            for (int b = s + q; b < e; b += TP) {
+                const float v = in[b];
+                if (v > m) { m = v; }
+            }
         }
     }
     if constexpr (TP > 1) {

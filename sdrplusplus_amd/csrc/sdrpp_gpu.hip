@@ -215,6 +215,8 @@ struct sdrpp_ctx {
     float2* d_twn = nullptr;   // [k1][n2] tw(n2*k1, N)
     float2* d_scratch = nullptr;
     float* d_lines = nullptr;
+    float* d_lines_grp = nullptr;  // per line: maxima of aligned groups of zoom_grp bins (pass 2 writes them for the zoom kernel); N > 4096 only
+    int zoom_grp = 0;
     size_t lines_cap = 0;
     int64_t fft_pos = 0, fft_next = 0;
     int n_lines = 0;
@@ -698,13 +700,15 @@ void launch_p1(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, int lg2) {
     launch(c, fft_pass1_kernel<LG1, C>, dim3(blocks), dim3(((1 << LG1) / 16) * C), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1,
            (const float2*)c->d_twn, c->d_scratch, lg2);
 }
+constexpr int pass2_rows(int lg2) { return lg2 == 7 ? 32 : (lg2 == 8 ? 16 : (lg2 == 9 ? 8 : 4)); }  // rows per workgroup of fft_pass2_kernel = bins per doZoom group
 template <int LG2, int R>
-void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out) {
+void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out, float* grp) {
+    static_assert(R == pass2_rows(LG2), "pass2_rows out of step with the launch table");
     const int blocks = nframes * ((1 << lg1) / R);
-    launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes);
+    launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes, grp);
 }
 
-int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out) {
+int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out, float* grp) {
     const int m = c->fft_lg;
     if (m <= 12) {
         FamilyTimer t(c, F_FFTS);
@@ -731,10 +735,10 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
     {
         FamilyTimer t(c, F_FFT2);
         switch (lg2) {
-        case 7: launch_p2<7, 32>(c, g.nframes, lg1, out); break;
-        case 8: launch_p2<8, 16>(c, g.nframes, lg1, out); break;
-        case 9: launch_p2<9, 8>(c, g.nframes, lg1, out); break;
-        case 10: launch_p2<10, 4>(c, g.nframes, lg1, out); break;
+        case 7: launch_p2<7, 32>(c, g.nframes, lg1, out, grp); break;
+        case 8: launch_p2<8, 16>(c, g.nframes, lg1, out, grp); break;
+        case 9: launch_p2<9, 8>(c, g.nframes, lg1, out, grp); break;
+        case 10: launch_p2<10, 4>(c, g.nframes, lg1, out, grp); break;
         default: return fail(c, SDRPP_ERR_UNSUPPORTED, "fft pass-2 size 2^%d unsupported", lg2);
         }
     }
@@ -743,14 +747,16 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
 
 // doZoom + palette launch: lanes per pixel from the view's bins per pixel (coalesced bin reads for wide pixels, no idle lanes for narrow ones)
 void launch_zoom(hipStream_t stream, const float* lines, int nlines, int fft_size, int view_bins, int data_width, const int32_t* zs, const int32_t* zc, float wf_min, float wf_max,
-                 float* zoomed, int32_t* index) {
-    const int bpp = view_bins / std::max(1, data_width);
+                 float* zoomed, int32_t* index, const float* grp = nullptr, int gsz = 0) {
+    int bpp = view_bins / std::max(1, data_width);
+    if (grp && gsz > 1 && bpp >= 2 * gsz) { bpp = bpp / gsz + gsz; }  // elements a pixel walks: whole groups + the ragged ends
+    else { grp = nullptr; }
     const int tp = (bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1);
     const dim3 grid((unsigned)((data_width + 256 / tp - 1) / (256 / tp)), (unsigned)nlines);
     switch (tp) {
-    case 16: hipLaunchKernelGGL(zoom_palette_kernel<16>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index); break;
-    case 4: hipLaunchKernelGGL(zoom_palette_kernel<4>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index); break;
-    default: hipLaunchKernelGGL(zoom_palette_kernel<1>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index); break;
+    case 16: hipLaunchKernelGGL(zoom_palette_kernel<16>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index, grp, gsz); break;
+    case 4: hipLaunchKernelGGL(zoom_palette_kernel<4>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index, grp, gsz); break;
+    default: hipLaunchKernelGGL(zoom_palette_kernel<1>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index, grp, gsz); break;
     }
 }
 
@@ -812,14 +818,15 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             g.stride = (int)P;
             g.nz = c->nz;
             g.first_start = (c->fft_next + f0) * P - c->fft_pos;
-            int rc = run_fft_chunk(c, src, g, c->d_lines + (size_t)f0 * c->fft_size);
+            int rc = run_fft_chunk(c, src, g, c->d_lines + (size_t)f0 * c->fft_size, c->zoom_grp ? c->d_lines_grp + (size_t)f0 * (c->fft_size / c->zoom_grp) : nullptr);
             if (rc) { return rc; }
         }
         if (c->data_width > 0) {
             int rc = ensure_zoom(c, (size_t)nframes);
             if (rc) { return rc; }
             FamilyTimer t(c, F_ZOOM);
-            launch_zoom(c->launch_stream, c->d_lines, (int)nframes, c->fft_size, c->view_size, c->data_width, c->d_zstart, c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index);
+            launch_zoom(c->launch_stream, c->d_lines, (int)nframes, c->fft_size, c->view_size, c->data_width, c->d_zstart, c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index,
+                        c->d_lines_grp, c->zoom_grp);
             if (c->wf.height > 0) {  // FFT trace: latestFFT after smoothing / hold (pushFFT, waterfall.cpp:913-939)
                 int rc2 = wf_ensure_trace(c);
                 if (rc2) { return rc2; }
@@ -2349,6 +2356,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     dev_free(c->d_twn);
     dev_free(c->d_scratch);
     dev_free(c->d_lines);
+    dev_free(c->d_lines_grp);
     dev_free(c->d_zstart);
     dev_free(c->d_zcount);
     dev_free(c->d_zoomed);
@@ -2436,6 +2444,13 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
     dev_free(c->d_lines);
     rc = dev_alloc(c, &c->d_lines, lines * (size_t)fft_size);
     if (rc) { return rc; }
+    dev_free(c->d_lines_grp);
+    c->d_lines_grp = nullptr;
+    c->zoom_grp = (m > 12) ? pass2_rows(m - m / 2) : 0;
+    if (c->zoom_grp) {
+        rc = dev_alloc(c, &c->d_lines_grp, lines * (size_t)(fft_size / c->zoom_grp));
+        if (rc) { return rc; }
+    }
     c->lines_cap = lines;
     c->fft_size = fft_size;
     c->fft_lg = m;
