@@ -246,9 +246,11 @@ def by_push_report(torch, capi, workloads, sr, nvfo):
         def deferred_pass(pinned=True):
             for _ in range(per_pass):
                 if pinned:
-                    ctx.push_host_ptr(ptr, B)
+                    ctx.push_host_ptr_async(ptr, B)  # page-locked source: the device fetches the block, one wait per pass
                 else:
                     ctx.push(xh)
+            if pinned:
+                ctx.push_wait()
             ctx.vfo_read_many(vids)
             ctx.fft_lines()
 
@@ -275,9 +277,9 @@ def by_push_report(torch, capi, workloads, sr, nvfo):
     except Exception as e:
         res["cpp_iqfrontend_run"] = {"error": repr(e)[:300]}
     res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push; deferred_read = "
-                   "sdrpp_set_deferred: pushes staged, one pass + one read per `deferred_pushes_per_pass` pushes, every push still its own reference block; "
+                   "sdrpp_set_deferred: pushes staged (pinned: sdrpp_push_pinned_async + one sdrpp_push_wait), one pass + one read per `deferred_pushes_per_pass` pushes, every push still its own reference block; "
                    "cpp_iqfrontend_run = tests/host_cpp/bench_blocks.cpp (SpeedTester-style source thread, one sink thread per VFO), buffered = 32-slot frame buffer whose "
-                   "backlog is processed as one deferred pass")
+                   "backlog is staged without per-block waits and processed as one deferred pass, results handed out by the worker and three helper threads")
     return res
 
 

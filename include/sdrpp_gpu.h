@@ -285,6 +285,13 @@ void sdrpp_host_free(void* p);
  * up at the reference's block size (sample_rate / 200), where a pass is launch-bound.  At most max_push samples can be staged:
  * a push beyond that returns SDRPP_ERR_INVALID (observe first).  Off (default): every push is processed at once. */
 int sdrpp_set_deferred(sdrpp_ctx* ctx, int on);
+/* Deferred mode, page-locked source (sdrpp_host_alloc): stage WITHOUT waiting for the copy — the device fetches the samples itself, the
+ * call returns at once.  The buffer must stay untouched until sdrpp_push_wait (all such copies have landed) or the next call that
+ * returns results of the pass (any *_read*, sdrpp_sync) has returned.  How a frame-buffer worker stages a whole backlog of blocks for the
+ * price of a few kernel launches and ONE wait (host/sdrpp_gpu_blocks.h: SampleFrameBuffer::worker, frame_buffer.h:76-98).  Outside
+ * deferred mode, or with memory that is not page-locked, it is sdrpp_push. */
+int sdrpp_push_pinned_async(sdrpp_ctx* ctx, const float* iq_pinned, int64_t count);
+int sdrpp_push_wait(sdrpp_ctx* ctx);
 int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed */
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */

@@ -159,6 +159,8 @@ def load():
     L.sdrpp_vfo_reset.argtypes = [vp, C.c_int]
     L.sdrpp_set_reference_block.argtypes = [vp, C.c_int]
     L.sdrpp_set_deferred.argtypes = [vp, C.c_int]
+    L.sdrpp_push_pinned_async.argtypes = [vp, c_float_p, C.c_int64]
+    L.sdrpp_push_wait.argtypes = [vp]
     L.sdrpp_host_alloc.restype = vp
     L.sdrpp_host_alloc.argtypes = [C.c_size_t]
     L.sdrpp_host_free.restype = None
@@ -195,7 +197,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
-    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -494,6 +496,13 @@ class Context:
     def push_host_ptr(self, host_ptr, count):
         """sdrpp_push from a raw host address (e.g. pinned memory the caller owns)."""
         self._chk(self.L.sdrpp_push(self.h, C.cast(C.c_void_p(host_ptr), c_float_p), int(count)))
+
+    def push_host_ptr_async(self, host_ptr, count):
+        """sdrpp_push_pinned_async: deferred mode, page-locked source, no wait for the copy (the buffer stays untouched until results are read)."""
+        self._chk(self.L.sdrpp_push_pinned_async(self.h, C.cast(C.c_void_p(host_ptr), c_float_p), int(count)))
+
+    def push_wait(self):
+        self._chk(self.L.sdrpp_push_wait(self.h))
 
     def push_int16(self, iq_i16):
         a = np.ascontiguousarray(iq_i16, dtype=np.int16)

@@ -146,6 +146,7 @@ struct sdrpp_ctx {
     bool land_used[2] = { false, false };
     int land_cur = 0;
     hipStream_t copy_stream = nullptr;
+    bool async_staged = false;     // sdrpp_push_pinned_async copies enqueued since the last pass
     hipEvent_t ev_copy = nullptr;
     // deferred processing (sdrpp_set_deferred): pushes are only staged; the next observing call processes them as ONE pass
     bool deferred = false;
@@ -3279,6 +3280,11 @@ static int landing_process(sdrpp_ctx* c, int64_t count, const std::vector<int>* 
 }
 int flush_pending(sdrpp_ctx* c) {
     if (c->pending == 0) { return SDRPP_OK; }
+    if (c->async_staged) {  // copy kernels of sdrpp_push_pinned_async still in flight: the pass waits for them on the device
+        c->async_staged = false;
+        HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    }
     const int64_t n = c->pending;
     c->pending = 0;  // cleared first: push_common's own helpers may call observing functions
     std::vector<int> ends;
@@ -3310,6 +3316,37 @@ int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
         return SDRPP_OK;
     }
     return landing_process(c, count, nullptr);
+}
+
+// Staging without a host wait: a copy KERNEL on the copy stream reads the page-locked (device-mapped) buffer over the bus; the pass that
+// follows waits for it on the device.  (hipMemcpyAsync is not used: see arena_commit.)
+__global__ __launch_bounds__(256) void pinned_stage_kernel(const float2* __restrict__ src, float2* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { dst[i] = src[i]; }
+}
+int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    void* dptr = nullptr;
+    if (!c->deferred || count <= 0 || !iq_pinned || hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
+        (void)hipGetLastError();
+        return sdrpp_push(c, iq_pinned, count);
+    }
+    int rc = push_args_ok(c, iq_pinned, count);
+    if (rc) { return rc; }
+    rc = landing_acquire(c, false);
+    if (rc) { return rc; }
+    float* land = c->iq_land[c->land_cur] + 2 * c->pending;
+    hipLaunchKernelGGL(pinned_stage_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 1023) / 1024, 128))), dim3(256), 0, c->copy_stream, (const float2*)dptr, (float2*)land,
+                       (long long)count);
+    c->async_staged = true;
+    c->pending += count;
+    c->pend_ends.push_back((int)c->pending);
+    return SDRPP_OK;
+}
+
+int sdrpp_push_wait(sdrpp_ctx* c) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (c->async_staged) { HIPCHK(c, hipStreamSynchronize(c->copy_stream)); }
+    return SDRPP_OK;
 }
 
 int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {

@@ -21,6 +21,7 @@
 #pragma once
 #include <atomic>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -149,6 +150,8 @@ public:
         for (auto& kv : vfos) { delete kv.second; }
         if (ctx) { sdrpp_destroy(ctx); }
         for (int i = 0; i < FRAME_SLOTS; i++) { sdrpp_host_free(frames[i]); }
+        sdrpp_host_free(gatherPin);
+        sdrpp_host_free(linesPin);
     }
 
     // iq_frontend.h:23.  decimRatio / dcBlocking configure the pre-processing chain (PowerDecimator -> DCBlocker -> Conjugate,
@@ -344,6 +347,22 @@ public:
     }
 
     sdrpp_ctx* context() { return ctx; }
+#ifdef SDRPP_GPU_BLOCKS_PROF
+    // diagnostic build of a host program: where the worker's wall time goes (microseconds, passes)
+    double profUs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    long profPasses = 0;
+    std::chrono::steady_clock::time_point profT;
+    void profReport() {
+        const double n = (double)std::max(1L, profPasses);
+        fprintf(stderr, "[sdrpp_gpu blocks prof] passes %ld, us per pass: wait for frames %.1f | stage (H2D) %.1f | process + line count %.1f | FFT lines out %.1f | bound IQ streams %.1f | VFO read (D2H) %.1f | VFO hand-off (memcpy + swap) %.1f\n",
+                profPasses, profUs[0] / n, profUs[1] / n, profUs[2] / n, profUs[3] / n, profUs[4] / n, profUs[5] / n, profUs[6] / n);
+    }
+#define SDRPP_BLOCKS_TICK(slot) { const auto _now = std::chrono::steady_clock::now(); profUs[slot] += std::chrono::duration<double, std::micro>(_now - profT).count(); profT = _now; }
+#define SDRPP_BLOCKS_TICK0() { profT = std::chrono::steady_clock::now(); }
+#else
+#define SDRPP_BLOCKS_TICK(slot)
+#define SDRPP_BLOCKS_TICK0()
+#endif
     static constexpr int64_t SDRPP_GPU_MAX_BLOCK = 1000000;
 
 protected:
@@ -351,6 +370,7 @@ protected:
     // frame_buffer.h:105-124)
     void doStart() override {
         stopFrameWorker = false;
+        helpers.start(3);
         workerThread = std::thread(&IQFrontEnd::workerLoop, this);
         frameThread = std::thread(&IQFrontEnd::frameWorker, this);
     }
@@ -364,6 +384,7 @@ protected:
         frameCnd.notify_all();
         if (workerThread.joinable()) { workerThread.join(); }
         if (frameThread.joinable()) { frameThread.join(); }
+        helpers.stop();
         for (auto& in : inputs) { in->clearReadStop(); }
         for (auto& out : outputs) { out->clearWriteStop(); }
     }
@@ -379,26 +400,34 @@ private:
     void frameWorker() {
         while (true) {
             int staged = 0, last = 0;
+            SDRPP_BLOCKS_TICK0()
             {
                 std::unique_lock<std::mutex> lck(frameMtx);
                 frameCnd.wait(lck, [this]() { return (((frameWrite - frameRead + FRAME_SLOTS) % FRAME_SLOTS) > 0) || stopFrameWorker; });
                 if (stopFrameWorker) { break; }
+                SDRPP_BLOCKS_TICK(0)
                 lck.unlock();
                 drainControl();  // may run a pass (a retune first processes what is staged): not under the producer's lock
                 lck.lock();
-                // under the lock, like the reference's copy into out.writeBuf: the copy to the device is complete when stage() returns
+                // under the lock, like the reference's copy into out.writeBuf.  The slots are page-locked: the device fetches the frames
+                // itself (sdrpp_push_pinned_async: a kernel launch per frame, no wait), ONE wait covers the whole backlog
                 while (((frameWrite - frameRead + FRAME_SLOTS) % FRAME_SLOTS) > 0) {
                     const int count = frameSizes[frameRead];
                     if (staged > 0 && ((int64_t)staged + count > SDRPP_GPU_MAX_BLOCK || !iqStreams.empty())) { break; }
                     if (!iqStreams.empty()) {  // the bound consumers need this block's samples after the lock is gone
                         tapCopy.assign(frames[frameRead], frames[frameRead] + count);
                     }
-                    if (stage(frames[frameRead], count) < 0) { return; }
+                    if (sdrpp_push_pinned_async(ctx, (const float*)frames[frameRead], count)) {
+                        fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
+                        return;
+                    }
                     frameRead = (frameRead + 1) % FRAME_SLOTS;
                     staged += count;
                     last = count;
                 }
+                if (sdrpp_push_wait(ctx)) { return; }
             }
+            SDRPP_BLOCKS_TICK(1)
             if (deliver(iqStreams.empty() ? nullptr : tapCopy.data(), last) < 0) { break; }
         }
     }
@@ -431,11 +460,27 @@ private:
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] processing failed: %s\n", sdrpp_last_error(ctx));
             return -1;
         }
-        for (int i = 0; i < nlines; i++) {
-            float* buf = _acquire ? _acquire(_fftCtx) : nullptr;  // may be NULL: still paired with release (iq_frontend.cpp:258-266)
-            if (buf) { sdrpp_fft_read(ctx, i, 1, buf, nullptr, nullptr); }
-            if (_release) { _release(_fftCtx); }
+        SDRPP_BLOCKS_TICK(2)
+        // all new lines with ONE device-to-host copy into page-locked staging; they are handed out below, next to the VFO blocks
+        if (nlines > 0 && _acquire) {
+            const size_t need = (size_t)nlines * (size_t)_fftSize;
+            if (need > linesCap) {
+                sdrpp_host_free(linesPin);
+                linesPin = (float*)sdrpp_host_alloc((need + (size_t)4 * _fftSize) * sizeof(float));
+                linesCap = linesPin ? need + (size_t)4 * _fftSize : 0;
+                if (!linesPin) { return -1; }
+            }
+            if (sdrpp_fft_read(ctx, 0, nlines, linesPin, nullptr, nullptr) < 0) { return -1; }
         }
+        std::vector<std::function<void()>> jobs;
+        jobs.emplace_back([this, nlines]() {  // the acquire / release protocol is sequential (one buffer in flight): one job for all lines
+            for (int i = 0; i < nlines; i++) {
+                float* buf = _acquire ? _acquire(_fftCtx) : nullptr;  // may be NULL: still paired with release (iq_frontend.cpp:258-266)
+                if (buf) { memcpy(buf, linesPin + (size_t)i * (size_t)_fftSize, (size_t)_fftSize * sizeof(float)); }
+                if (_release) { _release(_fftCtx); }
+            }
+        });
+        SDRPP_BLOCKS_TICK(3)
         if (!iqStreams.empty()) {  // Splitter::run: copy to every bound stream, then swap (blocking on the slowest consumer)
             const bool pre = _decimRatio > 1 || _dcBlocking || _invertIQ;
             for (auto* st : iqStreams) {
@@ -446,9 +491,13 @@ private:
                 if (n > 0 && !st->swap(n)) { return -1; }
             }
         }
+        SDRPP_BLOCKS_TICK(4)
         // every VFO's block with ONE device-to-host copy, then the per-stream hand-offs
         const int nv = (int)vfos.size();
-        if (nv == 0) { return count; }
+        if (nv == 0) {
+            helpers.run(std::move(jobs));
+            return count;
+        }
         ids.resize((size_t)nv);
         which.resize((size_t)nv);
         offs.resize((size_t)nv);
@@ -459,34 +508,58 @@ private:
             which[(size_t)k] = (kv.second->demod != Demod::RAW && kv.second->afOn) ? 2 : 0;
             k++;
         }
-        if (gather.size() < (size_t)2 * STREAM_BUFFER_SIZE) { gather.resize((size_t)2 * STREAM_BUFFER_SIZE); }
-        int total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
+        auto gatherRoom = [this](size_t floats) {
+            if (floats <= gatherCap) { return true; }
+            sdrpp_host_free(gatherPin);
+            gatherPin = (float*)sdrpp_host_alloc(floats * sizeof(float));
+            gatherCap = gatherPin ? floats : 0;
+            return gatherPin != nullptr;
+        };
+        if (!gatherRoom((size_t)2 * STREAM_BUFFER_SIZE)) { return -1; }
+        int total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gatherPin, (int64_t)(gatherCap / 2), offs.data(), cnts.data());
         if (total == SDRPP_ERR_INVALID) {  // more than the staging holds (very many VFOs at a high output rate): size it and retry once
             long long need = 0;
             for (auto& kv : vfos) { need += std::max(sdrpp_vfo_out_count(ctx, kv.second->id), kv.second->afOn ? sdrpp_vfo_af_count(ctx, kv.second->id) : 0); }
-            gather.resize((size_t)2 * (size_t)(need + 1024));
-            total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gather.data(), (int64_t)(gather.size() / 2), offs.data(), cnts.data());
+            if (!gatherRoom((size_t)2 * (size_t)(need + 1024))) { return -1; }
+            total = sdrpp_vfo_read_many(ctx, nv, ids.data(), which.data(), gatherPin, (int64_t)(gatherCap / 2), offs.data(), cnts.data());
         }
         if (total < 0) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] reading the VFO outputs failed: %s\n", sdrpp_last_error(ctx));
             return -1;
         }
-        k = 0;
-        for (auto& kv : vfos) {
-            RxVFO* v = kv.second;
-            const int n = cnts[(size_t)k];
-            const float* src = gather.data() + 2 * (size_t)offs[(size_t)k];
-            k++;
-            if (n <= 0) { continue; }
-            if (v->demod == Demod::RAW) {
-                memcpy(v->out.writeBuf, src, (size_t)n * sizeof(dsp::complex_t));
-                if (!v->out.swap(n)) { return -1; }
-            }
-            else {
-                memcpy(v->audio.writeBuf, src, (size_t)n * sizeof(dsp::stereo_t));
-                if (!v->audio.swap(n)) { return -1; }
+        SDRPP_BLOCKS_TICK(5)
+        // per-stream hand-offs (memcpy into the stream's write buffer + swap, which waits for the stream's reader), in three groups
+        std::atomic<bool> failed{ false };
+        {
+            std::vector<std::pair<RxVFO*, int>> order;
+            k = 0;
+            for (auto& kv : vfos) { order.emplace_back(kv.second, k++); }
+            const int groups = 3;
+            for (int g = 0; g < groups; g++) {
+                jobs.emplace_back([this, g, groups, order, &failed]() {
+                    for (size_t q = (size_t)g; q < order.size(); q += (size_t)groups) {
+                        RxVFO* v = order[q].first;
+                        const int n = cnts[(size_t)order[q].second];
+                        const float* src = gatherPin + 2 * (size_t)offs[(size_t)order[q].second];
+                        if (n <= 0) { continue; }
+                        if (v->demod == Demod::RAW) {
+                            memcpy(v->out.writeBuf, src, (size_t)n * sizeof(dsp::complex_t));
+                            if (!v->out.swap(n)) { failed = true; }
+                        }
+                        else {
+                            memcpy(v->audio.writeBuf, src, (size_t)n * sizeof(dsp::stereo_t));
+                            if (!v->audio.swap(n)) { failed = true; }
+                        }
+                    }
+                });
             }
         }
+        helpers.run(std::move(jobs));
+        if (failed) { return -1; }
+        SDRPP_BLOCKS_TICK(6)
+#ifdef SDRPP_GPU_BLOCKS_PROF
+        profPasses++;
+#endif
         return count;
     }
 
@@ -655,7 +728,68 @@ private:
     std::vector<dsp::stream<dsp::complex_t>*> iqStreams;
     std::vector<int> ids, which, cnts;
     std::vector<int64_t> offs;
-    std::vector<float> gather;
+    // page-locked staging of the two device-to-host copies of a pass (all VFO blocks; all new FFT lines)
+    float* gatherPin = nullptr;
+    size_t gatherCap = 0;  // floats
+    float* linesPin = nullptr;
+    size_t linesCap = 0;   // floats
+    // helpers of deliver(): the hand-offs of a pass (one memcpy + swap per VFO stream, one acquire / memcpy / release per FFT line) are
+    // host copies of several MB at the frame buffer's batch sizes; they run side by side
+    struct Helpers {
+        std::vector<std::thread> th;
+        std::mutex m;
+        std::condition_variable cv, done;
+        std::vector<std::function<void()>> jobs;
+        size_t next = 0;
+        int busy = 0;
+        bool quit = false;
+        void start(int n) {
+            quit = false;
+            for (int i = 0; i < n; i++) {
+                th.emplace_back([this]() {
+                    std::unique_lock<std::mutex> lck(m);
+                    while (true) {
+                        cv.wait(lck, [this]() { return quit || next < jobs.size(); });
+                        if (quit) { return; }
+                        auto job = std::move(jobs[next++]);
+                        busy++;
+                        lck.unlock();
+                        job();
+                        lck.lock();
+                        busy--;
+                        if (busy == 0 && next >= jobs.size()) { done.notify_all(); }
+                    }
+                });
+            }
+        }
+        void stop() {
+            {
+                std::lock_guard<std::mutex> lck(m);
+                quit = true;
+            }
+            cv.notify_all();
+            for (auto& t : th) { if (t.joinable()) { t.join(); } }
+            th.clear();
+        }
+        // run the jobs on the helpers AND the calling thread; returns when all are done
+        void run(std::vector<std::function<void()>>&& js) {
+            std::unique_lock<std::mutex> lck(m);
+            jobs = std::move(js);
+            next = 0;
+            cv.notify_all();
+            while (next < jobs.size()) {
+                auto job = std::move(jobs[next++]);
+                busy++;
+                lck.unlock();
+                job();
+                lck.lock();
+                busy--;
+            }
+            done.wait(lck, [this]() { return busy == 0 && next >= jobs.size(); });
+            jobs.clear();
+            next = 0;
+        }
+    } helpers;
     FFTWindow _fftWindow = NUTTALL;
     float* (*_acquire)(void*) = nullptr;
     void (*_release)(void*) = nullptr;

@@ -96,6 +96,9 @@ int main(int argc, char** argv) {
     fe.stop();
     for (auto* v : vfos) { v->audio.stopReader(); }
     for (auto& t : sinks) { t.join(); }
+#ifdef SDRPP_GPU_BLOCKS_PROF
+    fe.profReport();
+#endif
     // the frame buffer does not back-pressure its producer (an overrun drops a lap, like the reference's): count what came OUT
     const double processed = nvfo > 0 ? ((double)(a1 - a0) / nvfo) * (sr / 250000.0) : (double)(l1 - l0) * fftSize;
     printf("{\"block\": %d, \"buffered\": %s, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f}\n", block,

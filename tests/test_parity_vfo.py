@@ -11,6 +11,8 @@ FM and AM outputs do not see that drift; a product detector (SSB) and the raw IF
     arbitrary offsets, inside 1e-5 for any length (test_reference_rotator_mode_matches_the_reference);
   * closed-form NCO vs the pinned oracle at arbitrary offsets: what is left is the reference's own drift, bounded in
     test_ssb_arbitrary_offset_is_drift_limited."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -615,10 +617,11 @@ def test_deferred_pushes_equal_block_by_block(backend):
     x = x.astype(np.complex64)
     w = capi.design_fft_window(2, N)
 
-    def run(deferred, per_pass):
+    def run(deferred, per_pass, pinned_async=False):
         ctx = capi.Context(0, max_push=B * per_pass)
         ctx.fft_configure(N, N, 1000, w)
         ctx.set_deferred(deferred)
+        slots = [ctx.L.sdrpp_host_alloc(B * 8) for _ in range(per_pass)] if pinned_async else []
         vids = []
         for mode, off in specs:
             if_rate, bw = radio.RADIO_DEFAULTS.get(mode, (250e3, 250e3))
@@ -626,7 +629,13 @@ def test_deferred_pushes_equal_block_by_block(backend):
             vids.append(ctx.vfo_add(d, keep))
         lines, outs = [], [[] for _ in specs]
         for b in range(nblk):
-            ctx.push(x[b * B:(b + 1) * B])
+            if pinned_async:  # sdrpp_push_pinned_async: the device fetches the block itself, no wait per block (one slot per staged block)
+                C.memmove(slots[b % per_pass], x[b * B:(b + 1) * B].ctypes.data, B * 8)
+                ctx.push_host_ptr_async(slots[b % per_pass], B)
+                if (b + 1) % per_pass == 0:
+                    ctx.push_wait()
+            else:
+                ctx.push(x[b * B:(b + 1) * B])
             if deferred and (b + 1) % per_pass:
                 assert ctx.pending() == ((b % per_pass) + 1) * B
                 continue
@@ -640,11 +649,17 @@ def test_deferred_pushes_equal_block_by_block(backend):
             with pytest.raises(capi.SdrppError):
                 ctx.push(x[:B])
             assert ctx.pending() == per_pass * B
+        for p in slots:
+            ctx.L.sdrpp_host_free(p)
         ctx.close()
         return np.concatenate(lines), [np.concatenate(o) for o in outs]
 
     l0, o0 = run(False, 1)
     l1, o1 = run(True, 4)
+    l2, o2 = run(True, 4, pinned_async=True)
+    assert np.array_equal(l1, l2)
+    for a, b in zip(o1, o2):
+        assert np.array_equal(a, b)
     assert l0.shape == l1.shape and l0.shape[0] == n // (N + 1000) and np.array_equal(l0, l1)
     for (mode, _), a, b in zip(specs, o0, o1):
         assert a.shape == b.shape and len(a) > 100, mode
