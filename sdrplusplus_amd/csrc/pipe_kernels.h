@@ -42,6 +42,7 @@ struct PipeJob {
 // the next one, [3] own epilogue work before the ring + waiting for ring space, [4] writing outputs + publishing, [5] macro tiles,
 // [6] wavefront lifetime, [7] wavefronts
 __device__ unsigned long long g_pipe_prof[4][8];
+__device__ unsigned long long g_pipe_clock[4] = { 0ull, 0ull, ~0ull, 0ull };  // [2] min / [3] max wavefront lifetime (cycles)  // summed wavefront lifetimes in shader-clock cycles and in 100 MHz wall-clock ticks: the clock the chip held
 #endif
 
 __device__ __forceinline__ int pipe_pmod(int a, int m) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
     const int keep = ROLE < 3 ? Jp->keep[ROLE < 3 ? ROLE : 0] : 0;
 
     // ---- stage 0: window from HBM through registers, one macro tile ahead (as vfo_toep_kernel's interleaved path) ----
-    constexpr int PF4 = 9;
+    constexpr int PF4 = (G == 1) ? 5 : 9;  // sample PAIRS per lane: every unused one still costs its predicated load / select / LDS write
     const int npair = (span + 1) >> 1;
     float4 pf4[ROLE == 0 ? PF4 : 1];
     auto fetch = [&](int mt) {
@@ -204,6 +205,7 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
 #ifdef SDRPP_TOEP_PROF
     long long tp_acc[5] = { 0, 0, 0, 0, 0 };
     const long long tp_birth = TOEP_TICK();
+    const long long tp_birth_wall = (long long)wall_clock64();
 #endif
     for (int m = tb; m < te; m++) {
         const int obase = m * omt;
@@ -444,6 +446,10 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
         atomicAdd(&g_pipe_prof[ROLE][5], (unsigned long long)(te - tb));
         atomicAdd(&g_pipe_prof[ROLE][6], (unsigned long long)(TOEP_TICK() - tp_birth));
         atomicAdd(&g_pipe_prof[ROLE][7], 1ull);
+        atomicAdd(&g_pipe_clock[0], (unsigned long long)(TOEP_TICK() - tp_birth));
+        atomicAdd(&g_pipe_clock[1], (unsigned long long)((long long)wall_clock64() - tp_birth_wall));
+        atomicMin(&g_pipe_clock[2], (unsigned long long)(TOEP_TICK() - tp_birth));
+        atomicMax(&g_pipe_clock[3], (unsigned long long)(TOEP_TICK() - tp_birth));
     }
 #endif
     // nobody waits for a wavefront that has left

@@ -960,7 +960,7 @@ bool pipe_layout_try(PipeJob& J, int fifo_tiles, size_t* lds_bytes) {
         span[s] = W[s] - J.st[s].s_in + 4 * J.st[s].nsteps;
         omt[s] = G * 16 * J.st[s].rows;
     }
-    if (((span[0] + 1) >> 1) > 9 * 64) { return false; }  // stage 0's window is register-staged: nine sample pairs per lane
+    if (((span[0] + 1) >> 1) > (G == 1 ? 5 : 9) * 64) { return false; }  // stage 0's window is register-staged: five (G = 1) / nine sample pairs per lane
     J.win_off = take(2 * ((span[0] + 8) & ~3));
     J.zero_lo = off;
     for (int i = 0; i < 3; i++) {
@@ -2324,6 +2324,11 @@ int sdrpp_destroy(sdrpp_ctx* c) {
             }
             unsigned long long z[4][8] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_pipe_prof), z, sizeof(z));
+            unsigned long long ck[4] = { 0, 0, 0, 0 };
+            if (hipMemcpyFromSymbol(ck, HIP_SYMBOL(sdrpp_k::g_pipe_clock), sizeof(ck)) == hipSuccess && ck[1]) {
+                fprintf(stderr, "[sdrpp pipe prof] shader clock while the pipelined kernel ran: %.0f MHz (s_memtime cycles per 100 MHz s_memrealtime tick); wavefront lifetime min %llu max %llu cycles (all launches)\n",
+                        100.0 * (double)ck[0] / (double)ck[1], ck[2], ck[3]);
+            }
         }
     }
 #endif
