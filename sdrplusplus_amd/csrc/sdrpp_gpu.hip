@@ -947,7 +947,8 @@ void launch_toep(sdrpp_ctx* c, std::vector<ToepJob>& jobs, ToepJob* d_jobs, cons
 
 // ---- pipelined FM back end (vfo_pipe_kernel) ----
 constexpr int kPipeG = 1;    // groups of 16 tiles per macro tile: one keeps a job's LDS at ~30 KB, five workgroups per CU
-constexpr int kPipeBpc = 5;  // workgroups per CU the kernel is built for (launch bounds, LDS share)
+constexpr int kPipeBpc = 5;     // workgroups per CU the kernel is built for (launch bounds; jobs of ~30 KB)
+constexpr int kPipeBpcMin = 3;  // longer filters (NFM's 300-tap channel / audio filters: ~38 KB) run with fewer workgroups per CU
 // LDS layout of one job; false = does not fit / stage 0 not register-staged -> the VFO keeps its separate launches
 bool pipe_layout_try(PipeJob& J, int fifo_tiles, size_t* lds_bytes) {
     const int G = kPipeG;
@@ -986,18 +987,19 @@ bool pipe_layout_try(PipeJob& J, int fifo_tiles, size_t* lds_bytes) {
     J.zero_hi = off;
     J.flag_off = take(8);
     *lds_bytes = (size_t)off * sizeof(float);
-    return *lds_bytes <= (size_t)(160 * 1024) / kPipeBpc;
+    return *lds_bytes <= (size_t)(160 * 1024) / kPipeBpcMin;
 }
 bool pipe_layout(PipeJob& J, size_t* lds_bytes) { return pipe_layout_try(J, 2, lds_bytes) || pipe_layout_try(J, 1, lds_bytes); }
 // Segments per VFO, 0 = this push is better served by the separate launches.  A segment pays one warm-up macro tile per stage and the
 // pipeline's fill: with fewer than ~12 last-stage macro tiles per segment of a full grid the four launches win (measured: 1 M-sample
 // pushes of the 32-VFO bank, 2.6 tiles per segment, 14 % slower) — unless the push is so small that it is launch-bound anyway.
-int pipe_segments(const std::vector<PipeJob>& pipes, int forced) {
+int pipe_segments(const std::vector<PipeJob>& pipes, int forced, size_t lds) {
     if (pipes.empty()) { return 0; }
+    const int bpc = std::max(kPipeBpcMin, std::min(kPipeBpc, (int)((size_t)(160 * 1024) / std::max<size_t>(lds, 1))));
     int max_nmt = 1;
     for (auto& pj : pipes) { max_nmt = std::max(max_nmt, (pj.st[3].nout + kPipeG * 16 * pj.st[3].rows - 1) / (kPipeG * 16 * pj.st[3].rows)); }
     if (forced >= 2) { return std::min(forced, max_nmt); }
-    const int s_full = (256 * kPipeBpc + (int)pipes.size() - 1) / (int)pipes.size();
+    const int s_full = (256 * bpc + (int)pipes.size() - 1) / (int)pipes.size();
     if (max_nmt >= 12 * s_full) { return s_full; }
     if (max_nmt <= 16) { return 1; }
     return 0;
@@ -1552,7 +1554,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     RetuneJob* d_retune = arena_push(c, retune);
     const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
     if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!ssbx.empty() && !d_ssbx) || (!retune.empty() && !d_retune)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    const int pipe_seg = pipe_segments(pipes, c->pipe_on);
+    const int pipe_seg = pipe_segments(pipes, c->pipe_on, pipe_lds);
     if (!pipes.empty() && pipe_seg == 0) {  // not this push: the same four jobs go to the separate launches
         for (auto& pj : pipes) {
             for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {

@@ -18,6 +18,8 @@ plan = workloads.vfo_plan(4, nv)
 cuts = [150000, 3, 100003]
 cuts.append(n - sum(cuts))
 ctx = capi.Context(0, max_push=max(cuts))
+if os.environ.get("SDRPP_TOOL_PIPELINE"):  # 0: one launch per back-end stage, >= 2: forced segment count
+    ctx.set_backend_pipeline(int(os.environ["SDRPP_TOOL_PIPELINE"]))
 vids = []
 for mode, if_rate, bw, centre, _ in plan:
     d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode)
@@ -30,5 +32,5 @@ for c in cuts:
     for v in vids:
         h.update(np.ascontiguousarray(ctx.vfo_read_if(v)).tobytes())
         h.update(np.ascontiguousarray(ctx.vfo_read(v)).tobytes())
-print({k: v for k, v in os.environ.items() if k.startswith("SDRPP_GPU_")}, nv, "VFOs", h.hexdigest()[:24])
+print({k: v for k, v in os.environ.items() if k.startswith("SDRPP_GPU_") or k.startswith("SDRPP_TOOL_")}, nv, "VFOs", h.hexdigest()[:24])
 ctx.close()
