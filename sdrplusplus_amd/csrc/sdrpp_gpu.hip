@@ -2146,7 +2146,13 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
     }
     c->stream = c->own_stream;
     c->launch_stream = c->stream;
-    if (hipStreamCreateWithFlags(&c->fft_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_fork) != hipSuccess ||
+    {   // the FFT branch's stream gets the LOWEST queue priority: it is the filler behind the VFO bank, whose launches form the critical
+        // path (measured on the headline step: 0.686-0.693 ms against 0.704-0.706 at equal priority and 0.699-0.701 with the FFT favoured)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least (numerically largest), hi = greatest
+        if (hipStreamCreateWithPriority(&c->fft_stream, hipStreamNonBlocking, lo) != hipSuccess) { c->fft_stream = nullptr; }
+    }
+    if ((!c->fft_stream && hipStreamCreateWithFlags(&c->fft_stream, hipStreamNonBlocking) != hipSuccess) || hipEventCreate(&c->ev_fork) != hipSuccess ||
         hipEventCreate(&c->ev_join) != hipSuccess) {
         sdrpp_destroy(c);
         return SDRPP_ERR_NO_DEVICE;

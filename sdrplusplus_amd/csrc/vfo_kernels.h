@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
         tile_phasor(tb);
         if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop
         wave_sync();
+        wave_prio_low();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
         if constexpr (KS > 0) {
             // software pipeline: the LDS reads of pair p + 2 are issued (and fenced) two pairs = four matrix instructions ahead of
@@ -1290,6 +1291,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
             }
         }
         // ---- NCO: tile phasor x in-tile advance, then coalesced stores (lanes = consecutive outputs of one VFO) ----
+        wave_prio_high();  // outside the matrix loop the wavefront's vector instructions go first (1 % on the launch: they wait ~30 cycles each behind the neighbours' v_mfma's otherwise)
         {
             const int j0 = tb * tile;
             const bool live = j0 + jl < job.nout;
