@@ -660,6 +660,22 @@ def test_deferred_pushes_equal_block_by_block(backend):
     assert np.array_equal(l1, l2)
     for a, b in zip(o1, o2):
         assert np.array_equal(a, b)
+    # sdrpp_push_pinned_async degrades to sdrpp_push where it cannot do better: outside deferred mode, and for memory that is not page-locked
+    ctx = capi.Context(0, max_push=B)
+    ctx.fft_configure(N, N, 1000, w)
+    if_rate, bw = radio.RADIO_DEFAULTS.get("WFM", (250e3, 250e3))
+    d, keep = radio.vfo_desc(sr, if_rate, bw, 1.35e6, "WFM")
+    vid = ctx.vfo_add(d, keep)
+    got = []
+    for b in range(nblk):
+        blk = np.ascontiguousarray(x[b * B:(b + 1) * B])
+        if b == nblk // 2:
+            ctx.set_deferred(True)  # second half: deferred, from PAGEABLE memory
+        ctx.push_host_ptr_async(blk.ctypes.data, B)
+        ctx.push_wait()
+        got.append(ctx.vfo_read(vid).copy())
+    ctx.close()
+    assert np.max(np.abs(np.concatenate(got) - o0[0])) < 5e-6 * max(1.0, float(np.max(np.abs(o0[0]))))
     assert l0.shape == l1.shape and l0.shape[0] == n // (N + 1000) and np.array_equal(l0, l1)
     for (mode, _), a, b in zip(specs, o0, o1):
         assert a.shape == b.shape and len(a) > 100, mode
