@@ -3322,13 +3322,18 @@ int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     float* land = c->iq_land[c->land_cur] + 2 * c->pending;
     HIPCHK(c, hipMemcpyAsync(land, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
     HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
-    HIPCHK(c, hipEventSynchronize(c->ev_copy));  // the caller's buffer is free again; the kernels of the previous pass keep running meanwhile
     if (c->deferred) {
+        HIPCHK(c, hipEventSynchronize(c->ev_copy));  // the caller's buffer is free again; the kernels of the previous pass keep running meanwhile
         c->pending += count;
         c->pend_ends.push_back((int)c->pending);
         return SDRPP_OK;
     }
-    return landing_process(c, count, nullptr);
+    // the pass is enqueued behind the copy ON THE DEVICE while the copy runs (planning + launches take longer than the copy of a
+    // reference-sized block), and only then does the host wait for the copy: the caller's buffer is free on return, as before
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    rc = landing_process(c, count, nullptr);
+    HIPCHK(c, hipEventSynchronize(c->ev_copy));
+    return rc;
 }
 
 // Staging without a host wait: a copy KERNEL on the copy stream reads the page-locked (device-mapped) buffer over the bus; the pass that
