@@ -230,6 +230,10 @@ int sdrpp_abi_sizeof_af_desc(void);
  *   SampleStreamCompressor::process builds it (sample_stream_compressor.h:30-62): [u16 0][u16 pcm_type][f32 scaler][data], scaler =
  *   the largest VALUE of the block, data scaled by 128 / scaler or 32768 / scaler; returns bytes (0 for an empty block). */
 int sdrpp_vfo_read_pcm(sdrpp_ctx* ctx, int id, int which, int pcm_type, float scale, void* dst_host, int max_frames);
+/* The same conversion for the pre-processed wideband IQ of the most recent push (sdrpp_preproc_read's samples): what the recorder's baseband
+ * mode writes from its bindIQStream consumer (recorder/src/main.cpp:209, 528-530 -> wav::Writer::write, utils/wav.cpp:158-167); returns
+ * complex samples (2 values each). */
+int sdrpp_preproc_read_pcm(sdrpp_ctx* ctx, int pcm_type, float scale, void* dst_host, int max_samples);
 int sdrpp_vfo_read_compressed(sdrpp_ctx* ctx, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes);
 
 /* ---- WaterFall display state around the raw-line history (core/src/gui/widgets/waterfall.cpp) ---------------

@@ -119,6 +119,7 @@ def load():
     L.sdrpp_design_deemphasis_alpha.restype = C.c_float
     L.sdrpp_design_deemphasis_alpha.argtypes = [C.c_double, C.c_double]
     L.sdrpp_vfo_read_pcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int]
+    L.sdrpp_preproc_read_pcm.argtypes = [vp, C.c_int, C.c_float, vp, C.c_int]
     L.sdrpp_vfo_read_compressed.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int]
     L.sdrpp_wf_configure.argtypes = [vp, C.c_int]
     L.sdrpp_wf_set_smoothing.argtypes = [vp, C.c_int, C.c_float]
@@ -190,7 +191,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_create", "sdrpp_destroy", "sdrpp_strerror", "sdrpp_last_error", "sdrpp_set_stream", "sdrpp_sync", "sdrpp_abi_version", "sdrpp_device_info",
     "sdrpp_design_low_pass", "sdrpp_design_high_pass", "sdrpp_design_fft_window", "sdrpp_design_reshape_params",
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
-    "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed",
+    "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed", "sdrpp_preproc_read_pcm",
     "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster", "sdrpp_wf_signal_info",
     "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
@@ -457,6 +458,13 @@ class Context:
         n = self._chk(self.L.sdrpp_preproc_out_count(self.h))
         out = np.empty(max(n, 1), dtype=np.complex64)
         got = self._chk(self.L.sdrpp_preproc_read(self.h, out.view(np.float32).ctypes.data_as(c_float_p), n))
+        return out[:got]
+
+    def preproc_read_pcm(self, pcm_type, scale, max_samples=None):
+        """Pre-processed wideband IQ of the most recent push as int16 (pcm_type 1) / int8 (0) pairs, converted on the device."""
+        n = self._chk(self.L.sdrpp_preproc_out_count(self.h)) if max_samples is None else int(max_samples)
+        out = np.empty((max(n, 1), 2), dtype=np.int16 if pcm_type == 1 else np.int8)
+        got = self._chk(self.L.sdrpp_preproc_read_pcm(self.h, int(pcm_type), float(scale), out.ctypes.data_as(C.c_void_p), n))
         return out[:got]
 
     def vfo_set_af(self, vid, af_desc, keepalive=None):

@@ -3072,6 +3072,26 @@ int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scal
     return n;
 }
 
+// the pre-processed wideband IQ of the most recent push as int16 / int8: what the recorder's baseband mode writes (bindIQStream consumer ->
+// wav::Writer::write, utils/wav.cpp:158-167), converted on the device so that the copy to the host carries 4 (2) bytes per sample
+int sdrpp_preproc_read_pcm(sdrpp_ctx* c, int pcm_type, float scale, void* dst_host, int max_samples) {
+    if (!c || !dst_host || max_samples < 0 || (pcm_type != 0 && pcm_type != 1)) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
+    if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
+    const int n = std::min(max_samples, c->pre.last_n);
+    if (n == 0) { return 0; }
+    const long long nv = (long long)n * 2;
+    const size_t esz = pcm_type == 1 ? 2 : 1;
+    int rc = pack_scratch(c, (size_t)nv * esz);
+    if (rc) { return rc; }
+    const dim3 grid((unsigned)std::min<long long>((nv + 255) / 256, 4096));
+    if (pcm_type == 1) { hipLaunchKernelGGL(pack_convert_kernel<int16_t>, grid, dim3(256), 0, c->stream, (const float*)c->pre.last, scale, nv, (int16_t*)c->d_pack); }
+    else { hipLaunchKernelGGL(pack_convert_kernel<int8_t>, grid, dim3(256), 0, c->stream, (const float*)c->pre.last, scale, nv, (int8_t*)c->d_pack); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst_host, c->d_pack, (size_t)nv * esz, hipMemcpyDeviceToHost));
+    return n;
+}
+
 int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes) {
     if (!c || !dst_host || pcm_type < 0 || pcm_type > 2) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);

@@ -191,6 +191,16 @@ def test_preproc_chain(backend, ratio, dc, conj):
         ref = opre.process(blk)
         got = ctx.preproc_read()
         assert got.shape == ref.shape
+        if len(got):  # the recorder's baseband format (int16, utils/wav.cpp:166) and int8, converted on the device: bit-exact w.r.t. the float read
+            import ctypes as C
+            o = S.oracle()
+            f = np.ascontiguousarray(got).view(np.float32)
+            for pcm, scale, dt, conv in ((1, 32767.0, np.int16, o.orc_convert_16i), (0, 100.0, np.int8, o.orc_convert_8i)):
+                want = np.empty(len(f), dt)
+                conv.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_int, C.c_void_p]
+                conv(f.ctypes.data_as(C.POINTER(C.c_float)), scale, len(f), want.ctypes.data_as(C.c_void_p))
+                packed = ctx.preproc_read_pcm(pcm, scale)
+                assert packed.shape == (len(got), 2) and np.array_equal(packed.reshape(-1), want)
         if len(ref):
             worst_pre = max(worst_pre, rms(got - ref) / max(rms(ref), 1e-9))
         # downstream: oracle fed with the ORACLE's pre-processed stream (the reference graph), device fed by its own
