@@ -76,7 +76,10 @@ __device__ __forceinline__ void wave_sync() {
 // ordering there is to it; a waiting wavefront sleeps 64 cycles between looks so that it does not take issue slots from the others.
 __device__ __forceinline__ void lds_flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_flag_wait_ge(int* f, int need) {
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) { __builtin_amdgcn_s_sleep(1); }
+#ifndef SDRPP_FLAG_SLEEP
+#define SDRPP_FLAG_SLEEP 8  // 512 cycles between looks (1 -> 8: 2 % on the pipelined launch: every look is a vector compare and an LDS read taken from the matrix loops)
+#endif
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) { __builtin_amdgcn_s_sleep(SDRPP_FLAG_SLEEP); }
 }
 
 // Issue priority of this wavefront among the wavefronts of its SIMD (s_setprio 0..3)
