@@ -478,14 +478,23 @@ __global__ __launch_bounds__(256, 5) void vfo_pipe_kernel(const PipeJob* __restr
     int t0[4], t1[4];
     t0[3] = (int)((long long)nmt[3] * (long long)blockIdx.x / (long long)gridDim.x);
     t1[3] = (int)((long long)nmt[3] * (long long)(blockIdx.x + 1) / (long long)gridDim.x);
-    if (t1[3] <= t0[3]) { return; }
+    // The LAST segment takes every stage to the end of its stream whatever the stage behind it consumes in this push: a stage's trailing
+    // outputs (a decimator's odd sample, up to M - 1 resampler inputs, everything when a tiny push gives the later stages nothing to do)
+    // are the next push's filter history and must reach its stream.
+    const bool last_seg = blockIdx.x + 1 == gridDim.x;
+    if (t1[3] <= t0[3] && !last_seg) { return; }
 #pragma unroll
     for (int s = 3; s >= 1; s--) {
-        const int lo = b0[s] + t0[s] * W[s] - (s == 3 ? 1 : 0);  // (the discriminator also needs the sample in front)
-        const int hi = b0[s] + (t1[s] - 1) * W[s] + span[s];
-        int a = lo > 0 ? lo / omt[s - 1] : 0;
-        int b = hi > 0 ? (hi + omt[s - 1] - 1) / omt[s - 1] : 0;
+        int a = 0, b = 0;
+        if (t1[s] > t0[s]) {
+            const int lo = b0[s] + t0[s] * W[s] - (s == 3 ? 1 : 0);  // (the discriminator also needs the sample in front)
+            const int hi = b0[s] + (t1[s] - 1) * W[s] + span[s];
+            a = lo > 0 ? lo / omt[s - 1] : 0;
+            b = hi > 0 ? (hi + omt[s - 1] - 1) / omt[s - 1] : 0;
+        }
+        else { b = nmt[s - 1]; }  // nothing to do behind (a tiny push; only the last segment gets here): the whole stage
         b = b < nmt[s - 1] ? b : nmt[s - 1];
+        if (last_seg) { b = nmt[s - 1]; }
         a = a < b ? a : b;
         t0[s - 1] = a;
         t1[s - 1] = b;

@@ -731,3 +731,41 @@ def test_pipelined_fm_back_end_is_bit_identical(backend):
             assert a1[k].shape == a0[k].shape and i1[k].shape == i0[k].shape and len(a0[k]) > 500
             assert np.array_equal(a1[k].view(np.uint32), a0[k].view(np.uint32)), (mode, m)
             assert np.array_equal(i1[k].view(np.uint32), i0[k].view(np.uint32)), (mode, m)
+
+
+def test_pipelined_fm_back_end_tiny_ragged_pushes(backend):
+    """The pipelined FM back end over hundreds of tiny pushes of random length (1 … 300 samples: pushes that give a stage an output or two
+    and the stage behind it none, outputs that end exactly on a macro-tile boundary, empty pushes) — every sample a stage produces must reach
+    its stream (the next push needs it as filter history) whether or not a later stage consumes it in this push: bit-identical to one
+    launch per stage."""
+    from sdrplusplus_amd import capi, radio
+
+    sr = 10e6
+    r = np.random.default_rng(23)
+    cuts = [int(c) for c in r.integers(0, 300, 400)] + [40000] + [int(c) for c in r.integers(1, 120, 150)]
+    n = sum(cuts)
+    t = np.arange(n)
+    x = ((r.standard_normal(n) + 1j * r.standard_normal(n)) * 0.05 + 0.5 * np.exp(2j * np.pi * (1.35e6 / sr * t + 3.0 * np.sin(2 * np.pi * 3e3 / sr * t)))).astype(np.complex64)
+
+    def run(mode):
+        ctx = capi.Context(0, max_push=max(cuts))
+        ctx.set_backend_pipeline(mode)
+        if_rate, bw = radio.RADIO_DEFAULTS.get("WFM", (250e3, 250e3))
+        d, keep = radio.vfo_desc(sr, if_rate, bw, 1.35e6, "WFM")
+        vid = ctx.vfo_add(d, keep)
+        pos, audio, ifs = 0, [], []
+        for c in cuts:
+            ctx.push(x[pos:pos + c])
+            pos += c
+            audio.append(ctx.vfo_read(vid))
+            ifs.append(ctx.vfo_read_if(vid))
+        ctx.close()
+        return np.concatenate(audio), np.concatenate(ifs)
+
+    a0, i0 = run(0)
+    assert len(a0) > 2000
+    for mode in (1, 2):
+        a1, i1 = run(mode)
+        assert a1.shape == a0.shape and i1.shape == i0.shape
+        assert np.array_equal(a1.view(np.uint32), a0.view(np.uint32)), mode
+        assert np.array_equal(i1.view(np.uint32), i0.view(np.uint32)), mode
