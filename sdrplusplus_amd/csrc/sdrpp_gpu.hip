@@ -1873,9 +1873,14 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         const int iq_elems = carry[0].need * carry[0].width;
         int mx = 0;
         for (size_t k = 1; k < carry.size(); k++) { mx = std::max(mx, carry[k].need * carry[k].width); }
-        if (iq_elems > 16384 && carry.size() > 1) {
+        if (iq_elems > 16384 && carry.size() > 1 && iq_elems > 128 * 1024 * 2) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
             launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
             launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)carry.size() - 1), dim3(256), 0, (const CarryJob*)(d_carry + 1));
+        }
+        else if (iq_elems > 16384 && carry.size() > 1) {
+            // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
+            // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
+            launch(c, carry_kernel, dim3(128, (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
         }
         else {
             mx = std::max(mx, iq_elems);
