@@ -2036,7 +2036,14 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
     if (rc) { return rc; }
     IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
     // fork: the FFT branch goes to its own stream and overlaps the VFO bank; both only read the IQ buffers
-    const bool fork = c->fft_on && !c->vfos.empty();
+    // (a push that completes no frame launches nothing on the FFT branch: no fork / join either — each costs the main stream 5-9 us, and at
+    // the reference's block size every fourth push of a 65 536-point waterfall is such a push)
+    bool fft_work = false;
+    if (c->fft_on) {
+        const int64_t P = (int64_t)c->nz + c->skip;
+        fft_work = (c->fft_pos + count) - c->nz - c->fft_next * P >= 0;
+    }
+    const bool fork = fft_work && !c->vfos.empty();
     if (fork) {
         HostScope hs("fork events");
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
