@@ -1001,7 +1001,7 @@ int pipe_segments(const std::vector<PipeJob>& pipes, int forced, size_t lds) {
     if (forced >= 2) { return std::min(forced, max_nmt); }
     const int s_full = (256 * bpc + (int)pipes.size() - 1) / (int)pipes.size();
     if (max_nmt >= 12 * s_full) { return s_full; }
-    if (max_nmt <= 16) { return 1; }
+    if (max_nmt <= 16) { return std::max(1, (max_nmt + 1) / 2); }  // two macro tiles per workgroup: the chain of hand-offs is what a small push waits for (B = 50 000: 53 us per push with one segment, 48.5 with three)
     return 0;
 }
 

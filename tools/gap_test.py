@@ -5,6 +5,8 @@ from sdrplusplus_amd import capi, radio, workloads
 push = 50000
 for fft in (True, False):
     ctx = capi.Context(0, max_push=push)
+    if os.environ.get("SDRPP_TOOL_PIPELINE"):
+        ctx.set_backend_pipeline(int(os.environ["SDRPP_TOOL_PIPELINE"]))
     if fft:
         workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=32)
     else:
