@@ -2,7 +2,7 @@
 # Round-2 GPU call 3: full -m gpu suite, bench lines for cfg 3 (default, with by_push + cpu_baseline), cfg 2, cfg 4, host-side enqueue profile
 # at the reference block size, rocprofv3 kernel trace + PMC passes of the default workload.
 set -u
-O=gpurun_out/r02k
+O=gpurun_out/r02m
 mkdir -p $O
 export TMPDIR=/tmp
 ( time timeout 900 python -m pytest tests/ -x -q -m gpu -s --durations=8 ) > $O/pytest_gpu.log 2>&1
@@ -24,8 +24,8 @@ done
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $R/$O/pmc_SQ -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-by-push > $R/$O/pmc_SQ.log 2>&1
 cd $R
 T=$(find $O/trace -name "*.db" | head -1); F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1); Q=$(find $O/pmc_SQ -name "*.db" | head -1)
-python tools/rocpd_summary.py $T --pmc $F $W $Q --out $O/r02k_cfg3_16Mi.md --json $O/pmc_traffic.json --title "round 2, final state (pipelined FM back end, doZoom groups, FFT branch at low stream priority), cfg 3, 2^24 samples per step" --meta push=16777216 cfg=3 nvfo=32 2>&1 | tail -3
-head -30 $O/r02k_cfg3_16Mi.md
+python tools/rocpd_summary.py $T --pmc $F $W $Q --out $O/r02m_cfg3_16Mi.md --json $O/pmc_traffic.json --title "round 2, final state (pipelined FM back end, doZoom groups, FFT branch at low stream priority), cfg 3, 2^24 samples per step" --meta push=16777216 cfg=3 nvfo=32 2>&1 | tail -3
+head -30 $O/r02m_cfg3_16Mi.md
 find $O -name "*.db" -size +8M -delete
 ls -la $O
 echo "== VFO bank alone: pipelined back end on / off"
