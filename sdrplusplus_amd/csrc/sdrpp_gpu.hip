@@ -234,6 +234,7 @@ struct sdrpp_ctx {
     int ref_block = 0;             // 0: one push = one reference block
     int nco_exact = 0;             // 1: the reference's float rotator recursion instead of the closed-form NCO
     int pipe_on = 1;               // FM back ends as one pipelined launch where that pays (sdrpp_set_backend_pipeline)
+    bool pipe_launched = false;    // since the last sdrpp_sync (which then looks at the kernels' timeout counter)
     std::vector<int> vfo_bounds;   // reference-block ends (cumulative sample counts) of the current push at the VFO bank's input
 
     // VFOs
@@ -1782,6 +1783,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     if (!pipes.empty()) {
         FamilyTimer t(c, F_PIPE);
+        c->pipe_launched = true;
         launch(c, vfo_pipe_kernel<kPipeG>, dim3((unsigned)pipe_seg, (unsigned)pipes.size()), dim3(256), pipe_lds, (const PipeJob*)d_pipes);
     }
     if (!t_poly.empty()) {
@@ -2410,6 +2412,15 @@ int sdrpp_sync(sdrpp_ctx* c) {
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pipe_launched) {  // a pipelined launch whose wavefronts gave up waiting for each other (never seen; a hang would be worse)
+        c->pipe_launched = false;
+        int n = 0;
+        if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(sdrpp_k::g_flag_timeouts), sizeof(int)) == hipSuccess && n != 0) {
+            const int zero = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_flag_timeouts), &zero, sizeof(int));
+            return fail(c, SDRPP_ERR_HIP, "pipelined back end: %d wavefront waits timed out (results of the last pushes are invalid)", n);
+        }
+    }
     return SDRPP_OK;
 }
 

@@ -17,6 +17,7 @@ static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = 
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline void lds_flag_set(int* f, int v) { *(volatile int*)f = v; }
+static int g_flag_timeouts = 0;
 static inline void lds_flag_wait_ge(int* f, int need) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile
 static inline void wave_prio_high() {}
 static inline void wave_prio_low() {}

@@ -163,6 +163,9 @@ typedef struct hipemuEvent { double t; }* hipEvent_t;
 #define hipErrorNoDevice 100
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipStreamNonBlocking 1
+#define HIP_SYMBOL(x) (x)
+template <class T> static inline int hipMemcpyFromSymbol(void* dst, const T& sym, size_t n) { memcpy(dst, &sym, n); return 0; }
+template <class T> static inline int hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy(&sym, src, n); return 0; }
 #define hipHostMallocDefault 0
 #define hipHostMallocMapped 2
 static inline int hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
