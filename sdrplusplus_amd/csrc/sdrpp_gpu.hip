@@ -3278,6 +3278,14 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
         if (rc) { return rc; }
         c->gather_cap = (size_t)total + 4096;
     }
+    if (jobs.size() <= SDRPP_GATHER_INLINE) {
+        GatherArgs ga{};
+        for (size_t k = 0; k < jobs.size(); k++) { ga.j[k] = jobs[k]; }
+        hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)jobs.size()), dim3(256), 0, c->stream, ga, c->d_gather);
+        HIPCHK(c, hipMemcpyAsync(dst_host, c->d_gather, (size_t)total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return (int)std::min<int64_t>(total, 0x7fffffff);
+    }
     if ((int)jobs.size() > c->gather_jobs_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         dev_free(c->d_gather_jobs);

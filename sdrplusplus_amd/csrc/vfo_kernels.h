@@ -759,6 +759,14 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherJob* __restrict
     const GatherJob job = jobs[blockIdx.y];
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < job.n; i += (int)(gridDim.x * blockDim.x)) { dst[job.dst_off + i] = job.src[i]; }
 }
+// the same with the job table in the kernel arguments (up to 128 VFOs: 3 KB of the 4 KB the launch packet carries): no upload of the table,
+// which for a read after every reference-sized block was a staged host-to-device copy of its own
+#define SDRPP_GATHER_INLINE 128
+struct GatherArgs { GatherJob j[SDRPP_GATHER_INLINE]; };
+__global__ __launch_bounds__(256) void gather_inline_kernel(GatherArgs args, float2* __restrict__ dst) {
+    const GatherJob job = args.j[blockIdx.y];
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < job.n; i += (int)(gridDim.x * blockDim.x)) { dst[job.dst_off + i] = job.src[i]; }
+}
 
 // =====================================================================================================================
 // Register-blocked kernels (round-1 optimisation of the measured bottleneck).
