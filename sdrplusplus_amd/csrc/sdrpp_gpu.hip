@@ -146,7 +146,8 @@ struct sdrpp_ctx {
     bool land_used[2] = { false, false };
     int land_cur = 0;
     hipStream_t copy_stream = nullptr;
-    bool async_staged = false;     // sdrpp_push_pinned_async copies enqueued since the last pass
+    bool async_staged = false;     // sdrpp_push_pinned_async copies enqueued since the last pass (the pass waits for them on the device)
+    bool async_inflight = false;   // ... and not yet known to have landed: cleared only by a HOST synchronisation of the copy stream (sdrpp_push_wait)
     hipEvent_t ev_copy = nullptr;
     // deferred processing (sdrpp_set_deferred): pushes are only staged; the next observing call processes them as ONE pass
     bool deferred = false;
@@ -2103,6 +2104,26 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
+// HIP's current device is a per-THREAD setting: a host that owns several contexts on several GPUs (StreamBank, one worker thread
+// per IQFrontEnd) calls into a context from threads whose current device is some other GPU.  Every entry point that takes a context
+// therefore makes the context's device current for the duration of the call (allocations, launches, copies, symbol accesses all
+// follow the current device) and restores the caller's on return.
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(const sdrpp_ctx* c) {
+        if (!c) { return; }
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != c->device) {
+            prev = cur;
+            (void)hipSetDevice(c->device);
+        }
+    }
+    ~DeviceScope() {
+        if (prev >= 0) { (void)hipSetDevice(prev); }
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 // every call that observes results or changes the configuration first processes what deferred pushes have staged
 #define FLUSH_PENDING(c)                          \
     do {                                          \
@@ -2201,6 +2222,7 @@ static void wf_free(sdrpp_ctx* c) {
 }
 
 int sdrpp_wf_configure(sdrpp_ctx* c, int height) {
+    DeviceScope dev_scope_(c);
     if (!c || height < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2216,6 +2238,7 @@ int sdrpp_wf_configure(sdrpp_ctx* c, int height) {
 }
 
 int sdrpp_wf_set_smoothing(sdrpp_ctx* c, int enabled, float speed) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
@@ -2236,6 +2259,7 @@ int sdrpp_wf_set_smoothing(sdrpp_ctx* c, int enabled, float speed) {
 }
 
 int sdrpp_wf_set_hold(sdrpp_ctx* c, int enabled, float speed) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (c->wf.height <= 0) { return fail(c, SDRPP_ERR_INVALID, "no waterfall history configured (sdrpp_wf_configure)"); }
@@ -2254,6 +2278,7 @@ int sdrpp_wf_set_hold(sdrpp_ctx* c, int enabled, float speed) {
 }
 
 int sdrpp_wf_latest(sdrpp_ctx* c, float* latest, float* hold) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
@@ -2266,6 +2291,7 @@ int sdrpp_wf_latest(sdrpp_ctx* c, float* latest, float* hold) {
 
 // updateWaterfallFb (waterfall.cpp:600-631): every stored line re-zoomed with a NEW view, newest first
 int sdrpp_wf_raster(sdrpp_ctx* c, int draw_start, int draw_size, int data_width, float wf_min, float wf_max, int32_t* dst_host, int* n_lines) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst_host || data_width <= 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
@@ -2318,8 +2344,8 @@ static void preproc_free(sdrpp_ctx* c) {
 }
 
 int sdrpp_destroy(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_OK; }
-    (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
 #ifdef SDRPP_TOEP_PROF
@@ -2400,6 +2426,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
 const char* sdrpp_last_error(const sdrpp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2409,6 +2436,7 @@ int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
 }
 
 int sdrpp_sync(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2425,6 +2453,7 @@ int sdrpp_sync(sdrpp_ctx* c) {
 }
 
 int sdrpp_device_info(sdrpp_ctx* c, char* buf, int buflen) {
+    DeviceScope dev_scope_(c);
     if (!c || !buf || buflen <= 0) { return SDRPP_ERR_INVALID; }
     snprintf(buf, (size_t)buflen, "%s", c->devinfo.c_str());
     return SDRPP_OK;
@@ -2432,6 +2461,7 @@ int sdrpp_device_info(sdrpp_ctx* c, char* buf, int buflen) {
 
 // ---- FFT ---------------------------------------------------------------------------------------------------------------------
 int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const float* window) {
+    DeviceScope dev_scope_(c);
     if (!c || !window) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!is_pow2(fft_size) || fft_size < 1024 || fft_size > (1 << 20)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft_size %d: need a power of two in [1024, 1048576]", fft_size); }
@@ -2502,6 +2532,7 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
 }
 
 int sdrpp_fft_disable(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2511,6 +2542,7 @@ int sdrpp_fft_disable(sdrpp_ctx* c) {
 }
 
 int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float wf_min, float wf_max) {
+    DeviceScope dev_scope_(c);
     if (!c || data_width < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2533,12 +2565,14 @@ int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float 
 }
 
 int sdrpp_fft_lines(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     return c->n_lines;
 }
 
 int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
+    DeviceScope dev_scope_(c);
     if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (first >= c->n_lines) { return 0; }
@@ -2556,6 +2590,7 @@ int sdrpp_fft_read(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, in
 }
 
 int sdrpp_fft_copy_device(sdrpp_ctx* c, int first, int n, float* raw, float* zoomed, int32_t* index) {
+    DeviceScope dev_scope_(c);
     if (!c || first < 0 || n < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (first >= c->n_lines) { return 0; }
@@ -2568,6 +2603,7 @@ int sdrpp_fft_copy_device(sdrpp_ctx* c, int first, int n, float* raw, float* zoo
 }
 
 int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoomed, const int32_t** index, int* n_lines) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (raw) { *raw = c->d_lines; }
@@ -2578,6 +2614,7 @@ int sdrpp_fft_device_buffers(sdrpp_ctx* c, const float** raw, const float** zoom
 }
 
 int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps, float dc_rate, int conjugate) {
+    DeviceScope dev_scope_(c);
     if (!c || n_stages < 0 || n_stages > SDRPP_MAX_DECIM_STAGES) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     for (int s = 0; s < n_stages; s++) {
@@ -2633,6 +2670,7 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
 }
 
 int sdrpp_preproc_out_count(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
@@ -2640,6 +2678,7 @@ int sdrpp_preproc_out_count(sdrpp_ctx* c) {
 }
 
 int sdrpp_preproc_read(sdrpp_ctx* c, float* dst, int max) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
@@ -2650,6 +2689,7 @@ int sdrpp_preproc_read(sdrpp_ctx* c, float* dst, int max) {
 }
 
 int sdrpp_preproc_device_buffer(sdrpp_ctx* c, const float** iq, int* n) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
@@ -2660,6 +2700,7 @@ int sdrpp_preproc_device_buffer(sdrpp_ctx* c, const float** iq, int* n) {
 
 // ---- VFOs ----------------------------------------------------------------------------------------------------------------------
 int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
+    DeviceScope dev_scope_(c);
     if (!c || !d || !id) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (d->n_stages < 0 || d->n_stages > SDRPP_MAX_DECIM_STAGES) { return fail(c, SDRPP_ERR_INVALID, "n_stages %d", d->n_stages); }
@@ -2848,6 +2889,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
 }
 
 int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -2861,6 +2903,7 @@ int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
 int sdrpp_vfo_count(sdrpp_ctx* c) { return c ? (int)c->vfos.size() : SDRPP_ERR_INVALID; }
 
 int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -2881,6 +2924,7 @@ int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
 }
 
 int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
+    DeviceScope dev_scope_(c);
     if (!c || n < 0 || n > kChanHistCap + 1 || (n > 0 && !taps)) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -2925,6 +2969,7 @@ static void af_detach(Vfo& v) {
 }
 
 int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3020,6 +3065,7 @@ int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
 static Stream* af_stream(Vfo& v) { return (v.af.on && v.af.i_last >= 0) ? &v.st[(size_t)v.af.i_last] : nullptr; }
 
 int sdrpp_vfo_af_count(sdrpp_ctx* c, int id) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3030,6 +3076,7 @@ int sdrpp_vfo_af_count(sdrpp_ctx* c, int id) {
 }
 
 int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3043,6 +3090,7 @@ int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
 }
 
 int sdrpp_vfo_af_device_buffer(sdrpp_ctx* c, int id, const float** out, int* n_out) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3075,6 +3123,7 @@ static int pack_scratch(sdrpp_ctx* c, size_t bytes) {
 }
 
 int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scale, void* dst_host, int max_frames) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst_host || max_frames < 0 || (pcm_type != 0 && pcm_type != 1)) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3098,6 +3147,7 @@ int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scal
 // the pre-processed wideband IQ of the most recent push as int16 / int8: what the recorder's baseband mode writes (bindIQStream consumer ->
 // wav::Writer::write, utils/wav.cpp:158-167), converted on the device so that the copy to the host carries 4 (2) bytes per sample
 int sdrpp_preproc_read_pcm(sdrpp_ctx* c, int pcm_type, float scale, void* dst_host, int max_samples) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst_host || max_samples < 0 || (pcm_type != 0 && pcm_type != 1)) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!c->pre.on) { return fail(c, SDRPP_ERR_INVALID, "no pre-processing chain configured"); }
@@ -3116,6 +3166,7 @@ int sdrpp_preproc_read_pcm(sdrpp_ctx* c, int pcm_type, float scale, void* dst_ho
 }
 
 int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, unsigned char* dst_host, int max_bytes) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst_host || pcm_type < 0 || pcm_type > 2) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3162,6 +3213,7 @@ int sdrpp_vfo_read_compressed(sdrpp_ctx* c, int id, int which, int pcm_type, uns
 
 // calculateVFOSignalInfo (waterfall.cpp:558-598) on the newest line of the history ring
 int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, double whole_bandwidth, float* strength, float* snr) {
+    DeviceScope dev_scope_(c);
     if (!c || !strength || !snr) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     sdrpp_ctx::Wf& W = c->wf;
@@ -3189,6 +3241,7 @@ int sdrpp_wf_signal_info(sdrpp_ctx* c, double center_offset, double bandwidth, d
 }
 
 int sdrpp_set_reference_block(sdrpp_ctx* c, int ref_block) {
+    DeviceScope dev_scope_(c);
     if (!c || ref_block < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     c->ref_block = ref_block;
@@ -3196,11 +3249,13 @@ int sdrpp_set_reference_block(sdrpp_ctx* c, int ref_block) {
 }
 
 int sdrpp_set_backend_pipeline(sdrpp_ctx* c, int on) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     c->pipe_on = on < 0 ? 0 : on;
     return SDRPP_OK;
 }
 int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
+    DeviceScope dev_scope_(c);
     if (!c || (mode != SDRPP_NCO_CLOSED_FORM && mode != SDRPP_NCO_REFERENCE_ROTATOR)) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     if (!c->vfos.empty() && mode != c->nco_exact) { return fail(c, SDRPP_ERR_INVALID, "the NCO mode can only change while no VFO exists (it decides how a VFO's front end is built)"); }
@@ -3209,6 +3264,7 @@ int sdrpp_set_nco_mode(sdrpp_ctx* c, int mode) {
 }
 
 int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3222,6 +3278,7 @@ int sdrpp_vfo_set_ssb_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
 }
 
 int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3232,6 +3289,7 @@ int sdrpp_vfo_reset(sdrpp_ctx* c, int id) {
 static Stream* out_stream(Vfo& v) { return (v.d.demod == SDRPP_DEMOD_RAW) ? &v.st[(size_t)v.i_if] : &v.st[(size_t)v.i_out]; }
 
 int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3240,6 +3298,7 @@ int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
 }
 
 int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
+    DeviceScope dev_scope_(c);
     if (!c || !dst || max < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3252,6 +3311,7 @@ int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
 }
 
 int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, float* dst_host, int64_t max_samples, int64_t* offsets, int* counts) {
+    DeviceScope dev_scope_(c);
     if (!c || n < 0 || (n > 0 && (!ids || !dst_host || !offsets || !counts)) || max_samples < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     std::vector<GatherJob> jobs;
@@ -3302,6 +3362,7 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
 }
 
 int sdrpp_vfo_device_buffers(sdrpp_ctx* c, int id, const float** out, int* n_out, const float** if_out, int* n_if) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     auto it = c->vfos.find(id);
@@ -3365,6 +3426,7 @@ static int push_args_ok(sdrpp_ctx* c, const void* p, int64_t count) {
 }
 
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
+    DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
@@ -3393,6 +3455,7 @@ __global__ __launch_bounds__(256) void pinned_stage_kernel(const float2* __restr
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { dst[i] = src[i]; }
 }
 int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     void* dptr = nullptr;
     if (!c->deferred || count <= 0 || !iq_pinned || hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
@@ -3407,18 +3470,26 @@ int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count)
     hipLaunchKernelGGL(pinned_stage_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 1023) / 1024, 128))), dim3(256), 0, c->copy_stream, (const float2*)dptr, (float2*)land,
                        (long long)count);
     c->async_staged = true;
+    c->async_inflight = true;
     c->pending += count;
     c->pend_ends.push_back((int)c->pending);
     return SDRPP_OK;
 }
 
 int sdrpp_push_wait(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    if (c->async_staged) { HIPCHK(c, hipStreamSynchronize(c->copy_stream)); }
+    // (not `async_staged`: a flushing call that does not host-synchronise — sdrpp_fft_lines, sdrpp_vfo_out_count, a setter — clears that
+    // one while the copy kernels may still be reading the caller's page-locked buffers)
+    if (c->async_inflight) {
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        c->async_inflight = false;
+    }
     return SDRPP_OK;
 }
 
 int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
+    DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_dev, count);
     if (rc) { return rc; }
     if (!c->deferred) { return push_common(c, iq_dev, count); }  // read in place
@@ -3432,6 +3503,7 @@ int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
 }
 
 int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
+    DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
@@ -3466,6 +3538,7 @@ void sdrpp_host_free(void* p) {
 }
 
 int sdrpp_set_deferred(sdrpp_ctx* c, int on) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     int rc = flush_pending(c);
     c->deferred = on != 0;
@@ -3475,6 +3548,7 @@ int64_t sdrpp_pending(sdrpp_ctx* c) { return c ? c->pending : SDRPP_ERR_INVALID;
 
 // ---- measurement ---------------------------------------------------------------------------------------------------------------------
 int sdrpp_timing_enable(sdrpp_ctx* c, int on) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     timing_flush(c);
     c->timing = on != 0;
@@ -3487,6 +3561,7 @@ int sdrpp_timing_enable(sdrpp_ctx* c, int on) {
 }
 
 int sdrpp_timing_read(sdrpp_ctx* c, double* ms, int64_t* launches) {
+    DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     timing_flush(c);
     for (int i = 0; i < SDRPP_NUM_KERNEL_FAMILIES; i++) {
