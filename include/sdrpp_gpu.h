@@ -298,11 +298,50 @@ int sdrpp_push_pinned_async(sdrpp_ctx* ctx, const float* iq_pinned, int64_t coun
 int sdrpp_push_wait(sdrpp_ctx* ctx);
 int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed */
 
+/* ---- pipelined execution: one launch per block, results a few blocks late ----------------------------------------------------------
+ * At the reference's block size (sample_rate / 200 samples per swap(): core/src/dsp/stream.h:9, source_modules/file_source/src/main.cpp:157)
+ * a block is far less than one wave of work for the GPU and an ordinary pass costs the SUM of its ~8 dependent launches.  The reference
+ * itself is a pipeline at that grain — one thread per dsp::block, every stream<T> a hand-over between two of them (block.h:46-73,
+ * stream.h:43-92): while the demodulator works on block n the VFO already has block n + 1.  Pipelined mode does the same on the device:
+ * every sdrpp_push* launches ONE kernel ("tick") that runs the arrival of block n (its copy into device memory, the upload of its job
+ * tables) next to the front end / FFT pass 1 of block n - 1, the first decimator / FFT pass 2 of block n - 2, ... — every stage of every
+ * block exactly as in an ordinary pass (same kernels' bodies, same arithmetic: results are bit-identical), only not one after the
+ * other.  A block's results are complete `depth` launches later (depth <= 10, typically 6): with the next blocks, or at once when the
+ * caller asks (sdrpp_pipeline_flush, sdrpp_result_wait, any observing call such as sdrpp_vfo_read / sdrpp_sync — these run the queued
+ * stages without new input; sdrpp_fft_lines and sdrpp_vfo_out_count only report what the host already knows and do not).
+ *   sdrpp_push_device        reads the caller's buffer IN PLACE one launch later at the earliest: it must stay valid until sdrpp_sync.
+ *   sdrpp_push / _push_int16 copy into a page-locked staging slot (the caller's buffer is free on return), fetched by the next launch.
+ *   sdrpp_push_pinned_async  page-locked memory is fetched by the launch itself; sdrpp_push_wait returns when all such fetches have run.
+ * What cannot run that way (a pre-processing chain, the waterfall display state, the AF chain, the reference-rotator NCO, VFO groups
+ * without the matrix-core front end, a retune hand-over in progress, more FFT frames than one scratch chunk) is processed as an ordinary
+ * pass behind everything queued: always correct, pipelined where possible.
+ * result_flags (sdrpp_set_pipelined): which results every block also delivers into page-locked host memory, ready for sdrpp_result_wait
+ * without any copy call: 1 = every VFO's output block (what sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines.
+ * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push). */
+typedef struct sdrpp_result {
+    uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
+    int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */
+    const int* ids;           /* [n_vfo] VFO handles                                                                                 */
+    const int64_t* offsets;   /* [n_vfo] first sample (2 floats each) of the VFO's block in `samples`                                */
+    const int* counts;        /* [n_vfo] samples                                                                                     */
+    const float* samples;     /* page-locked host memory of the library, valid until sdrpp_result_release                            */
+    int n_lines, fft_size, data_width;
+    const float* zoomed;      /* [n_lines][data_width] (flag 2), else NULL                                                           */
+    const int32_t* index;     /* [n_lines][data_width] (flag 2)                                                                      */
+    const float* raw;         /* [n_lines][fft_size] (flag 4)                                                                        */
+} sdrpp_result;
+int sdrpp_set_pipelined(sdrpp_ctx* ctx, int on, int result_flags);
+uint64_t sdrpp_ticket(sdrpp_ctx* ctx);                       /* ticket of the most recent push (pushes so far in pipelined mode)    */
+int sdrpp_pipeline_flush(sdrpp_ctx* ctx);                    /* launch what is queued, no new input; does not wait                  */
+int sdrpp_result_ready(sdrpp_ctx* ctx, uint64_t ticket);     /* 1 / 0 without blocking or flushing; SDRPP_ERR_NOT_FOUND: no slot    */
+int sdrpp_result_wait(sdrpp_ctx* ctx, uint64_t ticket, sdrpp_result* out);   /* flushes if needed, waits, hands the slot out        */
+int sdrpp_result_release(sdrpp_ctx* ctx, uint64_t ticket);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.
  * family: 0 fft_pass1, 1 fft_pass2, 2 fft_single, 3 zoom, 4 vfo_stage1, 5 vfo_decim, 6 vfo_poly, 7 vfo_fir, 8 demod, 9 carry/misc,
- * 10 af_chain, 11 vfo_pipe (pipelined FM back ends) */
-#define SDRPP_NUM_KERNEL_FAMILIES 12
+ * 10 af_chain, 11 vfo_pipe (FM back ends as one launch), 12 tick (pipelined mode: one launch per block) */
+#define SDRPP_NUM_KERNEL_FAMILIES 13
 /* on = 0: off; 1: every family; 1 | (family_bitmask << 1): only the selected families (each timed launch costs two event
  * records on its stream, so a throughput run instruments just the kernel it reports). */
 int sdrpp_timing_enable(sdrpp_ctx* ctx, int on);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libsdrpp_gpu.so")
 
 MAX_DECIM_STAGES = 4
-NUM_KERNEL_FAMILIES = 12  # SDRPP_NUM_KERNEL_FAMILIES (checked against the header in tests/test_capi_host.py)
+NUM_KERNEL_FAMILIES = 13  # SDRPP_NUM_KERNEL_FAMILIES (checked against the header in tests/test_capi_host.py)
 
 DEMOD_RAW, DEMOD_WFM, DEMOD_NFM, DEMOD_AM, DEMOD_USB, DEMOD_LSB, DEMOD_DSB = -1, 0, 1, 2, 3, 4, 5
 
@@ -73,6 +73,25 @@ class AfDesc(C.Structure):
         ("hpf_ntaps", C.c_int),
         ("hpf_taps", c_float_p),
         ("deemph_alpha", C.c_float),
+    ]
+
+
+class Result(C.Structure):
+    """struct sdrpp_result (include/sdrpp_gpu.h): one block's results in the library's page-locked host memory (pipelined mode)."""
+
+    _fields_ = [
+        ("ticket", C.c_uint64),
+        ("n_vfo", C.c_int),
+        ("ids", c_int_p),
+        ("offsets", C.POINTER(C.c_int64)),
+        ("counts", c_int_p),
+        ("samples", c_float_p),
+        ("n_lines", C.c_int),
+        ("fft_size", C.c_int),
+        ("data_width", C.c_int),
+        ("zoomed", c_float_p),
+        ("index", c_int32_p),
+        ("raw", c_float_p),
     ]
 
 
@@ -178,6 +197,13 @@ def load():
     L.sdrpp_push.argtypes = [vp, c_float_p, C.c_int64]
     L.sdrpp_push_device.argtypes = [vp, vp, C.c_int64]
     L.sdrpp_push_int16.argtypes = [vp, C.POINTER(C.c_int16), C.c_int64]
+    L.sdrpp_set_pipelined.argtypes = [vp, C.c_int, C.c_int]
+    L.sdrpp_ticket.restype = C.c_uint64
+    L.sdrpp_ticket.argtypes = [vp]
+    L.sdrpp_pipeline_flush.argtypes = [vp]
+    L.sdrpp_result_ready.argtypes = [vp, C.c_uint64]
+    L.sdrpp_result_wait.argtypes = [vp, C.c_uint64, C.POINTER(Result)]
+    L.sdrpp_result_release.argtypes = [vp, C.c_uint64]
     L.sdrpp_timing_enable.argtypes = [vp, C.c_int]
     L.sdrpp_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.sdrpp_kernel_family_name.restype = C.c_char_p
@@ -200,6 +226,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
+    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
 
@@ -518,6 +545,44 @@ class Context:
 
     def push_device(self, dev_ptr, count):
         self._chk(self.L.sdrpp_push_device(self.h, C.c_void_p(dev_ptr), int(count)))
+
+    # pipelined execution (one launch per block, results a few blocks late)
+    def set_pipelined(self, on, result_flags=0):
+        """result_flags: 1 = every VFO's output block, 2 = zoomed lines + palette indices, 4 = raw dB lines into page-locked result slots."""
+        self._chk(self.L.sdrpp_set_pipelined(self.h, int(bool(on)), int(result_flags)))
+
+    def ticket(self):
+        return int(self.L.sdrpp_ticket(self.h))
+
+    def pipeline_flush(self):
+        self._chk(self.L.sdrpp_pipeline_flush(self.h))
+
+    def result_ready(self, ticket):
+        return bool(self._chk(self.L.sdrpp_result_ready(self.h, int(ticket))))
+
+    def result_wait(self, ticket, copy=True):
+        """-> dict(vfo={id: [n, 2] float32}, zoomed, index, raw); arrays are copies unless copy=False (then valid until result_release)."""
+        r = Result()
+        self._chk(self.L.sdrpp_result_wait(self.h, int(ticket), C.byref(r)))
+        out = {"ticket": int(r.ticket), "vfo": {}, "n_lines": r.n_lines, "zoomed": None, "index": None, "raw": None}
+        cp = (lambda a: a.copy()) if copy else (lambda a: a)
+        for i in range(r.n_vfo):
+            n = r.counts[i]
+            if n > 0:
+                a = np.ctypeslib.as_array(C.cast(C.addressof(r.samples.contents) + 8 * r.offsets[i], c_float_p), shape=(n, 2))
+                out["vfo"][r.ids[i]] = cp(a)
+            else:
+                out["vfo"][r.ids[i]] = np.zeros((0, 2), np.float32)
+        if r.n_lines > 0:
+            if r.zoomed:
+                out["zoomed"] = cp(np.ctypeslib.as_array(r.zoomed, shape=(r.n_lines, r.data_width)))
+                out["index"] = cp(np.ctypeslib.as_array(r.index, shape=(r.n_lines, r.data_width)))
+            if r.raw:
+                out["raw"] = cp(np.ctypeslib.as_array(r.raw, shape=(r.n_lines, r.fft_size)))
+        return out
+
+    def result_release(self, ticket):
+        self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))
 
     # measurement
     def timing_enable(self, on=True, families=None):

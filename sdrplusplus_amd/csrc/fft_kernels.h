@@ -22,6 +22,12 @@
 
 namespace sdrpp_k {
 
+// Workgroup coordinates handed to a kernel BODY.  Every kernel of the per-block path is written as a body function of (bid, gdim,
+// ...) plus a thin __global__ wrapper that passes blockIdx / gridDim: the same body then also runs as a ROLE inside the one-launch-
+// per-block kernel (tick_kernels.h), where a workgroup's role and coordinates come from a table instead of the launch grid.
+struct KIdx { int x, y; };
+template <class T> __device__ __forceinline__ KIdx kidx(const T& v) { return KIdx{ (int)v.x, (int)v.y }; }
+
 // Two-source sample accessor: index i is relative to the first sample of the current push; i < 0 reaches into the
 // history kept from earlier pushes (hist holds the most recent hist_len samples, oldest first).
 struct IqSrc {
@@ -226,16 +232,20 @@ struct IdxPad16 {
 };
 
 template <int LG, int FPW>
-__global__ __launch_bounds__(((1 << LG) / 16) * FPW) void fft_single_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
-                                                                           const float2* __restrict__ tw_g, float* __restrict__ out_db) {
+struct FftSingleLds {
+    static constexpr int L = 1 << LG;
+    static constexpr int PITCH = L + L / 16;
+    static constexpr int TW = L / 2, DATA = FPW * PITCH;  // float2 elements: twiddles, then the frames' images
+};
+template <int LG, int FPW>
+__device__ __forceinline__ void fft_single_body(const KIdx bid, float2* tw, float2* data, const IqSrc& src, const FrameGeom& g, const float* __restrict__ window,
+                                                const float2* __restrict__ tw_g, float* __restrict__ out_db) {
     constexpr int L = 1 << LG;
     constexpr int TPF = L / 16;
     constexpr int PITCH = L + L / 16;
-    __shared__ float2 tw[L / 2];
-    __shared__ float2 data[FPW * PITCH];
     const int t = threadIdx.x % TPF;
     const int fl = threadIdx.x / TPF;
-    const int frame = blockIdx.x * FPW + fl;
+    const int frame = bid.x * FPW + fl;
     const bool live = frame < g.nframes;
     for (int e = threadIdx.x; e < L / 2; e += TPF * FPW) { tw[e] = tw_g[e]; }
     float2 r[16];
@@ -261,6 +271,13 @@ __global__ __launch_bounds__(((1 << LG) / 16) * FPW) void fft_single_kernel(IqSr
         }
     }
 }
+template <int LG, int FPW>
+__global__ __launch_bounds__(((1 << LG) / 16) * FPW) void fft_single_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
+                                                                           const float2* __restrict__ tw_g, float* __restrict__ out_db) {
+    __shared__ float2 tw[FftSingleLds<LG, FPW>::TW];
+    __shared__ float2 data[FftSingleLds<LG, FPW>::DATA];
+    fft_single_body<LG, FPW>(kidx(blockIdx), tw, data, src, g, window, tw_g, out_db);
+}
 
 // ---- N > 4096, pass 1: column FFTs + inter-pass twiddle ---------------------------------------------------------------------------
 struct IdxCols {
@@ -271,17 +288,14 @@ struct IdxCols {
 // grid.x = nframes * (N2 / C); block = (N1/16) * C work-items, column index fastest.
 // scratch layout: A[frame][k1][n2] (n2 contiguous); tw_n2k1 has the same [k1][n2] layout and holds tw(n2*k1, N).
 template <int LG1, int C>
-__global__ __launch_bounds__(((1 << LG1) / 16) * C) void fft_pass1_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
-                                                                         const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1,
-                                                                         float2* __restrict__ scratch, int lg2) {
+__device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float2* data, const IqSrc& src, const FrameGeom& g, const float* __restrict__ window,
+                                               const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1, float2* __restrict__ scratch, int lg2) {
     constexpr int L1 = 1 << LG1;
     constexpr int TPF = L1 / 16;
-    __shared__ float2 tw[L1 / 2];
-    __shared__ float2 data[L1 * C];
     const int N2 = 1 << lg2;
     const int tiles = N2 / C;
-    const int frame = blockIdx.x / tiles;
-    const int c0 = (blockIdx.x % tiles) * C;
+    const int frame = bid.x / tiles;
+    const int c0 = (bid.x % tiles) * C;
     const int c = threadIdx.x % C;
     const int t = threadIdx.x / C;
     const int n2 = c0 + c;
@@ -314,6 +328,14 @@ __global__ __launch_bounds__(((1 << LG1) / 16) * C) void fft_pass1_kernel(IqSrc 
         }
     }
 }
+template <int LG1, int C>
+__global__ __launch_bounds__(((1 << LG1) / 16) * C) void fft_pass1_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
+                                                                         const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1,
+                                                                         float2* __restrict__ scratch, int lg2) {
+    __shared__ float2 tw[(1 << LG1) / 2];
+    __shared__ float2 data[(1 << LG1) * C];
+    fft_pass1_body<LG1, C>(kidx(blockIdx), tw, data, src, g, window, tw1_g, tw_n2k1, scratch, lg2);
+}
 
 // ---- N > 4096, pass 2: row FFTs + dB, output bin k = k1 + N1*k2 ------------------------------------------------------------------
 struct IdxRowPad {
@@ -323,17 +345,15 @@ struct IdxRowPad {
 
 // grid.x = nframes * (N1 / R); block = (N2/16) * R work-items, t fastest (coalesced row reads).
 template <int LG2, int R>
-__global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
-                                                                         float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
+__device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float2* data, const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
+                                               float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
     constexpr int L2 = 1 << LG2;
     constexpr int TPF = L2 / 16;
     constexpr int PITCH = L2 + L2 / 16;
-    __shared__ float2 tw[L2 / 2];
-    __shared__ float2 data[R * PITCH];
     const int N1 = 1 << lg1;
     const int tiles = N1 / R;
-    const int frame = blockIdx.x / tiles;
-    const int r0 = (blockIdx.x % tiles) * R;
+    const int frame = bid.x / tiles;
+    const int r0 = (bid.x % tiles) * R;
     const int t = threadIdx.x % TPF;
     const int row = threadIdx.x / TPF;
     for (int e = threadIdx.x; e < L2 / 2; e += TPF * R) { tw[e] = tw2_g[e]; }
@@ -386,6 +406,13 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
     }
     (void)nframes;
 }
+template <int LG2, int R>
+__global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
+                                                                         float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
+    __shared__ float2 tw[(1 << LG2) / 2];
+    __shared__ float2 data[R * ((1 << LG2) + (1 << LG2) / 16)];
+    fft_pass2_body<LG2, R>(kidx(blockIdx), tw, data, scratch, tw2_g, out_db, lg1, nframes, grp_max);
+}
 
 // ---- doZoom max-decimation + palette index (waterfall.cpp:65-90, 899-905) -------------------------------------------------------------
 // The float32 running index of doZoom is evaluated on the host once per view change (sdrpp_host::zoomTable: first bin and bin
@@ -394,15 +421,13 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
 // (`if (in > max) max = in`, -inf start, so a NaN never wins) and the partial maxima meet in LDS.  max is order independent: the
 // result is bit-identical to the sequential scan.
 template <int TP>
-__global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
-                                                          const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
-                                                          float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index,
-                                                          const float* __restrict__ grp_max, int gsz) {
+__device__ __forceinline__ void zoom_palette_body(const KIdx bid, float* part, const float* __restrict__ lines, int fft_size, int data_width,
+                                                  const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount, float wf_min, float wf_max,
+                                                  float* __restrict__ zoomed, int32_t* __restrict__ index, const float* __restrict__ grp_max, int gsz) {
     constexpr int PPB = 256 / TP;  // pixels per block
-    __shared__ float part[PPB * (TP + 1)];
-    const int line = blockIdx.y;
+    const int line = bid.y;
     const int p = threadIdx.x / TP, q = threadIdx.x % TP;
-    const int px = blockIdx.x * PPB + p;
+    const int px = bid.x * PPB + p;
     const float* in = lines + (size_t)line * fft_size;
     float m = __uint_as_float(0xff800000u);  // -inf
     if (px < data_width) {
@@ -442,6 +467,14 @@ __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restri
         const float pixel = (v - wf_min) / range;
         index[(size_t)line * data_width + px] = (int32_t)(pixel * 999999.0f);
     }
+}
+template <int TP>
+__global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restrict__ lines, int fft_size, int data_width,
+                                                          const int32_t* __restrict__ zstart, const int32_t* __restrict__ zcount,
+                                                          float wf_min, float wf_max, float* __restrict__ zoomed, int32_t* __restrict__ index,
+                                                          const float* __restrict__ grp_max, int gsz) {
+    __shared__ float part[(256 / TP) * (TP + 1)];
+    zoom_palette_body<TP>(kidx(blockIdx), part, lines, fft_size, data_width, zstart, zcount, wf_min, wf_max, zoomed, index, grp_max, gsz);
 }
 
 // ---- WaterFall display state (waterfall.cpp:875-941): raw-line ring, FFT trace smoothing / hold -----------------------------------------

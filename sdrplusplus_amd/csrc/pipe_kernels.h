@@ -35,6 +35,7 @@ struct PipeJob {
     int zero_lo, zero_hi;  // rings (cleared at start: a window may reach past what its producer ever writes, and 0 * NaN is NaN)
     int keep[3];        // stage s < 3 also writes its outputs with index >= keep[s] to its HBM stream (0: all of it)
     int dec_stage;      // (host) index of stage 0 in the VFO's decimation plan
+    int lvl;            // (host) level of stage 0 in the block's data flow
 };
 
 #ifdef SDRPP_TOEP_PROF

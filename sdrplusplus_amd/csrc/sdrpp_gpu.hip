@@ -9,9 +9,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sdrpp_gpu.h"
@@ -19,20 +21,25 @@
 #include "host_design.h"
 #include "vfo_kernels.h"
 #include "pipe_kernels.h"
+#include "tick_kernels.h"
 
 using namespace sdrpp_k;
 
 namespace {
 
-constexpr int kArenaSlots = 8;
+constexpr int kArenaSlots = 16;     // >= kTickDepth + 2: a block's job tables are read for kTickDepth ticks after their upload
 constexpr size_t kArenaBytes = 4u << 20;
+constexpr int kRing = 4;            // pipelined mode: buffers per per-block stream (a consumer runs at most 2 ticks behind its producer; + the gather)
+constexpr int kTickDepth = 10;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit())
+constexpr int kResSlots = 16;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
+constexpr int kStageSlots = 4;      // pipelined mode: page-locked staging buffers for pushes from pageable host memory
 constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
 constexpr size_t kScratchBytes = 64u << 20;
 constexpr int kMaxLds = 64 * 1024;
 
-enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF, F_PIPE };
+enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF, F_PIPE, F_TICK };
 const char* kFamilyNames[SDRPP_NUM_KERNEL_FAMILIES] = { "fft_pass1", "fft_pass2", "fft_single", "zoom_palette", "vfo_stage1",
-                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain",  "vfo_pipe" };
+                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain",  "vfo_pipe", "tick" };
 
 struct Stream {
     int width = 2;
@@ -43,6 +50,11 @@ struct Stream {
     float* hist[2] = { nullptr, nullptr };
     int cur = 0;
     int n = 0;
+    // pipelined mode: the other kRing - 1 data buffers (base allocations); `base` / `data` rotate through them block by block so that
+    // the producer of block n + 1 does not overwrite what a consumer of block n still reads (stream_rotate)
+    float* extra[kRing - 1] = {};
+    int n_extra = 0, rot = 0;
+    int clevel = 0;  // pipelined mode: level of the role that consumes this stream with memory (its history carry runs there)
 };
 
 // Tap tables of the matrix-core FIR kernel (vfo_toep_kernel): zero-padded taps + per-lane base indices (one set per carried
@@ -86,6 +98,7 @@ struct Vfo {
     // streams: 0..nstages-1 decimator outputs (index 0 also used by the rotate-only path), then poly, chan, dem, out
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
+    int lvl_if = 1, lvl_out = 1;  // levels (do_vfos_plan) at which the IF stream / the output of the most recent block are written
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
     // front end as one filter (what the fused translate + filter kernels evaluate): stages 0 (+ 1) of the plan
     bool fused_front = false;      // stages 0 and 1 run as one composite filter (front2_t2 > 0)
@@ -204,7 +217,8 @@ struct sdrpp_ctx {
     char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
     hipEvent_t arena_ev[kArenaSlots] = {};
     bool arena_used[kArenaSlots] = {};
-    char* arena_dev = nullptr;
+    char* arena_dev_slot[kArenaSlots] = {};  // a device arena per slot: the job tables of a block outlive its first launch in pipelined mode
+    char* arena_dev = nullptr;               // = arena_dev_slot[arena_slot]
     int arena_slot = 0;
     size_t arena_off = 0;
 
@@ -230,6 +244,11 @@ struct sdrpp_ctx {
     float* d_zoomed = nullptr;
     int32_t* d_index = nullptr;
     size_t zoom_cap = 0;
+    // pipelined mode: the other kRing - 1 sets of the per-block FFT buffers (scratch, lines, group maxima, zoomed, index); the members
+    // above rotate through them block by block (fft_ring_rotate), so they always name the buffers of the most recent block
+    struct FftBufs { float2* scratch = nullptr; float* lines = nullptr; float* grp = nullptr; float* zoomed = nullptr; int32_t* index = nullptr; };
+    FftBufs fft_extra[kRing - 1];
+    int fft_extra_n = 0, fft_rot = 0;
 
     // reference block structure / NCO flavour (sdrpp_set_reference_block, sdrpp_set_nco_mode)
     int ref_block = 0;             // 0: one push = one reference block
@@ -243,6 +262,45 @@ struct sdrpp_ctx {
     int next_id = 1;
     // cached stage-1 job tap arrays, keyed by membership signature
     std::map<std::string, float2*> s1_tap_cache;  // key = 16 raw bytes: two independent 64-bit hashes of (kind, member ids, increments)
+
+    // ---- pipelined ("tick") execution: one launch per block, the stages of consecutive blocks skewed over consecutive launches
+    //      (tick_kernels.h; sdrpp_set_pipelined) ----
+    struct RoleLaunch { TickEntry e; size_t lds; int level; int fam; };
+    struct Result {                       // what the host knows about the block in a result slot
+        uint64_t ticket = 0;              // 0: slot free
+        uint64_t done_tick = 0;           // its last level has run when this many ticks have completed
+        bool held = false;                // handed out by sdrpp_result_wait, not yet released
+        std::vector<int> ids, counts;
+        std::vector<int64_t> offsets;
+        int n_lines = 0;
+        size_t off_zoomed = 0, off_index = 0, off_raw = 0;  // byte offsets in the slot
+    };
+    bool pipelined = false;
+    int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
+    bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
+    bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
+    int plan_top = 0;                     // highest level + 1 the block being planned uses
+    std::vector<RoleLaunch> emits;        // roles of the block being planned
+    std::deque<std::vector<RoleLaunch>> tickq;  // [0]: roles of the next tick to launch, [1]: of the one after, ...
+    uint64_t ticks = 0;                   // ticks launched so far
+    uint64_t pushes = 0;                  // blocks accepted so far in pipelined mode (= ticket of the most recent one)
+    uint64_t land_tick = 0;               // landing copies of every push so far have run when this many ticks have completed
+    TickTable* next_tab = nullptr;        // device address of the role table of the next tick (uploaded by the tick before)
+    int next_tab_n = 0;
+    TickTable* empty_tab = nullptr;       // device: a table without roles
+    unsigned* d_tick_counter = nullptr;   // device: finished wavefronts, running total
+    unsigned tick_target = 0;             // its value when every tick launched so far has finished
+    unsigned* h_tick_flag = nullptr;      // page-locked: completed ticks (written by the last wavefront of each tick)
+    unsigned* hd_tick_flag = nullptr;     // the same, device address
+    uint64_t arena_tick[kArenaSlots] = {};  // pipelined: the tick that uploaded from this arena slot (+1; 0 = never)
+    float* tick_land[3] = {};             // landing ring of host pushes (max_push complex each; allocated on first use)
+    float* stage_host[kStageSlots] = {};  // page-locked staging of pushes from pageable memory (max_push complex each; allocated on first use)
+    uint64_t stage_tick[kStageSlots] = {};  // the tick whose landing copy reads the slot (+1)
+    int stage_cur = 0;
+    char* res_host[kResSlots] = {};       // page-locked result slots
+    char* res_dev[kResSlots] = {};        // their device addresses
+    size_t res_cap = 0;                   // bytes per slot
+    Result res[kResSlots];
 
     // timing
     bool timing = false;
@@ -328,6 +386,7 @@ struct FamilyTimer {
     int fam;
     hipEvent_t a = nullptr;
     FamilyTimer(sdrpp_ctx* c_, int f) : c(c_), fam(f) {
+        if (c->tick_planning) { return; }
         c->fam_launch[fam]++;
         if (c->timing && ((c->timing_mask >> fam) & 1u)) {
             a = get_event(c);
@@ -345,9 +404,18 @@ struct FamilyTimer {
 };
 
 // ---- job arena -------------------------------------------------------------------------------------------------------------
+void tick_wait_done(sdrpp_ctx* c, uint64_t nticks);
 int arena_begin(sdrpp_ctx* c) {
     c->arena_slot = (c->arena_slot + 1) % kArenaSlots;
-    if (c->arena_used[c->arena_slot]) { HIPCHK(c, hipEventSynchronize(c->arena_ev[c->arena_slot])); }
+    if (c->arena_used[c->arena_slot]) {
+        HIPCHK(c, hipEventSynchronize(c->arena_ev[c->arena_slot]));
+        c->arena_used[c->arena_slot] = false;
+    }
+    if (c->arena_tick[c->arena_slot]) {  // last used by a tick: its upload has run once that tick is complete (kArenaSlots ticks ago: normally long done)
+        tick_wait_done(c, c->arena_tick[c->arena_slot]);
+        c->arena_tick[c->arena_slot] = 0;
+    }
+    c->arena_dev = c->arena_dev_slot[c->arena_slot];
     c->arena_off = 0;
     return SDRPP_OK;
 }
@@ -370,7 +438,7 @@ __global__ __launch_bounds__(256) void arena_upload_kernel(const uint4* __restri
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) { dst[i] = src[i]; }
 }
 int arena_commit(sdrpp_ctx* c) {
-    if (c->arena_off == 0) { return SDRPP_OK; }
+    if (c->arena_off == 0 || c->tick_planning) { return SDRPP_OK; }  // (pipelined: the upload is part of the tick)
     const int n16 = (int)((c->arena_off + 15) / 16);
     hipLaunchKernelGGL(arena_upload_kernel, dim3((unsigned)std::min((n16 + 255) / 256, 64)), dim3(256), 0, c->stream,
                        (const uint4*)c->arena_host_dev[c->arena_slot], (uint4*)c->arena_dev, n16);
@@ -401,11 +469,29 @@ int stream_alloc(sdrpp_ctx* c, Stream& s, int width, int hist_len, size_t cap) {
 }
 void stream_free(Stream& s) {
     dev_free(s.base);
+    for (int i = 0; i < kRing - 1; i++) { dev_free(s.extra[i]); }
+    s.n_extra = 0;
+    s.rot = 0;
     s.data = nullptr;
     dev_free(s.hist[0]);
     dev_free(s.hist[1]);
 }
 StreamIn stream_in(const Stream& s) { return StreamIn{ s.data, s.hist[s.cur], s.hist_len, s.n }; }
+// pipelined mode: kRing data buffers per stream, used round robin block by block
+int stream_ring_ensure(sdrpp_ctx* c, Stream& s) {
+    while (s.n_extra < kRing - 1) {
+        int rc = dev_alloc(c, &s.extra[s.n_extra], (s.cap + 16) * s.width);
+        if (rc) { return rc; }
+        s.n_extra++;
+    }
+    return SDRPP_OK;
+}
+void stream_rotate(Stream& s) {
+    if (s.n_extra == 0 || !s.base) { return; }
+    std::swap(s.base, s.extra[s.rot]);
+    s.data = s.base;
+    s.rot = (s.rot + 1) % s.n_extra;
+}
 
 // Enlarge a stream's history (a consumer got more taps): the existing samples stay the most recent ones, older entries are
 // zero — exactly what fir.h:44-47 does to its delay line when the tap count grows.
@@ -674,8 +760,58 @@ struct HostScope {
 
 template <class K, class... A>
 void launch(sdrpp_ctx* c, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+    if (c->tick_planning) {  // a kernel that is not a role of the tick kernel: this block runs as an ordinary pass instead
+        if (!c->tick_abort && getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp tick] ordinary pass because of %s\n", __PRETTY_FUNCTION__); }
+        c->tick_abort = true;
+        return;
+    }
     HostScope hs("launch");
     hipLaunchKernelGGL(kernel, grid, block, lds, c->launch_stream, args...);
+}
+
+// ---- roles: kernels that exist both as a launch of their own and as a role of the tick kernel ------------------------------------------
+void launch_role(sdrpp_ctx* c, const sdrpp_ctx::RoleLaunch& r) {
+    const TickEntry& e = r.e;
+    const dim3 grid((unsigned)e.gx, (unsigned)e.gy), b256(256);
+    hipStream_t st = c->launch_stream;
+    HostScope hs("launch");
+    switch (e.role) {
+    case TR_COPY: hipLaunchKernelGGL(copy_kernel, grid, b256, 0, st, (const CopyJob*)e.jobs); break;
+    case TR_CARRY: hipLaunchKernelGGL(carry_kernel, grid, b256, 0, st, (const CarryJob*)e.jobs); break;
+    case TR_ROT: hipLaunchKernelGGL(vfo_rotate_kernel, grid, b256, 0, st, e.p.src, (const RotJob*)e.jobs); break;
+    case TR_FCM_132_4: hipLaunchKernelGGL((vfo_frontcm_kernel<10, 132, 4>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCM_6: hipLaunchKernelGGL((vfo_frontcm_kernel<6, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCM_10: hipLaunchKernelGGL((vfo_frontcm_kernel<10, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCM_16: hipLaunchKernelGGL((vfo_frontcm_kernel<16, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCL_0: hipLaunchKernelGGL((vfo_frontcl_kernel<0>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCL_PF: hipLaunchKernelGGL((vfo_frontcl_kernel<SDRPP_FCL_PF>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_TOEP_C: hipLaunchKernelGGL((vfo_toep_kernel<2, 2, false>), grid, b256, r.lds, st, (const ToepJob*)e.jobs); break;
+    case TR_TOEP_R: hipLaunchKernelGGL((vfo_toep_kernel<1, 2, false>), grid, b256, r.lds, st, (const ToepJob*)e.jobs); break;
+    case TR_TOEP_Q: hipLaunchKernelGGL((vfo_toep_kernel<1, 2, true>), grid, b256, r.lds, st, (const ToepJob*)e.jobs); break;
+    case TR_FIRB_C: hipLaunchKernelGGL((vfo_firb_kernel<2, false>), grid, dim3((unsigned)e.aux), r.lds, st, (const FirBJob*)e.jobs); break;
+    case TR_FIRB_R: hipLaunchKernelGGL((vfo_firb_kernel<1, false>), grid, dim3((unsigned)e.aux), r.lds, st, (const FirBJob*)e.jobs); break;
+    case TR_FIRB_S: hipLaunchKernelGGL((vfo_firb_kernel<1, true>), grid, dim3((unsigned)e.aux), r.lds, st, (const FirBJob*)e.jobs); break;
+    case TR_FIRB_Q: hipLaunchKernelGGL((vfo_firb_kernel<1, true, true>), grid, dim3((unsigned)e.aux), r.lds, st, (const FirBJob*)e.jobs); break;
+    case TR_PRE: hipLaunchKernelGGL(vfo_demod_pre_kernel, grid, b256, 0, st, (const PreJob*)e.jobs); break;
+    case TR_SEQ: hipLaunchKernelGGL(vfo_sequential_kernel, grid, dim3(64), 0, st, (const SeqJob*)e.jobs, e.aux); break;
+    default: break;  // (the FFT branch launches its kernels itself outside pipelined mode: its pass-1 workgroups are wider there)
+    }
+}
+// A launch of the block being processed at `level` of its data flow: now (an ordinary pass), or `level` ticks from now (pipelined).
+void emit(sdrpp_ctx* c, int level, int fam, int role, int gx, int gy, size_t lds, const void* jobs, const IqSrc* src = nullptr, int aux = 0) {
+    if (gx <= 0 || gy <= 0) { return; }
+    sdrpp_ctx::RoleLaunch r{};
+    r.e.role = role;
+    r.e.gx = gx;
+    r.e.gy = gy;
+    r.e.aux = aux;
+    r.e.jobs = jobs;
+    if (src) { r.e.p.src = *src; }
+    r.lds = lds;
+    r.level = level;
+    r.fam = fam;
+    if (c->tick_planning) { c->emits.push_back(r); }
+    else { launch_role(c, r); }
 }
 
 int pick_tile(int D, int K, int width_bytes) {
@@ -709,6 +845,46 @@ void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out, float* grp) {
     static_assert(R == pass2_rows(LG2), "pass2_rows out of step with the launch table");
     const int blocks = nframes * ((1 << lg1) / R);
     launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes, grp);
+}
+
+// pipelined mode: the FFT branch of one block as roles of the tick kernel — pass 1 (or the whole small transform) at level 1 next to the
+// front end, pass 2 at level 2, doZoom + palette index behind the lines (256-thread shapes of the same bodies: bit-identical)
+int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out, float* grp) {
+    const int m = c->fft_lg;
+    sdrpp_ctx::RoleLaunch r{};
+    r.e.gy = 1;
+    r.fam = F_FFTS;
+    if (m <= 12) {
+        const int fpw = m == 10 ? 4 : (m == 11 ? 2 : 1);
+        r.e.role = m == 10 ? TR_FFT_S10 : (m == 11 ? TR_FFT_S11 : TR_FFT_S12);
+        r.e.gx = (g.nframes + fpw - 1) / fpw;
+        r.e.p.fs = TickFS{ src, g, c->d_window, c->d_tw1, out };
+        r.lds = tick_lds_fft_single(m, fpw);
+        r.level = 1;
+        c->emits.push_back(r);
+        return SDRPP_OK;
+    }
+    const int lg1 = m / 2, lg2 = m - lg1;
+    static const int p1_role[5] = { TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10 }, p1_c[5] = { 64, 32, 16, 8, 4 };
+    static const int p2_role[4] = { TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10 };
+    if (lg1 < 6 || lg1 > 10 || lg2 < 7 || lg2 > 10) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft size 2^%d unsupported", m); }
+    r.e.role = p1_role[lg1 - 6];
+    r.e.gx = g.nframes * ((1 << lg2) / p1_c[lg1 - 6]);
+    r.e.p.p1 = TickP1{ src, g, c->d_window, c->d_tw1, c->d_twn, c->d_scratch, lg2, 0 };
+    r.lds = tick_lds_fft_p1(lg1, p1_c[lg1 - 6]);
+    r.level = 1;
+    r.fam = F_FFT1;
+    c->emits.push_back(r);
+    sdrpp_ctx::RoleLaunch q{};
+    q.e.gy = 1;
+    q.e.role = p2_role[lg2 - 7];
+    q.e.gx = g.nframes * ((1 << lg1) / pass2_rows(lg2));
+    q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, out, grp, lg1, g.nframes };
+    q.lds = tick_lds_fft_p2(lg2, pass2_rows(lg2));
+    q.level = 2;
+    q.fam = F_FFT2;
+    c->emits.push_back(q);
+    return SDRPP_OK;
 }
 
 int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out, float* grp) {
@@ -763,11 +939,56 @@ void launch_zoom(hipStream_t stream, const float* lines, int nlines, int fft_siz
     }
 }
 
+// pipelined mode: kRing sets of the per-block FFT buffers.  Every call that re-sizes one of them drops the extra sets first.
+void fft_ring_drop(sdrpp_ctx* c) {
+    for (int i = 0; i < kRing - 1; i++) {
+        sdrpp_ctx::FftBufs& b = c->fft_extra[i];
+        dev_free(b.scratch);
+        dev_free(b.lines);
+        dev_free(b.grp);
+        dev_free(b.zoomed);
+        dev_free(b.index);
+    }
+    c->fft_extra_n = 0;
+    c->fft_rot = 0;
+}
+int fft_ring_ensure(sdrpp_ctx* c) {
+    if (!c->fft_on || c->fft_extra_n == kRing - 1) { return SDRPP_OK; }
+    fft_ring_drop(c);
+    const size_t per_chunk = std::max<size_t>(1, kScratchBytes / ((size_t)c->fft_size * sizeof(float2)));
+    for (int i = 0; i < kRing - 1; i++) {
+        sdrpp_ctx::FftBufs& b = c->fft_extra[i];
+        int rc = SDRPP_OK;
+        if (c->d_scratch) { rc = dev_alloc(c, &b.scratch, per_chunk * (size_t)c->fft_size); }
+        if (!rc) { rc = dev_alloc(c, &b.lines, c->lines_cap * (size_t)c->fft_size); }
+        if (!rc && c->zoom_grp) { rc = dev_alloc(c, &b.grp, c->lines_cap * (size_t)(c->fft_size / c->zoom_grp)); }
+        if (!rc && c->zoom_cap) { rc = dev_alloc(c, &b.zoomed, c->zoom_cap); }
+        if (!rc && c->zoom_cap) { rc = dev_alloc(c, &b.index, c->zoom_cap); }
+        if (rc) {
+            fft_ring_drop(c);
+            return rc;
+        }
+        c->fft_extra_n = i + 1;
+    }
+    return SDRPP_OK;
+}
+void fft_ring_rotate(sdrpp_ctx* c) {
+    if (c->fft_extra_n == 0) { return; }
+    sdrpp_ctx::FftBufs& b = c->fft_extra[c->fft_rot];
+    std::swap(c->d_scratch, b.scratch);
+    std::swap(c->d_lines, b.lines);
+    std::swap(c->d_lines_grp, b.grp);
+    std::swap(c->d_zoomed, b.zoomed);
+    std::swap(c->d_index, b.index);
+    c->fft_rot = (c->fft_rot + 1) % c->fft_extra_n;
+}
+
 int ensure_zoom(sdrpp_ctx* c, size_t lines) {
     if (c->data_width <= 0) { return SDRPP_OK; }
     const size_t need = lines * (size_t)c->data_width;
     if (need <= c->zoom_cap) { return SDRPP_OK; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    fft_ring_drop(c);
     dev_free(c->d_zoomed);
     dev_free(c->d_index);
     int rc = dev_alloc(c, &c->d_zoomed, need);
@@ -815,6 +1036,44 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
     if (nframes > 0) {
         if ((size_t)nframes > c->lines_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: %lld frames exceed line capacity %zu", (long long)nframes, c->lines_cap); }
         const size_t per_chunk = std::max<size_t>(1, kScratchBytes / ((size_t)c->fft_size * sizeof(float2)));
+        if (c->tick_planning) {
+            // one chunk only (the chunks of an ordinary pass share the scratch matrix one after the other), no display state
+            if ((size_t)nframes > per_chunk || c->wf.height > 0) {
+                c->tick_abort = true;
+                return SDRPP_OK;
+            }
+            FrameGeom g;
+            g.nframes = (int)nframes;
+            g.stride = (int)P;
+            g.nz = c->nz;
+            g.first_start = c->fft_next * P - c->fft_pos;
+            int rc = plan_fft_roles(c, src, g, c->d_lines, c->zoom_grp ? c->d_lines_grp : nullptr);
+            if (rc) { return rc; }
+            const int lines_level = c->fft_lg <= 12 ? 1 : 2;
+            if (c->data_width > 0) {
+                if ((size_t)nframes * (size_t)c->data_width > c->zoom_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: zoom capacity"); }
+                int bpp = c->view_size / std::max(1, c->data_width);
+                const float* zgrp = c->d_lines_grp;
+                int gsz = c->zoom_grp;
+                if (zgrp && gsz > 1 && bpp >= 2 * gsz) { bpp = bpp / gsz + gsz; }
+                else { zgrp = nullptr; }
+                const int tp = (bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1);
+                sdrpp_ctx::RoleLaunch z{};
+                z.e.role = tp == 16 ? TR_ZOOM_16 : (tp == 4 ? TR_ZOOM_4 : TR_ZOOM_1);
+                z.e.gx = (c->data_width + 256 / tp - 1) / (256 / tp);
+                z.e.gy = (int)nframes;
+                z.e.p.z = TickZoom{ c->d_lines, c->d_zstart, c->d_zcount, c->d_zoomed, c->d_index, zgrp, c->fft_size, c->data_width, gsz, c->wf_min, c->wf_max, 0 };
+                z.lds = tick_lds_zoom(tp);
+                z.level = lines_level + 1;
+                z.fam = F_ZOOM;
+                c->emits.push_back(z);
+            }
+            c->plan_top = std::max(c->plan_top, lines_level + (c->data_width > 0 ? 2 : 1));
+            c->fft_next += nframes;
+            c->fft_pos = end;
+            c->n_lines = (int)nframes;
+            return SDRPP_OK;
+        }
         for (int64_t f0 = 0; f0 < nframes; f0 += (int64_t)per_chunk) {
             FrameGeom g;
             g.nframes = (int)std::min<int64_t>((int64_t)per_chunk, nframes - f0);
@@ -1007,7 +1266,30 @@ int pipe_segments(const std::vector<PipeJob>& pipes, int forced, size_t lds) {
     return 0;
 }
 
-int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>& carry) {
+// ---- levels: the position of a launch in the data flow of one block ---------------------------------------------------------------------
+constexpr int kLevels = 28;
+template <class T>
+struct Lev {
+    std::vector<T> at[kLevels];
+    T* dev[kLevels] = {};
+    int top = 0;  // highest level in use + 1
+    void add(int l, const T& j) {
+        if (l >= kLevels) { l = kLevels - 1; }
+        at[l].push_back(j);
+        if (l + 1 > top) { top = l + 1; }
+    }
+};
+template <class T>
+bool arena_push_lev(sdrpp_ctx* c, Lev<T>& L) {
+    for (int l = 0; l < L.top; l++) {
+        if (L.at[l].empty()) { continue; }
+        L.dev[l] = arena_push(c, L.at[l]);
+        if (!L.dev[l]) { return false; }
+    }
+    return true;
+}
+
+int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& iq_carry) {
     if (c->vfos.empty()) { return SDRPP_OK; }
 #ifdef SDRPP_TOEP_KNOCK
     {   // diagnostic build: SDRPP_TOEP_KNOCK=<mask> (1: no stores, 2: no loads, 4: no matrix loop) in vfo_toep_kernel
@@ -1022,33 +1304,42 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     const int n_in = (int)count;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;
-    std::vector<FirBJob> lvl[SDRPP_MAX_DECIM_STAGES];  // index 0 only in reference-rotator mode (stage 0 as a plain FIR)
+    Lev<FirBJob> f_dec;  // register-blocked decimators (tap counts the matrix form does not cover; stage 0 only in reference-rotator mode)
     std::vector<RotXJob> rotx;                          // reference-rotator mode: full-rate float recursion, one lane per VFO
-    std::vector<SsbRotXJob> ssbx;
     std::vector<RetuneJob> retune;                      // closed-form NCO: first outputs after a setOffset
     const std::vector<int>& fb = c->vfo_bounds;         // reference-block ends of this push (at least one entry: n_in)
     const bool blocks = fb.size() > 1;
-    std::vector<PolyJob> poly;
-    std::vector<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
-    std::vector<FirBJob> chan;
-    std::vector<SeqJob> seq;
-    std::vector<PreJob> pre;
-    std::vector<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
-    std::vector<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
+    // Every job carries the LEVEL of its launch in the block's data flow (level L reads what level L - 1 wrote): the front end is
+    // level 1 (level 0 = the block's arrival), every filter behind it one more.  A pass launches level by level; in pipelined mode
+    // level L of this block runs L ticks from now (tick_kernels.h).
+    Lev<PolyJob> poly;
+    Lev<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
+    Lev<FirBJob> chan;
+    Lev<SeqJob> seq;
+    Lev<PreJob> pre;
+    Lev<FirBJob> audio;     // AM: real stream -> low-pass -> stereo
+    Lev<FirBJob> audio_fm;  // WFM/NFM: IF -> discriminator -> low-pass -> stereo, one kernel
     // the same work on the matrix cores (vfo_toep_kernel) whenever the VFO has a tap table for it
-    std::vector<ToepJob> t_lvl[SDRPP_MAX_DECIM_STAGES], t_poly, t_chan, t_audio, t_audio_fm;
-    std::vector<PipeJob> pipes;  // FM back ends that run as one pipelined launch
+    Lev<ToepJob> t_dec, t_poly, t_chan, t_audio, t_audio_fm;
+    std::vector<PipeJob> pipes;  // FM back ends that run as one pipelined launch (all at the level of their decimator)
     size_t pipe_lds = 0;
     // radio AF chain (stereo frames have the layout of complex samples, so the same kernels serve)
-    std::vector<ToepJob> t_af_lvl[SDRPP_MAX_DECIM_STAGES], t_af_poly, t_af_hpf;
-    std::vector<FirBJob> af_lvl[SDRPP_MAX_DECIM_STAGES], af_hpf;
-    std::vector<PolyJob> af_poly;
-    std::vector<DeempJob> af_deemp;
+    Lev<ToepJob> t_af_dec, t_af_poly, t_af_hpf;
+    Lev<FirBJob> af_dec, af_hpf;
+    Lev<PolyJob> af_poly;
+    Lev<DeempJob> af_deemp;
+    Lev<SsbRotXJob> ssbx_l;
+    Lev<CarryJob> carry;  // history carries at the level of the stream's consumer (a pass without pipelining: all at the last level)
+    const bool ticking = c->tick_planning;
+    const int carry_last = kLevels - 1;
+    carry.add(ticking ? 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
     int max_rot = 0;
 
     for (auto& kv : c->vfos) {
         Vfo& v = *kv.second;
         Stream* cur = &v.st[(size_t)v.i_first];
+        int lvl = 1;  // level at which `cur` is written
+        for (auto& s : v.st) { s.clevel = 0; }
         // reference-block ends carried stage by stage down to the demodulator's rate, for the block-dependent operations there
         // (AGC look-ahead, SSB rotator calls)
         const bool agc_mode = v.d.demod == SDRPP_DEMOD_AM || (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB);
@@ -1147,7 +1438,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         // the FM back end as one pipelined launch: last decimator, resampler, channel filter, discriminator + audio low-pass all in
         // their matrix form, and the pipeline's LDS layout fits
         const int last_dec = v.d.n_stages - 1;
-        bool piped_be = c->pipe_on && (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) && last_dec >= first_sep && v.tp_stage[last_dec].ok &&
+        bool piped_be = c->pipe_on && !ticking && (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) && last_dec >= first_sep && v.tp_stage[last_dec].ok &&
                         v.i_poly >= 0 && v.tp_poly.ok && v.i_chan >= 0 && v.chan_ntaps > 0 && v.tp_chan.ok && v.tp_audio.ok;
         PipeJob pj{};
         size_t pj_lds = 0;
@@ -1163,13 +1454,16 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             const int Ds = v.d.stage_decim[s];
             const int no = decim_nout(cur->n, v.soff[s], Ds);
             if (need_bnd) { bounds_decim(bnd, v.soff[s], Ds); }
+            lvl++;
+            cur->clevel = lvl;
             if (piped_be && s == last_dec) {
                 pj.st[0] = toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f);
                 pj.keep[0] = std::max(0, no - nxt->hist_len);
                 pj.dec_stage = s;
+                pj.lvl = lvl;
             }
-            else if (v.tp_stage[s].ok) { t_lvl[s].push_back(toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
-            else { lvl[s].push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
+            else if (v.tp_stage[s].ok) { t_dec.add(lvl, toep_job(v.tp_stage[s], 0, stream_in(*cur), nxt->data, v.soff[s] - (v.d.stage_ntaps[s] - 1), no, 0.0f)); }
+            else { f_dec.add(lvl, FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
             v.soff[s] = v.soff[s] + no * Ds - cur->n;
             nxt->n = no;
             cur = nxt;
@@ -1178,17 +1472,19 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
             if (need_bnd) { bounds_poly(bnd, v.poff, v.pphase, v.d.interp, v.d.decim); }
+            lvl++;
+            cur->clevel = lvl;
             if (piped_be) {
                 pj.st[1] = toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f);
                 pj.keep[1] = std::max(0, no - nxt->hist_len);
             }
-            else if (v.tp_poly.ok) { t_poly.push_back(toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
+            else if (v.tp_poly.ok) { t_poly.add(lvl, toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
             else if (v.d_cyc) {
-                polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].push_back(PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
+                polyb[(v.cyc_lmax == 4 ? 0 : 1) + ((v.d.decim & 1) ? 2 : 0)].add(lvl, PolyBJob{ stream_in(*cur), (float2*)nxt->data, v.d_cyc + (size_t)v.pphase * v.cyc_rows * v.cyc_lmax, v.d.interp, v.d.decim,
                                                                   v.tpp, v.poff, no, v.cyc_rows });
             }
             else {
-                poly.push_back(PolyJob{ stream_in(*cur), (float2*)nxt->data, v.d_bank, v.d.interp, v.d.decim, v.tpp, v.pphase, v.poff, no });
+                poly.add(lvl, PolyJob{ stream_in(*cur), (float2*)nxt->data, v.d_bank, v.d.interp, v.d.decim, v.tpp, v.pphase, v.poff, no });
             }
             const long long A = (long long)v.pphase + (long long)no * v.d.decim;
             v.pphase = (int)(A % v.d.interp);
@@ -1198,16 +1494,20 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
+            lvl++;
+            cur->clevel = lvl;
             if (piped_be) {
                 pj.st[2] = toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f);
                 pj.keep[2] = 0;  // the IF stream is the RxVFO's output: all of it
             }
-            else if (v.tp_chan.ok) { t_chan.push_back(toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
-            else { chan.push_back(FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
+            else if (v.tp_chan.ok) { t_chan.add(lvl, toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
+            else { chan.add(lvl, FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
             cur = nxt;
         }
         v.i_if = (int)(cur - &v.st[0]);
+        v.lvl_if = lvl;
+        v.lvl_out = lvl;
         const int nif = cur->n;
         AgcState* agc = (AgcState*)v.d_state;
         float* dc = (float*)(v.d_state + 2 * sizeof(AgcState));
@@ -1219,33 +1519,41 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         const int nbnd = need_bnd ? (int)bnd.size() : 0;
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
+            lvl++;
+            cur->clevel = lvl;
             if (piped_be) {
                 pj.st[3] = toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation);
                 pipes.push_back(pj);
                 pipe_lds = std::max(pipe_lds, pj_lds);
             }
-            else if (v.tp_audio.ok) { t_audio_fm.push_back(toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
-            else { audio_fm.push_back(FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
+            else if (v.tp_audio.ok) { t_audio_fm.add(lvl, toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
+            else { audio_fm.add(lvl, FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
+            v.lvl_out = lvl;
         }
         else if (v.d.demod == SDRPP_DEMOD_AM) {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            if (!v.d.am_carrier_agc) { pre.push_back(PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
-            seq.push_back(SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, d_bnd, nbnd });
+            if (!v.d.am_carrier_agc) { pre.add(lvl + 1, PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
+            seq.add(lvl + 2, SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, d_bnd, nbnd });
             dem.n = nif;
-            if (v.tp_audio.ok) { t_audio.push_back(toep_job(v.tp_audio, 0, stream_in(dem), out.data, -(v.audio_ntaps - 1), nif, 0.0f)); }
-            else { audio.push_back(FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp }); }
+            lvl += 3;
+            dem.clevel = lvl;
+            if (v.tp_audio.ok) { t_audio.add(lvl, toep_job(v.tp_audio, 0, stream_in(dem), out.data, -(v.audio_ntaps - 1), nif, 0.0f)); }
+            else { audio.add(lvl, FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp }); }
             out.n = nif;
+            v.lvl_out = lvl;
         }
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            if (c->nco_exact) { ssbx.push_back(SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
-            else { pre.push_back(PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 }); }
-            seq.push_back(SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0, d_bnd, nbnd });
+            if (c->nco_exact) { ssbx_l.add(lvl + 1, SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
+            else { pre.add(lvl + 1, PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 }); }
+            seq.add(lvl + 2, SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0, d_bnd, nbnd });
+            lvl += 2;
             dem.n = 0;  // scratch only
             out.n = nif;
+            v.lvl_out = lvl;
             double p2 = v.phi2 + (double)nif * v.theta2;
             v.phi2 = p2 - std::floor(p2);
         }
@@ -1256,8 +1564,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
                 Stream* nxt = &v.st[(size_t)a.i_stage0 + s];
                 const int Ds = a.decim_s[s], K = (int)a.staps[s].size();
                 const int no = decim_nout(acur->n, a.soff[s], Ds);
-                if (a.tp_stage[s].ok) { t_af_lvl[s].push_back(toep_job(a.tp_stage[s], 0, stream_in(*acur), nxt->data, a.soff[s] - (K - 1), no, 0.0f)); }
-                else { af_lvl[s].push_back(FirBJob{ stream_in(*acur), nxt->data, a.d_staps[s], K, ilog2(Ds), a.soff[s], no, a.s_kp[s] }); }
+                lvl++;
+                acur->clevel = lvl;
+                if (a.tp_stage[s].ok) { t_af_dec.add(lvl, toep_job(a.tp_stage[s], 0, stream_in(*acur), nxt->data, a.soff[s] - (K - 1), no, 0.0f)); }
+                else { af_dec.add(lvl, FirBJob{ stream_in(*acur), nxt->data, a.d_staps[s], K, ilog2(Ds), a.soff[s], no, a.s_kp[s] }); }
                 a.soff[s] = a.soff[s] + no * Ds - acur->n;
                 nxt->n = no;
                 acur = nxt;
@@ -1265,8 +1575,10 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (a.i_poly >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_poly];
                 const int no = poly_nout(acur->n, a.poff, a.pphase, a.interp, a.decim);
-                if (a.tp_poly.ok) { t_af_poly.push_back(toep_job(a.tp_poly, a.pphase, stream_in(*acur), nxt->data, a.poff - (a.tpp - 1), no, 0.0f)); }
-                else { af_poly.push_back(PolyJob{ stream_in(*acur), (float2*)nxt->data, a.d_bank, a.interp, a.decim, a.tpp, a.pphase, a.poff, no }); }
+                lvl++;
+                acur->clevel = lvl;
+                if (a.tp_poly.ok) { t_af_poly.add(lvl, toep_job(a.tp_poly, a.pphase, stream_in(*acur), nxt->data, a.poff - (a.tpp - 1), no, 0.0f)); }
+                else { af_poly.add(lvl, PolyJob{ stream_in(*acur), (float2*)nxt->data, a.d_bank, a.interp, a.decim, a.tpp, a.pphase, a.poff, no }); }
                 const long long A = (long long)a.pphase + (long long)no * a.decim;
                 a.pphase = (int)(A % a.interp);
                 a.poff = a.poff + (int)(A / a.interp) - acur->n;
@@ -1276,17 +1588,21 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (a.i_hpf >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_hpf];
                 const int K = (int)a.htaps.size();
-                if (a.tp_hpf.ok) { t_af_hpf.push_back(toep_job(a.tp_hpf, 0, stream_in(*acur), nxt->data, -(K - 1), acur->n, 0.0f)); }
-                else { af_hpf.push_back(FirBJob{ stream_in(*acur), nxt->data, a.d_hpf, K, 0, 0, acur->n, a.hpf_kp }); }
+                lvl++;
+                acur->clevel = lvl;
+                if (a.tp_hpf.ok) { t_af_hpf.add(lvl, toep_job(a.tp_hpf, 0, stream_in(*acur), nxt->data, -(K - 1), acur->n, 0.0f)); }
+                else { af_hpf.add(lvl, FirBJob{ stream_in(*acur), nxt->data, a.d_hpf, K, 0, 0, acur->n, a.hpf_kp }); }
                 nxt->n = acur->n;
                 acur = nxt;
             }
             if (a.i_deemp >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_deemp];
-                af_deemp.push_back(DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last, a.d_seg,
+                lvl++;
+                af_deemp.add(lvl, DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last, a.d_seg,
                                              std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG), 0 });
                 nxt->n = acur->n;
                 acur = nxt;
+                lvl += 2;  // (the de-emphasis is three dependent launches)
             }
             a.i_last = (int)(acur - &v.st[0]);
         }
@@ -1295,8 +1611,14 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         v.seen += n_in;
         // history carries for every stream that has a consumer with memory
         for (auto& s : v.st) {
-            if (s.hist_len > 0 && s.data) { carry.push_back(CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len }); }
+            if (s.hist_len > 0 && s.data) {
+                // pipelined: at the level of the consumer (its window of the NEXT block reads the new history one tick later, the carry of
+                // the next block overwrites the old one one tick later still); a stream nobody reads with memory: behind the whole chain
+                const int cl = !ticking ? carry_last : (s.clevel > 0 ? s.clevel : lvl + 1);
+                carry.add(cl, CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len });
+            }
         }
+        c->plan_top = std::max(c->plan_top, lvl + 2);
     }
 
     // ---- stage 1 (optionally fused with stage 2): group VFOs with identical geometry, VT per job ----
@@ -1525,7 +1847,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         i = j;
     }
 
-    // ---- upload all job arrays in one copy ----
+    // ---- job tables into the arena (one upload for the whole block) ----
     Stage1Job* d_s1[4] = {};
     for (int k = 0; k < 4; k++) {
         if (!s1l[k].jobs.empty()) {
@@ -1550,83 +1872,46 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
             if (!d_fcm[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         }
     }
-    // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
     RotXJob* d_rotx = arena_push(c, rotx);
-    SsbRotXJob* d_ssbx = arena_push(c, ssbx);
     RetuneJob* d_retune = arena_push(c, retune);
+    RotJob* d_rot = arena_push(c, rot);
     const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
-    if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!ssbx.empty() && !d_ssbx) || (!retune.empty() && !d_retune)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!retune.empty() && !d_retune) || (!rot.empty() && !d_rot)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     const int pipe_seg = pipe_segments(pipes, c->pipe_on, pipe_lds);
+    int pipe_lvl = 0;
     if (!pipes.empty() && pipe_seg == 0) {  // not this push: the same four jobs go to the separate launches
         for (auto& pj : pipes) {
-            for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-                if (pj.dec_stage == s) { t_lvl[s].push_back(pj.st[0]); }
-            }
-            t_poly.push_back(pj.st[1]);
-            t_chan.push_back(pj.st[2]);
-            t_audio_fm.push_back(pj.st[3]);
+            t_dec.add(pj.lvl, pj.st[0]);
+            t_poly.add(pj.lvl + 1, pj.st[1]);
+            t_chan.add(pj.lvl + 2, pj.st[2]);
+            t_audio_fm.add(pj.lvl + 3, pj.st[3]);
         }
         pipes.clear();
     }
-    ToepPlan tp_lvl[SDRPP_MAX_DECIM_STAGES];
-    ToepJob* d_t_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-        tp_lvl[s] = toep_plan(t_lvl[s], 2);
-        d_t_lvl[s] = arena_push(c, t_lvl[s]);
-        if (!t_lvl[s].empty() && !d_t_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    }
-    const ToepPlan tp_poly = toep_plan(t_poly, 2), tp_chan = toep_plan(t_chan, 2), tp_audio = toep_plan(t_audio, 1), tp_audio_fm = toep_plan(t_audio_fm, 2);
+    for (auto& pj : pipes) { pipe_lvl = std::max(pipe_lvl, pj.lvl); }  // (one launch: at the latest level any of its jobs starts at)
     PipeJob* d_pipes = arena_push(c, pipes);
     if (!pipes.empty() && !d_pipes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    ToepJob* d_t_poly = arena_push(c, t_poly);
-    ToepJob* d_t_chan = arena_push(c, t_chan);
-    ToepJob* d_t_audio = arena_push(c, t_audio);
-    ToepJob* d_t_audio_fm = arena_push(c, t_audio_fm);
-    if ((!t_poly.empty() && !d_t_poly) || (!t_chan.empty() && !d_t_chan) || (!t_audio.empty() && !d_t_audio) || (!t_audio_fm.empty() && !d_t_audio_fm)) {
+    // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
+    struct ToepList { Lev<ToepJob>* L; int npl, width; bool quad; int fam; int role; };
+    ToepList tlists[] = { { &t_dec, 2, 2, false, F_DECIM, TR_TOEP_C },      { &t_poly, 2, 2, false, F_POLY, TR_TOEP_C },       { &t_chan, 2, 2, false, F_FIR, TR_TOEP_C },
+                          { &t_audio, 1, 1, false, F_FIR, TR_TOEP_R },      { &t_audio_fm, 2, 1, true, F_FIR, TR_TOEP_Q },     { &t_af_dec, 2, 2, false, F_AF, TR_TOEP_C },
+                          { &t_af_poly, 2, 2, false, F_AF, TR_TOEP_C },     { &t_af_hpf, 2, 2, false, F_AF, TR_TOEP_C } };
+    constexpr int kToepLists = (int)(sizeof(tlists) / sizeof(tlists[0]));
+    ToepPlan tplan[kToepLists][kLevels];
+    for (int i = 0; i < kToepLists; i++) {
+        Lev<ToepJob>& L = *tlists[i].L;
+        for (int l = 0; l < L.top; l++) {
+            if (L.at[l].empty()) { continue; }
+            tplan[i][l] = toep_plan(L.at[l], tlists[i].npl);
+            if (tplan[i][l].lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS"); }
+        }
+        if (!arena_push_lev(c, L)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    }
+    if (!arena_push_lev(c, f_dec) || !arena_push_lev(c, poly) || !arena_push_lev(c, polyb[0]) || !arena_push_lev(c, polyb[1]) || !arena_push_lev(c, polyb[2]) ||
+        !arena_push_lev(c, polyb[3]) || !arena_push_lev(c, chan) || !arena_push_lev(c, seq) || !arena_push_lev(c, pre) || !arena_push_lev(c, audio) ||
+        !arena_push_lev(c, audio_fm) || !arena_push_lev(c, af_dec) || !arena_push_lev(c, af_hpf) || !arena_push_lev(c, af_poly) || !arena_push_lev(c, af_deemp) ||
+        !arena_push_lev(c, ssbx_l) || !arena_push_lev(c, carry)) {
         return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
-    }
-    if (std::max({ tp_poly.lds, tp_chan.lds, tp_audio.lds, tp_audio_fm.lds, tp_lvl[0].lds, tp_lvl[1].lds, tp_lvl[2].lds, tp_lvl[3].lds }) > (size_t)kMaxLds) {
-        return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS");
-    }
-    ToepPlan tp_af_lvl[SDRPP_MAX_DECIM_STAGES];
-    ToepJob* d_t_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    FirBJob* d_af_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-        tp_af_lvl[s] = toep_plan(t_af_lvl[s], 2);
-        d_t_af_lvl[s] = arena_push(c, t_af_lvl[s]);
-        d_af_lvl[s] = arena_push(c, af_lvl[s]);
-        if ((!t_af_lvl[s].empty() && !d_t_af_lvl[s]) || (!af_lvl[s].empty() && !d_af_lvl[s])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    }
-    const ToepPlan tp_af_poly = toep_plan(t_af_poly, 2), tp_af_hpf = toep_plan(t_af_hpf, 2);
-    ToepJob* d_t_af_poly = arena_push(c, t_af_poly);
-    ToepJob* d_t_af_hpf = arena_push(c, t_af_hpf);
-    PolyJob* d_af_poly = arena_push(c, af_poly);
-    FirBJob* d_af_hpf = arena_push(c, af_hpf);
-    DeempJob* d_af_deemp = arena_push(c, af_deemp);
-    if ((!t_af_poly.empty() && !d_t_af_poly) || (!t_af_hpf.empty() && !d_t_af_hpf) || (!af_poly.empty() && !d_af_poly) || (!af_hpf.empty() && !d_af_hpf) ||
-        (!af_deemp.empty() && !d_af_deemp)) {
-        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
-    }
-    RotJob* d_rot = arena_push(c, rot);
-    FirBJob* d_lvl[SDRPP_MAX_DECIM_STAGES] = {};
-    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { d_lvl[s] = arena_push(c, lvl[s]); }
-    PolyJob* d_poly = arena_push(c, poly);
-    PolyBJob* d_polyb[4] = { arena_push(c, polyb[0]), arena_push(c, polyb[1]), arena_push(c, polyb[2]), arena_push(c, polyb[3]) };
-    FirBJob* d_chan = arena_push(c, chan);
-    SeqJob* d_seq = arena_push(c, seq);
-    PreJob* d_pre = arena_push(c, pre);
-    if (!pre.empty() && !d_pre) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    FirBJob* d_audio = arena_push(c, audio);
-    FirBJob* d_audio_fm = arena_push(c, audio_fm);
-    if (!audio_fm.empty() && !d_audio_fm) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    CarryJob* d_carry = arena_push(c, carry);
-    if ((!polyb[0].empty() && !d_polyb[0]) || (!polyb[1].empty() && !d_polyb[1]) || (!polyb[2].empty() && !d_polyb[2]) || (!polyb[3].empty() && !d_polyb[3])) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    if ((!rot.empty() && !d_rot) || (!poly.empty() && !d_poly) || (!chan.empty() && !d_chan) || (!seq.empty() && !d_seq) ||
-        (!audio.empty() && !d_audio) || (!carry.empty() && !d_carry)) {
-        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
-    }
-    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-        if (!lvl[s].empty() && !d_lvl[s]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     }
     int rc;
     {
@@ -1635,7 +1920,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
     }
     if (rc) { return rc; }
 
-    // ---- launches ----
+    // ---- level 1: the front end ----
     {
         FamilyTimer t(c, F_S1);
         if (!rotx.empty() && n_in > 0) {
@@ -1684,30 +1969,24 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         }
         for (int k = 0; k < 3; k++) {
             if (fcm[k].jobs.empty() || fcm[k].max_blocks == 0) { continue; }
-            const dim3 grid((unsigned)fcm[k].max_blocks, (unsigned)fcm[k].jobs.size());
             bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
             for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
-            if (k == 1 && all_132_4) { launch(c, vfo_frontcm_kernel<10, 132, 4>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
-            else if (k == 0) { launch(c, vfo_frontcm_kernel<6, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
-            else if (k == 1) { launch(c, vfo_frontcm_kernel<10, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
-            else { launch(c, vfo_frontcm_kernel<16, 0, 0>, grid, dim3(256), fcm[k].lds, src, (const FrontCMJob*)d_fcm[k]); }
+            const int role = (k == 1 && all_132_4) ? TR_FCM_132_4 : (k == 0 ? TR_FCM_6 : (k == 1 ? TR_FCM_10 : TR_FCM_16));
+            emit(c, 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
         }
         if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
             bool pf_ok = true;  // every window of the launch fits the register prefetch
             for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
-            if (pf_ok) { launch(c, vfo_frontcl_kernel<SDRPP_FCL_PF>, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl); }
-            else { launch(c, vfo_frontcl_kernel<0>, dim3((unsigned)fcl.max_blocks, (unsigned)fcl.jobs.size()), dim3(128), fcl.lds, src, (const FrontCMJob*)d_fcl); }
+            emit(c, 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
         }
-        if (!rot.empty() && max_rot > 0) {
-            launch(c, vfo_rotate_kernel, dim3(std::min((max_rot + 255) / 256, 4096), (unsigned)rot.size()), dim3(256), 0, src, (const RotJob*)d_rot);
-        }
+        if (!rot.empty() && max_rot > 0) { emit(c, 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
         if (!retune.empty()) {
             int mx = 0;
             for (auto& r : retune) { mx = std::max(mx, r.nfix); }
             launch(c, vfo_retune_fix_kernel, dim3((unsigned)mx, (unsigned)retune.size()), dim3(64), 0, src, (const RetuneJob*)d_retune);
         }
     }
-    auto launch_fir = [&](std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) -> int {
+    auto launch_fir = [&](int level, int fam, std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) -> int {
         if (jobs.empty()) { return SDRPP_OK; }
         const int R = SDRPP_FIR_R;
         int max_nout = 0, threads = 256;
@@ -1738,11 +2017,7 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         size_t lds = 0;
         for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
         const int tile = threads * R;
-        const dim3 grid((max_nout + tile - 1) / tile, (unsigned)jobs.size());
-        if (width == 2) { launch(c, vfo_firb_kernel<2, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
-        else if (quad) { launch(c, vfo_firb_kernel<1, true, true>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
-        else if (stereo) { launch(c, vfo_firb_kernel<1, true>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
-        else { launch(c, vfo_firb_kernel<1, false>, grid, dim3(threads), lds, (const FirBJob*)d_jobs); }
+        emit(c, level, fam, width == 2 ? TR_FIRB_C : (quad ? TR_FIRB_Q : (stereo ? TR_FIRB_S : TR_FIRB_R)), (max_nout + tile - 1) / tile, (int)jobs.size(), lds, d_jobs, nullptr, threads);
         return SDRPP_OK;
     };
     // resamplers with many phases (L > 8, e.g. 96/125): cycle-major kernel — one LDS window serves all L phases of up to 64 cycles;
@@ -1774,120 +2049,151 @@ int do_vfos(sdrpp_ctx* c, const IqSrc& src, int64_t count, std::vector<CarryJob>
         launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
         return SDRPP_OK;
     };
-    {
-        FamilyTimer t(c, F_DECIM);
-        for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-            launch_toep(c, t_lvl[s], d_t_lvl[s], tp_lvl[s], 2, false);
-            rc = launch_fir(lvl[s], d_lvl[s], 2, false);
-            if (rc) { return rc; }
-        }
-    }
-    if (!pipes.empty()) {
-        FamilyTimer t(c, F_PIPE);
-        c->pipe_launched = true;
-        launch(c, vfo_pipe_kernel<kPipeG>, dim3((unsigned)pipe_seg, (unsigned)pipes.size()), dim3(256), pipe_lds, (const PipeJob*)d_pipes);
-    }
-    if (!t_poly.empty()) {
-        FamilyTimer t(c, F_POLY);
-        launch_toep(c, t_poly, d_t_poly, tp_poly, 2, false);
-    }
-    if (!poly.empty()) {
-        FamilyTimer t(c, F_POLY);
-        rc = launch_polyc(poly, d_poly);
-        if (rc) { return rc; }
-    }
-    for (int li = 0; li < 4; li++) {
-        if (polyb[li].empty()) { continue; }
-        FamilyTimer t(c, F_POLY);
+    auto launch_polyb = [&](int li, std::vector<PolyBJob>& jobs, PolyBJob* d_jobs) -> int {
+        if (jobs.empty()) { return SDRPP_OK; }
         int max_cycles = 0, threads = 256;
         size_t lds = 0;
         auto lds_for = [&](const PolyBJob& jb, int nt) { return (size_t)jb.decim * (size_t)(nt + jb.rows / jb.decim + 2) * sizeof(float2); };
-        for (auto& jb : polyb[li]) {
+        for (auto& jb : jobs) {
             max_cycles = std::max(max_cycles, (jb.nout + jb.interp - 1) / jb.interp);
             int nt = 256;
             while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
             if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
             threads = std::min(threads, nt);
         }
-        if (max_cycles == 0) { continue; }
-        while (threads > 64 && (size_t)((max_cycles + threads - 1) / threads) * polyb[li].size() < 2048) { threads >>= 1; }
-        for (auto& jb : polyb[li]) { lds = std::max(lds, lds_for(jb, threads)); }
-        const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)polyb[li].size());
-        if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[0]); }
-        else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[1]); }
-        else if (li == 2) { launch(c, vfo_polyb_kernel<4, true>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[2]); }
-        else { launch(c, vfo_polyb_kernel<8, true>, grid, dim3(threads), lds, (const PolyBJob*)d_polyb[3]); }
-    }
-    {
-        FamilyTimer t(c, F_FIR);
-        launch_toep(c, t_chan, d_t_chan, tp_chan, 2, false);
-        rc = launch_fir(chan, d_chan, 2, false);
-        if (rc) { return rc; }
-    }
-    if (!pre.empty() || !seq.empty() || !ssbx.empty()) {
-        FamilyTimer t(c, F_DEMOD);
-        if (!ssbx.empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx.size()), dim3(64), 0, (const SsbRotXJob*)d_ssbx); }
-        if (!pre.empty()) {
-            int mx = 0;
-            for (auto& q : pre) { mx = std::max(mx, q.n); }
-            if (mx > 0) { launch(c, vfo_demod_pre_kernel, dim3(std::min((mx + 255) / 256, 1024), (unsigned)pre.size()), dim3(256), 0, (const PreJob*)d_pre); }
-        }
-        if (!seq.empty()) { launch(c, vfo_sequential_kernel, dim3((unsigned)seq.size()), dim3(64), 0, (const SeqJob*)d_seq, (int)seq.size()); }
-    }
-    {
-        FamilyTimer t(c, F_FIR);
-        launch_toep(c, t_audio, d_t_audio, tp_audio, 1, false);
-        launch_toep(c, t_audio_fm, d_t_audio_fm, tp_audio_fm, 1, true);
-        rc = launch_fir(audio, d_audio, 1, true);
-        if (rc) { return rc; }
-        rc = launch_fir(audio_fm, d_audio_fm, 1, true, true);
-        if (rc) { return rc; }
-    }
-    bool any_af = !af_deemp.empty() || !af_poly.empty() || !t_af_poly.empty() || !af_hpf.empty() || !t_af_hpf.empty();
-    for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { any_af = any_af || !af_lvl[s].empty() || !t_af_lvl[s].empty(); }
-    if (any_af) {
-        FamilyTimer t(c, F_AF);
-        for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) {
-            launch_toep(c, t_af_lvl[s], d_t_af_lvl[s], tp_af_lvl[s], 2, false);
-            rc = launch_fir(af_lvl[s], d_af_lvl[s], 2, false);
-            if (rc) { return rc; }
-        }
-        launch_toep(c, t_af_poly, d_t_af_poly, tp_af_poly, 2, false);
-        rc = launch_polyc(af_poly, d_af_poly);
-        if (rc) { return rc; }
-        launch_toep(c, t_af_hpf, d_t_af_hpf, tp_af_hpf, 2, false);
-        rc = launch_fir(af_hpf, d_af_hpf, 2, false);
-        if (rc) { return rc; }
-        if (!af_deemp.empty()) {
-            int max_seg = 0;
-            for (auto& jb : af_deemp) { max_seg = std::max(max_seg, jb.nseg); }
-            if (max_seg > 0) {
-                const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.size());
-                launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
-                launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)d_af_deemp);
-                launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.size() + 63) / 64), dim3(64), 0, (const DeempJob*)d_af_deemp, (int)af_deemp.size());
-            }
-        }
-    }
-    if (!carry.empty()) {
-        FamilyTimer t(c, F_MISC);
-        // job 0 = the shared IQ stream (up to a whole FFT frame long), the per-VFO histories are a few hundred samples: a long IQ carry
-        // gets its own wide grid, otherwise one launch serves all jobs (every block strides over its job)
-        const int iq_elems = carry[0].need * carry[0].width;
+        if (max_cycles == 0) { return SDRPP_OK; }
+        while (threads > 64 && (size_t)((max_cycles + threads - 1) / threads) * jobs.size() < 2048) { threads >>= 1; }
+        for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
+        const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)jobs.size());
+        if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+        else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+        else if (li == 2) { launch(c, vfo_polyb_kernel<4, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+        else { launch(c, vfo_polyb_kernel<8, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+        return SDRPP_OK;
+    };
+    auto emit_toep = [&](int i, int l) {
+        Lev<ToepJob>& L = *tlists[i].L;
+        if (l >= L.top || L.at[l].empty() || tplan[i][l].grid_x == 0) { return; }
+        emit(c, l, tlists[i].fam, tlists[i].role, tplan[i][l].grid_x, (int)L.at[l].size(), tplan[i][l].lds, L.dev[l]);
+    };
+    // the history carries of one level: job 0 of the IQ stream's level is the shared IQ stream (up to a whole FFT frame long), the per-VFO
+    // histories are a few hundred samples
+    auto launch_carry = [&](int l) {
+        std::vector<CarryJob>& cj = carry.at[l];
+        if (cj.empty()) { return; }
+        const bool has_iq = (l == (ticking ? 1 : carry_last));
+        const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
         int mx = 0;
-        for (size_t k = 1; k < carry.size(); k++) { mx = std::max(mx, carry[k].need * carry[k].width); }
-        if (iq_elems > 16384 && carry.size() > 1 && iq_elems > 128 * 1024 * 2) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
-            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
-            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)carry.size() - 1), dim3(256), 0, (const CarryJob*)(d_carry + 1));
+        for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }
+        if (iq_elems > 128 * 1024 * 2 && cj.size() > 1) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
+            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1, 0, carry.dev[l]);
+            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 255) / 256, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
         }
-        else if (iq_elems > 16384 && carry.size() > 1) {
+        else if (iq_elems > 16384 && cj.size() > 1) {
             // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
             // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
-            launch(c, carry_kernel, dim3(128, (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+            emit(c, l, F_MISC, TR_CARRY, 128, (int)cj.size(), 0, carry.dev[l]);
         }
         else {
             mx = std::max(mx, iq_elems);
-            launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((mx + 1023) / 1024, 2048)), (unsigned)carry.size()), dim3(256), 0, (const CarryJob*)d_carry);
+            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 2048)), (int)cj.size(), 0, carry.dev[l]);
+        }
+    };
+
+    // ---- levels 2 ...: everything behind the front end, level by level (within a level the launches are independent of each other) ----
+    int top = std::max({ t_dec.top, t_poly.top, t_chan.top, t_audio.top, t_audio_fm.top, t_af_dec.top, t_af_poly.top, t_af_hpf.top, f_dec.top, poly.top,
+                         polyb[0].top, polyb[1].top, polyb[2].top, polyb[3].top, chan.top, seq.top, pre.top, audio.top, audio_fm.top, af_dec.top, af_hpf.top,
+                         af_poly.top, af_deemp.top, ssbx_l.top, carry.top, pipe_lvl + 1 });
+    for (int l = 1; l < top; l++) {
+        {
+            FamilyTimer t(c, F_DECIM);
+            emit_toep(0, l);
+            if (l < f_dec.top) {
+                rc = launch_fir(l, F_DECIM, f_dec.at[l], f_dec.dev[l], 2, false);
+                if (rc) { return rc; }
+            }
+        }
+        if (!pipes.empty() && l == pipe_lvl) {
+            FamilyTimer t(c, F_PIPE);
+            c->pipe_launched = true;
+            launch(c, vfo_pipe_kernel<kPipeG>, dim3((unsigned)pipe_seg, (unsigned)pipes.size()), dim3(256), pipe_lds, (const PipeJob*)d_pipes);
+        }
+        {
+            FamilyTimer t(c, F_POLY);
+            emit_toep(1, l);
+            if (l < poly.top) {
+                rc = launch_polyc(poly.at[l], poly.dev[l]);
+                if (rc) { return rc; }
+            }
+            for (int li = 0; li < 4; li++) {
+                if (l < polyb[li].top) {
+                    rc = launch_polyb(li, polyb[li].at[l], polyb[li].dev[l]);
+                    if (rc) { return rc; }
+                }
+            }
+        }
+        {
+            FamilyTimer t(c, F_FIR);
+            emit_toep(2, l);
+            if (l < chan.top) {
+                rc = launch_fir(l, F_FIR, chan.at[l], chan.dev[l], 2, false);
+                if (rc) { return rc; }
+            }
+        }
+        if ((l < pre.top && !pre.at[l].empty()) || (l < seq.top && !seq.at[l].empty()) || (l < ssbx_l.top && !ssbx_l.at[l].empty())) {
+            FamilyTimer t(c, F_DEMOD);
+            if (l < ssbx_l.top && !ssbx_l.at[l].empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx_l.at[l].size()), dim3(64), 0, (const SsbRotXJob*)ssbx_l.dev[l]); }
+            if (l < pre.top && !pre.at[l].empty()) {
+                int mx = 0;
+                for (auto& q : pre.at[l]) { mx = std::max(mx, q.n); }
+                if (mx > 0) { emit(c, l, F_DEMOD, TR_PRE, std::min((mx + 255) / 256, 1024), (int)pre.at[l].size(), 0, pre.dev[l]); }
+            }
+            if (l < seq.top && !seq.at[l].empty()) { emit(c, l, F_DEMOD, TR_SEQ, (int)seq.at[l].size(), 1, 0, seq.dev[l], nullptr, (int)seq.at[l].size()); }
+        }
+        {
+            FamilyTimer t(c, F_FIR);
+            emit_toep(3, l);
+            emit_toep(4, l);
+            if (l < audio.top) {
+                rc = launch_fir(l, F_FIR, audio.at[l], audio.dev[l], 1, true);
+                if (rc) { return rc; }
+            }
+            if (l < audio_fm.top) {
+                rc = launch_fir(l, F_FIR, audio_fm.at[l], audio_fm.dev[l], 1, true, true);
+                if (rc) { return rc; }
+            }
+        }
+        if (l < std::max({ t_af_dec.top, t_af_poly.top, t_af_hpf.top, af_dec.top, af_hpf.top, af_poly.top, af_deemp.top })) {
+            FamilyTimer t(c, F_AF);
+            emit_toep(5, l);
+            if (l < af_dec.top) {
+                rc = launch_fir(l, F_AF, af_dec.at[l], af_dec.dev[l], 2, false);
+                if (rc) { return rc; }
+            }
+            emit_toep(6, l);
+            if (l < af_poly.top) {
+                rc = launch_polyc(af_poly.at[l], af_poly.dev[l]);
+                if (rc) { return rc; }
+            }
+            emit_toep(7, l);
+            if (l < af_hpf.top) {
+                rc = launch_fir(l, F_AF, af_hpf.at[l], af_hpf.dev[l], 2, false);
+                if (rc) { return rc; }
+            }
+            if (l < af_deemp.top && !af_deemp.at[l].empty()) {
+                int max_seg = 0;
+                for (auto& jb : af_deemp.at[l]) { max_seg = std::max(max_seg, jb.nseg); }
+                if (max_seg > 0) {
+                    const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.at[l].size());
+                    launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
+                    launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
+                    launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.at[l].size() + 63) / 64), dim3(64), 0, (const DeempJob*)af_deemp.dev[l], (int)af_deemp.at[l].size());
+                }
+            }
+        }
+        if (l < carry.top && !carry.at[l].empty()) {
+            FamilyTimer t(c, F_MISC);
+            launch_carry(l);
         }
     }
     // flip the ping-pong side of every carried stream
@@ -1988,6 +2294,90 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
     return SDRPP_OK;
 }
 
+// ---- streaming state that planning a block changes, for roll-back: a block either happens completely or not at all ----------------------
+struct PlanSnapshot {
+    struct V { int soff[SDRPP_MAX_DECIM_STAGES]; int pphase, poff; double phi, phi2; long long seen; int i_if, lvl_if, lvl_out; int n[24], cur[24]; size_t nrecs;
+               int af_soff[SDRPP_MAX_DECIM_STAGES], af_pphase, af_poff, af_last; };
+    std::vector<V> v;
+    int64_t fft_pos, fft_next;
+    int n_lines, iq_cur, wf_cur, wf_lines;
+    bool wf_have;
+    int pre_soff[SDRPP_MAX_DECIM_STAGES];
+};
+void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
+    S.v.resize(c->vfos.size());
+    size_t i = 0;
+    for (auto& kv : c->vfos) {
+        Vfo& v = *kv.second;
+        PlanSnapshot::V& q = S.v[i++];
+        for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { q.soff[k] = v.soff[k]; q.af_soff[k] = v.af.soff[k]; }
+        q.pphase = v.pphase; q.poff = v.poff; q.phi = v.phi; q.phi2 = v.phi2; q.seen = v.seen; q.i_if = v.i_if; q.lvl_if = v.lvl_if; q.lvl_out = v.lvl_out;
+        q.nrecs = v.recs.size();
+        q.af_pphase = v.af.pphase; q.af_poff = v.af.poff; q.af_last = v.af.i_last;
+        for (size_t k = 0; k < v.st.size() && k < 24; k++) { q.n[k] = v.st[k].n; q.cur[k] = v.st[k].cur; }
+    }
+    S.fft_pos = c->fft_pos; S.fft_next = c->fft_next; S.n_lines = c->n_lines; S.iq_cur = c->iq_cur;
+    S.wf_cur = c->wf.cur; S.wf_lines = c->wf.lines; S.wf_have = c->wf.have_latest;
+    for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { S.pre_soff[k] = c->pre.soff[k]; }
+}
+// (retune records a plan has dropped stay dropped: they were out of every window's reach)
+void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
+    size_t i = 0;
+    for (auto& kv : c->vfos) {
+        Vfo& v = *kv.second;
+        const PlanSnapshot::V& q = S.v[i++];
+        for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { v.soff[k] = q.soff[k]; v.af.soff[k] = q.af_soff[k]; }
+        v.pphase = q.pphase; v.poff = q.poff; v.phi = q.phi; v.phi2 = q.phi2; v.seen = q.seen; v.i_if = q.i_if; v.lvl_if = q.lvl_if; v.lvl_out = q.lvl_out;
+        v.af.pphase = q.af_pphase; v.af.poff = q.af_poff; v.af.i_last = q.af_last;
+        for (size_t k = 0; k < v.st.size() && k < 24; k++) { v.st[k].n = q.n[k]; v.st[k].cur = q.cur[k]; }
+    }
+    c->fft_pos = S.fft_pos; c->fft_next = S.fft_next; c->n_lines = S.n_lines; c->iq_cur = S.iq_cur;
+    c->wf.cur = S.wf_cur; c->wf.lines = S.wf_lines; c->wf.have_latest = S.wf_have;
+    for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { c->pre.soff[k] = S.pre_soff[k]; }
+}
+
+void block_bounds(sdrpp_ctx* c, int64_t count, const std::vector<int>* push_ends) {
+    // the reference's blocks inside this push (sdrpp_set_reference_block): ends as cumulative sample counts
+    // every push is at least one block of its own; with a reference block size it is cut further
+    std::vector<int>& B = c->vfo_bounds;
+    B.clear();
+    const std::vector<int> whole{ (int)count };
+    int64_t lo = 0;
+    for (int e : (push_ends ? *push_ends : whole)) {
+        if (c->ref_block > 0) {
+            for (int64_t q = lo + c->ref_block; q < e; q += c->ref_block) { B.push_back((int)q); }
+        }
+        if (e > lo || B.empty()) { B.push_back(e); }
+        lo = e;
+    }
+}
+int iq_hist_need(sdrpp_ctx* c) {
+    int need_hist = 1;
+    if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
+    for (auto& kv : c->vfos) {
+        const sdrpp_vfo_desc& d = kv.second->d;
+        if (d.n_stages > 0) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1); }
+        if (d.n_stages > 1) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }  // fused front
+    }
+    return need_hist;
+}
+// what the NEXT push can reach back to: the samples of the frame in progress and the deepest stage-1 (+ fused stage-2) window
+CarryJob iq_carry_job(sdrpp_ctx* c, const float* d_iq, int64_t count) {
+    int need = 1;
+    if (c->fft_on) {
+        const int64_t P = (int64_t)c->nz + c->skip;
+        const int64_t partial = c->fft_pos - c->fft_next * P;  // do_fft already advanced both
+        if (partial > 0) { need = std::max(need, (int)std::min<int64_t>(partial, c->nz - 1)); }
+    }
+    for (auto& kv : c->vfos) {
+        const sdrpp_vfo_desc& d = kv.second->d;
+        if (d.n_stages > 0) { need = std::max(need, d.stage_ntaps[0] - 1); }
+        if (d.n_stages > 1) { need = std::max(need, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }
+    }
+    need = std::min(need, c->iq_hist_cap);
+    return CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2, need };
+}
+
 // `push_ends`: cumulative ends of the pushes a deferred pass combines (nullptr: the pass is one push)
 int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vector<int>* push_ends = nullptr) {
     if (count == 0) {  // an empty block produces nothing (and changes no state)
@@ -2003,23 +2393,15 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
         rc0 = arena_begin(c);
     }
     if (rc0) { return rc0; }
-    {   // the reference's blocks inside this push (sdrpp_set_reference_block): ends as cumulative sample counts
-        // every push is at least one block of its own; with a reference block size it is cut further
-        std::vector<int>& B = c->vfo_bounds;
-        B.clear();
-        const std::vector<int> whole{ (int)count };
-        int64_t lo = 0;
-        for (int e : (push_ends ? *push_ends : whole)) {
-            if (c->ref_block > 0) {
-                for (int64_t q = lo + c->ref_block; q < e; q += c->ref_block) { B.push_back((int)q); }
-            }
-            if (e > lo || B.empty()) { B.push_back(e); }
-            lo = e;
-        }
-    }
+    PlanSnapshot snap;
+    plan_snapshot(c, snap);
+    block_bounds(c, count, push_ends);
     if (c->pre.on) {
         rc0 = run_preproc(c, &d_iq, &count);
-        if (rc0) { return rc0; }
+        if (rc0) {
+            plan_restore(c, snap);
+            return rc0;
+        }
         if (count == 0) {  // the decimator swallowed the whole block (offset carried): nothing reaches the FFT / VFOs
             c->n_lines = 0;
             for (auto& kv : c->vfos) {
@@ -2028,15 +2410,11 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
             return arena_end(c);
         }
     }
-    int need_hist = 1;
-    if (c->fft_on) { need_hist = std::max(need_hist, c->nz - 1); }
-    for (auto& kv : c->vfos) {
-        const sdrpp_vfo_desc& d = kv.second->d;
-        if (d.n_stages > 0) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1); }
-        if (d.n_stages > 1) { need_hist = std::max(need_hist, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }  // fused front
+    int rc = ensure_iq_hist(c, iq_hist_need(c));
+    if (rc) {
+        plan_restore(c, snap);
+        return rc;
     }
-    int rc = ensure_iq_hist(c, need_hist);
-    if (rc) { return rc; }
     IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
     // fork: the FFT branch goes to its own stream and overlaps the VFO bank; both only read the IQ buffers
     // (a push that completes no frame launches nothing on the FFT branch: no fork / join either — each costs the main stream 5-9 us, and at
@@ -2058,45 +2436,360 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
         rc = do_fft(c, src, count);
     }
     c->launch_stream = c->stream;
-    if (rc) { return rc; }
-    if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->fft_stream)); }
-    std::vector<CarryJob> carry;
-    {   // what the NEXT push can reach back to: the samples of the frame in progress and the deepest stage-1 (+ fused stage-2) window
-        int need = 1;
-        if (c->fft_on) {
-            const int64_t P = (int64_t)c->nz + c->skip;
-            const int64_t partial = c->fft_pos - c->fft_next * P;  // do_fft already advanced both
-            if (partial > 0) { need = std::max(need, (int)std::min<int64_t>(partial, c->nz - 1)); }
+    if (fork) { (void)hipEventRecord(c->ev_join, c->fft_stream); }
+    if (!rc) {
+        const CarryJob iqc = iq_carry_job(c, d_iq, count);
+        if (c->vfos.empty()) {
+            std::vector<CarryJob> carry{ iqc };
+            CarryJob* d_carry = arena_push(c, carry);
+            rc = arena_commit(c);
+            if (!rc) {
+                FamilyTimer t(c, F_MISC);
+                const int iq_elems = carry[0].need * 2;
+                launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
+            }
         }
-        for (auto& kv : c->vfos) {
-            const sdrpp_vfo_desc& d = kv.second->d;
-            if (d.n_stages > 0) { need = std::max(need, d.stage_ntaps[0] - 1); }
-            if (d.n_stages > 1) { need = std::max(need, d.stage_ntaps[0] - 1 + d.stage_decim[0] * (d.stage_ntaps[1] - 1)); }
+        else {
+            HostScope hs("do_vfos");
+            rc = do_vfos_plan(c, src, count, iqc);
         }
-        need = std::min(need, c->iq_hist_cap);
-        carry.push_back(CarryJob{ d_iq, c->iq_hist[c->iq_cur], c->iq_hist[c->iq_cur ^ 1], c->iq_hist_cap, (int)count, 2, need });
-    }
-    if (c->vfos.empty()) {
-        CarryJob* d_carry = arena_push(c, carry);
-        rc = arena_commit(c);
-        if (rc) { return rc; }
-        FamilyTimer t(c, F_MISC);
-        const int iq_elems = carry[0].need * 2;
-        launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry);
-    }
-    else {
-        HostScope hs("do_vfos");
-        rc = do_vfos(c, src, count, carry);
-        if (rc) { return rc; }
     }
     HostScope hs2("join + arena_end");
-    if (fork) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (fork) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }  // (also after a failure: the FFT branch's launches must not overtake what follows)
+    if (rc) {
+        // the block did not happen: the streaming state is what it was before the push (what the kernels launched so far wrote is never
+        // looked at: counts, history sides and frame positions are the host's)
+        plan_restore(c, snap);
+        (void)arena_end(c);
+        return rc;
+    }
     c->iq_cur ^= 1;
     rc = arena_end(c);
     if (rc) { return rc; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e)); }
     return SDRPP_OK;
+}
+
+// =====================================================================================================================
+// Pipelined execution (tick_kernels.h): queue, launch, drain
+// =====================================================================================================================
+void tick_wait_done(sdrpp_ctx* c, uint64_t nticks) {
+    if (!c->h_tick_flag) { return; }
+    // the flag holds the number of completed ticks modulo 2^32; at most kArenaSlots ticks are ever outstanding
+    const volatile unsigned* f = c->h_tick_flag;
+    long spins = 0;
+    while ((int)((unsigned)nticks - *f) > 0) {
+        if (++spins > 2000) { std::this_thread::yield(); }
+        if (spins > 40000000) {  // ~minutes: the device is gone; let the next HIP call report it
+            (void)hipStreamSynchronize(c->stream);
+            if ((int)((unsigned)nticks - *f) > 0) { return; }
+        }
+    }
+}
+bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag || (int)((unsigned)nticks - *(const volatile unsigned*)c->h_tick_flag) <= 0; }
+
+// One tick: level-0 work of the block that arrives with it (`land`: its landing copy, may be null; the arena slot the caller has filled
+// with the block's job tables) + every queued role whose turn it is.  The role table of the NEXT tick is appended to the arena slot and
+// travels with this tick's upload.
+int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
+    std::vector<sdrpp_ctx::RoleLaunch> now;
+    if (!c->tickq.empty()) {
+        now.swap(c->tickq.front());
+        c->tickq.pop_front();
+    }
+    if ((int)now.size() != c->next_tab_n) { return fail(c, SDRPP_ERR_HIP, "internal: tick table out of step (%zu roles queued, %d uploaded)", now.size(), c->next_tab_n); }
+    // the table of the tick after this one
+    TickTable* tab_dev_next = nullptr;
+    int tab_n_next = 0;
+    if (!c->tickq.empty() && !c->tickq.front().empty()) {
+        const std::vector<sdrpp_ctx::RoleLaunch>& nx = c->tickq.front();
+        if (nx.size() > SDRPP_TICK_MAX_ENTRIES) { return fail(c, SDRPP_ERR_UNSUPPORTED, "internal: %zu roles in one tick", nx.size()); }
+        const size_t off = (c->arena_off + 63) & ~(size_t)63;
+        if (off + sizeof(TickTable) > kArenaBytes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        TickTable* T = reinterpret_cast<TickTable*>(c->arena_host[c->arena_slot] + off);
+        T->n = (int)nx.size();
+        int total = 0;
+        for (size_t i = 0; i < nx.size(); i++) {
+            total += nx[i].e.gx * nx[i].e.gy;
+            T->block_end[i] = total;
+            T->e[i] = nx[i].e;
+        }
+        c->arena_off = off + offsetof(TickTable, e) + nx.size() * sizeof(TickEntry);
+        tab_dev_next = reinterpret_cast<TickTable*>(c->arena_dev + off);
+        tab_n_next = (int)nx.size();
+    }
+    TickL0 l0{};
+    if (land && land->bytes > 0) {
+        l0.job[0] = *land;
+        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 16383) / 16384, 64));
+    }
+    if (c->arena_off > 0) {
+        l0.job[1] = CopyJob{ c->arena_host_dev[c->arena_slot], c->arena_dev, (long long)((c->arena_off + 15) & ~(size_t)15), 0, 0 };
+        l0.blocks[1] = (int)std::max<size_t>(1, std::min<size_t>((c->arena_off + 16383) / 16384, 8));
+    }
+    int blocks = l0.blocks[0] + l0.blocks[1];
+    size_t lds = 0;
+    bool set1 = false;
+    for (auto& r : now) {
+        blocks += r.e.gx * r.e.gy;
+        lds = std::max(lds, r.lds);
+        set1 = set1 || r.e.role == TR_FCL_PF;
+    }
+    if (blocks == 0) {  // nothing to do at all (an idle flush)
+        c->next_tab = tab_dev_next;
+        c->next_tab_n = tab_n_next;
+        return SDRPP_OK;
+    }
+    c->tick_target += 4u * (unsigned)blocks;
+    c->ticks++;
+    TickDone done{ c->d_tick_counter, c->hd_tick_flag, c->tick_target, (unsigned)c->ticks };
+    const TickTable* tab = c->next_tab_n > 0 ? c->next_tab : c->empty_tab;
+    {
+        hipEvent_t ea = nullptr;
+        const bool timed = c->timing && ((c->timing_mask >> F_TICK) & 1u);
+        c->fam_launch[F_TICK]++;
+        if (timed) {
+            ea = get_event(c);
+            (void)hipEventRecord(ea, c->stream);
+        }
+        HostScope hs("launch");
+        if (set1) { hipLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        else { hipLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        if (timed) {
+            hipEvent_t eb = get_event(c);
+            (void)hipEventRecord(eb, c->stream);
+            c->tpairs.push_back({ ea, eb, F_TICK });
+            if (c->tpairs.size() > 8192) { timing_flush(c); }
+        }
+    }
+    c->arena_tick[c->arena_slot] = c->ticks;
+    c->next_tab = tab_dev_next;
+    c->next_tab_n = tab_n_next;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "tick launch failed: %s", hipGetErrorString(e)); }
+    return SDRPP_OK;
+}
+// run every queued role (no new input): what a caller that wants the results of the last blocks NOW pays for the skew
+int tick_drain(sdrpp_ctx* c) {
+    while (!c->tickq.empty()) {
+        int rc = arena_begin(c);
+        if (rc) { return rc; }
+        rc = tick_launch(c, nullptr);
+        if (rc) { return rc; }
+    }
+    return SDRPP_OK;
+}
+
+// Can this context's blocks run as ticks at all?  (What can only be seen while planning — a VFO group too small for the matrix front end,
+// a filter without the matrix form, more frames than one scratch chunk — aborts the plan instead.)
+bool tick_eligible(sdrpp_ctx* c) {
+    if (c->pre.on || c->wf.height > 0 || c->deferred || c->nco_exact) { return false; }
+    for (auto& kv : c->vfos) {
+        const Vfo& v = *kv.second;
+        if (v.af.on || !v.recs.empty() || v.st.size() > 24) { return false; }
+    }
+    return true;
+}
+
+// ---- results of a block in page-locked host memory (sdrpp_set_pipelined's result flags): gather roles one level behind the producers ----
+size_t tick_results_need(sdrpp_ctx* c) {
+    size_t need = 0;
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            need += ((s.cap + 16) * 8 + 15) & ~(size_t)15;
+        }
+    }
+    if (c->fft_on) {
+        if ((c->res_flags & 2) && c->data_width > 0) { need += 2 * ((c->lines_cap * (size_t)c->data_width * 4 + 15) & ~(size_t)15); }
+        if (c->res_flags & 4) { need += (c->lines_cap * (size_t)c->fft_size * 4 + 15) & ~(size_t)15; }
+    }
+    return need;
+}
+int tick_results_ensure(sdrpp_ctx* c) {
+    const size_t need = tick_results_need(c);
+    if (need <= c->res_cap) { return SDRPP_OK; }
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res[i].held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held: release them before the outputs grow", (unsigned long long)c->res[i].ticket); }
+    }
+    int rc = tick_drain(c);
+    if (rc) { return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
+        c->res_host[i] = nullptr;
+        c->res_dev[i] = nullptr;
+        c->res[i] = sdrpp_ctx::Result{};
+    }
+    c->res_cap = 0;
+    const size_t cap = need + need / 8 + 4096;
+    for (int i = 0; i < kResSlots; i++) {
+        if (hipHostMalloc((void**)&c->res_host[i], cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c->res_dev[i], c->res_host[i], 0) != hipSuccess) {
+            return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);
+        }
+    }
+    c->res_cap = cap;
+    return SDRPP_OK;
+}
+// gather roles of the block just planned -> c->emits; fills its result slot's description
+int tick_results_plan(sdrpp_ctx* c) {
+    const int slot = (int)(c->pushes % kResSlots);
+    sdrpp_ctx::Result& R = c->res[slot];
+    if (!c->res_flags) {
+        R = sdrpp_ctx::Result{};
+        return SDRPP_OK;
+    }
+    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
+    R = sdrpp_ctx::Result{};
+    R.ticket = c->pushes;
+    Lev<CopyJob> jobs;
+    size_t off = 0;
+    char* base = c->res_dev[slot];
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const bool raw = v.d.demod == SDRPP_DEMOD_RAW;
+            const Stream& s = raw ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            R.ids.push_back(v.id);
+            R.offsets.push_back((int64_t)(off / 8));
+            R.counts.push_back(s.n);
+            const size_t bytes = (size_t)s.n * 8;
+            if (bytes) { jobs.add((raw ? v.lvl_if : v.lvl_out) + 1, CopyJob{ s.data, base + off, (long long)bytes, 0x100, 0 }); }
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    R.n_lines = c->fft_on ? c->n_lines : 0;
+    if (R.n_lines > 0) {
+        const int lines_level = c->fft_lg <= 12 ? 1 : 2;
+        if ((c->res_flags & 2) && c->data_width > 0) {
+            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
+            R.off_zoomed = off;
+            jobs.add(lines_level + 2, CopyJob{ c->d_zoomed, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+            R.off_index = off;
+            jobs.add(lines_level + 2, CopyJob{ c->d_index, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+        }
+        if (c->res_flags & 4) {
+            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
+            R.off_raw = off;
+            jobs.add(lines_level + 1, CopyJob{ c->d_lines, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    if (off > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes exceed the slot (%zu)", off, c->res_cap); }
+    if (!arena_push_lev(c, jobs)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    for (int l = 0; l < jobs.top; l++) {
+        if (jobs.at[l].empty()) { continue; }
+        long long mx = 0;
+        for (auto& j : jobs.at[l]) { mx = std::max(mx, j.bytes); }
+        emit(c, l, F_MISC, TR_COPY, (int)std::max<long long>(1, std::min<long long>((mx + 32767) / 32768, 16)), (int)jobs.at[l].size(), 0, jobs.dev[l]);
+        c->plan_top = std::max(c->plan_top, l + 1);
+    }
+    return SDRPP_OK;
+}
+
+// One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
+int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
+    if (count == 0) { return SDRPP_OK; }
+    bool as_tick = tick_eligible(c);
+    if (as_tick) {  // rings of the per-block buffers, result slots (allocated on first use / after a change of the configuration)
+        for (auto& kv : c->vfos) {
+            for (auto& st : kv.second->st) {
+                if (st.n_extra < kRing - 1 && st.base) {
+                    int rc = stream_ring_ensure(c, st);
+                    if (rc) { return rc; }
+                }
+            }
+        }
+        int rc = fft_ring_ensure(c);
+        if (!rc && c->res_flags) { rc = tick_results_ensure(c); }
+        if (rc) { return rc; }
+    }
+    c->pushes++;
+    const bool have_slot = as_tick;
+    PlanSnapshot snap;
+    int rc = SDRPP_OK;
+    if (as_tick) {
+        HostScope hs("tick plan");
+        rc = arena_begin(c);
+        if (rc) {
+            c->pushes--;
+            return rc;
+        }
+        plan_snapshot(c, snap);
+        for (auto& kv : c->vfos) {
+            for (auto& s : kv.second->st) { stream_rotate(s); }
+        }
+        fft_ring_rotate(c);
+        c->tick_planning = true;
+        c->tick_abort = false;
+        c->emits.clear();
+        c->plan_top = 2;
+        block_bounds(c, count, nullptr);
+        rc = ensure_iq_hist(c, iq_hist_need(c));
+        if (!rc) {
+            IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
+            rc = do_fft(c, src, count);
+            if (!rc && !c->tick_abort) {
+                const CarryJob iqc = iq_carry_job(c, d_iq, count);
+                if (c->vfos.empty()) {
+                    std::vector<CarryJob> carry{ iqc };
+                    CarryJob* d_carry = arena_push(c, carry);
+                    if (!d_carry) { rc = fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+                    else { emit(c, 1, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 1023) / 1024, 2048)), 1, 0, d_carry); }
+                }
+                else { rc = do_vfos_plan(c, src, count, iqc); }
+            }
+            if (!rc && !c->tick_abort) { rc = tick_results_plan(c); }
+        }
+        c->tick_planning = false;
+        if (!rc && !c->tick_abort && c->plan_top > kTickDepth + 1) { c->tick_abort = true; }
+        if (rc || c->tick_abort) {
+            plan_restore(c, snap);
+            c->emits.clear();
+            if (!c->res[c->pushes % kResSlots].held) { c->res[c->pushes % kResSlots].ticket = 0; }
+            as_tick = false;
+            if (rc) {
+                c->pushes--;
+                return rc;
+            }
+            c->arena_off = 0;  // (the slot stays this tick's: only the next role table goes in)
+        }
+    }
+    if (!as_tick) {
+        // this block runs as an ordinary pass: everything queued first (the first of those ticks carries the landing copy), then the pass
+        // behind them on the same stream
+        if (!have_slot) {
+            rc = arena_begin(c);
+            if (rc) { return rc; }
+        }
+        rc = tick_launch(c, land);
+        if (!rc) { rc = tick_drain(c); }
+        if (land) { c->land_tick = c->ticks; }
+        if (!rc) { rc = push_common(c, d_iq, count, nullptr); }
+        // its results are where an ordinary pass leaves them: device buffers, readable after a synchronisation
+        sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
+        if (!R.held) { R = sdrpp_ctx::Result{}; }
+        return rc;
+    }
+    // queue the roles level by level and launch this block's tick
+    if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }
+    for (auto& r : c->emits) { c->tickq[(size_t)r.level].push_back(r); }
+    c->emits.clear();
+    c->iq_cur ^= 1;
+    // tickq[0] is this very tick: it holds only what earlier blocks queued (a block's own roles start at level 1)
+    {
+        HostScope hs("tick launch");
+        rc = tick_launch(c, land);
+    }
+    if (land) { c->land_tick = c->ticks; }
+    sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
+    if (R.ticket == c->pushes) { R.done_tick = c->ticks + (uint64_t)(c->plan_top - 1); }
+    return rc;
 }
 
 }  // namespace
@@ -2134,6 +2827,7 @@ struct DeviceScope {
 extern "C" {
 
 int flush_pending(sdrpp_ctx* c);  // deferred pushes -> one pass (defined with the data path below; internal, not part of the ABI header)
+int flush_pending_opt(sdrpp_ctx* c, int drain);  // drain = 0: a call that only reports what the HOST knows (counts) leaves the tick queue of the pipelined mode alone
 
 const char* sdrpp_strerror(int code) {
     switch (code) {
@@ -2204,10 +2898,26 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         sdrpp_destroy(c);
         return SDRPP_ERR_NO_DEVICE;
     }
-    if (dev_alloc(c, &c->arena_dev, kArenaBytes) != SDRPP_OK || dev_alloc(c, &c->iq_land[0], (size_t)max_push * 2 + 32) != SDRPP_OK) {
+    for (int i = 0; i < kArenaSlots; i++) {
+        if (dev_alloc(c, &c->arena_dev_slot[i], kArenaBytes) != SDRPP_OK) {
+            sdrpp_destroy(c);
+            return SDRPP_ERR_NOMEM;
+        }
+    }
+    c->arena_dev = c->arena_dev_slot[0];
+    if (dev_alloc(c, &c->iq_land[0], (size_t)max_push * 2 + 32) != SDRPP_OK) {
         sdrpp_destroy(c);
         return SDRPP_ERR_NOMEM;
     }
+    // completion flag and counter of the pipelined mode (sdrpp_set_pipelined)
+    if (dev_alloc(c, &c->d_tick_counter, 4) != SDRPP_OK || dev_alloc(c, &c->empty_tab, 1) != SDRPP_OK ||
+        hipMemset(c->d_tick_counter, 0, 16) != hipSuccess || hipMemset(c->empty_tab, 0, sizeof(TickTable)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_tick_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->hd_tick_flag, c->h_tick_flag, 0) != hipSuccess) {
+        sdrpp_destroy(c);
+        return SDRPP_ERR_NOMEM;
+    }
+    *c->h_tick_flag = 0;
     *out = c;
     return SDRPP_OK;
 }
@@ -2394,7 +3104,19 @@ int sdrpp_destroy(sdrpp_ctx* c) {
         if (c->arena_host[i]) { (void)hipHostFree(c->arena_host[i]); }
         if (c->arena_ev[i]) { (void)hipEventDestroy(c->arena_ev[i]); }
     }
-    dev_free(c->arena_dev);
+    for (int i = 0; i < kArenaSlots; i++) { dev_free(c->arena_dev_slot[i]); }
+    c->arena_dev = nullptr;
+    dev_free(c->d_tick_counter);
+    dev_free(c->empty_tab);
+    if (c->h_tick_flag) { (void)hipHostFree(c->h_tick_flag); }
+    for (int i = 0; i < 3; i++) { dev_free(c->tick_land[i]); }
+    for (int i = 0; i < kStageSlots; i++) {
+        if (c->stage_host[i]) { (void)hipHostFree(c->stage_host[i]); }
+    }
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
+    }
+    fft_ring_drop(c);
     for (int i = 0; i < 2; i++) {
         dev_free(c->iq_land[i]);
         dev_free(c->iq_land16[i]);
@@ -2478,6 +3200,7 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
         for (int e = 0; e < L / 2; e++) { sdrpp_host::twiddle(e, L, &t[(size_t)e].x, &t[(size_t)e].y); }
         return t;
     };
+    fft_ring_drop(c);
     dev_free(c->d_tw2);
     dev_free(c->d_twn);
     dev_free(c->d_scratch);
@@ -2552,6 +3275,7 @@ int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float 
     c->wf_min = wf_min;
     c->wf_max = wf_max;
     c->zoom_cap = 0;
+    fft_ring_drop(c);
     dev_free(c->d_zoomed);
     dev_free(c->d_index);
     if (data_width == 0 || c->fft_size == 0) { return SDRPP_OK; }
@@ -2567,7 +3291,10 @@ int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float 
 int sdrpp_fft_lines(sdrpp_ctx* c) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    FLUSH_PENDING(c);
+    {
+        int frc = flush_pending_opt(c, 0);
+        if (frc) { return frc; }
+    }
     return c->n_lines;
 }
 
@@ -3291,7 +4018,10 @@ static Stream* out_stream(Vfo& v) { return (v.d.demod == SDRPP_DEMOD_RAW) ? &v.s
 int sdrpp_vfo_out_count(sdrpp_ctx* c, int id) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    FLUSH_PENDING(c);
+    {
+        int frc = flush_pending_opt(c, 0);
+        if (frc) { return frc; }
+    }
     auto it = c->vfos.find(id);
     if (it == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", id); }
     return out_stream(*it->second)->n;
@@ -3403,7 +4133,12 @@ static int landing_process(sdrpp_ctx* c, int64_t count, const std::vector<int>* 
     c->land_cur ^= 1;
     return rc;
 }
-int flush_pending(sdrpp_ctx* c) {
+int flush_pending(sdrpp_ctx* c) { return flush_pending_opt(c, 1); }
+int flush_pending_opt(sdrpp_ctx* c, int drain) {
+    if (drain && c->pipelined && !c->tickq.empty()) {  // pipelined mode: run what the last blocks still have queued
+        int rc = tick_drain(c);
+        if (rc) { return rc; }
+    }
     if (c->pending == 0) { return SDRPP_OK; }
     if (c->async_staged) {  // copy kernels of sdrpp_push_pinned_async still in flight: the pass waits for them on the device
         c->async_staged = false;
@@ -3425,10 +4160,41 @@ static int push_args_ok(sdrpp_ctx* c, const void* p, int64_t count) {
     return SDRPP_OK;
 }
 
+// pipelined mode: a block from host memory.  `src_dev`: device address of page-locked memory the samples can be fetched from in place
+// (sdrpp_push_pinned_async); nullptr: `src_host` is copied into a page-locked staging slot first (the caller's buffer is free on return).
+// `bytes_per_sample`: 8 (complex float) or 4 (interleaved int16).
+static int tick_push_host(sdrpp_ctx* c, const void* src_host, const void* src_dev, int64_t count, int bytes_per_sample) {
+    const int li = (int)((c->pushes + 1) % 3);
+    if (!c->tick_land[li]) {
+        int rc = dev_alloc(c, &c->tick_land[li], (size_t)c->max_push * 2 + 32);
+        if (rc) { return rc; }
+    }
+    const size_t bytes = (size_t)count * (size_t)bytes_per_sample;
+    if (!src_dev) {
+        const int si = c->stage_cur;
+        c->stage_cur = (c->stage_cur + 1) % kStageSlots;
+        if (!c->stage_host[si]) {
+            if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer"); }
+        }
+        if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
+        memcpy(c->stage_host[si], src_host, bytes);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, c->stage_host[si], 0) != hipSuccess || !d) { return fail(c, SDRPP_ERR_HIP, "hipHostGetDevicePointer(staging) failed"); }
+        src_dev = d;
+        const CopyJob land{ src_dev, c->tick_land[li], (long long)bytes, bytes_per_sample == 4 ? 1 : 0, 0 };
+        int rc = tick_push(c, c->tick_land[li], count, &land);
+        c->stage_tick[si] = c->ticks;
+        return rc;
+    }
+    const CopyJob land{ src_dev, c->tick_land[li], (long long)bytes, bytes_per_sample == 4 ? 1 : 0, 0 };
+    return tick_push(c, c->tick_land[li], count, &land);
+}
+
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
+    if (c->pipelined) { return count == 0 ? SDRPP_OK : tick_push_host(c, iq_host, nullptr, count, 8); }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
     rc = landing_acquire(c, false);
     if (rc) { return rc; }
@@ -3458,6 +4224,16 @@ int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count)
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
     void* dptr = nullptr;
+    if (c->pipelined) {  // the tick's landing role fetches the block from the page-locked buffer itself; sdrpp_push_wait says when it has
+        int prc = push_args_ok(c, iq_pinned, count);
+        if (prc) { return prc; }
+        if (count == 0) { return SDRPP_OK; }
+        if (hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
+            (void)hipGetLastError();
+            return tick_push_host(c, iq_pinned, nullptr, count, 8);
+        }
+        return tick_push_host(c, iq_pinned, dptr, count, 8);
+    }
     if (!c->deferred || count <= 0 || !iq_pinned || hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
         (void)hipGetLastError();
         return sdrpp_push(c, iq_pinned, count);
@@ -3479,6 +4255,10 @@ int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count)
 int sdrpp_push_wait(sdrpp_ctx* c) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
+    if (c->pipelined && c->land_tick) {  // every landing copy so far has run once its tick is complete
+        tick_wait_done(c, c->land_tick);
+        return SDRPP_OK;
+    }
     // (not `async_staged`: a flushing call that does not host-synchronise — sdrpp_fft_lines, sdrpp_vfo_out_count, a setter — clears that
     // one while the copy kernels may still be reading the caller's page-locked buffers)
     if (c->async_inflight) {
@@ -3492,6 +4272,7 @@ int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_dev, count);
     if (rc) { return rc; }
+    if (c->pipelined) { return tick_push(c, iq_dev, count, nullptr); }  // read in place, one tick from now at the earliest
     if (!c->deferred) { return push_common(c, iq_dev, count); }  // read in place
     if (count == 0) { return SDRPP_OK; }
     rc = landing_acquire(c, false);
@@ -3506,6 +4287,7 @@ int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
+    if (c->pipelined) { return count == 0 ? SDRPP_OK : tick_push_host(c, iq_host, nullptr, count, 4); }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
     rc = landing_acquire(c, true);
     if (rc) { return rc; }
@@ -3540,11 +4322,80 @@ void sdrpp_host_free(void* p) {
 int sdrpp_set_deferred(sdrpp_ctx* c, int on) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
+    if (on && c->pipelined) { return fail(c, SDRPP_ERR_INVALID, "deferred and pipelined processing exclude each other"); }
     int rc = flush_pending(c);
     c->deferred = on != 0;
     return rc;
 }
 int64_t sdrpp_pending(sdrpp_ctx* c) { return c ? c->pending : SDRPP_ERR_INVALID; }
+
+// ---- pipelined execution ----------------------------------------------------------------------------------------------------------------
+int sdrpp_set_pipelined(sdrpp_ctx* c, int on, int result_flags) {
+    DeviceScope dev_scope_(c);
+    if (!c || result_flags < 0 || result_flags > 7) { return SDRPP_ERR_INVALID; }
+    if (on && c->deferred) { return fail(c, SDRPP_ERR_INVALID, "deferred and pipelined processing exclude each other"); }
+    int rc = flush_pending(c);  // (drains the queue when the mode is being left)
+    if (rc) { return rc; }
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res[i].held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held", (unsigned long long)c->res[i].ticket); }
+    }
+    c->pipelined = on != 0;
+    c->res_flags = on ? result_flags : 0;
+    return SDRPP_OK;
+}
+uint64_t sdrpp_ticket(sdrpp_ctx* c) { return c ? c->pushes : 0; }
+int sdrpp_pipeline_flush(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
+    if (!c) { return SDRPP_ERR_INVALID; }
+    return c->pipelined ? tick_drain(c) : SDRPP_OK;
+}
+static sdrpp_ctx::Result* result_of(sdrpp_ctx* c, uint64_t ticket) {
+    if (!c || ticket == 0 || ticket > c->pushes) { return nullptr; }
+    sdrpp_ctx::Result& R = c->res[ticket % kResSlots];
+    return R.ticket == ticket ? &R : nullptr;
+}
+int sdrpp_result_ready(sdrpp_ctx* c, uint64_t ticket) {
+    sdrpp_ctx::Result* R = result_of(c, ticket);
+    if (!R) { return c ? fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (not gathered, overwritten, or processed as an ordinary pass)", (unsigned long long)ticket) : SDRPP_ERR_INVALID; }
+    return (R->done_tick <= c->ticks && tick_is_done(c, R->done_tick)) ? 1 : 0;
+}
+int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
+    DeviceScope dev_scope_(c);
+    if (!c || !out) { return SDRPP_ERR_INVALID; }
+    sdrpp_ctx::Result* R = result_of(c, ticket);
+    if (!R) { return fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (not gathered, overwritten, or processed as an ordinary pass)", (unsigned long long)ticket); }
+    while (R->done_tick > c->ticks) {  // its last levels have not been launched yet: nothing more is coming, run them without new input
+        int rc = arena_begin(c);
+        if (!rc) { rc = tick_launch(c, nullptr); }
+        if (rc) { return rc; }
+        if (c->tickq.empty() && R->done_tick > c->ticks) { return fail(c, SDRPP_ERR_HIP, "internal: block %llu cannot complete", (unsigned long long)ticket); }
+    }
+    tick_wait_done(c, R->done_tick);
+    if (!tick_is_done(c, R->done_tick)) { return fail(c, SDRPP_ERR_HIP, "tick %llu did not complete", (unsigned long long)R->done_tick); }
+    R->held = true;
+    const char* base = c->res_host[ticket % kResSlots];
+    out->ticket = ticket;
+    out->n_vfo = (int)R->ids.size();
+    out->ids = R->ids.data();
+    out->offsets = R->offsets.data();
+    out->counts = R->counts.data();
+    out->samples = reinterpret_cast<const float*>(base);
+    out->n_lines = R->n_lines;
+    out->fft_size = c->fft_size;
+    out->data_width = c->data_width;
+    const bool zo = R->n_lines > 0 && (c->res_flags & 2) && c->data_width > 0;
+    out->zoomed = zo ? reinterpret_cast<const float*>(base + R->off_zoomed) : nullptr;
+    out->index = zo ? reinterpret_cast<const int32_t*>(base + R->off_index) : nullptr;
+    out->raw = (R->n_lines > 0 && (c->res_flags & 4)) ? reinterpret_cast<const float*>(base + R->off_raw) : nullptr;
+    return SDRPP_OK;
+}
+int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
+    sdrpp_ctx::Result* R = result_of(c, ticket);
+    if (!R) { return c ? SDRPP_ERR_NOT_FOUND : SDRPP_ERR_INVALID; }
+    R->held = false;
+    R->ticket = 0;
+    return SDRPP_OK;
+}
 
 // ---- measurement ---------------------------------------------------------------------------------------------------------------------
 int sdrpp_timing_enable(sdrpp_ctx* c, int on) {

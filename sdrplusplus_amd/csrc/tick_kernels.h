@@ -1,0 +1,242 @@
+// One launch per block ("tick"): the per-block execution path for hosts that hand blocks over one at a time at the reference's block
+// size (sample_rate / 200 samples, core/src/dsp/stream.h:9, source_modules/file_source/src/main.cpp:157).
+//
+// At that size every kernel of the path is latency-bound (a 50 000-sample block of the 32-VFO bank is less than one wave of work for
+// 256 CUs) and a block costs the SUM of its ~8 dependent launches + 2 cross-stream joins: 65 us per block, 0.75 GS/s, 1 % of the
+// roofline.  The stages of the path form a pipeline, though, and nothing but the data flow orders them: stage s of
+// block n needs stage s-1 of block n (and, as filter history, of block n-1).  So the stages are SKEWED over consecutive launches:
+// tick t runs stage 0 (landing copy of the samples, upload of the job tables) of block t, stage 1 (front end, FFT pass 1, IQ history)
+// of block t-1, stage 2 (first separate decimator, FFT pass 2) of block t-2, ... — all of them independent inside one tick, every
+// dependency satisfied by the kernel boundary in front of it.  No flags, no waiting inside a kernel, no events between streams: a
+// tick is ONE kernel whose workgroups look up their ROLE (which kernel body, which job table, which grid coordinates) in a table, and
+// a block costs the host one launch (2.6 us measured, tools/probe/tick_probe.hip) and the device max(stage) instead of sum(stages).
+// Results arrive `depth` ticks late; sdrpp_pipeline_flush / any observing call runs the remaining ticks without new input.
+//
+// The roles are the bodies of the ordinary kernels (fft_kernels.h, vfo_kernels.h): same code, same arithmetic, bit-identical results
+// (tests/test_pipelined.py compares the two execution paths sample for sample).  Per-block buffers are rings (`ring depth` buffers per
+// stream) so that a producer working on block n+1 does not overwrite what a consumer still reads of block n.
+#pragma once
+
+namespace sdrpp_k {
+
+// ---- generic copy role: landing copy of the input block (page-locked host memory or device memory -> landing ring), job-table upload
+//      (page-locked host arena -> device arena), result gather (device streams -> page-locked result slot of the block) ----
+struct CopyJob {
+    const void* src;
+    void* dst;
+    long long bytes;  // multiple of 4 (kind 1: SOURCE bytes, multiple of 2)
+    int kind;         // 0: verbatim; 1: interleaved int16 -> float (x / 32768: file_source/src/main.cpp:162); bit 8: dst is host memory
+    int pad;
+};
+__device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
+    const long long tid = (long long)bx * 256 + threadIdx.x, nth = (long long)gx * 256;
+    if ((job.kind & 0xff) == 1) {
+        const short* in = reinterpret_cast<const short*>(job.src);
+        float* out = reinterpret_cast<float*>(job.dst);
+        const float inv = 1.0f / 32768.0f;
+        const long long n = job.bytes / 2;
+        for (long long i = tid; i < n; i += nth) { out[i] = ((float)in[i]) * inv; }
+    }
+    else {
+        const bool al16 = ((((unsigned long long)job.src) | ((unsigned long long)job.dst)) & 15ull) == 0ull;
+        long long done = 0;
+        if (al16) {
+            const uint4* s = reinterpret_cast<const uint4*>(job.src);
+            uint4* d = reinterpret_cast<uint4*>(job.dst);
+            const long long n16 = job.bytes / 16;
+            for (long long i = tid; i < n16; i += nth) { d[i] = s[i]; }
+            done = n16 * 4;
+        }
+        const unsigned* s = reinterpret_cast<const unsigned*>(job.src);
+        unsigned* d = reinterpret_cast<unsigned*>(job.dst);
+        const long long n4 = job.bytes / 4;
+        for (long long i = done + tid; i < n4; i += nth) { d[i] = s[i]; }
+    }
+    if (job.kind & 0x100) { __threadfence_system(); }  // results for the host: on their way before this wavefront counts itself done
+}
+__device__ __forceinline__ void copy_body(const KIdx bid, const KIdx gdim, const CopyJob* __restrict__ jobs) { copy_one(jobs[bid.y], bid.x, gdim.x); }
+__global__ __launch_bounds__(256) void copy_kernel(const CopyJob* __restrict__ jobs) { copy_body(kidx(blockIdx), kidx(gridDim), jobs); }
+
+// ---- roles ----
+enum TickRole : int {
+    TR_NONE = 0,
+    TR_COPY,       // CopyJob[gy]
+    TR_CARRY,      // CarryJob[gy]
+    TR_ROT,        // RotJob[gy], p.src
+    TR_FCM_132_4,  // FrontCMJob[gy], p.src: vfo_frontcm_body<10, 132, 4>
+    TR_FCM_6,      // <6, 0, 0>
+    TR_FCM_10,     // <10, 0, 0>
+    TR_FCM_16,     // <16, 0, 0>
+    TR_FCL_0,      // vfo_frontcl_body<0> (two wavefronts per workgroup)
+    TR_FCL_PF,     // vfo_frontcl_body<SDRPP_FCL_PF> (247 registers: only in the SET = 1 build of the kernel)
+    TR_TOEP_C,     // ToepJob[gy]: vfo_toep_body<2, 2, false>
+    TR_TOEP_R,     // <1, 2, false>
+    TR_TOEP_Q,     // <1, 2, true>
+    TR_FIRB_C,     // FirBJob[gy], aux = work-items per workgroup: vfo_firb_body<2, false> (register-blocked VALU FIR: decimators by 4 and 8, very long filters)
+    TR_FIRB_R,     // <1, false>
+    TR_FIRB_S,     // <1, true>
+    TR_FIRB_Q,     // <1, true, true>
+    TR_PRE,        // PreJob[gy]
+    TR_SEQ,        // SeqJob[gx] (one wavefront per job), aux = njobs
+    TR_FFT_S10, TR_FFT_S11, TR_FFT_S12,                              // p.fs
+    TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10,  // p.p1
+    TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10,             // p.p2
+    TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
+    TR_COUNT
+};
+struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, pad; };
+struct TickP2 { const float2* scratch; const float2* tw2; float* out; float* grp; int lg1, nframes; };
+struct TickFS { IqSrc src; FrameGeom g; const float* window; const float2* tw; float* out; };
+struct TickZoom { const float* lines; const int32_t* zs; const int32_t* zc; float* zoomed; int32_t* index; const float* grp; int fft_size, data_width, gsz; float wf_min, wf_max; int pad; };
+struct TickEntry {
+    int role, gx, gy, aux;
+    const void* jobs;
+    union {
+        IqSrc src;
+        TickP1 p1;
+        TickP2 p2;
+        TickFS fs;
+        TickZoom z;
+    } p;
+};
+#define SDRPP_TICK_MAX_ENTRIES 64
+struct TickTable {
+    int n, pad[3];
+    int block_end[SDRPP_TICK_MAX_ENTRIES];  // running total of workgroups
+    TickEntry e[SDRPP_TICK_MAX_ENTRIES];
+};
+// stage 0 of the block that arrives with this tick: its descriptors are not in device memory yet (the upload is part of this very
+// tick), so they travel as kernel arguments — two copy jobs, kept small (3 KB of kernel arguments were measured to cost 6 us per launch)
+struct TickL0 {
+    CopyJob job[2];  // [0] landing copy, [1] job tables of this block + role table of the NEXT tick -> device arena
+    int blocks[2];
+};
+// completion without a host API call: every wavefront counts itself done, the last one publishes the tick's number in page-locked
+// host memory that the host polls (7 us from launch to "host knows" against 12.5 us for hipStreamSynchronize)
+struct TickDone {
+    unsigned* counter;    // device, running total of finished wavefronts
+    unsigned* host_flag;  // page-locked, device-mapped: number of completed ticks
+    unsigned target;      // value of the counter when this tick's last wavefront has finished (mod 2^32)
+    unsigned value;       // what to publish
+};
+__device__ __forceinline__ void tick_finish(const TickDone& d) {
+    __threadfence();
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned old = atomicAdd(d.counter, 1u);
+        if (old + 1u == d.target) {
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned*>(d.host_flag) = d.value;
+        }
+    }
+}
+
+// LDS (bytes) the FFT / zoom roles carve out of the dynamic allocation: what their stand-alone kernels declare statically
+__host__ __device__ inline size_t tick_lds_fft_single(int lg, int fpw) { return ((size_t)(1 << lg) / 2 + (size_t)fpw * ((1 << lg) + (1 << lg) / 16)) * 8; }
+__host__ __device__ inline size_t tick_lds_fft_p1(int lg1, int c) { return ((size_t)(1 << lg1) / 2 + (size_t)(1 << lg1) * c) * 8; }
+__host__ __device__ inline size_t tick_lds_fft_p2(int lg2, int r) { return ((size_t)(1 << lg2) / 2 + (size_t)r * ((1 << lg2) + (1 << lg2) / 16)) * 8; }
+__host__ __device__ inline size_t tick_lds_zoom(int tp) { return (size_t)(256 / tp) * (tp + 1) * 4; }
+
+template <int LG, int FPW>
+__device__ __forceinline__ void tick_fft_single(const KIdx bid, float* smem, const TickFS& q) {
+    const IqSrc src = q.src;
+    const FrameGeom g = q.g;
+    float2* tw = reinterpret_cast<float2*>(smem);
+    fft_single_body<LG, FPW>(bid, tw, tw + FftSingleLds<LG, FPW>::TW, src, g, q.window, q.tw, q.out);
+}
+template <int LG1, int C>
+__device__ __forceinline__ void tick_fft_p1(const KIdx bid, float* smem, const TickP1& q) {
+    static_assert(((1 << LG1) / 16) * C == 256, "tick roles run in 256-thread workgroups");
+    const IqSrc src = q.src;
+    const FrameGeom g = q.g;
+    float2* tw = reinterpret_cast<float2*>(smem);
+    fft_pass1_body<LG1, C>(bid, tw, tw + (1 << LG1) / 2, src, g, q.window, q.tw1, q.twn, q.scratch, q.lg2);
+}
+template <int LG2, int R>
+__device__ __forceinline__ void tick_fft_p2(const KIdx bid, float* smem, const TickP2& q) {
+    static_assert(((1 << LG2) / 16) * R == 256, "tick roles run in 256-thread workgroups");
+    float2* tw = reinterpret_cast<float2*>(smem);
+    fft_pass2_body<LG2, R>(bid, tw, tw + (1 << LG2) / 2, q.scratch, q.tw2, q.out, q.lg1, q.nframes, q.grp);
+}
+template <int TP>
+__device__ __forceinline__ void tick_zoom(const KIdx bid, float* smem, const TickZoom& q) {
+    zoom_palette_body<TP>(bid, smem, q.lines, q.fft_size, q.data_width, q.zs, q.zc, q.wf_min, q.wf_max, q.zoomed, q.index, q.grp, q.gsz);
+}
+
+// SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two)
+template <int SET>
+__global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, const TickTable* __restrict__ tab, TickDone done) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    int b = (int)blockIdx.x;
+    const int nb0 = l0.blocks[0] + l0.blocks[1];
+    if (b < nb0) {
+        if (b < l0.blocks[0]) { copy_one(l0.job[0], b, l0.blocks[0]); }
+        else { copy_one(l0.job[1], b - l0.blocks[0], l0.blocks[1]); }
+    }
+    else {
+        b -= nb0;
+        const int n = tab->n;
+        int ei = 0, first = 0;
+        while (ei < n) {
+            const int end = tab->block_end[ei];
+            if (b < end) { break; }
+            first = end;
+            ei++;
+        }
+        if (ei < n) {
+            const TickEntry& e = tab->e[ei];
+            const int lb = b - first, gx = e.gx;
+            const KIdx bid{ lb % gx, lb / gx }, gdim{ gx, e.gy };
+            switch (e.role) {
+            case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e.jobs)); break;
+            case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e.jobs)); break;
+            case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e.jobs)); } break;
+            case TR_FCM_132_4: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            case TR_FCM_6: { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            case TR_FCM_10: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            case TR_FCM_16: { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            case TR_FCL_0: { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            case TR_FCL_PF:
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); }
+                break;
+            case TR_TOEP_C: vfo_toep_body<2, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
+            case TR_TOEP_R: vfo_toep_body<1, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
+            case TR_TOEP_Q: vfo_toep_body<1, 2, true>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
+            case TR_FIRB_C:
+                vfo_firb_body<2, false>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                break;
+            case TR_FIRB_R:
+                vfo_firb_body<1, false>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                break;
+            case TR_FIRB_S:
+                vfo_firb_body<1, true>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                break;
+            case TR_FIRB_Q:
+                vfo_firb_body<1, true, true>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                break;
+            case TR_PRE: vfo_demod_pre_body(bid, gdim, reinterpret_cast<const PreJob*>(e.jobs)); break;
+            case TR_SEQ:
+                if (threadIdx.x < 64) { vfo_sequential_body(bid, reinterpret_cast<const SeqJob*>(e.jobs), e.aux); }
+                break;
+            case TR_FFT_S10: tick_fft_single<10, 4>(bid, smem, e.p.fs); break;
+            case TR_FFT_S11: tick_fft_single<11, 2>(bid, smem, e.p.fs); break;
+            case TR_FFT_S12: tick_fft_single<12, 1>(bid, smem, e.p.fs); break;
+            case TR_FFT_P1_6: tick_fft_p1<6, 64>(bid, smem, e.p.p1); break;
+            case TR_FFT_P1_7: tick_fft_p1<7, 32>(bid, smem, e.p.p1); break;
+            case TR_FFT_P1_8: tick_fft_p1<8, 16>(bid, smem, e.p.p1); break;
+            case TR_FFT_P1_9: tick_fft_p1<9, 8>(bid, smem, e.p.p1); break;
+            case TR_FFT_P1_10: tick_fft_p1<10, 4>(bid, smem, e.p.p1); break;
+            case TR_FFT_P2_7: tick_fft_p2<7, 32>(bid, smem, e.p.p2); break;
+            case TR_FFT_P2_8: tick_fft_p2<8, 16>(bid, smem, e.p.p2); break;
+            case TR_FFT_P2_9: tick_fft_p2<9, 8>(bid, smem, e.p.p2); break;
+            case TR_FFT_P2_10: tick_fft_p2<10, 4>(bid, smem, e.p.p2); break;
+            case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z); break;
+            case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z); break;
+            case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z); break;
+            default: break;
+            }
+        }
+    }
+    tick_finish(done);
+}
+
+}  // namespace sdrpp_k

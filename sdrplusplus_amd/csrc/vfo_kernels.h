@@ -234,9 +234,9 @@ struct RotJob {
     float2* out;
     int n;
 };
-__global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob* __restrict__ jobs) {
-    const RotJob& job = jobs[blockIdx.y];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void vfo_rotate_body(const KIdx bid, const KIdx gdim, const IqSrc& src, const RotJob* __restrict__ jobs) {
+    const RotJob& job = jobs[bid.y];
+    for (int i = bid.x * blockDim.x + threadIdx.x; i < job.n; i += gdim.x * blockDim.x) {
         double ph = fma((double)i, job.theta, job.phi0);
         ph -= rint(ph);
         float sn, cs;
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob
         job.out[i] = make_float2(fmaf(x.x, cs, -(x.y * sn)), fmaf(x.x, sn, x.y * cs));
     }
 }
+__global__ __launch_bounds__(256) void vfo_rotate_kernel(IqSrc src, const RotJob* __restrict__ jobs) { vfo_rotate_body(kidx(blockIdx), kidx(gridDim), src, jobs); }
 
 // =====================================================================================================================
 // Reference-rotator mode (sdrpp_set_nco_mode(ctx, 1); parity runs against the reference's CPU path).
@@ -497,9 +498,9 @@ struct PreJob {
     float* out;
     double theta2, phi2;
 };
-__global__ __launch_bounds__(256) void vfo_demod_pre_kernel(const PreJob* __restrict__ jobs) {
-    const PreJob& job = jobs[blockIdx.y];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.n; i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void vfo_demod_pre_body(const KIdx bid, const KIdx gdim, const PreJob* __restrict__ jobs) {
+    const PreJob& job = jobs[bid.y];
+    for (int i = bid.x * blockDim.x + threadIdx.x; i < job.n; i += gdim.x * blockDim.x) {
         const float2 x = job.in[i];
         if (job.mode == 2) { job.out[i] = sqrtf((x.x * x.x) + (x.y * x.y)); }
         else {
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void vfo_demod_pre_kernel(const PreJob* __rest
         }
     }
 }
+__global__ __launch_bounds__(256) void vfo_demod_pre_kernel(const PreJob* __restrict__ jobs) { vfo_demod_pre_body(kidx(blockIdx), kidx(gridDim), jobs); }
 
 struct SeqJob {
     int mode;  // 2 AM, 3/4/5 SSB family
@@ -563,8 +565,8 @@ __device__ __forceinline__ float agc_gain_of(float amp, float inAmp, const AgcSt
 // one-work-item loop over global memory pays ~1 us of load latency per sample.  The AGC's look-ahead to the end of the push
 // (agc.h:91-104) is a wave-wide max reduction where it is a plain maximum, and the same chunked loop where it has to re-run the
 // DC blocker forward (AM, audio AGC).
-__global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __restrict__ jobs, int njobs) {
-    const int id = blockIdx.x;
+__device__ __forceinline__ void vfo_sequential_body(const KIdx bid, const SeqJob* __restrict__ jobs, int njobs) {
+    const int id = bid.x;
     if (id >= njobs) { return; }
     const SeqJob job = jobs[id];
     const int lane = threadIdx.x;
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __rest
         if (lane == 0) { *job.agc = agc; }
     }
 }
+__global__ __launch_bounds__(64) void vfo_sequential_kernel(const SeqJob* __restrict__ jobs, int njobs) { vfo_sequential_body(kidx(blockIdx), jobs, njobs); }
 
 // =====================================================================================================================
 // History carry: after a push of n samples, the new history of a stream is the last hist_len samples of (old history ++ data).
@@ -735,16 +738,17 @@ struct CarryJob {
     int hist_len, n, width;
     int need;  // only the most recent `need` samples will be read by the next push: older entries are not copied
 };
-__global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) {
-    const CarryJob& job = jobs[blockIdx.y];
+__device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, const CarryJob* __restrict__ jobs) {
+    const CarryJob& job = jobs[bid.y];
     const int first = (job.hist_len - job.need) * job.width;
     const int total = job.hist_len * job.width;
-    for (int e = first + blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (int e = first + bid.x * blockDim.x + threadIdx.x; e < total; e += gdim.x * blockDim.x) {
         const int i = e / job.width, c = e % job.width;
         const long long s = (long long)job.n + i;  // index into old_hist ++ data
         job.new_hist[e] = (s < job.hist_len) ? job.old_hist[s * job.width + c] : job.data[(s - job.hist_len) * job.width + c];
     }
 }
+__global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) { carry_body(kidx(blockIdx), kidx(gridDim), jobs); }
 
 // =====================================================================================================================
 // Output gather (sdrpp_vfo_read_many): the per-VFO output blocks of one push packed back to back, so that the host gets all of them
@@ -814,13 +818,12 @@ __global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __re
 // to memory.  The reference keeps the previous phase as state; here it is recomputed from the IF history (atan2f(0, 0) = 0
 // reproduces the reset state).
 template <int WIDTH, bool STEREO, bool QUAD = false>
-__global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict__ jobs) {
+__device__ __forceinline__ void vfo_firb_body(const KIdx bid, float* smem, const int nthreads, const FirBJob* __restrict__ jobs) {  // nthreads: work-items of the workgroup that take part (a multiple of 64)
     constexpr int R = SDRPP_FIR_R;
-    HIP_DYNAMIC_SHARED(float, smem)
-    const FirBJob& job = jobs[blockIdx.y];
-    const int nthreads = blockDim.x;
+    const FirBJob& job = jobs[bid.y];
+    const int nall = (int)blockDim.x;  // every work-item of the workgroup loads, `nthreads` of them compute
     const int tile = nthreads * R;
-    const int j0 = blockIdx.x * tile;
+    const int j0 = bid.x * tile;
     if (j0 >= job.nout) { return; }
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD, kp = job.kp_pad;
     const int P1 = nthreads + kp / R + 1;  // columns per (phase, residue) row
@@ -833,18 +836,18 @@ __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict
     T* xs = reinterpret_cast<T*>(smem);
     if constexpr (QUAD) {
         float* phase = smem + ncomp;  // phase[i] = atan2f(x[base - 1 + i]), i = 0 .. nvalid
-        for (int s = threadIdx.x; s <= nvalid; s += nthreads) {
+        for (int s = threadIdx.x; s <= nvalid; s += nall) {
             const float2 x = stream_load2(job.in, base - 1 + s);
             phase[s] = fm_phase(x.y, x.x);
         }
         __syncthreads();
-        for (int s = threadIdx.x; s < ncomp; s += nthreads) {
+        for (int s = threadIdx.x; s < ncomp; s += nall) {
             const float v = (s < nvalid) ? normalize_phase(phase[s + 1] - phase[s]) * job.inv_deviation : 0.0f;
             xs[(s & (R - 1)) * P1 + (s >> 3)] = v;
         }
     }
     else {
-        for (int s = threadIdx.x; s < ncomp * D; s += nthreads) {
+        for (int s = threadIdx.x; s < ncomp * D; s += nall) {
             const int p = s & (D - 1), e = s >> lgD;
             T v;
             if constexpr (WIDTH == 2) { v = (s < nvalid) ? stream_load2(job.in, base + s) : make_float2(0.0f, 0.0f); }
@@ -854,6 +857,7 @@ __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict
     }
     __syncthreads();
     const int t = threadIdx.x;
+    if (t >= nthreads) { return; }  // (a role of the tick kernel: the workgroup is wider than the tile; everybody helped to load it and met the barriers)
     const UniformF32 taps = as_uniform(job.taps);
     T acc[R];
 #pragma unroll
@@ -895,6 +899,11 @@ __global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict
             else { job.out[jo + r] = acc[r]; }
         }
     }
+}
+template <int WIDTH, bool STEREO, bool QUAD = false>
+__global__ __launch_bounds__(256) void vfo_firb_kernel(const FirBJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    vfo_firb_body<WIDTH, STEREO, QUAD>(kidx(blockIdx), smem, (int)blockDim.x, jobs);
 }
 
 // Polyphase resampler, register-blocked over one full phase cycle per work-item: outputs n = c*L + r (r = 0..L-1) of cycle c
@@ -1151,9 +1160,8 @@ __host__ __device__ inline FCMLayout frontcm_layout(int K, int lgD) {
 // PF: IQ samples prefetched per lane (>= ceil(nsamp / 64)); KS > 0: geometry known at compile time (fully unrolled matrix loop:
 // every LDS offset is an immediate, the pair reads fuse into ds_read2_b32 and no scalar index arithmetic is left)
 template <int PF, int KS, int LGDS>
-__global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smemf)
-    const FrontCMJob& job = jobs[blockIdx.y];
+__device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs) {
+    const FrontCMJob& job = jobs[bid.y];
     constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = (KS > 0) ? KS : job.ntaps, lgD = (KS > 0) ? LGDS : job.log2_decim, D = 1 << lgD;
     const int NP = (K + 1) >> 1, NP4 = ((NP + 3) >> 2) << 2;
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
     if (tid < VT) { outp[tid] = job.out[tid]; }
     __syncthreads();
 
-    const int tile0 = (blockIdx.x * 4 + wv) * job.tiles_per_wave;
+    const int tile0 = (bid.x * 4 + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;  // tiles this wavefront really has
     if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
@@ -1316,6 +1324,11 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
         wave_sync();  // every lane is done with the planes and tile phasors before the next tile overwrites them
     }
 }
+template <int PF, int KS, int LGDS>
+__global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    vfo_frontcm_body<PF, KS, LGDS>(kidx(blockIdx), smemf, src, jobs);
+}
 
 // Long first stages (decimation by 32 or 64 with 143...726 taps: the plans for narrow channels in a very wide capture, e.g. cfg 4's
 // 61.44 MS/s -> 60 kS/s) use the same matrix formulation with the first stage alone as the "composite" filter, in a leaner
@@ -1330,9 +1343,8 @@ __host__ __device__ inline int frontcl_lds_floats(int K, int lgD) {
 // taps at /64); PF = 0: longer windows are loaded in place, unpipelined.
 #define SDRPP_FCL_PF 38
 template <int PF>
-__global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smemf)
-    const FrontCMJob& job = jobs[blockIdx.y];
+__device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs) {
+    const FrontCMJob& job = jobs[bid.y];
     constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
     const int NP = (K + 1) >> 1, NP8 = ((NP + 7) >> 3) << 3;
@@ -1346,7 +1358,8 @@ __global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const Fr
     float2** outp = reinterpret_cast<float2**>(smemf + 4 * pl + 2 * VT * 2);
     if (tid < VT) { outp[tid] = job.out[tid]; }
     __syncthreads();  // the only workgroup barrier
-    const int tile0 = (blockIdx.x * 2 + wv) * job.tiles_per_wave;
+    if (wv >= 2) { return; }  // (a role of the tick kernel: 256-wide workgroups, two tile engines)
+    const int tile0 = (bid.x * 2 + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
     if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
@@ -1448,6 +1461,11 @@ __global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const Fr
         wave_sync();
     }
 }
+template <int PF>
+__global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    vfo_frontcl_body<PF>(kidx(blockIdx), smemf, src, jobs);
+}
 
 // =====================================================================================================================
 // Per-stream FIR work on the matrix cores ("Toeplitz" form).  Any of the per-VFO filters behind the front end — a decimating
@@ -1491,9 +1509,8 @@ __device__ unsigned long long g_toep_prof[4][8];
 #endif
 
 template <int WIDTH, int G, bool QUAD>
-__global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smemt)
-    const ToepJob job = jobs[blockIdx.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
+__device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, float* smemt, const ToepJob* __restrict__ jobs) {
+    const ToepJob job = jobs[bid.y];  // by value: the fields stay in scalar registers (a reference is re-read from memory after every store)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef SDRPP_TOEP_KNOCK
     const int knock = g_toep_knock;
@@ -1511,7 +1528,7 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
     const int omt = G * 16 * rows;  // outputs per macro tile
     // macro tiles are dealt out CYCLICALLY: round `it` of wavefront w works on tile w + it * (wavefronts of this job), so at any
     // moment the wavefronts of a job stream through one contiguous region of its input and output
-    const int mt0 = blockIdx.x * 4 + wv, mts = gridDim.x * 4;
+    const int mt0 = bid.x * 4 + wv, mts = gdim.x * 4;
     const int c = lane & 15, kk = lane >> 4;
     const float* Bp = TLs + global_load_i32(job.lbase, lane);
     const float* Ar = XR + c * s_in + kk;
@@ -1787,6 +1804,11 @@ __global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restr
         atomicAdd(&g_toep_prof[kind][7], 1ull);
     }
 #endif
+}
+template <int WIDTH, int G, bool QUAD>
+__global__ __launch_bounds__(256, 5) void vfo_toep_kernel(const ToepJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemt)
+    vfo_toep_body<WIDTH, G, QUAD>(kidx(blockIdx), kidx(gridDim), smemt, jobs);
 }
 
 // =====================================================================================================================

@@ -168,6 +168,7 @@ template <class T> static inline int hipMemcpyFromSymbol(void* dst, const T& sym
 template <class T> static inline int hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy(&sym, src, n); return 0; }
 #define hipHostMallocDefault 0
 #define hipHostMallocMapped 2
+#define hipHostMallocCoherent 0x40000000
 static inline int hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
@@ -237,6 +238,8 @@ static inline void sincospif(float x, float* s, float* c) {
     *s = (float)sin(a);
     *c = (float)cos(a);
 }
+static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) { *p = v; } return o; }

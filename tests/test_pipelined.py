@@ -1,0 +1,213 @@
+"""Pipelined execution (sdrpp_set_pipelined: one launch per block, the stages of consecutive blocks skewed over consecutive launches,
+csrc/tick_kernels.h) against the ordinary pass, block for block and bit for bit: the roles of the tick kernel are the bodies of the
+ordinary kernels, so every result must be IDENTICAL — VFO blocks, raw dB lines, zoomed lines, palette indices — whatever the block
+sizes, including blocks that fall back to an ordinary pass in the middle of a pipelined run.  (The ordinary pass itself is what the
+other parity tests compare with the oracle.)"""
+import numpy as np
+import pytest
+
+from conftest import BACKENDS  # noqa: F401  (the `backend` fixture lives in conftest)
+
+
+def _ctx_pair(cfg, nv, max_push, fft_size, data_width=600, flags=7, ref_block=0):
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr = workloads.CFG[cfg]["sr"]
+    out = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=max_push)
+        if fft_size:
+            ctx.fft_configure(fft_size, fft_size, 0, capi.design_fft_window(2, fft_size))
+            start, size = capi.design_waterfall_view(0.0, sr, sr, fft_size)
+            ctx.fft_set_view(start, size, data_width, -120.0, 0.0)
+        vids = []
+        for mode, if_rate, bw, centre, _ in workloads.vfo_plan(cfg, nv):
+            d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        if ref_block:
+            ctx.set_reference_block(ref_block)
+        if pipelined:
+            ctx.set_pipelined(True, flags)
+        out.append((ctx, vids))
+    return out
+
+
+def _ordinary_results(ctx, vids, blk, fft):
+    ctx.push(blk)
+    r = {"vfo": {v: ctx.vfo_read(v).copy() for v in vids}}
+    if fft:
+        raw, zo, ix = ctx.fft_read()
+        r.update(raw=raw, zoomed=zo, index=ix)
+    return r
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (what, float(np.max(np.abs(a - b))) if a.size else 0.0)
+
+
+def _compare(ref, got, fft, what):
+    for v, a in ref["vfo"].items():
+        _same(a, got["vfo"][v], "%s vfo %d" % (what, v))
+    if fft:
+        n = len(ref["raw"])
+        assert got["n_lines"] == n, (what, got["n_lines"], n)
+        if n:
+            _same(ref["raw"], got["raw"], what + " raw lines")
+            _same(ref["zoomed"], got["zoomed"], what + " zoomed")
+            assert np.array_equal(ref["index"], got["index"]), what + " palette index"
+
+
+@pytest.mark.parametrize("fft_size", [4096, 16384])
+def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size):
+    """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
+    uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks."""
+    from sdrplusplus_amd import workloads
+
+    nv = 20
+    pushes = [50000, 1031, 20000, 7, 33333, 50000, 50000]
+    x = workloads.synth(3, sum(pushes), seed=5, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, max(pushes), fft_size)
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        refs.append(_ordinary_results(ca, va, blk, True))
+        cb.push(blk)  # returns at once: one launch
+    assert cb.ticket() == len(pushes)
+    assert cb.fft_lines() == len(refs[-1]["raw"])  # host knowledge: no flush needed
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    # the observing calls see the most recent block, as after an ordinary pass
+    for v_a, v_b in zip(va, vb):
+        _same(refs[-1]["vfo"][v_a], cb.vfo_read(v_b), "last block through sdrpp_vfo_read")
+    raw, zo, ix = cb.fft_read()
+    _same(refs[-1]["raw"], raw, "last block through sdrpp_fft_read")
+    assert np.array_equal(refs[-1]["index"], ix)
+    ca.close()
+    cb.close()
+
+
+def test_pipelined_equals_ordinary_mixed_modes(backend):
+    """cfg 4 geometry: 54 VFOs NFM / AM / USB at 61.44 MS/s (long first stages on the matrix cores, three or four decimators, resampler
+    or none, AM / SSB recursions with the reference's block ends) — chains of different depth share the ticks."""
+    from sdrplusplus_amd import workloads
+
+    nv = 54
+    pushes = [307200, 100003, 204397, 307200]
+    x = workloads.synth(4, sum(pushes), seed=7, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(4, nv, max(pushes), 0, flags=1, ref_block=50000)
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        refs.append(_ordinary_results(ca, va, blk, False))
+        cb.push(blk)
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block %d" % t)
+        cb.result_release(t)
+    ca.close()
+    cb.close()
+
+
+def test_pipelined_falls_back_to_ordinary_passes(backend):
+    """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
+    the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
+    from sdrplusplus_amd import capi, workloads
+
+    pushes = [50000, 12345, 50000]
+    x = workloads.synth(3, sum(pushes), seed=9, nvfo=2)
+    (ca, va), (cb, vb) = _ctx_pair(3, 2, max(pushes), 4096)
+    pos = 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        ref = _ordinary_results(ca, va, blk, True)
+        cb.push(blk)
+        with pytest.raises(capi.SdrppError):
+            cb.result_wait(cb.ticket())  # an ordinary pass leaves its results on the device
+        for v_a, v_b in zip(va, vb):
+            _same(ref["vfo"][v_a], cb.vfo_read(v_b), "vfo")
+        _same(ref["raw"], cb.fft_read()[0], "raw lines")
+    ca.close()
+    cb.close()
+    nv = 20
+    pushes = [50000, 50000, 20011, 50000, 50000, 50000]
+    x = workloads.synth(3, sum(pushes), seed=10, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, max(pushes), 0, flags=1)
+    pos = 0
+    tickets = []
+    for i, n in enumerate(pushes):
+        blk = x[pos:pos + n]
+        pos += n
+        if i == 2:
+            re, im = capi.design_phase_delta(-1.234e6, 10e6)
+            ca.vfo_set_phase_delta(va[3], re, im)
+            cb.vfo_set_phase_delta(vb[3], re, im)
+        ref = _ordinary_results(ca, va, blk, False)
+        cb.push(blk)
+        tickets.append((cb.ticket(), ref))
+    handed = 0
+    for t, ref in tickets:
+        try:
+            got = cb.result_wait(t)
+        except capi.SdrppError:
+            continue  # that block ran as an ordinary pass (the retune hand-over)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block %d" % t)
+        cb.result_release(t)
+        handed += 1
+    assert 3 <= handed < len(pushes)
+    for v_a, v_b in zip(va, vb):
+        _same(tickets[-1][1]["vfo"][v_a], cb.vfo_read(v_b), "last block")
+    ca.close()
+    cb.close()
+
+
+def test_pipelined_result_slots_and_modes(backend):
+    from sdrplusplus_amd import capi, workloads
+
+    nv, B = 20, 4000
+    x = workloads.synth(3, B * 40, seed=3, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 0, flags=1)
+    with pytest.raises(capi.SdrppError):
+        cb.set_deferred(True)
+    refs = []
+    for i in range(20):
+        blk = x[i * B:(i + 1) * B]
+        refs.append(_ordinary_results(ca, va, blk, False))
+        cb.push(blk)
+    # 16 slots: blocks 1 .. 4 have been overwritten by 17 .. 20
+    with pytest.raises(capi.SdrppError):
+        cb.result_wait(2)
+    got = cb.result_wait(7)
+    _compare({"vfo": dict(zip(vb, refs[6]["vfo"].values()))}, got, False, "block 7")
+    assert cb.result_ready(20) in (True, False)
+    cb.pipeline_flush()
+    cb.sync()
+    assert cb.result_ready(20)
+    # block 7 is still held: pushing on until its slot comes round again must fail, and work again after the release
+    with pytest.raises(capi.SdrppError):
+        for i in range(20, 40):
+            cb.push(x[i * B:(i + 1) * B])
+    assert cb.ticket() == 22  # block 23 would have needed slot 7
+    cb.result_release(7)
+    blk = x[22 * B:23 * B]
+    for i in range(20, 22):
+        _ordinary_results(ca, va, x[i * B:(i + 1) * B], False)
+    ref = _ordinary_results(ca, va, blk, False)
+    cb.push(blk)
+    got = cb.result_wait(23)
+    _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block 23")
+    # leaving the mode flushes; ordinary passes continue the same streams
+    cb.result_release(23)
+    cb.set_pipelined(False)
+    blk = x[23 * B:24 * B]
+    ref = _ordinary_results(ca, va, blk, False)
+    cb.push(blk)
+    for v_a, v_b in zip(va, vb):
+        _same(ref["vfo"][v_a], cb.vfo_read(v_b), "after leaving pipelined mode")
+    ca.close()
+    cb.close()
