@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <sdrpp_gfx950.h>
 
 namespace sdrpp_k {
 
@@ -44,6 +45,18 @@ __device__ __forceinline__ float2 iq_load(const IqSrc& s, long long i) {
 __device__ __forceinline__ float2 iq_load_clamped(const IqSrc& s, long long i) {
     if (i >= s.n_cur) { return make_float2(0.0f, 0.0f); }
     return iq_load(s, i);
+}
+
+// Branch-free form for loops that fetch several samples per work-item (every load unconditional, the address clamped into the buffers,
+// the value selected afterwards: the loads of a loop are all in flight before the first wait).  `valid` false -> zero.
+__device__ __forceinline__ float2 iq_load_nb(const IqSrc& s, long long i, bool valid) {
+    const bool cur = i >= 0;
+    valid = valid && i < s.n_cur;
+    long long ic = cur ? i : (long long)s.hist_len + i;
+    ic = (valid && ic >= 0) ? ic : 0;
+    const float2* p = (cur && valid) ? s.cur : s.hist;
+    const float2 v = global_load_f32x2(p, ic);
+    return valid ? v : make_float2(0.0f, 0.0f);
 }
 
 // ---- butterflies -------------------------------------------------------------------------------------------------------
@@ -219,11 +232,12 @@ struct FrameGeom {
     int nframes;
 };
 
+// (branch-free: the 16 loads of a work-item are in flight together; beyond the frame's nz samples the FFT input is zero)
 __device__ __forceinline__ float2 load_windowed(const IqSrc& src, const FrameGeom& g, const float* __restrict__ window, int frame, int i) {
-    if (i >= g.nz) { return make_float2(0.0f, 0.0f); }
-    const float2 x = iq_load(src, g.first_start + (long long)frame * g.stride + i);
-    const float w = window[i];
-    return make_float2(x.x * w, x.y * w);
+    const bool in = i < g.nz;
+    const float2 x = iq_load_nb(src, g.first_start + (long long)frame * g.stride + i, in);
+    const float w = window[in ? i : 0];
+    return in ? make_float2(x.x * w, x.y * w) : make_float2(0.0f, 0.0f);
 }
 
 // ---- N <= 4096: whole transform in one workgroup ------------------------------------------------------------------------------

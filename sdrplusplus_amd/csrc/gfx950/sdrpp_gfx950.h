@@ -29,6 +29,12 @@ __device__ __forceinline__ float2 global_load_f32x2(const float2* p, long long i
     const f32x2 v = ((const f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i];
     return make_float2(v.x, v.y);
 }
+// four consecutive floats, 16-byte aligned: one global_load_dwordx4
+__device__ __forceinline__ float4 global_load_f32x4(const float4* p, long long i) {
+    typedef float f32x4_ld __attribute__((ext_vector_type(4)));
+    const f32x4_ld v = ((const f32x4_ld __attribute__((address_space(1)))*)(uintptr_t)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // four consecutive floats (two complex samples) that are only 8-byte aligned: one global_load_dwordx4 (global memory accesses
 // need dword alignment only)
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -69,6 +75,34 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// diagnostic build (`make ticktrace`): time marks inside a kernel body (100 MHz wall clock), one set per workgroup of the launch
+#ifdef SDRPP_TICK_TRACE
+__device__ unsigned long long g_tick_mark[1 << 16][4];
+#define TICK_MARK(k)                                                                                      \
+    do {                                                                                                  \
+        if (threadIdx.x == 0) { g_tick_mark[blockIdx.x & 0xffff][k] = (unsigned long long)wall_clock64(); } \
+    } while (0)
+#else
+#define TICK_MARK(k) \
+    do {             \
+    } while (0)
+#endif
+
+// Every memory operation this wavefront has issued is complete (s_waitcnt vmcnt(0) lgkmcnt(0)) — no cache write-back, no invalidate.
+__device__ __forceinline__ void wave_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
+// Index of the first entry of the ascending table `ends[0 .. n)` (n <= 64) that is greater than b, and the entry in front of it (0 for the
+// first): every lane fetches one entry — ONE memory round trip instead of a chain of dependent scalar loads — and a ballot does the search.
+__device__ __forceinline__ int wave_upper_bound(const int* ends, int n, int b, int* prev_end) {
+    const int lane = threadIdx.x & 63;
+    const int mine = global_load_i32(ends, lane < n ? lane : (n > 0 ? n - 1 : 0));
+    const unsigned long long below = __ballot(lane < n && mine <= b);
+    const int idx = (int)__builtin_popcountll(below);
+    const int prev = __builtin_amdgcn_readlane(mine, idx > 0 ? idx - 1 : 0);
+    *prev_end = idx > 0 ? prev : 0;
+    return idx;
 }
 
 // Flags in LDS between the wavefronts of a workgroup (producer / consumer rings): a wavefront's LDS operations are carried out in

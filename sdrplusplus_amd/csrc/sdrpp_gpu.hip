@@ -288,7 +288,7 @@ struct sdrpp_ctx {
     TickTable* next_tab = nullptr;        // device address of the role table of the next tick (uploaded by the tick before)
     int next_tab_n = 0;
     TickTable* empty_tab = nullptr;       // device: a table without roles
-    unsigned* d_tick_counter = nullptr;   // device: finished wavefronts, running total
+    unsigned* d_tick_counter = nullptr;   // device: finished workgroups, running total
     unsigned tick_target = 0;             // its value when every tick launched so far has finished
     unsigned* h_tick_flag = nullptr;      // page-locked: completed ticks (written by the last wavefront of each tick)
     unsigned* hd_tick_flag = nullptr;     // the same, device address
@@ -2522,11 +2522,11 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     TickL0 l0{};
     if (land && land->bytes > 0) {
         l0.job[0] = *land;
-        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 16383) / 16384, 64));
+        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 8191) / 8192, 64));
     }
     if (c->arena_off > 0) {
         l0.job[1] = CopyJob{ c->arena_host_dev[c->arena_slot], c->arena_dev, (long long)((c->arena_off + 15) & ~(size_t)15), 0, 0 };
-        l0.blocks[1] = (int)std::max<size_t>(1, std::min<size_t>((c->arena_off + 16383) / 16384, 8));
+        l0.blocks[1] = (int)std::max<size_t>(1, std::min<size_t>((c->arena_off + 4095) / 4096, 16));  // one 16-byte load per work-item: a round trip over the bus each
     }
     int blocks = l0.blocks[0] + l0.blocks[1];
     size_t lds = 0;
@@ -2541,7 +2541,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         c->next_tab_n = tab_n_next;
         return SDRPP_OK;
     }
-    c->tick_target += 4u * (unsigned)blocks;
+    c->tick_target += (unsigned)blocks;
     c->ticks++;
     TickDone done{ c->d_tick_counter, c->hd_tick_flag, c->tick_target, (unsigned)c->ticks };
     const TickTable* tab = c->next_tab_n > 0 ? c->next_tab : c->empty_tab;
@@ -3058,6 +3058,23 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     if (!c) { return SDRPP_OK; }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     g_hostprof.report();
+#ifdef SDRPP_TICK_TRACE
+    if (const char* path = getenv("SDRPP_TICK_TRACE_FILE")) {
+        unsigned n = 0;
+        if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(sdrpp_k::g_tick_trace_n), sizeof(n)) == hipSuccess && n > 0) {
+            n = std::min<unsigned>(n, SDRPP_TICK_TRACE_CAP);
+            std::vector<sdrpp_k::TickTraceRec> recs(n);
+            if (hipMemcpyFromSymbol(recs.data(), HIP_SYMBOL(sdrpp_k::g_tick_trace), (size_t)n * sizeof(sdrpp_k::TickTraceRec)) == hipSuccess) {
+                if (FILE* f = fopen(path, "ab")) {
+                    fwrite(recs.data(), sizeof(sdrpp_k::TickTraceRec), n, f);
+                    fclose(f);
+                }
+            }
+            const unsigned zero = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_tick_trace_n), &zero, sizeof(zero));
+        }
+    }
+#endif
 #ifdef SDRPP_TOEP_PROF
     {
         unsigned long long h[4][8];

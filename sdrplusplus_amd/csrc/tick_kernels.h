@@ -52,7 +52,8 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
         const long long n4 = job.bytes / 4;
         for (long long i = done + tid; i < n4; i += nth) { d[i] = s[i]; }
     }
-    if (job.kind & 0x100) { __threadfence_system(); }  // results for the host: on their way before this wavefront counts itself done
+    // (results for the host: page-locked memory is not cached on the device, the stores are complete — tick_finish waits for them — before
+    // this wavefront counts itself done)
 }
 __device__ __forceinline__ void copy_body(const KIdx bid, const KIdx gdim, const CopyJob* __restrict__ jobs) { copy_one(jobs[bid.y], bid.x, gdim.x); }
 __global__ __launch_bounds__(256) void copy_kernel(const CopyJob* __restrict__ jobs) { copy_body(kidx(blockIdx), kidx(gridDim), jobs); }
@@ -114,14 +115,22 @@ struct TickL0 {
 // completion without a host API call: every wavefront counts itself done, the last one publishes the tick's number in page-locked
 // host memory that the host polls (7 us from launch to "host knows" against 12.5 us for hipStreamSynchronize)
 struct TickDone {
-    unsigned* counter;    // device, running total of finished wavefronts
+    unsigned* counter;    // device, running total of finished workgroups
     unsigned* host_flag;  // page-locked, device-mapped: number of completed ticks
-    unsigned target;      // value of the counter when this tick's last wavefront has finished (mod 2^32)
+    unsigned target;      // value of the counter when this tick's last workgroup has finished (mod 2^32)
     unsigned value;       // what to publish
 };
+// No device-scope fence per wavefront: on gfx950 that is a write-back of the XCD's whole L2 (65 us per tick of 800 wavefronts, 430 us at
+// 10^6-sample blocks, measured) — and what the roles write to device memory is made visible by the end of the kernel anyway, which is all
+// the next tick needs.  The host only ever looks at page-locked memory (uncached on the device: its stores are complete when the
+// wavefront's memory counter is down, wave_stores_done) after the flag that the LAST wavefront publishes behind a system-scope fence.
 __device__ __forceinline__ void tick_finish(const TickDone& d) {
-    __threadfence();
-    if ((threadIdx.x & 63) == 0) {
+    // ONE count per workgroup: 1 800 wavefronts adding to the same word were measured to cost more than the roles themselves (atomics to
+    // one address are carried out one after the other at the memory side).  Every wavefront reaches this point exactly once and past the
+    // last barrier of its role (the roles' early exits all lie behind their barriers), so a workgroup barrier is safe here.
+    wave_stores_done();
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const unsigned old = atomicAdd(d.counter, 1u);
         if (old + 1u == d.target) {
             __threadfence_system();
@@ -162,12 +171,25 @@ __device__ __forceinline__ void tick_zoom(const KIdx bid, float* smem, const Tic
     zoom_palette_body<TP>(bid, smem, q.lines, q.fft_size, q.data_width, q.zs, q.zc, q.wf_min, q.wf_max, q.zoomed, q.index, q.grp, q.gsz);
 }
 
+#ifdef SDRPP_TICK_TRACE
+// diagnostic build (`make ticktrace`): one record per workgroup — tick, role, entry, workgroup index, start / end in 100 MHz wall-clock
+// ticks, hardware id — in a device buffer the host dumps at sdrpp_destroy (SDRPP_TICK_TRACE_FILE); tools/tick_trace.py draws the timeline
+struct TickTraceRec { unsigned tick; short role, entry; int block; unsigned long long t0, t1; unsigned hwid, xcc; unsigned long long m[4]; };
+#define SDRPP_TICK_TRACE_CAP (1 << 20)
+__device__ TickTraceRec g_tick_trace[SDRPP_TICK_TRACE_CAP];
+__device__ unsigned g_tick_trace_n;
+#endif
+
 // SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two)
 template <int SET>
 __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, const TickTable* __restrict__ tab, TickDone done) {
     HIP_DYNAMIC_SHARED(float, smem)
     int b = (int)blockIdx.x;
     const int nb0 = l0.blocks[0] + l0.blocks[1];
+#ifdef SDRPP_TICK_TRACE
+    const unsigned long long tr_t0 = (unsigned long long)wall_clock64();
+    int tr_role = -1, tr_entry = -1;
+#endif
     if (b < nb0) {
         if (b < l0.blocks[0]) { copy_one(l0.job[0], b, l0.blocks[0]); }
         else { copy_one(l0.job[1], b - l0.blocks[0], l0.blocks[1]); }
@@ -175,15 +197,14 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
     else {
         b -= nb0;
         const int n = tab->n;
-        int ei = 0, first = 0;
-        while (ei < n) {
-            const int end = tab->block_end[ei];
-            if (b < end) { break; }
-            first = end;
-            ei++;
-        }
+        int first = 0;
+        const int ei = wave_upper_bound(tab->block_end, n, b, &first);
         if (ei < n) {
             const TickEntry& e = tab->e[ei];
+#ifdef SDRPP_TICK_TRACE
+            tr_role = e.role;
+            tr_entry = ei;
+#endif
             const int lb = b - first, gx = e.gx;
             const KIdx bid{ lb % gx, lb / gx }, gdim{ gx, e.gy };
             switch (e.role) {
@@ -236,6 +257,23 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             }
         }
     }
+#ifdef SDRPP_TICK_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned k = atomicAdd(&g_tick_trace_n, 1u);
+        if (k < SDRPP_TICK_TRACE_CAP) {
+            unsigned hw = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            TickTraceRec rec{ done.value, (short)tr_role, (short)tr_entry, (int)blockIdx.x, tr_t0, (unsigned long long)wall_clock64(), hw, xcc, { 0, 0, 0, 0 } };
+            for (int q = 0; q < 4; q++) {
+                rec.m[q] = g_tick_mark[blockIdx.x & 0xffff][q];
+                g_tick_mark[blockIdx.x & 0xffff][q] = 0;
+            }
+            g_tick_trace[k] = rec;
+        }
+    }
+#endif
     tick_finish(done);
 }
 

@@ -37,6 +37,24 @@ __device__ __forceinline__ float stream_load1(const StreamIn& s, int i) {
     if (i >= s.n) { return 0.0f; }
     return (i >= 0) ? s.data[i] : s.hist[s.hist_len + i];
 }
+// The same without a branch, for loops that fetch several samples per lane: the load is unconditional (the address is clamped into the
+// stream, the value selected afterwards), so the compiler issues all loads of the loop before the first wait — behind a per-element
+// branch every load costs its own memory round trip (measured: 18 x 0.75 us for the first window of the audio filter of a 50 000-sample
+// block).  Same values; needs i >= -hist_len like the functions above.
+__device__ __forceinline__ float2 stream_load2_nb(const StreamIn& s, int i, bool ok = true) {  // ok false: zero (no load is ever guarded by a branch)
+    const bool use = ok && i < s.n, cur = i >= 0;
+    int ic = cur ? i : (s.hist_len + i);
+    ic = (use && ic >= 0) ? ic : 0;
+    const float2 v = global_load_f32x2(reinterpret_cast<const float2*>((cur && use) ? s.data : s.hist), ic);
+    return use ? v : make_float2(0.0f, 0.0f);
+}
+__device__ __forceinline__ float stream_load1_nb(const StreamIn& s, int i, bool ok = true) {
+    const bool use = ok && i < s.n, cur = i >= 0;
+    int ic = cur ? i : (s.hist_len + i);
+    ic = (use && ic >= 0) ? ic : 0;
+    const float v = global_load_f32((cur && use) ? s.data : s.hist, ic);
+    return use ? v : 0.0f;
+}
 
 // =====================================================================================================================
 // Stage 1: frequency translation folded into the first decimating FIR, VT VFOs per work-item sharing one LDS input tile
@@ -739,13 +757,27 @@ struct CarryJob {
     int need;  // only the most recent `need` samples will be read by the next push: older entries are not copied
 };
 __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, const CarryJob* __restrict__ jobs) {
-    const CarryJob& job = jobs[bid.y];
+    const CarryJob job = jobs[bid.y];
     const int first = (job.hist_len - job.need) * job.width;
     const int total = job.hist_len * job.width;
-    for (int e = first + bid.x * blockDim.x + threadIdx.x; e < total; e += gdim.x * blockDim.x) {
-        const int i = e / job.width, c = e % job.width;
-        const long long s = (long long)job.n + i;  // index into old_hist ++ data
-        job.new_hist[e] = (s < job.hist_len) ? job.old_hist[s * job.width + c] : job.data[(s - job.hist_len) * job.width + c];
+    const int stride = gdim.x * 256;
+    // four independent elements per work-item and round, the loads branch-free and all in flight before the stores
+    for (int e0 = first + bid.x * 256 + (int)threadIdx.x; e0 < total; e0 += 4 * stride) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = min(e0 + q * stride, total - 1);  // (index clamped, never a guarded load)
+            const int i = e / job.width, c = e % job.width;
+            const long long sx = (long long)job.n + i;  // index into old_hist ++ data
+            const bool old = sx < job.hist_len;
+            const long long idx = old ? sx * job.width + c : (sx - job.hist_len) * job.width + c;
+            v[q] = global_load_f32(old ? job.old_hist : job.data, idx);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = e0 + q * stride;
+            if (e < total) { job.new_hist[e] = v[q]; }
+        }
     }
 }
 __global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) { carry_body(kidx(blockIdx), kidx(gridDim), jobs); }
@@ -1176,9 +1208,24 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);        // [VT]
 
     // ---- block prologue: tap operand table and output pointers (the only workgroup barrier of the kernel) ----
-    for (int i = tid; i < NP4 * 64; i += 256) { AL[i] = global_load_f32(job.atab, i); }
+    {   // (all loads of a work-item in flight before the first LDS write: a wait per load is a memory round trip each — 8 of them measured)
+        constexpr int NB = 5;  // 68 pairs x 64 lanes = 17 floats per work-item: four rounds of 16-byte loads + a rest
+        const int n4 = NP4 * 16;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        for (int i0 = tid; i0 < n4; i0 += 256 * NB) {
+            float4 tv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { tv[q] = global_load_f32x4(at4, min(i0 + q * 256, n4 - 1)); }  // (index clamped, never a guarded load)
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                if (i0 + q * 256 < n4) { AL4[i0 + q * 256] = tv[q]; }
+            }
+        }
+    }
     if (tid < VT) { outp[tid] = job.out[tid]; }
     __syncthreads();
+    TICK_MARK(0);
 
     const int tile0 = (bid.x * 4 + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
@@ -1201,7 +1248,7 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
             for (int q = 0; q < PF; q++) {
                 const int sidx = lane + q * 64;
                 const long long gi = base + sidx;
-                pf[q] = (sidx < nsamp && gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
+                pf[q] = iq_load_nb(src, gi, sidx < nsamp && gi >= job.min_idx);
             }
         }
     };
@@ -1245,6 +1292,7 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
         tile_phasor(tb);
         if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop
         wave_sync();
+        if (it == 0) { TICK_MARK(1); }
         wave_prio_low();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
         if constexpr (KS > 0) {
@@ -1307,6 +1355,7 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
             }
         }
         // ---- NCO: tile phasor x in-tile advance, then coalesced stores (lanes = consecutive outputs of one VFO) ----
+        if (it == 0) { TICK_MARK(2); }
         wave_prio_high();  // outside the matrix loop the wavefront's vector instructions go first (1 % on the launch: they wait ~30 cycles each behind the neighbours' v_mfma's otherwise)
         {
             const int j0 = tb * tile;
@@ -1523,8 +1572,20 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
     float* TLs = smemt;
     float* XR = smemt + tl_pad + wv * NPL * pl;
     float* XI = XR + pl;  // imaginary plane, or the phase scratch of the fused discriminator
-    for (int i = tid; i < job.tl_len; i += 256) { TLs[i] = global_load_f32(job.tl, i); }
+    {   // tap table -> LDS, all loads of a work-item in flight before the first LDS write (a wait per load is a memory round trip each)
+        constexpr int NB = 4;
+        for (int i0 = tid; i0 < job.tl_len; i0 += 256 * NB) {
+            float tv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { tv[q] = global_load_f32(job.tl, min(i0 + q * 256, job.tl_len - 1)); }  // (index clamped, never a guarded load)
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                if (i0 + q * 256 < job.tl_len) { TLs[i0 + q * 256] = tv[q]; }
+            }
+        }
+    }
     __syncthreads();  // the only workgroup barrier
+    TICK_MARK(0);
     const int omt = G * 16 * rows;  // outputs per macro tile
     // macro tiles are dealt out CYCLICALLY: round `it` of wavefront w works on tile w + it * (wavefronts of this job), so at any
     // moment the wavefronts of a job stream through one contiguous region of its input and output
@@ -1568,11 +1629,7 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
 #pragma unroll
                 for (int q = 0; q < PF4; q++) {
                     const int e = q * 64 + lane;
-                    float2 a = make_float2(0.0f, 0.0f), b = make_float2(0.0f, 0.0f);
-                    if (e < npair) {
-                        a = stream_load2(job.in, lo + 2 * e);
-                        b = stream_load2(job.in, lo + 2 * e + 1);
-                    }
+                    const float2 a = stream_load2_nb(job.in, lo + 2 * e, e < npair), b = stream_load2_nb(job.in, lo + 2 * e + 1, e < npair);
                     pf4[q] = make_float4(a.x, a.y, b.x, b.y);
                 }
             }
@@ -1590,7 +1647,7 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
 #pragma unroll
                 for (int q = 0; q < PF; q++) {
                     const int s = q * 64 + lane;
-                    pf2[q] = (s < cnt) ? stream_load2(job.in, lo + s) : make_float2(0.0f, 0.0f);
+                    pf2[q] = stream_load2_nb(job.in, lo + s, s < cnt);
                 }
             }
         }
@@ -1606,7 +1663,7 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
 #pragma unroll
                 for (int q = 0; q < PF; q++) {
                     const int s = q * 64 + lane;
-                    pf1[q] = (s < cnt) ? stream_load1(job.in, lo + s) : 0.0f;
+                    pf1[q] = stream_load1_nb(job.in, lo + s, s < cnt);
                 }
             }
         }
@@ -1653,6 +1710,7 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
         window_store();
         if (1 < job.mt_per_wave && (mt0 + mts) * omt < job.nout) { fetch(mt0 + mts); }
         discriminate();
+        TICK_MARK(1);
     }
     for (int it = 0; it < job.mt_per_wave; it++) {
         const int mt = mt0 + it * mts;
@@ -1733,6 +1791,7 @@ __device__ __forceinline__ void vfo_toep_body(const KIdx bid, const KIdx gdim, f
         const long long tp1 = TOEP_TICK();
         long long tp2 = tp1, tp3 = tp1, tp4 = tp1;
 #endif
+        if (it == 0) { TICK_MARK(2); }
         if (piped && it + 1 < job.mt_per_wave && (mt + mts) * omt < job.nout) {
             wave_sync();  // every lane has read its operands of this window
             window_store();

@@ -11,11 +11,20 @@ static inline UniformF32 as_uniform(const void* ptr) { return UniformF32{ (const
 static inline float global_load_f32(const float* p, long long i) { return p[i]; }
 static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
+static inline float4 global_load_f32x4(const float4* p, long long i) { return p[i]; }
 static inline float4 global_load_f32x4_unaligned(const float* p, long long i) { return make_float4(p[i], p[i + 1], p[i + 2], p[i + 3]); }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
+#define TICK_MARK(k) do { } while (0)
+static inline void wave_stores_done() {}
+static inline int wave_upper_bound(const int* ends, int n, int b, int* prev_end) {
+    int idx = 0;
+    while (idx < n && ends[idx] <= b) { idx++; }
+    *prev_end = idx > 0 ? ends[idx - 1] : 0;
+    return idx;
+}
 static inline void lds_flag_set(int* f, int v) { *(volatile int*)f = v; }
 static int g_flag_timeouts = 0;
 static inline void lds_flag_wait_ge(int* f, int need) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Run N pipelined blocks of a configuration on the `make ticktrace` build and dump the per-workgroup timeline of the tick kernel.
+   tools/tick_trace_run.py <cfg> <block> <nblocks> <dump.bin>"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sdrplusplus_amd import capi, workloads  # noqa: E402
+
+capi.DEFAULT_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", "libsdrpp_gpu_ticktrace.so")  # a switch of this TOOL, not of the binding
+import torch  # noqa: E402
+
+cfg, B, n, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+os.environ["SDRPP_TICK_TRACE_FILE"] = path
+if os.path.exists(path):
+    os.remove(path)
+nvfo = workloads.CFG[cfg]["nvfo"]
+ctx = capi.Context(0, max_push=B)
+workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo or None)
+xd = [torch.from_numpy(workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None).view(np.float32)).to("cuda") for i in range(4)]
+ctx.set_pipelined(True, 0)
+for i in range(n):
+    ctx.push_device(xd[i % 4].data_ptr(), B)
+ctx.sync()
+ctx.close()
+print("dumped", os.path.getsize(path) // 72, "records")
