@@ -277,6 +277,12 @@ struct sdrpp_ctx {
     };
     bool pipelined = false;
     int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
+    bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
+    // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
+    // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
+    int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
+    int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
+    int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
@@ -1060,7 +1066,11 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
                 const int tp = (bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1);
                 sdrpp_ctx::RoleLaunch z{};
                 z.e.role = tp == 16 ? TR_ZOOM_16 : (tp == 4 ? TR_ZOOM_4 : TR_ZOOM_1);
-                z.e.gx = (c->data_width + 256 / tp - 1) / (256 / tp);
+                const int zgroups = (c->data_width + 256 / tp - 1) / (256 / tp);
+                // pixel groups per workgroup (tick_kernels.h: tick_zoom): several once there are hundreds of them (10^6-sample blocks: 15 lines x 64
+                // groups, 13.3 -> 13.9 GS/s with 8), one when a block completes a line or two (a workgroup's groups run one after the other)
+                z.e.aux = std::max(1, std::min(std::min(c->tick_zoom_groups, zgroups), (int)nframes * zgroups / 128));
+                z.e.gx = (zgroups + z.e.aux - 1) / z.e.aux;
                 z.e.gy = (int)nframes;
                 z.e.p.z = TickZoom{ c->d_lines, c->d_zstart, c->d_zcount, c->d_zoomed, c->d_index, zgrp, c->fft_size, c->data_width, gsz, c->wf_min, c->wf_max, 0 };
                 z.lds = tick_lds_zoom(tp);
@@ -1176,7 +1186,7 @@ ToepJob toep_job(const ToepTab& T, int var, StreamIn in, float* out, int base0, 
 }
 
 struct ToepPlan { int grid_x = 0; size_t lds = 0; };
-ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
+ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl, int max_blocks = 2048) {
     ToepPlan P;
     if (jobs.empty()) { return P; }
     const int G = 2;
@@ -1186,7 +1196,7 @@ ToepPlan toep_plan(std::vector<ToepJob>& jobs, int npl) {
     for (; mtw < 16; mtw++) {
         size_t blocks = 0;
         for (auto& jb : jobs) { blocks += (size_t)((jb.nout + G * 16 * jb.rows - 1) / (G * 16 * jb.rows) + 4 * mtw - 1) / (size_t)(4 * mtw); }
-        if (blocks <= 2048) { break; }
+        if (blocks <= (size_t)max_blocks) { break; }
     }
     for (auto& jb : jobs) {
         jb.mt_per_wave = mtw;
@@ -1734,7 +1744,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
             // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
             const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD) * 4))) : 0;
-            const int resident = m_long ? 256 * long_blocks * 2 : 3072;
+            const int resident = m_long ? 256 * long_blocks * 2 : (c->tick_planning ? c->tick_fcm_waves : 3072);
             job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
             job.atab = reinterpret_cast<const float*>(d_taps);
             job.ptab = d_taps + (size_t)NP4 * 32;
@@ -1902,7 +1912,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         Lev<ToepJob>& L = *tlists[i].L;
         for (int l = 0; l < L.top; l++) {
             if (L.at[l].empty()) { continue; }
-            tplan[i][l] = toep_plan(L.at[l], tlists[i].npl);
+            tplan[i][l] = toep_plan(L.at[l], tlists[i].npl, c->tick_planning ? c->tick_toep_blocks : 2048);
             if (tplan[i][l].lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS"); }
         }
         if (!arena_push_lev(c, L)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
@@ -2492,6 +2502,21 @@ bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag 
 // One tick: level-0 work of the block that arrives with it (`land`: its landing copy, may be null; the arena slot the caller has filled
 // with the block's job tables) + every queued role whose turn it is.  The role table of the NEXT tick is appended to the arena slot and
 // travels with this tick's upload.
+// expected lifetime of a workgroup of a role relative to the others (tools/tick_trace.py timelines), for the order inside a tick
+inline int tick_role_weight(int role) {
+    switch (role) {
+    case TR_FCL_0: case TR_FCL_PF: return 100;
+    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;
+    case TR_SEQ: return 85;
+    case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
+    case TR_TOEP_Q: return 65;
+    case TR_TOEP_C: case TR_TOEP_R: case TR_FFT_S10: case TR_FFT_S11: case TR_FFT_S12: return 60;
+    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: return 50;
+    case TR_ROT: case TR_PRE: return 30;
+    case TR_ZOOM_16: case TR_ZOOM_4: case TR_ZOOM_1: return 20;
+    default: return 10;  // carry, copies
+    }
+}
 int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     std::vector<sdrpp_ctx::RoleLaunch> now;
     if (!c->tickq.empty()) {
@@ -2503,7 +2528,12 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     TickTable* tab_dev_next = nullptr;
     int tab_n_next = 0;
     if (!c->tickq.empty() && !c->tickq.front().empty()) {
-        const std::vector<sdrpp_ctx::RoleLaunch>& nx = c->tickq.front();
+        std::vector<sdrpp_ctx::RoleLaunch>& nx = c->tickq.front();
+        // The roles of a tick are independent of each other, so their order is free — and the hardware hands out workgroups in index
+        // order: longest workgroups first (front ends, FFT pass 1, the filters; zoom / carry / copies last), so that the tick ends on
+        // short ones instead of on a front end that only got its turn when everything else was through (10^6-sample blocks: the front
+        // end started 46 us into an 81 us tick).  The table is final here: later blocks only add to later ticks.
+        if (c->tick_order) { std::stable_sort(nx.begin(), nx.end(), [](const sdrpp_ctx::RoleLaunch& a, const sdrpp_ctx::RoleLaunch& b) { return tick_role_weight(a.e.role) > tick_role_weight(b.e.role); }); }
         if (nx.size() > SDRPP_TICK_MAX_ENTRIES) { return fail(c, SDRPP_ERR_UNSUPPORTED, "internal: %zu roles in one tick", nx.size()); }
         const size_t off = (c->arena_off + 63) & ~(size_t)63;
         if (off + sizeof(TickTable) > kArenaBytes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }

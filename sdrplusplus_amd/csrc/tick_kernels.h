@@ -166,9 +166,14 @@ __device__ __forceinline__ void tick_fft_p2(const KIdx bid, float* smem, const T
     float2* tw = reinterpret_cast<float2*>(smem);
     fft_pass2_body<LG2, R>(bid, tw, tw + (1 << LG2) / 2, q.scratch, q.tw2, q.out, q.lg1, q.nframes, q.grp);
 }
+// (a zoom workgroup of the stand-alone kernel covers 256 / TP pixels of one line — a few microseconds of latency and next to no work, yet a
+// resident workgroup slot for that long: in a tick, where slots are what the roles compete for, one workgroup walks `groups` such pixel groups)
 template <int TP>
-__device__ __forceinline__ void tick_zoom(const KIdx bid, float* smem, const TickZoom& q) {
-    zoom_palette_body<TP>(bid, smem, q.lines, q.fft_size, q.data_width, q.zs, q.zc, q.wf_min, q.wf_max, q.zoomed, q.index, q.grp, q.gsz);
+__device__ __forceinline__ void tick_zoom(const KIdx bid, float* smem, const TickZoom& q, int groups) {
+    for (int i = 0; i < groups; i++) {
+        if (i > 0) { __syncthreads(); }  // the partial maxima of the previous group have been read
+        zoom_palette_body<TP>(KIdx{ bid.x * groups + i, bid.y }, smem, q.lines, q.fft_size, q.data_width, q.zs, q.zc, q.wf_min, q.wf_max, q.zoomed, q.index, q.grp, q.gsz);
+    }
 }
 
 #ifdef SDRPP_TICK_TRACE
@@ -180,7 +185,9 @@ __device__ TickTraceRec g_tick_trace[SDRPP_TICK_TRACE_CAP];
 __device__ unsigned g_tick_trace_n;
 #endif
 
-// SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two)
+// SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two).
+// (SET 0 squeezed into 128 registers by the compiler — four wavefronts per SIMD, the matrix front end spilling 668 bytes per lane — was
+// measured slower at every block size: 12.9 against 13.3 GS/s at 10^6 samples, 2.5 against 3.1 at 50 000; profiles/r03e)
 template <int SET>
 __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, const TickTable* __restrict__ tab, TickDone done) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -250,9 +257,9 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_FFT_P2_8: tick_fft_p2<8, 16>(bid, smem, e.p.p2); break;
             case TR_FFT_P2_9: tick_fft_p2<9, 8>(bid, smem, e.p.p2); break;
             case TR_FFT_P2_10: tick_fft_p2<10, 4>(bid, smem, e.p.p2); break;
-            case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z); break;
-            case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z); break;
-            case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z); break;
+            case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
+            case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
+            case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
             default: break;
             }
         }
