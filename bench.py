@@ -9,14 +9,25 @@ Workload by --cfg (default: 3 on one GPU, 5 on several):
      discriminator, 237-tap audio low-pass) — the configuration BASELINE.json's metric is quoted on            [FP32 MFMA-bound]
   4  61.44 MS/s, 2^20-pt FFT + 128 VFOs mixed NFM / AM / USB
   5  one cfg-4 stream per GPU, seeds 0..N-1, RCCL gather of the finished (zoomed) waterfall lines on rank 0
-A "step" = one pass of the hot path (`sdrpp_push_device`) over one batch of `--push` complex samples already resident in HBM.
+
+A "step" = ONE BLOCK of `--push` complex samples (default 1 000 000 = the most a dsp::stream hand-over can carry,
+core/src/dsp/stream.h:9) already resident in HBM, handed to the hot path with `sdrpp_push_device` in PIPELINED mode
+(sdrpp_set_pipelined: one launch per block, the stages of consecutive blocks skewed over consecutive launches, include/sdrpp_gpu.h)
+with the reference's block semantics inside it (`sdrpp_set_reference_block(sr / 200)`: AGC look-ahead / rotator renormalisation see
+the blocks the file source would have cut, file_source/src/main.cpp:157), the zoomed waterfall lines of every block delivered into
+page-locked host memory and handed on in batches (multi.StreamRunner; with N > 1 gathered over RCCL).  The timed region = exactly K
+blocks pushed AND all their results delivered.  `--mode ordinary` runs the same blocks as ordinary passes (one launch per stage).
 Inputs come from sdrplusplus_amd/workloads.synth — the numpy generator the CPU baseline and the parity tests use too.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline      dominant kernel family, HIP events on its launch stream inside the timed region (algorithmic flops or bytes / time)
-  cpu_baseline  the reference's own RxVFO / demodulator / FFT code (oracle/_ref) timed on this host on a bounded sample
-  by_push       (cfg 3, one GPU) ingest rate as a function of the push size and of how the host drives the C-ABI, incl. the
-                reference's block size sr/200 through host pointers and through the C++ IQFrontEnd::run loop
+  roofline       dominant kernel (pipelined: the tick launch = every stage of the path over one block), HIP events on its launch stream
+                 inside the timed region (algorithmic flops or bytes / time)
+  cpu_baseline   the reference's own RxVFO / demodulator / FFT code (oracle/_ref) timed on this host on a bounded sample
+  ceiling        (one GPU) the same workload as ONE ordinary pass over 2^24 samples — what the kernels do with batches the
+                 dsp::stream boundary cannot carry; last round's headline, kept for comparison
+  other_configs  (one GPU) short runs of cfg 2 and cfg 4: pipelined at the stream cap + the 2^24 ceiling
+  by_push        (cfg 3, one GPU) ingest rate against the block size and the way the host drives the C-ABI, incl. the reference's
+                 block size sr/200 through host pointers, with results delivered, and through the C++ IQFrontEnd::run loop
 """
 import argparse
 import ctypes as C
@@ -32,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA peak (= packed FP32 VALU peak)
+STREAM_CAP = 1000000      # STREAM_BUFFER_SIZE, core/src/dsp/stream.h:9
 
 METRIC = {2: "IQ Msamples/s ingested (65536-pt FFT only, cfg2)", 3: "IQ Msamples/s ingested (65536-pt FFT + 32 VFO WFM)",
           4: "IQ Msamples/s ingested (2^20-pt FFT + 128 VFO mixed NFM/AM/USB, cfg4)", 5: "IQ Msamples/s ingested (cfg5: one 61.44 MS/s x 128-VFO stream per GPU, RCCL line gather)"}
@@ -42,7 +54,7 @@ FAMILY_KERNELS = {
     "vfo_stage1": ["vfo_frontcm_kernel", "vfo_frontcl_kernel", "vfo_front2_kernel", "vfo_stage1_kernel", "vfo_stage1_direct_kernel", "vfo_rotate_kernel"],
     "vfo_decim": ["vfo_toep_kernel<2, 2, false"], "vfo_poly": ["vfo_toep_kernel<2, 2, false", "vfo_polyc_kernel", "vfo_polyb_kernel", "vfo_poly_kernel"],
     "vfo_fir": ["vfo_toep_kernel<1, 2, true", "vfo_toep_kernel<2, 2, false", "vfo_toep_kernel<1, 2, false", "vfo_firb_kernel"],
-    "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"], "vfo_pipe": ["vfo_pipe_kernel"],
+    "demod": ["vfo_demod_pre_kernel", "vfo_sequential_kernel"], "carry_misc": ["carry_kernel"], "vfo_pipe": ["vfo_pipe_kernel"], "tick": ["tick_kernel", "void sdrpp_k::tick_kernel"],
 }
 
 
@@ -177,7 +189,7 @@ def algorithmic_work(push, plan, sr, nvfo, piped=False):
 def pmc_traffic(cfg, push, nvfo, dom):
     """HBM bytes per launch set of the dominant family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH_SIZE x2 per MI355X_MICROARCH.md, tools/rocpd_summary.py) — only when that profile was taken on this very workload."""
-    for name in ("pmc_traffic_cfg%d.json" % cfg, "pmc_traffic.json"):
+    for name in ("pmc_traffic_cfg%d_push%d.json" % (cfg, push), "pmc_traffic_cfg%d.json" % cfg, "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -194,61 +206,271 @@ def pmc_traffic(cfg, push, nvfo, dom):
     return None
 
 
-def by_push_report(torch, capi, workloads, sr, nvfo):
-    """cfg 3 ingest rate against the push size and the way the host drives the C-ABI.  Host buffers are page-locked (sdrpp_host_alloc —
-    what the C++ blocks use for their frame-buffer slots) unless marked pageable; every mode DELIVERS the outputs (all VFO blocks +
-    line count) to the host, except `device_no_read` (the step bench.py times: inputs resident, outputs left on the device)."""
+def path_work(push, plan, sr, nvfo, N):
+    """Whole-path ALGORITHMIC flops and compulsory HBM bytes of one block of `push` samples: what one tick launch of the
+    pipelined mode carries in steady state (every stage of the path, each on a different block)."""
+    fl, by, _ = algorithmic_work(push, plan, sr, nvfo, piped=False)
+    m = N.bit_length() - 1
+    fft_flops = push * (5.0 * m + 12.0)
+    vfo_flops = sum(v for k, v in fl.items() if k.startswith("vfo_"))
+    out_rate = sum(r for _, r, _, _, _ in plan) if nvfo else 0.0
+    bytes_per_sample = 12.0 + out_rate / sr * 8
+    return fft_flops + vfo_flops, bytes_per_sample * push, bytes_per_sample
+
+
+def make_inputs(torch, np, device, base, push, seed, nvfo, min_bytes=384 << 20):
+    """Resident input blocks: slices of one synthetic signal and of delayed copies of it — more than the 256 MiB Infinity Cache
+    holds, so a block is never served from the cache it was left in a few steps ago."""
+    total = max(push, 1 << 24)
+    total = (total + push - 1) // push * push if push <= (1 << 24) else push
+    x0 = synth_threaded(base, total, seed=seed, nvfo=nvfo if nvfo else None)
+    first = torch.from_numpy(x0.view(np.float32)).to(device)
+    del x0
+    copies = [first]
+    while len(copies) * total * 8 < min_bytes and len(copies) < 8:
+        copies.append(torch.roll(first, 2 * 4097 * len(copies)).contiguous())
+    bufs = []
+    for t in copies:
+        flat = t.view(-1)
+        for k in range(total // push):
+            bufs.append(flat[2 * k * push:2 * (k + 1) * push])
+    return bufs, copies
+
+
+def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4):
+    """One measured run of a configuration.  mode 'pipelined': sdrpp_set_pipelined, one launch per block; 'ordinary': one launch per
+    stage.  Returns (result dict for rank 0, inputs) — the inputs can be handed to a second run of the same configuration."""
+    from sdrplusplus_amd import capi, multi, workloads
+
+    base = 4 if cfg == 5 else cfg
+    sr, N = workloads.CFG[base]["sr"], workloads.CFG[base]["fft"]
+    stream_index = multi.stream_for_rank(rank, world, world)[0]
+    seed0 = multi.stream_seed(0x5D2B0001 if base != 4 else 0, stream_index)  # cfg 5: seeds 0 .. N-1 (SURVEY.md 8d)
+    if inputs is None or inputs[2] != (base, push, nvfo):
+        bufs, keep = make_inputs(torch, np, device, base, push, seed0 * 1000 + 1, nvfo)
+        inputs = (bufs, keep, (base, push, nvfo))
+    bufs = inputs[0]
+    ctx = capi.Context(local, max_push=push)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
+    info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo)
+    if ref_block is None:
+        ref_block = int(sr / 200)
+    if ref_block and ref_block < push:
+        ctx.set_reference_block(ref_block)
+    af_keep = []
+    if af and nvfo:
+        from sdrplusplus_amd import radio
+        for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
+            a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
+            ctx.vfo_set_af(vid, a_, k_)
+            af_keep.append(k_)
+    pipelined = mode == "pipelined"
+    max_lines = (push + N - 1) // N + 1
+    if pipelined:
+        ctx.set_pipelined(True, 2)  # zoomed lines + palette indices of every block into page-locked result slots
+        lines = torch.zeros((gather_every, max_lines + 1, data_width), dtype=torch.float32, device=device)
+    else:
+        lines = torch.empty((push // N, data_width), dtype=torch.float32, device=device)
+    runner = multi.StreamRunner(ctx, bufs, push, lines, sync=torch.cuda.synchronize, pipelined=pipelined, lag=lag, gather_every=gather_every)
+
+    for i in range(warmup):
+        runner.step(i)
+    runner.finish()
+    torch.cuda.synchronize()
+    # calibration (untimed): every kernel family bracketed by HIP events to find the dominant one and record the per-kernel split
+    ctx.timing_enable(True)
+    ncal = max(2, min(5, steps)) if not pipelined else max(8, min(24, steps))
+    for i in range(ncal):
+        runner.step(i)
+    runner.finish()
+    torch.cuda.synchronize()
+    fam_all = ctx.timing_read()
+    kernel_ms_all = {k: v[0] / ncal for k, v in fam_all.items() if v[0] > 0}
+    # dominant family = the longest one on the CRITICAL stream: in an ordinary pass with VFOs the FFT branch runs on a second stream as filler
+    # behind the VFO bank (its launches stretch while they wait for CUs, which says nothing about the kernels themselves), so only
+    # the VFO-bank families compete there; FFT-only runs (cfg 2) have just the FFT families.  Pipelined: the tick launch is everything.
+    filler = {"fft_pass1", "fft_pass2", "fft_single", "zoom_palette"} if nvfo else set()
+    cand = {k: v for k, v in kernel_ms_all.items() if k not in filler} or kernel_ms_all
+    dom = max(cand, key=cand.get) if cand else None
+    # timed region: only the dominant family keeps its event pair (two event records per launch on its launch stream)
+    ctx.timing_enable(True, families=[ctx.family_index(dom)] if dom else [])
+    blocks0 = runner.collected
+    elapsed = runner.timed(steps, first=warmup)
+    fam = ctx.timing_read()
+    ctx.timing_enable(False)
+
+    # sanity: the work was really done
+    if pipelined:
+        assert runner.collected - blocks0 == steps and not runner.tickets, (runner.collected, blocks0, steps)
+        assert runner.gathered is not None or rank != 0
+    else:
+        assert ctx.fft_lines() == push // N
+        if runner.collective and rank == 0:
+            assert runner.gathered is not None and tuple(runner.gathered.shape) == (world, push // N, data_width)
+    if base == 3:
+        for vid in info["vids"][:1]:
+            assert abs(ctx.vfo_out_count(vid) - push // 40) <= 2
+    out = None
+    if rank == 0:
+        total_samples = world * push * steps
+        value = total_samples / elapsed / 1e6
+        fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo, piped=kernel_ms_all.get("vfo_pipe", 0) > 0)
+        pflops, pbytes, bps = path_work(push, info["plan"], sr, nvfo, N)
+        fl["tick"], by["tick"], bound_of["tick"] = pflops, pbytes, ("mfma" if nvfo else "hbm")
+        launches = {k: max(1, v[1]) for k, v in fam.items()}
+        # average duration of one launch set of the dominant family inside the timed region (pipelined: of one tick launch; the few
+        # launches that drain the pipeline at the end carry less than a block's work and are part of the average)
+        kernel_ms = {k: (v[0] / (launches[k] if k == "tick" else steps)) for k, v in fam.items() if v[0] > 0}
+        roof = None
+        if dom is not None and dom in kernel_ms and dom in by:
+            dur = kernel_ms[dom] * 1e-3
+            gbs = by[dom] / dur / 1e9
+            traffic = pmc_traffic(base, push, nvfo, dom)
+            if bound_of.get(dom) == "mfma" and fl.get(dom):
+                tf = fl[dom] / dur / 1e12
+                roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5), "traffic": traffic,
+                        "algorithmic_flops_per_launch": fl[dom], "algorithmic_bytes_per_launch": by[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 5),
+                        "launches_timed": launches.get(dom),
+                        "note": ("tick = the ONE launch per block of pipelined mode: every stage of the path (front end, three decimator / resampler / channel stages, discriminator + audio filter, "
+                                 "FFT pass 1 / pass 2, zoom, carries, result copies), each working on a different block; flops / bytes = SURVEY.md 8(d) whole-path figures x samples per block; "
+                                 if dom == "tick" else
+                                 "family = all launches of this kind in one push (vfo_fir = channel filters + discriminator / audio low-passes; vfo_pipe = the pipelined FM back ends in one launch); ")
+                                + "peak = dense FP32 MFMA; traffic = HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic*.json, builder-run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes of this workload), null when no pass of this exact workload is committed"}
+            else:
+                roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": by[dom], "avg_launch_ms": round(kernel_ms[dom], 5), "launches_timed": launches.get(dom)}
+        roof_fft = {}
+        for f in ("fft_pass1", "fft_pass2", "fft_single", "zoom_palette"):
+            if f in kernel_ms_all and kernel_ms_all[f] > 0:
+                g = by[f] / (kernel_ms_all[f] * 1e-3) / 1e9
+                roof_fft[f] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(base, push, nvfo, f)}
+        per_gpu = value * 1e6 / world
+        roof_path = {"bound": "hbm", "achieved": round(per_gpu * bps / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(per_gpu * bps / 1e9 / HBM_PEAK_GBS, 5),
+                     "algorithmic_bytes_per_sample": bps, "algorithmic_TFLOPs": round(per_gpu * pflops / push / 1e12, 2), "frac_of_fp32_mfma_peak": round(per_gpu * pflops / push / 1e12 / FP32_PEAK_TFLOPS, 5),
+                     "note": "whole job, per GPU: SURVEY.md 8(d) path figures x ingest rate (wall clock of the timed region, result delivery included)"}
+        mode_names = "/".join(sorted({m for m, _, _, _, _ in info["plan"]})) if nvfo else ""
+        out = {
+            "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
+            "workload": "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s" % (cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else ""),
+            "samples_per_step_per_gpu": push, "mode": mode, "reference_block": ref_block if (ref_block and ref_block < push) else push,
+            "input_blocks_rotated": len(bufs), "input_bytes_rotated": len(bufs) * push * 8, "af_chain": bool(af and nvfo), "device": ctx.device_info(),
+            "roofline": roof, "roofline_fft": roof_fft, "roofline_path": roof_path,
+            "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
+            "realtime_factor": round(per_gpu / sr, 1), "sr": sr, "fft": N, "nvfo": nvfo,
+        }
+        if pipelined:
+            out["results_delivered"] = "zoomed lines + palette indices of every block in page-locked host memory (result flag 2), batches of %d blocks copied to the device%s; VFO outputs stay on the device" % (
+                gather_every, " and gathered on rank 0 over RCCL" if world > 1 else "")
+            out["result_lag_blocks"] = lag
+    ctx.close()
+    return out, inputs
+
+
+def compact(r):
+    if r is None:
+        return None
+    keep = ("value", "ms_per_step", "steps", "samples_per_step_per_gpu", "mode", "reference_block", "kernel_ms_per_step", "realtime_factor")
+    o = {k: r[k] for k in keep if k in r}
+    o["unit"] = "Msamples/s"
+    if r.get("roofline"):
+        o["roofline"] = {k: r["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms") if k in r["roofline"]}
+    if r.get("roofline_fft"):
+        o["roofline_fft"] = r["roofline_fft"]
+    o["roofline_path"] = {k: r["roofline_path"][k] for k in ("achieved", "frac", "algorithmic_TFLOPs", "frac_of_fp32_mfma_peak")}
+    return o
+
+
+def by_push_report(torch, capi, workloads, sr, nvfo, N):
+    """cfg 3 ingest rate against the block size and the way the host drives the C-ABI.  Host buffers are page-locked (sdrpp_host_alloc —
+    what the C++ blocks use for their frame-buffer slots) unless marked pageable.  `*_no_read` leave the outputs on the device; every other
+    mode DELIVERS all VFO blocks + the lines of every block to the host.  frac = rate x SURVEY.md 8(d) path flops / FP32 matrix peak."""
     import numpy as np
 
     res = {}
     dev = torch.device("cuda", torch.cuda.current_device())
-    for B in (int(sr / 200), 1000000):
-        per_pass = max(1, 1000000 // B)
+    for B in (int(sr / 200), STREAM_CAP):
+        per_pass = max(1, STREAM_CAP // B)
         ctx = capi.Context(dev.index or 0, max_push=B * per_pass)
         info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=nvfo)
         vids = info["vids"]
-        xh = workloads.synth(3, B, seed=7, nvfo=nvfo)
-        ptr = ctx.L.sdrpp_host_alloc(B * 8)
-        C.memmove(ptr, xh.ctypes.data, B * 8)
-        xd = torch.from_numpy(xh.view(np.float32)).to(dev)
+        nb = 4
+        xs = [workloads.synth(3, B, seed=7 + i, nvfo=nvfo) for i in range(nb)]
+        ptrs = []
+        for x in xs:
+            p = ctx.L.sdrpp_host_alloc(B * 8)
+            C.memmove(p, x.ctypes.data, B * 8)
+            ptrs.append(p)
+        xd = [torch.from_numpy(x.view(np.float32)).to(dev) for x in xs]
         entry = {"push": B}
 
-        def rate(fn, npush):
-            for _ in range(3):
-                fn()
-            ctx.sync()
+        def rate(fn, npush, end=None):
+            end = end or ctx.sync
+            for i in range(8):
+                fn(i)
+            end()
             best = 0.0
             for _trial in range(3):
                 t0 = time.perf_counter()
-                for _ in range(npush):
-                    fn()
-                ctx.sync()
+                for i in range(npush):
+                    fn(i)
+                end()
                 best = max(best, B * npush / (time.perf_counter() - t0) / 1e6)
             return round(best, 1)
 
-        npush = max(6, min(300, (1 << 25) // B))
-
-        def sync_pinned():
-            ctx.push_host_ptr(ptr, B)
+        npush = max(8, min(400, (1 << 26) // B))
+        # ---- ordinary passes ----
+        def sync_pinned(i):
+            ctx.push_host_ptr(ptrs[i % nb], B)
             ctx.vfo_read_many(vids)
             ctx.fft_lines()
 
-        def sync_pageable():
-            ctx.push(xh)
+        def sync_pageable(i):
+            ctx.push(xs[i % nb])
             ctx.vfo_read_many(vids)
             ctx.fft_lines()
 
-        entry["per_push_read_pinned"] = rate(sync_pinned, npush)
-        entry["per_push_read_pageable"] = rate(sync_pageable, npush)
-        entry["device_no_read"] = rate(lambda: ctx.push_device(xd.data_ptr(), B), npush)
+        entry["per_push_read_pinned"] = rate(sync_pinned, min(npush, 200))
+        entry["per_push_read_pageable"] = rate(sync_pageable, min(npush, 200))
+        entry["device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        # ---- pipelined: one launch per block ----
+        ctx.set_pipelined(True, 0)
+        entry["pipelined_device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        entry["pipelined_pinned_no_read"] = rate(lambda i: ctx.push_host_ptr_async(ptrs[i % nb], B), npush)
+        ctx.set_pipelined(False)
+        ctx.set_pipelined(True, 3)  # every VFO block + zoomed lines / palette indices of every block into page-locked result slots
+        lag = 8
+        state = {"next": ctx.ticket() + 1}
+
+        def collect(upto):
+            while state["next"] <= upto:
+                t = C.c_uint64(state["next"])
+                r = capi.Result()
+                ctx._chk(ctx.L.sdrpp_result_wait(ctx.h, t, C.byref(r)))
+                ctx._chk(ctx.L.sdrpp_result_release(ctx.h, t))
+                state["next"] += 1
+
+        def with_results(i):
+            ctx.push_host_ptr_async(ptrs[i % nb], B)
+            collect(ctx.ticket() - lag)
+
+        def with_results_pageable(i):
+            ctx.push(xs[i % nb])
+            collect(ctx.ticket() - lag)
+
+        entry["pipelined_pinned_results_delivered"] = rate(with_results, npush, lambda: collect(ctx.ticket()))
+        entry["pipelined_pageable_results_delivered"] = rate(with_results_pageable, npush, lambda: collect(ctx.ticket()))
+        entry["pipelined_result_lag_blocks"] = lag
+        ctx.set_pipelined(False)
+        # ---- deferred: many blocks staged, one ordinary pass ----
         ctx.set_deferred(True)
 
-        def deferred_pass(pinned=True):
-            for _ in range(per_pass):
+        def deferred_pass(i, pinned=True):
+            for k in range(per_pass):
                 if pinned:
-                    ctx.push_host_ptr_async(ptr, B)  # page-locked source: the device fetches the block, one wait per pass
+                    ctx.push_host_ptr_async(ptrs[(i + k) % nb], B)  # page-locked source: the device fetches the block, one wait per pass
                 else:
-                    ctx.push(xh)
+                    ctx.push(xs[(i + k) % nb])
             if pinned:
                 ctx.push_wait()
             ctx.vfo_read_many(vids)
@@ -256,10 +478,13 @@ def by_push_report(torch, capi, workloads, sr, nvfo):
 
         if per_pass > 1:
             entry["deferred_pushes_per_pass"] = per_pass
-            entry["deferred_read_pinned"] = round(rate(lambda: deferred_pass(True), max(3, npush // per_pass)) * per_pass, 1)
-            entry["deferred_read_pageable"] = round(rate(lambda: deferred_pass(False), max(3, npush // per_pass)) * per_pass, 1)
+            entry["deferred_read_pinned"] = round(rate(lambda i: deferred_pass(i, True), max(3, min(npush, 200) // per_pass)) * per_pass, 1)
+            entry["deferred_read_pageable"] = round(rate(lambda i: deferred_pass(i, False), max(3, min(npush, 200) // per_pass)) * per_pass, 1)
         ctx.set_deferred(False)
-        ctx.L.sdrpp_host_free(ptr)
+        pflops, _pb, _bps = path_work(B, info["plan"], sr, nvfo, N)
+        entry["frac_of_fp32_mfma_peak"] = {k: round(v * 1e6 * pflops / B / 1e12 / FP32_PEAK_TFLOPS, 5) for k, v in entry.items() if isinstance(v, float) and k not in ("push",)}
+        for p in ptrs:
+            ctx.L.sdrpp_host_free(p)
         ctx.close()
         res["B=%d" % B] = entry
     # through the C++ host mirror (source thread -> dsp::stream -> IQFrontEnd::run -> one sink thread per VFO), reference block size
@@ -269,31 +494,34 @@ def by_push_report(torch, capi, workloads, sr, nvfo):
             csrc = os.path.join(ROOT, "sdrplusplus_amd", "csrc")
             subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "bench_blocks.cpp"), "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"),
                             "-L" + csrc, "-lsdrpp_gpu", "-Wl,-rpath," + csrc, "-lpthread"], check=True, capture_output=True)
-            for buffered in (0, 1):
-                r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), "65536", str(nvfo), "3", str(buffered)],
+            for name, buffered, pipelined in (("bypass_pipelined", 0, 1), ("bypass_per_block", 0, 0), ("buffered", 1, 0)):
+                r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "3", str(buffered), str(pipelined)],
                                    capture_output=True, text=True, timeout=120)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                res["cpp_iqfrontend_run_%s" % ("buffered" if buffered else "bypass")] = json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
+                res["cpp_iqfrontend_run_%s" % name] = json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
     except Exception as e:
         res["cpp_iqfrontend_run"] = {"error": repr(e)[:300]}
-    res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push; deferred_read = "
-                   "sdrpp_set_deferred: pushes staged (pinned: sdrpp_push_pinned_async + one sdrpp_push_wait), one pass + one read per `deferred_pushes_per_pass` pushes, every push still its own reference block; "
-                   "cpp_iqfrontend_run = tests/host_cpp/bench_blocks.cpp (SpeedTester-style source thread, one sink thread per VFO), buffered = 32-slot frame buffer whose "
-                   "backlog is staged without per-block waits and processed as one deferred pass, results handed out by the worker and three helper threads")
+    res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push (ordinary pass); pipelined_* = sdrpp_set_pipelined, one launch per "
+                   "block: *_no_read leave the outputs on the device, *_results_delivered fetch the block from host memory AND deliver every VFO block + zoomed lines + palette indices into page-locked result slots "
+                   "(sdrpp_result_wait / _release `pipelined_result_lag_blocks` blocks behind the push; no deferral, no batching); deferred_read = sdrpp_set_deferred: pushes staged, one ordinary pass + one read per "
+                   "`deferred_pushes_per_pass` pushes; cpp_iqfrontend_run = tests/host_cpp/bench_blocks.cpp (SpeedTester-style source thread, one sink thread per VFO) through sdrpp_gpu::IQFrontEnd: bypass_pipelined = "
+                   "one block per launch, results handed to the streams a few blocks late; bypass_per_block = one ordinary pass per block; buffered = 32-slot frame buffer worked off as deferred passes")
     return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--push", type=int, default=1 << 24, help="complex samples per step (multiple of the FFT size); 2^24 = 1.7 s of the 10 MS/s stream per GPU and step")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--push", type=int, default=STREAM_CAP, help="complex samples per step = per block handed to the hot path (default: the dsp::stream cap, 10^6)")
+    ap.add_argument("--mode", choices=("pipelined", "ordinary"), default="pipelined", help="pipelined: one launch per block (sdrpp_set_pipelined); ordinary: one launch per stage")
+    ap.add_argument("--ref-block", type=int, default=-1, help="reference block inside a push (default sr/200, what the file source cuts; 0: the push is one block)")
     ap.add_argument("--nvfo", type=int, default=32)
-    ap.add_argument("--nbuf", type=int, default=4, help="distinct input batches rotated through (4 x 128 MiB at the default push: never resident in the 256 MiB MALL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-by-push", action="store_true")
-    ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload)")
+    ap.add_argument("--no-others", action="store_true", help="skip the ceiling and the cfg 2 / cfg 4 runs")
+    ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; runs as ordinary passes)")
     ap.add_argument("--fft-only", action="store_true", help="same as --cfg 2")
     ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3 on one GPU, 5 on several)")
     args = ap.parse_args()
@@ -309,139 +537,91 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    rccl = None
+    if world > 1 or os.environ.get("SDRPP_BENCH_FORCE_RCCL"):
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)  # backend "nccl" is RCCL on ROCm
+        names = [None] * world
+        dist.all_gather_object(names, "%s (rank %d, cuda:%d)" % (torch.cuda.get_device_name(local), rank, local))
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": names}
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
-    from sdrplusplus_amd import capi, multi, workloads
+    from sdrplusplus_amd import capi, workloads
 
     cfg = args.cfg if args.cfg in (2, 3, 4, 5) else (2 if args.fft_only else (3 if world == 1 else 5))
-    base = 4 if cfg == 5 else cfg  # cfg 5 = one cfg-4 stream per rank
+    base = 4 if cfg == 5 else cfg
     sr, N = workloads.CFG[base]["sr"], workloads.CFG[base]["fft"]
-    push = max(1, args.push // N) * N
     nvfo = 0 if base == 2 else (args.nvfo if base == 3 else 128)
-    stream_index = multi.stream_for_rank(rank, world, world)[0]
-    seed0 = multi.stream_seed(0x5D2B0001 if base != 4 else 0, stream_index)  # cfg 5: seeds 0 .. N-1
-    x0 = synth_threaded(base, push, seed=seed0 * 1000 + 1, nvfo=nvfo if nvfo else None)
-    first = torch.from_numpy(x0.view(np.float32)).to(device)
-    del x0
-    # further batches: the same signal delayed by a few thousand samples (distinct addresses and contents, same statistics)
-    bufs = [first] + [torch.roll(first, 2 * 4097 * b).contiguous() for b in range(1, args.nbuf)]
-    ctx = capi.Context(local, max_push=push)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
-    info = workloads.setup(ctx, base, dense_fft=True, data_width=1024, nvfo=nvfo)
-    af_keep = []
-    if args.af and nvfo:
-        from sdrplusplus_amd import radio
-        for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
-            a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
-            ctx.vfo_set_af(vid, a_, k_)
-            af_keep.append(k_)
-    lines_per_push = push // N
-    lines = torch.empty((lines_per_push, 1024), dtype=torch.float32, device=device)
-    runner = multi.StreamRunner(ctx, bufs, push, lines, sync=torch.cuda.synchronize)
-
-    for i in range(args.warmup):
-        runner.step(i)
-    torch.cuda.synchronize()
-    # calibration (untimed): every kernel family bracketed by HIP events to find the dominant one and record the per-kernel split
-    ctx.timing_enable(True)
-    ncal = max(2, min(5, args.steps))
-    for i in range(ncal):
-        runner.step(i)
-    torch.cuda.synchronize()
-    fam_all = ctx.timing_read()
-    kernel_ms_all = {k: v[0] / ncal for k, v in fam_all.items() if v[0] > 0}
-    # dominant family = the longest one on the CRITICAL stream: with VFOs present the FFT branch runs on a second stream as filler
-    # behind the VFO bank (its launches stretch while they wait for CUs, which says nothing about the kernels themselves), so only
-    # the VFO-bank families compete there; FFT-only runs (cfg 2) have just the FFT families.  The HBM-bound FFT kernels are still
-    # reported against 8 TB/s in `roofline_fft` below.
-    filler = {"fft_pass1", "fft_pass2", "fft_single", "zoom_palette"} if nvfo else set()
-    cand = {k: v for k, v in kernel_ms_all.items() if k not in filler} or kernel_ms_all
-    dom = max(cand, key=cand.get) if cand else None
-    # timed region: only the dominant family keeps its event pair (two event records per step on its launch stream)
-    ctx.timing_enable(True, families=[ctx.family_index(dom)] if dom else [])
-    elapsed = runner.timed(args.steps, first=args.warmup)
-    fam = ctx.timing_read()
-    ctx.timing_enable(False)
-
-    # sanity: the work was really done (outputs have the expected sizes)
-    assert ctx.fft_lines() == lines_per_push
-    if base == 3:
-        for vid in info["vids"][:1]:
-            assert abs(ctx.vfo_out_count(vid) - push // 40) <= 2
-    if world > 1 and rank == 0:
-        assert runner.gathered is not None and tuple(runner.gathered.shape) == (world, lines_per_push, 1024)
-
+    push = int(args.push)
+    mode = args.mode
+    if mode == "ordinary":
+        push = max(1, push // N) * N  # whole frames per step (the ordinary protocol copies a fixed number of lines)
+    ref_block = None if args.ref_block < 0 else args.ref_block
+    head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-
-    total_samples = world * push * args.steps
-    value = total_samples / elapsed / 1e6
-    ms_per_step = elapsed / args.steps * 1e3
-
-    # ---- roofline of the dominant kernel family (HIP events around its launches, on the launch stream, inside the timed region) ----
-    fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo, piped=kernel_ms_all.get("vfo_pipe", 0) > 0)
-    kernel_ms = {k: v[0] / args.steps for k, v in fam.items() if v[0] > 0}
-    roof = None
-    if dom is not None and dom in kernel_ms and dom in by:
-        dur = kernel_ms[dom] * 1e-3
-        gbs = by[dom] / dur / 1e9
-        traffic = pmc_traffic(base, push, nvfo, dom)
-        if bound_of.get(dom) == "mfma" and fl.get(dom):
-            tf = fl[dom] / dur / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5), "traffic": traffic,
-                    "algorithmic_flops_per_launch": fl[dom], "algorithmic_bytes_per_launch": by[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 4),
-                    "note": "family = all launches of this kind in one push (vfo_fir = channel filters + discriminator / audio low-passes; vfo_pipe = the pipelined FM back ends: last decimator + resampler + channel filter + discriminator / audio low-pass in one launch); peak = dense FP32 MFMA"}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": by[dom], "avg_launch_ms": round(kernel_ms[dom], 4)}
-    # the HBM-bound branch on its own (calibration pass: with VFOs present it shares the CUs with the matrix kernels and stretches)
-    roof_fft = {}
-    for f in ("fft_pass1", "fft_pass2", "fft_single", "zoom_palette"):
-        if f in kernel_ms_all and kernel_ms_all[f] > 0:
-            g = by[f] / (kernel_ms_all[f] * 1e-3) / 1e9
-            roof_fft[f] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(base, push, nvfo, f)}
-    # FFT 8 in + 4 out, VFO outputs at their IF rates; the IQ read is shared by both branches
-    out_rate = sum(r for _, r, _, _, _ in info["plan"]) if nvfo else 0.0
-    path_bytes = 12.0 + out_rate / sr * 8
-    per_gpu = value * 1e6 / world
-    roof_path = {"bound": "hbm", "achieved": round(per_gpu * path_bytes / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(per_gpu * path_bytes / 1e9 / HBM_PEAK_GBS, 5),
-                 "algorithmic_bytes_per_sample": path_bytes, "algorithmic_TFLOPs": round(per_gpu * sum(fl.values()) / push / 1e12, 2),
-                 "note": "whole step, per GPU: SURVEY.md 8(d) path figure x ingest rate"}
-
-    mode_names = "/".join(sorted({m for m, _, _, _, _ in info["plan"]})) if nvfo else ""
     out = {
-        "metric": METRIC[cfg], "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s" % (cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else ""),
-                   "samples_per_step_per_gpu": push, "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
-                   "input_batches_rotated": args.nbuf, "af_chain": bool(args.af and nvfo), "device": ctx.device_info()},
-        "roofline": roof, "roofline_fft": roof_fft, "roofline_path": roof_path,
-        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
-        "kernel_ms_note": "per-family HIP-event times from an untimed calibration pass (FFT branch and VFO bank run on two streams and overlap, so the "
-                          "entries sum to more than ms_per_step); roofline.avg_launch_ms is the dominant family re-measured inside the timed region",
-        "realtime_factor": round(per_gpu / sr, 1),
+        "metric": METRIC[cfg], "value": head["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": head["workload"], "samples_per_step_per_gpu": push, "mode": head["mode"] + (" (sdrpp_set_pipelined: one launch per block, results %d blocks late)" % head.get("result_lag_blocks", 0) if mode == "pipelined" else ""),
+                   "reference_block": head["reference_block"], "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
+                   "input_blocks_rotated": head["input_blocks_rotated"], "input_bytes_rotated": head["input_bytes_rotated"], "af_chain": head["af_chain"], "device": head["device"],
+                   "results_delivered": head.get("results_delivered")},
+        "roofline": head["roofline"], "roofline_fft": head["roofline_fft"], "roofline_path": head["roofline_path"],
+        "kernel_ms_per_step": head["kernel_ms_per_step"],
+        "kernel_ms_note": "per-family HIP-event times from an untimed calibration pass; pipelined mode has ONE family (tick: the launch per block); ordinary passes: the FFT branch and the VFO bank run on two "
+                          "streams and overlap, so the entries sum to more than ms_per_step; roofline.avg_launch_ms is the dominant family re-measured inside the timed region",
+        "realtime_factor": head["realtime_factor"],
     }
-    ctx.close()
-    del bufs, first
+    if rccl:
+        out["rccl"] = rccl
+    del inputs
     torch.cuda.empty_cache()
+    if world == 1 and not args.no_others:
+        others = {}
+        try:  # last round's headline geometry: ONE ordinary pass over 2^24 samples (1.7 s of the stream — more than a dsp::stream can hand over)
+            r, inp = run_workload(torch, np, device, local, cfg, max(1, (1 << 24) // N) * N, "ordinary", 10, 2, nvfo, af=args.af, ref_block=0)
+            out["ceiling"] = compact(r)
+            out["ceiling"]["note"] = "one ordinary pass over 2^24 samples per step (not API-legal through dsp::stream: cap 10^6); roofline = dominant kernel family of the pass"
+            del inp
+        except Exception as e:
+            out["ceiling"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+        for oc in (2, 4):
+            if oc == cfg:
+                continue
+            try:
+                ocN = workloads.CFG[oc]["fft"]
+                ocv = 0 if oc == 2 else 128
+                r1, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 60, 10, ocv)
+                del inp
+                torch.cuda.empty_cache()
+                r2, inp = run_workload(torch, np, device, local, oc, max(1, (1 << 24) // ocN) * ocN, "ordinary", 5, 2, ocv, ref_block=0)
+                del inp
+                torch.cuda.empty_cache()
+                others["cfg%d" % oc] = {"workload": r1["workload"], "pipelined_stream_cap": compact(r1), "ceiling_2p24_ordinary": compact(r2)}
+            except Exception as e:
+                others["cfg%d" % oc] = {"error": repr(e)[:300]}
+        out["other_configs"] = others
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(base, nvfo, N)
             if out["cpu_baseline"]:
-                out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
             out["cpu_baseline"] = {"error": repr(e)}
     if world == 1 and base == 3 and not args.no_by_push:
         try:
-            out["by_push"] = by_push_report(torch, capi, workloads, sr, nvfo)
+            out["by_push"] = by_push_report(torch, capi, workloads, sr, nvfo, N)
         except Exception as e:
             out["by_push"] = {"error": repr(e)[:400]}
     try:  # C stdio of anything loaded into this process goes out BEFORE the JSON line, which must be the last line on stdout

@@ -314,7 +314,8 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  *   sdrpp_push_pinned_async  page-locked memory is fetched by the launch itself; sdrpp_push_wait returns when all such fetches have run.
  * What cannot run that way (a pre-processing chain, the waterfall display state, the AF chain, the reference-rotator NCO, VFO groups
  * without the matrix-core front end, a retune hand-over in progress, more FFT frames than one scratch chunk) is processed as an ordinary
- * pass behind everything queued: always correct, pipelined where possible.
+ * pass behind everything queued: always correct, pipelined where possible — and its results are delivered into the block's result slot
+ * like any other block's (by plain copies and a wait inside the push: the slow path).
  * result_flags (sdrpp_set_pipelined): which results every block also delivers into page-locked host memory, ready for sdrpp_result_wait
  * without any copy call: 1 = every VFO's output block (what sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines.
  * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push). */

@@ -2722,6 +2722,57 @@ int tick_results_plan(sdrpp_ctx* c) {
     return SDRPP_OK;
 }
 
+// results of a block that ran as an ORDINARY pass inside a pipelined run (something the device cannot pipeline: a pre-processing chain, a
+// VFO group without the matrix front end, a retune hand-over ...): the same slot layout, filled by plain copies behind the pass and waited
+// for here — the slow path, but sdrpp_result_wait / _release then work for EVERY block of a pipelined run, whichever way it was processed
+int tick_results_direct(sdrpp_ctx* c) {
+    int rc = tick_results_ensure(c);
+    if (rc) { return rc; }
+    const int slot = (int)(c->pushes % kResSlots);
+    sdrpp_ctx::Result& R = c->res[slot];
+    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
+    R = sdrpp_ctx::Result{};
+    R.ticket = c->pushes;
+    size_t off = 0;
+    char* base = c->res_host[slot];
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            R.ids.push_back(v.id);
+            R.offsets.push_back((int64_t)(off / 8));
+            R.counts.push_back(s.n);
+            const size_t bytes = (size_t)s.n * 8;
+            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            if (bytes) { HIPCHK(c, hipMemcpyAsync(base + off, s.data, bytes, hipMemcpyDeviceToHost, c->stream)); }
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    R.n_lines = c->fft_on ? c->n_lines : 0;
+    if (R.n_lines > 0) {
+        if ((c->res_flags & 2) && c->data_width > 0) {
+            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
+            if (off + 2 * ((bytes + 15) & ~(size_t)15) > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            R.off_zoomed = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_zoomed, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+            R.off_index = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_index, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+        }
+        if (c->res_flags & 4) {
+            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
+            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            R.off_raw = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_lines, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.done_tick = c->ticks;  // nothing queued is left: complete as it stands
+    return SDRPP_OK;
+}
+
 // One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
 int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
     if (count == 0) { return SDRPP_OK; }
@@ -2801,9 +2852,13 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         if (!rc) { rc = tick_drain(c); }
         if (land) { c->land_tick = c->ticks; }
         if (!rc) { rc = push_common(c, d_iq, count, nullptr); }
-        // its results are where an ordinary pass leaves them: device buffers, readable after a synchronisation
-        sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
-        if (!R.held) { R = sdrpp_ctx::Result{}; }
+        // its results are where an ordinary pass leaves them (device buffers, readable after a synchronisation) and — with result flags —
+        // also in the block's result slot like every other block's
+        if (!rc && c->res_flags) { rc = tick_results_direct(c); }
+        else {
+            sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
+            if (!R.held) { R = sdrpp_ctx::Result{}; }
+        }
         return rc;
     }
     // queue the roles level by level and launch this block's tick

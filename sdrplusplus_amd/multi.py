@@ -30,50 +30,131 @@ def gather_lines(lines, dst=0, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lines = lines.contiguous()
-    if world == 1:
-        return lines.unsqueeze(0)
     out = [torch.empty_like(lines) for _ in range(world)] if rank == dst else None
     dist.gather(lines, out, dst=dst, group=group)
     return torch.stack(out) if rank == dst else None
 
 
 class StreamRunner:
-    """One rank = one IQ stream.  step(i): one push of the hot path over input batch i (already resident on the device), then —
-    with more than one rank — this rank's finished zoomed lines are copied out of the context and gathered on rank 0.
+    """One rank = one IQ stream.  Two protocols, the same object for a real context on a GPU and for the stub context of
+    tests/test_multi_gpu_gloo.py:
 
-    ctx needs push_device(ptr, count) and fft_copy_device(first, n, zoomed_ptr=...); `bufs` are the resident input batches
-    (anything with data_ptr()); `lines` is this rank's [lines_per_push, data_width] staging tensor; sync() blocks until the
-    device is idle (torch.cuda.synchronize on a GPU, a no-op for the CPU stub)."""
+    ordinary (pipelined=False): step(i) = one push of the hot path over input batch i (already resident on the device), then — with more
+    than one rank — this rank's finished zoomed lines are copied out of the context (`fft_copy_device`) and gathered on rank 0.
+    `lines` is this rank's [lines_per_push, data_width] staging tensor.
 
-    def __init__(self, ctx, bufs, push, lines, sync=None):
+    pipelined (sdrpp_set_pipelined, one launch per block, results `depth` launches late): step(i) = one push; the zoomed lines of the
+    block pushed `lag` steps earlier are taken from its page-locked result slot (`result_wait` never has to flush the pipeline for a block
+    that old) into a host staging buffer, and every `gather_every` blocks the batch goes to the device tensor `lines`
+    ([gather_every, max_lines + 1, data_width]; row max_lines, column 0 of a block's slot = its line count — blocks at the stream cap
+    complete a varying number of frames) and, with more than one rank, is gathered on rank 0.  Copy and gather run on a side stream:
+    nothing the host does for the lines waits for the launches queued on the compute stream.  finish() collects what is outstanding.
+
+    ctx needs push_device(ptr, count) and fft_copy_device(first, n, zoomed_ptr=...) resp. ticket() / result_wait(ticket, copy=False) /
+    result_release(ticket); `bufs` are the resident input batches (anything with data_ptr()); sync() blocks until the device is idle
+    (torch.cuda.synchronize on a GPU, a no-op for the CPU stub)."""
+
+    def __init__(self, ctx, bufs, push, lines, sync=None, pipelined=False, lag=8, gather_every=4):
         self.ctx, self.bufs, self.push, self.lines = ctx, bufs, int(push), lines
         self.sync = sync or (lambda: None)
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        # (a process group of ONE rank still runs the collectives: how a single-GPU box exercises the RCCL leg)
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.collective else 1
+        self.rank = dist.get_rank() if self.collective else 0
         self.gathered = None
+        self.pipelined = bool(pipelined)
+        self.lag, self.gather_every = int(lag), int(gather_every)
+        self.tickets = []
+        self.collected = 0   # blocks whose lines have been taken from their result slots
+        self.batches = 0     # batches handed to the device / gathered
+        self.nb = 0
+        if self.pipelined:
+            assert lines.dim() == 3 and lines.shape[0] == self.gather_every, "pipelined: lines = [gather_every, max_lines + 1, data_width]"
+            self.max_lines = lines.shape[1] - 1
+            on_gpu = lines.is_cuda
+            self.host = [torch.zeros(tuple(lines.shape), dtype=lines.dtype).pin_memory() if on_gpu else torch.zeros(tuple(lines.shape), dtype=lines.dtype) for _ in range(2)]
+            self.side = torch.cuda.Stream(device=lines.device) if on_gpu else None
+            self.host_free = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
+            self.cur = 0
+
+    # ---- pipelined protocol ----
+    def _collect(self, ticket):
+        r = self.ctx.result_wait(ticket, copy=False)
+        n = int(r["n_lines"])
+        if n > self.max_lines:
+            raise RuntimeError("block %d completed %d lines, staging holds %d" % (ticket, n, self.max_lines))
+        h = self.host[self.cur]
+        if n:
+            h[self.nb, :n].copy_(torch.from_numpy(r["zoomed"]))
+        h[self.nb, self.max_lines, 0] = float(n)
+        self.ctx.result_release(ticket)
+        self.collected += 1
+        self.nb += 1
+        if self.nb == self.gather_every:
+            self._flush_batch()
+
+    def _flush_batch(self):
+        if self.nb == 0:
+            return
+        h = self.host[self.cur]
+        for k in range(self.nb, self.gather_every):  # a partial last batch: the unused slots say "no lines"
+            h[k, self.max_lines, 0] = 0.0
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                self.lines.copy_(h, non_blocking=True)
+                self.host_free[self.cur].record(self.side)
+                if self.collective:
+                    self.gathered = gather_lines(self.lines, dst=0)
+            self.cur ^= 1
+            self.host_free[self.cur].synchronize()  # the staging buffer about to be refilled has left the host (two batches ago)
+        else:
+            self.lines.copy_(h)
+            if self.collective:
+                self.gathered = gather_lines(self.lines, dst=0)
+            self.cur ^= 1
+        if not self.collective:
+            self.gathered = self.lines.unsqueeze(0)
+        self.batches += 1
+        self.nb = 0
+
+    def finish(self):
+        """Collect every outstanding block (the first result_wait runs the queued stages), hand over the last partial batch."""
+        if not self.pipelined:
+            return
+        while self.tickets:
+            self._collect(self.tickets.pop(0))
+        self._flush_batch()
+        if self.side is not None:
+            self.side.synchronize()
 
     def step(self, i):
         self.ctx.push_device(self.bufs[i % len(self.bufs)].data_ptr(), self.push)
-        if self.world > 1:
+        if self.pipelined:
+            self.tickets.append(self.ctx.ticket())
+            if len(self.tickets) > self.lag:
+                self._collect(self.tickets.pop(0))
+        elif self.collective:
             self.ctx.fft_copy_device(0, self.lines.shape[0], zoomed_ptr=self.lines.data_ptr())
             self.gathered = gather_lines(self.lines, dst=0)
 
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             dist.barrier()
 
     def timed(self, steps, first=0):
-        """EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns the MAX over ranks of the wall time."""
+        """EXACTLY `steps` steps (pipelined: and the delivery of all their lines) bracketed by barrier + device sync on both sides;
+        returns the MAX over ranks of the wall time."""
         self.barrier()
         self.sync()
         t0 = time.perf_counter()
         for i in range(steps):
             self.step(first + i)
+        self.finish()
         self.sync()
         self.barrier()
         self.sync()
         elapsed = time.perf_counter() - t0
-        if self.world > 1:
+        if self.collective:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=self.lines.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())

@@ -50,6 +50,9 @@ int main(int argc, char** argv) {
     const double fftRate = atof(argv[6]);
     const std::string outdir = argv[7];
     const bool buffered = argc > 8 && std::string(argv[8]) == "buffered";
+    // "pipelined": the bypass path as one launch per block (IQFrontEnd::setPipelining), results handed out four blocks late and the tail by
+    // drainPipeline() after stop().  No IQ tap and no AF chain in this mode (they fall back to one pass per block, which "bypass" covers).
+    const bool pipelined = argc > 8 && std::string(argv[8]) == "pipelined";
     const int drainMs = argc > 9 ? atoi(argv[9]) : (buffered ? 1500 : 300);  // time to let handed-over blocks drain (the CPU emulator needs seconds)
     const size_t nsamp = iq.size() / 2;
 
@@ -83,8 +86,9 @@ int main(int argc, char** argv) {
 #endif
     // a consumer of the (pre-processed) wideband IQ, like the recorder's baseband tap (recorder/src/main.cpp:209,229)
     dsp::stream<dsp::complex_t> iqTap;
-    fe.bindIQStream(&iqTap);
-    {
+    if (pipelined) { fe.setPipelining(true, 4); }
+    else { fe.bindIQStream(&iqTap); }
+    if (!pipelined) {
         bool threw = false;
         try { fe.bindIQStream(&iqTap); } catch (const std::runtime_error&) { threw = true; }  // Splitter::bindStream, splitter.h:18-20
         dsp::stream<dsp::complex_t> other;
@@ -96,10 +100,24 @@ int main(int argc, char** argv) {
     sdrpp_gpu::RxVFO* wfmAf = fe.addVFO("radio_af", 250000.0, 150000.0, 300000.0);
     if (!wfmAf) { return 1; }
     wfmAf->attachDemod(sdrpp_gpu::Demod::WFM);
-    wfmAf->attachAF(48000.0, 50e-6, false);
+    if (!pipelined) { wfmAf->attachAF(48000.0, 50e-6, false); }
     if (fe.addVFO("raw", 1.0, 1.0, 0.0) != nullptr) { fprintf(stderr, "duplicate VFO name accepted\n"); return 1; }
     fe.removeVFO("nope");  // logs, like the reference
 
+    // pipelined mode: 17 more radios so that the bank has the matrix-core front end (>= 17 VFOs of one geometry) and the blocks really
+    // run as ticks; their audio is read and dropped
+    std::vector<sdrpp_gpu::RxVFO*> extra;
+    std::vector<std::vector<float>> extraOut(17);
+    std::vector<std::thread> extraThreads;
+    if (pipelined) {
+        for (int k = 0; k < 17; k++) {
+            sdrpp_gpu::RxVFO* v = fe.addVFO("x" + std::to_string(k), 250000.0, 150000.0, -1.0e6 + 50e3 * k);
+            if (!v) { return 1; }
+            v->attachDemod(sdrpp_gpu::Demod::WFM);
+            extra.push_back(v);
+        }
+        for (int k = 0; k < 17; k++) { extraThreads.emplace_back(drain<dsp::stereo_t>, &extra[(size_t)k]->audio, &extraOut[(size_t)k]); }
+    }
     std::vector<float> ifOut, audioOut, afOut, tapOut;
     std::thread t0(drain<dsp::complex_t>, &iqTap, &tapOut);
     std::thread t1(drain<dsp::complex_t>, &raw->out, &ifOut);
@@ -126,15 +144,24 @@ int main(int argc, char** argv) {
     // let the last block drain: a final empty swap is not part of the reference protocol, so wait on the line/audio counts instead
     std::this_thread::sleep_for(std::chrono::milliseconds(drainMs));
     fe.stop();
-    fe.unbindIQStream(&iqTap);
+    if (pipelined) {  // the blocks still in flight: handed out now (the sinks are still reading)
+        if (fe.drainPipeline() < 0) { fprintf(stderr, "drainPipeline\n"); return 1; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(drainMs));
+    }
+    else { fe.unbindIQStream(&iqTap); }
     iqTap.stopReader();
     raw->out.stopReader();
     wfm->audio.stopReader();
     wfmAf->audio.stopReader();
+    for (auto* v : extra) { v->audio.stopReader(); }
+    for (auto& t : extraThreads) { t.join(); }
     t0.join();
     t1.join();
     t2.join();
     t3.join();
+    for (auto& o : extraOut) {
+        if (pipelined && o.size() != audioOut.size()) { fprintf(stderr, "extra radio delivered %zu values, expected %zu\n", o.size(), audioOut.size()); return 1; }
+    }
     auto dump = [&](const char* name, const std::vector<float>& v) {
         std::ofstream o(outdir + "/" + name, std::ios::binary);
         o.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));

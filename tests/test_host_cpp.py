@@ -71,6 +71,12 @@ def _run_graph_and_check(exe, mode, tmp, drain_ms=None):
     ol, oi, oa, of = np.concatenate(ol), np.concatenate(oi), np.concatenate(oa), np.concatenate(of)
     assert lines.shape == ol.shape and np.array_equal(lines, ol)
     assert audio.shape == oa.shape and np.sqrt(np.mean((audio - oa) ** 2)) < 1e-5
+    if mode == "pipelined":  # setPipelining: no AF chain / IQ tap in the graph; the third VFO delivers the demodulator output itself
+        assert af.shape == oa.shape and np.array_equal(af, audio) and tap.size == 0
+        assert ifs.shape == oi.shape
+        n2 = 2 * 1250 - 10
+        assert np.sqrt(np.mean(np.abs(ifs[:n2] - oi[:n2]) ** 2)) / np.sqrt(np.mean(np.abs(oi[:n2]) ** 2)) < 5e-6
+        return
     # RxVFO::attachAF: resampler to 48 kHz + 50 us de-emphasis behind the demodulator, delivered on the same `audio` stream
     assert af.shape == of.shape and np.sqrt(np.mean((af - of) ** 2)) < 1e-5
     # bindIQStream: every block of the (here un-pre-processed) wideband IQ, bit for bit, across the setInput() change of source
@@ -85,7 +91,7 @@ def _run_graph_and_check(exe, mode, tmp, drain_ms=None):
     assert np.sqrt(np.mean(np.abs(ifs[:n2] - oi[:n2]) ** 2)) / np.sqrt(np.mean(np.abs(oi[:n2]) ** 2)) < 5e-6
 
 
-@pytest.mark.parametrize("mode", ["bypass", "buffered"])
+@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined"])
 def test_host_mirror_threaded_graph_on_the_emulator(mode):
     """The C++ mirror built against the test double of dsp::block / dsp::stream, linked with the CPU emulator build of the library:
     source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
@@ -118,7 +124,7 @@ def test_device_math_helpers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bypass", "buffered"])
+@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined"])
 def test_threaded_graph_matches_oracle(mode):
     with tempfile.TemporaryDirectory() as tmp:
         _run_graph_and_check(_build(tmp), mode, tmp)

@@ -133,6 +133,75 @@ def test_stream_runner_protocol_gloo():
     assert np.all(got[0][0] == 7.0) and np.all(got[0][1] == 1007.0)  # slot r = rank r's lines of the last (7th) push
 
 
+class _StubPipeCtx:
+    """Pipelined protocol: push_device + ticket / result_wait / result_release.  Block t of rank r "completes" (t % 3) + 1 lines, every
+    value of which is 1000 r + t."""
+
+    def __init__(self, rank, width):
+        self.rank, self.width, self.pushes, self.held, self.released = rank, width, 0, set(), []
+
+    def push_device(self, ptr, count):
+        self.pushes += 1
+
+    def ticket(self):
+        return self.pushes
+
+    def result_wait(self, ticket, copy=True):
+        assert 1 <= ticket <= self.pushes and ticket not in self.held and not copy
+        self.held.add(ticket)
+        n = (ticket % 3) + 1
+        return {"ticket": ticket, "n_lines": n, "zoomed": np.full((n, self.width), 1000.0 * self.rank + ticket, np.float32)}
+
+    def result_release(self, ticket):
+        self.held.remove(ticket)
+        self.released.append(ticket)
+
+
+def _pipe_runner_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdrplusplus_amd import multi
+
+    W, G, ML = 16, 4, 3
+    lines = torch.zeros((G, ML + 1, W), dtype=torch.float32)
+    bufs = [torch.zeros(8), torch.ones(8)]
+    ctx = _StubPipeCtx(rank, W)
+    r = multi.StreamRunner(ctx, bufs, push=4, lines=lines, pipelined=True, lag=3, gather_every=G)
+    elapsed = r.timed(10)  # 10 blocks: two full batches + a partial one of 2
+    assert elapsed > 0.0 and ctx.pushes == 10 and ctx.released == list(range(1, 11)) and not ctx.held
+    assert r.collected == 10 and r.batches == 3 and not r.tickets
+    q.put((rank, elapsed, None if r.gathered is None else r.gathered.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_runner_pipelined_protocol_gloo():
+    """The protocol bench.py runs in pipelined mode (one launch per block, lines taken from the result slot of the block `lag` pushes back,
+    batches of `gather_every` blocks gathered on rank 0, finish() inside the timed region) with world size 2 over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_runner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda x: x[0])
+    assert abs(res[0][1] - res[1][1]) < 1e-9
+    assert res[1][2] is None
+    got = res[0][2]
+    assert got.shape == (2, 4, 4, 16)  # [rank, block of the batch, max_lines + 1, width]
+    for rank in range(2):  # last batch = blocks 9 and 10, then two empty slots
+        for k, t in enumerate((9, 10)):
+            n = (t % 3) + 1
+            assert got[rank, k, 3, 0] == n and np.all(got[rank, k, :n] == 1000.0 * rank + t)
+        assert got[rank, 2, 3, 0] == 0 and got[rank, 3, 3, 0] == 0
+
+
 def test_stream_dealing():
     from sdrplusplus_amd import multi
 

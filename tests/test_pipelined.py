@@ -127,8 +127,10 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
         pos += n
         ref = _ordinary_results(ca, va, blk, True)
         cb.push(blk)
-        with pytest.raises(capi.SdrppError):
-            cb.result_wait(cb.ticket())  # an ordinary pass leaves its results on the device
+        # an ordinary pass leaves its results on the device AND — like every block of a pipelined run — in the block's result slot
+        got = cb.result_wait(cb.ticket())
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), "raw": ref["raw"], "zoomed": ref["zoomed"], "index": ref["index"]}, got, True, "fallback block")
+        cb.result_release(cb.ticket())
         for v_a, v_b in zip(va, vb):
             _same(ref["vfo"][v_a], cb.vfo_read(v_b), "vfo")
         _same(ref["raw"], cb.fft_read()[0], "raw lines")
@@ -150,16 +152,10 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
         ref = _ordinary_results(ca, va, blk, False)
         cb.push(blk)
         tickets.append((cb.ticket(), ref))
-    handed = 0
-    for t, ref in tickets:
-        try:
-            got = cb.result_wait(t)
-        except capi.SdrppError:
-            continue  # that block ran as an ordinary pass (the retune hand-over)
+    for t, ref in tickets:  # every block has its results, the one that ran as an ordinary pass (the retune hand-over) included
+        got = cb.result_wait(t)
         _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block %d" % t)
         cb.result_release(t)
-        handed += 1
-    assert 3 <= handed < len(pushes)
     for v_a, v_b in zip(va, vb):
         _same(tickets[-1][1]["vfo"][v_a], cb.vfo_read(v_b), "last block")
     ca.close()
