@@ -319,6 +319,12 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * result_flags (sdrpp_set_pipelined): which results every block also delivers into page-locked host memory, ready for sdrpp_result_wait
  * without any copy call: 1 = every VFO's output block (what sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines.
  * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push). */
+/* Host blocks in pipelined mode without the library's own copy: sdrpp_push_stage hands out the page-locked staging slot the next block is
+ * fetched from (room for max_push samples); the host fills it — with several threads if it likes: a 400 KB memcpy is the largest single
+ * item of a 50 000-sample block's host time — and its own buffer is free as soon as it has; sdrpp_push_staged then launches the block
+ * exactly like sdrpp_push.  One slot is open at a time. */
+int sdrpp_push_stage(sdrpp_ctx* ctx, int64_t count, float** slot);
+int sdrpp_push_staged(sdrpp_ctx* ctx, int64_t count);
 typedef struct sdrpp_result {
     uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
     int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */

@@ -181,6 +181,8 @@ def load():
     L.sdrpp_set_deferred.argtypes = [vp, C.c_int]
     L.sdrpp_push_pinned_async.argtypes = [vp, c_float_p, C.c_int64]
     L.sdrpp_push_wait.argtypes = [vp]
+    L.sdrpp_push_stage.argtypes = [vp, C.c_int64, C.POINTER(c_float_p)]
+    L.sdrpp_push_staged.argtypes = [vp, C.c_int64]
     L.sdrpp_host_alloc.restype = vp
     L.sdrpp_host_alloc.argtypes = [C.c_size_t]
     L.sdrpp_host_free.restype = None
@@ -225,7 +227,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
-    "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16",
+    "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged",
     "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -304,6 +306,7 @@ class Context:
         self.fft_size = 0
         self.data_width = 0
         self.wf_height = 0
+        self._res_scratch = Result()
 
     def _chk(self, rc):
         if rc < 0:
@@ -580,6 +583,28 @@ class Context:
             if r.raw:
                 out["raw"] = cp(np.ctypeslib.as_array(r.raw, shape=(r.n_lines, r.fft_size)))
         return out
+
+    def push_staged_from(self, iq):
+        """sdrpp_push_stage + fill + sdrpp_push_staged (pipelined mode): the block goes into the library's page-locked slot by the caller's copy."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        slot = c_float_p()
+        self._chk(self.L.sdrpp_push_stage(self.h, len(iq), C.byref(slot)))
+        C.memmove(slot, iq.ctypes.data, len(iq) * 8)
+        self._chk(self.L.sdrpp_push_staged(self.h, len(iq)))
+
+    def result_lines_into(self, ticket, dst_addr, max_lines):
+        """Lean form of result_wait + copy + release for the zoomed lines of a block (result flag 2): the lines go to host address
+        `dst_addr` (room for max_lines x data_width floats) with one memmove.  Returns the number of lines."""
+        r = self._res_scratch
+        self._chk(self.L.sdrpp_result_wait(self.h, int(ticket), C.byref(r)))
+        n = r.n_lines
+        if n > max_lines:
+            self.L.sdrpp_result_release(self.h, int(ticket))
+            raise RuntimeError("block %d completed %d lines, room for %d" % (ticket, n, max_lines))
+        if n > 0 and r.zoomed:
+            C.memmove(dst_addr, r.zoomed, n * r.data_width * 4)
+        self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))
+        return n
 
     def result_release(self, ticket):
         self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))

@@ -303,6 +303,7 @@ struct sdrpp_ctx {
     float* stage_host[kStageSlots] = {};  // page-locked staging of pushes from pageable memory (max_push complex each; allocated on first use)
     uint64_t stage_tick[kStageSlots] = {};  // the tick whose landing copy reads the slot (+1)
     int stage_cur = 0;
+    int stage_open = -1;                  // slot handed out by sdrpp_push_stage and not yet pushed
     char* res_host[kResSlots] = {};       // page-locked result slots
     char* res_dev[kResSlots] = {};        // their device addresses
     size_t res_cap = 0;                   // bytes per slot
@@ -4290,6 +4291,42 @@ static int tick_push_host(sdrpp_ctx* c, const void* src_host, const void* src_de
     }
     const CopyJob land{ src_dev, c->tick_land[li], (long long)bytes, bytes_per_sample == 4 ? 1 : 0, 0 };
     return tick_push(c, c->tick_land[li], count, &land);
+}
+
+// The staging slot of the next block handed to the HOST to fill (pipelined mode): what tick_push_host's memcpy does, in the caller's hands
+int sdrpp_push_stage(sdrpp_ctx* c, int64_t count, float** slot) {
+    DeviceScope dev_scope_(c);
+    if (!c || !slot) { return SDRPP_ERR_INVALID; }
+    if (!c->pipelined) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_stage: the context is not in pipelined mode"); }
+    if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_stage: count %lld out of range (max_push %lld)", (long long)count, (long long)c->max_push); }
+    const int si = c->stage_cur;
+    if (!c->stage_host[si]) {
+        if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer"); }
+    }
+    if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
+    c->stage_open = si;
+    *slot = reinterpret_cast<float*>(c->stage_host[si]);
+    return SDRPP_OK;
+}
+int sdrpp_push_staged(sdrpp_ctx* c, int64_t count) {
+    DeviceScope dev_scope_(c);
+    if (!c) { return SDRPP_ERR_INVALID; }
+    if (!c->pipelined || c->stage_open < 0 || c->stage_open != c->stage_cur) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged without an open staging slot (sdrpp_push_stage)"); }
+    if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged: count out of range"); }
+    const int si = c->stage_open;
+    c->stage_open = -1;
+    c->stage_cur = (c->stage_cur + 1) % kStageSlots;
+    const int li = (int)((c->pushes + 1) % 3);
+    if (!c->tick_land[li]) {
+        int rc = dev_alloc(c, &c->tick_land[li], (size_t)c->max_push * 2 + 32);
+        if (rc) { return rc; }
+    }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, c->stage_host[si], 0) != hipSuccess || !d) { return fail(c, SDRPP_ERR_HIP, "hipHostGetDevicePointer(staging) failed"); }
+    const CopyJob land{ d, c->tick_land[li], (long long)((size_t)count * 8), 0, 0 };
+    int rc = tick_push(c, c->tick_land[li], count, &land);
+    c->stage_tick[si] = c->ticks;
+    return rc;
 }
 
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {

@@ -207,11 +207,11 @@ public:
     }
     // Hands out everything still in flight (call with the block stopped, or from a control operation): -1 if a stream was stopped
     int drainPipeline() {
-        int rc = 0;
+        int rc = finishDelivery();
         while (!pendingTickets.empty()) {  // (a block whose hand-over failed — a stopped stream — is gone, like a block the reference had in flight)
             const uint64_t t = pendingTickets.front();
             pendingTickets.erase(pendingTickets.begin());
-            if (deliverResult(t) < 0) { rc = -1; }
+            if (startDelivery(t) < 0 || finishDelivery() < 0) { rc = -1; }
         }
         return rc;
     }
@@ -349,18 +349,36 @@ public:
             drainControl();
             if (_pipelining && pipelineEligible()) {
                 if (!pipeOn && enterPipelined() < 0) { return -1; }
-                // the block is copied into a page-locked staging slot (the stream buffer is free on return) and fetched by the launch
-                const int prc = sdrpp_push(ctx, (const float*)_in->readBuf, count);
-                _in->flush();
+                // the hand-over of the block delivered last has had a whole block's time on the helpers: join it (the helpers take one batch at a time)
+                // (a hand-over that failed means its stream was stopped under it — that block is gone, like a block the reference has in flight at a
+                // stop; whether THIS worker ends is decided by read() alone)
+                (void)finishDelivery();
+                // the block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
+                // 10 MS/s), so the helpers and this thread copy a quarter each — and is fetched from there by the launch
+                float* slot = nullptr;
+                int prc = sdrpp_push_stage(ctx, count, &slot);
+                if (!prc) {
+                    const char* srcb = (const char*)_in->readBuf;
+                    char* dstb = (char*)slot;
+                    const size_t bytes = (size_t)count * sizeof(dsp::complex_t), parts = bytes >= (size_t)(64 << 10) ? 4 : 1, per = ((bytes / parts) + 63) & ~(size_t)63;
+                    std::vector<std::function<void()>> cj;
+                    for (size_t q = 0; q < parts; q++) {
+                        const size_t o = q * per, n = o >= bytes ? 0 : std::min(per, bytes - o);
+                        if (n) { cj.emplace_back([srcb, dstb, o, n]() { memcpy(dstb + o, srcb + o, n); }); }
+                    }
+                    helpers.run(std::move(cj));
+                }
+                _in->flush();  // the stream buffer is free
+                if (!prc) { prc = sdrpp_push_staged(ctx, count); }
                 if (prc) {
                     fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
                     return -1;
                 }
                 pendingTickets.push_back(sdrpp_ticket(ctx));
-                while ((int)pendingTickets.size() > _pipeLag) {
+                if ((int)pendingTickets.size() > _pipeLag) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
                     const uint64_t t = pendingTickets.front();
                     pendingTickets.erase(pendingTickets.begin());
-                    if (deliverResult(t) < 0) { return -1; }
+                    if (startDelivery(t) < 0) { return -1; }
                 }
                 return count;
             }
@@ -501,8 +519,10 @@ private:
     }
     // one block's results: lines through acquire / release, one block out on every VFO stream (the VFOs the block was processed with:
     // a VFO removed or rebuilt since has a new handle and is skipped)
-    int deliverResult(uint64_t ticket) {
-        sdrpp_result r;
+    // (startDelivery hands the copies + swaps to the helpers and returns; finishDelivery joins them and releases the slot)
+    int startDelivery(uint64_t ticket) {
+        (void)finishDelivery();
+        sdrpp_result& r = inflight;
         if (sdrpp_result_wait(ctx, ticket, &r)) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] result of block %llu: %s\n", (unsigned long long)ticket, sdrpp_last_error(ctx));
             return -1;
@@ -517,8 +537,9 @@ private:
                 }
             });
         }
-        std::atomic<bool> failed{ false };
-        std::vector<std::pair<RxVFO*, int>> order;
+        deliveryFailed = false;
+        std::vector<std::pair<RxVFO*, int>>& order = inflightOrder;
+        order.clear();
         for (int k = 0; k < r.n_vfo; k++) {
             if (r.counts[k] <= 0) { continue; }
             for (auto& kv : vfos) {
@@ -530,7 +551,8 @@ private:
         }
         const int groups = 3;
         for (int g = 0; g < groups && !order.empty(); g++) {
-            jobs.emplace_back([g, groups, &order, &r, &failed]() {
+            jobs.emplace_back([this, g, groups, &order, &r]() {
+                std::atomic<bool>& failed = deliveryFailed;
                 for (size_t q = (size_t)g; q < order.size(); q += (size_t)groups) {
                     RxVFO* v = order[q].first;
                     const int k = order[q].second, n = r.counts[k];
@@ -546,9 +568,16 @@ private:
                 }
             });
         }
-        helpers.run(std::move(jobs));
-        sdrpp_result_release(ctx, ticket);
-        return failed ? -1 : 0;
+        inflightTicket = ticket;
+        helpers.begin(std::move(jobs));
+        return 0;
+    }
+    int finishDelivery() {
+        if (!inflightTicket) { return 0; }
+        helpers.finish();
+        sdrpp_result_release(ctx, inflightTicket);
+        inflightTicket = 0;
+        return deliveryFailed ? -1 : 0;
     }
 
     void drainControl() {
@@ -836,6 +865,10 @@ private:
     int _pipeLag = 6;
     bool pipeOn = false;                    // the context is in pipelined mode (owned by the worker)
     std::vector<uint64_t> pendingTickets;   // blocks launched whose results have not been handed out yet
+    uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
+    sdrpp_result inflight{};
+    std::vector<std::pair<RxVFO*, int>> inflightOrder;
+    std::atomic<bool> deliveryFailed{ false };
     // SampleFrameBuffer state (frame_buffer.h:100-134)
     dsp::complex_t* frames[FRAME_SLOTS] = {};
     int frameSizes[FRAME_SLOTS] = {};
@@ -893,6 +926,27 @@ private:
             cv.notify_all();
             for (auto& t : th) { if (t.joinable()) { t.join(); } }
             th.clear();
+        }
+        // hand the jobs to the helpers and return; finish() joins in and waits for the batch (one batch at a time)
+        void begin(std::vector<std::function<void()>>&& js) {
+            std::lock_guard<std::mutex> lck(m);
+            jobs = std::move(js);
+            next = 0;
+            cv.notify_all();
+        }
+        void finish() {
+            std::unique_lock<std::mutex> lck(m);
+            while (next < jobs.size()) {
+                auto job = std::move(jobs[next++]);
+                busy++;
+                lck.unlock();
+                job();
+                lck.lock();
+                busy--;
+            }
+            done.wait(lck, [this]() { return busy == 0 && next >= jobs.size(); });
+            jobs.clear();
+            next = 0;
         }
         // run the jobs on the helpers AND the calling thread; returns when all are done
         void run(std::vector<std::function<void()>>&& js) {

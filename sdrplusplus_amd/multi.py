@@ -76,18 +76,28 @@ class StreamRunner:
             self.side = torch.cuda.Stream(device=lines.device) if on_gpu else None
             self.host_free = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
             self.cur = 0
+            # a context with result_lines_into (capi.Context) copies a block's lines straight into the staging buffer
+            self.lean = hasattr(ctx, "result_lines_into")
+            self.host_np = [h.numpy() for h in self.host]
+            self.host_addr = [h.data_ptr() for h in self.host]
+            self.slot_bytes = lines.shape[1] * lines.shape[2] * lines.element_size()
+        self.buf_ptrs = [b.data_ptr() for b in bufs]
 
     # ---- pipelined protocol ----
     def _collect(self, ticket):
-        r = self.ctx.result_wait(ticket, copy=False)
-        n = int(r["n_lines"])
-        if n > self.max_lines:
-            raise RuntimeError("block %d completed %d lines, staging holds %d" % (ticket, n, self.max_lines))
-        h = self.host[self.cur]
-        if n:
-            h[self.nb, :n].copy_(torch.from_numpy(r["zoomed"]))
-        h[self.nb, self.max_lines, 0] = float(n)
-        self.ctx.result_release(ticket)
+        if self.lean:  # one call: wait, one memmove of the lines into the staging buffer, release
+            n = self.ctx.result_lines_into(ticket, self.host_addr[self.cur] + self.nb * self.slot_bytes, self.max_lines)
+            self.host_np[self.cur][self.nb, self.max_lines, 0] = n
+        else:
+            r = self.ctx.result_wait(ticket, copy=False)
+            n = int(r["n_lines"])
+            if n > self.max_lines:
+                raise RuntimeError("block %d completed %d lines, staging holds %d" % (ticket, n, self.max_lines))
+            h = self.host[self.cur]
+            if n:
+                h[self.nb, :n].copy_(torch.from_numpy(r["zoomed"]))
+            h[self.nb, self.max_lines, 0] = float(n)
+            self.ctx.result_release(ticket)
         self.collected += 1
         self.nb += 1
         if self.nb == self.gather_every:
@@ -98,7 +108,7 @@ class StreamRunner:
             return
         h = self.host[self.cur]
         for k in range(self.nb, self.gather_every):  # a partial last batch: the unused slots say "no lines"
-            h[k, self.max_lines, 0] = 0.0
+            self.host_np[self.cur][k, self.max_lines, 0] = 0.0
         if self.side is not None:
             with torch.cuda.stream(self.side):
                 self.lines.copy_(h, non_blocking=True)
@@ -128,7 +138,7 @@ class StreamRunner:
             self.side.synchronize()
 
     def step(self, i):
-        self.ctx.push_device(self.bufs[i % len(self.bufs)].data_ptr(), self.push)
+        self.ctx.push_device(self.buf_ptrs[i % len(self.buf_ptrs)], self.push)
         if self.pipelined:
             self.tickets.append(self.ctx.ticket())
             if len(self.tickets) > self.lag:

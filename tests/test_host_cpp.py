@@ -96,8 +96,10 @@ def test_host_mirror_threaded_graph_on_the_emulator(mode):
     """The C++ mirror built against the test double of dsp::block / dsp::stream, linked with the CPU emulator build of the library:
     source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
     flushInputBuffer, retune while running.  A logic check of the host code; the device leg is test_threaded_graph_matches_oracle."""
+    # (pipelined: the source is decoupled from the emulated launch by one more block and the 20-VFO bank takes seconds per block there,
+    # so "everything handed over has been consumed" needs a longer wait before the change of source)
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=4000)
+        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=12000 if mode == "pipelined" else 4000)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/core/src/dsp"), reason="needs the reference tree")

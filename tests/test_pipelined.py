@@ -73,7 +73,10 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size):
         blk = x[pos:pos + n]
         pos += n
         refs.append(_ordinary_results(ca, va, blk, True))
-        cb.push(blk)  # returns at once: one launch
+        if len(refs) % 2:
+            cb.push(blk)  # returns at once: one launch
+        else:
+            cb.push_staged_from(blk)  # sdrpp_push_stage / _staged: the host fills the library's page-locked slot itself
     assert cb.ticket() == len(pushes)
     assert cb.fft_lines() == len(refs[-1]["raw"])  # host knowledge: no flush needed
     for t, ref in enumerate(refs, start=1):
