@@ -199,9 +199,11 @@ public:
     // reference's own graph is a pipeline of one thread per block with a stream hand-over between each pair, a few blocks deep as well).
     // Same results, bit for bit; at the reference's block size the front end takes blocks 3-4x faster than with one pass per block.
     // What the device cannot pipeline (pre-processing, bound IQ streams, an AF chain) falls back to one pass per block by itself.
+    // lagBlocks should not be smaller than the depth of the device pipeline (6-8 launches for a radio bank + FFT): asking for a block's
+    // results earlier makes the library run the missing stages without new input, launch by launch.
     // Takes effect with the next block.  The tail still in flight when the input stops is handed out by drainPipeline() (worker stopped)
     // or with the next blocks.
-    void setPipelining(bool enabled, int lagBlocks = 6) {
+    void setPipelining(bool enabled, int lagBlocks = 8) {
         _pipeLag = lagBlocks < 1 ? 1 : (lagBlocks > 12 ? 12 : lagBlocks);
         _pipelining = enabled;
     }
@@ -862,7 +864,7 @@ private:
     bool _dcBlocking = false, _invertIQ = false;
     std::atomic<bool> _buffering{ false };
     std::atomic<bool> _pipelining{ false };
-    int _pipeLag = 6;
+    int _pipeLag = 8;
     bool pipeOn = false;                    // the context is in pipelined mode (owned by the worker)
     std::vector<uint64_t> pendingTickets;   // blocks launched whose results have not been handed out yet
     uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
@@ -892,28 +894,58 @@ private:
     // helpers of deliver(): the hand-offs of a pass (one memcpy + swap per VFO stream, one acquire / memcpy / release per FFT line) are
     // host copies of several MB at the frame buffer's batch sizes; they run side by side
     struct Helpers {
+        // A batch of jobs is claimed job by job through ONE atomic word (total << 32 | next) by the helpers and by the thread that waits
+        // for the batch.  A helper that runs out of work keeps looking for ~100 us before it goes to sleep on the condition variable: at
+        // hundreds of thousands of blocks per second a block's host budget is tens of microseconds, and a futex wake-up alone is 5-20 us
+        // (measured: with sleeping helpers the pipelined bypass path was SLOWER with the copies spread over four threads than with one).
         std::vector<std::thread> th;
         std::mutex m;
-        std::condition_variable cv, done;
+        std::condition_variable cv;
         std::vector<std::function<void()>> jobs;
-        size_t next = 0;
-        int busy = 0;
-        bool quit = false;
+        std::atomic<uint64_t> word{ 0 };   // (total << 32) | next
+        std::atomic<uint32_t> finished{ 0 };
+        std::atomic<int> sleepers{ 0 };
+        std::atomic<bool> quit{ false };
+        static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
+        }
+        bool claim_and_run() {
+            uint64_t w = word.load(std::memory_order_acquire);
+            while ((uint32_t)w < (uint32_t)(w >> 32)) {
+                if (word.compare_exchange_weak(w, w + 1, std::memory_order_acq_rel)) {
+                    jobs[(size_t)(uint32_t)w]();
+                    finished.fetch_add(1, std::memory_order_release);
+                    return true;
+                }
+            }
+            return false;
+        }
         void start(int n) {
             quit = false;
             for (int i = 0; i < n; i++) {
                 th.emplace_back([this]() {
-                    std::unique_lock<std::mutex> lck(m);
-                    while (true) {
-                        cv.wait(lck, [this]() { return quit || next < jobs.size(); });
-                        if (quit) { return; }
-                        auto job = std::move(jobs[next++]);
-                        busy++;
-                        lck.unlock();
-                        job();
-                        lck.lock();
-                        busy--;
-                        if (busy == 0 && next >= jobs.size()) { done.notify_all(); }
+                    auto idle_since = std::chrono::steady_clock::now();
+                    while (!quit.load(std::memory_order_relaxed)) {
+                        if (claim_and_run()) {
+                            idle_since = std::chrono::steady_clock::now();
+                            continue;
+                        }
+                        if (std::chrono::steady_clock::now() - idle_since < std::chrono::microseconds(100)) {
+                            relax();
+                            continue;
+                        }
+                        std::unique_lock<std::mutex> lck(m);
+                        sleepers++;
+                        cv.wait(lck, [this]() {
+                            const uint64_t w = word.load(std::memory_order_acquire);
+                            return quit.load() || (uint32_t)w < (uint32_t)(w >> 32);
+                        });
+                        sleepers--;
+                        idle_since = std::chrono::steady_clock::now();
                     }
                 });
             }
@@ -929,42 +961,29 @@ private:
         }
         // hand the jobs to the helpers and return; finish() joins in and waits for the batch (one batch at a time)
         void begin(std::vector<std::function<void()>>&& js) {
-            std::lock_guard<std::mutex> lck(m);
-            jobs = std::move(js);
-            next = 0;
-            cv.notify_all();
+            jobs = std::move(js);  // (no batch is open: every job of the previous one has been claimed AND finished, see finish())
+            finished.store(0, std::memory_order_relaxed);
+            word.store((uint64_t)jobs.size() << 32, std::memory_order_release);
+            if (sleepers.load(std::memory_order_acquire) > 0) {
+                std::lock_guard<std::mutex> lck(m);
+                cv.notify_all();
+            }
         }
         void finish() {
-            std::unique_lock<std::mutex> lck(m);
-            while (next < jobs.size()) {
-                auto job = std::move(jobs[next++]);
-                busy++;
-                lck.unlock();
-                job();
-                lck.lock();
-                busy--;
+            while (claim_and_run()) {}
+            const uint32_t total = (uint32_t)(word.load(std::memory_order_acquire) >> 32);
+            int spins = 0;
+            while (finished.load(std::memory_order_acquire) < total) {
+                if (++spins < 2000) { relax(); }
+                else { std::this_thread::yield(); }
             }
-            done.wait(lck, [this]() { return busy == 0 && next >= jobs.size(); });
+            word.store(0, std::memory_order_release);
             jobs.clear();
-            next = 0;
         }
         // run the jobs on the helpers AND the calling thread; returns when all are done
         void run(std::vector<std::function<void()>>&& js) {
-            std::unique_lock<std::mutex> lck(m);
-            jobs = std::move(js);
-            next = 0;
-            cv.notify_all();
-            while (next < jobs.size()) {
-                auto job = std::move(jobs[next++]);
-                busy++;
-                lck.unlock();
-                job();
-                lck.lock();
-                busy--;
-            }
-            done.wait(lck, [this]() { return busy == 0 && next >= jobs.size(); });
-            jobs.clear();
-            next = 0;
+            begin(std::move(js));
+            finish();
         }
     } helpers;
     FFTWindow _fftWindow = NUTTALL;
