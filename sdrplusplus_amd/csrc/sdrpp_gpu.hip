@@ -283,6 +283,10 @@ struct sdrpp_ctx {
     int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
     int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
     int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
+    long arena_begins = 0;                // blocks planned so far (block_bounds: one per ordinary pass / per block of a pipelined run)
+    int arena_allocs = 0;
+    long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
+    int test_fail_alloc = 0;
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
@@ -432,6 +436,9 @@ T* arena_push(sdrpp_ctx* c, const std::vector<T>& v, T** host_copy = nullptr) {
     size_t off = (c->arena_off + 63) & ~(size_t)63;
     size_t bytes = v.size() * sizeof(T);
     if (off + bytes > kArenaBytes) { return nullptr; }
+    // test hook (SDRPP_GPU_TEST_FAIL_ARENA="pass:allocation"): the job tables of that pass "do not fit" from that allocation on — the push
+    // fails half-way through its planning and must leave the stream exactly as it was (tests/test_parity_vfo.py::test_failed_push_changes_nothing)
+    if (c->test_fail_pass > 0 && c->arena_begins == c->test_fail_pass && ++c->arena_allocs >= c->test_fail_alloc) { return nullptr; }  // (counted in block_bounds)
     memcpy(c->arena_host[c->arena_slot] + off, v.data(), bytes);
     if (host_copy) { *host_copy = (T*)(c->arena_host[c->arena_slot] + off); }
     c->arena_off = off + bytes;
@@ -2348,6 +2355,8 @@ void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
 }
 
 void block_bounds(sdrpp_ctx* c, int64_t count, const std::vector<int>* push_ends) {
+    c->arena_begins++;
+    c->arena_allocs = 0;
     // the reference's blocks inside this push (sdrpp_set_reference_block): ends as cumulative sample counts
     // every push is at least one block of its own; with a reference block size it is cut further
     std::vector<int>& B = c->vfo_bounds;
@@ -2949,6 +2958,14 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
     sdrpp_ctx* c = new sdrpp_ctx;
     c->device = device;
     c->max_push = max_push;
+    if (const char* tf = getenv("SDRPP_GPU_TEST_FAIL_ARENA")) {
+        long a = 0;
+        int b = 0;
+        if (sscanf(tf, "%ld:%d", &a, &b) == 2) {
+            c->test_fail_pass = a;
+            c->test_fail_alloc = b;
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         char b[600];

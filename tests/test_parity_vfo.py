@@ -383,6 +383,56 @@ def test_push_size_invariance(backend):
         assert np.max(np.abs(i - outs[0][1])) < 2e-7
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_failed_push_changes_nothing(backend, pipelined, monkeypatch):
+    """A push that fails half-way through its planning ("job arena exhausted", forced by the library's test hook on the 3rd pass, from its
+    3rd job table on) returns an error and leaves the stream exactly as it was: the same block pushed again, and every block after it,
+    is bit-identical to a run without the failure (histories, decimation offsets, resampler phases, NCO phase, frame position)."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    nv, B = 20, 20000
+    x = workloads.synth(3, B * 5, seed=31, nvfo=nv)
+
+    def run(fail):
+        if fail:
+            monkeypatch.setenv("SDRPP_GPU_TEST_FAIL_ARENA", "3:3")
+        else:
+            monkeypatch.delenv("SDRPP_GPU_TEST_FAIL_ARENA", raising=False)
+        ctx = capi.Context(0, max_push=B)
+        ctx.fft_configure(4096, 4096, 0, capi.design_fft_window(2, 4096))
+        vids = []
+        for mode, if_rate, bw, centre, _ in workloads.vfo_plan(3, nv):
+            d, keep = radio.vfo_desc(10e6, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        if pipelined:
+            ctx.set_pipelined(True, 1 | 4)
+        outs, failures = [], 0
+        for b in range(5):
+            blk = x[b * B:(b + 1) * B]
+            try:
+                ctx.push(blk)
+            except capi.SdrppError as e:
+                assert "arena" in str(e)
+                failures += 1
+                ctx.push(blk)  # the block again: nothing of the failed attempt may be left behind
+            if pipelined:
+                r = ctx.result_wait(ctx.ticket())
+                outs.append(([r["vfo"][v] for v in vids], r["raw"]))
+                ctx.result_release(ctx.ticket())
+            else:
+                outs.append(([ctx.vfo_read(v).copy() for v in vids], ctx.fft_read(zoomed=False)[0].copy()))
+        ctx.close()
+        return outs, failures
+
+    good, f0 = run(False)
+    bad, f1 = run(True)
+    assert f0 == 0 and f1 == 1
+    for b, ((va, la), (vb, lb)) in enumerate(zip(good, bad)):
+        assert la.shape == lb.shape and np.array_equal(la, lb), b
+        for a, c in zip(va, vb):
+            assert a.shape == c.shape and np.array_equal(a.view(np.uint32), c.view(np.uint32)), b
+
+
 def test_retune_add_remove_reset(backend):
     sr, B = 10e6, 50000
     r = np.random.default_rng(13)
