@@ -169,7 +169,8 @@ static const float* get_tw_full(int lg) {
 }
 
 /* Forward unnormalised DFT, sign -1, n = 2^m, 1 <= m <= 20 (what fftwf_plan_dft_1d(FFTW_FORWARD) computes,
- * iq_frontend.cpp:62,255).  n <= 4096: one sub-FFT.  n > 4096: four-step, N1 = 2^floor(m/2), N2 = n / N1:
+ * iq_frontend.cpp:62,255).  n <= 4096: one sub-FFT.  n > 4096: four-step, N1 = 2^floor(m/2) up to n = 65536 and N1 = n / 4096 above
+ * (the row transform is then the largest single sub-FFT), N2 = n / N1:
  *   A[k1][n2] = subFFT_N1 over n1 of x[N2*n1 + n2]
  *   B[k1][n2] = A[k1][n2] * tw(n2*k1, n):  re = fmaf(a.re, w.re, -(a.im*w.im)),  im = fmaf(a.re, w.im, a.im*w.re)
  *   X[k1 + N1*k2] = subFFT_N2 over n2 of B[k1][n2]
@@ -189,7 +190,7 @@ void sdrpp_oracle_fft(int n, const float* in, float* out) {
         free(y);
         return;
     }
-    const int lg1 = m / 2, lg2 = m - lg1;
+    const int lg1 = (m <= 16) ? m / 2 : m - 12, lg2 = m - lg1;
     const int N1 = 1 << lg1, N2 = 1 << lg2;
     const float* tw1 = get_tw_half(lg1);
     const float* tw2 = get_tw_half(lg2);

@@ -12,7 +12,9 @@
 //     symmetric float table tw(e, L) (host generated, sdrpp_host::twiddle).  Groups of four consecutive stages run in
 //     registers (16 points per work-item); between groups the points are exchanged through LDS.  The grouping does not
 //     change any rounding: each butterfly sees the same operands whatever the schedule.
-//   * N > 4096: four-step N = N1 x N2 (N1 = 2^floor(m/2)): pass 1 = N1-point column FFTs (stride N2) + multiplication by
+//   * N > 4096: four-step N = N1 x N2 (N1 = 2^floor(m/2) up to N = 65536; N1 = N / 4096 above — the largest row transform one
+//     workgroup holds, so that the column pass keeps >= 128-byte row segments: with the even split a 2^20-point pass 1 read 32-byte
+//     segments at an 8 KB stride and cost 5x the 65536-point transform per sample): pass 1 = N1-point column FFTs (stride N2) + multiplication by
 //     tw(n2*k1, N) (re = fmaf(a.re, w.re, -(a.im*w.im)), im = fmaf(a.re, w.im, a.im*w.re)) into a scratch matrix
 //     A[k1][n2]; pass 2 = N2-point row FFTs, X[k1 + N1*k2], fused with the dB conversion.
 // All floating-point contraction is disabled for this translation unit (-ffp-contract=off); FMAs are explicit.
@@ -426,6 +428,91 @@ __global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const 
     __shared__ float2 tw[(1 << LG2) / 2];
     __shared__ float2 data[R * ((1 << LG2) + (1 << LG2) / 16)];
     fft_pass2_body<LG2, R>(kidx(blockIdx), tw, data, scratch, tw2_g, out_db, lg1, nframes, grp_max);
+}
+
+// ---- N > 65536, pass 2: ONE 4096-point row per workgroup ------------------------------------------------------------------------------
+// Row k1 of the scratch matrix (4096 complex values, contiguous) -> its 4096 dB values, written IN PLACE over the first half of the row
+// ([k1][k2] order: every access of this pass is contiguous).  A workgroup has all of its row in registers before the first LDS exchange,
+// i.e. long before it stores anything, and no other workgroup touches the row.  fft_transpose_body then puts the values into bin
+// order k = k1 + N1 * k2.  Same butterflies, same dB expression as fft_pass2_body: only where the results go differs.
+template <int LG2>
+__device__ __forceinline__ void fft_pass2row_body(const KIdx bid, float2* tw, float2* data, float2* __restrict__ scratch, const float2* __restrict__ tw2_g, int lg1) {
+    constexpr int L2 = 1 << LG2;
+    constexpr int TPF = L2 / 16;
+    const int t = threadIdx.x;
+    for (int e = threadIdx.x; e < L2 / 2; e += TPF) { tw[e] = tw2_g[e]; }
+    float2* row = scratch + ((size_t)bid.x << LG2);  // bid.x = frame * N1 + k1
+    float2 r[16];
+    using R0 = FftRound<LG2, 0, 4>;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = R0::pos(t, 0, j);
+        const int n = (int)(__brev((unsigned)p) >> (32 - LG2));
+        r[j] = row[n];
+    }
+    __syncthreads();
+    R0::compute(r, t, tw);
+    fft_rounds_after_first<LG2, 4, IdxPad16>(r, t, tw, data, IdxPad16());
+    using RL = typename FftLast<LG2>::Round;
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(data);  // [k2]
+    const float inv = 1.0f / (float)((size_t)1 << (LG2 + lg1));
+#pragma unroll
+    for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+        for (int j = 0; j < RL::GS; j++) { tile[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+    }
+    __syncthreads();
+    float* dst = reinterpret_cast<float*>(row);
+    for (int e = threadIdx.x; e < L2; e += TPF) { dst[e] = tile[e]; }
+}
+template <int LG2>
+__global__ __launch_bounds__((1 << LG2) / 16) void fft_pass2row_kernel(float2* __restrict__ scratch, const float2* __restrict__ tw2_g, int lg1) {
+    __shared__ float2 tw[(1 << LG2) / 2];
+    __shared__ float2 data[(1 << LG2) + (1 << LG2) / 16];
+    fft_pass2row_body<LG2>(kidx(blockIdx), tw, data, scratch, tw2_g, lg1);
+}
+
+// ---- N > 65536, pass 3: dB rows [k1][k2] -> bin order k = k1 + N1 * k2 (+ doZoom's group maxima) ---------------------------------------------
+// A workgroup moves a tile of all N1 rows x TK2 = 8192 / N1 consecutive k2 through LDS: it reads TK2 consecutive floats of every row
+// (the rows sit 2 * 4096 floats apart: the first half of each complex scratch row) and writes, for every k2 of the tile, the N1 consecutive
+// bins k1 + N1 * k2 — whole tiles of 32 KB are contiguous in the output line.  While the tile is in LDS it also leaves the maximum of every
+// aligned group of `gsz` bins for the zoom kernel (gsz divides N1; a maximum does not care how it is split: waterfall.cpp:65-90).
+#define SDRPP_FFT_TR_TILE 8192
+__device__ __forceinline__ void fft_transpose_body(const KIdx bid, float* tile, const float* __restrict__ rows, float* __restrict__ out_db, float* __restrict__ grp_max,
+                                                   int lg1, int lg2, int gsz) {
+    const int N1 = 1 << lg1, TK2 = SDRPP_FFT_TR_TILE >> lg1, tiles = (1 << lg2) / TK2;
+    const int frame = bid.x / tiles, k2_0 = (bid.x % tiles) * TK2;
+    const int pitch = N1 + 1;
+    const float* src = rows + (((size_t)frame << (lg1 + lg2)) << 1) + k2_0;
+    const int lgt = 13 - lg1;  // log2(TK2)
+    for (int e = threadIdx.x; e < SDRPP_FFT_TR_TILE; e += 256) {
+        const int k1 = e >> lgt, kk = e & (TK2 - 1);
+        tile[kk * pitch + k1] = src[((size_t)k1 << (lg2 + 1)) + kk];
+    }
+    __syncthreads();
+    float* dst = out_db + ((size_t)frame << (lg1 + lg2)) + ((size_t)k2_0 << lg1);
+    for (int e = threadIdx.x; e < SDRPP_FFT_TR_TILE; e += 256) {
+        const int kk = e >> lg1, k1 = e & (N1 - 1);
+        dst[e] = tile[kk * pitch + k1];
+    }
+    if (grp_max) {
+        const int gpr = N1 / gsz;  // groups per k2
+        float* gdst = grp_max + (((size_t)frame << (lg1 + lg2)) + ((size_t)k2_0 << lg1)) / gsz;
+        for (int g = threadIdx.x; g < TK2 * gpr; g += 256) {
+            const int kk = g / gpr, gi = g % gpr;
+            float m = __uint_as_float(0xff800000u);
+            for (int q = 0; q < gsz; q++) {
+                const float v = tile[kk * pitch + gi * gsz + q];
+                if (v > m) { m = v; }
+            }
+            gdst[g] = m;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fft_transpose_kernel(const float* __restrict__ rows, float* __restrict__ out_db, float* __restrict__ grp_max, int lg1, int lg2, int gsz) {
+    __shared__ float tile[SDRPP_FFT_TR_TILE + 256];
+    fft_transpose_body(kidx(blockIdx), tile, rows, out_db, grp_max, lg1, lg2, gsz);
 }
 
 // ---- doZoom max-decimation + palette index (waterfall.cpp:65-90, 899-905) -------------------------------------------------------------

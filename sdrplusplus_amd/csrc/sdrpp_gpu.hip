@@ -853,12 +853,27 @@ void launch_p1(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, int lg2) {
     launch(c, fft_pass1_kernel<LG1, C>, dim3(blocks), dim3(((1 << LG1) / 16) * C), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1,
            (const float2*)c->d_twn, c->d_scratch, lg2);
 }
+// four-step split of a 2^m-point transform (m > 12): N1 = 2^lg1 column transforms, N2 = 2^lg2 row transforms.  Even up to 65536 points;
+// above, the rows take the 4096 points one workgroup holds and the columns the rest (fft_kernels.h) — the oracle splits the same way
+inline void fft_split(int m, int* lg1, int* lg2) {
+    *lg1 = m <= 16 ? m / 2 : m - 12;
+    *lg2 = m - *lg1;
+}
+constexpr int kZoomGrpLong = 16;  // bins per doZoom group of the long transforms (left by the transpose pass)
 constexpr int pass2_rows(int lg2) { return lg2 == 7 ? 32 : (lg2 == 8 ? 16 : (lg2 == 9 ? 8 : 4)); }  // rows per workgroup of fft_pass2_kernel = bins per doZoom group
 template <int LG2, int R>
 void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out, float* grp) {
     static_assert(R == pass2_rows(LG2), "pass2_rows out of step with the launch table");
     const int blocks = nframes * ((1 << lg1) / R);
     launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes, grp);
+}
+
+void launch_p2row(sdrpp_ctx* c, int nframes, int lg1) {
+    launch(c, fft_pass2row_kernel<12>, dim3((unsigned)(nframes << lg1)), dim3(256), 0, c->d_scratch, (const float2*)c->d_tw2, lg1);
+}
+void launch_transpose(sdrpp_ctx* c, int nframes, int lg1, int lg2, float* out, float* grp) {
+    const int tiles = (1 << lg2) / (SDRPP_FFT_TR_TILE >> lg1);
+    launch(c, fft_transpose_kernel, dim3((unsigned)(nframes * tiles)), dim3(256), 0, (const float*)c->d_scratch, out, grp, lg1, lg2, kZoomGrpLong);
 }
 
 // pipelined mode: the FFT branch of one block as roles of the tick kernel — pass 1 (or the whole small transform) at level 1 next to the
@@ -878,17 +893,40 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         c->emits.push_back(r);
         return SDRPP_OK;
     }
-    const int lg1 = m / 2, lg2 = m - lg1;
-    static const int p1_role[5] = { TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10 }, p1_c[5] = { 64, 32, 16, 8, 4 };
+    int lg1, lg2;
+    fft_split(m, &lg1, &lg2);
+    static const int p1_role[6] = { TR_FFT_P1_5, TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10 }, p1_c[6] = { 128, 64, 32, 16, 8, 4 };
     static const int p2_role[4] = { TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10 };
-    if (lg1 < 6 || lg1 > 10 || lg2 < 7 || lg2 > 10) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft size 2^%d unsupported", m); }
-    r.e.role = p1_role[lg1 - 6];
-    r.e.gx = g.nframes * ((1 << lg2) / p1_c[lg1 - 6]);
+    if (lg1 < 5 || lg1 > 10 || lg2 < 7 || lg2 > 12 || (lg2 > 10 && lg2 != 12)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft size 2^%d unsupported", m); }
+    r.e.role = p1_role[lg1 - 5];
+    r.e.gx = g.nframes * ((1 << lg2) / p1_c[lg1 - 5]);
     r.e.p.p1 = TickP1{ src, g, c->d_window, c->d_tw1, c->d_twn, c->d_scratch, lg2, 0 };
-    r.lds = tick_lds_fft_p1(lg1, p1_c[lg1 - 6]);
+    r.lds = tick_lds_fft_p1(lg1, p1_c[lg1 - 5]);
     r.level = 1;
     r.fam = F_FFT1;
     c->emits.push_back(r);
+    if (lg2 == 12) {  // long transforms: 4096-point rows (dB in place), then the transpose into bin order one level later
+        sdrpp_ctx::RoleLaunch q{};
+        q.e.gy = 1;
+        q.e.role = TR_FFT_P2ROW;
+        q.e.gx = g.nframes << lg1;
+        q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, nullptr, nullptr, lg1, g.nframes };
+        q.lds = tick_lds_fft_single(12, 1);
+        q.level = 2;
+        q.fam = F_FFT2;
+        c->emits.push_back(q);
+        sdrpp_ctx::RoleLaunch t{};
+        t.e.gy = 1;
+        t.e.role = TR_FFT_TR;
+        t.e.gx = g.nframes * ((1 << lg2) / (SDRPP_FFT_TR_TILE >> lg1));
+        t.e.aux = kZoomGrpLong;
+        t.e.p.p2 = TickP2{ c->d_scratch, nullptr, out, grp, lg1, g.nframes };
+        t.lds = (size_t)(SDRPP_FFT_TR_TILE + 256) * sizeof(float);
+        t.level = 3;
+        t.fam = F_FFT2;
+        c->emits.push_back(t);
+        return SDRPP_OK;
+    }
     sdrpp_ctx::RoleLaunch q{};
     q.e.gy = 1;
     q.e.role = p2_role[lg2 - 7];
@@ -913,10 +951,12 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
         }
         return SDRPP_OK;
     }
-    const int lg1 = m / 2, lg2 = m - lg1;
+    int lg1, lg2;
+    fft_split(m, &lg1, &lg2);
     {
         FamilyTimer t(c, F_FFT1);
         switch (lg1) {
+        case 5: launch_p1<5, 128>(c, src, g, lg2); break;
         case 6: launch_p1<6, 64>(c, src, g, lg2); break;
         case 7: launch_p1<7, 32>(c, src, g, lg2); break;
         case 8: launch_p1<8, 32>(c, src, g, lg2); break;  // 256-byte row segments; measured 7 % faster than <8, 16>
@@ -928,6 +968,10 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
     {
         FamilyTimer t(c, F_FFT2);
         switch (lg2) {
+        case 12:
+            launch_p2row(c, g.nframes, lg1);
+            launch_transpose(c, g.nframes, lg1, lg2, out, grp);
+            break;
         case 7: launch_p2<7, 32>(c, g.nframes, lg1, out, grp); break;
         case 8: launch_p2<8, 16>(c, g.nframes, lg1, out, grp); break;
         case 9: launch_p2<9, 8>(c, g.nframes, lg1, out, grp); break;
@@ -1063,7 +1107,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             g.first_start = c->fft_next * P - c->fft_pos;
             int rc = plan_fft_roles(c, src, g, c->d_lines, c->zoom_grp ? c->d_lines_grp : nullptr);
             if (rc) { return rc; }
-            const int lines_level = c->fft_lg <= 12 ? 1 : 2;
+            const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
             if (c->data_width > 0) {
                 if ((size_t)nframes * (size_t)c->data_width > c->zoom_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: zoom capacity"); }
                 int bpp = c->view_size / std::max(1, c->data_width);
@@ -2518,10 +2562,11 @@ inline int tick_role_weight(int role) {
     case TR_FCL_0: case TR_FCL_PF: return 100;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;
     case TR_SEQ: return 85;
-    case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
+    case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
     case TR_TOEP_Q: return 65;
     case TR_TOEP_C: case TR_TOEP_R: case TR_FFT_S10: case TR_FFT_S11: case TR_FFT_S12: return 60;
-    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: return 50;
+    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: case TR_FFT_P2ROW: return 50;
+    case TR_FFT_TR: return 25;
     case TR_ROT: case TR_PRE: return 30;
     case TR_ZOOM_16: case TR_ZOOM_4: case TR_ZOOM_1: return 20;
     default: return 10;  // carry, copies
@@ -2703,7 +2748,7 @@ int tick_results_plan(sdrpp_ctx* c) {
     }
     R.n_lines = c->fft_on ? c->n_lines : 0;
     if (R.n_lines > 0) {
-        const int lines_level = c->fft_lg <= 12 ? 1 : 2;
+        const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
         if ((c->res_flags & 2) && c->data_width > 0) {
             const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
             R.off_zoomed = off;
@@ -3330,7 +3375,8 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
         if (rc) { return rc; }
     }
     else {
-        const int lg1 = m / 2, lg2 = m - lg1;
+        int lg1, lg2;
+        fft_split(m, &lg1, &lg2);
         const int N1 = 1 << lg1, N2 = 1 << lg2;
         auto t1 = half_table(N1);
         auto t2 = half_table(N2);
@@ -3356,7 +3402,7 @@ int sdrpp_fft_configure(sdrpp_ctx* c, int fft_size, int nz, int skip, const floa
     if (rc) { return rc; }
     dev_free(c->d_lines_grp);
     c->d_lines_grp = nullptr;
-    c->zoom_grp = (m > 12) ? pass2_rows(m - m / 2) : 0;
+    c->zoom_grp = (m > 16) ? kZoomGrpLong : ((m > 12) ? pass2_rows(m - m / 2) : 0);
     if (c->zoom_grp) {
         rc = dev_alloc(c, &c->d_lines_grp, lines * (size_t)(fft_size / c->zoom_grp));
         if (rc) { return rc; }

@@ -80,8 +80,9 @@ enum TickRole : int {
     TR_PRE,        // PreJob[gy]
     TR_SEQ,        // SeqJob[gx] (one wavefront per job), aux = njobs
     TR_FFT_S10, TR_FFT_S11, TR_FFT_S12,                              // p.fs
-    TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10,  // p.p1
+    TR_FFT_P1_5, TR_FFT_P1_6, TR_FFT_P1_7, TR_FFT_P1_8, TR_FFT_P1_9, TR_FFT_P1_10,  // p.p1
     TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10,             // p.p2
+    TR_FFT_P2ROW, TR_FFT_TR,                                         // p.p2 (long transforms: 4096-point rows in place; transpose into bin order, aux = doZoom group size)
     TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
     TR_COUNT
 };
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_FFT_S10: tick_fft_single<10, 4>(bid, smem, e.p.fs); break;
             case TR_FFT_S11: tick_fft_single<11, 2>(bid, smem, e.p.fs); break;
             case TR_FFT_S12: tick_fft_single<12, 1>(bid, smem, e.p.fs); break;
+            case TR_FFT_P1_5: tick_fft_p1<5, 128>(bid, smem, e.p.p1); break;
             case TR_FFT_P1_6: tick_fft_p1<6, 64>(bid, smem, e.p.p1); break;
             case TR_FFT_P1_7: tick_fft_p1<7, 32>(bid, smem, e.p.p1); break;
             case TR_FFT_P1_8: tick_fft_p1<8, 16>(bid, smem, e.p.p1); break;
@@ -257,6 +259,11 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_FFT_P2_8: tick_fft_p2<8, 16>(bid, smem, e.p.p2); break;
             case TR_FFT_P2_9: tick_fft_p2<9, 8>(bid, smem, e.p.p2); break;
             case TR_FFT_P2_10: tick_fft_p2<10, 4>(bid, smem, e.p.p2); break;
+            case TR_FFT_P2ROW: {
+                float2* tw = reinterpret_cast<float2*>(smem);
+                fft_pass2row_body<12>(bid, tw, tw + (1 << 12) / 2, const_cast<float2*>(e.p.p2.scratch), e.p.p2.tw2, e.p.p2.lg1);
+            } break;
+            case TR_FFT_TR: fft_transpose_body(bid, smem, reinterpret_cast<const float*>(e.p.p2.scratch), e.p.p2.out, e.p.p2.grp, e.p.p2.lg1, 12, e.aux); break;
             case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
             case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
             case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;

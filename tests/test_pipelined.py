@@ -116,6 +116,31 @@ def test_pipelined_equals_ordinary_mixed_modes(backend):
     cb.close()
 
 
+def test_pipelined_long_fft(backend):
+    """2^17-point transform (the long split: 32-point column pass, 4096-point rows with the dB values in place, transpose into bin order one
+    launch later) without VFOs: lines, zoomed lines (group maxima from the transpose pass) and palette indices identical to the ordinary
+    pass, frames straddling the blocks."""
+    from sdrplusplus_amd import workloads
+
+    N = 1 << 17
+    pushes = [100000, 70000, 131072, 50000, 180000]
+    x = workloads.synth(2, sum(pushes), seed=12)
+    (ca, va), (cb, vb) = _ctx_pair(2, 0, max(pushes), N, data_width=500)
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        refs.append(_ordinary_results(ca, va, blk, True))
+        cb.push(blk)
+    assert sum(len(r["raw"]) for r in refs) == sum(pushes) // N
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare(ref, got, True, "block %d" % t)
+        cb.result_release(t)
+    ca.close()
+    cb.close()
+
+
 def test_pipelined_falls_back_to_ordinary_passes(backend):
     """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
