@@ -406,6 +406,33 @@ public:
         return count;
     }
 
+    // Direct ingest of one block by a source that drives the front end itself (sdrpp_gpu::WavSource::start(IQFrontEnd*)): the block is
+    // processed and its results are handed out before the call returns, exactly like a block taken from the input stream in bypass
+    // mode.  ingestInt16 takes interleaved 16-bit IQ as file_source reads it from a WAV (main.cpp:160-162): the conversion x / 32768 runs on
+    // the device (sdrpp_push_int16) and the bus carries half the bytes.  The front end's own worker must not be running (no start()):
+    // returns -1 if it is, or when an output stream has been stopped.
+    int ingestInt16(const int16_t* iq, int count) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        if (running || count <= 0 || count > SDRPP_GPU_MAX_BLOCK) { return -1; }
+        if (pipeOn && leavePipelined() < 0) { return -1; }
+        if (sdrpp_push_int16(ctx, iq, count)) {
+            fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
+            return -1;
+        }
+        if (!iqStreams.empty()) {  // the bound consumers receive floats (what the Splitter would have copied)
+            tapCopy.resize((size_t)count);
+            for (int i = 0; i < count; i++) { tapCopy[(size_t)i] = dsp::complex_t{ (float)iq[2 * i] / 32768.0f, (float)iq[2 * i + 1] / 32768.0f }; }
+        }
+        return deliver((const dsp::complex_t*)nullptr, count);
+    }
+    int ingestFloat(const dsp::complex_t* iq, int count) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        if (running || count <= 0 || count > SDRPP_GPU_MAX_BLOCK) { return -1; }
+        if (pipeOn && leavePipelined() < 0) { return -1; }
+        if (stage(iq, count) < 0) { return -1; }
+        return deliver((const dsp::complex_t*)nullptr, count);
+    }
+
     sdrpp_ctx* context() { return ctx; }
 #ifdef SDRPP_GPU_BLOCKS_PROF
     // diagnostic build of a host program: where the worker's wall time goes (microseconds, passes)
