@@ -1,0 +1,103 @@
+// The one exchange step of the path in a one-process, several-GPU host: finished waterfall lines of every stream gathered
+// on the display GPU with RCCL over xGMI.  Stream i lives on device i with its own context (sdrpp_gpu::StreamBank / the C-ABI); nothing
+// else crosses devices.  The gather is a grouped ncclSend / ncclRecv (every rank sends its block to the root, the root receives one
+// block per rank: what ncclGather does, spelled with the point-to-point calls so that it also runs on RCCL builds without the
+// extension) — lines are a few hundred KB per refresh against ~153 GB/s per xGMI link, so a direct gather is right, not a ring.
+// Needs <rccl/rccl.h> + the HIP runtime (link -lrccl -lamdhip64); kept out of sdrpp_gpu_multi.h so that hosts without RCCL build.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sdrpp_gpu {
+
+class LineGather {
+public:
+    ~LineGather() { destroy(); }
+
+    // devices[i] = HIP device of stream i (all different: one RCCL rank per device); `floatsPerStream` = capacity of one stream's block
+    void init(const std::vector<int>& devices, size_t floatsPerStream, int rootIndex = 0) {
+        destroy();
+        devs = devices;
+        cap = floatsPerStream;
+        root = rootIndex;
+        const int n = (int)devs.size();
+        if (n <= 0 || root < 0 || root >= n) { throw std::runtime_error("[sdrpp_gpu::LineGather] bad device list"); }
+        comms.assign((size_t)n, nullptr);
+        streams.assign((size_t)n, nullptr);
+        check(ncclCommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll");
+        for (int i = 0; i < n; i++) {
+            hip(hipSetDevice(devs[(size_t)i]), "hipSetDevice");
+            hip(hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking), "hipStreamCreate");
+        }
+        hip(hipSetDevice(devs[(size_t)root]), "hipSetDevice");
+        hip(hipMalloc((void**)&gathered, (size_t)n * cap * sizeof(float)), "hipMalloc");
+        ready = true;
+    }
+    int ranks() const { return (int)devs.size(); }
+    const char* backend() const { return "rccl"; }
+
+    // send[i]: `count` floats in device memory of devices[i] (e.g. the zoomed lines sdrpp_fft_device_buffers points at, after the
+    // context's stream has been synchronised).  Returns the root's [ranks][count] buffer (device memory of the root), complete.
+    const float* gather(const std::vector<const float*>& send, size_t count) {
+        if (!ready || send.size() != devs.size() || count > cap) { throw std::runtime_error("[sdrpp_gpu::LineGather] bad gather call"); }
+        const int n = (int)devs.size();
+        check(ncclGroupStart(), "ncclGroupStart");
+        for (int i = 0; i < n; i++) {
+            check(ncclSend(send[(size_t)i], count, ncclFloat, root, comms[(size_t)i], streams[(size_t)i]), "ncclSend");
+            if (i == root) {
+                for (int r = 0; r < n; r++) { check(ncclRecv(gathered + (size_t)r * count, count, ncclFloat, r, comms[(size_t)i], streams[(size_t)i]), "ncclRecv"); }
+            }
+        }
+        check(ncclGroupEnd(), "ncclGroupEnd");
+        for (int i = 0; i < n; i++) {
+            hip(hipSetDevice(devs[(size_t)i]), "hipSetDevice");
+            hip(hipStreamSynchronize(streams[(size_t)i]), "hipStreamSynchronize");
+        }
+        return gathered;
+    }
+    // the gathered block to host memory ([ranks][count] floats)
+    void toHost(float* dst, size_t count) {
+        hip(hipSetDevice(devs[(size_t)root]), "hipSetDevice");
+        hip(hipMemcpy(dst, gathered, devs.size() * count * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    }
+
+    void destroy() {
+        if (!ready) { return; }
+        for (size_t i = 0; i < comms.size(); i++) {
+            if (comms[i]) { ncclCommDestroy(comms[i]); }
+            if (streams[i]) {
+                (void)hipSetDevice(devs[i]);
+                (void)hipStreamDestroy(streams[i]);
+            }
+        }
+        if (gathered) {
+            (void)hipSetDevice(devs[(size_t)root]);
+            (void)hipFree(gathered);
+        }
+        gathered = nullptr;
+        comms.clear();
+        streams.clear();
+        ready = false;
+    }
+
+private:
+    static void check(ncclResult_t r, const char* what) {
+        if (r != ncclSuccess) { throw std::runtime_error(std::string("[sdrpp_gpu::LineGather] ") + what + ": " + ncclGetErrorString(r)); }
+    }
+    static void hip(hipError_t e, const char* what) {
+        if (e != hipSuccess) { throw std::runtime_error(std::string("[sdrpp_gpu::LineGather] ") + what + ": " + hipGetErrorString(e)); }
+    }
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    float* gathered = nullptr;
+    size_t cap = 0;
+    int root = 0;
+    bool ready = false;
+};
+
+}  // namespace sdrpp_gpu

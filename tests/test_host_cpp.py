@@ -177,3 +177,36 @@ def test_stream_bank_two_streams_on_the_emulator():
 def test_stream_bank_two_streams_on_the_device():
     with tempfile.TemporaryDirectory() as tmp:
         _run_multi_and_check(_build(tmp, source="test_multi.cpp"), tmp, 500)
+
+
+@pytest.mark.gpu
+def test_rccl_line_gather_cpp():
+    """sdrpp_gpu::LineGather (host/sdrpp_gpu_rccl.h): the C++ host's RCCL gather of waterfall lines — one context and one RCCL rank per
+    visible device (one on the single-GPU test box: the collectives still run), gathered lines == sdrpp_fft_read of every stream."""
+    rocm = "/opt/rocm"
+    if not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        pytest.skip("no RCCL headers")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_rccl_gather")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_rccl_gather.cpp"),
+                        "-L" + CSRC, "-lsdrpp_gpu", "-L" + rocm + "/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + rocm + "/lib", "-Wl,-rpath," + CSRC, "-lpthread"], check=True)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "ok" in r.stdout and "ranks" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_protocol_over_rccl_with_one_rank():
+    """bench.py's N > 1 leg on the one GPU there is: init_process_group("nccl") with a world of one, the pipelined StreamRunner protocol,
+    the line batches going through dist.gather on RCCL, barrier + all_reduce(MAX) of the elapsed time — the JSON line says so."""
+    import json
+    import sys
+
+    env = dict(os.environ, SDRPP_BENCH_FORCE_RCCL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "6", "--no-others", "--no-by-push", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rccl"]["rccl_ranks"] == 1 and d["rccl"]["backend"] == "nccl" and len(d["rccl"]["devices"]) == 1
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["roofline"]["kernel"] == "tick"
