@@ -258,6 +258,16 @@ int sdrpp_wf_raster(sdrpp_ctx* ctx, int draw_data_start, int draw_data_size, int
  *      -> Conjugate.  Runs on the device in front of the FFT branch and the VFO bank: every later stage sees the pre-processed
  *      stream at the effective sample rate (FFT framing, VFO descriptors are the caller's, designed at that rate).  max_push of
  *      sdrpp_create counts RAW samples.  n_stages = 0, dc_rate = 0, conjugate = 0 removes the chain.  State starts cleared. */
+/* Numerics of the chain.  Default: the decimator stages run on the matrix cores (k-ordered fused multiply-adds) and the DC blocker as a
+ * parallel scan — the pre-processed stream then agrees with the reference to ~1e-7 (decimation only) resp. ~5e-5 (DC blocker on: the
+ * reference's sequential float32 integrator carries a rounding drift of its own that a parallel sum does not reproduce), and waterfall
+ * lines computed from it are NOT bit-exact any more (up to 5e-3 dB with decimation, 0.05 dB with DC blocking).  With
+ * sdrpp_preproc_set_reference_order(ctx, 1) the chain evaluates the reference's own arithmetic — VOLK's generic tap-ordered
+ * multiply-then-add dot product (decimating_fir.h:51-61) and the sequential DC-blocker recursion (dc_blocker.h:54-60), one wavefront,
+ * ~40 cycles per sample — and the pre-processed stream, and every waterfall line behind it, is bit-identical to the compiled reference
+ * (tests/test_parity_fft.py::test_preproc_chain_reference_order).  A parity mode: a few times real time at 10 MS/s, not thousands.
+ * The switch survives sdrpp_preproc_configure; streaming state (history, offsets, the DC estimate) is shared by both modes. */
+int sdrpp_preproc_set_reference_order(sdrpp_ctx* ctx, int on);
 int sdrpp_preproc_configure(sdrpp_ctx* ctx, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps,
                             float dc_rate, int conjugate);
 /* The pre-processed samples of the most recent push — what Splitter hands to streams bound with bindIQStream (iq_frontend.cpp:132-138). */

@@ -221,7 +221,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
     "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed", "sdrpp_preproc_read_pcm",
     "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster", "sdrpp_wf_signal_info",
-    "sdrpp_preproc_configure", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
+    "sdrpp_preproc_configure", "sdrpp_preproc_set_reference_order", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
@@ -483,6 +483,10 @@ class Context:
         arrs = [np.ascontiguousarray(t, dtype=np.float32) for _, t in stages]
         ptrs = (c_float_p * max(n, 1))(*[a.ctypes.data_as(c_float_p) for a in arrs])
         self._chk(self.L.sdrpp_preproc_configure(self.h, n, dec, nt, ptrs, float(dc_rate), int(bool(conjugate))))
+
+    def preproc_set_reference_order(self, on=True):
+        """Parity mode of the pre-processing chain: the reference's own tap-ordered multiply-then-add decimator and sequential DC blocker."""
+        self._chk(self.L.sdrpp_preproc_set_reference_order(self.h, int(bool(on))))
 
     def preproc_read(self):
         n = self._chk(self.L.sdrpp_preproc_out_count(self.h))

@@ -173,6 +173,7 @@ struct sdrpp_ctx {
     // IQFrontEnd pre-processing chain (sdrpp_preproc_configure): PowerDecimator -> DCBlocker -> Conjugate on the wideband stream,
     // in front of the FFT branch and the VFO bank (iq_frontend.cpp:32-39)
     struct Pre {
+        bool ref_order = false;            // sdrpp_preproc_set_reference_order: the reference's own summation order / sequential DC blocker
         bool on = false;
         int n_stages = 0, decim_s[SDRPP_MAX_DECIM_STAGES] = { 1, 1, 1, 1 };
         std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
@@ -287,6 +288,7 @@ struct sdrpp_ctx {
     int arena_allocs = 0;
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
     int test_fail_alloc = 0;
+    bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
@@ -2070,7 +2072,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         }
         if (threads == 0) {
             for (auto& jb : jobs) { max_nout = std::max(max_nout, jb.nout); }
-            if (max_nout > 0) { launch(c, vfo_fir_direct_kernel, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
+            if (max_nout > 0) { launch(c, vfo_fir_direct_kernel<false>, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
             return SDRPP_OK;
         }
         if (max_nout == 0) { return SDRPP_OK; }
@@ -2287,7 +2289,7 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
         const int no = decim_nout(cur->n, P.soff[s], D);
         if ((size_t)no > nxt->cap) { return fail(c, SDRPP_ERR_INVALID, "pre-processing stage %d: %d outputs exceed the capacity", s, no); }
         bounds_decim(c->vfo_bounds, P.soff[s], D);  // the reference's blocks behind this stage
-        if (P.tp[s].ok) { tj[s].push_back(toep_job(P.tp[s], 0, stream_in(*cur), nxt->data, P.soff[s] - (K - 1), no, 0.0f)); }
+        if (P.tp[s].ok && !P.ref_order) { tj[s].push_back(toep_job(P.tp[s], 0, stream_in(*cur), nxt->data, P.soff[s] - (K - 1), no, 0.0f)); }
         else { fj[s].push_back(FirBJob{ stream_in(*cur), nxt->data, P.d_staps[s], K, ilog2(D), P.soff[s], no, P.s_kp[s] }); }
         P.soff[s] = P.soff[s] + no * D - cur->n;
         nxt->n = no;
@@ -2322,6 +2324,10 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
         for (int s = 0; s < P.n_stages; s++) {
             launch_toep(c, tj[s], d_tj[s], tp[s], 2, false);
             for (auto& jb : fj[s]) {  // register-blocked fallback (one job): largest work-group whose window fits
+                if (P.ref_order) {  // parity mode: the reference's tap-ordered multiply-then-add dot product, one output per work-item
+                    if (jb.nout > 0) { launch(c, vfo_fir_direct_kernel<true>, dim3((unsigned)std::min((jb.nout + 255) / 256, 4096), 1), dim3(256), 0, (const FirBJob*)d_fj[s]); }
+                    continue;
+                }
                 const int R = SDRPP_FIR_R;
                 int threads = 256;
                 auto lds_for = [&](int nt) { return (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * 2 * 4; };
@@ -2330,7 +2336,10 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
                 if (jb.nout > 0) { launch(c, vfo_firb_kernel<2, false>, dim3((unsigned)((jb.nout + threads * R - 1) / (threads * R)), 1), dim3(threads), lds_for(threads), (const FirBJob*)d_fj[s]); }
             }
         }
-        if (!dc.empty() && dc[0].nseg > 0) {
+        if (!dc.empty() && P.ref_order) {  // parity mode: the sequential recursion itself
+            if (n_out > 0) { launch(c, iq_dc_block_exact_kernel, dim3(1), dim3(64), 0, dc[0].in, dc[0].out, n_out, P.dc_rate, (float2*)P.d_off, P.conj); }
+        }
+        else if (!dc.empty() && dc[0].nseg > 0) {
             const dim3 grid((unsigned)dc[0].nseg, 1);
             launch(c, vfo_deemph_kernel<1, 0>, grid, dim3(256), 0, (const DeempJob*)d_dc);
             launch(c, vfo_deemph_kernel<1, 1>, grid, dim3(256), 0, (const DeempJob*)d_dc);
@@ -3519,6 +3528,7 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
     preproc_free(c);
     if (n_stages == 0 && dc_rate == 0.0f && !conjugate) { return SDRPP_OK; }  // chain fully disabled: pushes go straight through
     sdrpp_ctx::Pre& P = c->pre;
+    P.ref_order = c->pre_ref_order;
     P.n_stages = n_stages;
     P.dc_rate = dc_rate;
     P.conj = conjugate ? 1 : 0;
@@ -3559,6 +3569,15 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
         if (rc) { return rc; }
     }
     P.on = true;
+    return SDRPP_OK;
+}
+
+int sdrpp_preproc_set_reference_order(sdrpp_ctx* c, int on) {
+    DeviceScope dev_scope_(c);
+    if (!c) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
+    c->pre_ref_order = on != 0;
+    c->pre.ref_order = c->pre_ref_order;
     return SDRPP_OK;
 }
 

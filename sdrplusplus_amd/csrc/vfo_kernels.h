@@ -829,6 +829,10 @@ struct FirBJob {
 // Decimating FIR on a complex stream whose window fits neither the matrix-core table nor an LDS tile (decimation 32 / 64 with hundreds
 // of taps as a PLAIN filter: only in reference-rotator mode, where the first stage cannot be fused with the translation).  One output
 // per work-item straight from global memory, k-ordered fmaf chain.  Correctness path of a parity mode, not tuned.
+// REFORDER: the reference's own arithmetic — VOLK's generic dot product as DecimatingFIR::process calls it (decimating_fir.h:51-61):
+// taps in order, product rounded, then added (two roundings per tap, no fused multiply-add).  The parity mode of the front end's
+// pre-processing decimator (sdrpp_preproc_set_reference_order): bit-identical to the compiled reference.
+template <bool REFORDER>
 __global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __restrict__ jobs) {
     const FirBJob& job = jobs[blockIdx.y];
     const int D = 1 << job.log2_decim, kp = job.kp_pad;
@@ -838,11 +842,42 @@ __global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __re
         for (int k = 0; k < job.ntaps; k++) {
             const float h = job.taps[(size_t)(k & (D - 1)) * kp + (size_t)(k >> job.log2_decim)];
             const float2 x = stream_load2(job.in, i0 + k);
-            acc.x = fmaf(h, x.x, acc.x);
-            acc.y = fmaf(h, x.y, acc.y);
+            if constexpr (REFORDER) {
+                const float pr = x.x * h, pi = x.y * h;  // (the translation unit is compiled with -ffp-contract=off: these stay products)
+                acc.x = acc.x + pr;
+                acc.y = acc.y + pi;
+            }
+            else {
+                acc.x = fmaf(h, x.x, acc.x);
+                acc.y = fmaf(h, x.y, acc.y);
+            }
         }
         reinterpret_cast<float2*>(job.out)[j] = acc;
     }
+}
+
+// The reference's DC blocker recursion itself (dc_blocker.h:54-60: out = in - offset; offset += out * rate, product rounded, then added)
+// over the wideband stream, for the parity mode of the pre-processing chain: ONE wavefront walks the block, 64 samples per coalesced
+// load, every lane evaluating the same recursion with sample i taken from lane i (v_readlane).  ~40 cycles per sample: a few times real
+// time for a 10 MS/s stream — the default (a two-level scan of affine maps, vfo_deemph_kernel<1, *>) is the fast one and agrees to ~5e-5.
+__global__ __launch_bounds__(64) void iq_dc_block_exact_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, float rate, float2* __restrict__ state, int conj) {
+    const int lane = (int)threadIdx.x;
+    float offr = state->x, offi = state->y;
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = (n - base < 64) ? n - base : 64;
+        const float2 v = (lane < cnt) ? in[base + lane] : make_float2(0.0f, 0.0f);
+        float2 res = make_float2(0.0f, 0.0f);
+        for (int i = 0; i < cnt; i++) {
+            const float xr = wave_bcast(v.x, i), xi = wave_bcast(v.y, i);
+            const float orr = xr - offr, oi = xi - offi;
+            const float pr = orr * rate, pi = oi * rate;
+            offr = offr + pr;
+            offi = offi + pi;
+            if (lane == i) { res = make_float2(orr, conj ? -oi : oi); }
+        }
+        if (lane < cnt) { out[base + lane] = res; }
+    }
+    if (lane == 0) { *state = make_float2(offr, offi); }
 }
 
 // QUAD (WIDTH 1, decimation 1): the input stream is the complex IF and the FM discriminator (quadrature.h:39-46) runs while the

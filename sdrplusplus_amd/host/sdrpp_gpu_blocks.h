@@ -341,6 +341,16 @@ public:
         tempStart();
     }
 
+    // Parity switch (not in the reference): the pre-processing chain (decimation / DC blocking) in the reference's own arithmetic — VOLK's
+    // generic tap-ordered dot product and the sequential DC-blocker recursion — so that the pre-processed stream and the waterfall lines
+    // behind it are bit-identical to a CPU build (sdrpp_preproc_set_reference_order).  A few times real time instead of thousands.
+    void setReferenceArithmetic(bool enabled) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        tempStop();
+        sdrpp_preproc_set_reference_order(ctx, enabled ? 1 : 0);
+        tempStart();
+    }
+
     // Worker of the block: one block from the input stream -> processed at once (bypass, the file source's setting:
     // file_source/src/main.cpp:74) or queued in the 32-slot frame buffer and processed by the second worker
     // (SampleFrameBuffer::run / worker, frame_buffer.h:51-98; same index arithmetic, so an overrun drops a whole lap like the reference).
