@@ -169,6 +169,11 @@ typedef struct sdrpp_vfo_desc {
     int am_carrier_agc;       /* AM: 1 = AGCMode::CARRIER, 0 = AGCMode::AUDIO (am.h:14-17)                               */
     float dc_block_rate;      /* AM: DCBlocker rate (am.h:32 -> dc_blocker.h:54-60)                                       */
     float ssb_phase_delta_re, ssb_phase_delta_im; /* SSB second xlator (ssb.h:24,106-117)                                */
+    /* NCO of THIS VFO: 0 = the context's mode (sdrpp_set_nco_mode), 1 = closed form, 2 = the reference's float rotator recursion.
+     * FM and AM do not see the difference (no output depends on the absolute phase); a product detector (SSB) and the raw IF follow
+     * the reference's own rounding drift only with the recursion, which costs a sequential pass over the full-rate stream — so a bank
+     * can keep its FM / AM channels on the fast path and pay for exactness where it shows. */
+    int nco_mode;
 } sdrpp_vfo_desc;
 
 /* IQFrontEnd::addVFO / removeVFO (iq_frontend.cpp:140-183).  Arrays in `desc` are copied.  *id receives a handle. */

@@ -55,6 +55,7 @@ class VfoDesc(C.Structure):
         ("dc_block_rate", C.c_float),
         ("ssb_phase_delta_re", C.c_float),
         ("ssb_phase_delta_im", C.c_float),
+        ("nco_mode", C.c_int),
     ]
 
 

@@ -68,6 +68,7 @@ struct ToepTab {
 };
 
 struct Vfo {
+    bool nco_exact = false;        // this VFO runs the reference's float rotator recursion (desc.nco_mode, else the context's mode)
     int id = 0;
     sdrpp_vfo_desc d{};
     std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
@@ -1407,11 +1408,11 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         // reference-block ends carried stage by stage down to the demodulator's rate, for the block-dependent operations there
         // (AGC look-ahead, SSB rotator calls)
         const bool agc_mode = v.d.demod == SDRPP_DEMOD_AM || (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB);
-        const bool need_bnd = agc_mode && (blocks || c->nco_exact);
+        const bool need_bnd = agc_mode && (blocks || v.nco_exact);
         std::vector<int> bnd;
         if (need_bnd) { bnd = fb; }
         int first_sep = 0;  // first decimator stage that runs as its own FIR launch
-        if (c->nco_exact) {
+        if (v.nco_exact) {
             // the reference's own data flow: rotate at the full rate (float recursion), then every stage of the plan as a plain FIR
             Stream* tgt = (v.d.n_stages == 0) ? cur : &v.st[(size_t)v.i_rot];
             rotx.push_back(RotXJob{ (float2*)tgt->data, v.d_rot, v.d.phase_delta_re, v.d.phase_delta_im });
@@ -1611,7 +1612,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
-            if (c->nco_exact) { ssbx_l.add(lvl + 1, SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
+            if (v.nco_exact) { ssbx_l.add(lvl + 1, SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
             else { pre.add(lvl + 1, PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 }); }
             seq.add(lvl + 2, SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0, d_bnd, nbnd });
             lvl += 2;
@@ -2678,10 +2679,10 @@ int tick_drain(sdrpp_ctx* c) {
 // Can this context's blocks run as ticks at all?  (What can only be seen while planning — a VFO group too small for the matrix front end,
 // a filter without the matrix form, more frames than one scratch chunk — aborts the plan instead.)
 bool tick_eligible(sdrpp_ctx* c) {
-    if (c->pre.on || c->wf.height > 0 || c->deferred || c->nco_exact) { return false; }
+    if (c->pre.on || c->wf.height > 0 || c->deferred) { return false; }
     for (auto& kv : c->vfos) {
         const Vfo& v = *kv.second;
-        if (v.af.on || !v.recs.empty() || v.st.size() > 24) { return false; }
+        if (v.af.on || v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
     }
     return true;
 }
@@ -3642,6 +3643,8 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     std::unique_ptr<Vfo, VfoFreer> v(new Vfo);
     v->id = c->next_id++;
     v->d = *d;
+    if (d->nco_mode < 0 || d->nco_mode > 2) { return fail(c, SDRPP_ERR_INVALID, "nco_mode %d: 0 (context), 1 (closed form) or 2 (reference rotator)", d->nco_mode); }
+    v->nco_exact = d->nco_mode == 0 ? (c->nco_exact != 0) : (d->nco_mode == 2);
     int rc;
     // capacities
     size_t cap = (size_t)c->max_push;
@@ -3667,7 +3670,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
         if (rc) { return rc; }
         rc = upload(c, &v->d_staps_nat[s], v->staps[s].data(), v->staps[s].size());
         if (rc) { return rc; }
-        if (s >= 1 || c->nco_exact) {  // stage 0 runs as a plain FIR only behind the reference rotator
+        if (s >= 1 || v->nco_exact) {  // stage 0 runs as a plain FIR only behind the reference rotator
             v->tp_stage[s].kind = 1;
             rc = toep_build_fir(c, v->tp_stage[s], v->staps[s].data(), (int)v->staps[s].size(), d->stage_decim[s]);
             if (rc) { return rc; }
@@ -3694,8 +3697,8 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             const std::vector<float>& h2 = v->staps[1];
             for (size_t k = 0; k < h2.size() / 2; k++) { v->no_fuse = v->no_fuse || (h2[k] != h2[h2.size() - 1 - k]); }
         }
-        v->fused_front = !c->nco_exact && !v->no_fuse && d->n_stages >= 2 && front2_t2(d->stage_ntaps[0], d->stage_decim[0], d->stage_ntaps[1], d->stage_decim[1], 8) > 0;
-        if (d->n_stages >= 1 && !c->nco_exact) {
+        v->fused_front = !v->nco_exact && !v->no_fuse && d->n_stages >= 2 && front2_t2(d->stage_ntaps[0], d->stage_decim[0], d->stage_ntaps[1], d->stage_decim[1], 8) > 0;
+        if (d->n_stages >= 1 && !v->nco_exact) {
             const int K0 = d->stage_ntaps[0], D1 = d->stage_decim[0], K2 = v->fused_front ? d->stage_ntaps[1] : 1;
             const int K = K0 + (K2 - 1) * D1;
             std::vector<double> h12((size_t)K, 0.0);
@@ -3709,7 +3712,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
             v->h12_K = K;
             v->h12_lgD = ilog2(D1) + (v->fused_front ? ilog2(d->stage_decim[1]) : 0);
         }
-        if (c->nco_exact && d->n_stages >= 1) {  // reference-rotator mode: the rotated full-rate stream feeds stage 0
+        if (v->nco_exact && d->n_stages >= 1) {  // reference-rotator mode: the rotated full-rate stream feeds stage 0
             v->i_rot = add_stream(2, d->stage_ntaps[0] - 1, (size_t)c->max_push);
             if (v->i_rot < 0) { return SDRPP_ERR_NOMEM; }
         }
@@ -3824,7 +3827,7 @@ int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
     const double th = sdrpp_host::turnsPerSample(re, im);
     // the samples already in the first decimator's delay line stay rotated with the old increment (rx_vfo.h:72-77 only swaps
     // phaseDelta): remember where it changed so the first outputs of the next pushes can be handed over exactly (do_vfos)
-    if (!c->nco_exact && v.d.n_stages > 0 && th != v.theta) {
+    if (!v.nco_exact && v.d.n_stages > 0 && th != v.theta) {
         if (!v.recs.empty() && v.recs.back().pos == v.seen) { /* retuned twice between pushes: the older increment stays the one before */ }
         else { v.recs.push_back(Vfo::Retune{ v.seen, v.theta }); }
     }

@@ -122,12 +122,16 @@ public:
     // every analog demodulator of the radio module).  detachAF() puts the demodulator output back on `audio`.
     void attachAF(double audioSamplerate = 48000.0, double deempTau = 50e-6, bool highPass = false);
     void detachAF();
+    // Parity switch for THIS channel (sdrpp_vfo_desc.nco_mode): true = the reference's float rotator recursion on the device (what an SSB
+    // product detector or a raw-IF consumer needs to follow a CPU build's own rounding drift), false = closed-form NCO, the fast path
+    void setReferenceRotator(bool enabled);
 
     double inSamplerate = 0, outSamplerate = 0, bandwidth = 0, offset = 0;
     double demodBandwidth = 0;  // 0: follows `bandwidth`
     Demod demod = Demod::RAW;
     bool lowPass = true, carrierAgc = false;
     double agcAttack = 50.0, agcDecay = 5.0;
+    int ncoMode = 0;  // 0: the front end's mode (IQFrontEnd::setReferenceRotator), 1: closed form, 2: reference rotator
     bool afOn = false, afHighPass = false;
     double afAudioRate = 48000.0, afDeempTau = 50e-6;
 
@@ -815,6 +819,7 @@ private:
             d.chan_taps = ctaps.data();
         }
         d.demod = (int)v.demod;
+        d.nco_mode = v.ncoMode;
         d.agc_set_point = 1.0f;
         d.agc_max_gain = 10e6;
         d.agc_max_output_amp = 10.0f;
@@ -1029,6 +1034,13 @@ private:
     void* _fftCtx = nullptr;
 };
 
+inline void RxVFO::setReferenceRotator(bool enabled) {
+    std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
+    fe->tempStop();
+    ncoMode = enabled ? 2 : 1;
+    fe->rebuild(*this);
+    fe->tempStart();
+}
 inline void RxVFO::setInSamplerate(double sr) {  // rx_vfo.h:38-43: xlator offset and resampler follow the new input rate
     std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
     fe->tempStop();

@@ -72,10 +72,11 @@ def _fp(a):
     return a.ctypes.data_as(capi.c_float_p)
 
 
-def vfo_desc(in_sr, out_sr, bandwidth, offset, mode="RAW", low_pass=True, agc_attack=50.0, agc_decay=5.0, carrier_agc=False):
+def vfo_desc(in_sr, out_sr, bandwidth, offset, mode="RAW", low_pass=True, agc_attack=50.0, agc_decay=5.0, carrier_agc=False, nco_mode=0):
     """Build a sdrpp_vfo_desc for RxVFO(in_sr -> out_sr, bandwidth, offset) followed by radio demodulator `mode`.
     Returns (desc, keepalive) — keepalive holds the numpy arrays the descriptor points into (sdrpp_vfo_add copies them)."""
     d = capi.VfoDesc()
+    d.nco_mode = int(nco_mode)  # 0: the context's NCO mode, 1: closed form, 2: the reference's float rotator recursion (this VFO only)
     keep = []
     # FrequencyXlator: xlator.init(NULL, -_offset, _inSamplerate) (rx_vfo.h:27)
     d.phase_delta_re, d.phase_delta_im = capi.design_phase_delta(-offset, in_sr)

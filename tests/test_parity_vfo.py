@@ -279,6 +279,34 @@ def test_reference_rotator_mode_matches_the_reference(backend, cut):
     ctx.close()
 
 
+def test_per_vfo_nco_mode_in_one_bank(backend):
+    """sdrpp_vfo_desc.nco_mode: the SSB / raw-IF channels of a bank run the reference's rotator recursion (pinned oracle matched at
+    arbitrary offsets: IF 2e-6, audio 1e-5) while its FM / AM channels stay on the closed-form fast path (audio 1e-5 against the same
+    pinned oracle: nothing they output depends on the absolute phase) — one context, the context's own mode left at closed form."""
+    from sdrplusplus_amd import capi, radio
+
+    sr, B, nblk = 10e6, 50000, 5
+    x = _two_tone_mix(sr, B * nblk, ARB_SPECS, 29)
+    ctx = capi.Context(0, max_push=B)
+    vids, chains = [], []
+    for mode, offset in ARB_SPECS:
+        if_rate, bw = radio.RADIO_DEFAULTS.get(mode, (250e3, 250e3))
+        exact = mode in ("USB", "LSB", "DSB", "RAW")
+        d, keep = radio.vfo_desc(sr, if_rate, bw, offset, mode, nco_mode=2 if exact else 1)
+        vids.append(ctx.vfo_add(d, keep))
+        chains.append(S.OracleChain(sr, if_rate, bw, offset, S.MODES.get(mode)))
+    res = _compare_streams(ctx, vids, chains, ARB_SPECS, x, [B] * nblk, [B] * nblk)
+    for (mode, off), (e_if, e_a) in res.items():
+        if mode in ("USB", "LSB", "DSB", "RAW"):
+            assert e_if < 2e-6 and e_a < 1e-5, (mode, e_if, e_a)
+        else:
+            assert e_a < 1e-5, (mode, e_if, e_a)  # (their IF carries the reference rotator's drift: section 5 of DESIGN.md)
+    with pytest.raises(capi.SdrppError):
+        d, keep = radio.vfo_desc(sr, 250e3, 250e3, 0.0, "RAW", nco_mode=7)
+        ctx.vfo_add(d, keep)
+    ctx.close()
+
+
 def test_reference_rotator_mode_retune_and_reset(backend):
     """setOffset in reference-rotator mode only swaps phaseDelta (rx_vfo.h:72-77): the phase state continues, the delay line keeps
     its old-increment samples — exact from the first output on; reset restarts the phase at (1, 0)."""
