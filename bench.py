@@ -512,7 +512,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--push", type=int, default=STREAM_CAP, help="complex samples per step = per block handed to the hot path (default: the dsp::stream cap, 10^6)")
     ap.add_argument("--mode", choices=("pipelined", "ordinary"), default="pipelined", help="pipelined: one launch per block (sdrpp_set_pipelined); ordinary: one launch per stage")

@@ -1,36 +1,40 @@
 #!/bin/bash
-# Round-2 GPU call 3: full -m gpu suite, bench lines for cfg 3 (default, with by_push + cpu_baseline), cfg 2, cfg 4, host-side enqueue profile
-# at the reference block size, rocprofv3 kernel trace + PMC passes of the default workload.
+# Round 3, final-state GPU call: the default bench line exactly as the driver runs it, bench lines for cfg 2 / cfg 4, rocprofv3 kernel trace +
+# PMC passes (FETCH_SIZE / WRITE_SIZE / matrix-pipe busy cycles, one pass each) of the headline workload (pipelined mode, 10^6-sample blocks),
+# tick timelines.   usage: bash tools/profile_all.sh [tag]
 set -u
-O=gpurun_out/r02m
+TAG=${1:-r03m}
+O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests/ -x -q -m gpu -s --durations=8 ) > $O/pytest_gpu.log 2>&1
-tail -15 $O/pytest_gpu.log
-for c in 3 2 4; do
-    echo "== bench cfg $c"
-    timeout 600 python bench.py --cfg $c --steps 20 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
-    tail -c 1500 $O/bench_cfg$c.json; echo
+R=${GRAFT_REPO_ROOT:-$PWD}
+( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2>&1 | tail -4
+tail -c 600 $O/bench_default.json; echo
+for c in 2 4; do
+    timeout 600 python bench.py --cfg $c --no-others > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
+    tail -c 300 $O/bench_cfg$c.json; echo
 done
-echo "== host enqueue profile, B = 50000"
-SDRPP_GPU_HOSTPROF=1 timeout 120 python tools/hosttime.py 50000 2>&1 | tail -25 | tee $O/hostprof_50k.log
 echo "== rocprofv3 kernel trace"
-R=$GRAFT_REPO_ROOT
+BENCH="python $R/bench.py --no-others --no-by-push --no-cpu-baseline"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o t -- python $R/bench.py --steps 10 --no-cpu-baseline --no-by-push > $R/$O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o t -- $BENCH --steps 200 > $R/$O/trace.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_$ctr -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-by-push > $R/$O/pmc_$ctr.log 2>&1
+    timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_$ctr -o p -- $BENCH --steps 60 --warmup 10 > $R/$O/pmc_$ctr.log 2>&1
 done
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $R/$O/pmc_SQ -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-by-push > $R/$O/pmc_SQ.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d $R/$O/pmc_SQ -o p -- $BENCH --steps 60 --warmup 10 > $R/$O/pmc_SQ.log 2>&1
 cd $R
 T=$(find $O/trace -name "*.db" | head -1); F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1); Q=$(find $O/pmc_SQ -name "*.db" | head -1)
-python tools/rocpd_summary.py $T --pmc $F $W $Q --out $O/r02m_cfg3_16Mi.md --json $O/pmc_traffic.json --title "round 2, final state (pipelined FM back end, doZoom groups, FFT branch at low stream priority), cfg 3, 2^24 samples per step" --meta push=16777216 cfg=3 nvfo=32 2>&1 | tail -3
-head -30 $O/r02m_cfg3_16Mi.md
+python tools/rocpd_summary.py $T --pmc $F $W $Q --out $O/${TAG}_cfg3_pipelined_1M.md --json $O/pmc_traffic_cfg3_push1000000.json \
+    --title "round 3, final state: headline workload (cfg 3, pipelined mode, 10^6-sample blocks, zoomed lines delivered), python bench.py --no-others --no-by-push --no-cpu-baseline" \
+    --meta push=1000000 cfg=3 nvfo=32 mode=pipelined 2>&1 | tail -3
+head -24 $O/${TAG}_cfg3_pipelined_1M.md
+grep -h "\"value\"" $O/trace.log | tail -c 400; echo
 find $O -name "*.db" -size +8M -delete
-ls -la $O
-echo "== VFO bank alone: pipelined back end on / off"
-for m in 1 0 1 0; do SDRPP_TOOL_PIPELINE=$m timeout 120 python tools/vfo_only_time.py 16777216 32 10 2>&1 | tail -1 | sed "s/^/pipeline $m: /" | tee -a $O/vfo_only.log; done
-echo "== per-role cycles of the pipelined kernel (prof build)"
-SDRPP_GPU_LIB=$PWD/sdrplusplus_amd/csrc/libsdrpp_gpu_prof.so timeout 120 python tools/vfo_only_time.py 16777216 32 10 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/pipe_prof.log
-echo "== C++ IQFrontEnd worker profile"
-bash tools/blocks_prof.sh 2>&1 | tee $O/blocks_prof.log
+for spec in "3 1000000 80" "3 50000 300" "4 307200 80"; do
+  set -- $spec
+  timeout 200 python tools/tick_trace_run.py $1 $2 $3 $O/tt.bin 2>&1 | grep -v amdgpu.ids
+  timeout 100 python tools/tick_trace.py $O/tt.bin 20 2>/dev/null > $O/tick_timeline_cfg$1_B$2.txt
+  rm -f $O/tt.bin
+done
+head -8 $O/tick_timeline_cfg3_B1000000.txt
+ls $O

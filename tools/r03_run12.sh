@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r03l
+mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1
+tail -6 $O/pytest_gpu.log
