@@ -237,7 +237,7 @@ def make_inputs(torch, np, device, base, push, seed, nvfo, min_bytes=384 << 20):
     return bufs, copies
 
 
-def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4):
+def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4, exact_ssb=False):
     """One measured run of a configuration.  mode 'pipelined': sdrpp_set_pipelined, one launch per block; 'ordinary': one launch per
     stage.  Returns (result dict for rank 0, inputs) — the inputs can be handed to a second run of the same configuration."""
     from sdrplusplus_amd import capi, multi, workloads
@@ -252,7 +252,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
     bufs = inputs[0]
     ctx = capi.Context(local, max_push=push)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
-    info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo)
+    info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo, exact_ssb=exact_ssb)
     if ref_block is None:
         ref_block = int(sr / 200)
     if ref_block and ref_block < push:
@@ -358,6 +358,8 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             "roofline": roof, "roofline_fft": roof_fft, "roofline_path": roof_path,
             "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
             "realtime_factor": round(per_gpu / sr, 1), "sr": sr, "fft": N, "nvfo": nvfo,
+            "nco": ("SSB / DSB / raw channels: the reference's float rotator recursion on the device (nco_mode 2: every channel inside the north-star tolerance against the "
+                    "compiled reference at arbitrary offsets); FM / AM channels closed form") if exact_ssb else "closed form (FM / AM exact to the tolerance; SSB / raw IF differ from the reference by ITS rotator's rounding drift, DESIGN.md 5)",
         }
         if pipelined:
             out["results_delivered"] = "zoomed lines + palette indices of every block in page-locked host memory (result flag 2), batches of %d blocks copied to the device%s; VFO outputs stay on the device" % (
@@ -370,7 +372,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
 def compact(r):
     if r is None:
         return None
-    keep = ("value", "ms_per_step", "steps", "samples_per_step_per_gpu", "mode", "reference_block", "kernel_ms_per_step", "realtime_factor")
+    keep = ("value", "ms_per_step", "steps", "samples_per_step_per_gpu", "mode", "reference_block", "kernel_ms_per_step", "realtime_factor", "nco")
     o = {k: r[k] for k in keep if k in r}
     o["unit"] = "Msamples/s"
     if r.get("roofline"):
@@ -523,6 +525,7 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="skip the ceiling and the cfg 2 / cfg 4 runs")
     ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; runs as ordinary passes)")
     ap.add_argument("--fft-only", action="store_true", help="same as --cfg 2")
+    ap.add_argument("--nco", choices=("closed", "ssb-exact"), default="closed", help="ssb-exact: SSB / DSB / raw channels on the reference's float rotator recursion (sdrpp_vfo_desc.nco_mode = 2); runs as ordinary passes")
     ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3 on one GPU, 5 on several)")
     args = ap.parse_args()
 
@@ -564,7 +567,7 @@ def main():
     if mode == "ordinary":
         push = max(1, push // N) * N  # whole frames per step (the ordinary protocol copies a fixed number of lines)
     ref_block = None if args.ref_block < 0 else args.ref_block
-    head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block)
+    head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block, exact_ssb=args.nco == "ssb-exact")
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -575,7 +578,7 @@ def main():
         "config": {"workload": head["workload"], "samples_per_step_per_gpu": push, "mode": head["mode"] + (" (sdrpp_set_pipelined: one launch per block, results %d blocks late)" % head.get("result_lag_blocks", 0) if mode == "pipelined" else ""),
                    "reference_block": head["reference_block"], "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
                    "input_blocks_rotated": head["input_blocks_rotated"], "input_bytes_rotated": head["input_bytes_rotated"], "af_chain": head["af_chain"], "device": head["device"],
-                   "results_delivered": head.get("results_delivered")},
+                   "results_delivered": head.get("results_delivered"), "nco": head["nco"]},
         "roofline": head["roofline"], "roofline_fft": head["roofline_fft"], "roofline_path": head["roofline_path"],
         "kernel_ms_per_step": head["kernel_ms_per_step"],
         "kernel_ms_note": "per-family HIP-event times from an untimed calibration pass; pipelined mode has ONE family (tick: the launch per block); ordinary passes: the FFT branch and the VFO bank run on two "
@@ -609,6 +612,11 @@ def main():
                 del inp
                 torch.cuda.empty_cache()
                 others["cfg%d" % oc] = {"workload": r1["workload"], "pipelined_stream_cap": compact(r1), "ceiling_2p24_ordinary": compact(r2)}
+                if oc == 4:  # the setting in which cfg 4's SSB channels follow the reference's own rotator (parity at arbitrary offsets): chain-bound
+                    r3, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "ordinary", 12, 3, ocv, exact_ssb=True)
+                    del inp
+                    torch.cuda.empty_cache()
+                    others["cfg4"]["ssb_channels_on_reference_rotator_stream_cap"] = compact(r3)
             except Exception as e:
                 others["cfg%d" % oc] = {"error": repr(e)[:300]}
         out["other_configs"] = others

@@ -290,6 +290,7 @@ struct sdrpp_ctx {
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
     int test_fail_alloc = 0;
     bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
+    bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
@@ -1989,7 +1990,8 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     {
         FamilyTimer t(c, F_S1);
         if (!rotx.empty() && n_in > 0) {
-            launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size());
+            if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
+            else { launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(256), (size_t)2 * 64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
         }
         for (int k = 0; k < 4; k++) {
             if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }

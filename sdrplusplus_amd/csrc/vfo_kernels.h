@@ -330,6 +330,92 @@ __global__ __launch_bounds__(64) void vfo_rotate_exact_kernel(IqSrc src, const R
     if (live) { *job.state = make_float2(pr, pi); }
 }
 
+// The same recursion with the work split over the four wavefronts of a workgroup (round 3): one wavefront per sample would spend ~16
+// vector instructions (64 cycles) on it — two broadcasts, the rotation, the LDS write, the phase update — but only the phase update is
+// sequential.  Wavefront 0 (lane = VFO) runs NOTHING but the phase chain (the two complex products' four multiplies, a subtraction and an
+// addition per sample, renormalised every 512 samples and at every reference-block end exactly like the reference's calls) and leaves
+// the 64 phases of a 64-sample chunk in LDS; wavefronts 1-3 (lane = sample) meanwhile apply the PREVIOUS chunk's phases to its samples,
+// VFO by VFO, and store coalesced rows.  Two LDS buffers, one workgroup barrier per chunk.  Same operations in the same order on the
+// same operands: bit-identical to vfo_rotate_exact_kernel (and to the reference's rotator).
+struct RotChunkIt {
+    int blk, base, b1, nb;
+    const int* bounds;
+    __device__ __forceinline__ void settle() {
+        while (blk < nb && base >= b1) {
+            blk++;
+            if (blk < nb) { b1 = bounds[blk]; }
+        }
+    }
+    __device__ __forceinline__ void init(const int* bnd, int n) {
+        bounds = bnd;
+        nb = n;
+        blk = 0;
+        base = 0;
+        b1 = n > 0 ? bnd[0] : 0;
+        settle();
+    }
+    __device__ __forceinline__ bool valid() const { return blk < nb; }
+    __device__ __forceinline__ int cnt() const { return (b1 - base < 64) ? b1 - base : 64; }
+    __device__ __forceinline__ bool ends_block() const { return base + cnt() >= b1; }
+    __device__ __forceinline__ void advance() {
+        base += cnt();
+        settle();
+    }
+};
+__global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds, int nb) {
+    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = (int)blockIdx.x * 64;
+    const int nrows = min(64, njobs - j0);
+    const bool live = j0 + lane < njobs;
+    const RotXJob job = jobs[live ? j0 + lane : njobs - 1];
+    float pr = job.state->x, pi = job.state->y;
+    const float dr = job.dr, di = job.di;
+    int since = 0;  // samples since the start of the reference block the producer is in
+    RotChunkIt pit, cit;  // producer one chunk ahead of the consumers
+    pit.init(bounds, nb);
+    cit.init(bounds, nb);
+    auto produce = [&](int buf) {
+        float2* ph = ph_tile + (size_t)buf * 64 * 65;
+        const int cnt = pit.cnt();
+        for (int i = 0; i < cnt; i++) {
+            ph[i * 65 + lane] = make_float2(pr, pi);
+            const float a0 = pr * dr, a1 = pr * di, b0 = pi * di, b1 = pi * dr;
+            pr = a0 - b0;
+            pi = a1 + b1;
+            since++;
+            if ((since & 511) == 0) { rotator_norm(pr, pi); }
+        }
+        if (pit.ends_block()) {
+            if ((since & 511) != 0) { rotator_norm(pr, pi); }
+            since = 0;
+        }
+        pit.advance();
+    };
+    if (wv == 0 && pit.valid()) { produce(0); }
+    __syncthreads();
+    int buf = 0;
+    while (cit.valid()) {
+        if (wv == 0) {
+            if (pit.valid()) { produce(buf ^ 1); }
+        }
+        else {
+            const float2* ph = ph_tile + (size_t)buf * 64 * 65;
+            const int cnt = cit.cnt(), base = cit.base;
+            const float2 x = (lane < cnt) ? src.cur[base + lane] : make_float2(0.0f, 0.0f);
+            for (int r = wv - 1; r < nrows; r += 3) {
+                const float2 p = ph[lane * 65 + r];
+                float2* o = jobs[j0 + r].out;
+                if (lane < cnt) { o[base + lane] = make_float2((x.x * p.x) - (x.y * p.y), (x.x * p.y) + (x.y * p.x)); }
+            }
+        }
+        cit.advance();
+        buf ^= 1;
+        __syncthreads();
+    }
+    if (wv == 0 && live) { *job.state = make_float2(pr, pi); }
+}
+
 // SSB's second translation (ssb.h:78, a FrequencyXlator at the IF rate) in reference-rotator mode: one wavefront per VFO, every lane
 // evaluates the same (uniform) recursion, lane i keeps Re{x[i] * phase} of sample i of the 64-sample chunk.
 struct SsbRotXJob {

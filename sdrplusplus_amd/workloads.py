@@ -84,8 +84,10 @@ def to_int16_wav_samples(x):
     return np.clip(np.rint(v * 32767.0 * 0.5), -32768, 32767).astype(np.int16)
 
 
-def setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=None, window_kind=2, wf_min=-120.0, wf_max=0.0, fft=True):
-    """Configure a capi.Context for a BASELINE configuration (fft=False: VFO bank only).  Returns dict(vids, plan, nz, skip, fft)."""
+def setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=None, window_kind=2, wf_min=-120.0, wf_max=0.0, fft=True, exact_ssb=False):
+    """Configure a capi.Context for a BASELINE configuration (fft=False: VFO bank only).  Returns dict(vids, plan, nz, skip, fft).
+    exact_ssb: the SSB / DSB / raw channels run the reference's float rotator recursion (sdrpp_vfo_desc.nco_mode = 2) — the setting in which
+    EVERY channel matches the compiled reference inside the north-star tolerance at arbitrary offsets; FM / AM channels stay closed form."""
     c = CFG[cfg]
     sr, N = c["sr"], c["fft"]
     if dense_fft and c["fft_rate"] is None:
@@ -99,6 +101,6 @@ def setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=None, window_kind=2, w
     vids = []
     plan = vfo_plan(cfg, nvfo)
     for mode, if_rate, bw, centre, _ in plan:
-        d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode)
+        d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode, nco_mode=2 if (exact_ssb and mode in ("USB", "LSB", "DSB", "RAW")) else 0)
         vids.append(ctx.vfo_add(d, keep))
     return dict(vids=vids, plan=plan, nz=nz, skip=skip, fft=N, sr=sr, view=(start, size, data_width, wf_min, wf_max))

@@ -64,8 +64,8 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks."""
     from sdrplusplus_amd import workloads
 
-    nv = 20
-    pushes = [50000, 1031, 20000, 7, 33333, 50000, 50000]
+    nv = 20 if backend == "gpu" else 17
+    pushes = [50000, 1031, 20000, 7, 33333, 50000, 50000] if backend == "gpu" else [25000, 1031, 10000, 7, 16667, 25000]
     x = workloads.synth(3, sum(pushes), seed=5, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(3, nv, max(pushes), fft_size)
     refs, pos = [], 0
@@ -99,7 +99,7 @@ def test_pipelined_equals_ordinary_mixed_modes(backend):
     from sdrplusplus_amd import workloads
 
     nv = 54
-    pushes = [307200, 100003, 204397, 307200]
+    pushes = [307200, 100003, 204397, 307200] if backend == "gpu" else [153600, 50003, 102197, 153600]  # (the emulator leg is a logic check: half the samples)
     x = workloads.synth(4, sum(pushes), seed=7, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(4, nv, max(pushes), 0, flags=1, ref_block=50000)
     refs, pos = [], 0
@@ -146,7 +146,7 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
     from sdrplusplus_amd import capi, workloads
 
-    pushes = [50000, 12345, 50000]
+    pushes = [50000, 12345, 50000] if backend == "gpu" else [20000, 12345, 20000]
     x = workloads.synth(3, sum(pushes), seed=9, nvfo=2)
     (ca, va), (cb, vb) = _ctx_pair(3, 2, max(pushes), 4096)
     pos = 0
@@ -164,8 +164,8 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
         _same(ref["raw"], cb.fft_read()[0], "raw lines")
     ca.close()
     cb.close()
-    nv = 20
-    pushes = [50000, 50000, 20011, 50000, 50000, 50000]
+    nv = 20 if backend == "gpu" else 17
+    pushes = [50000, 50000, 20011, 50000, 50000, 50000] if backend == "gpu" else [20000, 20000, 10011, 20000, 20000, 20000]
     x = workloads.synth(3, sum(pushes), seed=10, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(3, nv, max(pushes), 0, flags=1)
     pos = 0
@@ -193,7 +193,7 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
 def test_pipelined_result_slots_and_modes(backend):
     from sdrplusplus_amd import capi, workloads
 
-    nv, B = 20, 4000
+    nv, B = (20, 4000) if backend == "gpu" else (17, 2000)  # (>= 17 VFOs: the matrix-core front end, i.e. blocks that really run as ticks)
     x = workloads.synth(3, B * 40, seed=3, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 0, flags=1)
     with pytest.raises(capi.SdrppError):
