@@ -340,6 +340,11 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * exactly like sdrpp_push.  One slot is open at a time. */
 int sdrpp_push_stage(sdrpp_ctx* ctx, int64_t count, float** slot);
 int sdrpp_push_staged(sdrpp_ctx* ctx, int64_t count);
+/* The same with the host's copy threads still at work: the call plans the block at once (the job tables do not depend on the samples:
+ * ~8 us of a 50 000-sample block's ~50 us of host time) and waits, on the host, for *pending to reach 0 before the first launch that
+ * reads the slot.  `pending` = the number of unfinished parts of the caller's copy, decremented (release order) by the copying threads;
+ * a word that does not reach 0 within 5 s fails the push.  sdrpp_gpu::IQFrontEnd's pipelined worker stages its blocks this way. */
+int sdrpp_push_staged_when(sdrpp_ctx* ctx, int64_t count, const volatile uint32_t* pending);
 typedef struct sdrpp_result {
     uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
     int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */

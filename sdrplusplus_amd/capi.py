@@ -184,6 +184,7 @@ def load():
     L.sdrpp_push_wait.argtypes = [vp]
     L.sdrpp_push_stage.argtypes = [vp, C.c_int64, C.POINTER(c_float_p)]
     L.sdrpp_push_staged.argtypes = [vp, C.c_int64]
+    L.sdrpp_push_staged_when.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint32)]
     L.sdrpp_host_alloc.restype = vp
     L.sdrpp_host_alloc.argtypes = [C.c_size_t]
     L.sdrpp_host_free.restype = None
@@ -228,7 +229,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
-    "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged",
+    "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
     "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
@@ -596,6 +597,34 @@ class Context:
         self._chk(self.L.sdrpp_push_stage(self.h, len(iq), C.byref(slot)))
         C.memmove(slot, iq.ctypes.data, len(iq) * 8)
         self._chk(self.L.sdrpp_push_staged(self.h, len(iq)))
+
+    def push_staged_late_fill(self, iq, delay_s=0.002):
+        """sdrpp_push_stage + sdrpp_push_staged_when: a second thread fills the slot (after `delay_s`, in two parts) while the call is
+        already planning the block; the launch waits for the pending word.  Test helper for the C++ worker's staging protocol."""
+        import threading
+        import time
+
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        slot = c_float_p()
+        self._chk(self.L.sdrpp_push_stage(self.h, len(iq), C.byref(slot)))
+        pending = C.c_uint32(2)
+        dst = C.cast(slot, C.c_void_p).value
+        half = (len(iq) // 2) * 8
+
+        def fill():
+            time.sleep(delay_s)
+            C.memmove(dst, iq.ctypes.data, half)
+            pending.value = 1
+            time.sleep(delay_s)
+            C.memmove(dst + half, iq.ctypes.data + half, len(iq) * 8 - half)
+            pending.value = 0
+
+        th = threading.Thread(target=fill)
+        th.start()
+        try:
+            self._chk(self.L.sdrpp_push_staged_when(self.h, len(iq), C.byref(pending)))
+        finally:
+            th.join()
 
     def result_lines_into(self, ticket, dst_addr, max_lines):
         """Lean form of result_wait + copy + release for the zoomed lines of a block (result flag 2): the lines go to host address

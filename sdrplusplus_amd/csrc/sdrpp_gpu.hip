@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -242,6 +243,8 @@ struct sdrpp_ctx {
     int view_start = 0, view_size = 0, data_width = 0;
     float wf_min = -120.0f, wf_max = 0.0f;
     int32_t* d_zstart = nullptr;
+    std::vector<int32_t> h_zstart, h_zcount;  // host copies of the view's pixel ranges (zoom_lanes)
+    int zoom_tp_cache = 0, zoom_tp_grp = -1;     // lanes per pixel for (the view, zoom_grp == zoom_tp_grp)
     int32_t* d_zcount = nullptr;
     float* d_zoomed = nullptr;
     int32_t* d_index = nullptr;
@@ -290,6 +293,7 @@ struct sdrpp_ctx {
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
     int test_fail_alloc = 0;
     bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
+    const volatile uint32_t* stage_pending = nullptr;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for this word to reach 0
     bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
@@ -986,13 +990,37 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
     return SDRPP_OK;
 }
 
+// Lanes per pixel of the zoom kernel (16 / 4 / 1): from the LARGEST number of elements a pixel of the current view really walks — bins, or
+// with pass 2's group maxima ragged head + whole groups + ragged tail (zoom_palette_body).  An aligned full-span view of a 65536-point
+// line at 1024 pixels walks 4 group maxima per pixel: one lane per pixel, 4 workgroups per line instead of 64 and no LDS exchange (the
+// estimate bins / group + group — the worst ragged case — chose 16 lanes, 12 of them idle).  max is order independent: same bits.
+int zoom_lanes(sdrpp_ctx* c, bool with_grp) {
+    const int gsz = with_grp ? c->zoom_grp : 0;
+    if (c->zoom_tp_grp == gsz && c->zoom_tp_cache) { return c->zoom_tp_cache; }
+    int worst = 1;
+    for (size_t i = 0; i < c->h_zstart.size(); i++) {
+        const int s = c->h_zstart[i], n = c->h_zcount[i], e = s + n;
+        int el = n;
+        if (gsz > 1 && n >= 2 * gsz) {
+            const int a = ((s + gsz - 1) / gsz) * gsz, bnd = (e / gsz) * gsz;
+            el = (a - s) + (bnd - a) / gsz + (e - bnd);
+        }
+        worst = std::max(worst, el);
+    }
+    c->zoom_tp_cache = worst >= 16 ? 16 : (worst > 4 ? 4 : 1);
+    c->zoom_tp_grp = gsz;
+    return c->zoom_tp_cache;
+}
+// may a view use the group maxima at all?  (zoom_palette_body takes them for pixels of >= 2 groups; narrower views read the bins)
+inline bool zoom_uses_grp(const sdrpp_ctx* c, const float* grp, int view_bins, int data_width, int gsz) { return grp && gsz > 1 && view_bins / std::max(1, data_width) >= 2 * gsz; }
+
 // doZoom + palette launch: lanes per pixel from the view's bins per pixel (coalesced bin reads for wide pixels, no idle lanes for narrow ones)
 void launch_zoom(hipStream_t stream, const float* lines, int nlines, int fft_size, int view_bins, int data_width, const int32_t* zs, const int32_t* zc, float wf_min, float wf_max,
-                 float* zoomed, int32_t* index, const float* grp = nullptr, int gsz = 0) {
+                 float* zoomed, int32_t* index, const float* grp = nullptr, int gsz = 0, int tp_exact = 0) {
     int bpp = view_bins / std::max(1, data_width);
     if (grp && gsz > 1 && bpp >= 2 * gsz) { bpp = bpp / gsz + gsz; }  // elements a pixel walks: whole groups + the ragged ends
     else { grp = nullptr; }
-    const int tp = (bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1);
+    const int tp = tp_exact ? tp_exact : ((bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1));  // (tp_exact: zoom_lanes of the context's own view)
     const dim3 grid((unsigned)((data_width + 256 / tp - 1) / (256 / tp)), (unsigned)nlines);
     switch (tp) {
     case 16: hipLaunchKernelGGL(zoom_palette_kernel<16>, grid, dim3(256), 0, stream, lines, fft_size, data_width, zs, zc, wf_min, wf_max, zoomed, index, grp, gsz); break;
@@ -1114,12 +1142,10 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
             if (c->data_width > 0) {
                 if ((size_t)nframes * (size_t)c->data_width > c->zoom_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: zoom capacity"); }
-                int bpp = c->view_size / std::max(1, c->data_width);
                 const float* zgrp = c->d_lines_grp;
                 int gsz = c->zoom_grp;
-                if (zgrp && gsz > 1 && bpp >= 2 * gsz) { bpp = bpp / gsz + gsz; }
-                else { zgrp = nullptr; }
-                const int tp = (bpp >= 16) ? 16 : ((bpp >= 4) ? 4 : 1);
+                if (!zoom_uses_grp(c, zgrp, c->view_size, c->data_width, gsz)) { zgrp = nullptr; }
+                const int tp = zoom_lanes(c, zgrp != nullptr);
                 sdrpp_ctx::RoleLaunch z{};
                 z.e.role = tp == 16 ? TR_ZOOM_16 : (tp == 4 ? TR_ZOOM_4 : TR_ZOOM_1);
                 const int zgroups = (c->data_width + 256 / tp - 1) / (256 / tp);
@@ -1154,7 +1180,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             if (rc) { return rc; }
             FamilyTimer t(c, F_ZOOM);
             launch_zoom(c->launch_stream, c->d_lines, (int)nframes, c->fft_size, c->view_size, c->data_width, c->d_zstart, c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index,
-                        c->d_lines_grp, c->zoom_grp);
+                        c->d_lines_grp, c->zoom_grp, zoom_lanes(c, zoom_uses_grp(c, c->d_lines_grp, c->view_size, c->data_width, c->zoom_grp)));
             if (c->wf.height > 0) {  // FFT trace: latestFFT after smoothing / hold (pushFFT, waterfall.cpp:913-939)
                 int rc2 = wf_ensure_trace(c);
                 if (rc2) { return rc2; }
@@ -2840,6 +2866,24 @@ int tick_results_direct(sdrpp_ctx* c) {
     return SDRPP_OK;
 }
 
+// sdrpp_push_staged_when: the host is still filling the staging slot with other threads while this thread plans the block; nothing that
+// reads the slot may be launched before they are through (the word counts their unfinished parts).
+int stage_pending_wait(sdrpp_ctx* c) {
+    const volatile uint32_t* w = c->stage_pending;
+    if (!w) { return SDRPP_OK; }
+    c->stage_pending = nullptr;
+    HostScope hs("staging wait");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *w != 0u; spins++) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged_when: the staging slot was not completed within 5 s"); }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SDRPP_OK;
+}
+
 // One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
 int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
     if (count == 0) { return SDRPP_OK; }
@@ -2915,7 +2959,8 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             rc = arena_begin(c);
             if (rc) { return rc; }
         }
-        rc = tick_launch(c, land);
+        rc = stage_pending_wait(c);
+        if (!rc) { rc = tick_launch(c, land); }
         if (!rc) { rc = tick_drain(c); }
         if (land) { c->land_tick = c->ticks; }
         if (!rc) { rc = push_common(c, d_iq, count, nullptr); }
@@ -2934,7 +2979,8 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
     c->emits.clear();
     c->iq_cur ^= 1;
     // tickq[0] is this very tick: it holds only what earlier blocks queued (a block's own roles start at level 1)
-    {
+    rc = stage_pending_wait(c);
+    if (!rc) {
         HostScope hs("tick launch");
         rc = tick_launch(c, land);
     }
@@ -3463,6 +3509,9 @@ int sdrpp_fft_set_view(sdrpp_ctx* c, int start, int size, int data_width, float 
     if (rc) { return rc; }
     rc = upload(c, &c->d_zcount, zc.data(), zc.size());
     if (rc) { return rc; }
+    c->h_zstart = zs;
+    c->h_zcount = zc;
+    c->zoom_tp_cache = 0;
     return ensure_zoom(c, c->lines_cap);
 }
 
@@ -4395,9 +4444,22 @@ int sdrpp_push_stage(sdrpp_ctx* c, int64_t count, float** slot) {
     *slot = reinterpret_cast<float*>(c->stage_host[si]);
     return SDRPP_OK;
 }
+static int push_staged_impl(sdrpp_ctx* c, int64_t count);
 int sdrpp_push_staged(sdrpp_ctx* c, int64_t count) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
+    c->stage_pending = nullptr;
+    return push_staged_impl(c, count);
+}
+int sdrpp_push_staged_when(sdrpp_ctx* c, int64_t count, const volatile uint32_t* pending) {
+    DeviceScope dev_scope_(c);
+    if (!c) { return SDRPP_ERR_INVALID; }
+    c->stage_pending = pending;
+    const int rc = push_staged_impl(c, count);
+    c->stage_pending = nullptr;  // (a failed plan returns without having waited: the caller joins its own threads)
+    return rc;
+}
+static int push_staged_impl(sdrpp_ctx* c, int64_t count) {
     if (!c->pipelined || c->stage_open < 0 || c->stage_open != c->stage_cur) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged without an open staging slot (sdrpp_push_stage)"); }
     if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged: count out of range"); }
     const int si = c->stage_open;

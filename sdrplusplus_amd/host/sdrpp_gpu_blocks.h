@@ -48,6 +48,11 @@
 #endif
 #endif
 
+#ifdef SDRPP_GPU_BLOCKS_PROF
+#define SDRPP_PIPE_TICK(slot) { const auto _now = std::chrono::steady_clock::now(); pipeUs[slot] += std::chrono::duration<double, std::micro>(_now - pipeT).count(); pipeT = _now; }
+#else
+#define SDRPP_PIPE_TICK(slot)
+#endif
 namespace sdrpp_gpu {
 
 // The reference's power-of-two decimation plans (dsp/multirate/decim/plans.h).  Inside an SDR++ tree they come straight
@@ -359,8 +364,12 @@ public:
     // file_source/src/main.cpp:74) or queued in the 32-slot frame buffer and processed by the second worker
     // (SampleFrameBuffer::run / worker, frame_buffer.h:51-98; same index arithmetic, so an overrun drops a whole lap like the reference).
     int run() override {
+#ifdef SDRPP_GPU_BLOCKS_PROF
+        pipeT = std::chrono::steady_clock::now();
+#endif
         int count = _in->read();
         if (count < 0) { return -1; }
+        SDRPP_PIPE_TICK(0)
         if (!_buffering) {
             drainControl();
             if (_pipelining && pipelineEligible()) {
@@ -369,33 +378,53 @@ public:
                 // (a hand-over that failed means its stream was stopped under it — that block is gone, like a block the reference has in flight at a
                 // stop; whether THIS worker ends is decided by read() alone)
                 (void)finishDelivery();
+                SDRPP_PIPE_TICK(1)
                 // the block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
                 // 10 MS/s), so the helpers and this thread copy a quarter each — and is fetched from there by the launch
+                // (round 3b: the copy runs on the helpers WHILE this thread plans the block inside sdrpp_push_staged_when — the job tables do
+                // not depend on the samples — and the library holds the block's launch back until the last part has landed; the helper that
+                // finishes last frees the stream buffer, so the source is not held up by the planning either)
                 float* slot = nullptr;
                 int prc = sdrpp_push_stage(ctx, count, &slot);
                 if (!prc) {
                     const char* srcb = (const char*)_in->readBuf;
                     char* dstb = (char*)slot;
-                    const size_t bytes = (size_t)count * sizeof(dsp::complex_t), parts = bytes >= (size_t)(64 << 10) ? 4 : 1, per = ((bytes / parts) + 63) & ~(size_t)63;
+                    const size_t bytes = (size_t)count * sizeof(dsp::complex_t), parts = bytes >= (size_t)(64 << 10) ? 3 : 1, per = ((bytes / parts) + 63) & ~(size_t)63;
                     std::vector<std::function<void()>> cj;
+                    size_t njobs = 0;
+                    for (size_t q = 0; q < parts; q++) { njobs += (q * per < bytes) ? 1 : 0; }
+                    stageLeft.store((uint32_t)njobs, std::memory_order_relaxed);
+                    stagePending.store((uint32_t)njobs, std::memory_order_release);
                     for (size_t q = 0; q < parts; q++) {
                         const size_t o = q * per, n = o >= bytes ? 0 : std::min(per, bytes - o);
-                        if (n) { cj.emplace_back([srcb, dstb, o, n]() { memcpy(dstb + o, srcb + o, n); }); }
+                        if (!n) { continue; }
+                        cj.emplace_back([this, srcb, dstb, o, n]() {
+                            memcpy(dstb + o, srcb + o, n);
+                            if (stageLeft.fetch_sub(1, std::memory_order_acq_rel) == 1) { _in->flush(); }  // the stream buffer is free (BEFORE the word reaches 0: the worker's next read() follows it)
+                            stagePending.fetch_sub(1, std::memory_order_release);
+                        });
                     }
-                    helpers.run(std::move(cj));
+                    helpers.begin(std::move(cj));
+                    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the pending word is handed to the C ABI as a plain uint32_t");
+                    prc = sdrpp_push_staged_when(ctx, count, reinterpret_cast<const volatile uint32_t*>(&stagePending));
+                    helpers.finish();  // (joins the copy on a failed plan, which returns without waiting; a no-op otherwise)
                 }
-                _in->flush();  // the stream buffer is free
-                if (!prc) { prc = sdrpp_push_staged(ctx, count); }
+                else { _in->flush(); }
                 if (prc) {
                     fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
                     return -1;
                 }
                 pendingTickets.push_back(sdrpp_ticket(ctx));
+                SDRPP_PIPE_TICK(2)
                 if ((int)pendingTickets.size() > _pipeLag) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
                     const uint64_t t = pendingTickets.front();
                     pendingTickets.erase(pendingTickets.begin());
                     if (startDelivery(t) < 0) { return -1; }
                 }
+                SDRPP_PIPE_TICK(3)
+#ifdef SDRPP_GPU_BLOCKS_PROF
+                pipeBlocks++;
+#endif
                 return count;
             }
             if (pipeOn && leavePipelined() < 0) { return -1; }
@@ -452,11 +481,17 @@ public:
     // diagnostic build of a host program: where the worker's wall time goes (microseconds, passes)
     double profUs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     long profPasses = 0;
+    double pipeUs[5] = { 0, 0, 0, 0, 0 };  // pipelined bypass, per block: wait for the block | join the previous hand-over | stage + plan + launch | result wait + start of the hand-over
+    long pipeBlocks = 0;
+    std::chrono::steady_clock::time_point pipeT;
     std::chrono::steady_clock::time_point profT;
     void profReport() {
         const double n = (double)std::max(1L, profPasses);
         fprintf(stderr, "[sdrpp_gpu blocks prof] passes %ld, us per pass: wait for frames %.1f | stage (H2D) %.1f | process + line count %.1f | FFT lines out %.1f | bound IQ streams %.1f | VFO read (D2H) %.1f | VFO hand-off (memcpy + swap) %.1f\n",
                 profPasses, profUs[0] / n, profUs[1] / n, profUs[2] / n, profUs[3] / n, profUs[4] / n, profUs[5] / n, profUs[6] / n);
+        const double nb = (double)std::max(1L, pipeBlocks);
+        fprintf(stderr, "[sdrpp_gpu blocks prof] pipelined blocks %ld, us per block: wait for the block %.1f | join previous hand-over %.1f | stage + plan + launch %.1f | result wait + hand-over start %.1f\n",
+                pipeBlocks, pipeUs[0] / nb, pipeUs[1] / nb, pipeUs[2] / nb, pipeUs[3] / nb);
     }
 #define SDRPP_BLOCKS_TICK(slot) { const auto _now = std::chrono::steady_clock::now(); profUs[slot] += std::chrono::duration<double, std::micro>(_now - profT).count(); profT = _now; }
 #define SDRPP_BLOCKS_TICK0() { profT = std::chrono::steady_clock::now(); }
@@ -909,6 +944,7 @@ private:
     int _pipeLag = 8;
     bool pipeOn = false;                    // the context is in pipelined mode (owned by the worker)
     std::vector<uint64_t> pendingTickets;   // blocks launched whose results have not been handed out yet
+    std::atomic<uint32_t> stageLeft{ 0 }, stagePending{ 0 };  // staging copy of the block being pushed: parts not yet copied / not yet accounted for
     uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
     sdrpp_result inflight{};
     std::vector<std::pair<RxVFO*, int>> inflightOrder;

@@ -73,10 +73,12 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size):
         blk = x[pos:pos + n]
         pos += n
         refs.append(_ordinary_results(ca, va, blk, True))
-        if len(refs) % 2:
+        if len(refs) % 3 == 1:
             cb.push(blk)  # returns at once: one launch
-        else:
+        elif len(refs) % 3 == 2:
             cb.push_staged_from(blk)  # sdrpp_push_stage / _staged: the host fills the library's page-locked slot itself
+        else:
+            cb.push_staged_late_fill(blk)  # sdrpp_push_staged_when: another thread is still filling the slot while the call plans the block
     assert cb.ticket() == len(pushes)
     assert cb.fft_lines() == len(refs[-1]["raw"])  # host knowledge: no flush needed
     for t, ref in enumerate(refs, start=1):
