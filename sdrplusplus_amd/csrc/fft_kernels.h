@@ -301,56 +301,109 @@ struct IdxCols {
     __device__ __forceinline__ int operator()(int p) const { return p * ncols + c; }
 };
 
-// grid.x = nframes * (N2 / C); block = (N1/16) * C work-items, column index fastest.
+// block = (N1/16) * C work-items, column index fastest; a workgroup walks the tiles bid.x, bid.x + step, ... of the ntiles = nframes * (N2 / C)
+// tiles (frame-major) and keeps the NEXT tile's 16 IQ samples per work-item in flight while it transforms the current one (round 3b: one
+// tile per workgroup left the memory system idle during every workgroup's compute phase and the matrix of phases — load, 8 stages, LDS
+// exchange, twiddles, store — in lock-step on all CUs: 0.31-0.40 of the HBM rate with ~1 050 vector instructions per work-item being only
+// a quarter of the time).  With step a multiple of the tiles per frame a workgroup stays on its columns: window values are loaded once.
 // scratch layout: A[frame][k1][n2] (n2 contiguous); tw_n2k1 has the same [k1][n2] layout and holds tw(n2*k1, N).
 template <int LG1, int C>
 __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float2* data, const IqSrc& src, const FrameGeom& g, const float* __restrict__ window,
-                                               const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1, float2* __restrict__ scratch, int lg2) {
+                                               const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1, float2* __restrict__ scratch, int lg2, int ntiles, int step) {
     constexpr int L1 = 1 << LG1;
     constexpr int TPF = L1 / 16;
     const int N2 = 1 << lg2;
     const int tiles = N2 / C;
-    const int frame = bid.x / tiles;
-    const int c0 = (bid.x % tiles) * C;
-    const int c = threadIdx.x % C;
-    const int t = threadIdx.x / C;
-    const int n2 = c0 + c;
+    const int c_ = threadIdx.x % C;
+    const int t_ = threadIdx.x / C;
     for (int e = threadIdx.x; e < L1 / 2; e += TPF * C) { tw[e] = tw1_g[e]; }
-    float2 r[16];
     using R0 = FftRound<LG1, 0, 4>;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int p = R0::pos(t, 0, j);
-        const int n1 = (int)(__brev((unsigned)p) >> (32 - LG1));
-        r[j] = load_windowed(src, g, window, frame, (n1 << lg2) + n2);
-    }
-    __syncthreads();
-    R0::compute(r, t, tw);
-    IdxCols idx{ C, c };
-    fft_rounds_after_first<LG1, 4, IdxCols>(r, t, tw, data, idx);
     using RL = typename FftLast<LG1>::Round;
-    float2* dst = scratch + ((size_t)frame << (LG1 + lg2));
+    // raw samples of a tile (branch-free: the 16 loads of a work-item are in flight together; beyond the frame's nz samples the FFT input is zero)
+    auto fetch = [&](float2 (&x)[16], int tile) {
+        const int t = opaque(t_), c = opaque(c_);
+        const int frame = tile / tiles, n2 = (tile % tiles) * C + c;
 #pragma unroll
-    for (int i = 0; i < RL::NG; i++) {
-#pragma unroll
-        for (int j = 0; j < RL::GS; j++) {
-            const int k1 = RL::pos(t, i, j);
-            const size_t o = ((size_t)k1 << lg2) + n2;
-            const float2 a = r[i * RL::GS + j];
-            const float2 w = tw_n2k1[o];
-            const float pp = a.y * w.y;
-            const float qq = a.y * w.x;
-            dst[o] = make_float2(fmaf(a.x, w.x, -pp), fmaf(a.x, w.y, qq));
+        for (int j = 0; j < 16; j++) {
+            const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+            const int i = (n1 << lg2) + n2;
+            x[j] = iq_load_nb(src, g.first_start + (long long)frame * g.stride + i, i < g.nz);
         }
+    };
+    float wv[16];
+    int wv_n2 = -1;
+    auto transform = [&](float2 (&r)[16], int tile) {
+        const int t = opaque(t_), c = opaque(c_);  // (per-tile copies the optimiser cannot see through: it would otherwise hoist every LDS / global
+                                                   // address of the transform out of the tile loop and keep ~60 more registers alive across it)
+        const int frame = tile / tiles, n2 = (tile % tiles) * C + c;
+        if (n2 != wv_n2) {  // (uniform: all work-items of a workgroup change columns together)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+                const int i = (n1 << lg2) + n2;
+                wv[j] = window[i < g.nz ? i : 0];
+            }
+            wv_n2 = n2;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+            const bool in = ((n1 << lg2) + n2) < g.nz;
+            r[j] = in ? make_float2(r[j].x * wv[j], r[j].y * wv[j]) : make_float2(0.0f, 0.0f);
+        }
+        sched_fence();
+        R0::compute(r, t, tw);
+        sched_fence();
+        IdxCols idx{ C, c };
+        fft_rounds_after_first<LG1, 4, IdxCols>(r, t, tw, data, idx);
+        sched_fence();
+        float2* dst = scratch + ((size_t)frame << (LG1 + lg2));
+#pragma unroll
+        for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+            for (int j = 0; j < RL::GS; j++) {
+                const int k1 = RL::pos(t, i, j);
+                const size_t o = ((size_t)k1 << lg2) + n2;
+                const float2 a = r[i * RL::GS + j];
+                const float2 w = tw_n2k1[o];
+                const float pp = a.y * w.y;
+                const float qq = a.y * w.x;
+                dst[o] = make_float2(fmaf(a.x, w.x, -pp), fmaf(a.x, w.y, qq));
+            }
+        }
+    };
+    float2 r[16], rn[16];
+    int tile = bid.x;
+    if (tile >= ntiles) { return; }  // (no barrier has been passed yet)
+    fetch(r, tile);
+    __syncthreads();  // twiddle table visible
+#ifdef SDRPP_FFT_NO_PREFETCH  // (diagnostic build: the tile walk without the loads in flight)
+    while (true) {
+        transform(r, tile);
+        tile += step;
+        if (tile >= ntiles) { break; }
+        fetch(r, tile);
     }
+#else
+    while (true) {
+        const int next = tile + step;
+        const bool more = next < ntiles;
+        if (more) { fetch(rn, next); }  // in flight during the transform below
+        transform(r, tile);
+        if (!more) { break; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { r[j] = rn[j]; }
+        tile = next;
+    }
+#endif
 }
 template <int LG1, int C>
-__global__ __launch_bounds__(((1 << LG1) / 16) * C) void fft_pass1_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
+__global__ __launch_bounds__(((1 << LG1) / 16) * C, (((1 << LG1) / 16) * C) <= 256 ? 4 : 2) void fft_pass1_kernel(IqSrc src, FrameGeom g, const float* __restrict__ window,
                                                                          const float2* __restrict__ tw1_g, const float2* __restrict__ tw_n2k1,
-                                                                         float2* __restrict__ scratch, int lg2) {
+                                                                         float2* __restrict__ scratch, int lg2, int ntiles) {
     __shared__ float2 tw[(1 << LG1) / 2];
     __shared__ float2 data[(1 << LG1) * C];
-    fft_pass1_body<LG1, C>(kidx(blockIdx), tw, data, src, g, window, tw1_g, tw_n2k1, scratch, lg2);
+    fft_pass1_body<LG1, C>(kidx(blockIdx), tw, data, src, g, window, tw1_g, tw_n2k1, scratch, lg2, ntiles, (int)gridDim.x);
 }
 
 // ---- N > 4096, pass 2: row FFTs + dB, output bin k = k1 + N1*k2 ------------------------------------------------------------------
@@ -359,75 +412,107 @@ struct IdxRowPad {
     __device__ __forceinline__ int operator()(int p) const { return base + p + (p >> 4); }
 };
 
-// grid.x = nframes * (N1 / R); block = (N2/16) * R work-items, t fastest (coalesced row reads).
+// block = (N2/16) * R work-items, t fastest (coalesced row reads); a workgroup walks the tiles bid.x, bid.x + step, ... of the
+// ntiles = nframes * (N1 / R) row tiles and keeps the next tile's rows in flight while it transforms the current one (see fft_pass1_body).
 template <int LG2, int R>
 __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float2* data, const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
-                                               float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
+                                               float* __restrict__ out_db, int lg1, int ntiles, float* __restrict__ grp_max, int step) {
     constexpr int L2 = 1 << LG2;
     constexpr int TPF = L2 / 16;
     constexpr int PITCH = L2 + L2 / 16;
     const int N1 = 1 << lg1;
     const int tiles = N1 / R;
-    const int frame = bid.x / tiles;
-    const int r0 = (bid.x % tiles) * R;
-    const int t = threadIdx.x % TPF;
-    const int row = threadIdx.x / TPF;
+    const int t_ = threadIdx.x % TPF;
+    const int row_ = threadIdx.x / TPF;
     for (int e = threadIdx.x; e < L2 / 2; e += TPF * R) { tw[e] = tw2_g[e]; }
-    const float2* srcrow = scratch + ((size_t)frame << (LG2 + lg1)) + ((size_t)(r0 + row) << LG2);
-    float2 r[16];
     using R0 = FftRound<LG2, 0, 4>;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int p = R0::pos(t, 0, j);
-        const int n = (int)(__brev((unsigned)p) >> (32 - LG2));
-        r[j] = srcrow[n];
-    }
-    __syncthreads();
-    R0::compute(r, t, tw);
-    IdxRowPad idx{ row * PITCH };
-    fft_rounds_after_first<LG2, 4, IdxRowPad>(r, t, tw, data, idx);
     using RL = typename FftLast<LG2>::Round;
-    // dB values are transposed through LDS so that consecutive lanes write consecutive k1 (k = k1 + N1*k2).
-    __syncthreads();
-    float* tile = reinterpret_cast<float*>(data);  // [k2][R + 1]
+    auto fetch = [&](float2 (&x)[16], int tile) {
+        const int t = opaque(t_), row = opaque(row_);
+        const int frame = tile / tiles, r0 = (tile % tiles) * R;
+        const float2* srcrow = scratch + ((size_t)frame << (LG2 + lg1)) + ((size_t)(r0 + row) << LG2);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int n = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG2));
+            x[j] = srcrow[n];
+        }
+    };
     const float inv = 1.0f / (float)((size_t)1 << (LG2 + lg1));
+    auto transform = [&](float2 (&r)[16], int tile) {
+        const int t = opaque(t_), row = opaque(row_), tid = opaque((int)threadIdx.x);  // (see fft_pass1_body)
+        const int frame = tile / tiles, r0 = (tile % tiles) * R;
+        sched_fence();  // (phase boundaries are scheduling boundaries: left to itself the scheduler interleaves the 16 dB polynomials with everything
+                        // around them and needs 200 registers for a 104-register live set)
+        R0::compute(r, t, tw);
+        sched_fence();
+        // (fft_rounds_after_first opens with a barrier: the previous tile's dB values have been read out of `data` before it is rewritten)
+        IdxRowPad idx{ row * PITCH };
+        fft_rounds_after_first<LG2, 4, IdxRowPad>(r, t, tw, data, idx);
+        // dB values are transposed through LDS so that consecutive lanes write consecutive k1 (k = k1 + N1*k2).
+        __syncthreads();
+        float* tile_db = reinterpret_cast<float*>(data);  // [k2][R + 1]
 #pragma unroll
-    for (int i = 0; i < RL::NG; i++) {
+        for (int i = 0; i < RL::NG; i++) {
 #pragma unroll
-        for (int j = 0; j < RL::GS; j++) {
-            const int k2 = RL::pos(t, i, j);
-            tile[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
-        }
-    }
-    __syncthreads();
-    float* dst = out_db + ((size_t)frame << (LG2 + lg1)) + r0;
-    for (int e = threadIdx.x; e < L2 * R; e += TPF * R) {
-        const int k2 = e / R;
-        const int rr = e % R;
-        dst[((size_t)k2 << lg1) + rr] = tile[k2 * (R + 1) + rr];
-    }
-    // doZoom's maximum over the R consecutive bins k1 = r0 .. r0 + R - 1 of every k2, while the tile is in LDS: the zoom kernel then
-    // reads one value per aligned group of R bins instead of R (waterfall.cpp:65-90 takes a maximum, which does not care how it is split)
-    if (grp_max) {
-        float* gdst = grp_max + (((size_t)frame << (LG2 + lg1)) + r0) / R;
-        for (int k2 = threadIdx.x; k2 < L2; k2 += TPF * R) {
-            float m = __uint_as_float(0xff800000u);
-#pragma unroll
-            for (int rr = 0; rr < R; rr++) {
-                const float v = tile[k2 * (R + 1) + rr];
-                if (v > m) { m = v; }
+            for (int j = 0; j < RL::GS; j++) {
+                const int k2 = RL::pos(t, i, j);
+                tile_db[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
+                if ((j & 3) == 3) { sched_fence(); }
             }
-            gdst[((size_t)k2 << lg1) / R] = m;
         }
+        __syncthreads();
+        float* dst = out_db + ((size_t)frame << (LG2 + lg1)) + r0;
+        for (int e = tid; e < L2 * R; e += TPF * R) {
+            const int k2 = e / R;
+            const int rr = e % R;
+            dst[((size_t)k2 << lg1) + rr] = tile_db[k2 * (R + 1) + rr];
+        }
+        // doZoom's maximum over the R consecutive bins k1 = r0 .. r0 + R - 1 of every k2, while the tile is in LDS: the zoom kernel then
+        // reads one value per aligned group of R bins instead of R (waterfall.cpp:65-90 takes a maximum, which does not care how it is split)
+        if (grp_max) {
+            float* gdst = grp_max + (((size_t)frame << (LG2 + lg1)) + r0) / R;
+            for (int k2 = tid; k2 < L2; k2 += TPF * R) {
+                float m = __uint_as_float(0xff800000u);
+#pragma unroll
+                for (int rr = 0; rr < R; rr++) {
+                    const float v = tile_db[k2 * (R + 1) + rr];
+                    if (v > m) { m = v; }
+                }
+                gdst[((size_t)k2 << lg1) / R] = m;
+            }
+        }
+    };
+    float2 r[16], rn[16];
+    int tile = bid.x;
+    if (tile >= ntiles) { return; }  // (no barrier has been passed yet)
+    fetch(r, tile);
+    __syncthreads();  // twiddle table visible
+#ifdef SDRPP_FFT_NO_PREFETCH  // (diagnostic build: the tile walk without the loads in flight)
+    while (true) {
+        transform(r, tile);
+        tile += step;
+        if (tile >= ntiles) { break; }
+        fetch(r, tile);
     }
-    (void)nframes;
+#else
+    while (true) {
+        const int next = tile + step;
+        const bool more = next < ntiles;
+        if (more) { fetch(rn, next); }  // in flight during the transform below
+        transform(r, tile);
+        if (!more) { break; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { r[j] = rn[j]; }
+        tile = next;
+    }
+#endif
 }
 template <int LG2, int R>
-__global__ __launch_bounds__(((1 << LG2) / 16) * R) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
-                                                                         float* __restrict__ out_db, int lg1, int nframes, float* __restrict__ grp_max) {
+__global__ __launch_bounds__(((1 << LG2) / 16) * R, 4) void fft_pass2_kernel(const float2* __restrict__ scratch, const float2* __restrict__ tw2_g,
+                                                                         float* __restrict__ out_db, int lg1, int ntiles, float* __restrict__ grp_max) {
     __shared__ float2 tw[(1 << LG2) / 2];
     __shared__ float2 data[R * ((1 << LG2) + (1 << LG2) / 16)];
-    fft_pass2_body<LG2, R>(kidx(blockIdx), tw, data, scratch, tw2_g, out_db, lg1, nframes, grp_max);
+    fft_pass2_body<LG2, R>(kidx(blockIdx), tw, data, scratch, tw2_g, out_db, lg1, ntiles, grp_max, (int)gridDim.x);
 }
 
 // ---- N > 65536, pass 2: ONE 4096-point row per workgroup ------------------------------------------------------------------------------

@@ -67,6 +67,13 @@ __device__ __forceinline__ void global_store_f32x4(float* p, long long i, float4
 // of the matrix instructions that consume them (left alone, the scheduler sinks them next to their use and the wave then
 // waits out the full LDS latency in front of every v_mfma).
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// A value the optimiser cannot see through.  Used on thread indices at the top of a loop body whose address arithmetic is loop invariant:
+// hoisted out of the loop those addresses (LDS exchange positions, store offsets) stay alive across it — 60-90 registers in the FFT tile
+// walks — for the price of recomputing a handful of integer instructions per tile.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 // Wavefront-level synchronisation of LDS traffic: the 64 lanes of a wavefront run in lock step and its LDS operations complete in
 // order, so no hardware barrier is needed for one lane to read what another lane of the SAME wavefront wrote — only the compiler

@@ -285,6 +285,10 @@ struct sdrpp_ctx {
     bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
     // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
     // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
+    int fft_p1_grid = getenv("SDRPP_GPU_FFT_P1_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P1_GRID")) : 512;   // workgroups of a pass-1 / pass-2 launch (fft_walk_grid; 0: one tile per workgroup)
+    int fft_p2_grid = getenv("SDRPP_GPU_FFT_P2_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P2_GRID")) : 1024;
+    int fft_tick_grid = getenv("SDRPP_GPU_FFT_TICK_GRID") ? atoi(getenv("SDRPP_GPU_FFT_TICK_GRID")) : 128;  // ... of a pass-1 / pass-2 role inside a tick (a shared GPU)
+    bool fft_p1_c16 = getenv("SDRPP_GPU_FFT_P1_C16") != nullptr;  // measurement switch: 16 instead of 32 columns per pass-1 workgroup of a 65536-point transform
     int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
     int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
     int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
@@ -850,6 +854,13 @@ size_t fir_lds(int tile, int D, int K, int width_bytes) {
 }
 
 // ---- FFT launches ---------------------------------------------------------------------------------------------------------------
+// Workgroups of a pass whose workgroups WALK their tiles (fft_pass1_body / fft_pass2_body: tile, tile + grid, ... with the next tile's loads
+// in flight during the current tile's arithmetic): about one resident round, a multiple of the tiles per frame (so that a pass-1 workgroup
+// stays on its columns and keeps their window values), never more than there are tiles.
+inline int fft_walk_grid(int ntiles, int per_frame, int cap) {
+    if (cap <= 0 || ntiles <= cap) { return ntiles; }
+    return std::max(per_frame, (cap / per_frame) * per_frame);
+}
 template <int LG, int FPW>
 void launch_single(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out) {
     const int blocks = (g.nframes + FPW - 1) / FPW;
@@ -857,9 +868,9 @@ void launch_single(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
 }
 template <int LG1, int C>
 void launch_p1(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, int lg2) {
-    const int blocks = g.nframes * ((1 << lg2) / C);
-    launch(c, fft_pass1_kernel<LG1, C>, dim3(blocks), dim3(((1 << LG1) / 16) * C), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1,
-           (const float2*)c->d_twn, c->d_scratch, lg2);
+    const int per_frame = (1 << lg2) / C, ntiles = g.nframes * per_frame;
+    launch(c, fft_pass1_kernel<LG1, C>, dim3((unsigned)fft_walk_grid(ntiles, per_frame, c->fft_p1_grid)), dim3(((1 << LG1) / 16) * C), 0, src, g, (const float*)c->d_window, (const float2*)c->d_tw1,
+           (const float2*)c->d_twn, c->d_scratch, lg2, ntiles);
 }
 // four-step split of a 2^m-point transform (m > 12): N1 = 2^lg1 column transforms, N2 = 2^lg2 row transforms.  Even up to 65536 points;
 // above, the rows take the 4096 points one workgroup holds and the columns the rest (fft_kernels.h) — the oracle splits the same way
@@ -872,8 +883,8 @@ constexpr int pass2_rows(int lg2) { return lg2 == 7 ? 32 : (lg2 == 8 ? 16 : (lg2
 template <int LG2, int R>
 void launch_p2(sdrpp_ctx* c, int nframes, int lg1, float* out, float* grp) {
     static_assert(R == pass2_rows(LG2), "pass2_rows out of step with the launch table");
-    const int blocks = nframes * ((1 << lg1) / R);
-    launch(c, fft_pass2_kernel<LG2, R>, dim3(blocks), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, nframes, grp);
+    const int per_frame = (1 << lg1) / R, ntiles = nframes * per_frame;
+    launch(c, fft_pass2_kernel<LG2, R>, dim3((unsigned)fft_walk_grid(ntiles, per_frame, c->fft_p2_grid)), dim3(((1 << LG2) / 16) * R), 0, (const float2*)c->d_scratch, (const float2*)c->d_tw2, out, lg1, ntiles, grp);
 }
 
 void launch_p2row(sdrpp_ctx* c, int nframes, int lg1) {
@@ -907,8 +918,11 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
     static const int p2_role[4] = { TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10 };
     if (lg1 < 5 || lg1 > 10 || lg2 < 7 || lg2 > 12 || (lg2 > 10 && lg2 != 12)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "fft size 2^%d unsupported", m); }
     r.e.role = p1_role[lg1 - 5];
-    r.e.gx = g.nframes * ((1 << lg2) / p1_c[lg1 - 5]);
-    r.e.p.p1 = TickP1{ src, g, c->d_window, c->d_tw1, c->d_twn, c->d_scratch, lg2, 0 };
+    {
+        const int per_frame = (1 << lg2) / p1_c[lg1 - 5], ntiles = g.nframes * per_frame;
+        r.e.gx = fft_walk_grid(ntiles, per_frame, c->fft_tick_grid);
+        r.e.p.p1 = TickP1{ src, g, c->d_window, c->d_tw1, c->d_twn, c->d_scratch, lg2, ntiles };
+    }
     r.lds = tick_lds_fft_p1(lg1, p1_c[lg1 - 5]);
     r.level = 1;
     r.fam = F_FFT1;
@@ -938,8 +952,11 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
     sdrpp_ctx::RoleLaunch q{};
     q.e.gy = 1;
     q.e.role = p2_role[lg2 - 7];
-    q.e.gx = g.nframes * ((1 << lg1) / pass2_rows(lg2));
-    q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, out, grp, lg1, g.nframes };
+    {
+        const int per_frame = (1 << lg1) / pass2_rows(lg2), ntiles = g.nframes * per_frame;
+        q.e.gx = fft_walk_grid(ntiles, per_frame, c->fft_tick_grid);
+        q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, out, grp, lg1, ntiles };
+    }
     q.lds = tick_lds_fft_p2(lg2, pass2_rows(lg2));
     q.level = 2;
     q.fam = F_FFT2;
@@ -967,7 +984,10 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
         case 5: launch_p1<5, 128>(c, src, g, lg2); break;
         case 6: launch_p1<6, 64>(c, src, g, lg2); break;
         case 7: launch_p1<7, 32>(c, src, g, lg2); break;
-        case 8: launch_p1<8, 32>(c, src, g, lg2); break;  // 256-byte row segments; measured 7 % faster than <8, 16>
+        case 8:
+            if (c->fft_p1_c16) { launch_p1<8, 16>(c, src, g, lg2); }
+            else { launch_p1<8, 32>(c, src, g, lg2); }  // 256-byte row segments; measured 7 % faster than <8, 16> (one tile per workgroup)
+            break;
         case 9: launch_p1<9, 8>(c, src, g, lg2); break;
         case 10: launch_p1<10, 4>(c, src, g, lg2); break;
         default: return fail(c, SDRPP_ERR_UNSUPPORTED, "fft pass-1 size 2^%d unsupported", lg1);
@@ -2017,7 +2037,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         FamilyTimer t(c, F_S1);
         if (!rotx.empty() && n_in > 0) {
             if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
-            else { launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(256), (size_t)2 * 64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
+            else { launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
         }
         for (int k = 0; k < 4; k++) {
             if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }

@@ -86,8 +86,8 @@ enum TickRole : int {
     TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
     TR_COUNT
 };
-struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, pad; };
-struct TickP2 { const float2* scratch; const float2* tw2; float* out; float* grp; int lg1, nframes; };
+struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, ntiles; };
+struct TickP2 { const float2* scratch; const float2* tw2; float* out; float* grp; int lg1, ntiles; };
 struct TickFS { IqSrc src; FrameGeom g; const float* window; const float2* tw; float* out; };
 struct TickZoom { const float* lines; const int32_t* zs; const int32_t* zc; float* zoomed; int32_t* index; const float* grp; int fft_size, data_width, gsz; float wf_min, wf_max; int pad; };
 struct TickEntry {
@@ -154,18 +154,18 @@ __device__ __forceinline__ void tick_fft_single(const KIdx bid, float* smem, con
     fft_single_body<LG, FPW>(bid, tw, tw + FftSingleLds<LG, FPW>::TW, src, g, q.window, q.tw, q.out);
 }
 template <int LG1, int C>
-__device__ __forceinline__ void tick_fft_p1(const KIdx bid, float* smem, const TickP1& q) {
+__device__ __forceinline__ void tick_fft_p1(const KIdx bid, const KIdx gdim, float* smem, const TickP1& q) {
     static_assert(((1 << LG1) / 16) * C == 256, "tick roles run in 256-thread workgroups");
     const IqSrc src = q.src;
     const FrameGeom g = q.g;
     float2* tw = reinterpret_cast<float2*>(smem);
-    fft_pass1_body<LG1, C>(bid, tw, tw + (1 << LG1) / 2, src, g, q.window, q.tw1, q.twn, q.scratch, q.lg2);
+    fft_pass1_body<LG1, C>(bid, tw, tw + (1 << LG1) / 2, src, g, q.window, q.tw1, q.twn, q.scratch, q.lg2, q.ntiles, gdim.x);
 }
 template <int LG2, int R>
-__device__ __forceinline__ void tick_fft_p2(const KIdx bid, float* smem, const TickP2& q) {
+__device__ __forceinline__ void tick_fft_p2(const KIdx bid, const KIdx gdim, float* smem, const TickP2& q) {
     static_assert(((1 << LG2) / 16) * R == 256, "tick roles run in 256-thread workgroups");
     float2* tw = reinterpret_cast<float2*>(smem);
-    fft_pass2_body<LG2, R>(bid, tw, tw + (1 << LG2) / 2, q.scratch, q.tw2, q.out, q.lg1, q.nframes, q.grp);
+    fft_pass2_body<LG2, R>(bid, tw, tw + (1 << LG2) / 2, q.scratch, q.tw2, q.out, q.lg1, q.ntiles, q.grp, gdim.x);
 }
 // (a zoom workgroup of the stand-alone kernel covers 256 / TP pixels of one line — a few microseconds of latency and next to no work, yet a
 // resident workgroup slot for that long: in a tick, where slots are what the roles compete for, one workgroup walks `groups` such pixel groups)
@@ -249,16 +249,16 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_FFT_S10: tick_fft_single<10, 4>(bid, smem, e.p.fs); break;
             case TR_FFT_S11: tick_fft_single<11, 2>(bid, smem, e.p.fs); break;
             case TR_FFT_S12: tick_fft_single<12, 1>(bid, smem, e.p.fs); break;
-            case TR_FFT_P1_5: tick_fft_p1<5, 128>(bid, smem, e.p.p1); break;
-            case TR_FFT_P1_6: tick_fft_p1<6, 64>(bid, smem, e.p.p1); break;
-            case TR_FFT_P1_7: tick_fft_p1<7, 32>(bid, smem, e.p.p1); break;
-            case TR_FFT_P1_8: tick_fft_p1<8, 16>(bid, smem, e.p.p1); break;
-            case TR_FFT_P1_9: tick_fft_p1<9, 8>(bid, smem, e.p.p1); break;
-            case TR_FFT_P1_10: tick_fft_p1<10, 4>(bid, smem, e.p.p1); break;
-            case TR_FFT_P2_7: tick_fft_p2<7, 32>(bid, smem, e.p.p2); break;
-            case TR_FFT_P2_8: tick_fft_p2<8, 16>(bid, smem, e.p.p2); break;
-            case TR_FFT_P2_9: tick_fft_p2<9, 8>(bid, smem, e.p.p2); break;
-            case TR_FFT_P2_10: tick_fft_p2<10, 4>(bid, smem, e.p.p2); break;
+            case TR_FFT_P1_5: tick_fft_p1<5, 128>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P1_6: tick_fft_p1<6, 64>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P1_7: tick_fft_p1<7, 32>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P1_8: tick_fft_p1<8, 16>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P1_9: tick_fft_p1<9, 8>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P1_10: tick_fft_p1<10, 4>(bid, gdim, smem, e.p.p1); break;
+            case TR_FFT_P2_7: tick_fft_p2<7, 32>(bid, gdim, smem, e.p.p2); break;
+            case TR_FFT_P2_8: tick_fft_p2<8, 16>(bid, gdim, smem, e.p.p2); break;
+            case TR_FFT_P2_9: tick_fft_p2<9, 8>(bid, gdim, smem, e.p.p2); break;
+            case TR_FFT_P2_10: tick_fft_p2<10, 4>(bid, gdim, smem, e.p.p2); break;
             case TR_FFT_P2ROW: {
                 float2* tw = reinterpret_cast<float2*>(smem);
                 fft_pass2row_body<12>(bid, tw, tw + (1 << 12) / 2, const_cast<float2*>(e.p.p2.scratch), e.p.p2.tw2, e.p.p2.lg1);

@@ -362,58 +362,94 @@ struct RotChunkIt {
         settle();
     }
 };
+// (round 3b: the first version of this kernel ran at 63 ns per sample — 150 cycles — instead of the chain's ~16: every consumer row began
+// with a load of its output pointer from the job table (a memory round trip each, 15 per chunk and wavefront), the chunk's samples were
+// loaded when the chunk began (another round trip, on the critical path of every chunk) and the chain compiled to seven scalar-operand vector
+// instructions + a compare-and-branch per sample.  Now: pointers in LDS, the next chunk's samples requested one chunk ahead, the chain as
+// two packed multiplies + one packed add per sample — the same IEEE operations on the same operands — in straight-line code per full chunk.)
+typedef float rot_v2f __attribute__((vector_size(8)));
+#define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + 64 * sizeof(float2*))
 __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds, int nb) {
-    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO
+    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO; then the 64 output pointers
+    float2** outp = reinterpret_cast<float2**>(ph_tile + (size_t)2 * 64 * 65);
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j0 = (int)blockIdx.x * 64;
     const int nrows = min(64, njobs - j0);
     const bool live = j0 + lane < njobs;
     const RotXJob job = jobs[live ? j0 + lane : njobs - 1];
-    float pr = job.state->x, pi = job.state->y;
-    const float dr = job.dr, di = job.di;
+    if (wv == 1) { outp[lane] = job.out; }
+    rot_v2f p = { job.state->x, job.state->y };
+    const rot_v2f d = { job.dr, job.di }, dyxn = { -job.di, job.dr };
     int since = 0;  // samples since the start of the reference block the producer is in
     RotChunkIt pit, cit;  // producer one chunk ahead of the consumers
     pit.init(bounds, nb);
     cit.init(bounds, nb);
+    auto step = [&](float2* slot) {
+        *slot = make_float2(p[0], p[1]);
+        const rot_v2f pxx = { p[0], p[0] }, pyy = { p[1], p[1] };
+        const rot_v2f a = pxx * d;      // (pr * dr, pr * di)                  = (a0, a1)
+        const rot_v2f b = pyy * dyxn;   // (pi * -di, pi * dr) = (-(pi * di), b1) = (-b0, b1): a product's sign does not touch its rounding
+        p = a + b;                      // (a0 - b0, a1 + b1): x + (-y) is x - y bit for bit
+    };
+    auto norm = [&]() {
+        float pr = p[0], pi = p[1];
+        rotator_norm(pr, pi);
+        p = rot_v2f{ pr, pi };
+    };
     auto produce = [&](int buf) {
-        float2* ph = ph_tile + (size_t)buf * 64 * 65;
+        float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane;
         const int cnt = pit.cnt();
-        for (int i = 0; i < cnt; i++) {
-            ph[i * 65 + lane] = make_float2(pr, pi);
-            const float a0 = pr * dr, a1 = pr * di, b0 = pi * di, b1 = pi * dr;
-            pr = a0 - b0;
-            pi = a1 + b1;
-            since++;
-            if ((since & 511) == 0) { rotator_norm(pr, pi); }
+        if (cnt == 64 && (since & 63) == 0) {  // a full chunk between two possible renormalisation points: straight-line code
+#pragma unroll
+            for (int i = 0; i < 64; i++) { step(ph + i * 65); }
+            since += 64;
+            if ((since & 511) == 0) { norm(); }
+        }
+        else {
+            for (int i = 0; i < cnt; i++) {
+                step(ph + i * 65);
+                since++;
+                if ((since & 511) == 0) { norm(); }
+            }
         }
         if (pit.ends_block()) {
-            if ((since & 511) != 0) { rotator_norm(pr, pi); }
+            if ((since & 511) != 0) { norm(); }
             since = 0;
         }
         pit.advance();
     };
-    if (wv == 0 && pit.valid()) { produce(0); }
+    auto fetch = [&](const RotChunkIt& it) -> float2 { return (it.valid() && lane < it.cnt()) ? src.cur[it.base + lane] : make_float2(0.0f, 0.0f); };
+    float2 x_next = make_float2(0.0f, 0.0f);
+    if (wv == 0) {
+        if (pit.valid()) { produce(0); }
+    }
+    else { x_next = fetch(cit); }
     __syncthreads();
     int buf = 0;
     while (cit.valid()) {
         if (wv == 0) {
             if (pit.valid()) { produce(buf ^ 1); }
+            cit.advance();
         }
         else {
-            const float2* ph = ph_tile + (size_t)buf * 64 * 65;
+            const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
             const int cnt = cit.cnt(), base = cit.base;
-            const float2 x = (lane < cnt) ? src.cur[base + lane] : make_float2(0.0f, 0.0f);
-            for (int r = wv - 1; r < nrows; r += 3) {
-                const float2 p = ph[lane * 65 + r];
-                float2* o = jobs[j0 + r].out;
-                if (lane < cnt) { o[base + lane] = make_float2((x.x * p.x) - (x.y * p.y), (x.x * p.y) + (x.y * p.x)); }
+            const float2 x = x_next;
+            cit.advance();
+            x_next = fetch(cit);  // in flight while this chunk's rows are written
+            if (lane < cnt) {
+#pragma unroll 4
+                for (int r = wv - 1; r < nrows; r += 3) {
+                    const float2 ph_r = ph[r];
+                    float2* o = outp[r];
+                    global_store_f32x2(o, base + lane, make_float2((x.x * ph_r.x) - (x.y * ph_r.y), (x.x * ph_r.y) + (x.y * ph_r.x)));
+                }
             }
         }
-        cit.advance();
         buf ^= 1;
         __syncthreads();
     }
-    if (wv == 0 && live) { *job.state = make_float2(pr, pi); }
+    if (wv == 0 && live) { *job.state = make_float2(p[0], p[1]); }
 }
 
 // SSB's second translation (ssb.h:78, a FrequencyXlator at the IF rate) in reference-rotator mode: one wavefront per VFO, every lane

@@ -374,16 +374,13 @@ public:
             drainControl();
             if (_pipelining && pipelineEligible()) {
                 if (!pipeOn && enterPipelined() < 0) { return -1; }
-                // the hand-over of the block delivered last has had a whole block's time on the helpers: join it (the helpers take one batch at a time)
-                // (a hand-over that failed means its stream was stopped under it — that block is gone, like a block the reference has in flight at a
-                // stop; whether THIS worker ends is decided by read() alone)
-                (void)finishDelivery();
-                SDRPP_PIPE_TICK(1)
-                // the block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
-                // 10 MS/s), so the helpers and this thread copy a quarter each — and is fetched from there by the launch
-                // (round 3b: the copy runs on the helpers WHILE this thread plans the block inside sdrpp_push_staged_when — the job tables do
-                // not depend on the samples — and the library holds the block's launch back until the last part has landed; the helper that
-                // finishes last frees the stream buffer, so the source is not held up by the planning either)
+                // The block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
+                // 10 MS/s) — and is fetched from there by the launch.  Round 3b, in the order that frees the source soonest: the copy starts at
+                // once on threads of its own (`stagers`), the one that finishes last frees the stream buffer; meanwhile this thread joins the
+                // hand-over of the block delivered last (the helpers have had a block's time for it) and plans the new block inside
+                // sdrpp_push_staged_when — the job tables do not depend on the samples — and the library holds the block's launch back until the
+                // last part has landed.  (Per block the reference's stream costs two futex wake-ups, source -> worker -> source, ~10 us each:
+                // the time from read() to flush() is the one part of that cycle this side controls; it went from ~19 us to the copy's ~7.)
                 float* slot = nullptr;
                 int prc = sdrpp_push_stage(ctx, count, &slot);
                 if (!prc) {
@@ -404,12 +401,19 @@ public:
                             stagePending.fetch_sub(1, std::memory_order_release);
                         });
                     }
-                    helpers.begin(std::move(cj));
+                    stagers.begin(std::move(cj));
+                    // (a hand-over that failed means its stream was stopped under it — that block is gone, like a block the reference has in flight
+                    // at a stop; whether THIS worker ends is decided by read() alone)
+                    (void)finishDelivery();
+                    SDRPP_PIPE_TICK(1)
                     static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the pending word is handed to the C ABI as a plain uint32_t");
                     prc = sdrpp_push_staged_when(ctx, count, reinterpret_cast<const volatile uint32_t*>(&stagePending));
-                    helpers.finish();  // (joins the copy on a failed plan, which returns without waiting; a no-op otherwise)
+                    stagers.finish();  // (joins the copy on a failed plan, which returns without waiting; a no-op otherwise)
                 }
-                else { _in->flush(); }
+                else {
+                    (void)finishDelivery();
+                    _in->flush();
+                }
                 if (prc) {
                     fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] push failed: %s\n", sdrpp_last_error(ctx));
                     return -1;
@@ -506,7 +510,8 @@ protected:
     // frame_buffer.h:105-124)
     void doStart() override {
         stopFrameWorker = false;
-        helpers.start(3);
+        helpers.start(6);  // hand-overs: 32 stream swaps per block are 32 futex wake-ups (~3 us each for the waker)
+        stagers.start(3);
         workerThread = std::thread(&IQFrontEnd::workerLoop, this);
         frameThread = std::thread(&IQFrontEnd::frameWorker, this);
     }
@@ -521,6 +526,7 @@ protected:
         if (workerThread.joinable()) { workerThread.join(); }
         if (frameThread.joinable()) { frameThread.join(); }
         helpers.stop();
+        stagers.stop();
         for (auto& in : inputs) { in->clearReadStop(); }
         for (auto& out : outputs) { out->clearWriteStop(); }
     }
@@ -627,7 +633,7 @@ private:
                 }
             }
         }
-        const int groups = 3;
+        const int groups = 6;  // (one per helper)
         for (int g = 0; g < groups && !order.empty(); g++) {
             jobs.emplace_back([this, g, groups, &order, &r]() {
                 std::atomic<bool>& failed = deliveryFailed;
@@ -760,7 +766,7 @@ private:
             std::vector<std::pair<RxVFO*, int>> order;
             k = 0;
             for (auto& kv : vfos) { order.emplace_back(kv.second, k++); }
-            const int groups = 3;
+            const int groups = 6;
             for (int g = 0; g < groups; g++) {
                 jobs.emplace_back([this, g, groups, order, &failed]() {
                     for (size_t q = (size_t)g; q < order.size(); q += (size_t)groups) {
@@ -1063,7 +1069,7 @@ private:
             begin(std::move(js));
             finish();
         }
-    } helpers;
+    } helpers, stagers;  // (stagers: the staging copy of the pipelined bypass path, which must not queue behind a hand-over)
     FFTWindow _fftWindow = NUTTALL;
     float* (*_acquire)(void*) = nullptr;
     void (*_release)(void*) = nullptr;

@@ -17,6 +17,10 @@ static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] =
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
+static inline int opaque(int v) {
+    asm volatile("" : "+r"(v));
+    return v;
+}
 #define TICK_MARK(k) do { } while (0)
 static inline void wave_stores_done() {}
 static inline int wave_upper_bound(const int* ends, int n, int b, int* prev_end) {

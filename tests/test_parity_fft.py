@@ -54,6 +54,49 @@ def test_every_fft_size_bit_exact(backend, lg):
     ctx.close()
 
 
+@pytest.mark.parametrize("lg", [14, 16])
+def test_fft_workgroups_walk_their_tiles(backend, lg, monkeypatch):
+    """Pass 1 / pass 2 workgroups that walk several tiles (tile, tile + grid, ...) with the next tile's loads in flight: the grids are
+    forced down to the tiles of ONE frame (a workgroup then walks the same columns / rows of every frame of the push: one to four tiles,
+    frames with nz < N, frames that start in the history of the previous push), ordinary pass and pipelined mode — every line bit-exact."""
+    from sdrplusplus_amd import capi
+
+    monkeypatch.setenv("SDRPP_GPU_FFT_P1_GRID", "4")
+    monkeypatch.setenv("SDRPP_GPU_FFT_P2_GRID", "4")
+    monkeypatch.setenv("SDRPP_GPU_FFT_TICK_GRID", "4")
+    N = 1 << lg
+    nz, skip = N - 1000, 37
+    w = capi.design_fft_window(2, nz)
+    pushes = [N + 11, 3 * N + 901, 2 * N]
+    x = _signal(sum(pushes), lg)
+    sp = S.OracleSpectrum(N, nz, skip, w)
+    view = (N // 8, N // 2, 733, -110.0, -15.0)
+    for pipelined in (False, True):
+        ctx = _ctx(max(pushes))
+        ctx.fft_configure(N, nz, skip, w)
+        ctx.fft_set_view(*view)
+        if pipelined:
+            ctx.set_pipelined(True, 2 | 4)
+        sp = S.OracleSpectrum(N, nz, skip, w)
+        pos = 0
+        for t, n in enumerate(pushes, start=1):
+            blk = x[pos:pos + n]
+            pos += n
+            ctx.push(blk)
+            ol = sp.push(blk)
+            if pipelined:
+                got = ctx.result_wait(t)
+                raw, zo, ix = got["raw"], got["zoomed"], got["index"]
+                ctx.result_release(t)
+            else:
+                raw, zo, ix = ctx.fft_read()
+            assert raw.shape == ol.shape and len(ol) >= 1
+            assert np.array_equal(raw, ol)
+            oz, oi = _oracle_view(ol, *view)
+            assert np.array_equal(zo, oz) and np.array_equal(ix, oi)
+        ctx.close()
+
+
 @pytest.mark.parametrize("window_kind", [0, 1, 2])
 def test_reference_default_framing_streaming(backend, window_kind):
     """fftRate framing (keep nz, skip the rest) across pushes of awkward sizes, incl. empty and 1-sample pushes."""
