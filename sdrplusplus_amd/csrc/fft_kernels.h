@@ -351,12 +351,9 @@ __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float
             const bool in = ((n1 << lg2) + n2) < g.nz;
             r[j] = in ? make_float2(r[j].x * wv[j], r[j].y * wv[j]) : make_float2(0.0f, 0.0f);
         }
-        sched_fence();
         R0::compute(r, t, tw);
-        sched_fence();
         IdxCols idx{ C, c };
         fft_rounds_after_first<LG1, 4, IdxCols>(r, t, tw, data, idx);
-        sched_fence();
         float2* dst = scratch + ((size_t)frame << (LG1 + lg2));
 #pragma unroll
         for (int i = 0; i < RL::NG; i++) {
@@ -441,10 +438,7 @@ __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float
     auto transform = [&](float2 (&r)[16], int tile) {
         const int t = opaque(t_), row = opaque(row_), tid = opaque((int)threadIdx.x);  // (see fft_pass1_body)
         const int frame = tile / tiles, r0 = (tile % tiles) * R;
-        sched_fence();  // (phase boundaries are scheduling boundaries: left to itself the scheduler interleaves the 16 dB polynomials with everything
-                        // around them and needs 200 registers for a 104-register live set)
         R0::compute(r, t, tw);
-        sched_fence();
         // (fft_rounds_after_first opens with a barrier: the previous tile's dB values have been read out of `data` before it is rewritten)
         IdxRowPad idx{ row * PITCH };
         fft_rounds_after_first<LG2, 4, IdxRowPad>(r, t, tw, data, idx);
@@ -457,7 +451,6 @@ __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float
             for (int j = 0; j < RL::GS; j++) {
                 const int k2 = RL::pos(t, i, j);
                 tile_db[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
-                if ((j & 3) == 3) { sched_fence(); }
             }
         }
         __syncthreads();

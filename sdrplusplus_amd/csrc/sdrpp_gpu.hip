@@ -285,10 +285,13 @@ struct sdrpp_ctx {
     bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
     // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
     // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
-    int fft_p1_grid = getenv("SDRPP_GPU_FFT_P1_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P1_GRID")) : 512;   // workgroups of a pass-1 / pass-2 launch (fft_walk_grid; 0: one tile per workgroup)
-    int fft_p2_grid = getenv("SDRPP_GPU_FFT_P2_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P2_GRID")) : 1024;
-    int fft_tick_grid = getenv("SDRPP_GPU_FFT_TICK_GRID") ? atoi(getenv("SDRPP_GPU_FFT_TICK_GRID")) : 128;  // ... of a pass-1 / pass-2 role inside a tick (a shared GPU)
-    bool fft_p1_c16 = getenv("SDRPP_GPU_FFT_P1_C16") != nullptr;  // measurement switch: 16 instead of 32 columns per pass-1 workgroup of a 65536-point transform
+    // workgroups of a pass-1 / pass-2 launch (fft_walk_grid; 0: one tile per workgroup).  Measured on 65536-point frames, 2^24 samples per pass
+    // (profiles/r03o_fft16_sweeps.log): pass 1 with 16 columns per workgroup 0.069 ms at one tile each, 0.064 walking from 1024 workgroups (four
+    // per CU), 0.106 from 512; pass 2 0.0565 at one tile each, 0.057-0.061 walking (its tiles are contiguous 32 KB reads: nothing to hide)
+    int fft_p1_grid = getenv("SDRPP_GPU_FFT_P1_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P1_GRID")) : 1024;
+    int fft_p2_grid = getenv("SDRPP_GPU_FFT_P2_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P2_GRID")) : 0;
+    int fft_tick_grid = getenv("SDRPP_GPU_FFT_TICK_GRID") ? atoi(getenv("SDRPP_GPU_FFT_TICK_GRID")) : 0;  // ... of a pass-1 / pass-2 role inside a tick (a shared GPU: 18.4 / 16.2 / 18.8 / 18.5 GS/s at 0 / 64 / 128 / 256; cfg 2: 61.7 / - / 57.0)
+    bool fft_p1_c32 = getenv("SDRPP_GPU_FFT_P1_C32") != nullptr;  // measurement switch: 32 instead of 16 columns per pass-1 workgroup of a 65536-point transform
     int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
     int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
     int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
@@ -985,8 +988,11 @@ int run_fft_chunk(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* out
         case 6: launch_p1<6, 64>(c, src, g, lg2); break;
         case 7: launch_p1<7, 32>(c, src, g, lg2); break;
         case 8:
-            if (c->fft_p1_c16) { launch_p1<8, 16>(c, src, g, lg2); }
-            else { launch_p1<8, 32>(c, src, g, lg2); }  // 256-byte row segments; measured 7 % faster than <8, 16> (one tile per workgroup)
+            // 16 columns (128-byte row segments, 256 work-items, 34 KB of LDS: four workgroups per CU) against 32 (256-byte segments, 512
+            // work-items, 66 KB: two): 0.064-0.069 ms against 0.098-0.106 per 2^24 samples (round 2 had measured the wider one 7 % ahead: before
+            // the window values left the load path)
+            if (c->fft_p1_c32) { launch_p1<8, 32>(c, src, g, lg2); }
+            else { launch_p1<8, 16>(c, src, g, lg2); }
             break;
         case 9: launch_p1<9, 8>(c, src, g, lg2); break;
         case 10: launch_p1<10, 4>(c, src, g, lg2); break;

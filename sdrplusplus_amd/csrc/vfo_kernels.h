@@ -418,36 +418,53 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
         }
         pit.advance();
     };
+    // the chunks' samples are requested SDRPP_ROTX4_AHEAD chunks ahead (a chunk lasts ~0.4 us at the chain's pace, a first touch of the input in
+    // HBM ~2 us: one chunk ahead left the kernel waiting on that latency, 30 ns per sample)
+    constexpr int AHEAD = 6;
     auto fetch = [&](const RotChunkIt& it) -> float2 { return (it.valid() && lane < it.cnt()) ? src.cur[it.base + lane] : make_float2(0.0f, 0.0f); };
-    float2 x_next = make_float2(0.0f, 0.0f);
+    float2 xq[AHEAD];
+    RotChunkIt fit = cit;
     if (wv == 0) {
         if (pit.valid()) { produce(0); }
     }
-    else { x_next = fetch(cit); }
+    else {
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            xq[k] = fetch(fit);
+            if (fit.valid()) { fit.advance(); }
+        }
+    }
     __syncthreads();
     int buf = 0;
     while (cit.valid()) {
-        if (wv == 0) {
-            if (pit.valid()) { produce(buf ^ 1); }
-            cit.advance();
-        }
-        else {
-            const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
-            const int cnt = cit.cnt(), base = cit.base;
-            const float2 x = x_next;
-            cit.advance();
-            x_next = fetch(cit);  // in flight while this chunk's rows are written
-            if (lane < cnt) {
+        // (unrolled over the ring of requested chunks: slot u is consumed and refilled in place — shifting the ring would make every move wait
+        // for the request just issued)
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
+            if (!cit.valid()) { break; }  // (uniform over the workgroup)
+            if (wv == 0) {
+                if (pit.valid()) { produce(buf ^ 1); }
+                cit.advance();
+            }
+            else {
+                const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
+                const int cnt = cit.cnt(), base = cit.base;
+                const float2 x = xq[u];
+                cit.advance();
+                xq[u] = fetch(fit);
+                if (fit.valid()) { fit.advance(); }
+                if (lane < cnt) {
 #pragma unroll 4
-                for (int r = wv - 1; r < nrows; r += 3) {
-                    const float2 ph_r = ph[r];
-                    float2* o = outp[r];
-                    global_store_f32x2(o, base + lane, make_float2((x.x * ph_r.x) - (x.y * ph_r.y), (x.x * ph_r.y) + (x.y * ph_r.x)));
+                    for (int r = wv - 1; r < nrows; r += 3) {
+                        const float2 ph_r = ph[r];
+                        float2* o = outp[r];
+                        global_store_f32x2(o, base + lane, make_float2((x.x * ph_r.x) - (x.y * ph_r.y), (x.x * ph_r.y) + (x.y * ph_r.x)));
+                    }
                 }
             }
+            buf ^= 1;
+            __syncthreads();
         }
-        buf ^= 1;
-        __syncthreads();
     }
     if (wv == 0 && live) { *job.state = make_float2(p[0], p[1]); }
 }
