@@ -196,7 +196,8 @@ int sdrpp_vfo_read(sdrpp_ctx* ctx, int id, float* dst_host, int max);
 /* The same for many VFOs with ONE device-to-host copy (a host block that delivers every VFO stream after each block would otherwise
  * pay one small copy + synchronisation per VFO).  which[i]: 0 = what sdrpp_vfo_read returns, 1 = the complex IF, 2 = the AF chain
  * output (NULL: all 0).  The blocks are packed back to back into dst_host (2 floats per sample); offsets[i] / counts[i] (in samples)
- * locate VFO ids[i]'s block.  Returns the total number of samples, SDRPP_ERR_INVALID if max_samples is too small. */
+ * locate VFO ids[i]'s block.  Returns the total number of samples, SDRPP_ERR_INVALID if max_samples is too small.  dst_host = NULL is
+ * a size query: offsets / counts are filled and the total returned, nothing is copied. */
 int sdrpp_vfo_read_many(sdrpp_ctx* ctx, int n, const int* ids, const int* which, float* dst_host, int64_t max_samples, int64_t* offsets, int* counts);
 /* Device pointers: demodulated audio (or IF in RAW mode) and the complex IF stream (RxVFO::out) of the last push. */
 int sdrpp_vfo_device_buffers(sdrpp_ctx* ctx, int id, const float** out, int* n_out, const float** if_out, int* n_if);

@@ -432,10 +432,10 @@ class Context:
         n = len(vids)
         ids = (C.c_int * max(n, 1))(*[int(v) for v in vids])
         wh = (C.c_int * max(n, 1))(*[int(w) for w in which]) if which is not None else None
-        total = sum(self.vfo_out_count(v) for v in vids) if which is None else self.max_push * n
-        buf = np.empty((max(total, 1), 2), dtype=np.float32)
         offs = (C.c_int64 * max(n, 1))()
         cnts = (C.c_int * max(n, 1))()
+        total = self._chk(self.L.sdrpp_vfo_read_many(self.h, n, ids, wh, None, 0, offs, cnts))  # size query: the buffer follows the real counts
+        buf = np.empty((max(total, 1), 2), dtype=np.float32)
         self._chk(self.L.sdrpp_vfo_read_many(self.h, n, ids, wh, buf.ctypes.data_as(c_float_p), len(buf), offs, cnts))
         return [buf[offs[i]:offs[i] + cnts[i]] for i in range(n)]
 

@@ -117,17 +117,17 @@ __device__ __forceinline__ int wave_upper_bound(const int* ends, int n, int b, i
 // ordering there is to it; a waiting wavefront sleeps 64 cycles between looks so that it does not take issue slots from the others.
 __device__ __forceinline__ void lds_flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // A wait that cannot be satisfied (a bug in the tile bookkeeping) must not hang the device: after ~2^20 looks (a quarter of a second) the
-// wavefront gives up, counts the event in g_flag_timeouts — the host turns that into an error at the next sdrpp_sync — and goes on.
+// wavefront gives up, counts the event in its context's page-locked word (PipeJob::timeouts) — the host turns that into an error at the next
+// sdrpp_sync or host-synchronising read of that context — and goes on.
 #ifndef SDRPP_FLAG_SLEEP
 #define SDRPP_FLAG_SLEEP 8  // 512 cycles between looks (64 -> 512: 2 % on the pipelined launch: every look is a vector compare and an LDS read taken from the matrix loops)
 #endif
-__device__ int g_flag_timeouts;
-__device__ __forceinline__ void lds_flag_wait_ge(int* f, int need) {
+__device__ __forceinline__ void lds_flag_wait_ge(int* f, int need, int* timeouts) {
     int looks = 0;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
         __builtin_amdgcn_s_sleep(SDRPP_FLAG_SLEEP);
         if (++looks > (1 << 20)) {
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&g_flag_timeouts, 1); }
+            if ((threadIdx.x & 63) == 0 && timeouts) { __hip_atomic_fetch_add(timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             break;
         }
     }

@@ -25,6 +25,7 @@ namespace sdrpp_k {
 
 struct PipeJob {
     ToepJob st[4];      // decimator, resampler, channel filter, discriminator + audio low-pass: what the separate launches would get
+    int* timeouts;      // the context's page-locked count of flag waits that gave up (lds_flag_wait_ge)
     int tl_off[4];      // LDS offsets (floats) of the four tap tables
     int win_off;        // window of stage 0 (register-staged from HBM)
     int ring_off[3];    // rings feeding stages 1 and 2 (complex: 2 floats per sample), and the FIFO of IF PHASES between stage 2 and stage 3 (real)
@@ -156,7 +157,7 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
     auto convert_tile = [&]() {
         if constexpr (ROLE == 3) {
             const bool avail = dpos < pe * omtc;  // past the producer's last macro tile: zeros
-            if (avail) { lds_flag_wait_ge(prod_in, dpos + omtc); }
+            if (avail) { lds_flag_wait_ge(prod_in, dpos + omtc, Jp->timeouts); }
             const bool plain = avail && dpos + omtc <= job.nout && dslot + omtc <= Rin && dslot >= hin;
             // lane l takes positions dpos + l + 64 i; the phase in front of position dpos is the last one of the tile before
             constexpr int NI = 4 * G;  // omtc <= 16 * G * 15 samples
@@ -216,7 +217,7 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
         if constexpr (ROLE == 3) {
             while (dpos < job.base0 + m * W + span) { convert_tile(); }
         }
-        else if constexpr (ROLE > 0) { lds_flag_wait_ge(prod_in, job.base0 + m * W + span); }
+        else if constexpr (ROLE > 0) { lds_flag_wait_ge(prod_in, job.base0 + m * W + span, Jp->timeouts); }
         wave_sync();
         wave_prio_low();
 #ifdef SDRPP_TOEP_PROF
@@ -366,7 +367,7 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
                     }
                 }
             }
-            lds_flag_wait_ge(cons_out, obase + omt - Rout);
+            lds_flag_wait_ge(cons_out, obase + omt - Rout, Jp->timeouts);
 #ifdef SDRPP_TOEP_PROF
             sched_fence();
             tq4 = TOEP_TICK();

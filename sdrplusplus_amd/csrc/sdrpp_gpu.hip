@@ -259,7 +259,8 @@ struct sdrpp_ctx {
     int ref_block = 0;             // 0: one push = one reference block
     int nco_exact = 0;             // 1: the reference's float rotator recursion instead of the closed-form NCO
     int pipe_on = 1;               // FM back ends as one pipelined launch where that pays (sdrpp_set_backend_pipeline)
-    bool pipe_launched = false;    // since the last sdrpp_sync (which then looks at the kernels' timeout counter)
+    bool pipe_launched = false;    // since the last host synchronisation that looked at the kernels' timeout counter (pipe_timeouts_check)
+    int timeouts_seen = 0;         // value of the counter (h_tick_flag[8]) at that look
     std::vector<int> vfo_bounds;   // reference-block ends (cumulative sample counts) of the current push at the VFO bank's input
 
     // VFOs
@@ -1565,6 +1566,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             pj.st[1] = toep_job(v.tp_poly, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
             pj.st[2] = toep_job(v.tp_chan, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
             pj.st[3] = toep_job(v.tp_audio, 0, StreamIn{}, nullptr, 0, 0, 0.0f);
+            pj.timeouts = c->hd_tick_flag ? (int*)(c->hd_tick_flag + 8) : nullptr;
             piped_be = pipe_layout(pj, &pj_lds);
         }
         for (int s = first_sep; s < v.d.n_stages; s++) {
@@ -3150,6 +3152,7 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         return SDRPP_ERR_NOMEM;
     }
     *c->h_tick_flag = 0;
+    c->h_tick_flag[8] = 0;  // flag waits that gave up (PipeJob::timeouts)
     *out = c;
     return SDRPP_OK;
 }
@@ -3396,6 +3399,20 @@ int sdrpp_destroy(sdrpp_ctx* c) {
 
 const char* sdrpp_last_error(const sdrpp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// A pipelined back-end launch whose wavefronts gave up waiting for each other (never seen; a hang would be worse) counted that in THIS context's
+// page-locked word.  Called wherever the host has just synchronised with the stream and is about to hand out results.
+static int pipe_timeouts_check(sdrpp_ctx* c) {
+    if (!c->pipe_launched || !c->h_tick_flag) { return SDRPP_OK; }
+    c->pipe_launched = false;
+    const int n = *(const volatile int*)(c->h_tick_flag + 8);
+    if (n != c->timeouts_seen) {
+        const int d = n - c->timeouts_seen;
+        c->timeouts_seen = n;
+        return fail(c, SDRPP_ERR_HIP, "pipelined back end: %d wavefront waits timed out (results of the last pushes are invalid)", d);
+    }
+    return SDRPP_OK;
+}
+
 int sdrpp_set_stream(sdrpp_ctx* c, void* s) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
@@ -3411,15 +3428,7 @@ int sdrpp_sync(sdrpp_ctx* c) {
     if (!c) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->pipe_launched) {  // a pipelined launch whose wavefronts gave up waiting for each other (never seen; a hang would be worse)
-        c->pipe_launched = false;
-        int n = 0;
-        if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(sdrpp_k::g_flag_timeouts), sizeof(int)) == hipSuccess && n != 0) {
-            const int zero = 0;
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_flag_timeouts), &zero, sizeof(int));
-            return fail(c, SDRPP_ERR_HIP, "pipelined back end: %d wavefront waits timed out (results of the last pushes are invalid)", n);
-        }
-    }
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     return SDRPP_OK;
 }
 
@@ -4077,6 +4086,7 @@ int sdrpp_vfo_af_read(sdrpp_ctx* c, int id, float* dst, int max) {
     if (!s) { return fail(c, SDRPP_ERR_INVALID, "VFO %d has no AF chain", id); }
     const int n = std::min(max, s->n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     if (n > 0) { HIPCHK(c, hipMemcpy(dst, s->data, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
     return n;
 }
@@ -4132,6 +4142,7 @@ int sdrpp_vfo_read_pcm(sdrpp_ctx* c, int id, int which, int pcm_type, float scal
     if (pcm_type == 1) { hipLaunchKernelGGL(pack_convert_kernel<int16_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, scale, nv, (int16_t*)c->d_pack); }
     else { hipLaunchKernelGGL(pack_convert_kernel<int8_t>, grid, dim3(256), 0, c->stream, (const float*)s->data, scale, nv, (int8_t*)c->d_pack); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     HIPCHK(c, hipMemcpy(dst_host, c->d_pack, (size_t)nv * esz, hipMemcpyDeviceToHost));
     return n;
 }
@@ -4153,6 +4164,7 @@ int sdrpp_preproc_read_pcm(sdrpp_ctx* c, int pcm_type, float scale, void* dst_ho
     if (pcm_type == 1) { hipLaunchKernelGGL(pack_convert_kernel<int16_t>, grid, dim3(256), 0, c->stream, (const float*)c->pre.last, scale, nv, (int16_t*)c->d_pack); }
     else { hipLaunchKernelGGL(pack_convert_kernel<int8_t>, grid, dim3(256), 0, c->stream, (const float*)c->pre.last, scale, nv, (int8_t*)c->d_pack); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     HIPCHK(c, hipMemcpy(dst_host, c->d_pack, (size_t)nv * esz, hipMemcpyDeviceToHost));
     return n;
 }
@@ -4301,13 +4313,14 @@ int sdrpp_vfo_read(sdrpp_ctx* c, int id, float* dst, int max) {
     Stream* s = out_stream(*it->second);
     const int n = std::min(max, s->n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     if (n > 0) { HIPCHK(c, hipMemcpy(dst, s->data, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost)); }
     return n;
 }
 
 int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, float* dst_host, int64_t max_samples, int64_t* offsets, int* counts) {
     DeviceScope dev_scope_(c);
-    if (!c || n < 0 || (n > 0 && (!ids || !dst_host || !offsets || !counts)) || max_samples < 0) { return SDRPP_ERR_INVALID; }
+    if (!c || n < 0 || (n > 0 && (!ids || !offsets || !counts)) || max_samples < 0) { return SDRPP_ERR_INVALID; }
     FLUSH_PENDING(c);
     std::vector<GatherJob> jobs;
     int64_t total = 0;
@@ -4323,6 +4336,7 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
         mx = std::max(mx, s->n);
         total += s->n;
     }
+    if (!dst_host) { return (int)std::min<int64_t>(total, 0x7fffffff); }  // size query: offsets / counts filled, nothing copied
     if (total > max_samples) { return fail(c, SDRPP_ERR_INVALID, "the outputs need room for %lld samples", (long long)total); }
     if (total == 0) { return 0; }
     if ((size_t)total > c->gather_cap) {
@@ -4339,6 +4353,7 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
         hipLaunchKernelGGL(gather_inline_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)jobs.size()), dim3(256), 0, c->stream, ga, c->d_gather);
         HIPCHK(c, hipMemcpyAsync(dst_host, c->d_gather, (size_t)total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rc = pipe_timeouts_check(c)) { return rc; }
         return (int)std::min<int64_t>(total, 0x7fffffff);
     }
     if ((int)jobs.size() > c->gather_jobs_cap) {
@@ -4353,6 +4368,7 @@ int sdrpp_vfo_read_many(sdrpp_ctx* c, int n, const int* ids, const int* which, f
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::max(1, std::min((mx + 255) / 256, 64)), (unsigned)jobs.size()), dim3(256), 0, c->stream, (const GatherJob*)c->d_gather_jobs, c->d_gather);
     HIPCHK(c, hipMemcpyAsync(dst_host, c->d_gather, (size_t)total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // also keeps `jobs` alive until the upload has been consumed
+    if (int rc = pipe_timeouts_check(c)) { return rc; }
     return (int)std::min<int64_t>(total, 0x7fffffff);
 }
 
@@ -4514,7 +4530,11 @@ int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     if (rc) { return rc; }
     float* land = c->iq_land[c->land_cur] + 2 * c->pending;
     HIPCHK(c, hipMemcpyAsync(land, iq_host, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    // from here on the copy may be reading the caller's buffer: no return before the host has waited for it
+    if (hipEventRecord(c->ev_copy, c->copy_stream) != hipSuccess) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        return fail(c, SDRPP_ERR_HIP, "hipEventRecord after the landing copy");
+    }
     if (c->deferred) {
         HIPCHK(c, hipEventSynchronize(c->ev_copy));  // the caller's buffer is free again; the kernels of the previous pass keep running meanwhile
         c->pending += count;
@@ -4523,7 +4543,10 @@ int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     }
     // the pass is enqueued behind the copy ON THE DEVICE while the copy runs (planning + launches take longer than the copy of a
     // reference-sized block), and only then does the host wait for the copy: the caller's buffer is free on return, as before
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    if (hipStreamWaitEvent(c->stream, c->ev_copy, 0) != hipSuccess) {
+        (void)hipEventSynchronize(c->ev_copy);
+        return fail(c, SDRPP_ERR_HIP, "hipStreamWaitEvent on the landing copy");
+    }
     rc = landing_process(c, count, nullptr);
     HIPCHK(c, hipEventSynchronize(c->ev_copy));
     return rc;

@@ -30,8 +30,7 @@ static inline int wave_upper_bound(const int* ends, int n, int b, int* prev_end)
     return idx;
 }
 static inline void lds_flag_set(int* f, int v) { *(volatile int*)f = v; }
-static int g_flag_timeouts = 0;
-static inline void lds_flag_wait_ge(int* f, int need) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile
+static inline void lds_flag_wait_ge(int* f, int need, int* /*timeouts*/) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile
 static inline void wave_prio_high() {}
 static inline void wave_prio_low() {}
 static inline float wave_bcast(float v, int src) { return hipemu::wave_exchange(v, 0.0f)[src * 2]; }
