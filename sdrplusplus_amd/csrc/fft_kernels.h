@@ -187,6 +187,19 @@ struct FftLast {
 };
 
 // ---- log-power (VOLK power_spectrum generic; log2 per the shared specification) -------------------------------------------
+__device__ __forceinline__ float spec_log2_poly(float f, float e) {
+    float p = -0.107497893f;
+    p = fmaf(p, f, 0.184760332f);
+    p = fmaf(p, f, -0.191388384f);
+    p = fmaf(p, f, 0.204857647f);
+    p = fmaf(p, f, -0.239608124f);
+    p = fmaf(p, f, 0.288552552f);
+    p = fmaf(p, f, -0.360696554f);
+    p = fmaf(p, f, 0.480898529f);
+    p = fmaf(p, f, -0.721347332f);
+    p = fmaf(p, f, 1.44269502f);
+    return fmaf(f, p, e);
+}
 __device__ __forceinline__ float spec_log2f_non_ieee(float x) {
     // log2 of a non-negative float: subnormals rescaled by 2^23; mantissa folded into [sqrt(1/2), sqrt(2)); degree-9
     // polynomial in f = m - 1 evaluated with fmaf (Horner); result = fmaf(f, P, e).  An infinite result becomes +-127
@@ -207,24 +220,34 @@ __device__ __forceinline__ float spec_log2f_non_ieee(float x) {
         m = m * 0.5f;
         e += 1;
     }
-    const float f = m - 1.0f;
-    float p = -0.107497893f;
-    p = fmaf(p, f, 0.184760332f);
-    p = fmaf(p, f, -0.191388384f);
-    p = fmaf(p, f, 0.204857647f);
-    p = fmaf(p, f, -0.239608124f);
-    p = fmaf(p, f, 0.288552552f);
-    p = fmaf(p, f, -0.360696554f);
-    p = fmaf(p, f, 0.480898529f);
-    p = fmaf(p, f, -0.721347332f);
-    p = fmaf(p, f, 1.44269502f);
-    return fmaf(f, p, (float)e);
+    return spec_log2_poly(m - 1.0f, (float)e);
 }
-__device__ __forceinline__ float power_db(const float2 X, const float inv_norm) {
+// The same function for a POSITIVE NORMAL x (bit pattern in [0x00800000, 0x7f800000)) without a compare or a select: with m in [1, 2) the
+// test m >= 1.41421354f (0x3fb504f3) is a test of the mantissa field, halving m is exact (the exponent field drops from 127 to 126) and both
+// are integer arithmetic: adj = (mantissa + (0x800000 - 0x3504f3)) >> 23.  Bit for bit the value spec_log2f_non_ieee returns.
+// `abnormal` collects (max) the distance of the bit pattern from that range: >= 0x7f000000 means zero / subnormal / inf / NaN / negative,
+// and the caller then evaluates the general function instead (once for all its values: it practically never happens).
+__device__ __forceinline__ float spec_log2f_normal(float x, unsigned& abnormal) {
+    const unsigned u = __float_as_uint(x);
+    const unsigned d = u - 0x00800000u;
+    abnormal = d > abnormal ? d : abnormal;
+    const unsigned mant = u & 0x007fffffu;
+    const unsigned adj = (mant + 0x004afb0du) >> 23;
+    const float m = __uint_as_float((mant | 0x3f800000u) - (adj << 23));
+    const int e = (int)(u >> 23) - 127 + (int)adj;
+    return spec_log2_poly(m - 1.0f, (float)e);
+}
+#define SDRPP_LOG2_ABNORMAL 0x7f000000u
+__device__ __forceinline__ float power_of(const float2 X, const float inv_norm) {
     const float re = X.x * inv_norm;
     const float im = X.y * inv_norm;
-    const float p = (re * re) + (im * im);
-    return 3.01029995663981209120f * spec_log2f_non_ieee(p);
+    return (re * re) + (im * im);
+}
+__device__ __forceinline__ float power_db(const float2 X, const float inv_norm) {
+    return 3.01029995663981209120f * spec_log2f_non_ieee(power_of(X, inv_norm));
+}
+__device__ __forceinline__ float power_db_normal(const float2 X, const float inv_norm, unsigned& abnormal) {
+    return 3.01029995663981209120f * spec_log2f_normal(power_of(X, inv_norm), abnormal);
 }
 
 struct FrameGeom {
@@ -280,10 +303,18 @@ __device__ __forceinline__ void fft_single_body(const KIdx bid, float2* tw, floa
     if (live) {
         const float inv = 1.0f / (float)L;
         float* dst = out_db + (size_t)frame * L;
+        unsigned abn = 0;
 #pragma unroll
         for (int i = 0; i < RL::NG; i++) {
 #pragma unroll
-            for (int j = 0; j < RL::GS; j++) { dst[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+            for (int j = 0; j < RL::GS; j++) { dst[RL::pos(t, i, j)] = power_db_normal(r[i * RL::GS + j], inv, abn); }
+        }
+        if (abn >= SDRPP_LOG2_ABNORMAL) {  // a zero / subnormal / non-finite power among this work-item's 16: the general function, all again
+#pragma unroll
+            for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+                for (int j = 0; j < RL::GS; j++) { dst[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+            }
         }
     }
 }
@@ -319,15 +350,30 @@ __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float
     for (int e = threadIdx.x; e < L1 / 2; e += TPF * C) { tw[e] = tw1_g[e]; }
     using R0 = FftRound<LG1, 0, 4>;
     using RL = typename FftLast<LG1>::Round;
-    // raw samples of a tile (branch-free: the 16 loads of a work-item are in flight together; beyond the frame's nz samples the FFT input is zero)
+    // raw samples of a tile (branch-free: the 16 loads of a work-item are in flight together; beyond the frame's nz samples the FFT input is zero).
+    // A frame that lies inside the current push and has no zero padding — every frame of a dense framing but the few that begin in the
+    // history — takes the lean path: uniform base pointer + one 32-bit offset per load, no bounds to test (the general loader spends ~25
+    // vector instructions per load on 64-bit compares and selects: more than the transform itself).
+    const bool dense = g.nz == (L1 << lg2);
     auto fetch = [&](float2 (&x)[16], int tile) {
         const int t = opaque(t_), c = opaque(c_);
         const int frame = tile / tiles, n2 = (tile % tiles) * C + c;
+        const long long s0 = g.first_start + (long long)frame * g.stride;
+        if (dense && s0 >= 0 && s0 + ((long long)L1 << lg2) <= src.n_cur) {  // (uniform)
+            const float2* base = src.cur + s0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
-            const int i = (n1 << lg2) + n2;
-            x[j] = iq_load_nb(src, g.first_start + (long long)frame * g.stride + i, i < g.nz);
+            for (int j = 0; j < 16; j++) {
+                const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+                x[j] = global_load_f32x2_boff(base, (unsigned)((n1 << lg2) + n2) * 8u);
+            }
+        }
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+                const int i = (n1 << lg2) + n2;
+                x[j] = iq_load_nb(src, s0 + i, i < g.nz);
+            }
         }
     };
     float wv[16];
@@ -345,27 +391,33 @@ __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float
             }
             wv_n2 = n2;
         }
+        if (dense) {  // (uniform) every input of the transform is a windowed sample
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
-            const bool in = ((n1 << lg2) + n2) < g.nz;
-            r[j] = in ? make_float2(r[j].x * wv[j], r[j].y * wv[j]) : make_float2(0.0f, 0.0f);
+            for (int j = 0; j < 16; j++) { r[j] = make_float2(r[j].x * wv[j], r[j].y * wv[j]); }
+        }
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
+                const bool in = ((n1 << lg2) + n2) < g.nz;
+                r[j] = in ? make_float2(r[j].x * wv[j], r[j].y * wv[j]) : make_float2(0.0f, 0.0f);
+            }
         }
         R0::compute(r, t, tw);
         IdxCols idx{ C, c };
         fft_rounds_after_first<LG1, 4, IdxCols>(r, t, tw, data, idx);
-        float2* dst = scratch + ((size_t)frame << (LG1 + lg2));
+        float2* dst = scratch + ((size_t)frame << (LG1 + lg2));  // (uniform; a frame's scratch is at most 8 MiB: 32-bit byte offsets)
 #pragma unroll
         for (int i = 0; i < RL::NG; i++) {
 #pragma unroll
             for (int j = 0; j < RL::GS; j++) {
                 const int k1 = RL::pos(t, i, j);
-                const size_t o = ((size_t)k1 << lg2) + n2;
+                const unsigned o = (unsigned)((k1 << lg2) + n2) * 8u;
                 const float2 a = r[i * RL::GS + j];
-                const float2 w = tw_n2k1[o];
+                const float2 w = global_load_f32x2_boff(tw_n2k1, o);
                 const float pp = a.y * w.y;
                 const float qq = a.y * w.x;
-                dst[o] = make_float2(fmaf(a.x, w.x, -pp), fmaf(a.x, w.y, qq));
+                global_store_f32x2_boff(dst, o, make_float2(fmaf(a.x, w.x, -pp), fmaf(a.x, w.y, qq)));
             }
         }
     };
@@ -445,33 +497,49 @@ __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float
         // dB values are transposed through LDS so that consecutive lanes write consecutive k1 (k = k1 + N1*k2).
         __syncthreads();
         float* tile_db = reinterpret_cast<float*>(data);  // [k2][R + 1]
+        unsigned abn = 0;
 #pragma unroll
         for (int i = 0; i < RL::NG; i++) {
 #pragma unroll
             for (int j = 0; j < RL::GS; j++) {
                 const int k2 = RL::pos(t, i, j);
-                tile_db[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
+                tile_db[k2 * (R + 1) + row] = power_db_normal(r[i * RL::GS + j], inv, abn);
+            }
+        }
+        if (abn >= SDRPP_LOG2_ABNORMAL) {  // a zero / subnormal / non-finite power among this work-item's 16: the general function, all again
+#pragma unroll
+            for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+                for (int j = 0; j < RL::GS; j++) {
+                    const int k2 = RL::pos(t, i, j);
+                    tile_db[k2 * (R + 1) + row] = power_db(r[i * RL::GS + j], inv);
+                }
             }
         }
         __syncthreads();
-        float* dst = out_db + ((size_t)frame << (LG2 + lg1)) + r0;
-        for (int e = tid; e < L2 * R; e += TPF * R) {
-            const int k2 = e / R;
-            const int rr = e % R;
-            dst[((size_t)k2 << lg1) + rr] = tile_db[k2 * (R + 1) + rr];
+        float* dst = out_db + ((size_t)frame << (LG2 + lg1)) + r0;  // (uniform; a line is at most 4 MiB: 32-bit byte offsets)
+        {   // element e = tid + it * (TPF * R), it = 0 .. 15 -> k2 = e / R = tid / R + it * TPF, rr = e % R = tid % R: every step adds constants
+            const int k2_0 = tid / R, rr = tid % R;
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int k2 = k2_0 + it * TPF;
+                global_store_f32_boff(dst, (unsigned)((k2 << lg1) + rr) * 4u, tile_db[k2 * (R + 1) + rr]);
+            }
         }
         // doZoom's maximum over the R consecutive bins k1 = r0 .. r0 + R - 1 of every k2, while the tile is in LDS: the zoom kernel then
         // reads one value per aligned group of R bins instead of R (waterfall.cpp:65-90 takes a maximum, which does not care how it is split)
         if (grp_max) {
             float* gdst = grp_max + (((size_t)frame << (LG2 + lg1)) + r0) / R;
-            for (int k2 = tid; k2 < L2; k2 += TPF * R) {
+            static_assert(TPF * R == 256 && L2 * R == 4096, "256 work-items, 4096 values per tile");
+#pragma unroll
+            for (int k2 = tid; k2 < L2; k2 += 256) {
                 float m = __uint_as_float(0xff800000u);
 #pragma unroll
                 for (int rr = 0; rr < R; rr++) {
                     const float v = tile_db[k2 * (R + 1) + rr];
                     if (v > m) { m = v; }
                 }
-                gdst[((size_t)k2 << lg1) / R] = m;
+                global_store_f32_boff(gdst, (unsigned)((k2 << lg1) / R) * 4u, m);
             }
         }
     };
@@ -535,10 +603,18 @@ __device__ __forceinline__ void fft_pass2row_body(const KIdx bid, float2* tw, fl
     __syncthreads();
     float* tile = reinterpret_cast<float*>(data);  // [k2]
     const float inv = 1.0f / (float)((size_t)1 << (LG2 + lg1));
+    unsigned abn = 0;
 #pragma unroll
     for (int i = 0; i < RL::NG; i++) {
 #pragma unroll
-        for (int j = 0; j < RL::GS; j++) { tile[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+        for (int j = 0; j < RL::GS; j++) { tile[RL::pos(t, i, j)] = power_db_normal(r[i * RL::GS + j], inv, abn); }
+    }
+    if (abn >= SDRPP_LOG2_ABNORMAL) {  // (see fft_pass2_body)
+#pragma unroll
+        for (int i = 0; i < RL::NG; i++) {
+#pragma unroll
+            for (int j = 0; j < RL::GS; j++) { tile[RL::pos(t, i, j)] = power_db(r[i * RL::GS + j], inv); }
+        }
     }
     __syncthreads();
     float* dst = reinterpret_cast<float*>(row);

@@ -19,6 +19,21 @@ __device__ __forceinline__ UniformF32 as_uniform(const void* ptr) {
     return u;
 }
 
+// The same for a wave-uniform int table (indices uniform across the wave): s_load_dword, counted by lgkmcnt — not by the vector-memory
+// counter the kernel's loads and stores share.
+struct UniformI32 {
+    const int __attribute__((address_space(4))) * p;
+    __device__ __forceinline__ int operator[](int i) const { return p[i]; }
+};
+__device__ __forceinline__ UniformI32 as_uniform_i32(const void* ptr) {
+    UniformI32 u;
+    u.p = (const int __attribute__((address_space(4)))*)(uintptr_t)ptr;
+    return u;
+}
+
+// A value that is the same in every lane of the wavefront, stated so that the compiler keeps it (and what is computed from it) in scalar registers
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // Pointers fetched from a job table in memory have no known address space, so the compiler falls back to FLAT accesses — which
 // count against BOTH the vector-memory and the LDS wait counters (every LDS wait then also waits for L2/HBM).  These helpers
 // state that the pointer is device global memory, which restores global_load / global_store.
@@ -47,6 +62,23 @@ __device__ __forceinline__ void global_store_f32x2(float2* p, long long i, float
     t.x = v.x;
     t.y = v.y;
     ((f32x2 __attribute__((address_space(1)))*)(uintptr_t)p)[i] = t;
+}
+
+// Wave-uniform base pointer + a 32-bit BYTE offset per lane: the global_load / global_store form with the base in scalar registers and one
+// 32-bit offset register (no 64-bit address arithmetic per access).  The offset must stay below 4 GiB.
+__device__ __forceinline__ float2 global_load_f32x2_boff(const void* base, unsigned byte_off) {
+    const f32x2 v = *((const f32x2 __attribute__((address_space(1)))*)((const char __attribute__((address_space(1)))*)(uintptr_t)base + byte_off));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void global_store_f32x2_boff(void* base, unsigned byte_off, float2 v) {
+    f32x2 t;
+    t.x = v.x;
+    t.y = v.y;
+    *((f32x2 __attribute__((address_space(1)))*)((char __attribute__((address_space(1)))*)(uintptr_t)base + byte_off)) = t;
+}
+
+__device__ __forceinline__ void global_store_f32_boff(void* base, unsigned byte_off, float v) {
+    *((float __attribute__((address_space(1)))*)((char __attribute__((address_space(1)))*)(uintptr_t)base + byte_off)) = v;
 }
 
 // 1 / x to 1 ulp (v_rcp_f32); x must be a normal number

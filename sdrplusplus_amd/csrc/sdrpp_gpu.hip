@@ -303,6 +303,10 @@ struct sdrpp_ctx {
     bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
     const volatile uint32_t* stage_pending = nullptr;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for this word to reach 0
     bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
+    // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
+    // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
+    // (43 VFOs in one workgroup: 42 cycles per sample against the chain's ~27), and the input is 8 bytes per sample however often it is read.
+    int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
@@ -2045,7 +2049,10 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         FamilyTimer t(c, F_S1);
         if (!rotx.empty() && n_in > 0) {
             if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
-            else { launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
+            else {
+                const int vpw = c->rot_exact_vpw;
+                launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + vpw - 1) / vpw), dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw);
+            }
         }
         for (int k = 0; k < 4; k++) {
             if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }

@@ -339,14 +339,14 @@ __global__ __launch_bounds__(64) void vfo_rotate_exact_kernel(IqSrc src, const R
 // same operands: bit-identical to vfo_rotate_exact_kernel (and to the reference's rotator).
 struct RotChunkIt {
     int blk, base, b1, nb;
-    const int* bounds;
+    UniformI32 bounds;  // (scalar loads: block ends are wave-uniform, and a vector load here would put a `s_waitcnt vmcnt(0)` into the chunk walk)
     __device__ __forceinline__ void settle() {
         while (blk < nb && base >= b1) {
             blk++;
             if (blk < nb) { b1 = bounds[blk]; }
         }
     }
-    __device__ __forceinline__ void init(const int* bnd, int n) {
+    __device__ __forceinline__ void init(UniformI32 bnd, int n) {
         bounds = bnd;
         nb = n;
         blk = 0;
@@ -365,108 +365,137 @@ struct RotChunkIt {
 // (round 3b: the first version of this kernel ran at 63 ns per sample — 150 cycles — instead of the chain's ~16: every consumer row began
 // with a load of its output pointer from the job table (a memory round trip each, 15 per chunk and wavefront), the chunk's samples were
 // loaded when the chunk began (another round trip, on the critical path of every chunk) and the chain compiled to seven scalar-operand vector
-// instructions + a compare-and-branch per sample.  Now: pointers in LDS, the next chunk's samples requested one chunk ahead, the chain as
-// two packed multiplies + one packed add per sample — the same IEEE operations on the same operands — in straight-line code per full chunk.)
+// instructions + a compare-and-branch per sample.  Then: pointers in LDS, the chain as two packed multiplies + one packed add per sample —
+// the same IEEE operations on the same operands — in straight-line code per full chunk, the samples requested six chunks ahead by the
+// wavefronts that apply the phases: still 27 ns per sample (56 cycles), measured on cfg 4 (profiles/r03q_bench_cfg4_ssb_exact_before.json).
+// The ISA said why: loads and stores share ONE in-order counter (vmcnt) on gfx9, the applying wavefronts issue a data-dependent number of
+// stores between a request and its use, so the compiler can only wait with vmcnt(0) — every chunk waited for its own newest stores and
+// for all six requests in flight.  Round 3c: the wavefront that runs the chain is the only one that LOADS (its waits are exact counts: it
+// never stores) and hands a chunk's samples over in LDS next to the phases; the applying wavefronts only read LDS and store, and never
+// wait for memory at all.)
+// (and the two roles are two separate loops, each with its own barriers: in ONE loop with a branch per role the compiler's wait-count
+// analysis, which does not know that a wavefront keeps its role, merges "this register has a request in flight" with "any number of stores
+// have been issued since" and falls back to vmcnt(0) again)
 typedef float rot_v2f __attribute__((vector_size(8)));
-#define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + 64 * sizeof(float2*))
-__global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds, int nb) {
-    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO; then the 64 output pointers
-    float2** outp = reinterpret_cast<float2**>(ph_tile + (size_t)2 * 64 * 65);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j0 = (int)blockIdx.x * 64;
-    const int nrows = min(64, njobs - j0);
-    const bool live = j0 + lane < njobs;
-    const RotXJob job = jobs[live ? j0 + lane : njobs - 1];
-    if (wv == 1) { outp[lane] = job.out; }
-    rot_v2f p = { job.state->x, job.state->y };
-    const rot_v2f d = { job.dr, job.di }, dyxn = { -job.di, job.dr };
-    int since = 0;  // samples since the start of the reference block the producer is in
-    RotChunkIt pit, cit;  // producer one chunk ahead of the consumers
-    pit.init(bounds, nb);
+#define SDRPP_ROTX4_TRIP 4  // chunks per request round of the chain wavefront
+#define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + (size_t)2 * SDRPP_ROTX4_TRIP * 64 * sizeof(float2) + 64 * sizeof(float2*))
+__global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds_g, int nb, int vpw) {
+    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO; then [2 * TRIP][64] samples; then the 64 output pointers
+    constexpr int TRIP = SDRPP_ROTX4_TRIP;
+    float2* x_tile = ph_tile + (size_t)2 * 64 * 65;
+    float2** outp = reinterpret_cast<float2**>(x_tile + 2 * TRIP * 64);
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wv = wave_uniform(tid >> 6);  // (known to be uniform: the roles are scalar branches and the chunk walk stays in scalar registers)
+    const int j0 = (int)blockIdx.x * vpw;  // vpw <= 64 VFOs per workgroup (the host's choice: see rot_exact_vpw)
+    const int nrows = min(vpw, njobs - j0);
+    const UniformI32 bounds = as_uniform_i32(bounds_g);
+    RotChunkIt cit;  // the chunk every wavefront of the workgroup is at (one barrier per chunk)
     cit.init(bounds, nb);
-    auto step = [&](float2* slot) {
-        *slot = make_float2(p[0], p[1]);
-        const rot_v2f pxx = { p[0], p[0] }, pyy = { p[1], p[1] };
-        const rot_v2f a = pxx * d;      // (pr * dr, pr * di)                  = (a0, a1)
-        const rot_v2f b = pyy * dyxn;   // (pi * -di, pi * dr) = (-(pi * di), b1) = (-b0, b1): a product's sign does not touch its rounding
-        p = a + b;                      // (a0 - b0, a1 + b1): x + (-y) is x - y bit for bit
-    };
-    auto norm = [&]() {
-        float pr = p[0], pi = p[1];
-        rotator_norm(pr, pi);
-        p = rot_v2f{ pr, pi };
-    };
-    auto produce = [&](int buf) {
-        float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane;
-        const int cnt = pit.cnt();
-        if (cnt == 64 && (since & 63) == 0) {  // a full chunk between two possible renormalisation points: straight-line code
+    if (!cit.valid()) { return; }  // (uniform; no barrier has been passed)
+    if (wv == 0) {
+        // ---- the chain: lane = VFO ----
+        const bool live = lane < nrows;
+        const RotXJob job = jobs[live ? j0 + lane : njobs - 1];
+        outp[lane] = job.out;
+        rot_v2f p = { job.state->x, job.state->y };
+        const rot_v2f d = { job.dr, job.di }, dyxn = { -job.di, job.dr };
+        int since = 0;  // samples since the start of the reference block the producer is in
+        RotChunkIt pit, fit;  // phases (one chunk ahead of the consumers), sample requests (one to two rounds ahead)
+        pit.init(bounds, nb);
+        fit.init(bounds, nb);
+        auto step = [&](float2* slot) {
+            *slot = make_float2(p[0], p[1]);
+            const rot_v2f pxx = { p[0], p[0] }, pyy = { p[1], p[1] };
+            const rot_v2f a = pxx * d;      // (pr * dr, pr * di)                  = (a0, a1)
+            const rot_v2f b = pyy * dyxn;   // (pi * -di, pi * dr) = (-(pi * di), b1) = (-b0, b1): a product's sign does not touch its rounding
+            p = a + b;                      // (a0 - b0, a1 + b1): x + (-y) is x - y bit for bit
+        };
+        auto norm = [&]() {
+            float pr = p[0], pi = p[1];
+            rotator_norm(pr, pi);
+            p = rot_v2f{ pr, pi };
+        };
+        auto produce = [&](int buf) {
+            float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane;
+            const int cnt = pit.cnt();
+            if (cnt == 64 && (since & 63) == 0) {  // a full chunk between two possible renormalisation points: straight-line code
 #pragma unroll
-            for (int i = 0; i < 64; i++) { step(ph + i * 65); }
-            since += 64;
-            if ((since & 511) == 0) { norm(); }
-        }
-        else {
-            for (int i = 0; i < cnt; i++) {
-                step(ph + i * 65);
-                since++;
+                for (int i = 0; i < 64; i++) { step(ph + i * 65); }
+                since += 64;
                 if ((since & 511) == 0) { norm(); }
             }
-        }
-        if (pit.ends_block()) {
-            if ((since & 511) != 0) { norm(); }
-            since = 0;
-        }
-        pit.advance();
-    };
-    // the chunks' samples are requested SDRPP_ROTX4_AHEAD chunks ahead (a chunk lasts ~0.4 us at the chain's pace, a first touch of the input in
-    // HBM ~2 us: one chunk ahead left the kernel waiting on that latency, 30 ns per sample)
-    constexpr int AHEAD = 6;
-    auto fetch = [&](const RotChunkIt& it) -> float2 { return (it.valid() && lane < it.cnt()) ? src.cur[it.base + lane] : make_float2(0.0f, 0.0f); };
-    float2 xq[AHEAD];
-    RotChunkIt fit = cit;
-    if (wv == 0) {
-        if (pit.valid()) { produce(0); }
-    }
-    else {
-#pragma unroll
-        for (int k = 0; k < AHEAD; k++) {
-            xq[k] = fetch(fit);
-            if (fit.valid()) { fit.advance(); }
-        }
-    }
-    __syncthreads();
-    int buf = 0;
-    while (cit.valid()) {
-        // (unrolled over the ring of requested chunks: slot u is consumed and refilled in place — shifting the ring would make every move wait
-        // for the request just issued)
-#pragma unroll
-        for (int u = 0; u < AHEAD; u++) {
-            if (!cit.valid()) { break; }  // (uniform over the workgroup)
-            if (wv == 0) {
-                if (pit.valid()) { produce(buf ^ 1); }
-                cit.advance();
-            }
             else {
-                const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
-                const int cnt = cit.cnt(), base = cit.base;
-                const float2 x = xq[u];
-                cit.advance();
-                xq[u] = fetch(fit);
-                if (fit.valid()) { fit.advance(); }
-                if (lane < cnt) {
-#pragma unroll 4
-                    for (int r = wv - 1; r < nrows; r += 3) {
-                        const float2 ph_r = ph[r];
-                        float2* o = outp[r];
-                        global_store_f32x2(o, base + lane, make_float2((x.x * ph_r.x) - (x.y * ph_r.y), (x.x * ph_r.y) + (x.y * ph_r.x)));
-                    }
+                for (int i = 0; i < cnt; i++) {
+                    step(ph + i * 65);
+                    since++;
+                    if ((since & 511) == 0) { norm(); }
                 }
             }
+            if (pit.ends_block()) {
+                if ((since & 511) != 0) { norm(); }
+                since = 0;
+            }
+            pit.advance();
+        };
+        // Samples are requested a ROUND of TRIP chunks at a time, one to two rounds before the consumers reach them (a chunk lasts ~0.5 us at
+        // the chain's pace, a first touch of the input in HBM ~2 us), always all TRIP requests — past the end of the push with a clamped
+        // address — and handed over in LDS at the top of the next round: by then they have long landed.
+        auto fetch = [&]() -> float2 {
+            const bool ok = fit.valid() && lane < fit.cnt();
+            const float2 v = global_load_f32x2(src.cur, ok ? (long long)(fit.base + lane) : 0ll);
+            if (fit.valid()) { fit.advance(); }
+            return v;
+        };
+        float2 xr[TRIP];
+#pragma unroll
+        for (int k = 0; k < TRIP; k++) { xr[k] = fetch(); }  // round 0
+#pragma unroll
+        for (int k = 0; k < TRIP; k++) { x_tile[k * 64 + lane] = xr[k]; }
+#pragma unroll
+        for (int k = 0; k < TRIP; k++) { xr[k] = fetch(); }  // round 1
+        produce(0);
+        __syncthreads();
+        int buf = 0, half = 0;
+        while (cit.valid()) {
+            half ^= 1;
+#pragma unroll
+            for (int k = 0; k < TRIP; k++) { x_tile[(half * TRIP + k) * 64 + lane] = xr[k]; }  // the round after the one being consumed
+#pragma unroll
+            for (int k = 0; k < TRIP; k++) { xr[k] = fetch(); }                               // the round after that
+#pragma unroll
+            for (int k = 0; k < TRIP; k++) {
+                if (cit.valid()) {  // (uniform over the workgroup: the consumers walk the same chunks)
+                    if (pit.valid()) { produce(buf ^ 1); }
+                    cit.advance();
+                    buf ^= 1;
+                    __syncthreads();
+                }
+            }
+        }
+        if (live) { *job.state = make_float2(p[0], p[1]); }
+    }
+    else {
+        // ---- the consumers: lane = sample of the chunk; they read LDS and store, nothing else ----
+        __syncthreads();
+        int buf = 0, slot = 0;
+        while (cit.valid()) {
+            const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
+            const int cnt = cit.cnt(), base = cit.base;
+            const float2 x = x_tile[slot * 64 + lane];
+            if (lane < cnt) {
+#pragma unroll 4
+                for (int r = wv - 1; r < nrows; r += 3) {
+                    const float2 ph_r = ph[r];
+                    float2* o = outp[r];
+                    global_store_f32x2(o, base + lane, make_float2((x.x * ph_r.x) - (x.y * ph_r.y), (x.x * ph_r.y) + (x.y * ph_r.x)));
+                }
+            }
+            cit.advance();
             buf ^= 1;
+            slot = (slot + 1) & (2 * TRIP - 1);
             __syncthreads();
         }
     }
-    if (wv == 0 && live) { *job.state = make_float2(p[0], p[1]); }
 }
 
 // SSB's second translation (ssb.h:78, a FrequencyXlator at the IF rate) in reference-rotator mode: one wavefront per VFO, every lane

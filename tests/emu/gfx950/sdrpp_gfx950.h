@@ -8,12 +8,21 @@ struct UniformF32 {
     float operator[](int i) const { return p[i]; }
 };
 static inline UniformF32 as_uniform(const void* ptr) { return UniformF32{ (const float*)ptr }; }
+struct UniformI32 {
+    const int* p;
+    int operator[](int i) const { return p[i]; }
+};
+static inline UniformI32 as_uniform_i32(const void* ptr) { return UniformI32{ (const int*)ptr }; }
+static inline int wave_uniform(int v) { return v; }
 static inline float global_load_f32(const float* p, long long i) { return p[i]; }
 static inline int global_load_i32(const int* p, long long i) { return p[i]; }
 static inline float2 global_load_f32x2(const float2* p, long long i) { return p[i]; }
 static inline float4 global_load_f32x4(const float4* p, long long i) { return p[i]; }
 static inline float4 global_load_f32x4_unaligned(const float* p, long long i) { return make_float4(p[i], p[i + 1], p[i + 2], p[i + 3]); }
 static inline void global_store_f32x2(float2* p, long long i, float2 v) { p[i] = v; }
+static inline float2 global_load_f32x2_boff(const void* base, unsigned byte_off) { return *(const float2*)((const char*)base + byte_off); }
+static inline void global_store_f32x2_boff(void* base, unsigned byte_off, float2 v) { *(float2*)((char*)base + byte_off) = v; }
+static inline void global_store_f32_boff(void* base, unsigned byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}

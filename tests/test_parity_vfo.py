@@ -279,6 +279,35 @@ def test_reference_rotator_mode_matches_the_reference(backend, cut):
     ctx.close()
 
 
+def test_reference_rotator_four_wavefront_kernel_is_bit_identical(backend, monkeypatch):
+    """vfo_rotate_exact4_kernel (one wavefront runs the phase chain and requests the samples, three apply the phases) against the
+    one-wavefront form of the same recursion (SDRPP_GPU_ROT_EXACT_SINGLE, read when a context is created): IF and audio streams bit for bit,
+    over pushes that end inside a 64-sample chunk, reference blocks that do, pushes shorter than a chunk and seven VFOs (rows dealt to the
+    three applying wavefronts unevenly)."""
+    sr = 10e6
+    specs = ARB_SPECS + [("RAW", 123456.0)]
+    pushes = [50000, 63, 1, 120001, 64, 8 * 64 + 5, 70000, 100000]
+    x = _two_tone_mix(sr, sum(pushes), specs, 31)
+    outs = []
+    for single in (True, False):
+        if single:
+            monkeypatch.setenv("SDRPP_GPU_ROT_EXACT_SINGLE", "1")
+        else:
+            monkeypatch.delenv("SDRPP_GPU_ROT_EXACT_SINGLE", raising=False)
+        ctx, vids, _, _ = _setup(sr, specs, max(pushes), nco_mode=1, ref_block=50000)
+        got, pos = [], 0
+        for n in pushes:
+            ctx.push(x[pos:pos + n])
+            pos += n
+            got.append([a.copy() for a in ctx.vfo_read_many(vids)] + [a.copy() for a in ctx.vfo_read_many(vids, which=[1] * len(vids))])
+        outs.append(got)
+        ctx.close()
+    for ga, gb in zip(*outs):
+        for a, b in zip(ga, gb):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    assert sum(len(a) for a in outs[0][0]) > 0
+
+
 def test_per_vfo_nco_mode_in_one_bank(backend):
     """sdrpp_vfo_desc.nco_mode: the SSB / raw-IF channels of a bank run the reference's rotator recursion (pinned oracle matched at
     arbitrary offsets: IF 2e-6, audio 1e-5) while its FM / AM channels stay on the closed-form fast path (audio 1e-5 against the same
