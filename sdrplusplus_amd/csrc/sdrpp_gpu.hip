@@ -306,6 +306,7 @@ struct sdrpp_ctx {
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
     // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
     // (43 VFOs in one workgroup: 42 cycles per sample against the chain's ~27), and the input is 8 bytes per sample however often it is read.
+    int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 4;  // phases handed over per chunk: every 4th / 8th / 16th (measurement switch)
     int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
@@ -2051,7 +2052,10 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
             else {
                 const int vpw = c->rot_exact_vpw;
-                launch(c, vfo_rotate_exact4_kernel, dim3(((unsigned)rotx.size() + vpw - 1) / vpw), dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw);
+                const dim3 grid(((unsigned)rotx.size() + vpw - 1) / vpw);
+                if (c->rot_exact_skip >= 16) { launch(c, vfo_rotate_exact4_kernel<16>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+                else if (c->rot_exact_skip >= 8) { launch(c, vfo_rotate_exact4_kernel<8>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+                else { launch(c, vfo_rotate_exact4_kernel<4>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
             }
         }
         for (int k = 0; k < 4; k++) {
@@ -2631,6 +2635,10 @@ bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag 
 // travels with this tick's upload.
 // expected lifetime of a workgroup of a role relative to the others (tools/tick_trace.py timelines), for the order inside a tick
 inline int tick_role_weight(int role) {
+    // result copies write page-locked host memory over the bus: few workgroups whose life is mostly that round trip — started last they are the
+    // tail of the tick, started first they finish in its shadow (SDRPP_GPU_TICK_COPY_FIRST=0: the old order, for measurements)
+    static const bool copy_first = getenv("SDRPP_GPU_TICK_COPY_FIRST") ? atoi(getenv("SDRPP_GPU_TICK_COPY_FIRST")) != 0 : true;
+    if (role == TR_COPY && copy_first) { return 110; }
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return 100;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;

@@ -378,12 +378,16 @@ struct RotChunkIt {
 // have been issued since" and falls back to vmcnt(0) again)
 typedef float rot_v2f __attribute__((vector_size(8)));
 #define SDRPP_ROTX4_TRIP 4  // chunks per request round of the chain wavefront
-#define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + (size_t)2 * SDRPP_ROTX4_TRIP * 64 * sizeof(float2) + 64 * sizeof(float2*))
+// (SKIP, a template parameter: in a full chunk the chain publishes every SKIP-th phase; the applying wavefronts take the steps in between themselves)
+#define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + (size_t)2 * SDRPP_ROTX4_TRIP * 64 * sizeof(float2) + 64 * sizeof(float2*) + 64 * sizeof(float2) + 2 * sizeof(int))
+template <int SKIP>
 __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds_g, int nb, int vpw) {
     HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO; then [2 * TRIP][64] samples; then the 64 output pointers
     constexpr int TRIP = SDRPP_ROTX4_TRIP;
     float2* x_tile = ph_tile + (size_t)2 * 64 * 65;
     float2** outp = reinterpret_cast<float2**>(x_tile + 2 * TRIP * 64);
+    float2* dtab = reinterpret_cast<float2*>(outp + 64);  // phaseDelta of the workgroup's VFOs
+    int* sparse = reinterpret_cast<int*>(dtab + 64);       // [2]: the chunk in this buffer carries every SKIP-th phase only
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);  // (known to be uniform: the roles are scalar branches and the chunk walk stays in scalar registers)
     const int j0 = (int)blockIdx.x * vpw;  // vpw <= 64 VFOs per workgroup (the host's choice: see rot_exact_vpw)
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
         const bool live = lane < nrows;
         const RotXJob job = jobs[live ? j0 + lane : njobs - 1];
         outp[lane] = job.out;
+        dtab[lane] = make_float2(job.dr, job.di);
         rot_v2f p = { job.state->x, job.state->y };
         const rot_v2f d = { job.dr, job.di }, dyxn = { -job.di, job.dr };
         int since = 0;  // samples since the start of the reference block the producer is in
@@ -419,8 +424,19 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
             float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane;
             const int cnt = pit.cnt();
             if (cnt == 64 && (since & 63) == 0) {  // a full chunk between two possible renormalisation points: straight-line code
+                // Handing a phase over costs the chain ~12 cycles on top of its own ~21 per sample (the LDS write's operands go through the
+                // same register read port as the arithmetic, wherever the write is placed: tools/probe/chain_latency_probe.hip, variants A / E /
+                // F), so only every SKIP-th phase is handed over; the applying wavefronts take the up to SKIP - 1 steps in between
+                // themselves — the same two products and one sum on the same operands, so the same bits.  (No renormalisation can fall
+                // inside such a chunk: it starts a multiple of 64 samples into its block.)
 #pragma unroll
-                for (int i = 0; i < 64; i++) { step(ph + i * 65); }
+                for (int i = 0; i < 64; i++) {
+                    if (i % SKIP == 0) { ph[i * 65] = make_float2(p[0], p[1]); }
+                    const rot_v2f pxx = { p[0], p[0] }, pyy = { p[1], p[1] };
+                    const rot_v2f a = pxx * d, b = pyy * dyxn;
+                    p = a + b;
+                }
+                if (lane == 0) { sparse[buf] = 1; }
                 since += 64;
                 if ((since & 511) == 0) { norm(); }
             }
@@ -430,6 +446,7 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
                     since++;
                     if ((since & 511) == 0) { norm(); }
                 }
+                if (lane == 0) { sparse[buf] = 0; }
             }
             if (pit.ends_block()) {
                 if ((since & 511) != 0) { norm(); }
@@ -479,10 +496,29 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
         __syncthreads();
         int buf = 0, slot = 0;
         while (cit.valid()) {
-            const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
             const int cnt = cit.cnt(), base = cit.base;
             const float2 x = x_tile[slot * 64 + lane];
-            if (lane < cnt) {
+            if (wave_uniform(sparse[buf]) != 0) {  // a full chunk with every SKIP-th phase: lane i starts from phase i - i % SKIP and takes i % SKIP steps
+                const float2* ph = ph_tile + (size_t)buf * 64 * 65 + (lane & ~(SKIP - 1)) * 65;
+                const int more = lane & (SKIP - 1);
+#pragma unroll 2
+                for (int r = wv - 1; r < nrows; r += 3) {
+                    const float2 p0 = ph[r], dv = dtab[r];
+                    rot_v2f q = { p0.x, p0.y };
+                    const rot_v2f d = { dv.x, dv.y }, dyxn = { -dv.y, dv.x };
+#pragma unroll
+                    for (int st = 0; st < SKIP - 1; st++) {
+                        const rot_v2f qxx = { q[0], q[0] }, qyy = { q[1], q[1] };
+                        const rot_v2f a = qxx * d, b = qyy * dyxn;
+                        const rot_v2f n = a + b;
+                        q = (st < more) ? n : q;
+                    }
+                    float2* o = outp[r];
+                    global_store_f32x2(o, base + lane, make_float2((x.x * q[0]) - (x.y * q[1]), (x.x * q[1]) + (x.y * q[0])));
+                }
+            }
+            else if (lane < cnt) {
+                const float2* ph = ph_tile + (size_t)buf * 64 * 65 + lane * 65;
 #pragma unroll 4
                 for (int r = wv - 1; r < nrows; r += 3) {
                     const float2 ph_r = ph[r];

@@ -279,11 +279,14 @@ def test_reference_rotator_mode_matches_the_reference(backend, cut):
     ctx.close()
 
 
-def test_reference_rotator_four_wavefront_kernel_is_bit_identical(backend, monkeypatch):
+@pytest.mark.parametrize("vpw", [None, "3"])
+def test_reference_rotator_four_wavefront_kernel_is_bit_identical(backend, monkeypatch, vpw):
     """vfo_rotate_exact4_kernel (one wavefront runs the phase chain and requests the samples, three apply the phases) against the
     one-wavefront form of the same recursion (SDRPP_GPU_ROT_EXACT_SINGLE, read when a context is created): IF and audio streams bit for bit,
     over pushes that end inside a 64-sample chunk, reference blocks that do, pushes shorter than a chunk and seven VFOs (rows dealt to the
-    three applying wavefronts unevenly)."""
+    three applying wavefronts unevenly), in one workgroup and (SDRPP_GPU_ROTX_VPW = 3 VFOs per workgroup) in three."""
+    if vpw:
+        monkeypatch.setenv("SDRPP_GPU_ROTX_VPW", vpw)
     sr = 10e6
     specs = ARB_SPECS + [("RAW", 123456.0)]
     pushes = [50000, 63, 1, 120001, 64, 8 * 64 + 5, 70000, 100000]

@@ -16,6 +16,9 @@ def main():
 
     from sdrplusplus_amd import capi, workloads
 
+    if os.environ.get("SDRPP_TOOL_LIB"):  # a switch of this TOOL (A/B builds of the library), not of the binding
+        capi.DEFAULT_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", os.environ["SDRPP_TOOL_LIB"])
+
     lgs = [int(a) for a in sys.argv[1:]] or list(range(13, 21))
     push = 1 << 24
     x = workloads.synth(2, 1 << 22, seed=3)
