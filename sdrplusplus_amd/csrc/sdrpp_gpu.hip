@@ -305,9 +305,11 @@ struct sdrpp_ctx {
     bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
     // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
-    // (43 VFOs in one workgroup: 42 cycles per sample against the chain's ~27), and the input is 8 bytes per sample however often it is read.
-    int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 4;  // phases handed over per chunk: every 4th / 8th / 16th (measurement switch)
-    int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    // and the input is 8 bytes per sample however often it is read.
+    // phases handed over per full chunk: every 4th / 8th / 16th (cfg 4's 43 SSB channels, the family's time per 2^20 samples: 14.2 / 13.4 / 13.0 ms,
+    // profiles/r03x_*; the applying wavefronts take up to SKIP - 1 steps per sample themselves, so fewer VFOs per workgroup go with a larger stride)
+    int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 16;
+    int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
