@@ -114,7 +114,7 @@ def cpu_baseline(base_cfg, nvfo, fft_size):
     }
 
 
-def algorithmic_work(push, plan, sr, nvfo, piped=False):
+def algorithmic_work(push, plan, sr, nvfo, piped=False, fft_n=0, data_width=1024):
     """ALGORITHMIC flops / compulsory HBM bytes of ONE launch set of every kernel family for one push: real-tap FIR on
     complex data = 4 flop per tap and output; the fused front end in its tap-pair form (8 flop per pair and output + the NCO's two
     complex products); real audio filter 2 flop per tap.  Families hold several launches (vfo_fir = channel filter + audio low-pass).
@@ -123,6 +123,11 @@ def algorithmic_work(push, plan, sr, nvfo, piped=False):
     from sdrplusplus_amd import radio
 
     by = {"fft_pass1": push * 16.0, "fft_pass2": push * 12.0, "fft_single": push * 12.0, "zoom_palette": push * 4.0}
+    if fft_n > 4096:
+        # doZoom over transforms above 4096 points reads the maxima of aligned groups of R bins that FFT pass 2 (or the transpose pass) leaves —
+        # R = its rows per workgroup — plus up to 2 R ragged bins per pixel, and writes 8 bytes per pixel: that, not the whole line, is what it must move
+        R = 32 if fft_n <= (1 << 14) else 16
+        by["zoom_palette"] = push * 4.0 / R + (push / float(fft_n)) * data_width * (8.0 + 2 * R * 4.0)
     fl = {"fft_pass1": push * (3 * 2 * 8 + 8 + 2.0), "fft_pass2": push * (3 * 2 * 8 + 12.0), "fft_single": push * (5 * 12 + 12.0)}
     bound = {"fft_pass1": "hbm", "fft_pass2": "hbm", "fft_single": "hbm", "zoom_palette": "hbm", "carry_misc": "hbm", "demod": "hbm"}
     if not nvfo:
@@ -314,7 +319,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
     if rank == 0:
         total_samples = world * push * steps
         value = total_samples / elapsed / 1e6
-        fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo, piped=kernel_ms_all.get("vfo_pipe", 0) > 0)
+        fl, by, bound_of = algorithmic_work(push, info["plan"], sr, nvfo, piped=kernel_ms_all.get("vfo_pipe", 0) > 0, fft_n=N, data_width=data_width)
         pflops, pbytes, bps = path_work(push, info["plan"], sr, nvfo, N)
         fl["tick"], by["tick"], bound_of["tick"] = pflops, pbytes, ("mfma" if nvfo else "hbm")
         launches = {k: max(1, v[1]) for k, v in fam.items()}

@@ -283,6 +283,7 @@ struct sdrpp_ctx {
     };
     bool pipelined = false;
     int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
+    int num_cus = 256;
     bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
     // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
     // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
@@ -2636,11 +2637,18 @@ bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag 
 // with the block's job tables) + every queued role whose turn it is.  The role table of the NEXT tick is appended to the arena slot and
 // travels with this tick's upload.
 // expected lifetime of a workgroup of a role relative to the others (tools/tick_trace.py timelines), for the order inside a tick
-inline int tick_role_weight(int role) {
+inline int tick_role_weight(int role, bool crowded) {
     // result copies write page-locked host memory over the bus: few workgroups whose life is mostly that round trip — started last they are the
     // tail of the tick, started first they finish in its shadow (SDRPP_GPU_TICK_COPY_FIRST=0: the old order, for measurements)
     static const bool copy_first = getenv("SDRPP_GPU_TICK_COPY_FIRST") ? atoi(getenv("SDRPP_GPU_TICK_COPY_FIRST")) != 0 : true;
     if (role == TR_COPY && copy_first) { return 110; }
+    // FFT pass 1: since its workgroups walk their tiles and take the lean loader they live ~12 us at 10^6-sample blocks, shorter than the
+    // Toeplitz roles' 17-33 us.  In a CROWDED tick (more workgroups than the GPU holds at once: they are handed out in index order) they go
+    // behind the filters and pass 2, so that the tick ends on short workgroups: 18.6 -> 19.6 GS/s at 10^6-sample blocks; in a tick whose
+    // workgroups are all resident from the start the order only decides who gets going first, and pass 1 early is worth 2 % at 200 000-sample
+    // blocks (profiles/r03z_tick_p1_weight.log; SDRPP_GPU_TICK_P1_WEIGHT: measurement switch)
+    static const int p1_weight = getenv("SDRPP_GPU_TICK_P1_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_P1_WEIGHT")) : 0;
+    if (role >= TR_FFT_P1_5 && role <= TR_FFT_P1_10) { return p1_weight > 0 ? p1_weight : (crowded ? 45 : 70); }
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return 100;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;
@@ -2671,7 +2679,12 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         // order: longest workgroups first (front ends, FFT pass 1, the filters; zoom / carry / copies last), so that the tick ends on
         // short ones instead of on a front end that only got its turn when everything else was through (10^6-sample blocks: the front
         // end started 46 us into an 81 us tick).  The table is final here: later blocks only add to later ticks.
-        if (c->tick_order) { std::stable_sort(nx.begin(), nx.end(), [](const sdrpp_ctx::RoleLaunch& a, const sdrpp_ctx::RoleLaunch& b) { return tick_role_weight(a.e.role) > tick_role_weight(b.e.role); }); }
+        if (c->tick_order) {
+            long long wgs = 0;
+            for (auto& r : nx) { wgs += (long long)r.e.gx * r.e.gy; }
+            const bool crowded = wgs > 3ll * c->num_cus;  // (three workgroups of the tick kernel per CU)
+            std::stable_sort(nx.begin(), nx.end(), [crowded](const sdrpp_ctx::RoleLaunch& a, const sdrpp_ctx::RoleLaunch& b) { return tick_role_weight(a.e.role, crowded) > tick_role_weight(b.e.role, crowded); });
+        }
         if (nx.size() > SDRPP_TICK_MAX_ENTRIES) { return fail(c, SDRPP_ERR_UNSUPPORTED, "internal: %zu roles in one tick", nx.size()); }
         const size_t off = (c->arena_off + 63) & ~(size_t)63;
         if (off + sizeof(TickTable) > kArenaBytes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
@@ -3119,6 +3132,7 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         char b[600];
         snprintf(b, sizeof(b), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
         c->devinfo = b;
+        c->num_cus = std::max(1, prop.multiProcessorCount);
     }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
