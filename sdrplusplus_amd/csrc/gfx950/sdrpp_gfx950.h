@@ -165,6 +165,30 @@ __device__ __forceinline__ void lds_flag_wait_ge(int* f, int need, int* timeouts
     }
 }
 
+// The same search over a table of exactly 64 slots, fetching in the SAME round trip the first six dwords of the record that belongs to every
+// slot (records `stride_bytes` apart, dword aligned, all 64 readable): lane l asks for end l and record l, the ballot finds the slot and
+// v_readlane hands out its record — where a look-up followed by a load of the record it found is two trips to memory, one after the other
+// (a tick's workgroups start on a cold cache: every dependent load is ~1.5 us of a 13 us tick).
+__device__ __forceinline__ int wave_upper_bound64_rec(const int* ends, int n, int b, int* prev_end, const void* recs, int stride_bytes, int (&rec)[6]) {
+    const int lane = threadIdx.x & 63;
+    const int mine = global_load_i32(ends, lane);
+    const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(recs) + (size_t)lane * (size_t)stride_bytes);
+    const float4 r0 = global_load_f32x4_unaligned(rp, 0);
+    const float r4 = global_load_f32(rp, 4), r5 = global_load_f32(rp, 5);
+    const unsigned long long below = __ballot(lane < n && mine <= b);
+    const int idx = __popcll(below);
+    const int prev = __builtin_amdgcn_readlane(mine, idx > 0 ? idx - 1 : 0);
+    *prev_end = idx > 0 ? prev : 0;
+    const int src = idx < 64 ? idx : 63;
+    rec[0] = __builtin_amdgcn_readlane(__float_as_int(r0.x), src);
+    rec[1] = __builtin_amdgcn_readlane(__float_as_int(r0.y), src);
+    rec[2] = __builtin_amdgcn_readlane(__float_as_int(r0.z), src);
+    rec[3] = __builtin_amdgcn_readlane(__float_as_int(r0.w), src);
+    rec[4] = __builtin_amdgcn_readlane(__float_as_int(r4), src);
+    rec[5] = __builtin_amdgcn_readlane(__float_as_int(r5), src);
+    return idx;
+}
+
 // Issue priority of this wavefront among the wavefronts of its SIMD (s_setprio 0..3)
 __device__ __forceinline__ void wave_prio_high() { __builtin_amdgcn_s_setprio(3); }
 __device__ __forceinline__ void wave_prio_low() { __builtin_amdgcn_s_setprio(0); }

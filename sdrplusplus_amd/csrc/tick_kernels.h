@@ -16,6 +16,7 @@
 // (tests/test_pipelined.py compares the two execution paths sample for sample).  Per-block buffers are rings (`ring depth` buffers per
 // stream) so that a producer working on block n+1 does not overwrite what a consumer still reads of block n.
 #pragma once
+#include <cstddef>
 
 namespace sdrpp_k {
 
@@ -206,45 +207,51 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
         b -= nb0;
         const int n = tab->n;
         int first = 0;
-        const int ei = wave_upper_bound(tab->block_end, n, b, &first);
+        // the entry's header (role, grid, aux, job table) comes with the look-up itself; only the per-role parameter block `p` still costs a
+        // load of its own, and that one runs beside the load of the job table it no longer has to wait for
+        static_assert(offsetof(TickEntry, jobs) == 16 && sizeof(void*) == 8, "wave_upper_bound64_rec hands out the first six dwords of an entry");
+        int hdr[6];
+        const int ei = wave_upper_bound64_rec(tab->block_end, n, b, &first, tab->e, (int)sizeof(TickEntry), hdr);
         if (ei < n) {
             const TickEntry& e = tab->e[ei];
+            const int e_role = hdr[0], e_gy = hdr[2], e_aux = hdr[3];
+            const void* e_jobs = reinterpret_cast<const void*>(((unsigned long long)(unsigned)hdr[5] << 32) | (unsigned long long)(unsigned)hdr[4]);
 #ifdef SDRPP_TICK_TRACE
-            tr_role = e.role;
+            tr_role = e_role;
             tr_entry = ei;
 #endif
-            const int lb = b - first, gx = e.gx;
-            const KIdx bid{ lb % gx, lb / gx }, gdim{ gx, e.gy };
-            switch (e.role) {
-            case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e.jobs)); break;
-            case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e.jobs)); break;
-            case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e.jobs)); } break;
-            case TR_FCM_132_4: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
-            case TR_FCM_6: { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
-            case TR_FCM_10: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
-            case TR_FCM_16: { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
-            case TR_FCL_0: { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); } break;
+            const int lb = b - first, gx = hdr[1];
+            const KIdx bid{ lb % gx, lb / gx }, gdim{ gx, e_gy };
+            switch (e_role) {
+            case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e_jobs)); break;
+            case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e_jobs)); break;
+            case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e_jobs)); } break;
+            case TR_FCM_132_4: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCM_6: { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCM_10: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCM_16: { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCL_0: { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCL_PF:
-                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e.jobs)); }
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
-            case TR_TOEP_C: vfo_toep_body<2, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
-            case TR_TOEP_R: vfo_toep_body<1, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
-            case TR_TOEP_Q: vfo_toep_body<1, 2, true>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e.jobs)); break;
+            case TR_TOEP_C: vfo_toep_body<2, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e_jobs)); break;
+            case TR_TOEP_R: vfo_toep_body<1, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e_jobs)); break;
+            case TR_TOEP_Q: vfo_toep_body<1, 2, true>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e_jobs)); break;
             case TR_FIRB_C:
-                vfo_firb_body<2, false>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                vfo_firb_body<2, false>(bid, smem, e_aux, reinterpret_cast<const FirBJob*>(e_jobs));
                 break;
             case TR_FIRB_R:
-                vfo_firb_body<1, false>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                vfo_firb_body<1, false>(bid, smem, e_aux, reinterpret_cast<const FirBJob*>(e_jobs));
                 break;
             case TR_FIRB_S:
-                vfo_firb_body<1, true>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                vfo_firb_body<1, true>(bid, smem, e_aux, reinterpret_cast<const FirBJob*>(e_jobs));
                 break;
             case TR_FIRB_Q:
-                vfo_firb_body<1, true, true>(bid, smem, e.aux, reinterpret_cast<const FirBJob*>(e.jobs));
+                vfo_firb_body<1, true, true>(bid, smem, e_aux, reinterpret_cast<const FirBJob*>(e_jobs));
                 break;
-            case TR_PRE: vfo_demod_pre_body(bid, gdim, reinterpret_cast<const PreJob*>(e.jobs)); break;
+            case TR_PRE: vfo_demod_pre_body(bid, gdim, reinterpret_cast<const PreJob*>(e_jobs)); break;
             case TR_SEQ:
-                if (threadIdx.x < 64) { vfo_sequential_body(bid, reinterpret_cast<const SeqJob*>(e.jobs), e.aux); }
+                if (threadIdx.x < 64) { vfo_sequential_body(bid, reinterpret_cast<const SeqJob*>(e_jobs), e_aux); }
                 break;
             case TR_FFT_S10: tick_fft_single<10, 4>(bid, smem, e.p.fs); break;
             case TR_FFT_S11: tick_fft_single<11, 2>(bid, smem, e.p.fs); break;
@@ -263,10 +270,10 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
                 float2* tw = reinterpret_cast<float2*>(smem);
                 fft_pass2row_body<12>(bid, tw, tw + (1 << 12) / 2, const_cast<float2*>(e.p.p2.scratch), e.p.p2.tw2, e.p.p2.lg1);
             } break;
-            case TR_FFT_TR: fft_transpose_body(bid, smem, reinterpret_cast<const float*>(e.p.p2.scratch), e.p.p2.out, e.p.p2.grp, e.p.p2.lg1, 12, e.aux); break;
-            case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
-            case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
-            case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e.aux > 0 ? e.aux : 1); break;
+            case TR_FFT_TR: fft_transpose_body(bid, smem, reinterpret_cast<const float*>(e.p.p2.scratch), e.p.p2.out, e.p.p2.grp, e.p.p2.lg1, 12, e_aux); break;
+            case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
+            case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
+            case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             default: break;
             }
         }

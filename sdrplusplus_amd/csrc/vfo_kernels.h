@@ -1528,6 +1528,7 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     for (int it = 0; it < ntl; it++) {
         const int tb = tile0 + it;
         planes_store();   // registers -> this wavefront's planes (the previous tile's reads are complete: wave_sync below)
+        if (it == 0) { TICK_MARK(3); }
         tile_phasor(tb);
         if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop
         wave_sync();

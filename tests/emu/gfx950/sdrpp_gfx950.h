@@ -38,6 +38,12 @@ static inline int wave_upper_bound(const int* ends, int n, int b, int* prev_end)
     *prev_end = idx > 0 ? ends[idx - 1] : 0;
     return idx;
 }
+static inline int wave_upper_bound64_rec(const int* ends, int n, int b, int* prev_end, const void* recs, int stride_bytes, int (&rec)[6]) {
+    const int idx = wave_upper_bound(ends, n, b, prev_end);
+    const int* r = reinterpret_cast<const int*>(reinterpret_cast<const char*>(recs) + (size_t)(idx < 64 ? idx : 63) * (size_t)stride_bytes);
+    for (int k = 0; k < 6; k++) { rec[k] = r[k]; }
+    return idx;
+}
 static inline void lds_flag_set(int* f, int v) { *(volatile int*)f = v; }
 static inline void lds_flag_wait_ge(int* f, int need, int* /*timeouts*/) { while (*(volatile int*)f < need) { hipemu::yield(); } }  // the other wavefronts' fibers run meanwhile
 static inline void wave_prio_high() {}
