@@ -708,6 +708,43 @@ def test_packed_reads(backend):
     ctx.close()
 
 
+def test_read_many_size_query_and_streams(backend):
+    """sdrpp_vfo_read_many: a NULL destination is a size query (offsets / counts / total, nothing copied: the binding sizes its buffer from
+    it instead of max_push x VFOs); the packed blocks equal the per-VFO reads for every stream (demodulator output, IF, AF); a buffer
+    that is too small is refused with the total in the message."""
+    import ctypes as C
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr = 10e6
+    x = workloads.synth(3, 60000, seed=43, nvfo=4)
+    plan = workloads.vfo_plan(3, 4)
+    ctx, vids, _, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan[:3]], 60000)
+    a, keep = radio.af_desc(250e3, 48000.0, 50e-6, False)
+    for v in vids:
+        ctx.vfo_set_af(v, a, keep)
+    ctx.push(x)
+    n = len(vids)
+    ids = (C.c_int * n)(*vids)
+    for which in (None, [1] * n, [2] * n, [0, 1, 2]):
+        wh = (C.c_int * n)(*which) if which is not None else None
+        offs, cnts = (C.c_int64 * n)(), (C.c_int * n)()
+        total = ctx._chk(ctx.L.sdrpp_vfo_read_many(ctx.h, n, ids, wh, None, 0, offs, cnts))
+        single = []
+        for i, v in enumerate(vids):
+            w = 0 if which is None else which[i]
+            single.append(ctx.vfo_read(v) if w == 0 else (ctx.vfo_read_if(v).view(np.float32).reshape(-1, 2) if w == 1 else ctx.vfo_af_read(v)))
+        assert total == sum(len(b) for b in single) > 0
+        assert [cnts[i] for i in range(n)] == [len(b) for b in single]
+        assert [offs[i] for i in range(n)] == list(np.cumsum([0] + [len(b) for b in single[:-1]]))
+        got = ctx.vfo_read_many(vids, which=which)
+        for g, b in zip(got, single):
+            assert g.shape == b.shape and np.array_equal(g, b)
+        small = np.empty((total - 1, 2), np.float32)
+        rc = ctx.L.sdrpp_vfo_read_many(ctx.h, n, ids, wh, small.ctypes.data_as(C.POINTER(C.c_float)), len(small), offs, cnts)
+        assert rc < 0 and str(total) in ctx.L.sdrpp_last_error(ctx.h).decode()
+    ctx.close()
+
+
 def test_deferred_pushes_equal_block_by_block(backend):
     """sdrpp_set_deferred: pushes are staged and the next observing call processes them as ONE pass.  The result is the concatenation of
     what pushing and reading block by block gives — including the block-dependent AGC look-ahead (bursts make it rescan), because every
