@@ -2649,8 +2649,12 @@ inline int tick_role_weight(int role, bool crowded) {
     // blocks (profiles/r03z_tick_p1_weight.log; SDRPP_GPU_TICK_P1_WEIGHT: measurement switch)
     static const int p1_weight = getenv("SDRPP_GPU_TICK_P1_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_P1_WEIGHT")) : 0;
     if (role >= TR_FFT_P1_5 && role <= TR_FFT_P1_10) { return p1_weight > 0 ? p1_weight : (crowded ? 45 : 70); }
+    // the long first stages (cfg 4): far more workgroups than the GPU holds — behind the sequential recursions and the filters, whose few long
+    // workgroups then run beside them instead of after them (10^6-sample blocks 4.25 -> 4.33 GS/s, 307 200: 3.08 -> 3.24;
+    // profiles/r03zj_tick_fcl_weight.log; SDRPP_GPU_TICK_FCL_WEIGHT: measurement switch)
+    static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 58;
     switch (role) {
-    case TR_FCL_0: case TR_FCL_PF: return 100;
+    case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;
     case TR_SEQ: return 85;
     case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
