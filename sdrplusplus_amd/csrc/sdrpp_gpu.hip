@@ -307,6 +307,8 @@ struct sdrpp_ctx {
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
     // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
     // and the input is 8 bytes per sample however often it is read.
+    // 32-output tiles per front-end job up to which the ratio-32 front end runs in its small-block shape (vfo_frontcm16_body); 0: never
+    int fcm16_max_tiles = getenv("SDRPP_GPU_FCM16_MAX_TILES") ? atoi(getenv("SDRPP_GPU_FCM16_MAX_TILES")) : 0;
     // phases handed over per full chunk: every 4th / 8th / 16th (cfg 4's 43 SSB channels, the family's time per 2^20 samples: 14.2 / 13.4 / 13.0 ms,
     // profiles/r03x_*; the applying wavefronts take up to SKIP - 1 steps per sample themselves, so fewer VFOs per workgroup go with a larger stride)
     int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 16;
@@ -821,6 +823,7 @@ void launch_role(sdrpp_ctx* c, const sdrpp_ctx::RoleLaunch& r) {
     case TR_FCM_6: hipLaunchKernelGGL((vfo_frontcm_kernel<6, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCM_10: hipLaunchKernelGGL((vfo_frontcm_kernel<10, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCM_16: hipLaunchKernelGGL((vfo_frontcm_kernel<16, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCM16_132_4: hipLaunchKernelGGL((vfo_frontcm16_kernel<132, 4>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCL_0: hipLaunchKernelGGL((vfo_frontcl_kernel<0>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCL_PF: hipLaunchKernelGGL((vfo_frontcl_kernel<SDRPP_FCL_PF>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_TOEP_C: hipLaunchKernelGGL((vfo_toep_kernel<2, 2, false>), grid, b256, r.lds, st, (const ToepJob*)e.jobs); break;
@@ -2107,6 +2110,19 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
             for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
             const int role = (k == 1 && all_132_4) ? TR_FCM_132_4 : (k == 0 ? TR_FCM_6 : (k == 1 ? TR_FCM_10 : TR_FCM_16));
+            // small blocks: every wavefront of the 32 x 32 x 2 form would have ONE tile and spend 4 us in its matrix loop alone — a workgroup
+            // per tile in the 16 x 16 x 4 shape instead (same sums in the same order: bit-identical), up to fcm16_max_tiles tiles per job
+            int max_tiles = 0;
+            bool one_tile = true;
+            for (auto& jb : fcm[k].jobs) {
+                max_tiles = std::max(max_tiles, (jb.nout + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE);
+                one_tile = one_tile && jb.tiles_per_wave == 1;
+            }
+            if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= c->fcm16_max_tiles) {
+                if (getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp] front end in its small-block shape: %d tiles x %zu jobs\n", max_tiles, fcm[k].jobs.size()); }
+                emit(c, 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
+                continue;
+            }
             emit(c, 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
         }
         if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
@@ -2655,7 +2671,7 @@ inline int tick_role_weight(int role, bool crowded) {
     static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 58;
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
-    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: return 90;
+    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
     case TR_SEQ: return 85;
     case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
     case TR_TOEP_Q: return 65;

@@ -69,6 +69,7 @@ enum TickRole : int {
     TR_FCM_6,      // <6, 0, 0>
     TR_FCM_10,     // <10, 0, 0>
     TR_FCM_16,     // <16, 0, 0>
+    TR_FCM16_132_4,  // vfo_frontcm16_body<132, 4>: the ratio-32 front end in 16 x 16 x 4 shape, one 32-output tile per WORKGROUP (small blocks)
     TR_FCL_0,      // vfo_frontcl_body<0> (two wavefronts per workgroup)
     TR_FCL_PF,     // vfo_frontcl_body<SDRPP_FCL_PF> (247 registers: only in the SET = 1 build of the kernel)
     TR_TOEP_C,     // ToepJob[gy]: vfo_toep_body<2, 2, false>
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_FCM_6: { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCM_10: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCM_16: { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCM16_132_4: { const IqSrc src = e.p.src; vfo_frontcm16_body<132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCL_0: { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCL_PF:
                 if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }

@@ -115,8 +115,6 @@ __device__ __forceinline__ void stage1_accumulate_static(const float2* xs, int p
     const float2* xj = xs + j;
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int kb = K - 1 - k;
         const float2 a = xj[(k & (D - 1)) * pitch + (k >> LGD)];
         float2 b = xj[(kb & (D - 1)) * pitch + (kb >> LGD)];
@@ -1617,6 +1615,151 @@ template <int PF, int KS, int LGDS>
 __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
     HIP_DYNAMIC_SHARED(float, smemf)
     vfo_frontcm_body<PF, KS, LGDS>(kidx(blockIdx), smemf, src, jobs);
+}
+
+// ---- the same front end in the 16 x 16 x 4 matrix shape, for SMALL blocks ---------------------------------------------------------------
+// At the reference's own block size (sr/200 = 50 000 samples: 98 tiles of 32 outputs for the ratio-32 plan) every wavefront of the kernel
+// above has ONE tile, and its 132 matrix instructions of 64 cycles each are 4 of the 12 us a front-end workgroup lives — the longest role of
+// a 13 us tick.  Here a WORKGROUP takes one 32-output tile and its four wavefronts a quarter each: 16 VFOs x 16 outputs, two tap pairs per
+// v_mfma_f32_16x16x4_f32 (k = 0: gr * sums, 1: -gi * differences of pair p; k = 2, 3: the same of pair p + 1), 66 instructions of 32 cycles
+// instead of 132 of 64.  The matrix instruction accumulates its k in order, so every output is the same chain of fmaf's as in the 32 x 32 x 2
+// form — pair after pair, sums before differences — and the NCO values come from the same tile phasor and the same in-tile table:
+// bit-identical outputs (test_small_block_front_end_shape_is_bit_identical).  Same tap operand table, same job.
+struct FCM16Layout { int pl, a_off, pt_off, out_off, total; };
+__host__ __device__ inline FCM16Layout frontcm16_layout(int K, int lgD) {
+    FCM16Layout L;
+    const int nsamp = 15 * (1 << lgD) + K;
+    const int np4 = ((((K + 1) >> 1) + 3) >> 2) << 2;
+    L.pl = frontcm_plane(nsamp, lgD);
+    L.a_off = 4 * 2 * L.pl;
+    L.pt_off = L.a_off + np4 * 64;
+    L.out_off = L.pt_off + SDRPP_FCM_VT * 2;
+    L.total = L.out_off + SDRPP_FCM_VT * 2;
+    return L;
+}
+template <int KS, int LGDS>
+__device__ __forceinline__ void vfo_frontcm16_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs) {
+    const FrontCMJob& job = jobs[bid.y];
+    constexpr int K = KS, lgD = LGDS, D = 1 << lgD, VT = SDRPP_FCM_VT, tile = SDRPP_FCM_TILE;
+    constexpr int NP = (K + 1) >> 1, NP4 = ((NP + 3) >> 2) << 2, NSTEP = (NP + 1) >> 1;
+    constexpr int nsamp = 15 * D + K;
+    constexpr int PF = (nsamp + 63) / 64;
+    const FCM16Layout L = frontcm16_layout(K, lgD);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int vh = wv & 1, nh = wv >> 1;                     // this wavefront's half of the VFOs / of the tile's outputs
+    const int jj = lane & 15, kq = lane >> 4, comp = kq & 1, po = kq >> 1;  // matrix k index kq: pair p + po, sums (0) or differences (1)
+    float* XR = smemf + wv * 2 * L.pl;
+    float* XI = XR + L.pl;
+    float* AL = smemf + L.a_off;
+    float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off);      // [VT] tile phasors, shared by the workgroup
+    float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);  // [VT]
+    const int tb = bid.x;  // the 32-output tile of this workgroup
+    const long long tbase = (long long)job.off + (long long)tb * tile * D;
+    // this wavefront's IQ window and its slice of the in-tile NCO table: requested first
+    float2 pf[PF];
+    {
+        const long long base = tbase + (long long)nh * 16 * D;
+        if (base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur) {
+            const float2* p = src.cur + base;
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = lane + q * 64;
+                pf[q] = (sidx < nsamp) ? p[sidx] : make_float2(0.0f, 0.0f);
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = lane + q * 64;
+                const long long gi = base + sidx;
+                pf[q] = iq_load_nb(src, gi, sidx < nsamp && gi >= job.min_idx);
+            }
+        }
+    }
+    float2 pt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { pt[r] = global_load_f32x2(job.ptab, (vh * 16 + 4 * kq + r) * tile + nh * 16 + jj); }
+    {   // tap operand table (as in vfo_frontcm_body)
+        constexpr int NB = 5;
+        const int n4 = NP4 * 16;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        for (int i0 = tid; i0 < n4; i0 += 256 * NB) {
+            float4 tv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { tv[q] = global_load_f32x4(at4, min(i0 + q * 256, n4 - 1)); }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                if (i0 + q * 256 < n4) { AL4[i0 + q * 256] = tv[q]; }
+            }
+        }
+    }
+    if (tid < VT) {
+        outp[tid] = job.out[tid];
+        if (tid < job.nv) {  // the tile's phasor per VFO: exactly vfo_frontcm_body's tile_phasor
+            double ph = fma((double)tbase + 0.5 * (double)(K - 1), job.theta[tid], job.phi0[tid]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            ptile[tid] = make_float2(cs, sn);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int sidx = lane + q * 64;
+        if (sidx < nsamp) {
+            const int idx = sidx + (sidx >> lgD);
+            XR[idx] = pf[q].x;
+            XI[idx] = pf[q].y;
+        }
+    }
+    __syncthreads();
+    TICK_MARK(0);
+    if (tb * tile >= job.nout) { return; }
+    const float sgn = comp ? -1.0f : 1.0f;
+    const int ib = jj * D + jj;  // skewed index of IQ sample jj * D
+    // pair p = 2 m + po of step m: with K even and an even number of pairs every index below is a per-lane base + a compile-time offset
+    // ((2 m + po) >> lgD == 2 m >> lgD, and K - 1 - 2 m is odd, so taking po off it never crosses a multiple of D either)
+    static_assert((K & 1) == 0 && (NP & 1) == 0 && NSTEP * 2 == NP, "even filters with an even number of tap pairs");
+    const float* P1a = (comp ? XI : XR) + ib + po;
+    const float* P2a = (comp ? XR : XI) + ib + po;
+    const float* P1b = (comp ? XI : XR) + ib - po;
+    const float* P2b = (comp ? XR : XI) + ib - po;
+    const float* Ap = AL + po * 64 + comp * 32 + vh * 16 + jj;
+    wave_prio_low();
+    f32x4 accR = mfma4_zero(), accI = mfma4_zero();
+#pragma unroll
+    for (int m = 0; m < NSTEP; m++) {
+        const int oa = 2 * m + ((2 * m) >> lgD);
+        const int ob = (K - 1 - 2 * m) + ((K - 1 - 2 * m) >> lgD);
+        const float a1 = P1a[oa], a2 = P2a[oa];
+        const float b1 = P1b[ob], b2 = P2b[ob];
+        const float bre = fmaf(sgn, b1, a1);  // sums: a.re + b.re   differences: a.im - b.im
+        const float bim = fmaf(sgn, a2, b2);  // sums: a.im + b.im   differences: b.re - a.re (-dr: the (gr, -gi) operand serves both products)
+        const float a_op = Ap[2 * m * 64];
+        accR = mfma_16x16x4(a_op, bre, accR);
+        accI = mfma_16x16x4(a_op, bim, accI);
+    }
+    TICK_MARK(2);
+    wave_prio_high();
+    {
+        const int n = tb * tile + nh * 16 + jj;
+        const bool live = n < job.nout;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int v = vh * 16 + 4 * kq + r;
+            if (v < job.nv && live) {
+                const float2 P = ptile[v];
+                const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                global_store_f32x2(outp[v], n, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+            }
+        }
+    }
+}
+template <int KS, int LGDS>
+__global__ __launch_bounds__(256) void vfo_frontcm16_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    vfo_frontcm16_body<KS, LGDS>(kidx(blockIdx), smemf, src, jobs);
 }
 
 // Long first stages (decimation by 32 or 64 with 143...726 taps: the plans for narrow channels in a very wide capture, e.g. cfg 4's

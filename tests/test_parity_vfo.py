@@ -108,6 +108,44 @@ def test_matrix_core_front_bank(backend, nv):
     ctx.close()
 
 
+def test_small_block_front_end_shape_is_bit_identical(backend, monkeypatch):
+    """The ratio-32 front end in its small-block shape (vfo_frontcm16_body: one 32-output tile per workgroup, 16 x 16 x 4 matrix
+    instructions, SDRPP_GPU_FCM16_MAX_TILES read when a context is created) against the 32 x 32 x 2 form: IF and audio of every VFO bit
+    for bit — full and partly filled jobs (32 and 20 VFOs), pushes that end inside a tile, pushes shorter than a tile, windows that reach
+    into the history; ordinary passes and pipelined mode."""
+    from sdrplusplus_amd import workloads
+
+    sr = 10e6
+    for nv in (32, 20):
+        pushes = [50000, 1031, 20000, 7, 33333, 50000]
+        x = workloads.synth(3, sum(pushes), seed=13, nvfo=nv)
+        plan = workloads.vfo_plan(3, nv)
+        for pipelined in (False, True):
+            outs = []
+            for small in ("0", "4096"):
+                monkeypatch.setenv("SDRPP_GPU_FCM16_MAX_TILES", small)
+                ctx, vids, _, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan], max(pushes))
+                if pipelined:
+                    ctx.set_pipelined(True, 1)
+                got, pos = [], 0
+                for n in pushes:
+                    ctx.push(x[pos:pos + n])
+                    pos += n
+                    if pipelined:
+                        r = ctx.result_wait(ctx.ticket(), copy=True)
+                        got.append([r["vfo"][v] for v in vids])
+                        ctx.result_release(r["ticket"])
+                    else:
+                        got.append([a.copy() for a in ctx.vfo_read_many(vids)] + [a.copy() for a in ctx.vfo_read_many(vids, which=[1] * len(vids))])
+                outs.append(got)
+                ctx.close()
+            for ga, gb in zip(*outs):
+                assert len(ga) == len(gb)
+                for a, b in zip(ga, gb):
+                    assert a.shape == b.shape and np.array_equal(a, b)
+            assert sum(len(a) for a in outs[0][0]) > 0
+
+
 def test_long_first_stage_bank(backend):
     """cfg 4 geometry (61.44 MS/s; plans 1024 / 4096 / 2048 with a /64 first stage of 257 / 400 / 329 taps): 18 VFOs per mode take
     the matrix-core kernel for long first stages (vfo_frontcl_kernel), the stages behind it the Toeplitz kernels."""
