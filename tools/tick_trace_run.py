@@ -14,6 +14,7 @@ capi.DEFAULT_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", "libsdrpp_gpu_t
 import torch  # noqa: E402
 
 cfg, B, n, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+from_host = len(sys.argv) > 5 and sys.argv[5] == "host"  # blocks fetched from page-locked host memory by the tick's landing copy
 os.environ["SDRPP_TICK_TRACE_FILE"] = path
 if os.path.exists(path):
     os.remove(path)
@@ -22,8 +23,19 @@ ctx = capi.Context(0, max_push=B)
 workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo or None)
 xd = [torch.from_numpy(workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None).view(np.float32)).to("cuda") for i in range(4)]
 ctx.set_pipelined(True, 0)
+if from_host:
+    import ctypes as C
+    ptrs = []
+    for i in range(4):
+        x = workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None)
+        p = ctx.L.sdrpp_host_alloc(B * 8)
+        C.memmove(p, x.ctypes.data, B * 8)
+        ptrs.append(p)
 for i in range(n):
-    ctx.push_device(xd[i % 4].data_ptr(), B)
+    if from_host:
+        ctx.push_host_ptr_async(ptrs[i % 4], B)
+    else:
+        ctx.push_device(xd[i % 4].data_ptr(), B)
 ctx.sync()
 ctx.close()
 print("dumped", os.path.getsize(path) // 72, "records")
