@@ -3,7 +3,7 @@
 # PMC passes (FETCH_SIZE / WRITE_SIZE / matrix-pipe busy cycles, one pass each) of the headline workload (pipelined mode, 10^6-sample blocks),
 # tick timelines.   usage: bash tools/profile_all.sh [tag]
 set -u
-TAG=${1:-r03m}
+TAG=${1:-r03zh}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
