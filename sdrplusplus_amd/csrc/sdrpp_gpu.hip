@@ -307,8 +307,12 @@ struct sdrpp_ctx {
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
     // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
     // and the input is 8 bytes per sample however often it is read.
-    // 32-output tiles per front-end job up to which the ratio-32 front end runs in its small-block shape (vfo_frontcm16_body); 0: never
-    int fcm16_max_tiles = getenv("SDRPP_GPU_FCM16_MAX_TILES") ? atoi(getenv("SDRPP_GPU_FCM16_MAX_TILES")) : 0;
+    // 32-output tiles per front-end job up to which the ratio-32 front end runs in its small-block shape (vfo_frontcm16_body); 0: never.
+    // Unset: 256 for pipelined blocks that are read where they lie in device memory (sr/200 blocks 3.48 -> 3.96 GS/s), never for blocks the
+    // tick's landing copy fetches from host memory — workgroups that share a CU with a landing-copy workgroup start 8 us late, which the longer
+    // front end hides and the short one does not (profiles/r03zl-r03zn) — and never for ordinary passes.
+    int fcm16_max_tiles = getenv("SDRPP_GPU_FCM16_MAX_TILES") ? atoi(getenv("SDRPP_GPU_FCM16_MAX_TILES")) : -1;
+    bool plan_block_from_host = false;    // the block being planned reaches the device through a landing copy
     // phases handed over per full chunk: every 4th / 8th / 16th (cfg 4's 43 SSB channels, the family's time per 2^20 samples: 14.2 / 13.4 / 13.0 ms,
     // profiles/r03x_*; the applying wavefronts take up to SKIP - 1 steps per sample themselves, so fewer VFOs per workgroup go with a larger stride)
     int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 16;
@@ -2118,7 +2122,8 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
                 max_tiles = std::max(max_tiles, (jb.nout + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE);
                 one_tile = one_tile && jb.tiles_per_wave == 1;
             }
-            if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= c->fcm16_max_tiles) {
+            const int small_limit = c->fcm16_max_tiles >= 0 ? c->fcm16_max_tiles : ((c->tick_planning && !c->plan_block_from_host) ? 256 : 0);
+            if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= small_limit) {
                 if (getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp] front end in its small-block shape: %d tiles x %zu jobs\n", max_tiles, fcm[k].jobs.size()); }
                 emit(c, 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
                 continue;
@@ -2965,6 +2970,7 @@ int stage_pending_wait(sdrpp_ctx* c) {
 // One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
 int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
     if (count == 0) { return SDRPP_OK; }
+    c->plan_block_from_host = land != nullptr && land->bytes > 0;
     bool as_tick = tick_eligible(c);
     if (as_tick) {  // rings of the per-block buffers, result slots (allocated on first use / after a change of the configuration)
         for (auto& kv : c->vfos) {
