@@ -2742,6 +2742,12 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         lds = std::max(lds, r.lds);
         set1 = set1 || r.e.role == TR_FCL_PF;
     }
+    {   // where the stage-0 copies stand among the tick's workgroups (SDRPP_GPU_TICK_L0_AT: 0 = in front (default), -1 = behind all roles, n = behind
+        // the first n role workgroups): a switch for the measurement DESIGN.md 4b names as the next step
+        static const int l0_at = getenv("SDRPP_GPU_TICK_L0_AT") ? atoi(getenv("SDRPP_GPU_TICK_L0_AT")) : 0;
+        const int role_blocks = blocks - l0.blocks[0] - l0.blocks[1];
+        l0.first = l0_at < 0 ? role_blocks : std::min(l0_at, role_blocks);
+    }
     if (blocks == 0) {  // nothing to do at all (an idle flush)
         c->next_tab = tab_dev_next;
         c->next_tab_n = tab_n_next;

@@ -114,6 +114,8 @@ struct TickTable {
 struct TickL0 {
     CopyJob job[2];  // [0] landing copy, [1] job tables of this block + role table of the NEXT tick -> device arena
     int blocks[2];
+    int first;       // index of the first of these workgroups in the launch grid (0: in front of the roles)
+    int pad;
 };
 // completion without a host API call: every wavefront counts itself done, the last one publishes the tick's number in page-locked
 // host memory that the host polls (7 us from launch to "host knows" against 12.5 us for hipStreamSynchronize)
@@ -196,16 +198,20 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
     HIP_DYNAMIC_SHARED(float, smem)
     int b = (int)blockIdx.x;
     const int nb0 = l0.blocks[0] + l0.blocks[1];
+    // (where in the grid the stage-0 copies stand is the host's choice — workgroups are handed out round the CUs in index order, and a
+    // workgroup that shares a CU with a landing copy from host memory waits behind its reads over the bus: DESIGN.md 4b)
+    const bool is_l0 = b >= l0.first && b < l0.first + nb0;
+    if (is_l0) { b -= l0.first; }
+    else if (b >= l0.first + nb0) { b -= nb0; }
 #ifdef SDRPP_TICK_TRACE
     const unsigned long long tr_t0 = (unsigned long long)wall_clock64();
     int tr_role = -1, tr_entry = -1;
 #endif
-    if (b < nb0) {
+    if (is_l0) {
         if (b < l0.blocks[0]) { copy_one(l0.job[0], b, l0.blocks[0]); }
         else { copy_one(l0.job[1], b - l0.blocks[0], l0.blocks[1]); }
     }
     else {
-        b -= nb0;
         const int n = tab->n;
         int first = 0;
         // the entry's header (role, grid, aux, job table) comes with the look-up itself; only the per-role parameter block `p` still costs a
