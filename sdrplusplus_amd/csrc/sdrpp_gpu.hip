@@ -284,6 +284,7 @@ struct sdrpp_ctx {
     bool pipelined = false;
     int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
     int num_cus = 256;
+    int tick_l0_at = getenv("SDRPP_GPU_TICK_L0_AT") ? atoi(getenv("SDRPP_GPU_TICK_L0_AT")) : 0;  // (read when the context is created)
     bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
     // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
     // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
@@ -2744,7 +2745,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     }
     {   // where the stage-0 copies stand among the tick's workgroups (SDRPP_GPU_TICK_L0_AT: 0 = in front (default), -1 = behind all roles, n = behind
         // the first n role workgroups): a switch for the measurement DESIGN.md 4b names as the next step
-        static const int l0_at = getenv("SDRPP_GPU_TICK_L0_AT") ? atoi(getenv("SDRPP_GPU_TICK_L0_AT")) : 0;
+        const int l0_at = c->tick_l0_at;
         const int role_blocks = blocks - l0.blocks[0] - l0.blocks[1];
         l0.first = l0_at < 0 ? role_blocks : std::min(l0_at, role_blocks);
     }
