@@ -58,12 +58,12 @@ def _compare(ref, got, fft, what):
             assert np.array_equal(ref["index"], got["index"]), what + " palette index"
 
 
-@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "-1")])
+@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37")])
 def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatch):
     """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks.  l0_at: the stage-0
-    copies of a tick (landing copy, job-table upload) behind the first 37 role workgroups / behind all roles instead of in front
-    (SDRPP_GPU_TICK_L0_AT, read when a context is created)."""
+    copies of a tick (landing copy, job-table upload) behind the first 37 role workgroups instead of in front (SDRPP_GPU_TICK_L0_AT,
+    read when a context is created)."""
     from sdrplusplus_amd import workloads
 
     if l0_at is not None:
