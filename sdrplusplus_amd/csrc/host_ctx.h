@@ -1,0 +1,330 @@
+// The context: constants, per-stream / per-VFO state, struct sdrpp_ctx (what one IQ stream on one GPU owns).
+// Part of the one translation unit sdrpp_gpu.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+constexpr int kArenaSlots = 16;     // >= kTickDepth + 2: a block's job tables are read for kTickDepth ticks after their upload
+constexpr size_t kArenaBytes = 4u << 20;
+constexpr int kRing = 4;            // pipelined mode: buffers per per-block stream (a consumer runs at most 2 ticks behind its producer; + the gather)
+constexpr int kTickDepth = 10;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit())
+constexpr int kResSlots = 16;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
+constexpr int kStageSlots = 4;      // pipelined mode: page-locked staging buffers for pushes from pageable host memory
+constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
+constexpr size_t kScratchBytes = 64u << 20;
+constexpr int kMaxLds = 64 * 1024;
+
+enum Family { F_FFT1 = 0, F_FFT2, F_FFTS, F_ZOOM, F_S1, F_DECIM, F_POLY, F_FIR, F_DEMOD, F_MISC, F_AF, F_PIPE, F_TICK };
+const char* kFamilyNames[SDRPP_NUM_KERNEL_FAMILIES] = { "fft_pass1", "fft_pass2", "fft_single", "zoom_palette", "vfo_stage1",
+                                                        "vfo_decim", "vfo_poly",  "vfo_fir",    "demod",        "carry_misc", "af_chain",  "vfo_pipe", "tick" };
+
+struct Stream {
+    int width = 2;
+    int hist_len = 0;
+    float* data = nullptr;
+    float* base = nullptr;  // the allocation `data` lives in (data = base + skew, see stream_alloc)
+    size_t cap = 0;  // samples
+    float* hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    int n = 0;
+    // pipelined mode: the other kRing - 1 data buffers (base allocations); `base` / `data` rotate through them block by block so that
+    // the producer of block n + 1 does not overwrite what a consumer of block n still reads (stream_rotate)
+    float* extra[kRing - 1] = {};
+    int n_extra = 0, rot = 0;
+    int clevel = 0;  // pipelined mode: level of the role that consumes this stream with memory (its history carry runs there)
+};
+
+// Tap tables of the matrix-core FIR kernel (vfo_toep_kernel): zero-padded taps + per-lane base indices (one set per carried
+// resampler phase).
+struct ToepTab {
+    float* d_tl = nullptr;
+    int* d_lb = nullptr;  // [nvar][64]
+    int tl_len = 0, nsteps = 0, s_in = 0, rows = 0, nvar = 0;
+    int kind = 0;  // 1 decimator, 2 resampler, 4 channel filter, 8 audio low-pass
+    bool ok = false;
+};
+
+struct Vfo {
+    bool nco_exact = false;        // this VFO runs the reference's float rotator recursion (desc.nco_mode, else the context's mode)
+    int id = 0;
+    sdrpp_vfo_desc d{};
+    std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
+    std::vector<float> rtaps, ctaps_chan, ataps;
+    // NCO
+    double theta = 0.0, phi = 0.0;
+    std::vector<float2> modtaps;  // stage-1 modulated taps
+    bool modtaps_dirty = true;
+    // integer streaming state
+    int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+    int tpp = 0, pphase = 0, poff = 0;
+    long long seen = 0;  // input samples this VFO has consumed since it was added / reset (bounds its view of the IQ history)
+    // device constants
+    float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };  // phase-major, padded (FirBJob)
+    float* d_staps_nat[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };  // natural order (fused front kernel)
+    int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+    float* d_bank = nullptr;
+    float* d_cyc = nullptr;  // blocked polyphase: [interp][rows][lmax] cycle tap tables (one per carried phase)
+    int cyc_rows = 0, cyc_lmax = 0;
+    int chan_kp = 0, audio_kp = 0;
+    float* d_chan = nullptr;
+    int chan_ntaps = 0;
+    float* d_audio = nullptr;
+    int audio_ntaps = 0;
+    // device loop state: [AgcState agc][AgcState carrier][float dc]
+    char* d_state = nullptr;
+    double theta2 = 0.0, phi2 = 0.0;
+    // streams: 0..nstages-1 decimator outputs (index 0 also used by the rotate-only path), then poly, chan, dem, out
+    std::vector<Stream> st;
+    int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
+    int lvl_if = 1, lvl_out = 1;  // levels (do_vfos_plan) at which the IF stream / the output of the most recent block are written
+    ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
+    // front end as one filter (what the fused translate + filter kernels evaluate): stages 0 (+ 1) of the plan
+    bool fused_front = false;      // stages 0 and 1 run as one composite filter (front2_t2 > 0)
+    bool no_fuse = false;          // stage-1 taps are not linear phase: the composite forms do not apply
+    unsigned long long tap_hash = 0;  // of the stage-0 / stage-1 taps: only VFOs with identical taps share a front-end job
+    float* d_h12 = nullptr;        // composite (or stage-0) taps, real, natural order — used by the retune hand-over kernel
+    int h12_K = 0, h12_lgD = 0;
+    // RxVFO::setOffset hand-over (closed-form NCO): retune points whose old-increment samples a filter window can still reach
+    struct Retune { long long pos; double theta_before; };  // pos: input samples consumed (Vfo::seen) when the increment changed
+    std::vector<Retune> recs;
+    // reference-rotator mode (sdrpp_set_nco_mode): rotated full-rate stream + persistent float phases (main xlator, SSB xlator)
+    int i_rot = -1;
+    float2* d_rot = nullptr;
+    // radio AF chain (sdrpp_vfo_set_af): RationalResampler<stereo_t> -> high-pass -> de-emphasis, fed by st[i_out]
+    struct Af {
+        bool on = false;
+        int n_stages = 0, decim_s[SDRPP_MAX_DECIM_STAGES] = { 1, 1, 1, 1 };
+        std::vector<float> staps[SDRPP_MAX_DECIM_STAGES], rtaps, htaps;
+        float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+        int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_hpf;
+        int interp = 1, decim = 1, tpp = 0;
+        float* d_bank = nullptr;
+        float* d_hpf = nullptr;
+        int hpf_kp = 0;
+        float alpha = 0.0f;
+        float2* d_last = nullptr;  // Deemphasis::lastOut
+        float4* d_seg = nullptr;   // per-segment affine maps of the de-emphasis scan
+        int seg_cap = 0;
+        int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        int pphase = 0, poff = 0;
+        int i_stage0 = -1, i_poly = -1, i_hpf = -1, i_deemp = -1, i_last = -1;  // indices into st (i_last: where the AF output is)
+        int base = -1;  // first AF stream in st (they are appended behind the VFO's own streams)
+    } af;
+};
+
+struct TimingPair { hipEvent_t a, b; int family; };
+
+}  // namespace
+
+struct sdrpp_ctx {
+    int device = 0;
+    int64_t max_push = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;         // main stream (VFO bank, copies); may be the caller's
+    hipStream_t fft_stream = nullptr;     // FFT branch runs here, concurrently with the VFO bank (HBM-bound vs VALU-bound)
+    hipStream_t launch_stream = nullptr;  // stream the next launches / timers go to
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::string err;
+    std::string devinfo;
+
+    // input: landing buffers of host pushes / of a deferred pass (max_push complex each), ping-pong per pass so that the copies of the
+    // next pass overlap the kernels of the current one; copies run on their own stream and are host-synchronised (the caller's
+    // buffer is free again when sdrpp_push returns, like a dsp::stream read buffer after flush())
+    float* iq_land[2] = { nullptr, nullptr };
+    int16_t* iq_land16[2] = { nullptr, nullptr };
+    hipEvent_t land_ev[2] = { nullptr, nullptr };   // recorded behind the pass that read the buffer
+    bool land_used[2] = { false, false };
+    int land_cur = 0;
+    hipStream_t copy_stream = nullptr;
+    bool async_staged = false;     // sdrpp_push_pinned_async copies enqueued since the last pass (the pass waits for them on the device)
+    bool async_inflight = false;   // ... and not yet known to have landed: cleared only by a HOST synchronisation of the copy stream (sdrpp_push_wait)
+    hipEvent_t ev_copy = nullptr;
+    // deferred processing (sdrpp_set_deferred): pushes are only staged; the next observing call processes them as ONE pass
+    bool deferred = false;
+    int64_t pending = 0;
+    std::vector<int> pend_ends;       // cumulative end of every staged push
+    float* iq_hist[2] = { nullptr, nullptr };
+    int iq_hist_cap = 0;              // samples of history kept
+    int iq_cur = 0;
+
+    // IQFrontEnd pre-processing chain (sdrpp_preproc_configure): PowerDecimator -> DCBlocker -> Conjugate on the wideband stream,
+    // in front of the FFT branch and the VFO bank (iq_frontend.cpp:32-39)
+    struct Pre {
+        bool ref_order = false;            // sdrpp_preproc_set_reference_order: the reference's own summation order / sequential DC blocker
+        bool on = false;
+        int n_stages = 0, decim_s[SDRPP_MAX_DECIM_STAGES] = { 1, 1, 1, 1 };
+        std::vector<float> staps[SDRPP_MAX_DECIM_STAGES];
+        ToepTab tp[SDRPP_MAX_DECIM_STAGES];
+        float* d_staps[SDRPP_MAX_DECIM_STAGES] = { nullptr, nullptr, nullptr, nullptr };
+        int s_kp[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
+        float dc_rate = 0.0f;
+        int conj = 0;
+        Stream raw;               // history of the caller's buffer (data stays the caller's)
+        std::vector<Stream> st;   // decimator stage outputs
+        Stream out;               // DC blocker / conjugate output
+        float2* d_off = nullptr;  // DCBlocker::offset
+        float4* d_seg = nullptr;
+        int seg_cap = 0;
+        const float* last = nullptr;  // what the chain handed on for the most recent push
+        int last_n = 0;
+    } pre;
+
+    // WaterFall display state (sdrpp_wf_*): raw-line ring in HBM, FFT trace smoothing / hold
+    struct Wf {
+        int height = 0;
+        float* d_ring = nullptr;  // [height][fft_size]
+        int cur = 0, lines = 0;   // currentFFTLine, fftLines (waterfall.cpp:879-882)
+        int width = 0;            // data_width the trace arrays were sized for
+        float* d_latest = nullptr;
+        float* d_smooth = nullptr;  // nullptr = smoothing off
+        float* d_hold = nullptr;
+        bool hold_on = false, have_latest = false;
+        float alpha = 0.0f, beta = 1.0f, hold_speed = 0.0f;
+    } wf;
+
+    char* d_pack = nullptr;  // scratch of the packed-sample reads (sdrpp_vfo_read_pcm / _compressed)
+    size_t pack_cap = 0;
+    float2* d_gather = nullptr;     // sdrpp_vfo_read_many: packed outputs + job table
+    size_t gather_cap = 0;          // samples
+    GatherJob* d_gather_jobs = nullptr;
+    int gather_jobs_cap = 0;
+
+    // job arena
+    char* arena_host[kArenaSlots] = {};
+    char* arena_host_dev[kArenaSlots] = {};  // device-side address of the same pinned memory
+    hipEvent_t arena_ev[kArenaSlots] = {};
+    bool arena_used[kArenaSlots] = {};
+    char* arena_dev_slot[kArenaSlots] = {};  // a device arena per slot: the job tables of a block outlive its first launch in pipelined mode
+    char* arena_dev = nullptr;               // = arena_dev_slot[arena_slot]
+    int arena_slot = 0;
+    size_t arena_off = 0;
+
+    // FFT
+    bool fft_on = false;
+    int fft_size = 0, fft_lg = 0, nz = 0, skip = 0;
+    float* d_window = nullptr;
+    float2* d_tw1 = nullptr;   // tw(e, N1) / tw(e, N) for single pass, e < L/2
+    float2* d_tw2 = nullptr;
+    float2* d_twn = nullptr;   // [k1][n2] tw(n2*k1, N)
+    float2* d_scratch = nullptr;
+    float* d_lines = nullptr;
+    float* d_lines_grp = nullptr;  // per line: maxima of aligned groups of zoom_grp bins (pass 2 writes them for the zoom kernel); N > 4096 only
+    int zoom_grp = 0;
+    size_t lines_cap = 0;
+    int64_t fft_pos = 0, fft_next = 0;
+    int n_lines = 0;
+    // view
+    int view_start = 0, view_size = 0, data_width = 0;
+    float wf_min = -120.0f, wf_max = 0.0f;
+    int32_t* d_zstart = nullptr;
+    std::vector<int32_t> h_zstart, h_zcount;  // host copies of the view's pixel ranges (zoom_lanes)
+    int zoom_tp_cache = 0, zoom_tp_grp = -1;     // lanes per pixel for (the view, zoom_grp == zoom_tp_grp)
+    int32_t* d_zcount = nullptr;
+    float* d_zoomed = nullptr;
+    int32_t* d_index = nullptr;
+    size_t zoom_cap = 0;
+    // pipelined mode: the other kRing - 1 sets of the per-block FFT buffers (scratch, lines, group maxima, zoomed, index); the members
+    // above rotate through them block by block (fft_ring_rotate), so they always name the buffers of the most recent block
+    struct FftBufs { float2* scratch = nullptr; float* lines = nullptr; float* grp = nullptr; float* zoomed = nullptr; int32_t* index = nullptr; };
+    FftBufs fft_extra[kRing - 1];
+    int fft_extra_n = 0, fft_rot = 0;
+
+    // reference block structure / NCO flavour (sdrpp_set_reference_block, sdrpp_set_nco_mode)
+    int ref_block = 0;             // 0: one push = one reference block
+    int nco_exact = 0;             // 1: the reference's float rotator recursion instead of the closed-form NCO
+    int pipe_on = 1;               // FM back ends as one pipelined launch where that pays (sdrpp_set_backend_pipeline)
+    bool pipe_launched = false;    // since the last host synchronisation that looked at the kernels' timeout counter (pipe_timeouts_check)
+    int timeouts_seen = 0;         // value of the counter (h_tick_flag[8]) at that look
+    std::vector<int> vfo_bounds;   // reference-block ends (cumulative sample counts) of the current push at the VFO bank's input
+
+    // VFOs
+    std::map<int, std::unique_ptr<Vfo>> vfos;
+    int next_id = 1;
+    // cached stage-1 job tap arrays, keyed by membership signature
+    std::map<std::string, float2*> s1_tap_cache;  // key = 16 raw bytes: two independent 64-bit hashes of (kind, member ids, increments)
+
+    // ---- pipelined ("tick") execution: one launch per block, the stages of consecutive blocks skewed over consecutive launches
+    //      (tick_kernels.h; sdrpp_set_pipelined) ----
+    struct RoleLaunch { TickEntry e; size_t lds; int level; int fam; };
+    struct Result {                       // what the host knows about the block in a result slot
+        uint64_t ticket = 0;              // 0: slot free
+        uint64_t done_tick = 0;           // its last level has run when this many ticks have completed
+        bool held = false;                // handed out by sdrpp_result_wait, not yet released
+        std::vector<int> ids, counts;
+        std::vector<int64_t> offsets;
+        int n_lines = 0;
+        size_t off_zoomed = 0, off_index = 0, off_raw = 0;  // byte offsets in the slot
+    };
+    bool pipelined = false;
+    int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
+    int num_cus = 256;
+    int tick_l0_at = getenv("SDRPP_GPU_TICK_L0_AT") ? atoi(getenv("SDRPP_GPU_TICK_L0_AT")) : 0;  // (read when the context is created)
+    bool tick_order = getenv("SDRPP_GPU_TICK_ORDER") ? atoi(getenv("SDRPP_GPU_TICK_ORDER")) != 0 : true;  // longest roles first inside a tick (diagnostic switch)
+    // grid rules of the roles inside a tick (the stand-alone kernels size their grids for a GPU of their own; in a tick ~8 roles share it, and
+    // fewer, longer workgroups amortise the per-workgroup prologues): environment overrides are for measurements
+    // workgroups of a pass-1 / pass-2 launch (fft_walk_grid; 0: one tile per workgroup).  Measured on 65536-point frames, 2^24 samples per pass
+    // (profiles/r03o_fft16_sweeps.log): pass 1 with 16 columns per workgroup 0.069 ms at one tile each, 0.064 walking from 1024 workgroups (four
+    // per CU), 0.106 from 512; pass 2 0.0565 at one tile each, 0.057-0.061 walking (its tiles are contiguous 32 KB reads: nothing to hide)
+    int fft_p1_grid = getenv("SDRPP_GPU_FFT_P1_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P1_GRID")) : 1024;
+    int fft_p2_grid = getenv("SDRPP_GPU_FFT_P2_GRID") ? atoi(getenv("SDRPP_GPU_FFT_P2_GRID")) : 0;
+    int fft_tick_grid = getenv("SDRPP_GPU_FFT_TICK_GRID") ? atoi(getenv("SDRPP_GPU_FFT_TICK_GRID")) : 0;  // ... of a pass-1 / pass-2 role inside a tick (a shared GPU: 18.4 / 16.2 / 18.8 / 18.5 GS/s at 0 / 64 / 128 / 256; cfg 2: 61.7 / - / 57.0)
+    bool fft_p1_c32 = getenv("SDRPP_GPU_FFT_P1_C32") != nullptr;  // measurement switch: 32 instead of 16 columns per pass-1 workgroup of a 65536-point transform
+    int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
+    int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
+    int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
+    long arena_begins = 0;                // blocks planned so far (block_bounds: one per ordinary pass / per block of a pipelined run)
+    int arena_allocs = 0;
+    long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
+    int test_fail_alloc = 0;
+    bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
+    const volatile uint32_t* stage_pending = nullptr;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for this word to reach 0
+    bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
+    // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
+    // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
+    // and the input is 8 bytes per sample however often it is read.
+    // 32-output tiles per front-end job up to which the ratio-32 front end runs in its small-block shape (vfo_frontcm16_body); 0: never.
+    // Unset: 256 for ordinary passes (sr/200 pushes 764 -> 814 MS/s) and for pipelined blocks that are read where they lie in device memory
+    // (3.48 -> 3.96 GS/s), never for blocks the tick's landing copy fetches from host memory — workgroups that share a CU with a landing-copy
+    // workgroup start 8 us late, which the longer front end hides and the short one does not (profiles/r03zl-r03zn).
+    int fcm16_max_tiles = getenv("SDRPP_GPU_FCM16_MAX_TILES") ? atoi(getenv("SDRPP_GPU_FCM16_MAX_TILES")) : -1;
+    bool plan_block_from_host = false;    // the block being planned reaches the device through a landing copy
+    // phases handed over per full chunk: every 4th / 8th / 16th (cfg 4's 43 SSB channels, the family's time per 2^20 samples: 14.2 / 13.4 / 13.0 ms,
+    // profiles/r03x_*; the applying wavefronts take up to SKIP - 1 steps per sample themselves, so fewer VFOs per workgroup go with a larger stride)
+    int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 16;
+    int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
+    bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
+    int plan_top = 0;                     // highest level + 1 the block being planned uses
+    std::vector<RoleLaunch> emits;        // roles of the block being planned
+    std::deque<std::vector<RoleLaunch>> tickq;  // [0]: roles of the next tick to launch, [1]: of the one after, ...
+    uint64_t ticks = 0;                   // ticks launched so far
+    uint64_t pushes = 0;                  // blocks accepted so far in pipelined mode (= ticket of the most recent one)
+    uint64_t land_tick = 0;               // landing copies of every push so far have run when this many ticks have completed
+    TickTable* next_tab = nullptr;        // device address of the role table of the next tick (uploaded by the tick before)
+    int next_tab_n = 0;
+    TickTable* empty_tab = nullptr;       // device: a table without roles
+    unsigned* d_tick_counter = nullptr;   // device: finished workgroups, running total
+    unsigned tick_target = 0;             // its value when every tick launched so far has finished
+    unsigned* h_tick_flag = nullptr;      // page-locked: completed ticks (written by the last wavefront of each tick)
+    unsigned* hd_tick_flag = nullptr;     // the same, device address
+    uint64_t arena_tick[kArenaSlots] = {};  // pipelined: the tick that uploaded from this arena slot (+1; 0 = never)
+    float* tick_land[3] = {};             // landing ring of host pushes (max_push complex each; allocated on first use)
+    float* stage_host[kStageSlots] = {};  // page-locked staging of pushes from pageable memory (max_push complex each; allocated on first use)
+    uint64_t stage_tick[kStageSlots] = {};  // the tick whose landing copy reads the slot (+1)
+    int stage_cur = 0;
+    int stage_open = -1;                  // slot handed out by sdrpp_push_stage and not yet pushed
+    char* res_host[kResSlots] = {};       // page-locked result slots
+    char* res_dev[kResSlots] = {};        // their device addresses
+    size_t res_cap = 0;                   // bytes per slot
+    Result res[kResSlots];
+
+    // timing
+    bool timing = false;
+    unsigned timing_mask = 0xffffffffu;  // families whose launches are bracketed by events while timing is on
+    std::vector<TimingPair> tpairs;
+    std::vector<hipEvent_t> ev_pool;
+    double fam_ms[SDRPP_NUM_KERNEL_FAMILIES] = {};
+    int64_t fam_launch[SDRPP_NUM_KERNEL_FAMILIES] = {};
+};

@@ -1,0 +1,451 @@
+// Pipelined execution, host side (tick_kernels.h): role queue, one launch per block, result slots, drain.
+// Part of the one translation unit sdrpp_gpu.hip (included there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// =====================================================================================================================
+// Pipelined execution (tick_kernels.h): queue, launch, drain
+// =====================================================================================================================
+void tick_wait_done(sdrpp_ctx* c, uint64_t nticks) {
+    if (!c->h_tick_flag) { return; }
+    // the flag holds the number of completed ticks modulo 2^32; at most kArenaSlots ticks are ever outstanding
+    const volatile unsigned* f = c->h_tick_flag;
+    long spins = 0;
+    while ((int)((unsigned)nticks - *f) > 0) {
+        if (++spins > 2000) { std::this_thread::yield(); }
+        if (spins > 40000000) {  // ~minutes: the device is gone; let the next HIP call report it
+            (void)hipStreamSynchronize(c->stream);
+            if ((int)((unsigned)nticks - *f) > 0) { return; }
+        }
+    }
+}
+bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag || (int)((unsigned)nticks - *(const volatile unsigned*)c->h_tick_flag) <= 0; }
+
+// One tick: level-0 work of the block that arrives with it (`land`: its landing copy, may be null; the arena slot the caller has filled
+// with the block's job tables) + every queued role whose turn it is.  The role table of the NEXT tick is appended to the arena slot and
+// travels with this tick's upload.
+// expected lifetime of a workgroup of a role relative to the others (tools/tick_trace.py timelines), for the order inside a tick
+inline int tick_role_weight(int role, bool crowded) {
+    // result copies write page-locked host memory over the bus: few workgroups whose life is mostly that round trip — started last they are the
+    // tail of the tick, started first they finish in its shadow (SDRPP_GPU_TICK_COPY_FIRST=0: the old order, for measurements)
+    static const bool copy_first = getenv("SDRPP_GPU_TICK_COPY_FIRST") ? atoi(getenv("SDRPP_GPU_TICK_COPY_FIRST")) != 0 : true;
+    if (role == TR_COPY && copy_first) { return 110; }
+    // FFT pass 1: since its workgroups walk their tiles and take the lean loader they live ~12 us at 10^6-sample blocks, shorter than the
+    // Toeplitz roles' 17-33 us.  In a CROWDED tick (more workgroups than the GPU holds at once: they are handed out in index order) they go
+    // behind the filters and pass 2, so that the tick ends on short workgroups: 18.6 -> 19.6 GS/s at 10^6-sample blocks; in a tick whose
+    // workgroups are all resident from the start the order only decides who gets going first, and pass 1 early is worth 2 % at 200 000-sample
+    // blocks (profiles/r03z_tick_p1_weight.log; SDRPP_GPU_TICK_P1_WEIGHT: measurement switch)
+    static const int p1_weight = getenv("SDRPP_GPU_TICK_P1_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_P1_WEIGHT")) : 0;
+    if (role >= TR_FFT_P1_5 && role <= TR_FFT_P1_10) { return p1_weight > 0 ? p1_weight : (crowded ? 45 : 70); }
+    // the long first stages (cfg 4): far more workgroups than the GPU holds — behind the sequential recursions and the filters, whose few long
+    // workgroups then run beside them instead of after them (10^6-sample blocks 4.25 -> 4.33 GS/s, 307 200: 3.08 -> 3.24;
+    // profiles/r03zj_tick_fcl_weight.log; SDRPP_GPU_TICK_FCL_WEIGHT: measurement switch)
+    static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 58;
+    switch (role) {
+    case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
+    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
+    case TR_SEQ: return 85;
+    case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
+    case TR_TOEP_Q: return 65;
+    case TR_TOEP_C: case TR_TOEP_R: case TR_FFT_S10: case TR_FFT_S11: case TR_FFT_S12: return 60;
+    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: case TR_FFT_P2ROW: return 50;
+    case TR_FFT_TR: return 25;
+    case TR_ROT: case TR_PRE: return 30;
+    case TR_ZOOM_16: case TR_ZOOM_4: case TR_ZOOM_1: return 20;
+    default: return 10;  // carry, copies
+    }
+}
+int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
+    std::vector<sdrpp_ctx::RoleLaunch> now;
+    if (!c->tickq.empty()) {
+        now.swap(c->tickq.front());
+        c->tickq.pop_front();
+    }
+    if ((int)now.size() != c->next_tab_n) { return fail(c, SDRPP_ERR_HIP, "internal: tick table out of step (%zu roles queued, %d uploaded)", now.size(), c->next_tab_n); }
+    // the table of the tick after this one
+    TickTable* tab_dev_next = nullptr;
+    int tab_n_next = 0;
+    if (!c->tickq.empty() && !c->tickq.front().empty()) {
+        std::vector<sdrpp_ctx::RoleLaunch>& nx = c->tickq.front();
+        // The roles of a tick are independent of each other, so their order is free — and the hardware hands out workgroups in index
+        // order: longest workgroups first (front ends, FFT pass 1, the filters; zoom / carry / copies last), so that the tick ends on
+        // short ones instead of on a front end that only got its turn when everything else was through (10^6-sample blocks: the front
+        // end started 46 us into an 81 us tick).  The table is final here: later blocks only add to later ticks.
+        if (c->tick_order) {
+            long long wgs = 0;
+            for (auto& r : nx) { wgs += (long long)r.e.gx * r.e.gy; }
+            const bool crowded = wgs > 3ll * c->num_cus;  // (three workgroups of the tick kernel per CU)
+            std::stable_sort(nx.begin(), nx.end(), [crowded](const sdrpp_ctx::RoleLaunch& a, const sdrpp_ctx::RoleLaunch& b) { return tick_role_weight(a.e.role, crowded) > tick_role_weight(b.e.role, crowded); });
+        }
+        if (nx.size() > SDRPP_TICK_MAX_ENTRIES) { return fail(c, SDRPP_ERR_UNSUPPORTED, "internal: %zu roles in one tick", nx.size()); }
+        const size_t off = (c->arena_off + 63) & ~(size_t)63;
+        if (off + sizeof(TickTable) > kArenaBytes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        TickTable* T = reinterpret_cast<TickTable*>(c->arena_host[c->arena_slot] + off);
+        T->n = (int)nx.size();
+        int total = 0;
+        for (size_t i = 0; i < nx.size(); i++) {
+            total += nx[i].e.gx * nx[i].e.gy;
+            T->block_end[i] = total;
+            T->e[i] = nx[i].e;
+        }
+        c->arena_off = off + offsetof(TickTable, e) + nx.size() * sizeof(TickEntry);
+        tab_dev_next = reinterpret_cast<TickTable*>(c->arena_dev + off);
+        tab_n_next = (int)nx.size();
+    }
+    TickL0 l0{};
+    if (land && land->bytes > 0) {
+        l0.job[0] = *land;
+        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 8191) / 8192, 64));
+    }
+    if (c->arena_off > 0) {
+        l0.job[1] = CopyJob{ c->arena_host_dev[c->arena_slot], c->arena_dev, (long long)((c->arena_off + 15) & ~(size_t)15), 0, 0 };
+        l0.blocks[1] = (int)std::max<size_t>(1, std::min<size_t>((c->arena_off + 4095) / 4096, 16));  // one 16-byte load per work-item: a round trip over the bus each
+    }
+    int blocks = l0.blocks[0] + l0.blocks[1];
+    size_t lds = 0;
+    bool set1 = false;
+    for (auto& r : now) {
+        blocks += r.e.gx * r.e.gy;
+        lds = std::max(lds, r.lds);
+        set1 = set1 || r.e.role == TR_FCL_PF;
+    }
+    {   // where the stage-0 copies stand among the tick's workgroups (SDRPP_GPU_TICK_L0_AT: 0 = in front (default), -1 = behind all roles, n = behind
+        // the first n role workgroups): a switch for the measurement DESIGN.md 4b names as the next step
+        const int l0_at = c->tick_l0_at;
+        const int role_blocks = blocks - l0.blocks[0] - l0.blocks[1];
+        l0.first = l0_at < 0 ? role_blocks : std::min(l0_at, role_blocks);
+    }
+    if (blocks == 0) {  // nothing to do at all (an idle flush)
+        c->next_tab = tab_dev_next;
+        c->next_tab_n = tab_n_next;
+        return SDRPP_OK;
+    }
+    c->tick_target += (unsigned)blocks;
+    c->ticks++;
+    TickDone done{ c->d_tick_counter, c->hd_tick_flag, c->tick_target, (unsigned)c->ticks };
+    const TickTable* tab = c->next_tab_n > 0 ? c->next_tab : c->empty_tab;
+    {
+        hipEvent_t ea = nullptr;
+        const bool timed = c->timing && ((c->timing_mask >> F_TICK) & 1u);
+        c->fam_launch[F_TICK]++;
+        if (timed) {
+            ea = get_event(c);
+            (void)hipEventRecord(ea, c->stream);
+        }
+        HostScope hs("launch");
+        if (set1) { hipLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        else { hipLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        if (timed) {
+            hipEvent_t eb = get_event(c);
+            (void)hipEventRecord(eb, c->stream);
+            c->tpairs.push_back({ ea, eb, F_TICK });
+            if (c->tpairs.size() > 8192) { timing_flush(c); }
+        }
+    }
+    c->arena_tick[c->arena_slot] = c->ticks;
+    c->next_tab = tab_dev_next;
+    c->next_tab_n = tab_n_next;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "tick launch failed: %s", hipGetErrorString(e)); }
+    return SDRPP_OK;
+}
+// run every queued role (no new input): what a caller that wants the results of the last blocks NOW pays for the skew
+int tick_drain(sdrpp_ctx* c) {
+    while (!c->tickq.empty()) {
+        int rc = arena_begin(c);
+        if (rc) { return rc; }
+        rc = tick_launch(c, nullptr);
+        if (rc) { return rc; }
+    }
+    return SDRPP_OK;
+}
+
+// Can this context's blocks run as ticks at all?  (What can only be seen while planning — a VFO group too small for the matrix front end,
+// a filter without the matrix form, more frames than one scratch chunk — aborts the plan instead.)
+bool tick_eligible(sdrpp_ctx* c) {
+    if (c->pre.on || c->wf.height > 0 || c->deferred) { return false; }
+    for (auto& kv : c->vfos) {
+        const Vfo& v = *kv.second;
+        if (v.af.on || v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
+    }
+    return true;
+}
+
+// ---- results of a block in page-locked host memory (sdrpp_set_pipelined's result flags): gather roles one level behind the producers ----
+size_t tick_results_need(sdrpp_ctx* c) {
+    size_t need = 0;
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            need += ((s.cap + 16) * 8 + 15) & ~(size_t)15;
+        }
+    }
+    if (c->fft_on) {
+        if ((c->res_flags & 2) && c->data_width > 0) { need += 2 * ((c->lines_cap * (size_t)c->data_width * 4 + 15) & ~(size_t)15); }
+        if (c->res_flags & 4) { need += (c->lines_cap * (size_t)c->fft_size * 4 + 15) & ~(size_t)15; }
+    }
+    return need;
+}
+int tick_results_ensure(sdrpp_ctx* c) {
+    const size_t need = tick_results_need(c);
+    if (need <= c->res_cap) { return SDRPP_OK; }
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res[i].held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held: release them before the outputs grow", (unsigned long long)c->res[i].ticket); }
+    }
+    int rc = tick_drain(c);
+    if (rc) { return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < kResSlots; i++) {
+        if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
+        c->res_host[i] = nullptr;
+        c->res_dev[i] = nullptr;
+        c->res[i] = sdrpp_ctx::Result{};
+    }
+    c->res_cap = 0;
+    const size_t cap = need + need / 8 + 4096;
+    for (int i = 0; i < kResSlots; i++) {
+        if (hipHostMalloc((void**)&c->res_host[i], cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c->res_dev[i], c->res_host[i], 0) != hipSuccess) {
+            return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);
+        }
+    }
+    c->res_cap = cap;
+    return SDRPP_OK;
+}
+// gather roles of the block just planned -> c->emits; fills its result slot's description
+int tick_results_plan(sdrpp_ctx* c) {
+    const int slot = (int)(c->pushes % kResSlots);
+    sdrpp_ctx::Result& R = c->res[slot];
+    if (!c->res_flags) {
+        R = sdrpp_ctx::Result{};
+        return SDRPP_OK;
+    }
+    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
+    R = sdrpp_ctx::Result{};
+    R.ticket = c->pushes;
+    Lev<CopyJob> jobs;
+    size_t off = 0;
+    char* base = c->res_dev[slot];
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const bool raw = v.d.demod == SDRPP_DEMOD_RAW;
+            const Stream& s = raw ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            R.ids.push_back(v.id);
+            R.offsets.push_back((int64_t)(off / 8));
+            R.counts.push_back(s.n);
+            const size_t bytes = (size_t)s.n * 8;
+            if (bytes) { jobs.add((raw ? v.lvl_if : v.lvl_out) + 1, CopyJob{ s.data, base + off, (long long)bytes, 0x100, 0 }); }
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    R.n_lines = c->fft_on ? c->n_lines : 0;
+    if (R.n_lines > 0) {
+        const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
+        if ((c->res_flags & 2) && c->data_width > 0) {
+            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
+            R.off_zoomed = off;
+            jobs.add(lines_level + 2, CopyJob{ c->d_zoomed, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+            R.off_index = off;
+            jobs.add(lines_level + 2, CopyJob{ c->d_index, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+        }
+        if (c->res_flags & 4) {
+            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
+            R.off_raw = off;
+            jobs.add(lines_level + 1, CopyJob{ c->d_lines, base + off, (long long)bytes, 0x100, 0 });
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    if (off > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes exceed the slot (%zu)", off, c->res_cap); }
+    if (!arena_push_lev(c, jobs)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    for (int l = 0; l < jobs.top; l++) {
+        if (jobs.at[l].empty()) { continue; }
+        long long mx = 0;
+        for (auto& j : jobs.at[l]) { mx = std::max(mx, j.bytes); }
+        emit(c, l, F_MISC, TR_COPY, (int)std::max<long long>(1, std::min<long long>((mx + 32767) / 32768, 16)), (int)jobs.at[l].size(), 0, jobs.dev[l]);
+        c->plan_top = std::max(c->plan_top, l + 1);
+    }
+    return SDRPP_OK;
+}
+
+// results of a block that ran as an ORDINARY pass inside a pipelined run (something the device cannot pipeline: a pre-processing chain, a
+// VFO group without the matrix front end, a retune hand-over ...): the same slot layout, filled by plain copies behind the pass and waited
+// for here — the slow path, but sdrpp_result_wait / _release then work for EVERY block of a pipelined run, whichever way it was processed
+int tick_results_direct(sdrpp_ctx* c) {
+    int rc = tick_results_ensure(c);
+    if (rc) { return rc; }
+    const int slot = (int)(c->pushes % kResSlots);
+    sdrpp_ctx::Result& R = c->res[slot];
+    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
+    R = sdrpp_ctx::Result{};
+    R.ticket = c->pushes;
+    size_t off = 0;
+    char* base = c->res_host[slot];
+    if (c->res_flags & 1) {
+        for (auto& kv : c->vfos) {
+            const Vfo& v = *kv.second;
+            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            R.ids.push_back(v.id);
+            R.offsets.push_back((int64_t)(off / 8));
+            R.counts.push_back(s.n);
+            const size_t bytes = (size_t)s.n * 8;
+            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            if (bytes) { HIPCHK(c, hipMemcpyAsync(base + off, s.data, bytes, hipMemcpyDeviceToHost, c->stream)); }
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    R.n_lines = c->fft_on ? c->n_lines : 0;
+    if (R.n_lines > 0) {
+        if ((c->res_flags & 2) && c->data_width > 0) {
+            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
+            if (off + 2 * ((bytes + 15) & ~(size_t)15) > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            R.off_zoomed = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_zoomed, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+            R.off_index = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_index, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+        }
+        if (c->res_flags & 4) {
+            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
+            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+            R.off_raw = off;
+            HIPCHK(c, hipMemcpyAsync(base + off, c->d_lines, bytes, hipMemcpyDeviceToHost, c->stream));
+            off += (bytes + 15) & ~(size_t)15;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.done_tick = c->ticks;  // nothing queued is left: complete as it stands
+    return SDRPP_OK;
+}
+
+// sdrpp_push_staged_when: the host is still filling the staging slot with other threads while this thread plans the block; nothing that
+// reads the slot may be launched before they are through (the word counts their unfinished parts).
+int stage_pending_wait(sdrpp_ctx* c) {
+    const volatile uint32_t* w = c->stage_pending;
+    if (!w) { return SDRPP_OK; }
+    c->stage_pending = nullptr;
+    HostScope hs("staging wait");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *w != 0u; spins++) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged_when: the staging slot was not completed within 5 s"); }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SDRPP_OK;
+}
+
+// One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
+int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
+    if (count == 0) { return SDRPP_OK; }
+    c->plan_block_from_host = land != nullptr && land->bytes > 0;
+    bool as_tick = tick_eligible(c);
+    if (as_tick) {  // rings of the per-block buffers, result slots (allocated on first use / after a change of the configuration)
+        for (auto& kv : c->vfos) {
+            for (auto& st : kv.second->st) {
+                if (st.n_extra < kRing - 1 && st.base) {
+                    int rc = stream_ring_ensure(c, st);
+                    if (rc) { return rc; }
+                }
+            }
+        }
+        int rc = fft_ring_ensure(c);
+        if (!rc && c->res_flags) { rc = tick_results_ensure(c); }
+        if (rc) { return rc; }
+    }
+    c->pushes++;
+    const bool have_slot = as_tick;
+    PlanSnapshot snap;
+    int rc = SDRPP_OK;
+    if (as_tick) {
+        HostScope hs("tick plan");
+        rc = arena_begin(c);
+        if (rc) {
+            c->pushes--;
+            return rc;
+        }
+        plan_snapshot(c, snap);
+        for (auto& kv : c->vfos) {
+            for (auto& s : kv.second->st) { stream_rotate(s); }
+        }
+        fft_ring_rotate(c);
+        c->tick_planning = true;
+        c->tick_abort = false;
+        c->emits.clear();
+        c->plan_top = 2;
+        block_bounds(c, count, nullptr);
+        rc = ensure_iq_hist(c, iq_hist_need(c));
+        if (!rc) {
+            IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
+            rc = do_fft(c, src, count);
+            if (!rc && !c->tick_abort) {
+                const CarryJob iqc = iq_carry_job(c, d_iq, count);
+                if (c->vfos.empty()) {
+                    std::vector<CarryJob> carry{ iqc };
+                    CarryJob* d_carry = arena_push(c, carry);
+                    if (!d_carry) { rc = fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+                    else { emit(c, 1, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 1023) / 1024, 2048)), 1, 0, d_carry); }
+                }
+                else { rc = do_vfos_plan(c, src, count, iqc); }
+            }
+            if (!rc && !c->tick_abort) { rc = tick_results_plan(c); }
+        }
+        c->tick_planning = false;
+        if (!rc && !c->tick_abort && c->plan_top > kTickDepth + 1) { c->tick_abort = true; }
+        if (rc || c->tick_abort) {
+            plan_restore(c, snap);
+            c->emits.clear();
+            if (!c->res[c->pushes % kResSlots].held) { c->res[c->pushes % kResSlots].ticket = 0; }
+            as_tick = false;
+            if (rc) {
+                c->pushes--;
+                return rc;
+            }
+            c->arena_off = 0;  // (the slot stays this tick's: only the next role table goes in)
+        }
+    }
+    if (!as_tick) {
+        // this block runs as an ordinary pass: everything queued first (the first of those ticks carries the landing copy), then the pass
+        // behind them on the same stream
+        if (!have_slot) {
+            rc = arena_begin(c);
+            if (rc) { return rc; }
+        }
+        rc = stage_pending_wait(c);
+        if (!rc) { rc = tick_launch(c, land); }
+        if (!rc) { rc = tick_drain(c); }
+        if (land) { c->land_tick = c->ticks; }
+        if (!rc) { rc = push_common(c, d_iq, count, nullptr); }
+        // its results are where an ordinary pass leaves them (device buffers, readable after a synchronisation) and — with result flags —
+        // also in the block's result slot like every other block's
+        if (!rc && c->res_flags) { rc = tick_results_direct(c); }
+        else {
+            sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
+            if (!R.held) { R = sdrpp_ctx::Result{}; }
+        }
+        return rc;
+    }
+    // queue the roles level by level and launch this block's tick
+    if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }
+    for (auto& r : c->emits) { c->tickq[(size_t)r.level].push_back(r); }
+    c->emits.clear();
+    c->iq_cur ^= 1;
+    // tickq[0] is this very tick: it holds only what earlier blocks queued (a block's own roles start at level 1)
+    rc = stage_pending_wait(c);
+    if (!rc) {
+        HostScope hs("tick launch");
+        rc = tick_launch(c, land);
+    }
+    if (land) { c->land_tick = c->ticks; }
+    sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
+    if (R.ticket == c->pushes) { R.done_tick = c->ticks + (uint64_t)(c->plan_top - 1); }
+    return rc;
+}
+
+}  // namespace
