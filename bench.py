@@ -242,7 +242,66 @@ def make_inputs(torch, np, device, base, push, seed, nvfo, min_bytes=384 << 20):
     return bufs, copies
 
 
-def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4, exact_ssb=False):
+def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=1024, nblocks=3):
+    """Before anything is timed: the first `nblocks` input blocks through a PIPELINED context (result flags 7) and through an ORDINARY-pass
+    context of the same configuration — every VFO block, raw dB line, zoomed line and palette index of every block must be bit-identical
+    (the ordinary pass is what the parity tests compare with the oracle at every size; tests/test_bench_geometry_gpu.py compares the
+    pipelined mode with the oracle directly).  Returns a dict for the JSON line; raises if the two paths differ."""
+    import hashlib
+
+    from sdrplusplus_amd import capi, workloads
+
+    base = 4 if cfg == 5 else cfg
+    out = {"blocks": nblocks, "samples_per_block": push}
+    digests = []
+    for pipelined in (True, False):
+        ctx = capi.Context(local, max_push=push)
+        info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo)
+        if ref_block and ref_block < push:
+            ctx.set_reference_block(ref_block)
+        h = hashlib.sha256()
+        counts = [0, 0]
+        if pipelined:
+            ctx.set_pipelined(True, 7)
+            for b in range(nblocks):
+                ctx.push_device(bufs[b % len(bufs)].data_ptr(), push)
+            for t in range(1, nblocks + 1):
+                r = ctx.result_wait(t, copy=False)
+                for vid in info["vids"]:
+                    h.update(np.ascontiguousarray(r["vfo"][vid]).tobytes())
+                    counts[0] += len(r["vfo"][vid])
+                for k in ("raw", "zoomed", "index"):
+                    if r["n_lines"] > 0 and r[k] is not None:
+                        h.update(np.ascontiguousarray(r[k]).tobytes())
+                counts[1] += int(r["n_lines"])
+                ctx.result_release(t)
+            st = ctx.pipeline_stats()
+            out["blocks_as_ticks"] = st["tick_blocks"]
+            out["blocks_as_ordinary_passes"] = st["pass_blocks"]
+            out["roles"] = sorted(st["roles"])
+        else:
+            for b in range(nblocks):
+                ctx.push_device(bufs[b % len(bufs)].data_ptr(), push)
+                for vid in info["vids"]:
+                    a = ctx.vfo_read(vid)
+                    h.update(np.ascontiguousarray(a).tobytes())
+                    counts[0] += len(a)
+                if ctx.fft_lines() > 0:
+                    raw, zo, ix = ctx.fft_read()
+                    for a in (raw, zo, ix):
+                        h.update(np.ascontiguousarray(a).tobytes())
+                    counts[1] += len(raw)
+        ctx.close()
+        digests.append((h.hexdigest(), counts))
+    out["sha256_pipelined"], out["sha256_ordinary"] = digests[0][0][:32], digests[1][0][:32]
+    out["vfo_samples_hashed"], out["lines_hashed"] = digests[0][1]
+    out["identical"] = digests[0] == digests[1]
+    if not out["identical"]:
+        raise RuntimeError("pipelined and ordinary-pass results differ: %r" % (digests,))
+    return out
+
+
+def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4, exact_ssb=False, check=False):
     """One measured run of a configuration.  mode 'pipelined': sdrpp_set_pipelined, one launch per block; 'ordinary': one launch per
     stage.  Returns (result dict for rank 0, inputs) — the inputs can be handed to a second run of the same configuration."""
     from sdrplusplus_amd import capi, multi, workloads
@@ -270,6 +329,9 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             ctx.vfo_set_af(vid, a_, k_)
             af_keep.append(k_)
     pipelined = mode == "pipelined"
+    checked = None
+    if check and pipelined and rank == 0 and not af and not exact_ssb:
+        checked = self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=data_width)
     max_lines = (push + N - 1) // N + 1
     if pipelined:
         ctx.set_pipelined(True, 2)  # zoomed lines + palette indices of every block into page-locked result slots
@@ -333,7 +395,14 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             traffic = pmc_traffic(base, push, nvfo, dom)
             if bound_of.get(dom) == "mfma" and fl.get(dom):
                 tf = fl[dom] / dur / 1e12
+                # pipelined: a timed region of K blocks holds K + depth - 1 launches (the last ones drain the pipeline and carry less than a block's
+                # work), so "one block's flops / mean launch time" over-states short runs; the work-weighted figure — K blocks' flops over the SUM of
+                # the launch times — is the same for a 20-step and a 400-step run and is what `frac` reports.  `frac_full_launch` keeps the old formula.
+                tf_full = tf
+                if dom == "tick" and fam[dom][0] > 0:
+                    tf = fl[dom] * steps / (fam[dom][0] * 1e-3) / 1e12
                 roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5), "traffic": traffic,
+                        "frac_full_launch": round(tf_full / FP32_PEAK_TFLOPS, 5), "sum_launch_ms": round(fam[dom][0], 4), "blocks_timed": steps,
                         "algorithmic_flops_per_launch": fl[dom], "algorithmic_bytes_per_launch": by[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 5),
                         "launches_timed": launches.get(dom),
                         "note": ("tick = the ONE launch per block of pipelined mode: every stage of the path (front end, three decimator / resampler / channel stages, discriminator + audio filter, "
@@ -343,8 +412,11 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
                                 + "peak = dense FP32 MFMA; traffic = HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic*.json, builder-run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                   "passes of this workload), null when no pass of this exact workload is committed"}
             else:
+                gbs_full = gbs
+                if dom == "tick" and fam[dom][0] > 0:
+                    gbs = by[dom] * steps / (fam[dom][0] * 1e-3) / 1e9  # work-weighted, as above
                 roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": by[dom], "avg_launch_ms": round(kernel_ms[dom], 5), "launches_timed": launches.get(dom)}
+                        "frac_full_launch": round(gbs_full / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": by[dom], "avg_launch_ms": round(kernel_ms[dom], 5), "launches_timed": launches.get(dom)}
         roof_fft = {}
         for f in ("fft_pass1", "fft_pass2", "fft_single", "zoom_palette"):
             if f in kernel_ms_all and kernel_ms_all[f] > 0:
@@ -357,7 +429,9 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         mode_names = "/".join(sorted({m for m, _, _, _, _ in info["plan"]})) if nvfo else ""
         out = {
             "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
-            "workload": "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s" % (cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else ""),
+            "workload": "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s%s" % (
+                cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else "",
+                ("; zoomed lines + palette indices of every block DELIVERED to page-locked host memory" + (", VFO outputs left in HBM" if nvfo else "")) if pipelined else "; outputs left in HBM"),
             "samples_per_step_per_gpu": push, "mode": mode, "reference_block": ref_block if (ref_block and ref_block < push) else push,
             "input_blocks_rotated": len(bufs), "input_bytes_rotated": len(bufs) * push * 8, "af_chain": bool(af and nvfo), "device": ctx.device_info(),
             "roofline": roof, "roofline_fft": roof_fft, "roofline_path": roof_path,
@@ -370,6 +444,14 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             out["results_delivered"] = "zoomed lines + palette indices of every block in page-locked host memory (result flag 2), batches of %d blocks copied to the device%s; VFO outputs stay on the device" % (
                 gather_every, " and gathered on rank 0 over RCCL" if world > 1 else "")
             out["result_lag_blocks"] = lag
+            st = ctx.pipeline_stats()
+            out["pipeline"] = {"ticks": st["ticks"], "blocks_as_ticks": st["tick_blocks"], "blocks_as_ordinary_passes": st["pass_blocks"], "crowded_ticks": st["crowded_ticks"], "depth_levels": st["depth"],
+                               "roles": sorted(st["roles"])}
+        if checked is not None:
+            out["self_check"] = checked
+        out["rank_local_s"] = runner.local_elapsed
+    else:
+        out = {"rank_local_s": runner.local_elapsed}
     ctx.close()
     return out, inputs
 
@@ -516,6 +598,68 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
     return res
 
 
+def dry_launch(args, np, torch):
+    """`--gpus N --dry-launch` on a machine without GPUs: everything of the N > 1 launch that does not need a device — the ranks spawned by
+    the launcher branch of main(), the rendezvous (gloo instead of RCCL), the per-rank device naming, multi.StreamRunner's pipelined protocol
+    (barrier, K steps, delivery, MAX over ranks) on a stub context, the per-rank rates and rank 0's ONE JSON line."""
+    import torch.distributed as dist
+
+    from sdrplusplus_amd import multi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    names = [None] * world
+    dist.all_gather_object(names, "stub device (rank %d, pid %d)" % (rank, os.getpid()))
+    push, width, max_lines, every = 1000, 16, 2, 4
+
+    class Stub:
+        """What StreamRunner needs of a context: tickets, result slots with a line count that depends on the block and the rank."""
+
+        def __init__(self):
+            self.n = 0
+
+        def push_device(self, ptr, count):
+            self.n += 1
+
+        def ticket(self):
+            return self.n
+
+        def result_wait(self, t, copy=False):
+            nl = 1 + (t + rank) % 2
+            return {"n_lines": nl, "zoomed": np.full((nl, width), float(1000 * rank + t), np.float32)}
+
+        def result_release(self, t):
+            pass
+
+    lines = torch.zeros((every, max_lines + 1, width), dtype=torch.float32)
+    runner = multi.StreamRunner(Stub(), [torch.zeros(2 * push)], push, lines, pipelined=True, lag=8, gather_every=every)
+    for i in range(args.warmup):
+        runner.step(i)
+    runner.finish()
+    elapsed = runner.timed(args.steps, first=args.warmup)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "local_s": runner.local_elapsed, "collected": runner.collected})
+    ok = True
+    if rank == 0:
+        g = runner.gathered
+        ok = g is not None and tuple(g.shape) == (world, every, max_lines + 1, width) and all(p["collected"] == args.steps + args.warmup for p in per_rank)
+        print(json.dumps({"dry_launch": True, "ok": bool(ok), "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": dist.get_backend(), "devices": names,
+                          "value": round(world * push * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s (stub context: the protocol, not the hot path)",
+                          "per_rank": [{"rank": p["rank"], "Msamples_per_s": round(push * args.steps / max(p["local_s"], 1e-9) / 1e6, 1)} for p in per_rank],
+                          "gathered_shape": list(g.shape) if g is not None else None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -527,15 +671,35 @@ def main():
     ap.add_argument("--nvfo", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-by-push", action="store_true")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the untimed comparison of the pipelined path with ordinary passes on the first blocks")
     ap.add_argument("--no-others", action="store_true", help="skip the ceiling and the cfg 2 / cfg 4 runs")
     ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; runs as ordinary passes)")
     ap.add_argument("--fft-only", action="store_true", help="same as --cfg 2")
     ap.add_argument("--nco", choices=("closed", "ssb-exact"), default="closed", help="ssb-exact: SSB / DSB / raw channels on the reference's float rotator recursion (sdrpp_vfo_desc.nco_mode = 2); runs as ordinary passes")
     ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3 on one GPU, 5 on several)")
+    ap.add_argument("--dry-launch", action="store_true", help="N > 1 without GPUs: spawn the ranks, rendezvous over gloo, run the StreamRunner protocol on a stub context, print the JSON line (CPU test of the launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the one-GPU run (`python bench.py --gpus N`): become the launcher — one rank per GPU through torch.distributed.run, the
+        # same command line; rank 0's JSON line is the last line of this process's stdout as well
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
+
+    if args.dry_launch:
+        return dry_launch(args, np, torch)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -559,7 +723,8 @@ def main():
         names = [None] * world
         dist.all_gather_object(names, "%s (rank %d, cuda:%d)" % (torch.cuda.get_device_name(local), rank, local))
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": names}
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
 
     from sdrplusplus_amd import capi, workloads
 
@@ -572,7 +737,13 @@ def main():
     if mode == "ordinary":
         push = max(1, push // N) * N  # whole frames per step (the ordinary protocol copies a fixed number of lines)
     ref_block = None if args.ref_block < 0 else args.ref_block
-    head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block, exact_ssb=args.nco == "ssb-exact")
+    head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block, exact_ssb=args.nco == "ssb-exact",
+                                check=not args.no_self_check)
+    per_rank = None
+    if dist is not None:  # every rank's own rate (its K blocks over its own wall time, before it waits for the slowest rank)
+        mine = {"rank": rank, "device": "cuda:%d" % local, "local_s": head["rank_local_s"]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -592,6 +763,11 @@ def main():
     }
     if rccl:
         out["rccl"] = rccl
+    if per_rank:
+        out["per_rank"] = [{"rank": r["rank"], "device": r["device"], "Msamples_per_s": round(push * args.steps / r["local_s"] / 1e6, 1) if r.get("local_s") else None} for r in per_rank]
+    for k in ("pipeline", "self_check"):
+        if head.get(k) is not None:
+            out[k] = head[k]
     del inputs
     torch.cuda.empty_cache()
     if world == 1 and not args.no_others:

@@ -51,6 +51,7 @@ const char* sdrpp_last_error(const sdrpp_ctx* ctx);
 int sdrpp_set_stream(sdrpp_ctx* ctx, void* hip_stream);
 int sdrpp_sync(sdrpp_ctx* ctx);
 /* ABI self-description for foreign-function bindings: returns the ABI version and, if non-NULL, sizeof(sdrpp_vfo_desc). */
+#define SDRPP_ABI_VERSION 2   /* 2: sdrpp_vfo_desc.nco_mode, sdrpp_pipeline_stats */
 int sdrpp_abi_version(int* sizeof_vfo_desc);
 /* Human-readable device name / arch into buf (for logs and bench records). */
 int sdrpp_device_info(sdrpp_ctx* ctx, char* buf, int buflen);
@@ -364,6 +365,15 @@ int sdrpp_pipeline_flush(sdrpp_ctx* ctx);                    /* launch what is q
 int sdrpp_result_ready(sdrpp_ctx* ctx, uint64_t ticket);     /* 1 / 0 without blocking or flushing; SDRPP_ERR_NOT_FOUND: no slot    */
 int sdrpp_result_wait(sdrpp_ctx* ctx, uint64_t ticket, sdrpp_result* out);   /* flushes if needed, waits, hands the slot out        */
 int sdrpp_result_release(sdrpp_ctx* ctx, uint64_t ticket);
+/* How the blocks of a pipelined run were executed — for tests and bench.py, which assert the mode they mean to measure.
+ * out[0] launches ("ticks") so far, [1] blocks that ran as ticks, [2] blocks that fell back to an ordinary pass, [3] ticks with more role
+ * workgroups than the device holds at once (3 per CU: "crowded" order of the roles, tick_host.h), [4] levels of the most recent block (its
+ * results are complete that many launches after its push), [5] number of roles R, [6..7] reserved; then out[8 + r], r < R: workgroups
+ * launched so far in role r (sdrpp_pipeline_role_name(r); e.g. "fcm16_132_4" = the front end in its small-block shape).
+ * Returns the number of entries written (<= max).  Counters start at sdrpp_create. */
+#define SDRPP_PIPELINE_STATS_HEAD 8
+int sdrpp_pipeline_stats(sdrpp_ctx* ctx, int64_t* out, int max);
+const char* sdrpp_pipeline_role_name(int role);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------------------------------------- */
 /* Cumulative per-kernel-family device time measured with HIP events on the context's stream while timing is enabled.

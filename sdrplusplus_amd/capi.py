@@ -96,6 +96,9 @@ class Result(C.Structure):
     ]
 
 
+ABI_VERSION = 2  # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
+
+
 class SdrppError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("sdrpp error %d: %s" % (code, msg))
@@ -131,7 +134,7 @@ def load():
     L.sdrpp_device_info.argtypes = [vp, C.c_char_p, C.c_int]
     L.sdrpp_abi_version.argtypes = [c_int_p]
     sz = C.c_int()
-    if L.sdrpp_abi_version(C.byref(sz)) != 1 or sz.value != C.sizeof(VfoDesc):
+    if L.sdrpp_abi_version(C.byref(sz)) != ABI_VERSION or sz.value != C.sizeof(VfoDesc):
         raise ImportError("sdrpp_vfo_desc layout mismatch: library %d bytes, binding %d" % (sz.value, C.sizeof(VfoDesc)))
     L.sdrpp_abi_sizeof_af_desc.argtypes = []
     if L.sdrpp_abi_sizeof_af_desc() != C.sizeof(AfDesc):
@@ -208,6 +211,9 @@ def load():
     L.sdrpp_result_ready.argtypes = [vp, C.c_uint64]
     L.sdrpp_result_wait.argtypes = [vp, C.c_uint64, C.POINTER(Result)]
     L.sdrpp_result_release.argtypes = [vp, C.c_uint64]
+    L.sdrpp_pipeline_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
+    L.sdrpp_pipeline_role_name.restype = C.c_char_p
+    L.sdrpp_pipeline_role_name.argtypes = [C.c_int]
     L.sdrpp_timing_enable.argtypes = [vp, C.c_int]
     L.sdrpp_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.sdrpp_kernel_family_name.restype = C.c_char_p
@@ -230,7 +236,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
-    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release",
+    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
 
@@ -642,6 +648,17 @@ class Context:
 
     def result_release(self, ticket):
         self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))
+
+    def pipeline_stats(self):
+        """sdrpp_pipeline_stats -> dict(ticks, tick_blocks, pass_blocks, crowded_ticks, depth, roles={name: workgroups launched})."""
+        buf = (C.c_int64 * 128)()
+        n = self._chk(self.L.sdrpp_pipeline_stats(self.h, buf, 128))
+        nroles = int(buf[5])
+        roles = {}
+        for r in range(nroles):
+            if 8 + r < n and buf[8 + r]:
+                roles[self.L.sdrpp_pipeline_role_name(r).decode()] = int(buf[8 + r])
+        return dict(ticks=int(buf[0]), tick_blocks=int(buf[1]), pass_blocks=int(buf[2]), crowded_ticks=int(buf[3]), depth=int(buf[4]), roles=roles)
 
     # measurement
     def timing_enable(self, on=True, families=None):

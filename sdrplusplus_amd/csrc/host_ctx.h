@@ -255,6 +255,7 @@ struct sdrpp_ctx {
         std::vector<int> ids, counts;
         std::vector<int64_t> offsets;
         int n_lines = 0;
+        int fft_size = 0, data_width = 0, flags = 0;        // what the block was PLANNED with (the view / FFT size / result flags may change before it is collected)
         size_t off_zoomed = 0, off_index = 0, off_raw = 0;  // byte offsets in the slot
     };
     bool pipelined = false;
@@ -318,7 +319,12 @@ struct sdrpp_ctx {
     char* res_host[kResSlots] = {};       // page-locked result slots
     char* res_dev[kResSlots] = {};        // their device addresses
     size_t res_cap = 0;                   // bytes per slot
+    size_t res_cap_slot[kResSlots] = {};  // ... of each slot's current buffer (they grow one by one, tick_results_ensure)
+    std::vector<char*> res_retired[kResSlots];  // smaller buffers of slots that were HELD when the slots grew: the host's pointers into them stay valid until it releases
     Result res[kResSlots];
+    // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
+    int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0;
+    int64_t stat_role_wgs[64] = {};
 
     // timing
     bool timing = false;

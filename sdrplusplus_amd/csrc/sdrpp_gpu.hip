@@ -82,9 +82,9 @@ const char* sdrpp_strerror(int code) {
     }
 }
 
-int sdrpp_abi_version(int* sizeof_vfo_desc) {
+int sdrpp_abi_version(int* sizeof_vfo_desc) {  // 2: sdrpp_vfo_desc carries nco_mode (round 3); sdrpp_pipeline_stats
     if (sizeof_vfo_desc) { *sizeof_vfo_desc = (int)sizeof(sdrpp_vfo_desc); }
-    return 1;
+    return SDRPP_ABI_VERSION;
 }
 
 const char* sdrpp_kernel_family_name(int family) { return (family >= 0 && family < SDRPP_NUM_KERNEL_FAMILIES) ? kFamilyNames[family] : "?"; }
@@ -382,6 +382,8 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     }
     for (int i = 0; i < kResSlots; i++) {
         if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
+        for (char* q : c->res_retired[i]) { (void)hipHostFree(q); }
+        c->res_retired[i].clear();
     }
     fft_ring_drop(c);
     for (int i = 0; i < 2; i++) {
@@ -1733,12 +1735,13 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     out->counts = R->counts.data();
     out->samples = reinterpret_cast<const float*>(base);
     out->n_lines = R->n_lines;
-    out->fft_size = c->fft_size;
-    out->data_width = c->data_width;
-    const bool zo = R->n_lines > 0 && (c->res_flags & 2) && c->data_width > 0;
+    // shapes and presence as the block was planned: sdrpp_fft_set_view / sdrpp_fft_configure between push and wait do not re-label the slot
+    out->fft_size = R->fft_size;
+    out->data_width = R->data_width;
+    const bool zo = R->n_lines > 0 && (R->flags & 2) && R->data_width > 0;
     out->zoomed = zo ? reinterpret_cast<const float*>(base + R->off_zoomed) : nullptr;
     out->index = zo ? reinterpret_cast<const int32_t*>(base + R->off_index) : nullptr;
-    out->raw = (R->n_lines > 0 && (c->res_flags & 4)) ? reinterpret_cast<const float*>(base + R->off_raw) : nullptr;
+    out->raw = (R->n_lines > 0 && (R->flags & 4)) ? reinterpret_cast<const float*>(base + R->off_raw) : nullptr;
     return SDRPP_OK;
 }
 int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
@@ -1746,7 +1749,29 @@ int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
     if (!R) { return c ? SDRPP_ERR_NOT_FOUND : SDRPP_ERR_INVALID; }
     R->held = false;
     R->ticket = 0;
+    std::vector<char*>& old = c->res_retired[ticket % kResSlots];  // (buffers this slot outgrew while the host held it)
+    if (!old.empty()) {
+        DeviceScope dev_scope_(c);
+        for (char* q : old) { (void)hipHostFree(q); }
+        old.clear();
+    }
     return SDRPP_OK;
+}
+
+int sdrpp_pipeline_stats(sdrpp_ctx* c, int64_t* out, int max) {
+    if (!c || !out || max < 0) { return SDRPP_ERR_INVALID; }
+    const int64_t head[SDRPP_PIPELINE_STATS_HEAD] = { (int64_t)c->ticks, c->stat_tick_blocks, c->stat_pass_blocks, c->stat_crowded, c->stat_last_depth, (int64_t)TR_COUNT, 0, 0 };
+    int n = 0;
+    for (; n < SDRPP_PIPELINE_STATS_HEAD && n < max; n++) { out[n] = head[n]; }
+    for (int r = 0; r < TR_COUNT && n < max; r++, n++) { out[n] = c->stat_role_wgs[r]; }
+    return n;
+}
+const char* sdrpp_pipeline_role_name(int role) {
+    static const char* const names[] = { "none", "copy", "carry", "rot", "fcm_132_4", "fcm_6", "fcm_10", "fcm_16", "fcm16_132_4", "fcl_0", "fcl_pf", "toep_c", "toep_r", "toep_q",
+                                         "firb_c", "firb_r", "firb_s", "firb_q", "pre", "seq", "fft_s10", "fft_s11", "fft_s12", "fft_p1_5", "fft_p1_6", "fft_p1_7", "fft_p1_8", "fft_p1_9",
+                                         "fft_p1_10", "fft_p2_7", "fft_p2_8", "fft_p2_9", "fft_p2_10", "fft_p2row", "fft_tr", "zoom_16", "zoom_4", "zoom_1" };
+    static_assert(sizeof(names) / sizeof(names[0]) == TR_COUNT, "role names out of step with TickRole");
+    return (role >= 0 && role < TR_COUNT) ? names[role] : nullptr;
 }
 
 // ---- measurement ---------------------------------------------------------------------------------------------------------------------

@@ -105,11 +105,15 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     int blocks = l0.blocks[0] + l0.blocks[1];
     size_t lds = 0;
     bool set1 = false;
+    long long role_wgs = 0;
     for (auto& r : now) {
         blocks += r.e.gx * r.e.gy;
+        role_wgs += (long long)r.e.gx * r.e.gy;
         lds = std::max(lds, r.lds);
         set1 = set1 || r.e.role == TR_FCL_PF;
+        if (r.e.role >= 0 && r.e.role < 64) { c->stat_role_wgs[r.e.role] += (int64_t)r.e.gx * r.e.gy; }
     }
+    if (role_wgs > 3ll * c->num_cus) { c->stat_crowded++; }
     {   // where the stage-0 copies stand among the tick's workgroups (SDRPP_GPU_TICK_L0_AT: 0 = in front (default), -1 = behind all roles, n = behind
         // the first n role workgroups): a switch for the measurement DESIGN.md 4b names as the next step
         const int l0_at = c->tick_l0_at;
@@ -191,25 +195,31 @@ size_t tick_results_need(sdrpp_ctx* c) {
 int tick_results_ensure(sdrpp_ctx* c) {
     const size_t need = tick_results_need(c);
     if (need <= c->res_cap) { return SDRPP_OK; }
-    for (int i = 0; i < kResSlots; i++) {
-        if (c->res[i].held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held: release them before the outputs grow", (unsigned long long)c->res[i].ticket); }
-    }
+    // The slots grow (a VFO was added, a larger view / FFT configured) in the middle of a run: results that are complete or on their way
+    // but not yet collected must survive — a host keeps tickets across such a change (IQFrontEnd: pendingTickets across tempStop / addVFO).
+    // Everything queued runs to its end first, then every live slot moves into its larger buffer; a slot the host is holding (handed out by
+    // sdrpp_result_wait) keeps its old buffer alive until it is released — the pointers the host was given stay valid.
     int rc = tick_drain(c);
     if (rc) { return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < kResSlots; i++) {
-        if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
-        c->res_host[i] = nullptr;
-        c->res_dev[i] = nullptr;
-        c->res[i] = sdrpp_ctx::Result{};
-    }
-    c->res_cap = 0;
+    tick_wait_done(c, c->ticks);
     const size_t cap = need + need / 8 + 4096;
     for (int i = 0; i < kResSlots; i++) {
-        if (hipHostMalloc((void**)&c->res_host[i], cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-            hipHostGetDevicePointer((void**)&c->res_dev[i], c->res_host[i], 0) != hipSuccess) {
-            return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);
+        char* nh = nullptr;
+        char* nd = nullptr;
+        if (hipHostMalloc((void**)&nh, cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&nd, nh, 0) != hipSuccess) {
+            if (nh) { (void)hipHostFree(nh); }
+            return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);  // (slots < i are already the larger ones: res_cap stays, the next push tries again)
         }
+        char* old = c->res_host[i];
+        if (old && c->res[i].ticket != 0 && c->res_cap_slot[i] > 0) { memcpy(nh, old, std::min(cap, c->res_cap_slot[i])); }
+        if (old) {
+            if (c->res[i].held) { c->res_retired[i].push_back(old); }  // freed at sdrpp_result_release / sdrpp_destroy
+            else { (void)hipHostFree(old); }
+        }
+        c->res_host[i] = nh;
+        c->res_dev[i] = nd;
+        c->res_cap_slot[i] = cap;
     }
     c->res_cap = cap;
     return SDRPP_OK;
@@ -225,6 +235,9 @@ int tick_results_plan(sdrpp_ctx* c) {
     if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
     R = sdrpp_ctx::Result{};
     R.ticket = c->pushes;
+    R.fft_size = c->fft_size;
+    R.data_width = c->data_width;
+    R.flags = c->res_flags;
     Lev<CopyJob> jobs;
     size_t off = 0;
     char* base = c->res_dev[slot];
@@ -283,6 +296,9 @@ int tick_results_direct(sdrpp_ctx* c) {
     if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
     R = sdrpp_ctx::Result{};
     R.ticket = c->pushes;
+    R.fft_size = c->fft_size;
+    R.data_width = c->data_width;
+    R.flags = c->res_flags;
     size_t off = 0;
     char* base = c->res_host[slot];
     if (c->res_flags & 1) {
@@ -411,6 +427,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         }
     }
     if (!as_tick) {
+        c->stat_pass_blocks++;
         // this block runs as an ordinary pass: everything queued first (the first of those ticks carries the landing copy), then the pass
         // behind them on the same stream
         if (!have_slot) {
@@ -432,6 +449,8 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         return rc;
     }
     // queue the roles level by level and launch this block's tick
+    c->stat_tick_blocks++;
+    c->stat_last_depth = c->plan_top;
     if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }
     for (auto& r : c->emits) { c->tickq[(size_t)r.level].push_back(r); }
     c->emits.clear();

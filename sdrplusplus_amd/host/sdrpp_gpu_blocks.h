@@ -525,6 +525,10 @@ protected:
         frameCnd.notify_all();
         if (workerThread.joinable()) { workerThread.join(); }
         if (frameThread.joinable()) { frameThread.join(); }
+        // close an open hand-over batch before the helpers go: its unclaimed jobs hold RxVFO pointers (inflightOrder) that a removeVFO after
+        // this stop would leave dangling for the next start's helpers.  The writers are stopped, so the swaps fail fast.
+        (void)finishDelivery();
+        inflightOrder.clear();
         helpers.stop();
         stagers.stop();
         for (auto& in : inputs) { in->clearReadStop(); }
@@ -607,7 +611,12 @@ private:
     int startDelivery(uint64_t ticket) {
         (void)finishDelivery();
         sdrpp_result& r = inflight;
-        if (sdrpp_result_wait(ctx, ticket, &r)) {
+        const int wrc = sdrpp_result_wait(ctx, ticket, &r);
+        if (wrc == SDRPP_ERR_NOT_FOUND) {  // no slot for this block any more (the context was rebuilt around it): the block is gone, like one the reference had in flight across a tempStop
+            fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] block %llu skipped: %s\n", (unsigned long long)ticket, sdrpp_last_error(ctx));
+            return 0;
+        }
+        if (wrc) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] result of block %llu: %s\n", (unsigned long long)ticket, sdrpp_last_error(ctx));
             return -1;
         }
@@ -1023,12 +1032,14 @@ private:
                             continue;
                         }
                         std::unique_lock<std::mutex> lck(m);
-                        sleepers++;
-                        cv.wait(lck, [this]() {
-                            const uint64_t w = word.load(std::memory_order_acquire);
+                        sleepers.fetch_add(1, std::memory_order_seq_cst);
+                        // (bounded wait: begin()'s store of the word and its look at `sleepers` against this thread's increment and its look at
+                        // the word are a store -> load pair on either side; both are sequentially consistent, the time-out is the belt to that brace)
+                        cv.wait_for(lck, std::chrono::milliseconds(2), [this]() {
+                            const uint64_t w = word.load(std::memory_order_seq_cst);
                             return quit.load() || (uint32_t)w < (uint32_t)(w >> 32);
                         });
-                        sleepers--;
+                        sleepers.fetch_sub(1, std::memory_order_seq_cst);
                         idle_since = std::chrono::steady_clock::now();
                     }
                 });
@@ -1047,8 +1058,8 @@ private:
         void begin(std::vector<std::function<void()>>&& js) {
             jobs = std::move(js);  // (no batch is open: every job of the previous one has been claimed AND finished, see finish())
             finished.store(0, std::memory_order_relaxed);
-            word.store((uint64_t)jobs.size() << 32, std::memory_order_release);
-            if (sleepers.load(std::memory_order_acquire) > 0) {
+            word.store((uint64_t)jobs.size() << 32, std::memory_order_seq_cst);
+            if (sleepers.load(std::memory_order_seq_cst) > 0) {
                 std::lock_guard<std::mutex> lck(m);
                 cv.notify_all();
             }

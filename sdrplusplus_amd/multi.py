@@ -68,6 +68,7 @@ class StreamRunner:
         self.collected = 0   # blocks whose lines have been taken from their result slots
         self.batches = 0     # batches handed to the device / gathered
         self.nb = 0
+        self.local_elapsed = 0.0
         if self.pipelined:
             assert lines.dim() == 3 and lines.shape[0] == self.gather_every, "pipelined: lines = [gather_every, max_lines + 1, data_width]"
             self.max_lines = lines.shape[1] - 1
@@ -161,6 +162,7 @@ class StreamRunner:
             self.step(first + i)
         self.finish()
         self.sync()
+        self.local_elapsed = time.perf_counter() - t0  # this rank's own steps + deliveries (before it waits for the slowest rank)
         self.barrier()
         self.sync()
         elapsed = time.perf_counter() - t0

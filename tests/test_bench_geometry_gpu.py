@@ -1,0 +1,176 @@
+"""The mode bench.py measures, at the geometry it measures it in, DIRECTLY against the oracle (not through "pipelined == ordinary pass"):
+pipelined execution (sdrpp_set_pipelined: one launch per block), the reference's sr/200 blocks marked inside larger blocks
+(sdrpp_set_reference_block), result flags 1 | 2 | 4, enough blocks for the steady state of the role queue (crowded ticks, every level of the
+pipeline busy).  Every raw dB line / zoomed line / palette index bit-exact (iq_frontend.cpp:248-267, waterfall.cpp:65-90), every audio stream
+within BASELINE.json's 1e-5 RMS (rx_vfo.h:89-100, broadcast_fm.h:146-212, fm.h, am.h, ssb.h).  sdrpp_pipeline_stats says which roles ran,
+so a silent fall-back to ordinary passes or to another front-end shape fails the test instead of passing it.
+
+  (a) cfg 3 as bench.py sets it up: 32 x WFM + dense 65536-point FFT, 10^6-sample blocks resident on the device, reference block 50 000
+  (b) the same at sr/200 = 50 000-sample blocks: device-resident (front end in its small-block shape) and fetched from host memory
+  (c) cfg 4: 128 VFOs NFM / AM / USB + 2^20-point FFT, 10^6- and 307 200-sample blocks (long first stages: the SET = 1 build of the kernel)
+  (d) cfg 2: FFT only, 65536 and 2^20 points, 10^6-sample blocks"""
+import numpy as np
+import pytest
+
+import support as S
+from test_full_configs_gpu import _oracle_streams, _synth_threaded, rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_blocks(x, B):
+    """The signal cut into blocks of B samples resident on the device (what bench.py pushes: sdrpp_push_device reads them in place)."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).to("cuda:0")
+    torch.cuda.synchronize()
+    return t, [(t.data_ptr() + 8 * i, min(B, len(x) - i)) for i in range(0, len(x), B)]
+
+
+def _check_lines(spec, view, x, cuts, results):
+    """results[t]: sdrpp_result of block t; the oracle's frames do not depend on how the stream is cut, the assignment of lines to blocks does."""
+    start, size, width, lo, hi = view
+    pos, total = 0, 0
+    for t, n in enumerate(cuts):
+        ol = spec.push(x[pos:pos + n])
+        pos += n
+        r = results[t]
+        assert r["n_lines"] == len(ol), (t, r["n_lines"], len(ol))
+        total += len(ol)
+        if len(ol) == 0:
+            continue
+        assert r["raw"] is not None and np.array_equal(r["raw"].view(np.uint32), ol.view(np.uint32)), "block %d: raw dB lines differ from the oracle" % t
+        if r["zoomed"] is not None:
+            oz = np.stack([S.oracle_do_zoom(start, size, width, l) for l in ol])
+            assert np.array_equal(r["zoomed"].view(np.uint32), oz.view(np.uint32)), "block %d: zoomed lines" % t
+            assert np.array_equal(r["index"], np.stack([S.oracle_palette_index(z, lo, hi) for z in oz])), "block %d: palette indices" % t
+    return total
+
+
+def _run_pipelined(ctx, feed, cuts, lag=9):
+    """Push every block, collecting results `lag` blocks behind like a streaming host; returns the per-block result dicts."""
+    out = []
+    for t, n in enumerate(cuts):
+        feed(t, n)
+        if t + 1 > lag:
+            out.append(ctx.result_wait(t + 1 - lag))
+            ctx.result_release(t + 1 - lag)
+    for t in range(len(out) + 1, len(cuts) + 1):
+        out.append(ctx.result_wait(t))
+        ctx.result_release(t)
+    return out
+
+
+def _audio_check(info, results, ref, tol=1e-5, what=""):
+    worst = {}
+    for k, (vid, (m, _, _, _, _)) in enumerate(zip(info["vids"], info["plan"])):
+        ga = np.concatenate([r["vfo"][vid] for r in results])
+        oa = ref[k][1]
+        assert ga.shape == oa.shape, (what, k, m, ga.shape, oa.shape)
+        e = rms(ga - oa) / max(1.0, rms(oa))
+        worst[m] = max(worst.get(m, 0.0), e)
+        assert e < tol, (what, k, m, e)
+    return worst
+
+
+@pytest.mark.parametrize("fed", ["device_1M", "device_sr200", "host_sr200"])
+def test_cfg3_pipelined_bench_geometry_vs_oracle(fed):
+    """(a) + (b).  32 x WFM, 65536-point dense FFT, 1024-pixel full view, pipelined, flags 7, reference block 50 000."""
+    from sdrplusplus_amd import capi, workloads
+
+    B, nblk = (1000000, 13) if fed == "device_1M" else (50000, 48)
+    x = _synth_threaded(3, B * nblk, seed=0x3A + nblk)
+    ctx = capi.Context(0, max_push=B)
+    info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=32)
+    if B > 50000:
+        ctx.set_reference_block(50000)
+    ctx.set_pipelined(True, 1 | 2 | 4)
+    cuts = [B] * nblk
+    if fed.startswith("device"):
+        keep, blocks = _device_blocks(x, B)
+        feed = lambda t, n: ctx.push_device(blocks[t][0], n)
+    else:
+        keep = None
+        feed = lambda t, n: ctx.push(x[t * B:t * B + n])  # pageable host memory -> page-locked staging slot -> the tick's landing copy
+    results = _run_pipelined(ctx, feed, cuts)
+    st = ctx.pipeline_stats()
+    assert st["tick_blocks"] == nblk and st["pass_blocks"] == 0, st
+    if fed == "device_1M":
+        assert st["crowded_ticks"] >= nblk - 2, st  # the order of the roles bench.py's ticks run in
+        assert "fcm_132_4" in st["roles"] and "fcm16_132_4" not in st["roles"], st
+    elif fed == "device_sr200":
+        assert "fcm16_132_4" in st["roles"] and "fcm_132_4" not in st["roles"], st  # small-block shape of the front end
+    else:
+        assert "fcm_132_4" in st["roles"] and "fcm16_132_4" not in st["roles"], st  # host-fetched blocks keep the 32 x 32 x 2 shape
+    assert any(k in st["roles"] for k in ("toep_q", "pipe")) and "fft_p1_8" in st["roles"] and "fft_p2_8" in st["roles"], st
+    spec = S.OracleSpectrum(65536, 65536, 0, capi.design_fft_window(2, 65536))
+    nlines = _check_lines(spec, info["view"], x, cuts, results)
+    assert nlines == (B * nblk) // 65536
+    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m]) for m, r, bw, c, _ in info["plan"]]
+    ref = _oracle_streams(chains, x, [50000] * (B * nblk // 50000))
+    worst = _audio_check(info, results, ref, what=fed)
+    print("cfg3 pipelined %s: %d lines bit-exact, worst WFM audio error %.2e over %d samples; roles %s" % (fed, nlines, worst["WFM"], B * nblk, sorted(st["roles"])))
+    del keep
+    ctx.close()
+
+
+@pytest.mark.parametrize("B,nblk", [(1000000, 10), (307200, 12)])
+def test_cfg4_pipelined_vs_oracle(B, nblk):
+    """(c) 128 VFOs NFM / AM / USB at 61.44 MS/s + the 2^20-point FFT, pipelined.  NFM / AM against the PINNED oracle; USB against the oracle
+    with its ideal-NCO switch (the default closed-form NCO differs from the reference by the reference rotator's own drift, DESIGN.md 5 —
+    the reference-rotator mode that meets the pinned oracle is tested in test_full_configs_gpu.py)."""
+    from sdrplusplus_amd import capi, workloads
+
+    RB = 307200
+    x = _synth_threaded(4, B * nblk, seed=0x4C)
+    ctx = capi.Context(0, max_push=B)
+    info = workloads.setup(ctx, 4, dense_fft=True, data_width=1024)
+    if B != RB:
+        ctx.set_reference_block(RB)
+    ctx.set_pipelined(True, 1 | 2 | 4)
+    keep, blocks = _device_blocks(x, B)
+    cuts = [B] * nblk
+    results = _run_pipelined(ctx, lambda t, n: ctx.push_device(blocks[t][0], n), cuts)
+    st = ctx.pipeline_stats()
+    assert st["tick_blocks"] == nblk and st["pass_blocks"] == 0, st
+    assert "fcl_pf" in st["roles"], st  # long first stages with the register-prefetched window: the 247-register build of the tick kernel
+    assert "fft_p2row" in st["roles"] and "fft_tr" in st["roles"] and "seq" in st["roles"], st
+    N = 1 << 20
+    spec = S.OracleSpectrum(N, N, 0, capi.design_fft_window(2, N))
+    nlines = _check_lines(spec, info["view"], x, cuts, results)
+    assert nlines == (B * nblk) // N
+    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m], ideal_nco=(m == "USB")) for m, r, bw, c, _ in info["plan"]]
+    # the reference's blocks: RB-sample blocks restarting with every push (sdrpp_set_reference_block cuts every push from its start)
+    per = [RB] * (B // RB) + ([B % RB] if B % RB else [])
+    ref = _oracle_streams(chains, x, per * nblk)
+    worst = _audio_check(info, results, ref, what="cfg4 B=%d" % B)
+    print("cfg4 pipelined B=%d: %d 2^20-point lines bit-exact, worst relative audio error per mode %s" % (B, nlines, {m: "%.2e" % v for m, v in worst.items()}))
+    del keep
+    ctx.close()
+
+
+@pytest.mark.parametrize("lgn", [16, 20])
+def test_cfg2_pipelined_vs_oracle(lgn):
+    """(d) FFT branch alone, pipelined, 10^6-sample blocks: 65536 points (pass 1 / pass 2 roles) and 2^20 points (column pass, 4096-point rows,
+    transpose)."""
+    from sdrplusplus_amd import capi, workloads
+
+    N, B, nblk = 1 << lgn, 1000000, 12
+    x = _synth_threaded(2, B * nblk, seed=0x2D + lgn)
+    ctx = capi.Context(0, max_push=B)
+    ctx.fft_configure(N, N, 0, capi.design_fft_window(2, N))
+    start, size = capi.design_waterfall_view(0.0, 10e6, 10e6, N)
+    view = (start, size, 1024, -120.0, 0.0)
+    ctx.fft_set_view(*view)
+    ctx.set_pipelined(True, 2 | 4)
+    keep, blocks = _device_blocks(x, B)
+    cuts = [B] * nblk
+    results = _run_pipelined(ctx, lambda t, n: ctx.push_device(blocks[t][0], n), cuts)
+    st = ctx.pipeline_stats()
+    assert st["tick_blocks"] == nblk and st["pass_blocks"] == 0, st
+    assert ("fft_p2_8" in st["roles"]) if lgn == 16 else ("fft_p2row" in st["roles"] and "fft_tr" in st["roles"]), st
+    spec = S.OracleSpectrum(N, N, 0, capi.design_fft_window(2, N))
+    nlines = _check_lines(spec, view, x, cuts, results)
+    assert nlines == (B * nblk) // N
+    del keep
+    ctx.close()

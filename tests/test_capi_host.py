@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libsdrpp_gpu.so does not export " + name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
     sz = C.c_int()
-    assert L.sdrpp_abi_version(C.byref(sz)) == 1 and sz.value == C.sizeof(capi.VfoDesc)  # ctypes mirror == C struct layout
+    assert L.sdrpp_abi_version(C.byref(sz)) == capi.ABI_VERSION and sz.value == C.sizeof(capi.VfoDesc)  # ctypes mirror == C struct layout
 
 
 def test_no_cpu_fallback_without_device():

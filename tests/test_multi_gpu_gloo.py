@@ -208,3 +208,27 @@ def test_stream_dealing():
     assert multi.stream_for_rank(0, 8, 8) == [0] and multi.stream_for_rank(7, 8, 8) == [7]
     assert multi.stream_for_rank(1, 2, 8) == [1, 3, 5, 7]
     assert [multi.stream_seed(0, s) for s in range(8)] == list(range(8))
+
+
+def test_bench_spawns_its_ranks_when_started_like_the_one_gpu_run():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver starts `--gpus 1`) must start its own ranks: the launcher branch
+    re-executes bench.py through torch.distributed.run with one rank per GPU.  --dry-launch takes the ranks through everything of the N > 1
+    path that needs no device — rendezvous (gloo here, RCCL on the node), device naming, StreamRunner's pipelined protocol on a stub context,
+    per-rank rates, ONE JSON line from rank 0 as the last line of stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "9", "--warmup", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    out = json.loads(last)
+    assert out["dry_launch"] and out["ok"] and out["n_gpus"] == 2 and out["steps"] == 9 and len(out["devices"]) == 2
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and out["gathered_shape"][0] == 2
+    # a launcher that already set WORLD_SIZE to something else is an error message, not an AssertionError
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

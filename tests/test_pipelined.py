@@ -242,3 +242,48 @@ def test_pipelined_result_slots_and_modes(backend):
         _same(ref["vfo"][v_a], cb.vfo_read(v_b), "after leaving pipelined mode")
     ca.close()
     cb.close()
+
+
+def test_results_survive_growing_result_slots(backend):
+    """A host keeps tickets across a change of the configuration (IQFrontEnd: pendingTickets across tempStop / addVFO).  Adding a VFO makes
+    every block's results larger than the page-locked slots were sized for: the slots grow — and the results of the blocks pushed before,
+    complete or still in flight, HELD by the host or not, must all still be there afterwards (they used to be dropped: the next
+    sdrpp_result_wait failed with NOT_FOUND and the pipelined worker of the C++ front end died)."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    nv, B = (20, 4000) if backend == "gpu" else (17, 2000)
+    plan = workloads.vfo_plan(3, nv + 12)
+    x = workloads.synth(3, B * 12, seed=14, nvfo=nv + 12)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 4096, flags=7)
+    refs = []
+    for i in range(5):
+        blk = x[i * B:(i + 1) * B]
+        refs.append(_ordinary_results(ca, va, blk, True))
+        cb.push(blk)
+    held = cb.result_wait(2, copy=False)  # handed out and NOT released: its arrays point into the slot's page-locked memory
+    held_copy = {v: a.copy() for v, a in held["vfo"].items()}
+    st0 = cb.pipeline_stats()
+    assert st0["tick_blocks"] == 5 and st0["pass_blocks"] == 0, st0
+    # twelve more VFOs on both contexts: 1.6 x the result bytes per block — more than the slots' 12.5 % slack
+    for mode, if_rate, bw, centre, _ in plan[nv:]:
+        for ctx, vids in ((ca, va), (cb, vb)):
+            d, keep = radio.vfo_desc(10e6, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+    for i in range(5, 9):
+        blk = x[i * B:(i + 1) * B]
+        refs.append(_ordinary_results(ca, va, blk, True))
+        cb.push(blk)
+    # the held block's memory is still the host's (old buffer kept alive), bit for bit
+    for v, a in held["vfo"].items():
+        assert np.array_equal(a.view(np.uint32), held_copy[v].view(np.uint32))
+    cb.result_release(2)
+    for t, ref in enumerate(refs, start=1):
+        if t == 2:
+            continue
+        got = cb.result_wait(t)
+        n_v = nv if t <= 5 else nv + 12
+        assert len(got["vfo"]) == n_v, (t, len(got["vfo"]))
+        _compare({"vfo": dict(zip(vb[:n_v], [ref["vfo"][v] for v in va[:n_v]])), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    ca.close()
+    cb.close()
