@@ -129,8 +129,12 @@ __device__ unsigned long long g_tick_mark[1 << 16][4];
     } while (0)
 #endif
 
-// Every memory operation this wavefront has issued is complete (s_waitcnt vmcnt(0) lgkmcnt(0)) — no cache write-back, no invalidate.
-__device__ __forceinline__ void wave_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Every memory operation this wavefront has issued is complete — no cache write-back, no invalidate.  The wait is spelled out: a
+// workgroup-scope release fence (`__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")`) compiles to NOTHING for global stores on gfx950
+// outside threadgroup-split mode (the waves of a workgroup share their L1), and a workgroup was then counted "done" — and the tick's completion
+// flag published to the host — with the result stores of three of its four wavefronts still in flight: a host that read a result slot
+// within microseconds of the flag met pieces of the previous content (found by tests/test_bench_geometry_gpu.py, round 4).
+__device__ __forceinline__ void wave_stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // Index of the first entry of the ascending table `ends[0 .. n)` (n <= 64) that is greater than b, and the entry in front of it (0 for the
 // first): every lane fetches one entry — ONE memory round trip instead of a chain of dependent scalar loads — and a ballot does the search.

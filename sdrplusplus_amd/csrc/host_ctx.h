@@ -247,7 +247,7 @@ struct sdrpp_ctx {
 
     // ---- pipelined ("tick") execution: one launch per block, the stages of consecutive blocks skewed over consecutive launches
     //      (tick_kernels.h; sdrpp_set_pipelined) ----
-    struct RoleLaunch { TickEntry e; size_t lds; int level; int fam; };
+    struct RoleLaunch { TickEntry e; size_t lds; int level; int fam; bool to_host; };  // to_host: a copy into a page-locked result slot
     struct Result {                       // what the host knows about the block in a result slot
         uint64_t ticket = 0;              // 0: slot free
         uint64_t done_tick = 0;           // its last level has run when this many ticks have completed
@@ -322,6 +322,14 @@ struct sdrpp_ctx {
     size_t res_cap_slot[kResSlots] = {};  // ... of each slot's current buffer (they grow one by one, tick_results_ensure)
     std::vector<char*> res_retired[kResSlots];  // smaller buffers of slots that were HELD when the slots grew: the host's pointers into them stay valid until it releases
     Result res[kResSlots];
+    // Completion of a tick whose roles wrote RESULTS into page-locked host memory, as the host may rely on it: an event recorded behind the
+    // launch.  The flag the kernel itself publishes (h_tick_flag) says that every workgroup has finished and its stores are acknowledged — but
+    // a result block is megabytes of posted writes over the bus from every XCD, and the four bytes of the flag were measured to overtake them by
+    // up to ~100 us (round 4: a host that copied a VFO block within microseconds of the flag met the slot's previous content).  The command
+    // processor's end-of-kernel release behind an event is the ordering HIP guarantees for kernel writes to host memory.
+    static constexpr int kTickEvents = 32;
+    hipEvent_t tick_ev[kTickEvents] = {};
+    uint64_t tick_ev_tick[kTickEvents] = {};   // the tick the event was last recorded behind (0: never)
     // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
     int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0;
     int64_t stat_role_wgs[64] = {};

@@ -380,6 +380,9 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     for (int i = 0; i < kStageSlots; i++) {
         if (c->stage_host[i]) { (void)hipHostFree(c->stage_host[i]); }
     }
+    for (int i = 0; i < sdrpp_ctx::kTickEvents; i++) {
+        if (c->tick_ev[i]) { (void)hipEventDestroy(c->tick_ev[i]); }
+    }
     for (int i = 0; i < kResSlots; i++) {
         if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
         for (char* q : c->res_retired[i]) { (void)hipHostFree(q); }
@@ -1711,7 +1714,9 @@ static sdrpp_ctx::Result* result_of(sdrpp_ctx* c, uint64_t ticket) {
 int sdrpp_result_ready(sdrpp_ctx* c, uint64_t ticket) {
     sdrpp_ctx::Result* R = result_of(c, ticket);
     if (!R) { return c ? fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (not gathered, overwritten, or processed as an ordinary pass)", (unsigned long long)ticket) : SDRPP_ERR_INVALID; }
-    return (R->done_tick <= c->ticks && tick_is_done(c, R->done_tick)) ? 1 : 0;
+    if (R->done_tick > c->ticks) { return 0; }
+    DeviceScope dev_scope_(c);
+    return tick_results_visible(c, R->done_tick, false);
 }
 int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     DeviceScope dev_scope_(c);
@@ -1724,7 +1729,10 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
         if (rc) { return rc; }
         if (c->tickq.empty() && R->done_tick > c->ticks) { return fail(c, SDRPP_ERR_HIP, "internal: block %llu cannot complete", (unsigned long long)ticket); }
     }
-    tick_wait_done(c, R->done_tick);
+    {   // complete on the device AND visible here (the flag alone is not: see tick_results_visible)
+        const int vis = tick_results_visible(c, R->done_tick, true);
+        if (vis < 0) { return vis; }
+    }
     if (!tick_is_done(c, R->done_tick)) { return fail(c, SDRPP_ERR_HIP, "tick %llu did not complete", (unsigned long long)R->done_tick); }
     R->held = true;
     const char* base = c->res_host[ticket % kResSlots];

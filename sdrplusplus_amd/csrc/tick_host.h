@@ -20,6 +20,28 @@ void tick_wait_done(sdrpp_ctx* c, uint64_t nticks) {
         }
     }
 }
+// The results tick `nticks` wrote into page-locked host memory are visible to this thread: 1 yes, 0 not yet (wait = false), < 0 error.
+// The flag first (cheap: a cached word the device writes once per tick), then the event recorded behind that tick — or behind a later one
+// that took its place in the ring, which orders the earlier tick's writes just as well.
+int tick_results_visible(sdrpp_ctx* c, uint64_t nticks, bool wait) {
+    if (nticks == 0) { return 1; }
+    if (wait) { tick_wait_done(c, nticks); }
+    else if (c->h_tick_flag && (int)((unsigned)nticks - *(const volatile unsigned*)c->h_tick_flag) > 0) { return 0; }
+    const int k = (int)(nticks % sdrpp_ctx::kTickEvents);
+    if (!c->tick_ev[k] || c->tick_ev_tick[k] < nticks) {
+        // no event behind that tick (a block without result copies in it): the stream itself
+        if (!wait) { return hipStreamQuery(c->stream) == hipSuccess ? 1 : 0; }
+        return hipStreamSynchronize(c->stream) == hipSuccess ? 1 : fail(c, SDRPP_ERR_HIP, "hipStreamSynchronize failed");
+    }
+    long spins = 0;
+    for (;;) {
+        const hipError_t e = hipEventQuery(c->tick_ev[k]);
+        if (e == hipSuccess) { return 1; }
+        if (e != hipErrorNotReady) { return fail(c, SDRPP_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(e)); }
+        if (!wait) { return 0; }
+        if (++spins > 200) { std::this_thread::yield(); }
+    }
+}
 bool tick_is_done(const sdrpp_ctx* c, uint64_t nticks) { return !c->h_tick_flag || (int)((unsigned)nticks - *(const volatile unsigned*)c->h_tick_flag) <= 0; }
 
 // One tick: level-0 work of the block that arrives with it (`land`: its landing copy, may be null; the arena slot the caller has filled
@@ -106,7 +128,9 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     size_t lds = 0;
     bool set1 = false;
     long long role_wgs = 0;
+    bool to_host = false;
     for (auto& r : now) {
+        to_host = to_host || r.to_host;
         blocks += r.e.gx * r.e.gy;
         role_wgs += (long long)r.e.gx * r.e.gy;
         lds = std::max(lds, r.lds);
@@ -146,6 +170,12 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
             c->tpairs.push_back({ ea, eb, F_TICK });
             if (c->tpairs.size() > 8192) { timing_flush(c); }
         }
+    }
+    if (to_host) {  // results for the host in this tick: their completion is an event (see host_ctx.h)
+        const int k = (int)(c->ticks % sdrpp_ctx::kTickEvents);
+        if (!c->tick_ev[k] && hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "hipEventCreate failed"); }
+        HIPCHK(c, hipEventRecord(c->tick_ev[k], c->stream));
+        c->tick_ev_tick[k] = c->ticks;
     }
     c->arena_tick[c->arena_slot] = c->ticks;
     c->next_tab = tab_dev_next;
@@ -280,6 +310,7 @@ int tick_results_plan(sdrpp_ctx* c) {
         long long mx = 0;
         for (auto& j : jobs.at[l]) { mx = std::max(mx, j.bytes); }
         emit(c, l, F_MISC, TR_COPY, (int)std::max<long long>(1, std::min<long long>((mx + 32767) / 32768, 16)), (int)jobs.at[l].size(), 0, jobs.dev[l]);
+        if (!c->emits.empty()) { c->emits.back().to_host = true; }
         c->plan_top = std::max(c->plan_top, l + 1);
     }
     return SDRPP_OK;

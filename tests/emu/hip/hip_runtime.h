@@ -161,6 +161,8 @@ typedef struct hipemuEvent { double t; }* hipEvent_t;
 #define hipErrorInvalidValue 1
 #define hipErrorOutOfMemory 2
 #define hipErrorNoDevice 100
+#define hipErrorNotReady 600
+#define hipEventDisableTiming 2
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipStreamNonBlocking 1
 #define HIP_SYMBOL(x) (x)
@@ -197,6 +199,9 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{ 0
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return 0; }
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };

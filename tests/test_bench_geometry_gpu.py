@@ -11,6 +11,7 @@ so a silent fall-back to ordinary passes or to another front-end shape fails the
   (d) cfg 2: FFT only, 65536 and 2^20 points, 10^6-sample blocks"""
 import numpy as np
 import pytest
+import torch  # BEFORE the product library: torch preloads its own copy of the HIP runtime by path, and the second runtime in a process finds no device
 
 import support as S
 from test_full_configs_gpu import _oracle_streams, _synth_threaded, rms
@@ -20,8 +21,6 @@ pytestmark = pytest.mark.gpu
 
 def _device_blocks(x, B):
     """The signal cut into blocks of B samples resident on the device (what bench.py pushes: sdrpp_push_device reads them in place)."""
-    import torch
-
     t = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).to("cuda:0")
     torch.cuda.synchronize()
     return t, [(t.data_ptr() + 8 * i, min(B, len(x) - i)) for i in range(0, len(x), B)]
