@@ -330,6 +330,14 @@ struct sdrpp_ctx {
     static constexpr int kTickEvents = 32;
     hipEvent_t tick_ev[kTickEvents] = {};
     uint64_t tick_ev_tick[kTickEvents] = {};   // the tick the event was last recorded behind (0: never)
+    hipEvent_t tick_ev_start[kTickEvents] = {}; // timing on: the start event of that tick's launch (the pair is read out when the entry comes round again, or at timing_flush)
+    int tick_ev_next = 0;
+    uint64_t tick_ev_last = 0;                 // the newest tick an event stands behind
+    // measurement switches: an event behind every n-th tick with results (a waiter takes the first event at or behind its tick, recording one on
+    // demand); the event as the tick launch's own completion signal (hipExtLaunchKernelGGL's stop event) instead of a packet of its own
+    int tick_ev_every = getenv("SDRPP_GPU_TICK_EVENT_EVERY") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_EVENT_EVERY"))) : 1;
+    bool tick_ev_ext = getenv("SDRPP_GPU_TICK_EVENT_EXT") ? atoi(getenv("SDRPP_GPU_TICK_EVENT_EXT")) != 0 : true;  // (15.8 against 15.2 GS/s with the event as a packet of its own: profiles/r04h_*)
+    int tick_ev_skipped = 0;
     // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
     int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0;
     int64_t stat_role_wgs[64] = {};

@@ -61,7 +61,17 @@ hipEvent_t get_event(sdrpp_ctx* c) {
     (void)hipEventCreate(&e);
     return e;
 }
+// a tick launch timed through its own start / stop events (tick_host.h): read the pair out, give the start event back to the pool
+void tick_ev_resolve(sdrpp_ctx* c, int k) {
+    if (!c->tick_ev_start[k]) { return; }
+    float ms = 0.0f;
+    (void)hipEventSynchronize(c->tick_ev[k]);
+    if (hipEventElapsedTime(&ms, c->tick_ev_start[k], c->tick_ev[k]) == hipSuccess) { c->fam_ms[F_TICK] += ms; }
+    c->ev_pool.push_back(c->tick_ev_start[k]);
+    c->tick_ev_start[k] = nullptr;
+}
 void timing_flush(sdrpp_ctx* c) {
+    for (int k = 0; k < sdrpp_ctx::kTickEvents; k++) { tick_ev_resolve(c, k); }
     if (c->tpairs.empty()) { return; }
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->fft_stream);

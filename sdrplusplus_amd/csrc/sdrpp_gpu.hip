@@ -2,6 +2,7 @@
 // One context = one IQ stream on one GPU; everything is enqueued on one HIP stream so a push is a fixed sequence of
 // launches whose sizes are computed on the host from integer state (decimation offsets, polyphase phase, frame position).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -382,6 +383,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     }
     for (int i = 0; i < sdrpp_ctx::kTickEvents; i++) {
         if (c->tick_ev[i]) { (void)hipEventDestroy(c->tick_ev[i]); }
+        if (c->tick_ev_start[i]) { (void)hipEventDestroy(c->tick_ev_start[i]); }
     }
     for (int i = 0; i < kResSlots; i++) {
         if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }

@@ -20,22 +20,36 @@ void tick_wait_done(sdrpp_ctx* c, uint64_t nticks) {
         }
     }
 }
+// An event behind everything launched so far (c->ticks), from the ring.  `pre`: only reserve the ring entry and return it — the caller hands
+// the event to the launch itself (hipExtLaunchKernelGGL's stop event).
+hipEvent_t tick_event_take(sdrpp_ctx* c, uint64_t behind_tick) {
+    const int k = c->tick_ev_next;
+    c->tick_ev_next = (k + 1) % sdrpp_ctx::kTickEvents;
+    tick_ev_resolve(c, k);  // (the launch it timed is kTickEvents ticks old: long complete)
+    if (!c->tick_ev[k] && hipEventCreate(&c->tick_ev[k]) != hipSuccess) { return nullptr; }
+    c->tick_ev_tick[k] = behind_tick;
+    c->tick_ev_last = behind_tick;
+    return c->tick_ev[k];
+}
 // The results tick `nticks` wrote into page-locked host memory are visible to this thread: 1 yes, 0 not yet (wait = false), < 0 error.
-// The flag first (cheap: a cached word the device writes once per tick), then the event recorded behind that tick — or behind a later one
-// that took its place in the ring, which orders the earlier tick's writes just as well.
+// The flag first (cheap: a cached word the device writes once per tick), then the first event recorded at or behind that tick — a later
+// tick's event orders the earlier tick's writes just as well; if there is none yet, one is recorded now behind everything launched.
 int tick_results_visible(sdrpp_ctx* c, uint64_t nticks, bool wait) {
     if (nticks == 0) { return 1; }
     if (wait) { tick_wait_done(c, nticks); }
     else if (c->h_tick_flag && (int)((unsigned)nticks - *(const volatile unsigned*)c->h_tick_flag) > 0) { return 0; }
-    const int k = (int)(nticks % sdrpp_ctx::kTickEvents);
-    if (!c->tick_ev[k] || c->tick_ev_tick[k] < nticks) {
-        // no event behind that tick (a block without result copies in it): the stream itself
-        if (!wait) { return hipStreamQuery(c->stream) == hipSuccess ? 1 : 0; }
-        return hipStreamSynchronize(c->stream) == hipSuccess ? 1 : fail(c, SDRPP_ERR_HIP, "hipStreamSynchronize failed");
+    int best = -1;
+    for (int k = 0; k < sdrpp_ctx::kTickEvents; k++) {
+        if (c->tick_ev[k] && c->tick_ev_tick[k] >= nticks && (best < 0 || c->tick_ev_tick[k] < c->tick_ev_tick[best])) { best = k; }
+    }
+    hipEvent_t ev = best >= 0 ? c->tick_ev[best] : nullptr;
+    if (!ev) {
+        ev = tick_event_take(c, c->ticks);
+        if (!ev || hipEventRecord(ev, c->stream) != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "hipEventRecord failed"); }
     }
     long spins = 0;
     for (;;) {
-        const hipError_t e = hipEventQuery(c->tick_ev[k]);
+        const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) { return 1; }
         if (e != hipErrorNotReady) { return fail(c, SDRPP_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(e)); }
         if (!wait) { return 0; }
@@ -152,30 +166,43 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     c->tick_target += (unsigned)blocks;
     c->ticks++;
     TickDone done{ c->d_tick_counter, c->hd_tick_flag, c->tick_target, (unsigned)c->ticks };
+    hipEvent_t stop_ev = nullptr;
     const TickTable* tab = c->next_tab_n > 0 ? c->next_tab : c->empty_tab;
     {
-        hipEvent_t ea = nullptr;
+        // Completion events ride on the launch itself (hipExtLaunchKernelGGL's start / stop events: the dispatch packet's own signal, no packet
+        // of their own in the queue): the stop event orders the tick's result writes for the host (host_ctx.h), start + stop time the launch.
         const bool timed = c->timing && ((c->timing_mask >> F_TICK) & 1u);
         c->fam_launch[F_TICK]++;
-        if (timed) {
-            ea = get_event(c);
-            (void)hipEventRecord(ea, c->stream);
+        bool want_ev = timed;
+        if (to_host && c->tick_ev_ext && ++c->tick_ev_skipped >= c->tick_ev_every) {
+            c->tick_ev_skipped = 0;
+            want_ev = true;
+        }
+        hipEvent_t ea = nullptr;
+        if (want_ev) {
+            const int k = c->tick_ev_next;
+            stop_ev = tick_event_take(c, c->ticks);
+            if (!stop_ev) { return fail(c, SDRPP_ERR_HIP, "hipEventCreate failed"); }
+            if (timed) {
+                ea = get_event(c);
+                c->tick_ev_start[k] = ea;
+            }
         }
         HostScope hs("launch");
-        if (set1) { hipLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
-        else { hipLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
-        if (timed) {
-            hipEvent_t eb = get_event(c);
-            (void)hipEventRecord(eb, c->stream);
-            c->tpairs.push_back({ ea, eb, F_TICK });
-            if (c->tpairs.size() > 8192) { timing_flush(c); }
+        if (stop_ev) {
+            if (set1) { hipExtLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), (unsigned)lds, c->stream, ea, stop_ev, 0, l0, tab, done); }
+            else { hipExtLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), (unsigned)lds, c->stream, ea, stop_ev, 0, l0, tab, done); }
         }
+        else if (set1) { hipLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        else { hipLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
     }
-    if (to_host) {  // results for the host in this tick: their completion is an event (see host_ctx.h)
-        const int k = (int)(c->ticks % sdrpp_ctx::kTickEvents);
-        if (!c->tick_ev[k] && hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { return fail(c, SDRPP_ERR_HIP, "hipEventCreate failed"); }
-        HIPCHK(c, hipEventRecord(c->tick_ev[k], c->stream));
-        c->tick_ev_tick[k] = c->ticks;
+    if (to_host && !c->tick_ev_ext) {  // measurement switch: the event as a packet of its own behind the launch
+        if (++c->tick_ev_skipped >= c->tick_ev_every) {
+            c->tick_ev_skipped = 0;
+            hipEvent_t ev = tick_event_take(c, c->ticks);
+            if (!ev) { return fail(c, SDRPP_ERR_HIP, "hipEventCreate failed"); }
+            HIPCHK(c, hipEventRecord(ev, c->stream));
+        }
     }
     c->arena_tick[c->arena_slot] = c->ticks;
     c->next_tab = tab_dev_next;
