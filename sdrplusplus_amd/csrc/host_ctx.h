@@ -32,6 +32,8 @@ struct Stream {
     float* extra[kRing - 1] = {};
     int n_extra = 0, rot = 0;
     int clevel = 0;  // pipelined mode: level of the role that consumes this stream with memory (its history carry runs there)
+    float* prev_data = nullptr;  // pipelined mode: the data buffer of the block before (stream_rotate) and its sample count — where a piped back end
+    int prev_n = 0;              // finds the tail of the previous block (do_vfos_plan: pipe_in)
 };
 
 // Tap tables of the matrix-core FIR kernel (vfo_toep_kernel): zero-padded taps + per-lane base indices (one set per carried
@@ -275,6 +277,14 @@ struct sdrpp_ctx {
     int tick_zoom_groups = getenv("SDRPP_GPU_TICK_ZOOM_GROUPS") ? atoi(getenv("SDRPP_GPU_TICK_ZOOM_GROUPS")) : 8;
     int tick_fcm_waves = getenv("SDRPP_GPU_TICK_FCM_WAVES") ? atoi(getenv("SDRPP_GPU_TICK_FCM_WAVES")) : 768;
     int tick_toep_blocks = getenv("SDRPP_GPU_TICK_TOEP_BLOCKS") ? atoi(getenv("SDRPP_GPU_TICK_TOEP_BLOCKS")) : 256;
+    // FM back ends as ONE role of the tick (last decimator -> resampler -> channel filter -> discriminator + audio low-pass in a workgroup, the
+    // streams between them in LDS: pipe_kernels.h) instead of four roles on four ticks.  Bit-identical, two levels shallower, half the
+    // inter-stage traffic — and SLOWER wherever it was measured (profiles/r04j_pipe_role_sweep.log): a segment's four coupled stages are one
+    // long dependent walk (10^6-sample blocks: tick 82.6 us with 256 workgroups, 70.8 with 512, against 50.0 for the four roles; sr/200 blocks
+    // 32 us against 12), and blocks shorter than a filter history per VFO (cfg 4's NFM channels at sr/200) would fall back to ordinary passes.
+    // Off by default; SDRPP_GPU_TICK_PIPE=1 for measurements (tests/test_pipelined.py keeps it bit-identical).
+    bool tick_pipe = getenv("SDRPP_GPU_TICK_PIPE") ? atoi(getenv("SDRPP_GPU_TICK_PIPE")) != 0 : false;
+    int tick_pipe_blocks = getenv("SDRPP_GPU_TICK_PIPE_BLOCKS") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_PIPE_BLOCKS"))) : 256;
     long arena_begins = 0;                // blocks planned so far (block_bounds: one per ordinary pass / per block of a pipelined run)
     int arena_allocs = 0;
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)

@@ -193,6 +193,8 @@ int stream_ring_ensure(sdrpp_ctx* c, Stream& s) {
 }
 void stream_rotate(Stream& s) {
     if (s.n_extra == 0 || !s.base) { return; }
+    s.prev_data = s.data;
+    s.prev_n = s.n;
     std::swap(s.base, s.extra[s.rot]);
     s.data = s.base;
     s.rot = (s.rot + 1) % s.n_extra;
@@ -500,6 +502,7 @@ void launch_role(sdrpp_ctx* c, const sdrpp_ctx::RoleLaunch& r) {
     case TR_FIRB_Q: hipLaunchKernelGGL((vfo_firb_kernel<1, true, true>), grid, dim3((unsigned)e.aux), r.lds, st, (const FirBJob*)e.jobs); break;
     case TR_PRE: hipLaunchKernelGGL(vfo_demod_pre_kernel, grid, b256, 0, st, (const PreJob*)e.jobs); break;
     case TR_SEQ: hipLaunchKernelGGL(vfo_sequential_kernel, grid, dim3(64), 0, st, (const SeqJob*)e.jobs, e.aux); break;
+    case TR_PIPE: hipLaunchKernelGGL(vfo_pipe_kernel<1>, grid, b256, r.lds, st, (const PipeJob*)e.jobs); break;
     default: break;  // (the FFT branch launches its kernels itself outside pipelined mode: its pass-1 workgroups are wider there)
     }
 }

@@ -461,10 +461,10 @@ __device__ __forceinline__ void pipe_role(float* smp, const PipeJob* __restrict_
     }
 }
 
+// (body of the launch and of the tick kernel's TR_PIPE role: bid.x = segment, gdim.x = segments per VFO, bid.y = job)
 template <int G>
-__global__ __launch_bounds__(256, 5) void vfo_pipe_kernel(const PipeJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float, smp)
-    const PipeJob* __restrict__ Jp = jobs + blockIdx.y;
+__device__ __forceinline__ void vfo_pipe_body(const KIdx bid, const KIdx gdim, float* smp, const PipeJob* __restrict__ jobs) {
+    const PipeJob* __restrict__ Jp = jobs + bid.y;
     const int tid = threadIdx.x, wv = tid >> 6;
     // macro-tile ranges of the four stages for this segment: the last stage's share, then back through the windows
     int omt[4], W[4], span[4], nmt[4], b0[4];
@@ -478,13 +478,13 @@ __global__ __launch_bounds__(256, 5) void vfo_pipe_kernel(const PipeJob* __restr
         b0[s] = Jp->st[s].base0;
     }
     int t0[4], t1[4];
-    t0[3] = (int)((long long)nmt[3] * (long long)blockIdx.x / (long long)gridDim.x);
-    t1[3] = (int)((long long)nmt[3] * (long long)(blockIdx.x + 1) / (long long)gridDim.x);
+    t0[3] = (int)((long long)nmt[3] * (long long)bid.x / (long long)gdim.x);
+    t1[3] = (int)((long long)nmt[3] * (long long)(bid.x + 1) / (long long)gdim.x);
     // The LAST segment takes every stage to the end of its stream whatever the stage behind it consumes in this push: a stage's trailing
     // outputs (a decimator's odd sample, up to M - 1 resampler inputs, everything when a tiny push gives the later stages nothing to do)
     // are the next push's filter history and must reach its stream.
-    const bool last_seg = blockIdx.x + 1 == gridDim.x;
-    if (t1[3] <= t0[3] && !last_seg) { return; }
+    const bool last_seg = bid.x + 1 == gdim.x;
+    if (t1[3] <= t0[3] && !last_seg) { return; }  // (the whole workgroup: no barrier is left waiting)
 #pragma unroll
     for (int s = 3; s >= 1; s--) {
         int a = 0, b = 0;
@@ -518,11 +518,16 @@ __global__ __launch_bounds__(256, 5) void vfo_pipe_kernel(const PipeJob* __restr
     }
     __syncthreads();
     // roles rotate with the segment index, so that whichever SIMD the hardware gives wavefront w does not always run the same stage
-    const int role = (wv + (int)blockIdx.x) & 3;
+    const int role = (wv + bid.x) & 3;
     if (role == 0) { pipe_role<G, 0>(smp, Jp, flags, t0[0], t1[0], 0, 0); }
     else if (role == 1) { pipe_role<G, 1>(smp, Jp, flags, t0[1], t1[1], t0[0], t1[0]); }
     else if (role == 2) { pipe_role<G, 2>(smp, Jp, flags, t0[2], t1[2], t0[1], t1[1]); }
     else { pipe_role<G, 3>(smp, Jp, flags, t0[3], t1[3], t0[2], t1[2]); }
+}
+template <int G>
+__global__ __launch_bounds__(256, 5) void vfo_pipe_kernel(const PipeJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smp)
+    vfo_pipe_body<G>(kidx(blockIdx), kidx(gridDim), smp, jobs);
 }
 
 }  // namespace sdrpp_k

@@ -146,12 +146,19 @@ bool pipe_layout(PipeJob& J, size_t* lds_bytes) { return pipe_layout_try(J, 2, l
 // Segments per VFO, 0 = this push is better served by the separate launches.  A segment pays one warm-up macro tile per stage and the
 // pipeline's fill: with fewer than ~12 last-stage macro tiles per segment of a full grid the four launches win (measured: 1 M-sample
 // pushes of the 32-VFO bank, 2.6 tiles per segment, 14 % slower) — unless the push is so small that it is launch-bound anyway.
-int pipe_segments(const std::vector<PipeJob>& pipes, int forced, size_t lds) {
+int pipe_segments(const std::vector<PipeJob>& pipes, int forced, size_t lds, int tick_blocks = 0) {
     if (pipes.empty()) { return 0; }
     const int bpc = std::max(kPipeBpcMin, std::min(kPipeBpc, (int)((size_t)(160 * 1024) / std::max<size_t>(lds, 1))));
     int max_nmt = 1;
     for (auto& pj : pipes) { max_nmt = std::max(max_nmt, (pj.st[3].nout + kPipeG * 16 * pj.st[3].rows - 1) / (kPipeG * 16 * pj.st[3].rows)); }
     if (forced >= 2) { return std::min(forced, max_nmt); }
+    if (tick_blocks > 0) {
+        // a role of the tick kernel (pipelined mode): ALWAYS the pipeline — whether a VFO's back end runs as one role or as four is a property of
+        // its filters, never of the block, because the streams between the stages are handed from block to block differently in the two forms
+        // (do_vfos_plan) — with about `tick_blocks` workgroups for the whole role (a tick's roles share the GPU) and at least two last-stage
+        // macro tiles per segment (every segment pays one warm-up macro tile per stage)
+        return std::max(1, std::min((tick_blocks + (int)pipes.size() - 1) / (int)pipes.size(), (max_nmt + 1) / 2));
+    }
     const int s_full = (256 * bpc + (int)pipes.size() - 1) / (int)pipes.size();
     if (max_nmt >= 12 * s_full) { return s_full; }
     if (max_nmt <= 16) { return std::max(1, (max_nmt + 1) / 2); }  // two macro tiles per workgroup: the chain of hand-offs is what a small push waits for (B = 50 000: 53 us per push with one segment, 48.5 with three)
@@ -330,8 +337,23 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         // the FM back end as one pipelined launch: last decimator, resampler, channel filter, discriminator + audio low-pass all in
         // their matrix form, and the pipeline's LDS layout fits
         const int last_dec = v.d.n_stages - 1;
-        bool piped_be = c->pipe_on && !ticking && (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) && last_dec >= first_sep && v.tp_stage[last_dec].ok &&
+        bool piped_be = c->pipe_on && (!ticking || c->tick_pipe) && (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) && last_dec >= first_sep && v.tp_stage[last_dec].ok &&
                         v.i_poly >= 0 && v.tp_poly.ok && v.i_chan >= 0 && v.chan_ntaps > 0 && v.tp_chan.ok && v.tp_audio.ok;
+        // Pipelined mode: the four stages of a piped back end run in ONE tick (level L), so a stage cannot take the history of its input stream
+        // from the side buffer — the carry that fills it from the previous block's tail runs one level behind that block's pipeline role, i.e. in
+        // the very tick this block's role runs in.  It reads the tail where the previous block's role left it instead: the end of the previous
+        // block's data buffer (the buffers are a ring of kRing, that one is not written again for three more ticks).  Needs the previous block to
+        // have produced at least a history's worth of samples; a block after a shorter one runs as an ordinary pass (which waits for everything
+        // queued and finds the side buffers complete).  With nothing queued the side buffers ARE complete and are used as they stand.
+        auto pipe_in = [&](Stream& sx) -> StreamIn {
+            StreamIn in = stream_in(sx);
+            if (ticking && sx.hist_len > 0 && !c->tickq.empty()) {
+                if (sx.prev_data && sx.prev_n >= sx.hist_len) { in.hist = sx.prev_data + (size_t)(sx.prev_n - sx.hist_len) * (size_t)sx.width; }
+                else { c->tick_abort = true; }
+            }
+            return in;
+        };
+        const bool tick_piped = ticking;  // (all four stages at the level of the decimator)
         PipeJob pj{};
         size_t pj_lds = 0;
         if (piped_be) {
@@ -365,10 +387,13 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
             if (need_bnd) { bounds_poly(bnd, v.poff, v.pphase, v.d.interp, v.d.decim); }
-            lvl++;
-            cur->clevel = lvl;
+            if (piped_be && tick_piped) { cur->clevel = lvl + 1; }  // (its tail is carried one level behind the role that writes it)
+            else {
+                lvl++;
+                cur->clevel = lvl;
+            }
             if (piped_be) {
-                pj.st[1] = toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f);
+                pj.st[1] = toep_job(v.tp_poly, v.pphase, tick_piped ? pipe_in(*cur) : stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f);
                 pj.keep[1] = std::max(0, no - nxt->hist_len);
             }
             else if (v.tp_poly.ok) { t_poly.add(lvl, toep_job(v.tp_poly, v.pphase, stream_in(*cur), nxt->data, v.poff - (v.tpp - 1), no, 0.0f)); }
@@ -387,10 +412,13 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
             Stream* nxt = &v.st[(size_t)v.i_chan];
-            lvl++;
-            cur->clevel = lvl;
+            if (piped_be && tick_piped) { cur->clevel = lvl + 1; }
+            else {
+                lvl++;
+                cur->clevel = lvl;
+            }
             if (piped_be) {
-                pj.st[2] = toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f);
+                pj.st[2] = toep_job(v.tp_chan, 0, tick_piped ? pipe_in(*cur) : stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f);
                 pj.keep[2] = 0;  // the IF stream is the RxVFO's output: all of it
             }
             else if (v.tp_chan.ok) { t_chan.add(lvl, toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
@@ -412,10 +440,13 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         const int nbnd = need_bnd ? (int)bnd.size() : 0;
         if (v.d.demod == SDRPP_DEMOD_WFM || v.d.demod == SDRPP_DEMOD_NFM) {
             Stream& out = v.st[(size_t)v.i_out];
-            lvl++;
-            cur->clevel = lvl;
+            if (piped_be && tick_piped) { cur->clevel = lvl + 1; }
+            else {
+                lvl++;
+                cur->clevel = lvl;
+            }
             if (piped_be) {
-                pj.st[3] = toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation);
+                pj.st[3] = toep_job(v.tp_audio, 0, tick_piped ? pipe_in(*cur) : stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation);
                 pipes.push_back(pj);
                 pipe_lds = std::max(pipe_lds, pj_lds);
             }
@@ -770,9 +801,12 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     RotJob* d_rot = arena_push(c, rot);
     const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
     if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!retune.empty() && !d_retune) || (!rot.empty() && !d_rot)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    const int pipe_seg = pipe_segments(pipes, c->pipe_on, pipe_lds);
-    int pipe_lvl = 0;
-    if (!pipes.empty() && pipe_seg == 0) {  // not this push: the same four jobs go to the separate launches
+    // Pipelined back ends.  An ordinary pass: ONE launch, at the latest level any of its jobs starts at (levels only order the launches of a
+    // pass) — or none, when this push is better served by the separate launches.  Pipelined mode: one role per LEVEL (a role that ran later
+    // than its VFO's level would find the history of its first stage's input overwritten by the next block's carry), always the pipeline.
+    struct PipeGroup { int lvl = 0; std::vector<PipeJob> jobs; PipeJob* dev = nullptr; int seg = 0; };
+    std::vector<PipeGroup> pgroups;
+    if (!pipes.empty() && !ticking && pipe_segments(pipes, c->pipe_on, pipe_lds) == 0) {  // not this push: the same four jobs go to the separate launches
         for (auto& pj : pipes) {
             t_dec.add(pj.lvl, pj.st[0]);
             t_poly.add(pj.lvl + 1, pj.st[1]);
@@ -781,9 +815,26 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         }
         pipes.clear();
     }
-    for (auto& pj : pipes) { pipe_lvl = std::max(pipe_lvl, pj.lvl); }  // (one launch: at the latest level any of its jobs starts at)
-    PipeJob* d_pipes = arena_push(c, pipes);
-    if (!pipes.empty() && !d_pipes) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+    for (auto& pj : pipes) {
+        PipeGroup* g = nullptr;
+        for (auto& q : pgroups) {
+            if (!ticking || q.lvl == pj.lvl) { g = &q; }
+        }
+        if (!g) {
+            pgroups.emplace_back();
+            g = &pgroups.back();
+            g->lvl = pj.lvl;
+        }
+        g->lvl = std::max(g->lvl, pj.lvl);
+        g->jobs.push_back(pj);
+    }
+    int pipe_top = 0;
+    for (auto& g : pgroups) {
+        g.seg = pipe_segments(g.jobs, c->pipe_on, pipe_lds, ticking ? c->tick_pipe_blocks : 0);
+        g.dev = arena_push(c, g.jobs);
+        if (!g.dev) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        pipe_top = std::max(pipe_top, g.lvl + 1);
+    }
     // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
     struct ToepList { Lev<ToepJob>* L; int npl, width; bool quad; int fam; int role; };
     ToepList tlists[] = { { &t_dec, 2, 2, false, F_DECIM, TR_TOEP_C },      { &t_poly, 2, 2, false, F_POLY, TR_TOEP_C },       { &t_chan, 2, 2, false, F_FIR, TR_TOEP_C },
@@ -1017,7 +1068,7 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     // ---- levels 2 ...: everything behind the front end, level by level (within a level the launches are independent of each other) ----
     int top = std::max({ t_dec.top, t_poly.top, t_chan.top, t_audio.top, t_audio_fm.top, t_af_dec.top, t_af_poly.top, t_af_hpf.top, f_dec.top, poly.top,
                          polyb[0].top, polyb[1].top, polyb[2].top, polyb[3].top, chan.top, seq.top, pre.top, audio.top, audio_fm.top, af_dec.top, af_hpf.top,
-                         af_poly.top, af_deemp.top, ssbx_l.top, carry.top, pipe_lvl + 1 });
+                         af_poly.top, af_deemp.top, ssbx_l.top, carry.top, pipe_top });
     for (int l = 1; l < top; l++) {
         {
             FamilyTimer t(c, F_DECIM);
@@ -1027,10 +1078,11 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
                 if (rc) { return rc; }
             }
         }
-        if (!pipes.empty() && l == pipe_lvl) {
+        for (auto& g : pgroups) {
+            if (g.lvl != l || g.seg <= 0) { continue; }
             FamilyTimer t(c, F_PIPE);
             c->pipe_launched = true;
-            launch(c, vfo_pipe_kernel<kPipeG>, dim3((unsigned)pipe_seg, (unsigned)pipes.size()), dim3(256), pipe_lds, (const PipeJob*)d_pipes);
+            emit(c, l, F_PIPE, TR_PIPE, g.seg, (int)g.jobs.size(), pipe_lds, g.dev);
         }
         {
             FamilyTimer t(c, F_POLY);

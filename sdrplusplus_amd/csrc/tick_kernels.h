@@ -86,6 +86,7 @@ enum TickRole : int {
     TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10,             // p.p2
     TR_FFT_P2ROW, TR_FFT_TR,                                         // p.p2 (long transforms: 4096-point rows in place; transpose into bin order, aux = doZoom group size)
     TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
+    TR_PIPE,       // PipeJob[gy], gx = segments per VFO: vfo_pipe_body<1> — an FM back end (last decimator, resampler, channel filter, discriminator + audio low-pass) as ONE role
     TR_COUNT
 };
 struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, ntiles; };
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
+            case TR_PIPE: vfo_pipe_body<1>(bid, gdim, smem, reinterpret_cast<const PipeJob*>(e_jobs)); break;
             default: break;
             }
         }

@@ -58,7 +58,7 @@ def _compare(ref, got, fft, what):
             assert np.array_equal(ref["index"], got["index"]), what + " palette index"
 
 
-@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37")])
+@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe")])
 def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatch):
     """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks.  l0_at: the stage-0
@@ -66,7 +66,9 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatc
     read when a context is created)."""
     from sdrplusplus_amd import workloads
 
-    if l0_at is not None:
+    if l0_at == "pipe":  # the FM back ends as ONE role of the tick (SDRPP_GPU_TICK_PIPE: a measurement switch, off by default) — blocks shorter than
+        monkeypatch.setenv("SDRPP_GPU_TICK_PIPE", "1")  # a filter history (the 1031- and 7-sample ones and the one behind each) fall back to ordinary passes
+    elif l0_at is not None:
         monkeypatch.setenv("SDRPP_GPU_TICK_L0_AT", l0_at)
 
     nv = 20 if backend == "gpu" else 17
@@ -263,7 +265,8 @@ def test_results_survive_growing_result_slots(backend):
     held = cb.result_wait(2, copy=False)  # handed out and NOT released: its arrays point into the slot's page-locked memory
     held_copy = {v: a.copy() for v, a in held["vfo"].items()}
     st0 = cb.pipeline_stats()
-    assert st0["tick_blocks"] == 5 and st0["pass_blocks"] == 0, st0
+    # (blocks this small leave the piped back ends less than a filter history per block: every other one runs as an ordinary pass)
+    assert st0["tick_blocks"] + st0["pass_blocks"] == 5 and st0["tick_blocks"] >= 1, st0
     # twelve more VFOs on both contexts: 1.6 x the result bytes per block — more than the slots' 12.5 % slack
     for mode, if_rate, bw, centre, _ in plan[nv:]:
         for ctx, vids in ((ca, va), (cb, vb)):
