@@ -188,29 +188,25 @@ bool arena_push_lev(sdrpp_ctx* c, Lev<T>& L) {
     return true;
 }
 
-int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& iq_carry) {
-    if (c->vfos.empty()) { return SDRPP_OK; }
-#ifdef SDRPP_TOEP_KNOCK
-    {   // diagnostic build: SDRPP_TOEP_KNOCK=<mask> (1: no stores, 2: no loads, 4: no matrix loop) in vfo_toep_kernel
-        static bool once = false;
-        if (!once) {
-            once = true;
-            const int m = getenv("SDRPP_TOEP_KNOCK") ? atoi(getenv("SDRPP_TOEP_KNOCK")) : 0;
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_toep_knock), &m, sizeof(int));
-        }
-    }
-#endif
-    const int n_in = (int)count;
+// One block of the VFO bank, planned in steps: every VFO's chain is walked once (chain: stage by stage — outputs per stage from the integer
+// streaming state, one job per stage in the list of its kind and LEVEL), the first stages are grouped into front-end jobs (group_front),
+// the job tables go into the arena in one piece (upload), then the launches — or, in pipelined mode, the roles — are emitted level by level
+// (emit_front, emit_levels).  Every job carries the LEVEL of its launch in the block's data flow (level L reads what level L - 1 wrote): the
+// front end is level 1 (level 0 = the block's arrival), every filter behind it one more.  A pass launches level by level; in pipelined mode
+// level L of this block runs L ticks from now (tick_kernels.h).
+struct BankPlan {
+    sdrpp_ctx* c;
+    const IqSrc& src;
+    const int n_in;
+    const bool ticking;
+    static constexpr int carry_last = kLevels - 1;
+    const std::vector<int>& fb;  // reference-block ends of this push (at least one entry: n_in)
+    const bool blocks;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;
     Lev<FirBJob> f_dec;  // register-blocked decimators (tap counts the matrix form does not cover; stage 0 only in reference-rotator mode)
     std::vector<RotXJob> rotx;                          // reference-rotator mode: full-rate float recursion, one lane per VFO
     std::vector<RetuneJob> retune;                      // closed-form NCO: first outputs after a setOffset
-    const std::vector<int>& fb = c->vfo_bounds;         // reference-block ends of this push (at least one entry: n_in)
-    const bool blocks = fb.size() > 1;
-    // Every job carries the LEVEL of its launch in the block's data flow (level L reads what level L - 1 wrote): the front end is
-    // level 1 (level 0 = the block's arrival), every filter behind it one more.  A pass launches level by level; in pipelined mode
-    // level L of this block runs L ticks from now (tick_kernels.h).
     Lev<PolyJob> poly;
     Lev<PolyBJob> polyb[4];  // [0]: LMAX 4, [1]: LMAX 8 (de-interleaved tile); [2], [3]: same with odd decimation (linear tile)
     Lev<FirBJob> chan;
@@ -229,13 +225,45 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     Lev<DeempJob> af_deemp;
     Lev<SsbRotXJob> ssbx_l;
     Lev<CarryJob> carry;  // history carries at the level of the stream's consumer (a pass without pipelining: all at the last level)
-    const bool ticking = c->tick_planning;
-    const int carry_last = kLevels - 1;
-    carry.add(ticking ? 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
     int max_rot = 0;
+    // front-end jobs (group_front)
+    struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
+    struct F2Launch { int vt; std::vector<Front2Job> jobs; int max_blocks = 0; size_t lds = 0; };
+    struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; };
+    S1Launch s1l[4];
+    F2Launch f2l[4];
+    FCMLaunch fcm[3];  // PF 6 / 10 / 16
+    FCMLaunch fcl;     // long first stages (vfo_frontcl_kernel)
+    const int vts[4] = { 8, 4, 2, 1 };
+    // device addresses of the job tables (upload)
+    Stage1Job* d_s1[4] = {};
+    Front2Job* d_f2[4] = {};
+    FrontCMJob* d_fcl = nullptr;
+    FrontCMJob* d_fcm[3] = {};
+    RotXJob* d_rotx = nullptr;
+    RetuneJob* d_retune = nullptr;
+    RotJob* d_rot = nullptr;
+    const int* d_fb = nullptr;
+    struct PipeGroup { int lvl = 0; std::vector<PipeJob> jobs; PipeJob* dev = nullptr; int seg = 0; };
+    std::vector<PipeGroup> pgroups;
+    int pipe_top = 0;
+    struct ToepList { Lev<ToepJob>* L; int npl, width; bool quad; int fam; int role; };
+    static constexpr int kToepLists = 8;
+    ToepList tlists[kToepLists] = { { &t_dec, 2, 2, false, F_DECIM, TR_TOEP_C },      { &t_poly, 2, 2, false, F_POLY, TR_TOEP_C },       { &t_chan, 2, 2, false, F_FIR, TR_TOEP_C },
+                                    { &t_audio, 1, 1, false, F_FIR, TR_TOEP_R },      { &t_audio_fm, 2, 1, true, F_FIR, TR_TOEP_Q },     { &t_af_dec, 2, 2, false, F_AF, TR_TOEP_C },
+                                    { &t_af_poly, 2, 2, false, F_AF, TR_TOEP_C },     { &t_af_hpf, 2, 2, false, F_AF, TR_TOEP_C } };
+    ToepPlan tplan[kToepLists][kLevels];
 
-    for (auto& kv : c->vfos) {
-        Vfo& v = *kv.second;
+    BankPlan(sdrpp_ctx* c_, const IqSrc& src_, int64_t count, const CarryJob& iq_carry)
+        : c(c_), src(src_), n_in((int)count), ticking(c_->tick_planning), fb(c_->vfo_bounds), blocks(c_->vfo_bounds.size() > 1) {
+        for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
+        carry.add(ticking ? 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
+    }
+    BankPlan(const BankPlan&) = delete;
+    BankPlan& operator=(const BankPlan&) = delete;
+
+    // ---- one VFO's chain: stage by stage, a job per stage in the list of its kind and level ----
+    int chain(Vfo& v) {
         Stream* cur = &v.st[(size_t)v.i_first];
         int lvl = 1;  // level at which `cur` is written
         for (auto& s : v.st) { s.clevel = 0; }
@@ -543,625 +571,644 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
             }
         }
         c->plan_top = std::max(c->plan_top, lvl + 2);
+        return SDRPP_OK;
     }
 
     // ---- stage 1 (optionally fused with stage 2): group VFOs with identical geometry, VT per job ----
-    auto same = [](const S1Member& a, const S1Member& b) {
-        return a.fused == b.fused && a.K == b.K && a.lgD == b.lgD && a.off0 == b.off0 && a.nout == b.nout && a.min_idx == b.min_idx && a.K2 == b.K2 &&
-               a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2 && a.taph == b.taph;
-    };
-    std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
-        if (a.fused != b.fused) { return a.fused < b.fused; }
-        if (a.K != b.K) { return a.K < b.K; }
-        if (a.lgD != b.lgD) { return a.lgD < b.lgD; }
-        if (a.off0 != b.off0) { return a.off0 < b.off0; }
-        if (a.nout != b.nout) { return a.nout < b.nout; }
-        if (a.min_idx != b.min_idx) { return a.min_idx < b.min_idx; }
-        if (a.K2 != b.K2) { return a.K2 < b.K2; }
-        if (a.lgD2 != b.lgD2) { return a.lgD2 < b.lgD2; }
-        if (a.off2 != b.off2) { return a.off2 < b.off2; }
-        if (a.nout2 != b.nout2) { return a.nout2 < b.nout2; }
-        if (a.taph != b.taph) { return a.taph < b.taph; }
-        return a.v->id < b.v->id;
-    });
-    struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
-    struct F2Launch { int vt; std::vector<Front2Job> jobs; int max_blocks = 0; size_t lds = 0; };
-    struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; };
-    S1Launch s1l[4];
-    F2Launch f2l[4];
-    FCMLaunch fcm[3];  // PF 6 / 10 / 16
-    FCMLaunch fcl;     // long first stages (vfo_frontcl_kernel)
-    const int vts[4] = { 8, 4, 2, 1 };
-    for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
-    size_t i = 0;
-    while (i < s1.size()) {
-        size_t j = i;
-        while (j < s1.size() && same(s1[j], s1[i])) { j++; }
-        size_t g = i;
-        // ---- matrix-core path: >= 17 fused VFOs of one geometry -> jobs of up to 32 VFOs, stages 1 + 2 as one composite FIR ----
-        int m_pf = 0;
-        const bool m_fused = s1[i].fused && frontcm_ok(s1[i].K, s1[i].lgD, s1[i].K2, s1[i].lgD2, &m_pf);
-        // ... or a long first stage on its own (decimation >= 32: no fusion, vfo_frontcl_kernel)
-        const bool m_long = !m_fused && !s1[i].fused && s1[i].lgD >= 5 && s1[i].K >= 9 && (size_t)frontcl_lds_floats(s1[i].K, s1[i].lgD) * 4 <= (size_t)kMaxLds;
-        const bool m_ok = m_fused || m_long;
-        // worth it from 17 VFOs against the fused VALU kernel (8 VFOs per work-item); a long first stage has no good VALU form (its
-        // per-VFO windows do not fit LDS), there the matrix kernel pays off from 2 VFOs on
-        const size_t m_min = m_long ? 2 : 17;
-        while (m_ok && j - g >= m_min) {
-            const int vt = (int)std::min<size_t>(j - g, SDRPP_FCM_VT);
-            S1Member h = s1[g];
-            if (m_long) {  // the "composite" is the first stage alone
-                h.K2 = 1;
-                h.lgD2 = 0;
-                h.off2 = 0;
-                h.nout2 = h.nout;
-            }
-            const int D1 = 1 << h.lgD;
-            const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
-            const int NP = (K + 1) / 2, NP4 = (NP + 7) / 8 * 8;  // rows of the tap operand table, zero padded (the kernels read 4 / 8 rows at a time)
-            const std::string key = member_key(m_long ? 'L' : 'M', &s1[g], vt);
-            float2* d_taps = nullptr;
-            auto it = c->s1_tap_cache.find(key);
-            if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
-            else {
-                // [NP4][64] floats (= NP4 * 32 float2; rows >= NP are zero padding) followed by [32][TILE] float2
-                std::vector<float2> host((size_t)NP4 * 32 + (size_t)SDRPP_FCM_VT * SDRPP_FCM_TILE, make_float2(0.0f, 0.0f));
-                float* at = reinterpret_cast<float*>(host.data());
-                std::vector<double> h12((size_t)K);
-                const double kc = 0.5 * (double)(K - 1);
-                for (int m = 0; m < vt; m++) {
-                    const Vfo& vv = *s1[g + m].v;
-                    // composite taps h12 = h1 (*) upsample(h2, D1) in double precision (both are linear phase, so is h12)
-                    std::fill(h12.begin(), h12.end(), 0.0);
-                    for (int k2 = 0; k2 < h.K2; k2++) {
-                        const double w2 = m_long ? 1.0 : (double)vv.staps[1][(size_t)k2];
-                        for (int k1 = 0; k1 < h.K; k1++) { h12[(size_t)k2 * D1 + k1] += w2 * (double)vv.staps[0][(size_t)k1]; }
-                    }
-                    for (int pz = 0; pz < NP; pz++) {
-                        double t = ((double)pz - kc) * vv.theta;  // modulation centred on the filter: g[K-1-k] = conj(g[k])
-                        t -= std::rint(t);
-                        const double a = 2.0 * 3.14159265358979323846 * t;
-                        double gr = h12[(size_t)pz] * std::cos(a), gi = h12[(size_t)pz] * std::sin(a);
-                        if ((K & 1) && pz == NP - 1) { gr = h12[(size_t)pz]; gi = 0.0; }
-                        at[(size_t)pz * 64 + m] = (float)gr;
-                        at[(size_t)pz * 64 + 32 + m] = (float)-gi;
-                    }
+    int group_front() {
+        auto same = [](const S1Member& a, const S1Member& b) {
+            return a.fused == b.fused && a.K == b.K && a.lgD == b.lgD && a.off0 == b.off0 && a.nout == b.nout && a.min_idx == b.min_idx && a.K2 == b.K2 &&
+                   a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2 && a.taph == b.taph;
+        };
+        std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
+            if (a.fused != b.fused) { return a.fused < b.fused; }
+            if (a.K != b.K) { return a.K < b.K; }
+            if (a.lgD != b.lgD) { return a.lgD < b.lgD; }
+            if (a.off0 != b.off0) { return a.off0 < b.off0; }
+            if (a.nout != b.nout) { return a.nout < b.nout; }
+            if (a.min_idx != b.min_idx) { return a.min_idx < b.min_idx; }
+            if (a.K2 != b.K2) { return a.K2 < b.K2; }
+            if (a.lgD2 != b.lgD2) { return a.lgD2 < b.lgD2; }
+            if (a.off2 != b.off2) { return a.off2 < b.off2; }
+            if (a.nout2 != b.nout2) { return a.nout2 < b.nout2; }
+            if (a.taph != b.taph) { return a.taph < b.taph; }
+            return a.v->id < b.v->id;
+        });
+        size_t i = 0;
+        while (i < s1.size()) {
+            size_t j = i;
+            while (j < s1.size() && same(s1[j], s1[i])) { j++; }
+            size_t g = i;
+            // ---- matrix-core path: >= 17 fused VFOs of one geometry -> jobs of up to 32 VFOs, stages 1 + 2 as one composite FIR ----
+            int m_pf = 0;
+            const bool m_fused = s1[i].fused && frontcm_ok(s1[i].K, s1[i].lgD, s1[i].K2, s1[i].lgD2, &m_pf);
+            // ... or a long first stage on its own (decimation >= 32: no fusion, vfo_frontcl_kernel)
+            const bool m_long = !m_fused && !s1[i].fused && s1[i].lgD >= 5 && s1[i].K >= 9 && (size_t)frontcl_lds_floats(s1[i].K, s1[i].lgD) * 4 <= (size_t)kMaxLds;
+            const bool m_ok = m_fused || m_long;
+            // worth it from 17 VFOs against the fused VALU kernel (8 VFOs per work-item); a long first stage has no good VALU form (its
+            // per-VFO windows do not fit LDS), there the matrix kernel pays off from 2 VFOs on
+            const size_t m_min = m_long ? 2 : 17;
+            while (m_ok && j - g >= m_min) {
+                const int vt = (int)std::min<size_t>(j - g, SDRPP_FCM_VT);
+                S1Member h = s1[g];
+                if (m_long) {  // the "composite" is the first stage alone
+                    h.K2 = 1;
+                    h.lgD2 = 0;
+                    h.off2 = 0;
+                    h.nout2 = h.nout;
                 }
-                for (int m = 0; m < SDRPP_FCM_VT; m++) {
-                    const double step = m < vt ? s1[g + m].v->theta * (double)(1 << lgD) : 0.0;
-                    for (int jj = 0; jj < SDRPP_FCM_TILE; jj++) {
-                        double tt = step * (double)jj;
-                        tt -= std::rint(tt);
-                        const double a = 2.0 * 3.14159265358979323846 * tt;
-                        host[(size_t)NP4 * 32 + (size_t)m * SDRPP_FCM_TILE + jj] = make_float2((float)std::cos(a), (float)std::sin(a));
-                    }
-                }
-                if (c->s1_tap_cache.size() > 4096) {
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
-                    for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
-                    c->s1_tap_cache.clear();
-                }
-                int rc = dev_alloc(c, &d_taps, host.size());
-                if (rc) { return rc; }
-                HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                c->s1_tap_cache[key] = d_taps;
-            }
-            FrontCMJob job{};
-            job.nv = vt;
-            job.ntaps = K;
-            job.log2_decim = lgD;
-            job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1);
-            job.nout = h.nout2;
-            job.min_idx = h.min_idx;
-            const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
-            // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
-            // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
-            const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD) * 4))) : 0;
-            const int resident = m_long ? 256 * long_blocks * 2 : (c->tick_planning ? c->tick_fcm_waves : 3072);
-            job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
-            job.atab = reinterpret_cast<const float*>(d_taps);
-            job.ptab = d_taps + (size_t)NP4 * 32;
-            for (int m = 0; m < SDRPP_FCM_VT; m++) {
-                Vfo* v = s1[g + std::min(m, vt - 1)].v;
-                job.theta[m] = v->theta;
-                job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
-                job.out[m] = (float2*)v->st[(size_t)v->i_first + (m_long ? 0 : 1)].data;
-            }
-            if (m_long) {
-                fcl.jobs.push_back(job);
-                fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + 2 * job.tiles_per_wave - 1) / (2 * job.tiles_per_wave));
-                fcl.lds = std::max(fcl.lds, (size_t)frontcl_lds_floats(K, lgD) * 4);
-            }
-            else {
-                FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
-                L.jobs.push_back(job);
-                L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
-                L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
-            }
-            g += (size_t)vt;
-        }
-        while (g < j) {
-            const size_t left = j - g;
-            int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
-            const int vt = vts[li];
-            // tap array for this membership (cached on the device)
-            const std::string key = member_key('V', &s1[g], vt);
-            float2* d_taps = nullptr;
-            auto it = c->s1_tap_cache.find(key);
-            if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
-            else {
-                const int K = (s1[g].K + 1) / 2;  // tap pairs
-                std::vector<float2> host((size_t)K * vt + (size_t)256 * vt);
-                for (int k = 0; k < K; k++) {
-                    for (int m = 0; m < vt; m++) { host[(size_t)k * vt + m] = s1[g + m].v->modtaps[(size_t)k]; }
-                }
-                // NCO advance inside a 256-output tile: exp(j*2*pi*theta*D1*j) (fused front kernel)
-                for (int m = 0; m < vt; m++) {
-                    const double step = s1[g + m].v->theta * (double)(1 << s1[g].lgD);
-                    for (int jj = 0; jj < 256; jj++) {
-                        double tt = step * (double)jj;
-                        tt -= std::rint(tt);
-                        const double a = 2.0 * 3.14159265358979323846 * tt;
-                        host[(size_t)K * vt + (size_t)jj * vt + m] = make_float2((float)std::cos(a), (float)std::sin(a));
-                    }
-                }
-                if (c->s1_tap_cache.size() > 4096) {  // retune churn: drop everything (rare)
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
-                    for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
-                    c->s1_tap_cache.clear();
-                }
-                int rc = dev_alloc(c, &d_taps, host.size());
-                if (rc) { return rc; }
-                HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));  // `host` is pageable and goes out of scope
-                c->s1_tap_cache[key] = d_taps;
-            }
-            const S1Member& h = s1[g];
-            if (h.fused) {
-                Front2Job job{};
-                job.nv = vt;
-                job.ntaps1 = h.K;
-                job.log2_decim1 = h.lgD;
-                job.off1 = h.off0;
-                job.ntaps2 = h.K2;
-                job.log2_decim2 = h.lgD2;
-                job.off2 = h.off2;
-                job.nout2 = h.nout2;
-                job.t2 = front2_t2(h.K, 1 << h.lgD, h.K2, 1 << h.lgD2, 8);
-                job.min_idx = h.min_idx;
-                job.ctaps = d_taps;
-                job.ptab = d_taps + (size_t)((h.K + 1) / 2) * vt;
-                job.taps2 = h.v->d_staps_nat[1];
-                for (int m = 0; m < vt; m++) {
-                    Vfo* v = s1[g + m].v;
-                    job.theta[m] = v->theta;
-                    job.phi0[m] = s1[g + m].phi0;
-                    job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
-                }
-                f2l[li].jobs.push_back(job);
-                f2l[li].max_blocks = std::max(f2l[li].max_blocks, (job.nout2 + job.t2 - 1) / job.t2);
                 const int D1 = 1 << h.lgD;
-                f2l[li].lds = std::max(f2l[li].lds, (std::max((size_t)D1 * (256 + (h.K - 1 + D1 - 1) / D1 + 1), (size_t)vt * 272) + (size_t)vt) * sizeof(float2));
-            }
-            else {
-                Stage1Job job{};
-                job.nv = vt;
-                job.ntaps = h.K;
-                job.log2_decim = h.lgD;
-                job.off0 = h.off0;
-                job.nout = h.nout;
-                job.min_idx = h.min_idx;
-                job.ctaps = d_taps;
-                for (int m = 0; m < vt; m++) {
-                    Vfo* v = s1[g + m].v;
-                    job.theta[m] = v->theta;
-                    job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
-                    job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+                const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
+                const int NP = (K + 1) / 2, NP4 = (NP + 7) / 8 * 8;  // rows of the tap operand table, zero padded (the kernels read 4 / 8 rows at a time)
+                const std::string key = member_key(m_long ? 'L' : 'M', &s1[g], vt);
+                float2* d_taps = nullptr;
+                auto it = c->s1_tap_cache.find(key);
+                if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
+                else {
+                    // [NP4][64] floats (= NP4 * 32 float2; rows >= NP are zero padding) followed by [32][TILE] float2
+                    std::vector<float2> host((size_t)NP4 * 32 + (size_t)SDRPP_FCM_VT * SDRPP_FCM_TILE, make_float2(0.0f, 0.0f));
+                    float* at = reinterpret_cast<float*>(host.data());
+                    std::vector<double> h12((size_t)K);
+                    const double kc = 0.5 * (double)(K - 1);
+                    for (int m = 0; m < vt; m++) {
+                        const Vfo& vv = *s1[g + m].v;
+                        // composite taps h12 = h1 (*) upsample(h2, D1) in double precision (both are linear phase, so is h12)
+                        std::fill(h12.begin(), h12.end(), 0.0);
+                        for (int k2 = 0; k2 < h.K2; k2++) {
+                            const double w2 = m_long ? 1.0 : (double)vv.staps[1][(size_t)k2];
+                            for (int k1 = 0; k1 < h.K; k1++) { h12[(size_t)k2 * D1 + k1] += w2 * (double)vv.staps[0][(size_t)k1]; }
+                        }
+                        for (int pz = 0; pz < NP; pz++) {
+                            double t = ((double)pz - kc) * vv.theta;  // modulation centred on the filter: g[K-1-k] = conj(g[k])
+                            t -= std::rint(t);
+                            const double a = 2.0 * 3.14159265358979323846 * t;
+                            double gr = h12[(size_t)pz] * std::cos(a), gi = h12[(size_t)pz] * std::sin(a);
+                            if ((K & 1) && pz == NP - 1) { gr = h12[(size_t)pz]; gi = 0.0; }
+                            at[(size_t)pz * 64 + m] = (float)gr;
+                            at[(size_t)pz * 64 + 32 + m] = (float)-gi;
+                        }
+                    }
+                    for (int m = 0; m < SDRPP_FCM_VT; m++) {
+                        const double step = m < vt ? s1[g + m].v->theta * (double)(1 << lgD) : 0.0;
+                        for (int jj = 0; jj < SDRPP_FCM_TILE; jj++) {
+                            double tt = step * (double)jj;
+                            tt -= std::rint(tt);
+                            const double a = 2.0 * 3.14159265358979323846 * tt;
+                            host[(size_t)NP4 * 32 + (size_t)m * SDRPP_FCM_TILE + jj] = make_float2((float)std::cos(a), (float)std::sin(a));
+                        }
+                    }
+                    if (c->s1_tap_cache.size() > 4096) {
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
+                        c->s1_tap_cache.clear();
+                    }
+                    int rc = dev_alloc(c, &d_taps, host.size());
+                    if (rc) { return rc; }
+                    HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    c->s1_tap_cache[key] = d_taps;
                 }
-                s1l[li].jobs.push_back(job);
-                s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
-                const int D = 1 << job.log2_decim;
-                const int tile = pick_tile(D, job.ntaps, 8);
-                if (tile == 0 && job.log2_decim < 5) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
-                if (tile > 0) { s1l[li].tile = std::min(s1l[li].tile, tile); }
+                FrontCMJob job{};
+                job.nv = vt;
+                job.ntaps = K;
+                job.log2_decim = lgD;
+                job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1);
+                job.nout = h.nout2;
+                job.min_idx = h.min_idx;
+                const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
+                // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
+                // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
+                const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD) * 4))) : 0;
+                const int resident = m_long ? 256 * long_blocks * 2 : (c->tick_planning ? c->tick_fcm_waves : 3072);
+                job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
+                job.atab = reinterpret_cast<const float*>(d_taps);
+                job.ptab = d_taps + (size_t)NP4 * 32;
+                for (int m = 0; m < SDRPP_FCM_VT; m++) {
+                    Vfo* v = s1[g + std::min(m, vt - 1)].v;
+                    job.theta[m] = v->theta;
+                    job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
+                    job.out[m] = (float2*)v->st[(size_t)v->i_first + (m_long ? 0 : 1)].data;
+                }
+                if (m_long) {
+                    fcl.jobs.push_back(job);
+                    fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + 2 * job.tiles_per_wave - 1) / (2 * job.tiles_per_wave));
+                    fcl.lds = std::max(fcl.lds, (size_t)frontcl_lds_floats(K, lgD) * 4);
+                }
+                else {
+                    FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
+                    L.jobs.push_back(job);
+                    L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
+                    L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
+                }
+                g += (size_t)vt;
             }
-            g += (size_t)vt;
+            while (g < j) {
+                const size_t left = j - g;
+                int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
+                const int vt = vts[li];
+                // tap array for this membership (cached on the device)
+                const std::string key = member_key('V', &s1[g], vt);
+                float2* d_taps = nullptr;
+                auto it = c->s1_tap_cache.find(key);
+                if (it != c->s1_tap_cache.end()) { d_taps = it->second; }
+                else {
+                    const int K = (s1[g].K + 1) / 2;  // tap pairs
+                    std::vector<float2> host((size_t)K * vt + (size_t)256 * vt);
+                    for (int k = 0; k < K; k++) {
+                        for (int m = 0; m < vt; m++) { host[(size_t)k * vt + m] = s1[g + m].v->modtaps[(size_t)k]; }
+                    }
+                    // NCO advance inside a 256-output tile: exp(j*2*pi*theta*D1*j) (fused front kernel)
+                    for (int m = 0; m < vt; m++) {
+                        const double step = s1[g + m].v->theta * (double)(1 << s1[g].lgD);
+                        for (int jj = 0; jj < 256; jj++) {
+                            double tt = step * (double)jj;
+                            tt -= std::rint(tt);
+                            const double a = 2.0 * 3.14159265358979323846 * tt;
+                            host[(size_t)K * vt + (size_t)jj * vt + m] = make_float2((float)std::cos(a), (float)std::sin(a));
+                        }
+                    }
+                    if (c->s1_tap_cache.size() > 4096) {  // retune churn: drop everything (rare)
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        for (auto& e : c->s1_tap_cache) { (void)hipFree(e.second); }
+                        c->s1_tap_cache.clear();
+                    }
+                    int rc = dev_alloc(c, &d_taps, host.size());
+                    if (rc) { return rc; }
+                    HIPCHK(c, hipMemcpyAsync(d_taps, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));  // `host` is pageable and goes out of scope
+                    c->s1_tap_cache[key] = d_taps;
+                }
+                const S1Member& h = s1[g];
+                if (h.fused) {
+                    Front2Job job{};
+                    job.nv = vt;
+                    job.ntaps1 = h.K;
+                    job.log2_decim1 = h.lgD;
+                    job.off1 = h.off0;
+                    job.ntaps2 = h.K2;
+                    job.log2_decim2 = h.lgD2;
+                    job.off2 = h.off2;
+                    job.nout2 = h.nout2;
+                    job.t2 = front2_t2(h.K, 1 << h.lgD, h.K2, 1 << h.lgD2, 8);
+                    job.min_idx = h.min_idx;
+                    job.ctaps = d_taps;
+                    job.ptab = d_taps + (size_t)((h.K + 1) / 2) * vt;
+                    job.taps2 = h.v->d_staps_nat[1];
+                    for (int m = 0; m < vt; m++) {
+                        Vfo* v = s1[g + m].v;
+                        job.theta[m] = v->theta;
+                        job.phi0[m] = s1[g + m].phi0;
+                        job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
+                    }
+                    f2l[li].jobs.push_back(job);
+                    f2l[li].max_blocks = std::max(f2l[li].max_blocks, (job.nout2 + job.t2 - 1) / job.t2);
+                    const int D1 = 1 << h.lgD;
+                    f2l[li].lds = std::max(f2l[li].lds, (std::max((size_t)D1 * (256 + (h.K - 1 + D1 - 1) / D1 + 1), (size_t)vt * 272) + (size_t)vt) * sizeof(float2));
+                }
+                else {
+                    Stage1Job job{};
+                    job.nv = vt;
+                    job.ntaps = h.K;
+                    job.log2_decim = h.lgD;
+                    job.off0 = h.off0;
+                    job.nout = h.nout;
+                    job.min_idx = h.min_idx;
+                    job.ctaps = d_taps;
+                    for (int m = 0; m < vt; m++) {
+                        Vfo* v = s1[g + m].v;
+                        job.theta[m] = v->theta;
+                        job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
+                        job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+                    }
+                    s1l[li].jobs.push_back(job);
+                    s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);
+                    const int D = 1 << job.log2_decim;
+                    const int tile = pick_tile(D, job.ntaps, 8);
+                    if (tile == 0 && job.log2_decim < 5) { return fail(c, SDRPP_ERR_UNSUPPORTED, "stage-1 filter (decim %d, %d taps) does not fit in LDS", D, job.ntaps); }
+                    if (tile > 0) { s1l[li].tile = std::min(s1l[li].tile, tile); }
+                }
+                g += (size_t)vt;
+            }
+            i = j;
         }
-        i = j;
+        return SDRPP_OK;
     }
 
     // ---- job tables into the arena (one upload for the whole block) ----
-    Stage1Job* d_s1[4] = {};
-    for (int k = 0; k < 4; k++) {
-        if (!s1l[k].jobs.empty()) {
-            for (auto& jb : s1l[k].jobs) { s1l[k].lds = std::max(s1l[k].lds, fir_lds(s1l[k].tile, 1 << jb.log2_decim, jb.ntaps, 8)); }
-            d_s1[k] = arena_push(c, s1l[k].jobs);
-            if (!d_s1[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-        }
-    }
-    Front2Job* d_f2[4] = {};
-    for (int k = 0; k < 4; k++) {
-        if (!f2l[k].jobs.empty()) {
-            d_f2[k] = arena_push(c, f2l[k].jobs);
-            if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-        }
-    }
-    FrontCMJob* d_fcl = arena_push(c, fcl.jobs);
-    if (!fcl.jobs.empty() && !d_fcl) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    FrontCMJob* d_fcm[3] = {};
-    for (int k = 0; k < 3; k++) {
-        if (!fcm[k].jobs.empty()) {
-            d_fcm[k] = arena_push(c, fcm[k].jobs);
-            if (!d_fcm[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-        }
-    }
-    RotXJob* d_rotx = arena_push(c, rotx);
-    RetuneJob* d_retune = arena_push(c, retune);
-    RotJob* d_rot = arena_push(c, rot);
-    const int* d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
-    if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!retune.empty() && !d_retune) || (!rot.empty() && !d_rot)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    // Pipelined back ends.  An ordinary pass: ONE launch, at the latest level any of its jobs starts at (levels only order the launches of a
-    // pass) — or none, when this push is better served by the separate launches.  Pipelined mode: one role per LEVEL (a role that ran later
-    // than its VFO's level would find the history of its first stage's input overwritten by the next block's carry), always the pipeline.
-    struct PipeGroup { int lvl = 0; std::vector<PipeJob> jobs; PipeJob* dev = nullptr; int seg = 0; };
-    std::vector<PipeGroup> pgroups;
-    if (!pipes.empty() && !ticking && pipe_segments(pipes, c->pipe_on, pipe_lds) == 0) {  // not this push: the same four jobs go to the separate launches
-        for (auto& pj : pipes) {
-            t_dec.add(pj.lvl, pj.st[0]);
-            t_poly.add(pj.lvl + 1, pj.st[1]);
-            t_chan.add(pj.lvl + 2, pj.st[2]);
-            t_audio_fm.add(pj.lvl + 3, pj.st[3]);
-        }
-        pipes.clear();
-    }
-    for (auto& pj : pipes) {
-        PipeGroup* g = nullptr;
-        for (auto& q : pgroups) {
-            if (!ticking || q.lvl == pj.lvl) { g = &q; }
-        }
-        if (!g) {
-            pgroups.emplace_back();
-            g = &pgroups.back();
-            g->lvl = pj.lvl;
-        }
-        g->lvl = std::max(g->lvl, pj.lvl);
-        g->jobs.push_back(pj);
-    }
-    int pipe_top = 0;
-    for (auto& g : pgroups) {
-        g.seg = pipe_segments(g.jobs, c->pipe_on, pipe_lds, ticking ? c->tick_pipe_blocks : 0);
-        g.dev = arena_push(c, g.jobs);
-        if (!g.dev) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-        pipe_top = std::max(pipe_top, g.lvl + 1);
-    }
-    // matrix-core FIR launches: macro tiles per wavefront, grid and LDS size per job list (before the job tables are uploaded)
-    struct ToepList { Lev<ToepJob>* L; int npl, width; bool quad; int fam; int role; };
-    ToepList tlists[] = { { &t_dec, 2, 2, false, F_DECIM, TR_TOEP_C },      { &t_poly, 2, 2, false, F_POLY, TR_TOEP_C },       { &t_chan, 2, 2, false, F_FIR, TR_TOEP_C },
-                          { &t_audio, 1, 1, false, F_FIR, TR_TOEP_R },      { &t_audio_fm, 2, 1, true, F_FIR, TR_TOEP_Q },     { &t_af_dec, 2, 2, false, F_AF, TR_TOEP_C },
-                          { &t_af_poly, 2, 2, false, F_AF, TR_TOEP_C },     { &t_af_hpf, 2, 2, false, F_AF, TR_TOEP_C } };
-    constexpr int kToepLists = (int)(sizeof(tlists) / sizeof(tlists[0]));
-    ToepPlan tplan[kToepLists][kLevels];
-    for (int i = 0; i < kToepLists; i++) {
-        Lev<ToepJob>& L = *tlists[i].L;
-        for (int l = 0; l < L.top; l++) {
-            if (L.at[l].empty()) { continue; }
-            tplan[i][l] = toep_plan(L.at[l], tlists[i].npl, c->tick_planning ? c->tick_toep_blocks : 2048);
-            if (tplan[i][l].lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS"); }
-        }
-        if (!arena_push_lev(c, L)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-    }
-    if (!arena_push_lev(c, f_dec) || !arena_push_lev(c, poly) || !arena_push_lev(c, polyb[0]) || !arena_push_lev(c, polyb[1]) || !arena_push_lev(c, polyb[2]) ||
-        !arena_push_lev(c, polyb[3]) || !arena_push_lev(c, chan) || !arena_push_lev(c, seq) || !arena_push_lev(c, pre) || !arena_push_lev(c, audio) ||
-        !arena_push_lev(c, audio_fm) || !arena_push_lev(c, af_dec) || !arena_push_lev(c, af_hpf) || !arena_push_lev(c, af_poly) || !arena_push_lev(c, af_deemp) ||
-        !arena_push_lev(c, ssbx_l) || !arena_push_lev(c, carry)) {
-        return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
-    }
-    int rc;
-    {
-        HostScope hs("arena_commit (H2D)");
-        rc = arena_commit(c);
-    }
-    if (rc) { return rc; }
-
-    // ---- level 1: the front end ----
-    {
-        FamilyTimer t(c, F_S1);
-        if (!rotx.empty() && n_in > 0) {
-            if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
-            else {
-                const int vpw = c->rot_exact_vpw;
-                const dim3 grid(((unsigned)rotx.size() + vpw - 1) / vpw);
-                if (c->rot_exact_skip >= 16) { launch(c, vfo_rotate_exact4_kernel<16>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
-                else if (c->rot_exact_skip >= 8) { launch(c, vfo_rotate_exact4_kernel<8>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
-                else { launch(c, vfo_rotate_exact4_kernel<4>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+    int upload() {
+        for (int k = 0; k < 4; k++) {
+            if (!s1l[k].jobs.empty()) {
+                for (auto& jb : s1l[k].jobs) { s1l[k].lds = std::max(s1l[k].lds, fir_lds(s1l[k].tile, 1 << jb.log2_decim, jb.ntaps, 8)); }
+                d_s1[k] = arena_push(c, s1l[k].jobs);
+                if (!d_s1[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
             }
         }
         for (int k = 0; k < 4; k++) {
-            if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }
-            bool direct = true;  // every job of the class decimates by >= 32: stream from global memory, no LDS tile
-            for (auto& jb : s1l[k].jobs) { direct = direct && jb.log2_decim >= 5; }
-            if (direct) {
-                const dim3 grid((s1l[k].max_nout + 255) / 256, (unsigned)s1l[k].jobs.size());
-                switch (s1l[k].vt) {
-                case 8: launch(c, vfo_stage1_direct_kernel<8>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
-                case 4: launch(c, vfo_stage1_direct_kernel<4>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
-                case 2: launch(c, vfo_stage1_direct_kernel<2>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
-                default: launch(c, vfo_stage1_direct_kernel<1>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
-                }
-                continue;
-            }
-            const dim3 grid((s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (unsigned)s1l[k].jobs.size());
-            const dim3 block(s1l[k].tile);
-            switch (s1l[k].vt) {
-            case 8: launch(c, vfo_stage1_kernel<8>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
-            case 4: launch(c, vfo_stage1_kernel<4>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
-            case 2: launch(c, vfo_stage1_kernel<2>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
-            default: launch(c, vfo_stage1_kernel<1>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+            if (!f2l[k].jobs.empty()) {
+                d_f2[k] = arena_push(c, f2l[k].jobs);
+                if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
             }
         }
-        for (int k = 0; k < 4; k++) {
-            if (f2l[k].jobs.empty() || f2l[k].max_blocks == 0) { continue; }
-            const dim3 grid((unsigned)f2l[k].max_blocks, (unsigned)f2l[k].jobs.size());
-            const dim3 block(256);
-            // all jobs of a launch class share VT; the (44 taps, /8) first stage of the ratio-32 plan (10 MS/s -> 312.5 kS/s) has a
-            // fully unrolled instance, everything else runs the generic loop
-            bool all_44_3 = true;
-            for (auto& jb : f2l[k].jobs) { all_44_3 = all_44_3 && jb.ntaps1 == 44 && jb.log2_decim1 == 3; }
-            switch (f2l[k].vt) {
-            case 8:
-                if (all_44_3) { launch(c, vfo_front2_kernel<8, 44, 3>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
-                else { launch(c, vfo_front2_kernel<8, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
-                break;
-            case 4: launch(c, vfo_front2_kernel<4, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
-            case 2: launch(c, vfo_front2_kernel<2, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
-            default: launch(c, vfo_front2_kernel<1, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
-            }
-        }
+        d_fcl = arena_push(c, fcl.jobs);
+        if (!fcl.jobs.empty() && !d_fcl) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         for (int k = 0; k < 3; k++) {
-            if (fcm[k].jobs.empty() || fcm[k].max_blocks == 0) { continue; }
-            bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
-            for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
-            const int role = (k == 1 && all_132_4) ? TR_FCM_132_4 : (k == 0 ? TR_FCM_6 : (k == 1 ? TR_FCM_10 : TR_FCM_16));
-            // small blocks: every wavefront of the 32 x 32 x 2 form would have ONE tile and spend 4 us in its matrix loop alone — a workgroup
-            // per tile in the 16 x 16 x 4 shape instead (same sums in the same order: bit-identical), up to fcm16_max_tiles tiles per job
-            int max_tiles = 0;
-            bool one_tile = true;
-            for (auto& jb : fcm[k].jobs) {
-                max_tiles = std::max(max_tiles, (jb.nout + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE);
-                one_tile = one_tile && jb.tiles_per_wave == 1;
+            if (!fcm[k].jobs.empty()) {
+                d_fcm[k] = arena_push(c, fcm[k].jobs);
+                if (!d_fcm[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
             }
-            const int small_limit = c->fcm16_max_tiles >= 0 ? c->fcm16_max_tiles : ((c->tick_planning && c->plan_block_from_host) ? 0 : 256);
-            if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= small_limit) {
-                if (getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp] front end in its small-block shape: %d tiles x %zu jobs\n", max_tiles, fcm[k].jobs.size()); }
-                emit(c, 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
-                continue;
+        }
+        d_rotx = arena_push(c, rotx);
+        d_retune = arena_push(c, retune);
+        d_rot = arena_push(c, rot);
+        d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
+        if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!retune.empty() && !d_retune) || (!rot.empty() && !d_rot)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        // Pipelined back ends.  An ordinary pass: ONE launch, at the latest level any of its jobs starts at (levels only order the launches of a
+        // pass) — or none, when this push is better served by the separate launches.  Pipelined mode: one role per LEVEL (a role that ran later
+        // than its VFO's level would find the history of its first stage's input overwritten by the next block's carry), always the pipeline.
+        if (!pipes.empty() && !ticking && pipe_segments(pipes, c->pipe_on, pipe_lds) == 0) {  // not this push: the same four jobs go to the separate launches
+            for (auto& pj : pipes) {
+                t_dec.add(pj.lvl, pj.st[0]);
+                t_poly.add(pj.lvl + 1, pj.st[1]);
+                t_chan.add(pj.lvl + 2, pj.st[2]);
+                t_audio_fm.add(pj.lvl + 3, pj.st[3]);
             }
-            emit(c, 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
+            pipes.clear();
         }
-        if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
-            bool pf_ok = true;  // every window of the launch fits the register prefetch
-            for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
-            emit(c, 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
-        }
-        if (!rot.empty() && max_rot > 0) { emit(c, 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
-        if (!retune.empty()) {
-            int mx = 0;
-            for (auto& r : retune) { mx = std::max(mx, r.nfix); }
-            launch(c, vfo_retune_fix_kernel, dim3((unsigned)mx, (unsigned)retune.size()), dim3(64), 0, src, (const RetuneJob*)d_retune);
-        }
-    }
-    auto launch_fir = [&](int level, int fam, std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) -> int {
-        if (jobs.empty()) { return SDRPP_OK; }
-        const int R = SDRPP_FIR_R;
-        int max_nout = 0, threads = 256;
-        auto lds_for = [&](const FirBJob& jb, int nt) {
-            size_t b = (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * width * 4;
-            if (quad) { b += ((size_t)nt * R + jb.ntaps + 2) * 4; }  // phase scratch of the fused discriminator
-            return b;
-        };
-        for (auto& jb : jobs) {
-            max_nout = std::max(max_nout, jb.nout);
-            int nt = 256;
-            while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
-            if (nt < 32) {
-                if (width != 2 || quad || stereo) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
-                threads = 0;  // complex stream: the untiled kernel takes the whole list
-                break;
+        for (auto& pj : pipes) {
+            PipeGroup* g = nullptr;
+            for (auto& q : pgroups) {
+                if (!ticking || q.lvl == pj.lvl) { g = &q; }
             }
-            threads = std::min(threads, nt);
-        }
-        if (threads == 0) {
-            for (auto& jb : jobs) { max_nout = std::max(max_nout, jb.nout); }
-            if (max_nout > 0) { launch(c, vfo_fir_direct_kernel<false>, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
-            return SDRPP_OK;
-        }
-        if (max_nout == 0) { return SDRPP_OK; }
-        // enough blocks to load-balance 256 CUs: shrink the tile while the grid has fewer than ~8 blocks per CU
-        while (threads > 64 && (size_t)((max_nout + threads * R - 1) / (threads * R)) * jobs.size() < 2048) { threads >>= 1; }
-        size_t lds = 0;
-        for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
-        const int tile = threads * R;
-        emit(c, level, fam, width == 2 ? TR_FIRB_C : (quad ? TR_FIRB_Q : (stereo ? TR_FIRB_S : TR_FIRB_R)), (max_nout + tile - 1) / tile, (int)jobs.size(), lds, d_jobs, nullptr, threads);
-        return SDRPP_OK;
-    };
-    // resamplers with many phases (L > 8, e.g. 96/125): cycle-major kernel — one LDS window serves all L phases of up to 64 cycles;
-    // a filter whose single cycle does not fit falls back to the per-output kernel
-    auto launch_polyc = [&](std::vector<PolyJob>& jobs, PolyJob* d_jobs) -> int {
-        if (jobs.empty()) { return SDRPP_OK; }
-        const int cap2 = kMaxLds / (int)sizeof(float2);
-        bool fits = true;
-        int max_nout = 0, max_tiles = 0;
-        for (auto& jb : jobs) {
-            max_nout = std::max(max_nout, jb.nout);
-            const int ct = std::min(64, (cap2 - jb.tpp - jb.decim) / jb.decim);
-            if (ct < 1) { fits = false; continue; }
-            const int ncyc = (jb.nout + jb.interp - 1) / jb.interp;
-            max_tiles = std::max(max_tiles, (ncyc + ct - 1) / ct);
-        }
-        if (max_nout == 0) { return SDRPP_OK; }
-        if (fits) {
-            launch(c, vfo_polyc_kernel, dim3((unsigned)max_tiles, (unsigned)jobs.size()), dim3(256), (size_t)kMaxLds, (const PolyJob*)d_jobs, cap2);
-            return SDRPP_OK;
-        }
-        size_t lds = 0;
-        const int tile = 256;
-        for (auto& jb : jobs) {
-            const size_t ns = (size_t)((long long)tile * jb.decim / jb.interp) + jb.tpp + 4;
-            lds = std::max(lds, ns * sizeof(float2));
-        }
-        if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
-        launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
-        return SDRPP_OK;
-    };
-    auto launch_polyb = [&](int li, std::vector<PolyBJob>& jobs, PolyBJob* d_jobs) -> int {
-        if (jobs.empty()) { return SDRPP_OK; }
-        int max_cycles = 0, threads = 256;
-        size_t lds = 0;
-        auto lds_for = [&](const PolyBJob& jb, int nt) { return (size_t)jb.decim * (size_t)(nt + jb.rows / jb.decim + 2) * sizeof(float2); };
-        for (auto& jb : jobs) {
-            max_cycles = std::max(max_cycles, (jb.nout + jb.interp - 1) / jb.interp);
-            int nt = 256;
-            while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
-            if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
-            threads = std::min(threads, nt);
-        }
-        if (max_cycles == 0) { return SDRPP_OK; }
-        while (threads > 64 && (size_t)((max_cycles + threads - 1) / threads) * jobs.size() < 2048) { threads >>= 1; }
-        for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
-        const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)jobs.size());
-        if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
-        else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
-        else if (li == 2) { launch(c, vfo_polyb_kernel<4, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
-        else { launch(c, vfo_polyb_kernel<8, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
-        return SDRPP_OK;
-    };
-    auto emit_toep = [&](int i, int l) {
-        Lev<ToepJob>& L = *tlists[i].L;
-        if (l >= L.top || L.at[l].empty() || tplan[i][l].grid_x == 0) { return; }
-        emit(c, l, tlists[i].fam, tlists[i].role, tplan[i][l].grid_x, (int)L.at[l].size(), tplan[i][l].lds, L.dev[l]);
-    };
-    // the history carries of one level: job 0 of the IQ stream's level is the shared IQ stream (up to a whole FFT frame long), the per-VFO
-    // histories are a few hundred samples
-    auto launch_carry = [&](int l) {
-        std::vector<CarryJob>& cj = carry.at[l];
-        if (cj.empty()) { return; }
-        const bool has_iq = (l == (ticking ? 1 : carry_last));
-        const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
-        int mx = 0;
-        for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }
-        if (iq_elems > 128 * 1024 * 2 && cj.size() > 1) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
-            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1, 0, carry.dev[l]);
-            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 255) / 256, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
-        }
-        else if (iq_elems > 16384 && cj.size() > 1) {
-            // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
-            // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
-            emit(c, l, F_MISC, TR_CARRY, 128, (int)cj.size(), 0, carry.dev[l]);
-        }
-        else {
-            mx = std::max(mx, iq_elems);
-            emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 2048)), (int)cj.size(), 0, carry.dev[l]);
-        }
-    };
-
-    // ---- levels 2 ...: everything behind the front end, level by level (within a level the launches are independent of each other) ----
-    int top = std::max({ t_dec.top, t_poly.top, t_chan.top, t_audio.top, t_audio_fm.top, t_af_dec.top, t_af_poly.top, t_af_hpf.top, f_dec.top, poly.top,
-                         polyb[0].top, polyb[1].top, polyb[2].top, polyb[3].top, chan.top, seq.top, pre.top, audio.top, audio_fm.top, af_dec.top, af_hpf.top,
-                         af_poly.top, af_deemp.top, ssbx_l.top, carry.top, pipe_top });
-    for (int l = 1; l < top; l++) {
-        {
-            FamilyTimer t(c, F_DECIM);
-            emit_toep(0, l);
-            if (l < f_dec.top) {
-                rc = launch_fir(l, F_DECIM, f_dec.at[l], f_dec.dev[l], 2, false);
-                if (rc) { return rc; }
+            if (!g) {
+                pgroups.emplace_back();
+                g = &pgroups.back();
+                g->lvl = pj.lvl;
             }
+            g->lvl = std::max(g->lvl, pj.lvl);
+            g->jobs.push_back(pj);
         }
         for (auto& g : pgroups) {
-            if (g.lvl != l || g.seg <= 0) { continue; }
-            FamilyTimer t(c, F_PIPE);
-            c->pipe_launched = true;
-            emit(c, l, F_PIPE, TR_PIPE, g.seg, (int)g.jobs.size(), pipe_lds, g.dev);
+            g.seg = pipe_segments(g.jobs, c->pipe_on, pipe_lds, ticking ? c->tick_pipe_blocks : 0);
+            g.dev = arena_push(c, g.jobs);
+            if (!g.dev) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+            pipe_top = std::max(pipe_top, g.lvl + 1);
         }
-        {
-            FamilyTimer t(c, F_POLY);
-            emit_toep(1, l);
-            if (l < poly.top) {
-                rc = launch_polyc(poly.at[l], poly.dev[l]);
-                if (rc) { return rc; }
+        for (int i = 0; i < kToepLists; i++) {
+            Lev<ToepJob>& L = *tlists[i].L;
+            for (int l = 0; l < L.top; l++) {
+                if (L.at[l].empty()) { continue; }
+                tplan[i][l] = toep_plan(L.at[l], tlists[i].npl, c->tick_planning ? c->tick_toep_blocks : 2048);
+                if (tplan[i][l].lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS"); }
             }
-            for (int li = 0; li < 4; li++) {
-                if (l < polyb[li].top) {
-                    rc = launch_polyb(li, polyb[li].at[l], polyb[li].dev[l]);
+            if (!arena_push_lev(c, L)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
+        if (!arena_push_lev(c, f_dec) || !arena_push_lev(c, poly) || !arena_push_lev(c, polyb[0]) || !arena_push_lev(c, polyb[1]) || !arena_push_lev(c, polyb[2]) ||
+            !arena_push_lev(c, polyb[3]) || !arena_push_lev(c, chan) || !arena_push_lev(c, seq) || !arena_push_lev(c, pre) || !arena_push_lev(c, audio) ||
+            !arena_push_lev(c, audio_fm) || !arena_push_lev(c, af_dec) || !arena_push_lev(c, af_hpf) || !arena_push_lev(c, af_poly) || !arena_push_lev(c, af_deemp) ||
+            !arena_push_lev(c, ssbx_l) || !arena_push_lev(c, carry)) {
+            return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted");
+        }
+        int rc;
+        {
+            HostScope hs("arena_commit (H2D)");
+            rc = arena_commit(c);
+        }
+        if (rc) { return rc; }
+        return SDRPP_OK;
+    }
+
+    // ---- level 1: the front end ----
+    int emit_front() {
+        {
+            FamilyTimer t(c, F_S1);
+            if (!rotx.empty() && n_in > 0) {
+                if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
+                else {
+                    const int vpw = c->rot_exact_vpw;
+                    const dim3 grid(((unsigned)rotx.size() + vpw - 1) / vpw);
+                    if (c->rot_exact_skip >= 16) { launch(c, vfo_rotate_exact4_kernel<16>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+                    else if (c->rot_exact_skip >= 8) { launch(c, vfo_rotate_exact4_kernel<8>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+                    else { launch(c, vfo_rotate_exact4_kernel<4>, grid, dim3(256), SDRPP_ROTX4_LDS_BYTES, src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size(), vpw); }
+                }
+            }
+            for (int k = 0; k < 4; k++) {
+                if (s1l[k].jobs.empty() || s1l[k].max_nout == 0) { continue; }
+                bool direct = true;  // every job of the class decimates by >= 32: stream from global memory, no LDS tile
+                for (auto& jb : s1l[k].jobs) { direct = direct && jb.log2_decim >= 5; }
+                if (direct) {
+                    const dim3 grid((s1l[k].max_nout + 255) / 256, (unsigned)s1l[k].jobs.size());
+                    switch (s1l[k].vt) {
+                    case 8: launch(c, vfo_stage1_direct_kernel<8>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                    case 4: launch(c, vfo_stage1_direct_kernel<4>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                    case 2: launch(c, vfo_stage1_direct_kernel<2>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                    default: launch(c, vfo_stage1_direct_kernel<1>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
+                    }
+                    continue;
+                }
+                const dim3 grid((s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (unsigned)s1l[k].jobs.size());
+                const dim3 block(s1l[k].tile);
+                switch (s1l[k].vt) {
+                case 8: launch(c, vfo_stage1_kernel<8>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+                case 4: launch(c, vfo_stage1_kernel<4>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+                case 2: launch(c, vfo_stage1_kernel<2>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+                default: launch(c, vfo_stage1_kernel<1>, grid, block, s1l[k].lds, src, (const Stage1Job*)d_s1[k]); break;
+                }
+            }
+            for (int k = 0; k < 4; k++) {
+                if (f2l[k].jobs.empty() || f2l[k].max_blocks == 0) { continue; }
+                const dim3 grid((unsigned)f2l[k].max_blocks, (unsigned)f2l[k].jobs.size());
+                const dim3 block(256);
+                // all jobs of a launch class share VT; the (44 taps, /8) first stage of the ratio-32 plan (10 MS/s -> 312.5 kS/s) has a
+                // fully unrolled instance, everything else runs the generic loop
+                bool all_44_3 = true;
+                for (auto& jb : f2l[k].jobs) { all_44_3 = all_44_3 && jb.ntaps1 == 44 && jb.log2_decim1 == 3; }
+                switch (f2l[k].vt) {
+                case 8:
+                    if (all_44_3) { launch(c, vfo_front2_kernel<8, 44, 3>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
+                    else { launch(c, vfo_front2_kernel<8, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); }
+                    break;
+                case 4: launch(c, vfo_front2_kernel<4, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
+                case 2: launch(c, vfo_front2_kernel<2, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
+                default: launch(c, vfo_front2_kernel<1, 0, 0>, grid, block, f2l[k].lds, src, (const Front2Job*)d_f2[k]); break;
+                }
+            }
+            for (int k = 0; k < 3; k++) {
+                if (fcm[k].jobs.empty() || fcm[k].max_blocks == 0) { continue; }
+                bool all_132_4 = true;  // ratio-32 plan: fir_32_8 (44 taps, /8) + fir_4_2 (12 taps, /2) -> 132 composite taps, /16
+                for (auto& jb : fcm[k].jobs) { all_132_4 = all_132_4 && jb.ntaps == 132 && jb.log2_decim == 4; }
+                const int role = (k == 1 && all_132_4) ? TR_FCM_132_4 : (k == 0 ? TR_FCM_6 : (k == 1 ? TR_FCM_10 : TR_FCM_16));
+                // small blocks: every wavefront of the 32 x 32 x 2 form would have ONE tile and spend 4 us in its matrix loop alone — a workgroup
+                // per tile in the 16 x 16 x 4 shape instead (same sums in the same order: bit-identical), up to fcm16_max_tiles tiles per job
+                int max_tiles = 0;
+                bool one_tile = true;
+                for (auto& jb : fcm[k].jobs) {
+                    max_tiles = std::max(max_tiles, (jb.nout + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE);
+                    one_tile = one_tile && jb.tiles_per_wave == 1;
+                }
+                const int small_limit = c->fcm16_max_tiles >= 0 ? c->fcm16_max_tiles : ((c->tick_planning && c->plan_block_from_host) ? 0 : 256);
+                if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= small_limit) {
+                    if (getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp] front end in its small-block shape: %d tiles x %zu jobs\n", max_tiles, fcm[k].jobs.size()); }
+                    emit(c, 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
+                    continue;
+                }
+                emit(c, 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
+            }
+            if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
+                bool pf_ok = true;  // every window of the launch fits the register prefetch
+                for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
+                emit(c, 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
+            }
+            if (!rot.empty() && max_rot > 0) { emit(c, 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
+            if (!retune.empty()) {
+                int mx = 0;
+                for (auto& r : retune) { mx = std::max(mx, r.nfix); }
+                launch(c, vfo_retune_fix_kernel, dim3((unsigned)mx, (unsigned)retune.size()), dim3(64), 0, src, (const RetuneJob*)d_retune);
+            }
+        }
+        return SDRPP_OK;
+    }
+
+    int launch_fir(int level, int fam, std::vector<FirBJob>& jobs, FirBJob* d_jobs, int width, bool stereo, bool quad = false) {
+            if (jobs.empty()) { return SDRPP_OK; }
+            const int R = SDRPP_FIR_R;
+            int max_nout = 0, threads = 256;
+            auto lds_for = [&](const FirBJob& jb, int nt) {
+                size_t b = (size_t)(1 << jb.log2_decim) * R * (size_t)(nt + jb.kp_pad / R + 1) * width * 4;
+                if (quad) { b += ((size_t)nt * R + jb.ntaps + 2) * 4; }  // phase scratch of the fused discriminator
+                return b;
+            };
+            for (auto& jb : jobs) {
+                max_nout = std::max(max_nout, jb.nout);
+                int nt = 256;
+                while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
+                if (nt < 32) {
+                    if (width != 2 || quad || stereo) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
+                    threads = 0;  // complex stream: the untiled kernel takes the whole list
+                    break;
+                }
+                threads = std::min(threads, nt);
+            }
+            if (threads == 0) {
+                for (auto& jb : jobs) { max_nout = std::max(max_nout, jb.nout); }
+                if (max_nout > 0) { launch(c, vfo_fir_direct_kernel<false>, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
+                return SDRPP_OK;
+            }
+            if (max_nout == 0) { return SDRPP_OK; }
+            // enough blocks to load-balance 256 CUs: shrink the tile while the grid has fewer than ~8 blocks per CU
+            while (threads > 64 && (size_t)((max_nout + threads * R - 1) / (threads * R)) * jobs.size() < 2048) { threads >>= 1; }
+            size_t lds = 0;
+            for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
+            const int tile = threads * R;
+            emit(c, level, fam, width == 2 ? TR_FIRB_C : (quad ? TR_FIRB_Q : (stereo ? TR_FIRB_S : TR_FIRB_R)), (max_nout + tile - 1) / tile, (int)jobs.size(), lds, d_jobs, nullptr, threads);
+            return SDRPP_OK;
+    }
+    // resamplers with many phases (L > 8, e.g. 96/125): cycle-major kernel — one LDS window serves all L phases of up to 64 cycles;
+    // a filter whose single cycle does not fit falls back to the per-output kernel
+    int launch_polyc(std::vector<PolyJob>& jobs, PolyJob* d_jobs) {
+            if (jobs.empty()) { return SDRPP_OK; }
+            const int cap2 = kMaxLds / (int)sizeof(float2);
+            bool fits = true;
+            int max_nout = 0, max_tiles = 0;
+            for (auto& jb : jobs) {
+                max_nout = std::max(max_nout, jb.nout);
+                const int ct = std::min(64, (cap2 - jb.tpp - jb.decim) / jb.decim);
+                if (ct < 1) { fits = false; continue; }
+                const int ncyc = (jb.nout + jb.interp - 1) / jb.interp;
+                max_tiles = std::max(max_tiles, (ncyc + ct - 1) / ct);
+            }
+            if (max_nout == 0) { return SDRPP_OK; }
+            if (fits) {
+                launch(c, vfo_polyc_kernel, dim3((unsigned)max_tiles, (unsigned)jobs.size()), dim3(256), (size_t)kMaxLds, (const PolyJob*)d_jobs, cap2);
+                return SDRPP_OK;
+            }
+            size_t lds = 0;
+            const int tile = 256;
+            for (auto& jb : jobs) {
+                const size_t ns = (size_t)((long long)tile * jb.decim / jb.interp) + jb.tpp + 4;
+                lds = std::max(lds, ns * sizeof(float2));
+            }
+            if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
+            launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
+            return SDRPP_OK;
+    }
+    int launch_polyb(int li, std::vector<PolyBJob>& jobs, PolyBJob* d_jobs) {
+            if (jobs.empty()) { return SDRPP_OK; }
+            int max_cycles = 0, threads = 256;
+            size_t lds = 0;
+            auto lds_for = [&](const PolyBJob& jb, int nt) { return (size_t)jb.decim * (size_t)(nt + jb.rows / jb.decim + 2) * sizeof(float2); };
+            for (auto& jb : jobs) {
+                max_cycles = std::max(max_cycles, (jb.nout + jb.interp - 1) / jb.interp);
+                int nt = 256;
+                while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
+                if (nt < 32) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
+                threads = std::min(threads, nt);
+            }
+            if (max_cycles == 0) { return SDRPP_OK; }
+            while (threads > 64 && (size_t)((max_cycles + threads - 1) / threads) * jobs.size() < 2048) { threads >>= 1; }
+            for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
+            const dim3 grid((max_cycles + threads - 1) / threads, (unsigned)jobs.size());
+            if (li == 0) { launch(c, vfo_polyb_kernel<4, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+            else if (li == 1) { launch(c, vfo_polyb_kernel<8, false>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+            else if (li == 2) { launch(c, vfo_polyb_kernel<4, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+            else { launch(c, vfo_polyb_kernel<8, true>, grid, dim3(threads), lds, (const PolyBJob*)d_jobs); }
+            return SDRPP_OK;
+    }
+    void emit_toep(int i, int l) {
+            Lev<ToepJob>& L = *tlists[i].L;
+            if (l >= L.top || L.at[l].empty() || tplan[i][l].grid_x == 0) { return; }
+            emit(c, l, tlists[i].fam, tlists[i].role, tplan[i][l].grid_x, (int)L.at[l].size(), tplan[i][l].lds, L.dev[l]);
+    }
+    // the history carries of one level: job 0 of the IQ stream's level is the shared IQ stream (up to a whole FFT frame long), the per-VFO
+    // histories are a few hundred samples
+    void launch_carry(int l) {
+            std::vector<CarryJob>& cj = carry.at[l];
+            if (cj.empty()) { return; }
+            const bool has_iq = (l == (ticking ? 1 : carry_last));
+            const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
+            int mx = 0;
+            for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }
+            if (iq_elems > 128 * 1024 * 2 && cj.size() > 1) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1, 0, carry.dev[l]);
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 255) / 256, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
+            }
+            else if (iq_elems > 16384 && cj.size() > 1) {
+                // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
+                // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
+                emit(c, l, F_MISC, TR_CARRY, 128, (int)cj.size(), 0, carry.dev[l]);
+            }
+            else {
+                mx = std::max(mx, iq_elems);
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 2048)), (int)cj.size(), 0, carry.dev[l]);
+            }
+    }
+
+    // ---- levels 2 ...: everything behind the front end, level by level (within a level the launches are independent of each other) ----
+    int emit_levels() {
+        int rc = SDRPP_OK;
+        int top = std::max({ t_dec.top, t_poly.top, t_chan.top, t_audio.top, t_audio_fm.top, t_af_dec.top, t_af_poly.top, t_af_hpf.top, f_dec.top, poly.top,
+                             polyb[0].top, polyb[1].top, polyb[2].top, polyb[3].top, chan.top, seq.top, pre.top, audio.top, audio_fm.top, af_dec.top, af_hpf.top,
+                             af_poly.top, af_deemp.top, ssbx_l.top, carry.top, pipe_top });
+        for (int l = 1; l < top; l++) {
+            {
+                FamilyTimer t(c, F_DECIM);
+                emit_toep(0, l);
+                if (l < f_dec.top) {
+                    rc = launch_fir(l, F_DECIM, f_dec.at[l], f_dec.dev[l], 2, false);
                     if (rc) { return rc; }
                 }
             }
-        }
-        {
-            FamilyTimer t(c, F_FIR);
-            emit_toep(2, l);
-            if (l < chan.top) {
-                rc = launch_fir(l, F_FIR, chan.at[l], chan.dev[l], 2, false);
-                if (rc) { return rc; }
+            for (auto& g : pgroups) {
+                if (g.lvl != l || g.seg <= 0) { continue; }
+                FamilyTimer t(c, F_PIPE);
+                c->pipe_launched = true;
+                emit(c, l, F_PIPE, TR_PIPE, g.seg, (int)g.jobs.size(), pipe_lds, g.dev);
             }
-        }
-        if ((l < pre.top && !pre.at[l].empty()) || (l < seq.top && !seq.at[l].empty()) || (l < ssbx_l.top && !ssbx_l.at[l].empty())) {
-            FamilyTimer t(c, F_DEMOD);
-            if (l < ssbx_l.top && !ssbx_l.at[l].empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx_l.at[l].size()), dim3(64), 0, (const SsbRotXJob*)ssbx_l.dev[l]); }
-            if (l < pre.top && !pre.at[l].empty()) {
-                int mx = 0;
-                for (auto& q : pre.at[l]) { mx = std::max(mx, q.n); }
-                if (mx > 0) { emit(c, l, F_DEMOD, TR_PRE, std::min((mx + 255) / 256, 1024), (int)pre.at[l].size(), 0, pre.dev[l]); }
-            }
-            if (l < seq.top && !seq.at[l].empty()) { emit(c, l, F_DEMOD, TR_SEQ, (int)seq.at[l].size(), 1, 0, seq.dev[l], nullptr, (int)seq.at[l].size()); }
-        }
-        {
-            FamilyTimer t(c, F_FIR);
-            emit_toep(3, l);
-            emit_toep(4, l);
-            if (l < audio.top) {
-                rc = launch_fir(l, F_FIR, audio.at[l], audio.dev[l], 1, true);
-                if (rc) { return rc; }
-            }
-            if (l < audio_fm.top) {
-                rc = launch_fir(l, F_FIR, audio_fm.at[l], audio_fm.dev[l], 1, true, true);
-                if (rc) { return rc; }
-            }
-        }
-        if (l < std::max({ t_af_dec.top, t_af_poly.top, t_af_hpf.top, af_dec.top, af_hpf.top, af_poly.top, af_deemp.top })) {
-            FamilyTimer t(c, F_AF);
-            emit_toep(5, l);
-            if (l < af_dec.top) {
-                rc = launch_fir(l, F_AF, af_dec.at[l], af_dec.dev[l], 2, false);
-                if (rc) { return rc; }
-            }
-            emit_toep(6, l);
-            if (l < af_poly.top) {
-                rc = launch_polyc(af_poly.at[l], af_poly.dev[l]);
-                if (rc) { return rc; }
-            }
-            emit_toep(7, l);
-            if (l < af_hpf.top) {
-                rc = launch_fir(l, F_AF, af_hpf.at[l], af_hpf.dev[l], 2, false);
-                if (rc) { return rc; }
-            }
-            if (l < af_deemp.top && !af_deemp.at[l].empty()) {
-                int max_seg = 0;
-                for (auto& jb : af_deemp.at[l]) { max_seg = std::max(max_seg, jb.nseg); }
-                if (max_seg > 0) {
-                    const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.at[l].size());
-                    launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
-                    launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
-                    launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.at[l].size() + 63) / 64), dim3(64), 0, (const DeempJob*)af_deemp.dev[l], (int)af_deemp.at[l].size());
+            {
+                FamilyTimer t(c, F_POLY);
+                emit_toep(1, l);
+                if (l < poly.top) {
+                    rc = launch_polyc(poly.at[l], poly.dev[l]);
+                    if (rc) { return rc; }
+                }
+                for (int li = 0; li < 4; li++) {
+                    if (l < polyb[li].top) {
+                        rc = launch_polyb(li, polyb[li].at[l], polyb[li].dev[l]);
+                        if (rc) { return rc; }
+                    }
                 }
             }
+            {
+                FamilyTimer t(c, F_FIR);
+                emit_toep(2, l);
+                if (l < chan.top) {
+                    rc = launch_fir(l, F_FIR, chan.at[l], chan.dev[l], 2, false);
+                    if (rc) { return rc; }
+                }
+            }
+            if ((l < pre.top && !pre.at[l].empty()) || (l < seq.top && !seq.at[l].empty()) || (l < ssbx_l.top && !ssbx_l.at[l].empty())) {
+                FamilyTimer t(c, F_DEMOD);
+                if (l < ssbx_l.top && !ssbx_l.at[l].empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx_l.at[l].size()), dim3(64), 0, (const SsbRotXJob*)ssbx_l.dev[l]); }
+                if (l < pre.top && !pre.at[l].empty()) {
+                    int mx = 0;
+                    for (auto& q : pre.at[l]) { mx = std::max(mx, q.n); }
+                    if (mx > 0) { emit(c, l, F_DEMOD, TR_PRE, std::min((mx + 255) / 256, 1024), (int)pre.at[l].size(), 0, pre.dev[l]); }
+                }
+                if (l < seq.top && !seq.at[l].empty()) { emit(c, l, F_DEMOD, TR_SEQ, (int)seq.at[l].size(), 1, 0, seq.dev[l], nullptr, (int)seq.at[l].size()); }
+            }
+            {
+                FamilyTimer t(c, F_FIR);
+                emit_toep(3, l);
+                emit_toep(4, l);
+                if (l < audio.top) {
+                    rc = launch_fir(l, F_FIR, audio.at[l], audio.dev[l], 1, true);
+                    if (rc) { return rc; }
+                }
+                if (l < audio_fm.top) {
+                    rc = launch_fir(l, F_FIR, audio_fm.at[l], audio_fm.dev[l], 1, true, true);
+                    if (rc) { return rc; }
+                }
+            }
+            if (l < std::max({ t_af_dec.top, t_af_poly.top, t_af_hpf.top, af_dec.top, af_hpf.top, af_poly.top, af_deemp.top })) {
+                FamilyTimer t(c, F_AF);
+                emit_toep(5, l);
+                if (l < af_dec.top) {
+                    rc = launch_fir(l, F_AF, af_dec.at[l], af_dec.dev[l], 2, false);
+                    if (rc) { return rc; }
+                }
+                emit_toep(6, l);
+                if (l < af_poly.top) {
+                    rc = launch_polyc(af_poly.at[l], af_poly.dev[l]);
+                    if (rc) { return rc; }
+                }
+                emit_toep(7, l);
+                if (l < af_hpf.top) {
+                    rc = launch_fir(l, F_AF, af_hpf.at[l], af_hpf.dev[l], 2, false);
+                    if (rc) { return rc; }
+                }
+                if (l < af_deemp.top && !af_deemp.at[l].empty()) {
+                    int max_seg = 0;
+                    for (auto& jb : af_deemp.at[l]) { max_seg = std::max(max_seg, jb.nseg); }
+                    if (max_seg > 0) {
+                        const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.at[l].size());
+                        launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
+                        launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
+                        launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.at[l].size() + 63) / 64), dim3(64), 0, (const DeempJob*)af_deemp.dev[l], (int)af_deemp.at[l].size());
+                    }
+                }
+            }
+            if (l < carry.top && !carry.at[l].empty()) {
+                FamilyTimer t(c, F_MISC);
+                launch_carry(l);
+            }
         }
-        if (l < carry.top && !carry.at[l].empty()) {
-            FamilyTimer t(c, F_MISC);
-            launch_carry(l);
+        return SDRPP_OK;
+    }
+};
+
+int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& iq_carry) {
+    if (c->vfos.empty()) { return SDRPP_OK; }
+#ifdef SDRPP_TOEP_KNOCK
+    {   // diagnostic build: SDRPP_TOEP_KNOCK=<mask> (1: no stores, 2: no loads, 4: no matrix loop) in vfo_toep_kernel
+        static bool once = false;
+        if (!once) {
+            once = true;
+            const int m = getenv("SDRPP_TOEP_KNOCK") ? atoi(getenv("SDRPP_TOEP_KNOCK")) : 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(sdrpp_k::g_toep_knock), &m, sizeof(int));
         }
     }
+#endif
+    const int n_in = (int)count;
+    std::unique_ptr<BankPlan> P(new BankPlan(c, src, count, iq_carry));  // (a few hundred KB of job-list heads: not on the stack)
+    int rc = SDRPP_OK;
+    for (auto& kv : c->vfos) {
+        rc = P->chain(*kv.second);
+        if (rc) { return rc; }
+    }
+    rc = P->group_front();
+    if (!rc) { rc = P->upload(); }
+    if (!rc) { rc = P->emit_front(); }
+    if (!rc) { rc = P->emit_levels(); }
+    if (rc) { return rc; }
     // flip the ping-pong side of every carried stream
     for (auto& kv : c->vfos) {
         for (auto& s : kv.second->st) {
