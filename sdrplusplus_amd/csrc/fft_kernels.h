@@ -735,20 +735,23 @@ __global__ __launch_bounds__(256) void zoom_palette_kernel(const float* __restri
 // ---- WaterFall display state (waterfall.cpp:875-941): raw-line ring, FFT trace smoothing / hold -----------------------------------------
 // getFFTBuffer (:875-886): every new line moves currentFFTLine one slot DOWN (mod height) and is written there.  Line f of this
 // push (0 = oldest) therefore lands in slot (cur0 - 1 - f) mod H; when a push brings more than H lines only the last H survive.
-__global__ __launch_bounds__(256) void wf_ring_store_kernel(const float* __restrict__ lines, int nframes, int fft_size, float* __restrict__ ring, int height, int cur0) {
-    const int f = blockIdx.y;
+__device__ __forceinline__ void wf_ring_store_body(const KIdx bid, const KIdx gdim, const float* __restrict__ lines, int nframes, int fft_size, float* __restrict__ ring, int height, int cur0) {
+    const int f = bid.y;
     if (f < nframes - height) { return; }
     int slot = (cur0 - 1 - f) % height;
     if (slot < 0) { slot += height; }
     const float4* src = reinterpret_cast<const float4*>(lines + (size_t)f * fft_size);
     float4* dst = reinterpret_cast<float4*>(ring + (size_t)slot * fft_size);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fft_size / 4; i += gridDim.x * blockDim.x) { dst[i] = src[i]; }
+    for (int i = bid.x * 256 + (int)threadIdx.x; i < fft_size / 4; i += gdim.x * 256) { dst[i] = src[i]; }
+}
+__global__ __launch_bounds__(256) void wf_ring_store_kernel(const float* __restrict__ lines, int nframes, int fft_size, float* __restrict__ ring, int height, int cur0) {
+    wf_ring_store_body(kidx(blockIdx), kidx(gridDim), lines, nframes, fft_size, ring, height, cur0);
 }
 // pushFFT tail (:913-939), one work-item per pixel walking over the new lines in order: smoothing = three separately rounded passes
 // (latest *= alpha; buf *= beta; buf += latest; latest = buf), hold[i] = max(latest[i], hold[i] - speed) for i >= 1.
-__global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__ zoomed, int nframes, int data_width, float* __restrict__ latest,
-                                                      float* __restrict__ smooth, float alpha, float beta, float* __restrict__ hold, float hold_speed) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wf_trace_body(const KIdx bid, const float* __restrict__ zoomed, int nframes, int data_width, float* __restrict__ latest,
+                                              float* __restrict__ smooth, float alpha, float beta, float* __restrict__ hold, float hold_speed) {
+    const int j = bid.x * 256 + (int)threadIdx.x;
     if (j >= data_width) { return; }
     float s = smooth ? smooth[j] : 0.0f;
     float h = hold ? hold[j] : 0.0f;
@@ -769,6 +772,10 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__
     latest[j] = l;
     if (smooth) { smooth[j] = s; }
     if (hold) { hold[j] = h; }
+}
+__global__ __launch_bounds__(256) void wf_trace_kernel(const float* __restrict__ zoomed, int nframes, int data_width, float* __restrict__ latest,
+                                                      float* __restrict__ smooth, float alpha, float beta, float* __restrict__ hold, float hold_speed) {
+    wf_trace_body(kidx(blockIdx), zoomed, nframes, data_width, latest, smooth, alpha, beta, hold, hold_speed);
 }
 
 // calculateVFOSignalInfo (waterfall.cpp:558-598) on one raw line: out[0] = max over [o1, o2], out[1] = max - mean of [o0, o1) and (o2, o3)

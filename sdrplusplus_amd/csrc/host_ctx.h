@@ -4,10 +4,10 @@
 
 namespace {
 
-constexpr int kArenaSlots = 16;     // >= kTickDepth + 2: a block's job tables are read for kTickDepth ticks after their upload
+constexpr int kArenaSlots = 24;     // >= kTickDepth + 2: a block's job tables are read for kTickDepth ticks after their upload
 constexpr size_t kArenaBytes = 4u << 20;
 constexpr int kRing = 4;            // pipelined mode: buffers per per-block stream (a consumer runs at most 2 ticks behind its producer; + the gather)
-constexpr int kTickDepth = 10;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit())
+constexpr int kTickDepth = 18;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit()): pre-processing chain 3 + VFO chain 5 + AF chain 5 + result copy
 constexpr int kResSlots = 16;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
 constexpr int kStageSlots = 4;      // pipelined mode: page-locked staging buffers for pushes from pageable host memory
 constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
@@ -78,7 +78,7 @@ struct Vfo {
     // streams: 0..nstages-1 decimator outputs (index 0 also used by the rotate-only path), then poly, chan, dem, out
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
-    int lvl_if = 1, lvl_out = 1;  // levels (do_vfos_plan) at which the IF stream / the output of the most recent block are written
+    int lvl_if = 1, lvl_out = 1, lvl_af = 1;  // levels (do_vfos_plan) at which the IF stream / the demodulator's output / the AF chain's output of the most recent block are written
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
     // front end as one filter (what the fused translate + filter kernels evaluate): stages 0 (+ 1) of the plan
     bool fused_front = false;      // stages 0 and 1 run as one composite filter (front2_t2 > 0)
@@ -105,7 +105,8 @@ struct Vfo {
         float* d_hpf = nullptr;
         int hpf_kp = 0;
         float alpha = 0.0f;
-        float2* d_last = nullptr;  // Deemphasis::lastOut
+        float2* d_last = nullptr;  // Deemphasis::lastOut: two slots, read from [state_cur], written to the other (DeempJob)
+        int state_cur = 0;
         float4* d_seg = nullptr;   // per-segment affine maps of the de-emphasis scan
         int seg_cap = 0;
         int soff[SDRPP_MAX_DECIM_STAGES] = { 0, 0, 0, 0 };
@@ -166,7 +167,8 @@ struct sdrpp_ctx {
         Stream raw;               // history of the caller's buffer (data stays the caller's)
         std::vector<Stream> st;   // decimator stage outputs
         Stream out;               // DC blocker / conjugate output
-        float2* d_off = nullptr;  // DCBlocker::offset
+        float2* d_off = nullptr;  // DCBlocker::offset: two slots like Vfo::Af::d_last
+        int state_cur = 0;
         float4* d_seg = nullptr;
         int seg_cap = 0;
         const float* last = nullptr;  // what the chain handed on for the most recent push
@@ -283,6 +285,8 @@ struct sdrpp_ctx {
     // long dependent walk (10^6-sample blocks: tick 82.6 us with 256 workgroups, 70.8 with 512, against 50.0 for the four roles; sr/200 blocks
     // 32 us against 12), and blocks shorter than a filter history per VFO (cfg 4's NFM channels at sr/200) would fall back to ordinary passes.
     // Off by default; SDRPP_GPU_TICK_PIPE=1 for measurements (tests/test_pipelined.py keeps it bit-identical).
+    int tick_lds_cap = 24 * 1024;       // LDS window of the many-phase resampler as a role of a tick (launch_polyc)
+    int tick_lds_cap_fir = 40 * 1024;   // ... of the register-blocked FIR roles (launch_fir)
     bool tick_pipe = getenv("SDRPP_GPU_TICK_PIPE") ? atoi(getenv("SDRPP_GPU_TICK_PIPE")) != 0 : false;
     int tick_pipe_blocks = getenv("SDRPP_GPU_TICK_PIPE_BLOCKS") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_PIPE_BLOCKS"))) : 256;
     long arena_begins = 0;                // blocks planned so far (block_bounds: one per ordinary pass / per block of a pipelined run)

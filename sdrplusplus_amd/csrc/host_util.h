@@ -391,7 +391,7 @@ int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.af.soff[i] = 0; }
     v.af.pphase = 0;
     v.af.poff = 0;
-    if (v.af.d_last) { HIPCHK(c, hipMemsetAsync(v.af.d_last, 0, sizeof(float2), c->stream)); }
+    if (v.af.d_last) { HIPCHK(c, hipMemsetAsync(v.af.d_last, 0, 2 * sizeof(float2), c->stream)); }
     for (auto& s : v.st) {
         for (int i = 0; i < 2; i++) {
             if (s.hist[i]) { HIPCHK(c, hipMemsetAsync(s.hist[i], 0, (size_t)std::max(s.hist_len, 1) * s.width * sizeof(float), c->stream)); }
@@ -503,6 +503,13 @@ void launch_role(sdrpp_ctx* c, const sdrpp_ctx::RoleLaunch& r) {
     case TR_PRE: hipLaunchKernelGGL(vfo_demod_pre_kernel, grid, b256, 0, st, (const PreJob*)e.jobs); break;
     case TR_SEQ: hipLaunchKernelGGL(vfo_sequential_kernel, grid, dim3(64), 0, st, (const SeqJob*)e.jobs, e.aux); break;
     case TR_PIPE: hipLaunchKernelGGL(vfo_pipe_kernel<1>, grid, b256, r.lds, st, (const PipeJob*)e.jobs); break;
+    case TR_POLYC: hipLaunchKernelGGL(vfo_polyc_kernel, grid, b256, r.lds, st, (const PolyJob*)e.jobs, e.aux); break;
+    case TR_DEEMP_P0: hipLaunchKernelGGL((vfo_deemph_kernel<0, 0>), grid, b256, 0, st, (const DeempJob*)e.jobs); break;
+    case TR_DEEMP_P1: hipLaunchKernelGGL((vfo_deemph_kernel<0, 1>), grid, b256, 0, st, (const DeempJob*)e.jobs); break;
+    case TR_DC_P0: hipLaunchKernelGGL((vfo_deemph_kernel<1, 0>), grid, b256, 0, st, (const DeempJob*)e.jobs); break;
+    case TR_DC_P1: hipLaunchKernelGGL((vfo_deemph_kernel<1, 1>), grid, b256, 0, st, (const DeempJob*)e.jobs); break;
+    case TR_WF_RING: hipLaunchKernelGGL(wf_ring_store_kernel, grid, b256, 0, st, e.p.wf.src, e.p.wf.n0, e.p.wf.n1, e.p.wf.a, e.p.wf.n2, e.p.wf.n3); break;
+    case TR_WF_TRACE: hipLaunchKernelGGL(wf_trace_kernel, grid, b256, 0, st, e.p.wf.src, e.p.wf.n0, e.p.wf.n1, e.p.wf.a, e.p.wf.b, e.p.wf.f0, e.p.wf.f1, e.p.wf.c, e.p.wf.f2); break;
     default: break;  // (the FFT branch launches its kernels itself outside pipelined mode: its pass-1 workgroups are wider there)
     }
 }
@@ -517,6 +524,20 @@ void emit(sdrpp_ctx* c, int level, int fam, int role, int gx, int gy, size_t lds
     r.e.jobs = jobs;
     if (src) { r.e.p.src = *src; }
     r.lds = lds;
+    r.level = level;
+    r.fam = fam;
+    if (c->tick_planning) { c->emits.push_back(r); }
+    else { launch_role(c, r); }
+}
+
+// ... the same for a role whose parameters travel in the entry itself (TickWf)
+void emit_wf(sdrpp_ctx* c, int level, int fam, int role, int gx, int gy, const TickWf& q) {
+    if (gx <= 0 || gy <= 0) { return; }
+    sdrpp_ctx::RoleLaunch r{};
+    r.e.role = role;
+    r.e.gx = gx;
+    r.e.gy = gy;
+    r.e.p.wf = q;
     r.level = level;
     r.fam = fam;
     if (c->tick_planning) { c->emits.push_back(r); }

@@ -290,6 +290,29 @@ int wf_ensure_trace(sdrpp_ctx* c) {
     return SDRPP_OK;
 }
 
+// WaterFall display state behind the lines of one block (waterfall.cpp:875-941): the raw lines into the ring at `level`, the FFT trace's
+// smoothing / hold over the block's zoomed lines one level behind the zoom (`level` + 1) — launches in an ordinary pass, roles of later
+// ticks in pipelined mode (consecutive blocks' roles run in consecutive ticks: the read-modify-write of the trace arrays stays in order).
+int plan_wf_state(sdrpp_ctx* c, int nframes, int level) {
+    if (c->wf.height <= 0) { return SDRPP_OK; }
+    if (c->data_width > 0) {  // FFT trace: latestFFT after smoothing / hold (pushFFT, waterfall.cpp:913-939)
+        int rc = wf_ensure_trace(c);
+        if (rc) { return rc; }
+        FamilyTimer t(c, F_ZOOM);
+        emit_wf(c, level + 1, F_ZOOM, TR_WF_TRACE, (c->data_width + 255) / 256, 1,
+                TickWf{ c->d_zoomed, c->wf.d_latest, c->wf.d_smooth, c->wf.hold_on ? c->wf.d_hold : (float*)nullptr, nframes, c->data_width, 0, 0, c->wf.alpha, c->wf.beta, c->wf.hold_speed, 0.0f });
+        c->wf.have_latest = true;
+    }
+    {   // raw lines into the ring (getFFTBuffer, waterfall.cpp:875-886)
+        FamilyTimer t(c, F_ZOOM);
+        emit_wf(c, level, F_ZOOM, TR_WF_RING, std::max(1, std::min(c->fft_size / 1024, 64)), nframes, TickWf{ c->d_lines, c->wf.d_ring, nullptr, nullptr, nframes, c->fft_size, c->wf.height, c->wf.cur, 0.0f, 0.0f, 0.0f, 0.0f });
+        const long long nc = (long long)c->wf.cur - nframes;
+        c->wf.cur = (int)(((nc % c->wf.height) + c->wf.height) % c->wf.height);
+        c->wf.lines = (int)std::min<int64_t>((int64_t)c->wf.lines + nframes, c->wf.height);
+    }
+    return SDRPP_OK;
+}
+
 int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
     c->n_lines = 0;
     if (!c->fft_on) { return SDRPP_OK; }
@@ -301,8 +324,8 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
         if ((size_t)nframes > c->lines_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: %lld frames exceed line capacity %zu", (long long)nframes, c->lines_cap); }
         const size_t per_chunk = std::max<size_t>(1, kScratchBytes / ((size_t)c->fft_size * sizeof(float2)));
         if (c->tick_planning) {
-            // one chunk only (the chunks of an ordinary pass share the scratch matrix one after the other), no display state
-            if ((size_t)nframes > per_chunk || c->wf.height > 0) {
+            // one chunk only (the chunks of an ordinary pass share the scratch matrix one after the other)
+            if ((size_t)nframes > per_chunk) {
                 c->tick_abort = true;
                 return SDRPP_OK;
             }
@@ -335,6 +358,11 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
                 c->emits.push_back(z);
             }
             c->plan_top = std::max(c->plan_top, lines_level + (c->data_width > 0 ? 2 : 1));
+            if (c->wf.height > 0) {
+                rc = plan_wf_state(c, (int)nframes, lines_level + 1);
+                if (rc) { return rc; }
+                c->plan_top = std::max(c->plan_top, lines_level + (c->data_width > 0 ? 3 : 2));
+            }
             c->fft_next += nframes;
             c->fft_pos = end;
             c->n_lines = (int)nframes;
@@ -355,21 +383,10 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             FamilyTimer t(c, F_ZOOM);
             launch_zoom(c->launch_stream, c->d_lines, (int)nframes, c->fft_size, c->view_size, c->data_width, c->d_zstart, c->d_zcount, c->wf_min, c->wf_max, c->d_zoomed, c->d_index,
                         c->d_lines_grp, c->zoom_grp, zoom_lanes(c, zoom_uses_grp(c, c->d_lines_grp, c->view_size, c->data_width, c->zoom_grp)));
-            if (c->wf.height > 0) {  // FFT trace: latestFFT after smoothing / hold (pushFFT, waterfall.cpp:913-939)
-                int rc2 = wf_ensure_trace(c);
-                if (rc2) { return rc2; }
-                launch(c, wf_trace_kernel, dim3((unsigned)(c->data_width + 255) / 256), dim3(256), 0, (const float*)c->d_zoomed, (int)nframes, c->data_width, c->wf.d_latest, c->wf.d_smooth,
-                       c->wf.alpha, c->wf.beta, c->wf.hold_on ? c->wf.d_hold : (float*)nullptr, c->wf.hold_speed);
-                c->wf.have_latest = true;
-            }
         }
-        if (c->wf.height > 0) {  // raw lines into the ring (getFFTBuffer, waterfall.cpp:875-886)
-            FamilyTimer t(c, F_ZOOM);
-            launch(c, wf_ring_store_kernel, dim3((unsigned)std::max(1, std::min(c->fft_size / 1024, 64)), (unsigned)nframes), dim3(256), 0, (const float*)c->d_lines, (int)nframes, c->fft_size,
-                   c->wf.d_ring, c->wf.height, c->wf.cur);
-            const long long nc = (long long)c->wf.cur - nframes;
-            c->wf.cur = (int)(((nc % c->wf.height) + c->wf.height) % c->wf.height);
-            c->wf.lines = (int)std::min<int64_t>((int64_t)c->wf.lines + nframes, c->wf.height);
+        if (c->wf.height > 0) {
+            int rc = plan_wf_state(c, (int)nframes, 1);
+            if (rc) { return rc; }
         }
         c->fft_next += nframes;
     }

@@ -35,7 +35,9 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
     const float* result = cur->data;
     if (P.dc_rate != 0.0f) {
         const int nseg = std::min(P.seg_cap, (n_out + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG);
-        dc.push_back(DeempJob{ (const float2*)cur->data, (float2*)P.out.data, n_out, P.dc_rate, P.d_off, P.d_seg, nseg, P.conj });
+        dc.push_back(DeempJob{ (const float2*)cur->data, (float2*)P.out.data, n_out, P.dc_rate, P.d_off + P.state_cur, P.d_off + (P.ref_order ? P.state_cur : (P.state_cur ^ 1)),
+                               P.d_seg + (size_t)P.state_cur * ((size_t)P.seg_cap + 1), nseg, P.conj });
+        if (nseg > 0 && !P.ref_order) { P.state_cur ^= 1; }
         result = P.out.data;
     }
     else if (P.conj) { result = P.out.data; }
@@ -72,13 +74,12 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
             }
         }
         if (!dc.empty() && P.ref_order) {  // parity mode: the sequential recursion itself
-            if (n_out > 0) { launch(c, iq_dc_block_exact_kernel, dim3(1), dim3(64), 0, dc[0].in, dc[0].out, n_out, P.dc_rate, (float2*)P.d_off, P.conj); }
+            if (n_out > 0) { launch(c, iq_dc_block_exact_kernel, dim3(1), dim3(64), 0, dc[0].in, dc[0].out, n_out, P.dc_rate, dc[0].state_out, P.conj); }
         }
         else if (!dc.empty() && dc[0].nseg > 0) {
             const dim3 grid((unsigned)dc[0].nseg, 1);
             launch(c, vfo_deemph_kernel<1, 0>, grid, dim3(256), 0, (const DeempJob*)d_dc);
             launch(c, vfo_deemph_kernel<1, 1>, grid, dim3(256), 0, (const DeempJob*)d_dc);
-            launch(c, vfo_deemph_state_kernel<1>, dim3(1), dim3(64), 0, (const DeempJob*)d_dc, 1);
         }
         else if (dc.empty() && P.conj && n_out > 0) {
             launch(c, iq_conjugate_kernel, dim3((unsigned)std::min((n_out + 255) / 256, 4096)), dim3(256), 0, (const float2*)cur->data, (float2*)P.out.data, n_out);

@@ -6,13 +6,13 @@ namespace {
 
 // ---- streaming state that planning a block changes, for roll-back: a block either happens completely or not at all ----------------------
 struct PlanSnapshot {
-    struct V { int soff[SDRPP_MAX_DECIM_STAGES]; int pphase, poff; double phi, phi2; long long seen; int i_if, lvl_if, lvl_out; int n[24], cur[24]; size_t nrecs;
-               int af_soff[SDRPP_MAX_DECIM_STAGES], af_pphase, af_poff, af_last; };
+    struct V { int soff[SDRPP_MAX_DECIM_STAGES]; int pphase, poff; double phi, phi2; long long seen; int i_if, lvl_if, lvl_out, lvl_af; int n[24], cur[24]; size_t nrecs;
+               int af_soff[SDRPP_MAX_DECIM_STAGES], af_pphase, af_poff, af_last, af_state; };
     std::vector<V> v;
     int64_t fft_pos, fft_next;
     int n_lines, iq_cur, wf_cur, wf_lines;
     bool wf_have;
-    int pre_soff[SDRPP_MAX_DECIM_STAGES];
+    int pre_soff[SDRPP_MAX_DECIM_STAGES], pre_state;
 };
 void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
     S.v.resize(c->vfos.size());
@@ -21,14 +21,15 @@ void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
         Vfo& v = *kv.second;
         PlanSnapshot::V& q = S.v[i++];
         for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { q.soff[k] = v.soff[k]; q.af_soff[k] = v.af.soff[k]; }
-        q.pphase = v.pphase; q.poff = v.poff; q.phi = v.phi; q.phi2 = v.phi2; q.seen = v.seen; q.i_if = v.i_if; q.lvl_if = v.lvl_if; q.lvl_out = v.lvl_out;
+        q.pphase = v.pphase; q.poff = v.poff; q.phi = v.phi; q.phi2 = v.phi2; q.seen = v.seen; q.i_if = v.i_if; q.lvl_if = v.lvl_if; q.lvl_out = v.lvl_out; q.lvl_af = v.lvl_af;
         q.nrecs = v.recs.size();
-        q.af_pphase = v.af.pphase; q.af_poff = v.af.poff; q.af_last = v.af.i_last;
+        q.af_pphase = v.af.pphase; q.af_poff = v.af.poff; q.af_last = v.af.i_last; q.af_state = v.af.state_cur;
         for (size_t k = 0; k < v.st.size() && k < 24; k++) { q.n[k] = v.st[k].n; q.cur[k] = v.st[k].cur; }
     }
     S.fft_pos = c->fft_pos; S.fft_next = c->fft_next; S.n_lines = c->n_lines; S.iq_cur = c->iq_cur;
     S.wf_cur = c->wf.cur; S.wf_lines = c->wf.lines; S.wf_have = c->wf.have_latest;
     for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { S.pre_soff[k] = c->pre.soff[k]; }
+    S.pre_state = c->pre.state_cur;
 }
 // (retune records a plan has dropped stay dropped: they were out of every window's reach)
 void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
@@ -37,13 +38,14 @@ void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
         Vfo& v = *kv.second;
         const PlanSnapshot::V& q = S.v[i++];
         for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { v.soff[k] = q.soff[k]; v.af.soff[k] = q.af_soff[k]; }
-        v.pphase = q.pphase; v.poff = q.poff; v.phi = q.phi; v.phi2 = q.phi2; v.seen = q.seen; v.i_if = q.i_if; v.lvl_if = q.lvl_if; v.lvl_out = q.lvl_out;
-        v.af.pphase = q.af_pphase; v.af.poff = q.af_poff; v.af.i_last = q.af_last;
+        v.pphase = q.pphase; v.poff = q.poff; v.phi = q.phi; v.phi2 = q.phi2; v.seen = q.seen; v.i_if = q.i_if; v.lvl_if = q.lvl_if; v.lvl_out = q.lvl_out; v.lvl_af = q.lvl_af;
+        v.af.pphase = q.af_pphase; v.af.poff = q.af_poff; v.af.i_last = q.af_last; v.af.state_cur = q.af_state;
         for (size_t k = 0; k < v.st.size() && k < 24; k++) { v.st[k].n = q.n[k]; v.st[k].cur = q.cur[k]; }
     }
     c->fft_pos = S.fft_pos; c->fft_next = S.fft_next; c->n_lines = S.n_lines; c->iq_cur = S.iq_cur;
     c->wf.cur = S.wf_cur; c->wf.lines = S.wf_lines; c->wf.have_latest = S.wf_have;
     for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { c->pre.soff[k] = S.pre_soff[k]; }
+    c->pre.state_cur = S.pre_state;
 }
 
 void block_bounds(sdrpp_ctx* c, int64_t count, const std::vector<int>* push_ends) {

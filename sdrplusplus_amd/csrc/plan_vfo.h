@@ -550,13 +550,16 @@ struct BankPlan {
             if (a.i_deemp >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_deemp];
                 lvl++;
-                af_deemp.add(lvl, DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last, a.d_seg,
-                                             std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG), 0 });
+                const int nseg = std::min(a.seg_cap, (acur->n + SDRPP_DEEMP_SEG - 1) / SDRPP_DEEMP_SEG);
+                af_deemp.add(lvl, DeempJob{ (const float2*)acur->data, (float2*)nxt->data, acur->n, a.alpha, a.d_last + a.state_cur, a.d_last + (a.state_cur ^ 1),
+                                             a.d_seg + (size_t)a.state_cur * ((size_t)a.seg_cap + 1), nseg, 0 });
+                if (nseg > 0) { a.state_cur ^= 1; }  // (a block without audio leaves the state where it is)
                 nxt->n = acur->n;
                 acur = nxt;
-                lvl += 2;  // (the de-emphasis is three dependent launches)
+                lvl += 1;  // (the de-emphasis is two dependent launches: segment maps, then the outputs)
             }
             a.i_last = (int)(acur - &v.st[0]);
+            v.lvl_af = lvl;
         }
         double p = v.phi + (double)n_in * v.theta;
         v.phi = p - std::floor(p);
@@ -980,6 +983,8 @@ struct BankPlan {
             for (auto& jb : jobs) {
                 max_nout = std::max(max_nout, jb.nout);
                 int nt = 256;
+                // (a role of a tick: every workgroup of the launch gets the largest role's LDS — stay near the other roles' ~40 KB where the filter allows)
+                while (ticking && nt > 64 && lds_for(jb, nt) > (size_t)c->tick_lds_cap_fir) { nt >>= 1; }
                 while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
                 if (nt < 32) {
                     if (width != 2 || quad || stereo) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
@@ -1004,9 +1009,16 @@ struct BankPlan {
     }
     // resamplers with many phases (L > 8, e.g. 96/125): cycle-major kernel — one LDS window serves all L phases of up to 64 cycles;
     // a filter whose single cycle does not fit falls back to the per-output kernel
-    int launch_polyc(std::vector<PolyJob>& jobs, PolyJob* d_jobs) {
+    int launch_polyc(int level, int fam, std::vector<PolyJob>& jobs, PolyJob* d_jobs) {
             if (jobs.empty()) { return SDRPP_OK; }
-            const int cap2 = kMaxLds / (int)sizeof(float2);
+            // LDS window of a tile: all 64 KB for a launch of its own (64 cycles per tile); as a role of a tick — whose workgroups all get the
+            // largest role's LDS — about 24 KB (e.g. 19 cycles of the 96 / 125 resampler) unless a single cycle needs more
+            int cap2 = kMaxLds / (int)sizeof(float2);
+            if (ticking) {
+                int need = c->tick_lds_cap / (int)sizeof(float2);
+                for (auto& jb : jobs) { need = std::max(need, jb.tpp + 2 * jb.decim + 1); }
+                cap2 = std::min(cap2, need);
+            }
             bool fits = true;
             int max_nout = 0, max_tiles = 0;
             for (auto& jb : jobs) {
@@ -1018,7 +1030,7 @@ struct BankPlan {
             }
             if (max_nout == 0) { return SDRPP_OK; }
             if (fits) {
-                launch(c, vfo_polyc_kernel, dim3((unsigned)max_tiles, (unsigned)jobs.size()), dim3(256), (size_t)kMaxLds, (const PolyJob*)d_jobs, cap2);
+                emit(c, level, fam, TR_POLYC, max_tiles, (int)jobs.size(), (size_t)cap2 * sizeof(float2), d_jobs, nullptr, cap2);
                 return SDRPP_OK;
             }
             size_t lds = 0;
@@ -1107,7 +1119,7 @@ struct BankPlan {
                 FamilyTimer t(c, F_POLY);
                 emit_toep(1, l);
                 if (l < poly.top) {
-                    rc = launch_polyc(poly.at[l], poly.dev[l]);
+                    rc = launch_polyc(l, F_POLY, poly.at[l], poly.dev[l]);
                     if (rc) { return rc; }
                 }
                 for (int li = 0; li < 4; li++) {
@@ -1157,7 +1169,7 @@ struct BankPlan {
                 }
                 emit_toep(6, l);
                 if (l < af_poly.top) {
-                    rc = launch_polyc(af_poly.at[l], af_poly.dev[l]);
+                    rc = launch_polyc(l, F_AF, af_poly.at[l], af_poly.dev[l]);
                     if (rc) { return rc; }
                 }
                 emit_toep(7, l);
@@ -1168,11 +1180,9 @@ struct BankPlan {
                 if (l < af_deemp.top && !af_deemp.at[l].empty()) {
                     int max_seg = 0;
                     for (auto& jb : af_deemp.at[l]) { max_seg = std::max(max_seg, jb.nseg); }
-                    if (max_seg > 0) {
-                        const dim3 grid((unsigned)max_seg, (unsigned)af_deemp.at[l].size());
-                        launch(c, vfo_deemph_kernel<0, 0>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
-                        launch(c, vfo_deemph_kernel<0, 1>, grid, dim3(256), 0, (const DeempJob*)af_deemp.dev[l]);
-                        launch(c, vfo_deemph_state_kernel<0>, dim3(((unsigned)af_deemp.at[l].size() + 63) / 64), dim3(64), 0, (const DeempJob*)af_deemp.dev[l], (int)af_deemp.at[l].size());
+                    if (max_seg > 0) {  // segment maps at this level, the outputs (and the state the next block starts from) one level later
+                        emit(c, l, F_AF, TR_DEEMP_P0, max_seg, (int)af_deemp.at[l].size(), 3 * 256 * sizeof(float), af_deemp.dev[l]);
+                        emit(c, l + 1, F_AF, TR_DEEMP_P1, max_seg, (int)af_deemp.at[l].size(), 3 * 256 * sizeof(float), af_deemp.dev[l]);
                     }
                 }
             }

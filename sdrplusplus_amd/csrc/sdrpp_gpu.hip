@@ -670,11 +670,12 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
         if (rc) { return rc; }
     }
     if (dc_rate != 0.0f) {
-        rc = dev_alloc(c, &P.d_off, 1);
+        rc = dev_alloc(c, &P.d_off, 2);
         if (rc) { return rc; }
-        HIPCHK(c, hipMemset(P.d_off, 0, sizeof(float2)));
+        HIPCHK(c, hipMemset(P.d_off, 0, 2 * sizeof(float2)));
+        P.state_cur = 0;
         P.seg_cap = (int)(cap / SDRPP_DEEMP_SEG) + 2;
-        rc = dev_alloc(c, &P.d_seg, (size_t)P.seg_cap + 1);
+        rc = dev_alloc(c, &P.d_seg, 2 * ((size_t)P.seg_cap + 1));
         if (rc) { return rc; }
     }
     P.on = true;
@@ -1071,11 +1072,12 @@ int sdrpp_vfo_set_af(sdrpp_ctx* c, int id, const sdrpp_af_desc* af) {
         if (a.i_hpf < 0) { return SDRPP_ERR_NOMEM; }
     }
     if (a.alpha != 0.0f) {
-        rc = dev_alloc(c, &a.d_last, 1);
+        rc = dev_alloc(c, &a.d_last, 2);
         if (rc) { return rc; }
-        HIPCHK(c, hipMemset(a.d_last, 0, sizeof(float2)));
+        HIPCHK(c, hipMemset(a.d_last, 0, 2 * sizeof(float2)));
+        a.state_cur = 0;
         a.seg_cap = (int)(cap / SDRPP_DEEMP_SEG) + 2;
-        rc = dev_alloc(c, &a.d_seg, (size_t)a.seg_cap + 1);
+        rc = dev_alloc(c, &a.d_seg, 2 * ((size_t)a.seg_cap + 1));
         if (rc) { return rc; }
         a.i_deemp = add_stream(0, cap);
         if (a.i_deemp < 0) { return SDRPP_ERR_NOMEM; }
@@ -1779,7 +1781,8 @@ int sdrpp_pipeline_stats(sdrpp_ctx* c, int64_t* out, int max) {
 const char* sdrpp_pipeline_role_name(int role) {
     static const char* const names[] = { "none", "copy", "carry", "rot", "fcm_132_4", "fcm_6", "fcm_10", "fcm_16", "fcm16_132_4", "fcl_0", "fcl_pf", "toep_c", "toep_r", "toep_q",
                                          "firb_c", "firb_r", "firb_s", "firb_q", "pre", "seq", "fft_s10", "fft_s11", "fft_s12", "fft_p1_5", "fft_p1_6", "fft_p1_7", "fft_p1_8", "fft_p1_9",
-                                         "fft_p1_10", "fft_p2_7", "fft_p2_8", "fft_p2_9", "fft_p2_10", "fft_p2row", "fft_tr", "zoom_16", "zoom_4", "zoom_1", "pipe" };
+                                         "fft_p1_10", "fft_p2_7", "fft_p2_8", "fft_p2_9", "fft_p2_10", "fft_p2row", "fft_tr", "zoom_16", "zoom_4", "zoom_1", "polyc", "deemp_p0", "deemp_p1",
+                                         "dc_p0", "dc_p1", "wf_ring", "wf_trace", "pipe" };
     static_assert(sizeof(names) / sizeof(names[0]) == TR_COUNT, "role names out of step with TickRole");
     return (role >= 0 && role < TR_COUNT) ? names[role] : nullptr;
 }

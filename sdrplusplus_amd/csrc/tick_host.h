@@ -226,22 +226,34 @@ int tick_drain(sdrpp_ctx* c) {
 // Can this context's blocks run as ticks at all?  (What can only be seen while planning — a VFO group too small for the matrix front end,
 // a filter without the matrix form, more frames than one scratch chunk — aborts the plan instead.)
 bool tick_eligible(sdrpp_ctx* c) {
-    if (c->pre.on || c->wf.height > 0 || c->deferred) { return false; }
+    if (c->pre.on || c->deferred) { return false; }
     for (auto& kv : c->vfos) {
         const Vfo& v = *kv.second;
-        if (v.af.on || v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
+        if (v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
     }
     return true;
 }
 
 // ---- results of a block in page-locked host memory (sdrpp_set_pipelined's result flags): gather roles one level behind the producers ----
+// What result flag 1 delivers per VFO: the end of its chain — the AF chain's output where one is attached (what the radio module's audio
+// stream carries, radio_module.h:98-110), else the demodulator's, else (no demodulator) the IF stream — and the level it is written at.
+const Stream& result_stream(const Vfo& v, int* level = nullptr) {
+    if (v.af.on && v.af.i_last >= 0 && v.d.demod != SDRPP_DEMOD_RAW) {
+        if (level) { *level = v.lvl_af; }
+        return v.st[(size_t)v.af.i_last];
+    }
+    const bool raw = v.d.demod == SDRPP_DEMOD_RAW;
+    if (level) { *level = raw ? v.lvl_if : v.lvl_out; }
+    return raw ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+}
 size_t tick_results_need(sdrpp_ctx* c) {
     size_t need = 0;
     if (c->res_flags & 1) {
         for (auto& kv : c->vfos) {
             const Vfo& v = *kv.second;
-            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
-            need += ((s.cap + 16) * 8 + 15) & ~(size_t)15;
+            size_t cap = std::max(result_stream(v).cap, v.st[(size_t)v.i_if].cap);  // (which stream ends the chain can change with sdrpp_vfo_set_af: room for either)
+            if (v.i_out >= 0) { cap = std::max(cap, v.st[(size_t)v.i_out].cap); }
+            need += ((cap + 16) * 8 + 15) & ~(size_t)15;
         }
     }
     if (c->fft_on) {
@@ -302,13 +314,13 @@ int tick_results_plan(sdrpp_ctx* c) {
     if (c->res_flags & 1) {
         for (auto& kv : c->vfos) {
             const Vfo& v = *kv.second;
-            const bool raw = v.d.demod == SDRPP_DEMOD_RAW;
-            const Stream& s = raw ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            int lvl = 1;
+            const Stream& s = result_stream(v, &lvl);
             R.ids.push_back(v.id);
             R.offsets.push_back((int64_t)(off / 8));
             R.counts.push_back(s.n);
             const size_t bytes = (size_t)s.n * 8;
-            if (bytes) { jobs.add((raw ? v.lvl_if : v.lvl_out) + 1, CopyJob{ s.data, base + off, (long long)bytes, 0x100, 0 }); }
+            if (bytes) { jobs.add(lvl + 1, CopyJob{ s.data, base + off, (long long)bytes, 0x100, 0 }); }
             off += (bytes + 15) & ~(size_t)15;
         }
     }
@@ -363,7 +375,7 @@ int tick_results_direct(sdrpp_ctx* c) {
     if (c->res_flags & 1) {
         for (auto& kv : c->vfos) {
             const Vfo& v = *kv.second;
-            const Stream& s = (v.d.demod == SDRPP_DEMOD_RAW) ? v.st[(size_t)v.i_if] : v.st[(size_t)v.i_out];
+            const Stream& s = result_stream(v);
             R.ids.push_back(v.id);
             R.offsets.push_back((int64_t)(off / 8));
             R.counts.push_back(s.n);

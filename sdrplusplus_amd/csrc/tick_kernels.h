@@ -26,7 +26,7 @@ struct CopyJob {
     const void* src;
     void* dst;
     long long bytes;  // multiple of 4 (kind 1: SOURCE bytes, multiple of 2)
-    int kind;         // 0: verbatim; 1: interleaved int16 -> float (x / 32768: file_source/src/main.cpp:162); bit 8: dst is host memory
+    int kind;         // 0: verbatim; 1: interleaved int16 -> float (x / 32768: file_source/src/main.cpp:162); 2: complex conjugate (dsp/math/conjugate.h:12-15, bytes a multiple of 8); bit 8: dst is host memory
     int pad;
 };
 __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
@@ -37,6 +37,15 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
         const float inv = 1.0f / 32768.0f;
         const long long n = job.bytes / 2;
         for (long long i = tid; i < n; i += nth) { out[i] = ((float)in[i]) * inv; }
+    }
+    else if ((job.kind & 0xff) == 2) {
+        const float2* in = reinterpret_cast<const float2*>(job.src);
+        float2* out = reinterpret_cast<float2*>(job.dst);
+        const long long n = job.bytes / 8;
+        for (long long i = tid; i < n; i += nth) {
+            const float2 x = in[i];
+            out[i] = make_float2(x.x, -x.y);
+        }
     }
     else {
         const bool al16 = ((((unsigned long long)job.src) | ((unsigned long long)job.dst)) & 15ull) == 0ull;
@@ -86,6 +95,10 @@ enum TickRole : int {
     TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10,             // p.p2
     TR_FFT_P2ROW, TR_FFT_TR,                                         // p.p2 (long transforms: 4096-point rows in place; transpose into bin order, aux = doZoom group size)
     TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
+    TR_POLYC,      // PolyJob[gy], aux = LDS window in float2: vfo_polyc_body (many-phase resampler, cycle-major: the AF chain's 96/125)
+    TR_DEEMP_P0, TR_DEEMP_P1,  // DeempJob[gy]: vfo_deemph_body<0, 0 / 1> (de-emphasis: segment maps, then the outputs one level later)
+    TR_DC_P0, TR_DC_P1,        // DeempJob[gy]: vfo_deemph_body<1, 0 / 1> (the front end's DC blocker)
+    TR_WF_RING, TR_WF_TRACE,   // p.wf: raw lines into the waterfall's ring; FFT trace smoothing / hold over the block's zoomed lines
     TR_PIPE,       // PipeJob[gy], gx = segments per VFO: vfo_pipe_body<1> — an FM back end (last decimator, resampler, channel filter, discriminator + audio low-pass) as ONE role
     TR_COUNT
 };
@@ -93,6 +106,8 @@ struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; 
 struct TickP2 { const float2* scratch; const float2* tw2; float* out; float* grp; int lg1, ntiles; };
 struct TickFS { IqSrc src; FrameGeom g; const float* window; const float2* tw; float* out; };
 struct TickZoom { const float* lines; const int32_t* zs; const int32_t* zc; float* zoomed; int32_t* index; const float* grp; int fft_size, data_width, gsz; float wf_min, wf_max; int pad; };
+// waterfall display state (fft_kernels.h: wf_ring_store_body / wf_trace_body)
+struct TickWf { const float* src; float* a; float* b; float* c; int n0, n1, n2, n3; float f0, f1, f2, pad; };
 struct TickEntry {
     int role, gx, gy, aux;
     const void* jobs;
@@ -102,6 +117,7 @@ struct TickEntry {
         TickP2 p2;
         TickFS fs;
         TickZoom z;
+        TickWf wf;
     } p;
 };
 #define SDRPP_TICK_MAX_ENTRIES 64
@@ -283,6 +299,13 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
+            case TR_POLYC: vfo_polyc_body(bid, reinterpret_cast<float2*>(smem), reinterpret_cast<const PolyJob*>(e_jobs), e_aux); break;
+            case TR_DEEMP_P0: vfo_deemph_body<0, 0>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;
+            case TR_DEEMP_P1: vfo_deemph_body<0, 1>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;
+            case TR_DC_P0: vfo_deemph_body<1, 0>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;
+            case TR_DC_P1: vfo_deemph_body<1, 1>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;
+            case TR_WF_RING: { const TickWf q = e.p.wf; wf_ring_store_body(bid, gdim, q.src, q.n0, q.n1, q.a, q.n2, q.n3); } break;
+            case TR_WF_TRACE: { const TickWf q = e.p.wf; wf_trace_body(bid, q.src, q.n0, q.n1, q.a, q.b, q.f0, q.f1, q.c, q.f2); } break;
             case TR_PIPE: vfo_pipe_body<1>(bid, gdim, smem, reinterpret_cast<const PipeJob*>(e_jobs)); break;
             default: break;
             }

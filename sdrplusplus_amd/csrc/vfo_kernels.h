@@ -2265,8 +2265,10 @@ struct DeempJob {
     float2* out;
     int n;
     float alpha;      // KIND 0: de-emphasis alpha; KIND 1: DC-blocker rate
-    float2* state;    // KIND 0: lastOut (deephasis.h:72-73); KIND 1: offset (dc_blocker.h:57), device resident
-    float4* seg;      // [nseg] scratch: per segment (m, a.l, a.r, -): state_end = m * state_in + a
+    const float2* state_in;  // KIND 0: lastOut (deephasis.h:72-73); KIND 1: offset (dc_blocker.h:57) as the block before left it, device resident
+    float2* state_out;       // ... as this block leaves it (the host alternates two slots block by block: in pipelined mode pass 1 of block n + 1
+                             // runs one launch behind pass 1 of block n and must neither wait for a third launch nor overwrite what is being read)
+    float4* seg;      // [nseg] scratch: per segment (m, a.l, a.r, -): state_end = m * state_in + a (two buffers, alternating like the state)
     int nseg;         // segments of SDRPP_DEEMP_SEG frames
     int conj;         // KIND 1: negate the imaginary part of the output (dsp/math/conjugate.h) after the DC blocker
 };
@@ -2306,12 +2308,12 @@ __device__ __forceinline__ void deemph_block_scan(float* sm_m, float2* sm_a, int
 // before it onto the carried state (a few dozen multiply-adds), then each work-item re-runs the reference's exact expression from
 // its true carry-in; vfo_deemph_state_kernel stores the new state.
 template <int KIND, int PASS>
-__global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restrict__ jobs) {
-    __shared__ float sm_m[256];
-    __shared__ float2 sm_a[256];
-    const DeempJob& job = jobs[blockIdx.y];
-    const int sg = blockIdx.x;
-    if (sg >= job.nseg) { return; }
+__device__ __forceinline__ void vfo_deemph_body(const KIdx bid, float* smem, const DeempJob* __restrict__ jobs) {
+    float* sm_m = smem;                                        // [256]
+    float2* sm_a = reinterpret_cast<float2*>(smem + 256);      // [256]
+    const DeempJob& job = jobs[bid.y];
+    const int sg = bid.x;
+    if (sg >= job.nseg) { return; }  // (the whole workgroup)
     constexpr int C = SDRPP_DEEMP_C;
     const int t = threadIdx.x;
     const float alpha = job.alpha, beta = 1.0f - alpha;
@@ -2340,7 +2342,7 @@ __global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restr
         if (t == 255) { job.seg[sg] = make_float4(sm_m[255], sm_a[255].x, sm_a[255].y, 0.0f); }
     }
     else {
-        float2 c0 = *job.state;  // carry into the push, then through the earlier segments (uniform: every work-item does the same)
+        float2 c0 = *job.state_in;  // carry into the push, then through the earlier segments (uniform: every work-item does the same)
         for (int q = 0; q < sg; q++) {
             const float4 g = job.seg[q];
             c0 = make_float2(g.y + g.x * c0.x, g.z + g.x * c0.y);
@@ -2363,23 +2365,15 @@ __global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restr
                 }
             }
         }
-        if constexpr (KIND == 1) {
-            // the offset after the last sample is not an output: the last segment's last live work-item keeps it for the state kernel
-            if (sg == job.nseg - 1 && i0 < job.n && i0 + C >= job.n) { job.seg[job.nseg] = make_float4(0.0f, y.x, y.y, 0.0f); }
-        }
+        // the state the NEXT block starts from: lastOut = out[n - 1] (deephasis.h:72-73) resp. the offset after the last sample — the work-item
+        // that holds the last sample of the push has it in `y`
+        if (sg == job.nseg - 1 && i0 < job.n && i0 + C >= job.n) { *job.state_out = y; }
     }
 }
-// lastOut = out[n-1] (deephasis.h:72-73), after all segments are done
-template <int KIND>
-__global__ void vfo_deemph_state_kernel(const DeempJob* __restrict__ jobs, int njobs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < njobs && jobs[i].n > 0) {
-        if constexpr (KIND == 0) { *jobs[i].state = jobs[i].out[jobs[i].n - 1]; }
-        else {
-            const float4 g = jobs[i].seg[jobs[i].nseg];
-            *jobs[i].state = make_float2(g.y, g.z);
-        }
-    }
+template <int KIND, int PASS>
+__global__ __launch_bounds__(256) void vfo_deemph_kernel(const DeempJob* __restrict__ jobs) {
+    __shared__ float sm[3 * 256];
+    vfo_deemph_body<KIND, PASS>(kidx(blockIdx), sm, jobs);
 }
 // Conjugate alone (dsp/math/conjugate.h:12-15)
 __global__ __launch_bounds__(256) void iq_conjugate_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n) {
@@ -2394,13 +2388,12 @@ __global__ __launch_bounds__(256) void iq_conjugate_kernel(const float2* __restr
 // CT * M inputs); lane j owns cycle j, a wavefront walks over phases r = w, w + 4, ...: within a wavefront the phase — hence
 // the tap row — is uniform (scalar loads) and all L phases reuse ONE LDS window of CT * M + tpp input samples.
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void vfo_polyc_kernel(const PolyJob* __restrict__ jobs, int cap2) {
-    HIP_DYNAMIC_SHARED(float2, xsc)
-    const PolyJob& job = jobs[blockIdx.y];
+__device__ __forceinline__ void vfo_polyc_body(const KIdx bid, float2* xsc, const PolyJob* __restrict__ jobs, int cap2) {
+    const PolyJob& job = jobs[bid.y];
     const int L = job.interp, M = job.decim, tpp = job.tpp;
     int CT = (cap2 - tpp - M) / M;  // cycles per tile: window (CT - 1) * M + o_max + tpp <= cap2, o_max <= M
     if (CT > 64) { CT = 64; }
-    const int c0 = blockIdx.x * CT;
+    const int c0 = bid.x * CT;
     if ((long long)c0 * L >= job.nout) { return; }
     const int first = job.off0 + c0 * M - (tpp - 1);
     const int nwin = CT * M + M + tpp;
@@ -2423,6 +2416,10 @@ __global__ __launch_bounds__(256) void vfo_polyc_kernel(const PolyJob* __restric
             if (n < job.nout) { global_store_f32x2(job.out, n, acc); }
         }
     }
+}
+__global__ __launch_bounds__(256) void vfo_polyc_kernel(const PolyJob* __restrict__ jobs, int cap2) {
+    HIP_DYNAMIC_SHARED(float2, xsc)
+    vfo_polyc_body(kidx(blockIdx), xsc, jobs, cap2);
 }
 
 }  // namespace sdrpp_k

@@ -290,3 +290,96 @@ def test_results_survive_growing_result_slots(backend):
         cb.result_release(t)
     ca.close()
     cb.close()
+
+
+@pytest.mark.parametrize("high_pass,tau", [(False, 50e-6), (True, None)])
+def test_pipelined_equals_ordinary_with_af_chain(backend, high_pass, tau):
+    """The radio's AF chain (radio_module.h:98-110: the AF resampler is ALWAYS on) behind every VFO of a pipelined bank: pre-decimators and
+    the 96 / 125 resampler, the 1824-tap high-pass or the de-emphasis run as roles of the ticks too (de-emphasis: two levels, its state handed
+    from block to block through two alternating slots) — no block falls back to an ordinary pass, and what result flag 1 delivers is the AF
+    chain's output (what the radio's audio stream carries), bit-identical to sdrpp_vfo_af_read after ordinary passes."""
+    from sdrplusplus_amd import radio, workloads
+
+    nv = 20 if backend == "gpu" else 17
+    pushes = [50000, 30011, 50000, 20000, 50000, 50000] if backend == "gpu" else [25000, 15011, 25000, 10000, 25000]
+    x = workloads.synth(3, sum(pushes), seed=15, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, max(pushes), 4096, flags=7)
+    for ctx, vids in ((ca, va), (cb, vb)):
+        for vid in vids:
+            a, keep = radio.af_desc(250e3, 48000.0, tau, high_pass)
+            ctx.vfo_set_af(vid, a, keep)
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        ca.push(blk)
+        r = {"vfo": {v: ca.vfo_af_read(v).copy() for v in va}}
+        raw, zo, ix = ca.fft_read()
+        r.update(raw=raw, zoomed=zo, index=ix)
+        refs.append(r)
+        cb.push(blk)
+    total = 0
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        total += sum(len(a) for a in got["vfo"].values())
+        cb.result_release(t)
+    assert total > 0
+    st = cb.pipeline_stats()  # (roles are counted as their ticks are launched: all of them by now)
+    assert st["tick_blocks"] == len(pushes) and st["pass_blocks"] == 0, st
+    assert "polyc" in st["roles"] and (("firb_c" in st["roles"]) if high_pass else ("deemp_p0" in st["roles"] and "deemp_p1" in st["roles"])), st
+    for v_a, v_b in zip(va, vb):  # the observing calls see the most recent block's AF output
+        _same(refs[-1]["vfo"][v_a], cb.vfo_af_read(v_b), "last block through sdrpp_vfo_af_read")
+    ca.close()
+    cb.close()
+
+
+def test_pipelined_equals_ordinary_with_waterfall_state(backend):
+    """The waterfall widget's display state (sdrpp_wf_configure: raw-line ring, FFT trace smoothing / hold — waterfall.cpp:875-941) no longer
+    throws a pipelined block onto an ordinary pass: ring store and trace update are roles of the ticks.  Same lines, same trace, same re-raster
+    as after ordinary passes, with the ring wrapping, smoothing and hold switched on mid-stream and blocks that complete 0, 1 and several lines."""
+    from sdrplusplus_amd import capi, workloads
+
+    sr, N, W, H = 10e6, 4096, 600, 5
+    pushes = [N // 2, N, N * 3 + 17, 100, N * 5, N * 2]
+    x = workloads.synth(2, sum(pushes), seed=33)
+    ctxs = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=N * 5)
+        ctx.fft_configure(N, N, 0, capi.design_fft_window(2, N))
+        start, size = capi.design_waterfall_view(1.0e6, 4.0e6, sr, N)
+        ctx.fft_set_view(start, size, W, -110.0, -10.0)
+        ctx.wf_configure(H)
+        if pipelined:
+            ctx.set_pipelined(True, 6)
+        ctxs.append(ctx)
+    ca, cb = ctxs
+    pos = 0
+    for step, npush in enumerate(pushes):
+        if step == 2:
+            for c_ in ctxs:
+                c_.wf_set_smoothing(True, 0.25)
+        if step == 3:
+            for c_ in ctxs:
+                c_.wf_set_hold(True, 1.5)
+        blk = x[pos:pos + npush]
+        pos += npush
+        ca.push(blk)
+        cb.push(blk)
+        if step in (1, 4, 5):  # observed only now and then: in between the trace roles of consecutive blocks run back to back
+            raw, zo, ix = ca.fft_read()
+            got = cb.result_wait(cb.ticket())
+            _compare({"vfo": {}, "raw": raw, "zoomed": zo, "index": ix}, got, True, "block %d" % (step + 1))
+            cb.result_release(cb.ticket())
+            la, ha = ca.wf_latest(W)
+            lb, hb = cb.wf_latest(W)
+            _same(la, lb, "latest FFT trace")
+            if step > 3:
+                _same(ha, hb, "hold trace")
+            s2, z2 = capi.design_waterfall_view(-2.0e6, 1.0e6, sr, N)
+            (ra, na), (rb, nb) = ca.wf_raster(s2, z2, 400, -100.0, 0.0), cb.wf_raster(s2, z2, 400, -100.0, 0.0)
+            assert na == nb and ra.shape == rb.shape and np.array_equal(ra, rb), "re-raster of the ring"
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] == 0 and "wf_ring" in st["roles"] and "wf_trace" in st["roles"], st
+    ca.close()
+    cb.close()
