@@ -242,7 +242,7 @@ def make_inputs(torch, np, device, base, push, seed, nvfo, min_bytes=384 << 20):
     return bufs, copies
 
 
-def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=1024, nblocks=3):
+def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=1024, nblocks=3, af=False):
     """Before anything is timed: the first `nblocks` input blocks through a PIPELINED context (result flags 7) and through an ORDINARY-pass
     context of the same configuration — every VFO block, raw dB line, zoomed line and palette index of every block must be bit-identical
     (the ordinary pass is what the parity tests compare with the oracle at every size; tests/test_bench_geometry_gpu.py compares the
@@ -259,6 +259,13 @@ def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=10
         info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo)
         if ref_block and ref_block < push:
             ctx.set_reference_block(ref_block)
+        af_keep = []
+        if af and nvfo:
+            from sdrplusplus_amd import radio
+            for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
+                a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
+                ctx.vfo_set_af(vid, a_, k_)
+                af_keep.append(k_)
         h = hashlib.sha256()
         counts = [0, 0]
         if pipelined:
@@ -283,7 +290,7 @@ def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=10
             for b in range(nblocks):
                 ctx.push_device(bufs[b % len(bufs)].data_ptr(), push)
                 for vid in info["vids"]:
-                    a = ctx.vfo_read(vid)
+                    a = ctx.vfo_af_read(vid) if (af and nvfo) else ctx.vfo_read(vid)
                     h.update(np.ascontiguousarray(a).tobytes())
                     counts[0] += len(a)
                 if ctx.fft_lines() > 0:
@@ -330,8 +337,10 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             af_keep.append(k_)
     pipelined = mode == "pipelined"
     checked = None
-    if check and pipelined and rank == 0 and not af and not exact_ssb:
-        checked = self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=data_width)
+    if check and pipelined and rank == 0 and not exact_ssb:
+        checked = self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=data_width, af=af)
+    if af and nvfo and pipelined:
+        lag = max(lag, 13)  # (the AF chain's five levels behind the demodulator: a block's lines and audio are complete 12 launches after its push)
     max_lines = (push + N - 1) // N + 1
     if pipelined:
         ctx.set_pipelined(True, 2)  # zoomed lines + palette indices of every block into page-locked result slots
@@ -660,6 +669,62 @@ def dry_launch(args, np, torch):
         raise SystemExit(1)
 
 
+def af_sr200_delivered(torch, capi, workloads, sr, nvfo):
+    """cfg 3 + the AF chain on every VFO at the reference's block size (sr / 200), pipelined: every block fetched from page-locked host memory,
+    every VFO's 48 kHz AF block + zoomed lines + palette indices delivered into page-locked result slots 13 blocks behind the push."""
+    import numpy as np
+
+    from sdrplusplus_amd import radio
+
+    B, lag = int(sr / 200), 13
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ctx = capi.Context(dev.index or 0, max_push=B)
+    info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=nvfo)
+    keep = []
+    for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
+        a_, k_ = radio.af_desc(r_, 48000.0, 50e-6, False)
+        ctx.vfo_set_af(vid, a_, k_)
+        keep.append(k_)
+    nb = 4
+    ptrs = []
+    for i in range(nb):
+        x = workloads.synth(3, B, seed=7 + i, nvfo=nvfo)
+        p = ctx.L.sdrpp_host_alloc(B * 8)
+        C.memmove(p, x.ctypes.data, B * 8)
+        ptrs.append(p)
+    ctx.set_pipelined(True, 3)
+    state = {"next": ctx.ticket() + 1}
+
+    def collect(upto):
+        while state["next"] <= upto:
+            t = C.c_uint64(state["next"])
+            r = capi.Result()
+            ctx._chk(ctx.L.sdrpp_result_wait(ctx.h, t, C.byref(r)))
+            ctx._chk(ctx.L.sdrpp_result_release(ctx.h, t))
+            state["next"] += 1
+
+    def step(i):
+        ctx.push_host_ptr_async(ptrs[i % nb], B)
+        collect(ctx.ticket() - lag)
+
+    for i in range(40):
+        step(i)
+    collect(ctx.ticket())
+    best = 0.0
+    npush = 400
+    for _trial in range(3):
+        t0 = time.perf_counter()
+        for i in range(npush):
+            step(i)
+        collect(ctx.ticket())
+        best = max(best, B * npush / (time.perf_counter() - t0) / 1e6)
+    st = ctx.pipeline_stats()
+    for p in ptrs:
+        ctx.L.sdrpp_host_free(p)
+    ctx.close()
+    return {"value": round(best, 1), "unit": "Msamples/s", "push": B, "result_lag_blocks": lag, "blocks_as_ordinary_passes": st["pass_blocks"], "depth_levels": st["depth"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -673,7 +738,7 @@ def main():
     ap.add_argument("--no-by-push", action="store_true")
     ap.add_argument("--no-self-check", action="store_true", help="skip the untimed comparison of the pipelined path with ordinary passes on the first blocks")
     ap.add_argument("--no-others", action="store_true", help="skip the ceiling and the cfg 2 / cfg 4 runs")
-    ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; runs as ordinary passes)")
+    ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; pipelined like everything else)")
     ap.add_argument("--fft-only", action="store_true", help="same as --cfg 2")
     ap.add_argument("--nco", choices=("closed", "ssb-exact"), default="closed", help="ssb-exact: SSB / DSB / raw channels on the reference's float rotator recursion (sdrpp_vfo_desc.nco_mode = 2); runs as ordinary passes")
     ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3 on one GPU, 5 on several)")
@@ -793,6 +858,12 @@ def main():
                 del inp
                 torch.cuda.empty_cache()
                 others["cfg%d" % oc] = {"workload": r1["workload"], "pipelined_stream_cap": compact(r1), "ceiling_2p24_ordinary": compact(r2)}
+                if oc == 2 and cfg == 3:  # the headline workload with the radio module's AF chain behind every VFO (radio_module.h:98-110: the AF resampler is always on)
+                    ra, inp = run_workload(torch, np, device, local, 3, STREAM_CAP, "pipelined", 60, 14, nvfo, af=True)
+                    del inp
+                    torch.cuda.empty_cache()
+                    others["cfg3_af"] = {"workload": ra["workload"] + " + AF chain (resampler to 48 kHz, 50 us de-emphasis) on every VFO", "pipelined_stream_cap": compact(ra),
+                                         "sr200_pinned_results_delivered": af_sr200_delivered(torch, capi, workloads, sr, nvfo)}
                 if oc == 4:  # the setting in which cfg 4's SSB channels follow the reference's own rotator (parity at arbitrary offsets): chain-bound
                     r3, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "ordinary", 12, 3, ocv, exact_ssb=True)
                     del inp

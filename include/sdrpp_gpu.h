@@ -323,18 +323,22 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * every sdrpp_push* launches ONE kernel ("tick") that runs the arrival of block n (its copy into device memory, the upload of its job
  * tables) next to the front end / FFT pass 1 of block n - 1, the first decimator / FFT pass 2 of block n - 2, ... — every stage of every
  * block exactly as in an ordinary pass (same kernels' bodies, same arithmetic: results are bit-identical), only not one after the
- * other.  A block's results are complete `depth` launches later (depth <= 10, typically 6): with the next blocks, or at once when the
+ * other.  A block's results are complete `depth` launches later (depth <= 18; 7 for a WFM bank + 65536-point FFT, 12 with the AF chain): with the next blocks, or at once when the
  * caller asks (sdrpp_pipeline_flush, sdrpp_result_wait, any observing call such as sdrpp_vfo_read / sdrpp_sync — these run the queued
  * stages without new input; sdrpp_fft_lines and sdrpp_vfo_out_count only report what the host already knows and do not).
  *   sdrpp_push_device        reads the caller's buffer IN PLACE one launch later at the earliest: it must stay valid until sdrpp_sync.
  *   sdrpp_push / _push_int16 copy into a page-locked staging slot (the caller's buffer is free on return), fetched by the next launch.
  *   sdrpp_push_pinned_async  page-locked memory is fetched by the launch itself; sdrpp_push_wait returns when all such fetches have run.
- * What cannot run that way (a pre-processing chain, the waterfall display state, the AF chain, the reference-rotator NCO, VFO groups
- * without the matrix-core front end, a retune hand-over in progress, more FFT frames than one scratch chunk) is processed as an ordinary
+ * The pre-processing chain (sdrpp_preproc_configure, default arithmetic), the radio's AF chain (sdrpp_vfo_set_af) and the waterfall display
+ * state (sdrpp_wf_configure) run that way too — their stages are further levels of the block.  What cannot (the reference-rotator NCO, the
+ * reference-order arithmetic of the pre-processing chain, VFO groups without the matrix-core front end, a retune hand-over in progress, more
+ * FFT frames than one scratch chunk, a block the pre-processing decimator swallows whole) is processed as an ordinary
  * pass behind everything queued: always correct, pipelined where possible — and its results are delivered into the block's result slot
  * like any other block's (by plain copies and a wait inside the push: the slow path).
  * result_flags (sdrpp_set_pipelined): which results every block also delivers into page-locked host memory, ready for sdrpp_result_wait
- * without any copy call: 1 = every VFO's output block (what sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines.
+ * without any copy call: 1 = every VFO's output block (the end of its chain: the AF chain's output where one is attached, else what
+ * sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines, 8 = the pre-processed IQ stream of the block (only with a
+ * pre-processing chain configured: without one it is the input block itself).
  * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push). */
 /* Host blocks in pipelined mode without the library's own copy: sdrpp_push_stage hands out the page-locked staging slot the next block is
  * fetched from (room for max_push samples); the host fills it — with several threads if it likes: a 400 KB memcpy is the largest single
@@ -358,6 +362,8 @@ typedef struct sdrpp_result {
     const float* zoomed;      /* [n_lines][data_width] (flag 2), else NULL                                                           */
     const int32_t* index;     /* [n_lines][data_width] (flag 2)                                                                      */
     const float* raw;         /* [n_lines][fft_size] (flag 4)                                                                        */
+    int n_iq;                 /* pre-processed IQ samples of the block (flag 8 with a pre-processing chain configured), else 0       */
+    const float* iq;          /* [n_iq] complex: what streams bound with bindIQStream receive (iq_frontend.cpp:32-39 -> Splitter)    */
 } sdrpp_result;
 int sdrpp_set_pipelined(sdrpp_ctx* ctx, int on, int result_flags);
 uint64_t sdrpp_ticket(sdrpp_ctx* ctx);                       /* ticket of the most recent push (pushes so far in pipelined mode)    */

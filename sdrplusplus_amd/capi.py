@@ -93,6 +93,8 @@ class Result(C.Structure):
         ("zoomed", c_float_p),
         ("index", c_int32_p),
         ("raw", c_float_p),
+        ("n_iq", C.c_int),
+        ("iq", c_float_p),
     ]
 
 
@@ -563,7 +565,8 @@ class Context:
 
     # pipelined execution (one launch per block, results a few blocks late)
     def set_pipelined(self, on, result_flags=0):
-        """result_flags: 1 = every VFO's output block, 2 = zoomed lines + palette indices, 4 = raw dB lines into page-locked result slots."""
+        """result_flags: 1 = every VFO's output block (AF output where a chain is attached), 2 = zoomed lines + palette indices, 4 = raw dB lines,
+        8 = the pre-processed IQ stream (with a pre-processing chain) into page-locked result slots."""
         self._chk(self.L.sdrpp_set_pipelined(self.h, int(bool(on)), int(result_flags)))
 
     def ticket(self):
@@ -579,7 +582,7 @@ class Context:
         """-> dict(vfo={id: [n, 2] float32}, zoomed, index, raw); arrays are copies unless copy=False (then valid until result_release)."""
         r = Result()
         self._chk(self.L.sdrpp_result_wait(self.h, int(ticket), C.byref(r)))
-        out = {"ticket": int(r.ticket), "vfo": {}, "n_lines": r.n_lines, "zoomed": None, "index": None, "raw": None}
+        out = {"ticket": int(r.ticket), "vfo": {}, "n_lines": r.n_lines, "zoomed": None, "index": None, "raw": None, "iq": None}
         cp = (lambda a: a.copy()) if copy else (lambda a: a)
         for i in range(r.n_vfo):
             n = r.counts[i]
@@ -594,6 +597,8 @@ class Context:
                 out["index"] = cp(np.ctypeslib.as_array(r.index, shape=(r.n_lines, r.data_width)))
             if r.raw:
                 out["raw"] = cp(np.ctypeslib.as_array(r.raw, shape=(r.n_lines, r.fft_size)))
+        if r.n_iq > 0 and r.iq:
+            out["iq"] = cp(np.ctypeslib.as_array(r.iq, shape=(2 * r.n_iq,)).view(np.complex64))
         return out
 
     def push_staged_from(self, iq):

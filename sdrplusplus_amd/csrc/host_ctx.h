@@ -260,7 +260,8 @@ struct sdrpp_ctx {
         std::vector<int64_t> offsets;
         int n_lines = 0;
         int fft_size = 0, data_width = 0, flags = 0;        // what the block was PLANNED with (the view / FFT size / result flags may change before it is collected)
-        size_t off_zoomed = 0, off_index = 0, off_raw = 0;  // byte offsets in the slot
+        size_t off_zoomed = 0, off_index = 0, off_raw = 0, off_iq = 0;  // byte offsets in the slot
+        int n_iq = 0;                                        // pre-processed IQ samples delivered (result flag 8)
     };
     bool pipelined = false;
     int res_flags = 0;                    // bit 0: gather every VFO's output, bit 1: zoomed lines + palette indices, bit 2: raw dB lines
@@ -312,6 +313,7 @@ struct sdrpp_ctx {
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses
+    int plan_lvl0 = 0;                    // levels the pre-processing chain of the block being planned takes in front of the FFT branch / VFO bank (pipelined mode; 0 in a pass)
     std::vector<RoleLaunch> emits;        // roles of the block being planned
     std::deque<std::vector<RoleLaunch>> tickq;  // [0]: roles of the next tick to launch, [1]: of the one after, ...
     uint64_t ticks = 0;                   // ticks launched so far

@@ -59,7 +59,7 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         r.e.gx = (g.nframes + fpw - 1) / fpw;
         r.e.p.fs = TickFS{ src, g, c->d_window, c->d_tw1, out };
         r.lds = tick_lds_fft_single(m, fpw);
-        r.level = 1;
+        r.level = 1 + c->plan_lvl0;
         c->emits.push_back(r);
         return SDRPP_OK;
     }
@@ -75,7 +75,7 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         r.e.p.p1 = TickP1{ src, g, c->d_window, c->d_tw1, c->d_twn, c->d_scratch, lg2, ntiles };
     }
     r.lds = tick_lds_fft_p1(lg1, p1_c[lg1 - 5]);
-    r.level = 1;
+    r.level = 1 + c->plan_lvl0;
     r.fam = F_FFT1;
     c->emits.push_back(r);
     if (lg2 == 12) {  // long transforms: 4096-point rows (dB in place), then the transpose into bin order one level later
@@ -85,7 +85,7 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         q.e.gx = g.nframes << lg1;
         q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, nullptr, nullptr, lg1, g.nframes };
         q.lds = tick_lds_fft_single(12, 1);
-        q.level = 2;
+        q.level = 2 + c->plan_lvl0;
         q.fam = F_FFT2;
         c->emits.push_back(q);
         sdrpp_ctx::RoleLaunch t{};
@@ -95,7 +95,7 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         t.e.aux = kZoomGrpLong;
         t.e.p.p2 = TickP2{ c->d_scratch, nullptr, out, grp, lg1, g.nframes };
         t.lds = (size_t)(SDRPP_FFT_TR_TILE + 256) * sizeof(float);
-        t.level = 3;
+        t.level = 3 + c->plan_lvl0;
         t.fam = F_FFT2;
         c->emits.push_back(t);
         return SDRPP_OK;
@@ -109,7 +109,7 @@ int plan_fft_roles(sdrpp_ctx* c, const IqSrc& src, const FrameGeom& g, float* ou
         q.e.p.p2 = TickP2{ c->d_scratch, c->d_tw2, out, grp, lg1, ntiles };
     }
     q.lds = tick_lds_fft_p2(lg2, pass2_rows(lg2));
-    q.level = 2;
+    q.level = 2 + c->plan_lvl0;
     q.fam = F_FFT2;
     c->emits.push_back(q);
     return SDRPP_OK;
@@ -336,7 +336,7 @@ int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
             g.first_start = c->fft_next * P - c->fft_pos;
             int rc = plan_fft_roles(c, src, g, c->d_lines, c->zoom_grp ? c->d_lines_grp : nullptr);
             if (rc) { return rc; }
-            const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
+            const int lines_level = c->plan_lvl0 + (c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3));
             if (c->data_width > 0) {
                 if ((size_t)nframes * (size_t)c->data_width > c->zoom_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: zoom capacity"); }
                 const float* zgrp = c->d_lines_grp;

@@ -12,7 +12,7 @@ struct PlanSnapshot {
     int64_t fft_pos, fft_next;
     int n_lines, iq_cur, wf_cur, wf_lines;
     bool wf_have;
-    int pre_soff[SDRPP_MAX_DECIM_STAGES], pre_state;
+    int pre_soff[SDRPP_MAX_DECIM_STAGES], pre_state, pre_raw_cur, pre_cur[SDRPP_MAX_DECIM_STAGES];
 };
 void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
     S.v.resize(c->vfos.size());
@@ -30,6 +30,8 @@ void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
     S.wf_cur = c->wf.cur; S.wf_lines = c->wf.lines; S.wf_have = c->wf.have_latest;
     for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { S.pre_soff[k] = c->pre.soff[k]; }
     S.pre_state = c->pre.state_cur;
+    S.pre_raw_cur = c->pre.raw.cur;
+    for (size_t k = 0; k < c->pre.st.size() && k < SDRPP_MAX_DECIM_STAGES; k++) { S.pre_cur[k] = c->pre.st[k].cur; }
 }
 // (retune records a plan has dropped stay dropped: they were out of every window's reach)
 void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
@@ -46,6 +48,8 @@ void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
     c->wf.cur = S.wf_cur; c->wf.lines = S.wf_lines; c->wf.have_latest = S.wf_have;
     for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { c->pre.soff[k] = S.pre_soff[k]; }
     c->pre.state_cur = S.pre_state;
+    c->pre.raw.cur = S.pre_raw_cur;
+    for (size_t k = 0; k < c->pre.st.size() && k < SDRPP_MAX_DECIM_STAGES; k++) { c->pre.st[k].cur = S.pre_cur[k]; }
 }
 
 void block_bounds(sdrpp_ctx* c, int64_t count, const std::vector<int>* push_ends) {
@@ -109,6 +113,7 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
     if (rc0) { return rc0; }
     PlanSnapshot snap;
     plan_snapshot(c, snap);
+    c->plan_lvl0 = 0;
     block_bounds(c, count, push_ends);
     if (c->pre.on) {
         rc0 = run_preproc(c, &d_iq, &count);

@@ -199,6 +199,7 @@ struct BankPlan {
     const IqSrc& src;
     const int n_in;
     const bool ticking;
+    const int L0;  // levels the pre-processing chain takes in front (pipelined mode): the front end runs at level L0 + 1
     static constexpr int carry_last = kLevels - 1;
     const std::vector<int>& fb;  // reference-block ends of this push (at least one entry: n_in)
     const bool blocks;
@@ -255,9 +256,9 @@ struct BankPlan {
     ToepPlan tplan[kToepLists][kLevels];
 
     BankPlan(sdrpp_ctx* c_, const IqSrc& src_, int64_t count, const CarryJob& iq_carry)
-        : c(c_), src(src_), n_in((int)count), ticking(c_->tick_planning), fb(c_->vfo_bounds), blocks(c_->vfo_bounds.size() > 1) {
+        : c(c_), src(src_), n_in((int)count), ticking(c_->tick_planning), L0(c_->tick_planning ? c_->plan_lvl0 : 0), fb(c_->vfo_bounds), blocks(c_->vfo_bounds.size() > 1) {
         for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
-        carry.add(ticking ? 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
+        carry.add(ticking ? L0 + 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
     }
     BankPlan(const BankPlan&) = delete;
     BankPlan& operator=(const BankPlan&) = delete;
@@ -265,7 +266,7 @@ struct BankPlan {
     // ---- one VFO's chain: stage by stage, a job per stage in the list of its kind and level ----
     int chain(Vfo& v) {
         Stream* cur = &v.st[(size_t)v.i_first];
-        int lvl = 1;  // level at which `cur` is written
+        int lvl = L0 + 1;  // level at which `cur` is written
         for (auto& s : v.st) { s.clevel = 0; }
         // reference-block ends carried stage by stage down to the demodulator's rate, for the block-dependent operations there
         // (AGC look-ahead, SSB rotator calls)
@@ -951,17 +952,17 @@ struct BankPlan {
                 const int small_limit = c->fcm16_max_tiles >= 0 ? c->fcm16_max_tiles : ((c->tick_planning && c->plan_block_from_host) ? 0 : 256);
                 if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= small_limit) {
                     if (getenv("SDRPP_TICK_DEBUG")) { fprintf(stderr, "[sdrpp] front end in its small-block shape: %d tiles x %zu jobs\n", max_tiles, fcm[k].jobs.size()); }
-                    emit(c, 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
+                    emit(c, L0 + 1, F_S1, TR_FCM16_132_4, max_tiles, (int)fcm[k].jobs.size(), (size_t)frontcm16_layout(132, 4).total * 4, d_fcm[k], &src);
                     continue;
                 }
-                emit(c, 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
+                emit(c, L0 + 1, F_S1, role, fcm[k].max_blocks, (int)fcm[k].jobs.size(), fcm[k].lds, d_fcm[k], &src);
             }
             if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
                 bool pf_ok = true;  // every window of the launch fits the register prefetch
                 for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
-                emit(c, 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
+                emit(c, L0 + 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
             }
-            if (!rot.empty() && max_rot > 0) { emit(c, 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
+            if (!rot.empty() && max_rot > 0) { emit(c, L0 + 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
             if (!retune.empty()) {
                 int mx = 0;
                 for (auto& r : retune) { mx = std::max(mx, r.nfix); }
@@ -1075,7 +1076,7 @@ struct BankPlan {
     void launch_carry(int l) {
             std::vector<CarryJob>& cj = carry.at[l];
             if (cj.empty()) { return; }
-            const bool has_iq = (l == (ticking ? 1 : carry_last));
+            const bool has_iq = (l == (ticking ? L0 + 1 : carry_last));
             const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
             int mx = 0;
             for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }

@@ -1693,7 +1693,7 @@ int64_t sdrpp_pending(sdrpp_ctx* c) { return c ? c->pending : SDRPP_ERR_INVALID;
 // ---- pipelined execution ----------------------------------------------------------------------------------------------------------------
 int sdrpp_set_pipelined(sdrpp_ctx* c, int on, int result_flags) {
     DeviceScope dev_scope_(c);
-    if (!c || result_flags < 0 || result_flags > 7) { return SDRPP_ERR_INVALID; }
+    if (!c || result_flags < 0 || result_flags > 15) { return SDRPP_ERR_INVALID; }
     if (on && c->deferred) { return fail(c, SDRPP_ERR_INVALID, "deferred and pipelined processing exclude each other"); }
     int rc = flush_pending(c);  // (drains the queue when the mode is being left)
     if (rc) { return rc; }
@@ -1754,6 +1754,8 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     out->zoomed = zo ? reinterpret_cast<const float*>(base + R->off_zoomed) : nullptr;
     out->index = zo ? reinterpret_cast<const int32_t*>(base + R->off_index) : nullptr;
     out->raw = (R->n_lines > 0 && (R->flags & 4)) ? reinterpret_cast<const float*>(base + R->off_raw) : nullptr;
+    out->n_iq = R->n_iq;
+    out->iq = R->n_iq > 0 ? reinterpret_cast<const float*>(base + R->off_iq) : nullptr;
     return SDRPP_OK;
 }
 int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {

@@ -226,7 +226,7 @@ int tick_drain(sdrpp_ctx* c) {
 // Can this context's blocks run as ticks at all?  (What can only be seen while planning — a VFO group too small for the matrix front end,
 // a filter without the matrix form, more frames than one scratch chunk — aborts the plan instead.)
 bool tick_eligible(sdrpp_ctx* c) {
-    if (c->pre.on || c->deferred) { return false; }
+    if ((c->pre.on && c->pre.ref_order) || c->deferred) { return false; }  // (the reference-order arithmetic of the pre-processing chain has no roles)
     for (auto& kv : c->vfos) {
         const Vfo& v = *kv.second;
         if (v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
@@ -255,6 +255,11 @@ size_t tick_results_need(sdrpp_ctx* c) {
             if (v.i_out >= 0) { cap = std::max(cap, v.st[(size_t)v.i_out].cap); }
             need += ((cap + 16) * 8 + 15) & ~(size_t)15;
         }
+    }
+    if ((c->res_flags & 8) && c->pre.on) {
+        size_t cap = c->pre.out.base ? c->pre.out.cap : 0;
+        for (auto& st : c->pre.st) { cap = std::max(cap, st.cap); }
+        need += ((cap + 16) * 8 + 15) & ~(size_t)15;
     }
     if (c->fft_on) {
         if ((c->res_flags & 2) && c->data_width > 0) { need += 2 * ((c->lines_cap * (size_t)c->data_width * 4 + 15) & ~(size_t)15); }
@@ -324,9 +329,16 @@ int tick_results_plan(sdrpp_ctx* c) {
             off += (bytes + 15) & ~(size_t)15;
         }
     }
+    if ((c->res_flags & 8) && c->pre.on && c->pre.last_n > 0) {  // the pre-processed stream of the block (what streams bound with bindIQStream receive)
+        const size_t bytes = (size_t)c->pre.last_n * 8;
+        R.off_iq = off;
+        R.n_iq = c->pre.last_n;
+        jobs.add(c->plan_lvl0 + 1, CopyJob{ c->pre.last, base + off, (long long)bytes, 0x100, 0 });
+        off += (bytes + 15) & ~(size_t)15;
+    }
     R.n_lines = c->fft_on ? c->n_lines : 0;
     if (R.n_lines > 0) {
-        const int lines_level = c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3);
+        const int lines_level = c->plan_lvl0 + (c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3));
         if ((c->res_flags & 2) && c->data_width > 0) {
             const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
             R.off_zoomed = off;
@@ -385,6 +397,14 @@ int tick_results_direct(sdrpp_ctx* c) {
             off += (bytes + 15) & ~(size_t)15;
         }
     }
+    if ((c->res_flags & 8) && c->pre.on && c->pre.last_n > 0) {
+        const size_t bytes = (size_t)c->pre.last_n * 8;
+        if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
+        R.off_iq = off;
+        R.n_iq = c->pre.last_n;
+        HIPCHK(c, hipMemcpyAsync(base + off, c->pre.last, bytes, hipMemcpyDeviceToHost, c->stream));
+        off += (bytes + 15) & ~(size_t)15;
+    }
     R.n_lines = c->fft_on ? c->n_lines : 0;
     if (R.n_lines > 0) {
         if ((c->res_flags & 2) && c->data_width > 0) {
@@ -431,6 +451,8 @@ int stage_pending_wait(sdrpp_ctx* c) {
 // One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
 int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
     if (count == 0) { return SDRPP_OK; }
+    const float* const d_iq_raw = d_iq;  // (planning a pre-processing chain moves d_iq / count on to the pre-processed stream)
+    const int64_t count_raw = count;
     c->plan_block_from_host = land != nullptr && land->bytes > 0;
     bool as_tick = tick_eligible(c);
     if (as_tick) {  // rings of the per-block buffers, result slots (allocated on first use / after a change of the configuration)
@@ -440,6 +462,18 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
                     int rc = stream_ring_ensure(c, st);
                     if (rc) { return rc; }
                 }
+            }
+        }
+        if (c->pre.on) {  // the pre-processing chain's stage outputs are per-block buffers too
+            for (auto& st : c->pre.st) {
+                if (st.n_extra < kRing - 1 && st.base) {
+                    int rc = stream_ring_ensure(c, st);
+                    if (rc) { return rc; }
+                }
+            }
+            if (c->pre.out.base && c->pre.out.n_extra < kRing - 1) {
+                int rc = stream_ring_ensure(c, c->pre.out);
+                if (rc) { return rc; }
             }
         }
         int rc = fft_ring_ensure(c);
@@ -462,13 +496,22 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             for (auto& s : kv.second->st) { stream_rotate(s); }
         }
         fft_ring_rotate(c);
+        if (c->pre.on) {
+            for (auto& st : c->pre.st) { stream_rotate(st); }
+            stream_rotate(c->pre.out);
+        }
         c->tick_planning = true;
         c->tick_abort = false;
         c->emits.clear();
         c->plan_top = 2;
+        c->plan_lvl0 = 0;
         block_bounds(c, count, nullptr);
-        rc = ensure_iq_hist(c, iq_hist_need(c));
-        if (!rc) {
+        if (c->pre.on) {  // levels 1 .. plan_lvl0 of the block: from here on `d_iq` / `count` are the pre-processed stream
+            rc = run_preproc(c, &d_iq, &count);
+            if (!rc && count == 0) { c->tick_abort = true; }  // (the decimator swallowed the whole block: an ordinary pass sorts that out)
+        }
+        if (!rc && !c->tick_abort) { rc = ensure_iq_hist(c, iq_hist_need(c)); }
+        if (!rc && !c->tick_abort) {
             IqSrc src{ (const float2*)d_iq, (const float2*)c->iq_hist[c->iq_cur], c->iq_hist_cap, (long long)count };
             rc = do_fft(c, src, count);
             if (!rc && !c->tick_abort) {
@@ -477,7 +520,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
                     std::vector<CarryJob> carry{ iqc };
                     CarryJob* d_carry = arena_push(c, carry);
                     if (!d_carry) { rc = fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-                    else { emit(c, 1, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 1023) / 1024, 2048)), 1, 0, d_carry); }
+                    else { emit(c, 1 + c->plan_lvl0, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 1023) / 1024, 2048)), 1, 0, d_carry); }
                 }
                 else { rc = do_vfos_plan(c, src, count, iqc); }
             }
@@ -509,7 +552,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         if (!rc) { rc = tick_launch(c, land); }
         if (!rc) { rc = tick_drain(c); }
         if (land) { c->land_tick = c->ticks; }
-        if (!rc) { rc = push_common(c, d_iq, count, nullptr); }
+        if (!rc) { rc = push_common(c, d_iq_raw, count_raw, nullptr); }
         // its results are where an ordinary pass leaves them (device buffers, readable after a synchronisation) and — with result flags —
         // also in the block's result slot like every other block's
         if (!rc && c->res_flags) { rc = tick_results_direct(c); }

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -224,6 +225,7 @@ public:
             pendingTickets.erase(pendingTickets.begin());
             if (startDelivery(t) < 0 || finishDelivery() < 0) { rc = -1; }
         }
+        tapPending.clear();
         return rc;
     }
     // iq_frontend.cpp:200-202 -> SampleFrameBuffer::flush (frame_buffer.h:46-49): drop what is queued
@@ -373,7 +375,11 @@ public:
         if (!_buffering) {
             drainControl();
             if (_pipelining && pipelineEligible()) {
+                if (pipeOn && pipeFlags != pipelineFlags() && leavePipelined() < 0) { return -1; }  // (a stream was bound / a chain configured since)
                 if (!pipeOn && enterPipelined() < 0) { return -1; }
+                if (!iqStreams.empty() && !(pipeFlags & 8)) {  // bound streams, no chain in front: they receive this very block (Splitter::run) — when its turn comes
+                    tapPending.emplace_back(0, std::vector<dsp::complex_t>(_in->readBuf, _in->readBuf + count));
+                }
                 // The block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
                 // 10 MS/s) — and is fetched from there by the launch.  Round 3b, in the order that frees the source soonest: the copy starts at
                 // once on threads of its own (`stagers`), the one that finishes last frees the stream buffer; meanwhile this thread joins the
@@ -419,8 +425,13 @@ public:
                     return -1;
                 }
                 pendingTickets.push_back(sdrpp_ticket(ctx));
+                if (!tapPending.empty() && tapPending.back().first == 0) { tapPending.back().first = sdrpp_ticket(ctx); }
                 SDRPP_PIPE_TICK(2)
-                if ((int)pendingTickets.size() > _pipeLag) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
+                // (a block's results are complete `depth` launches after its push — 7 levels for a WFM bank + FFT, 12 with the AF chain, 3 more behind a
+                // pre-processing chain: asking for them sooner makes the library run the missing stages as launches without new input)
+                int64_t pst[SDRPP_PIPELINE_STATS_HEAD] = {};
+                const int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(14, std::max(_pipeLag, (int)pst[4])) : _pipeLag;
+                if ((int)pendingTickets.size() > lagNow) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
                     const uint64_t t = pendingTickets.front();
                     pendingTickets.erase(pendingTickets.begin());
                     if (startDelivery(t) < 0) { return -1; }
@@ -579,17 +590,20 @@ private:
     }
 
     // ---- pipelined bypass (setPipelining) ----
-    bool pipelineEligible() {
-        if (!iqStreams.empty() || _decimRatio > 1 || _dcBlocking || _invertIQ) { return false; }
-        for (auto& kv : vfos) {
-            if (kv.second->afOn && kv.second->demod != Demod::RAW) { return false; }
-        }
-        return true;
+    // (round 4: the pre-processing chain, the radio's AF chain and bound IQ streams no longer keep a front end out of pipelined mode — their
+    // stages are levels of the block on the device like everything else, and what they deliver comes out of the block's result slot)
+    bool pipelineEligible() { return true; }
+    // what every block delivers into its result slot: every VFO's block (the AF chain's output where one is attached), the raw dB lines, and —
+    // with streams bound AND a pre-processing chain in front — the pre-processed IQ (without a chain the bound streams get the input block itself)
+    int pipelineFlags() const {
+        const bool pre = _decimRatio > 1 || _dcBlocking || _invertIQ;
+        return 1 | 4 | ((pre && !iqStreams.empty()) ? 8 : 0);
     }
     int enterPipelined() {
         if (sdrpp_sync(ctx)) { return -1; }  // (nothing is staged in bypass mode; a deferred pass left over from buffered mode runs here)
         sdrpp_set_deferred(ctx, 0);
-        if (sdrpp_set_pipelined(ctx, 1, 1 | 4)) {  // every VFO's block + the raw dB lines of every block into page-locked result slots
+        pipeFlags = pipelineFlags();
+        if (sdrpp_set_pipelined(ctx, 1, pipeFlags)) {
             fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] pipelined mode refused: %s\n", sdrpp_last_error(ctx));
             sdrpp_set_deferred(ctx, 1);
             _pipelining = false;
@@ -631,6 +645,30 @@ private:
             });
         }
         deliveryFailed = false;
+        // Splitter::run for the streams bound with bindIQStream: the pre-processed block out of the result slot, or the input block kept at the push
+        while (!tapPending.empty() && tapPending.front().first < ticket) { tapPending.pop_front(); }  // (blocks that were never delivered)
+        if (!iqStreams.empty()) {
+            const dsp::complex_t* src = nullptr;
+            int n = 0;
+            if (r.n_iq > 0 && r.iq) {
+                src = (const dsp::complex_t*)r.iq;
+                n = r.n_iq;
+            }
+            else if (!tapPending.empty() && tapPending.front().first == ticket) {
+                inflightTap.swap(tapPending.front().second);
+                tapPending.pop_front();
+                src = inflightTap.data();
+                n = (int)inflightTap.size();
+            }
+            if (src && n > 0) {
+                jobs.emplace_back([this, src, n]() {
+                    for (auto* st : iqStreams) {
+                        memcpy(st->writeBuf, src, (size_t)n * sizeof(dsp::complex_t));
+                        if (!st->swap(n)) { deliveryFailed = true; }
+                    }
+                });
+            }
+        }
         std::vector<std::pair<RxVFO*, int>>& order = inflightOrder;
         order.clear();
         for (int k = 0; k < r.n_vfo; k++) {
@@ -969,6 +1007,9 @@ private:
     int frameSizes[FRAME_SLOTS] = {};
     int frameWrite = 0, frameRead = 0;
     std::vector<dsp::complex_t> tapCopy;  // the block the bound IQ consumers are about to receive
+    std::deque<std::pair<uint64_t, std::vector<dsp::complex_t>>> tapPending;  // pipelined: (ticket, input block) kept for the bound streams until the block's turn
+    std::vector<dsp::complex_t> inflightTap;
+    int pipeFlags = 0;                      // result flags the context was put into pipelined mode with
     std::mutex ctlMtx;
     std::vector<std::function<void()>> ctlOps;
     std::mutex frameMtx;

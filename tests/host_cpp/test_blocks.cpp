@@ -50,8 +50,8 @@ int main(int argc, char** argv) {
     const double fftRate = atof(argv[6]);
     const std::string outdir = argv[7];
     const bool buffered = argc > 8 && std::string(argv[8]) == "buffered";
-    // "pipelined": the bypass path as one launch per block (IQFrontEnd::setPipelining), results handed out four blocks late and the tail by
-    // drainPipeline() after stop().  No IQ tap and no AF chain in this mode (they fall back to one pass per block, which "bypass" covers).
+    // "pipelined": the bypass path as one launch per block (IQFrontEnd::setPipelining), results handed out a few blocks late and the tail by
+    // drainPipeline() after stop() — with the IQ tap bound and the AF chain attached like in the other modes (round 4: both stay pipelined).
     const bool pipelined = argc > 8 && std::string(argv[8]) == "pipelined";
     const int drainMs = argc > 9 ? atoi(argv[9]) : (buffered ? 1500 : 300);  // time to let handed-over blocks drain (the CPU emulator needs seconds)
     const size_t nsamp = iq.size() / 2;
@@ -87,8 +87,8 @@ int main(int argc, char** argv) {
     // a consumer of the (pre-processed) wideband IQ, like the recorder's baseband tap (recorder/src/main.cpp:209,229)
     dsp::stream<dsp::complex_t> iqTap;
     if (pipelined) { fe.setPipelining(true, 4); }
-    else { fe.bindIQStream(&iqTap); }
-    if (!pipelined) {
+    fe.bindIQStream(&iqTap);
+    {
         bool threw = false;
         try { fe.bindIQStream(&iqTap); } catch (const std::runtime_error&) { threw = true; }  // Splitter::bindStream, splitter.h:18-20
         dsp::stream<dsp::complex_t> other;
@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
     sdrpp_gpu::RxVFO* wfmAf = fe.addVFO("radio_af", 250000.0, 150000.0, 300000.0);
     if (!wfmAf) { return 1; }
     wfmAf->attachDemod(sdrpp_gpu::Demod::WFM);
-    if (!pipelined) { wfmAf->attachAF(48000.0, 50e-6, false); }
+    wfmAf->attachAF(48000.0, 50e-6, false);
     if (fe.addVFO("raw", 1.0, 1.0, 0.0) != nullptr) { fprintf(stderr, "duplicate VFO name accepted\n"); return 1; }
     fe.removeVFO("nope");  // logs, like the reference
 
@@ -148,7 +148,7 @@ int main(int argc, char** argv) {
         if (fe.drainPipeline() < 0) { fprintf(stderr, "drainPipeline\n"); return 1; }
         std::this_thread::sleep_for(std::chrono::milliseconds(drainMs));
     }
-    else { fe.unbindIQStream(&iqTap); }
+    fe.unbindIQStream(&iqTap);
     iqTap.stopReader();
     raw->out.stopReader();
     wfm->audio.stopReader();

@@ -383,3 +383,59 @@ def test_pipelined_equals_ordinary_with_waterfall_state(backend):
     assert st["pass_blocks"] == 0 and "wf_ring" in st["roles"] and "wf_trace" in st["roles"], st
     ca.close()
     cb.close()
+
+
+@pytest.mark.parametrize("ratio,dc,conj", [(2, True, True), (4, False, False), (1, False, True), (1, True, False)])
+def test_pipelined_equals_ordinary_with_preproc_chain(backend, ratio, dc, conj):
+    """IQFrontEnd's pre-processing chain (setDecimation / setDCBlocking / setInvertIQ, iq_frontend.cpp:32-39 and :105-130) in front of a
+    pipelined bank: its decimator stages, the DC blocker's two passes and the conjugate are the first levels of every block, the FFT branch
+    and the VFO bank start that many ticks later.  Pre-processed stream (result flag 8: what bindIQStream consumers receive), VFO blocks and
+    lines bit-identical to ordinary passes; no block falls back except one the decimator swallows whole."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    nv = 20 if backend == "gpu" else 17
+    eff = 10e6
+    scale = 1 if backend == "gpu" else 2
+    pushes = [n * ratio // scale for n in (50000, 30011, 50000, 20000, 50000)] + [ratio - 1 if ratio > 1 else 7, 50000 * ratio // scale]
+    x0 = workloads.synth(3, (sum(pushes) + ratio - 1) // ratio + 8, seed=17, nvfo=nv)
+    x = np.repeat(x0, ratio)[:sum(pushes)].astype(np.complex64) + np.complex64(0.05 + 0.03j)  # (a crude oversampled copy: content does not matter here)
+    if conj:
+        x = np.conj(x)
+    ctxs = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=max(pushes))
+        stages = radio.plans().stages(ratio) if ratio > 1 else []
+        ctx.preproc_configure(stages, 50.0 / eff if dc else 0.0, conj)
+        ctx.fft_configure(4096, 4096, 0, capi.design_fft_window(2, 4096))
+        start, size = capi.design_waterfall_view(0.0, eff, eff, 4096)
+        ctx.fft_set_view(start, size, 600, -120.0, 0.0)
+        vids = []
+        for mode, if_rate, bw, centre, _ in workloads.vfo_plan(3, nv):
+            d, keep = radio.vfo_desc(eff, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        if pipelined:
+            ctx.set_pipelined(True, 15)
+        ctxs.append((ctx, vids))
+    (ca, va), (cb, vb) = ctxs
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        r = _ordinary_results(ca, va, blk, True)
+        r["iq"] = ca.preproc_read().copy()
+        refs.append(r)
+        cb.push(blk)
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        if len(ref["iq"]):
+            assert got["iq"] is not None and got["iq"].shape == ref["iq"].shape, (t, None if got["iq"] is None else got["iq"].shape, ref["iq"].shape)
+            _same(ref["iq"].view(np.float32), got["iq"].view(np.float32), "block %d pre-processed IQ" % t)
+        cb.result_release(t)
+    _same(ca.preproc_read().view(np.float32), cb.preproc_read().view(np.float32), "last block through sdrpp_preproc_read")
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] <= (1 if ratio > 1 else 0) and st["tick_blocks"] >= len(pushes) - 1, st
+    if dc:
+        assert "dc_p0" in st["roles"] and "dc_p1" in st["roles"], st
+    ca.close()
+    cb.close()
