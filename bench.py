@@ -447,7 +447,9 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             "kernel_ms_per_step": {k: round(v, 5) for k, v in sorted(kernel_ms_all.items(), key=lambda kv: -kv[1])},
             "realtime_factor": round(per_gpu / sr, 1), "sr": sr, "fft": N, "nvfo": nvfo,
             "nco": ("SSB / DSB / raw channels: the reference's float rotator recursion on the device (nco_mode 2: every channel inside the north-star tolerance against the "
-                    "compiled reference at arbitrary offsets); FM / AM channels closed form") if exact_ssb else "closed form (FM / AM exact to the tolerance; SSB / raw IF differ from the reference by ITS rotator's rounding drift, DESIGN.md 5)",
+                    "compiled reference at arbitrary offsets); FM / AM channels closed form") if exact_ssb else ("closed form: FM / AM inside the tolerance for any run length; SSB / DSB audio and the raw IF differ from the reference by ITS rotator's rounding drift — "
+                                                         "+1.1e-6 .. 5.6e-6 (audio) / 1.8e-6 .. 9.1e-6 (IF) relative per 10^5 input samples at cfg 4, i.e. inside 1e-5 for the first ~1.8e5 .. 9e5 input samples after a VFO (re)starts, "
+                                                         "3e-7 for any length against the reference with an exact NCO (include/sdrpp_gpu.h, DESIGN.md 5); --nco ssb-exact runs those channels on the reference's own recursion"),
         }
         if pipelined:
             out["results_delivered"] = "zoomed lines + palette indices of every block in page-locked host memory (result flag 2), batches of %d blocks copied to the device%s; VFO outputs stay on the device" % (

@@ -87,12 +87,24 @@ void sdrpp_design_waterfall_view(double view_offset, double view_bandwidth, doub
 int sdrpp_set_reference_block(sdrpp_ctx* ctx, int ref_block);
 /* NCO of the frequency translations (RxVFO's xlator, SSB's second xlator).
  *   SDRPP_NCO_CLOSED_FORM (default): phase = arg(phaseDelta) * n evaluated in float64, folded into the first filter's taps; exact
- *     frequency, no drift.  FM / AM outputs agree with the reference to ~1e-7; the raw IF and an SSB product detector additionally see
- *     the reference rotator's own rounding drift (1e-10 .. 2e-9 rad per sample, linear in time), which this mode does not have.
+ *     frequency, no drift.  FM / AM outputs agree with the reference to ~1e-7 for any run length; the raw IF and an SSB product detector
+ *     additionally see the reference rotator's own rounding drift (1e-10 .. 2e-9 rad per sample, linear in time), which this mode does not have.
+ *     VALIDITY WINDOW against the reference for SSB / DSB audio and the raw IF (measured at BASELINE cfg 4, 61.44 MS/s, 43 USB channels,
+ *     DESIGN.md 5): the difference grows by 1.1e-6 .. 5.6e-6 (audio, relative RMS) resp. 1.8e-6 .. 9.1e-6 (IF) per 10^5 INPUT samples since the
+ *     VFO was added / reset, i.e. it is inside BASELINE.json's 1e-5 for the first ~1.8e5 (worst channel) .. 9e5 (best) input samples — 3 to 15 ms
+ *     of a 61.44 MS/s stream — and outside it from then on; against the reference with its rotator replaced by an exact NCO it stays at
+ *     3e-7 for any length.  A host that needs SSB / raw-IF parity with the reference's OWN phase sequence beyond that window selects
+ *     SDRPP_NCO_REFERENCE_ROTATOR for those channels (sdrpp_vfo_desc.nco_mode = 2: per VFO, the FM / AM channels of the bank stay on the fast path).
  *   SDRPP_NCO_REFERENCE_ROTATOR: the reference's float recursion itself (VOLK generic rotator2: phase *= phaseDelta in float, renormalised
  *     every 512 samples and at the end of every block), one lane per VFO at the full input rate, then the plan's stages as plain FIRs.
  *     Reproduces the reference's phase sequence — IF and SSB parity ~1e-7 for any run length — at a few times real time instead of
  *     thousands: a parity mode.  Set sdrpp_set_reference_block as well: the renormalisation points are the reference's block ends.
+ *     Why there is no third, "re-seeded" mode (closed form inside a reference block, phase re-seeded from the recursion's value at every block
+ *     end): the block-end phases ARE the recursion — N dependent float multiply-adds per block and VFO whatever is done with the samples, and a
+ *     dependent packed multiply + add is 21 cycles on this SIMD (tools/probe/chain_latency_probe.hip), i.e. <= 115 MS/s for ANY scheme that
+ *     follows the reference's phase sequence; the reference-rotator kernel runs at 26 cycles per sample (cfg 4: 67-69 MS/s with every SSB channel
+ *     exact), so the re-seeded form could gain at most 1.2x while giving up exactness inside the block (its error would saw-tooth to ~1.7e-5 per
+ *     307 200-sample block unless the drift were interpolated as well).  Not built; the numbers are in DESIGN.md 5.
  * Can only be changed while the context has no VFO. */
 #define SDRPP_NCO_CLOSED_FORM 0
 #define SDRPP_NCO_REFERENCE_ROTATOR 1

@@ -1031,7 +1031,15 @@ struct BankPlan {
             }
             if (max_nout == 0) { return SDRPP_OK; }
             if (fits) {
-                emit(c, level, fam, TR_POLYC, max_tiles, (int)jobs.size(), (size_t)cap2 * sizeof(float2), d_jobs, nullptr, cap2);
+                // phase groups (a tick: always — a role's workgroup life is what the tick waits for): two phases per wavefront when the launch is a
+                // handful of tiles (sr/200 blocks: 13 us -> 9 us of workgroup life, 767 -> 2 081 MS/s with the AF chain on 32 VFOs), six when there are
+                // many (every group loads the tile's whole window again: 1 152 workgroups of 13.5 us were a third of a 10^6-sample tick's slot time)
+                const int ppw = (long long)max_tiles * (long long)jobs.size() >= 64 ? 6 : 2;
+                int G = 1;
+                for (auto& jb : jobs) { G = std::max(G, ((jb.interp + 3) / 4 + ppw - 1) / ppw); }
+                if (!ticking && (long long)max_tiles * (long long)jobs.size() >= 1024) { G = 1; }
+                G = std::max(1, std::min(G, 128));
+                emit(c, level, fam, TR_POLYC, max_tiles * G, (int)jobs.size(), (size_t)cap2 * sizeof(float2), d_jobs, nullptr, cap2 | ((G - 1) << 24));
                 return SDRPP_OK;
             }
             size_t lds = 0;

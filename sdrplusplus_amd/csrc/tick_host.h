@@ -83,6 +83,9 @@ inline int tick_role_weight(int role, bool crowded) {
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
     case TR_SEQ: return 85;
     case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
+    case TR_POLYC: return 55;
+    case TR_DEEMP_P1: case TR_DC_P1: return 52;
+    case TR_DEEMP_P0: case TR_DC_P0: return 48;
     case TR_PIPE: return 80;  // the longest-lived workgroups behind the front end: a whole segment of four stages
     case TR_TOEP_Q: return 65;
     case TR_TOEP_C: case TR_TOEP_R: case TR_FFT_S10: case TR_FFT_S11: case TR_FFT_S12: return 60;

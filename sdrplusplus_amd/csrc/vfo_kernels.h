@@ -2388,19 +2388,24 @@ __global__ __launch_bounds__(256) void iq_conjugate_kernel(const float2* __restr
 // CT * M inputs); lane j owns cycle j, a wavefront walks over phases r = w, w + 4, ...: within a wavefront the phase — hence
 // the tap row — is uniform (scalar loads) and all L phases reuse ONE LDS window of CT * M + tpp input samples.
 // =====================================================================================================================
-__device__ __forceinline__ void vfo_polyc_body(const KIdx bid, float2* xsc, const PolyJob* __restrict__ jobs, int cap2) {
+// `cap2g` = LDS window in float2 (low 24 bits) | phase groups G - 1 (bits 24 ..): a tile's L phases can be dealt out over G workgroups (each loads
+// the tile's window and walks phases wv + 4 g, wv + 4 g + 4 G, ...) — what a wavefront does one after the other is L / 4 phases x tpp taps, the
+// whole life of the workgroup, and at the reference's block size a block's AF output is 2-3 cycles: 3 busy lanes walking 24 phases x 99 taps.
+__device__ __forceinline__ void vfo_polyc_body(const KIdx bid, float2* xsc, const PolyJob* __restrict__ jobs, int cap2g) {
     const PolyJob& job = jobs[bid.y];
     const int L = job.interp, M = job.decim, tpp = job.tpp;
+    const int cap2 = cap2g & 0xffffff, G = (cap2g >> 24) + 1;
     int CT = (cap2 - tpp - M) / M;  // cycles per tile: window (CT - 1) * M + o_max + tpp <= cap2, o_max <= M
     if (CT > 64) { CT = 64; }
-    const int c0 = bid.x * CT;
+    const int g = bid.x % G;
+    const int c0 = (bid.x / G) * CT;
     if ((long long)c0 * L >= job.nout) { return; }
     const int first = job.off0 + c0 * M - (tpp - 1);
     const int nwin = CT * M + M + tpp;
     for (int s = threadIdx.x; s < nwin; s += 256) { xsc[s] = stream_load2(job.in, first + s); }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int r = wv; r < L; r += 4) {
+    for (int r = wv + 4 * g; r < L; r += 4 * G) {
         const int A = job.phase0 + r * M, ph = A % L, o = A / L;
         const UniformF32 taps = as_uniform(job.bank + (size_t)ph * tpp);
         const float2* xp = xsc + lane * M + o;

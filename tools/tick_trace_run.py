@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run N pipelined blocks of a configuration on the `make ticktrace` build and dump the per-workgroup timeline of the tick kernel.
-   tools/tick_trace_run.py <cfg> <block> <nblocks> <dump.bin>"""
+   tools/tick_trace_run.py <cfg> <block> <nblocks> <dump.bin> [host|af]   (af: the radio's AF chain behind every VFO)"""
 import os
 import sys
 
@@ -20,7 +20,14 @@ if os.path.exists(path):
     os.remove(path)
 nvfo = workloads.CFG[cfg]["nvfo"]
 ctx = capi.Context(0, max_push=B)
-workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo or None)
+info = workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo or None)
+if len(sys.argv) > 5 and sys.argv[5] == "af":
+    from sdrplusplus_amd import radio
+    _keep = []
+    for vid, (m_, r_, _b, _c, _x) in zip(info["vids"], info["plan"]):
+        a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
+        ctx.vfo_set_af(vid, a_, k_)
+        _keep.append(k_)
 xd = [torch.from_numpy(workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None).view(np.float32)).to("cuda") for i in range(4)]
 ctx.set_pipelined(True, 0)
 if from_host:
