@@ -286,6 +286,7 @@ struct sdrpp_ctx {
     // long dependent walk (10^6-sample blocks: tick 82.6 us with 256 workgroups, 70.8 with 512, against 50.0 for the four roles; sr/200 blocks
     // 32 us against 12), and blocks shorter than a filter history per VFO (cfg 4's NFM channels at sr/200) would fall back to ordinary passes.
     // Off by default; SDRPP_GPU_TICK_PIPE=1 for measurements (tests/test_pipelined.py keeps it bit-identical).
+    int tick_land_blocks = getenv("SDRPP_GPU_TICK_LAND_BLOCKS") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_LAND_BLOCKS"))) : 64;  // workgroups of a tick's landing copy (host-fed blocks), at most
     int tick_lds_cap = 24 * 1024;       // LDS window of the many-phase resampler as a role of a tick (launch_polyc)
     int tick_lds_cap_fir = 40 * 1024;   // ... of the register-blocked FIR roles (launch_fir)
     bool tick_pipe = getenv("SDRPP_GPU_TICK_PIPE") ? atoi(getenv("SDRPP_GPU_TICK_PIPE")) != 0 : false;

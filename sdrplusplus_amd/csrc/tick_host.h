@@ -136,7 +136,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     TickL0 l0{};
     if (land && land->bytes > 0) {
         l0.job[0] = *land;
-        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 8191) / 8192, 64));
+        l0.blocks[0] = (int)std::max<long long>(1, std::min<long long>((land->bytes + 8191) / 8192, c->tick_land_blocks));
     }
     if (c->arena_off > 0) {
         l0.job[1] = CopyJob{ c->arena_host_dev[c->arena_slot], c->arena_dev, (long long)((c->arena_off + 15) & ~(size_t)15), 0, 0 };

@@ -54,7 +54,19 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
             const uint4* s = reinterpret_cast<const uint4*>(job.src);
             uint4* d = reinterpret_cast<uint4*>(job.dst);
             const long long n16 = job.bytes / 16;
-            for (long long i = tid; i < n16; i += nth) { d[i] = s[i]; }
+            // eight loads in flight per work-item before the first store: a copy out of page-locked host memory is a round trip over the bus per
+            // load, and FEW workgroups with many loads each disturb fewer CUs than many with one (whoever shares a CU with such a
+            // workgroup waits behind its reads)
+            constexpr int U = 8;
+            long long i = tid;
+            for (; i + (U - 1) * nth < n16; i += U * nth) {
+                uint4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { v[u] = s[i + u * nth]; }
+#pragma unroll
+                for (int u = 0; u < U; u++) { d[i + u * nth] = v[u]; }
+            }
+            for (; i < n16; i += nth) { d[i] = s[i]; }
             done = n16 * 4;
         }
         const unsigned* s = reinterpret_cast<const unsigned*>(job.src);
