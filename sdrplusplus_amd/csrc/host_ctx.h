@@ -286,6 +286,15 @@ struct sdrpp_ctx {
     // long dependent walk (10^6-sample blocks: tick 82.6 us with 256 workgroups, 70.8 with 512, against 50.0 for the four roles; sr/200 blocks
     // 32 us against 12), and blocks shorter than a filter history per VFO (cfg 4's NFM channels at sr/200) would fall back to ordinary passes.
     // Off by default; SDRPP_GPU_TICK_PIPE=1 for measurements (tests/test_pipelined.py keeps it bit-identical).
+    // Large blocks in pipelined mode: the ratio-32 front end in its 16 x 16 x 4 shape walking its tiles (vfo_frontcm16w_body: 84 registers, 31 KB of
+    // LDS), so that the whole tick runs in the FOUR-wavefronts-per-SIMD build of the tick kernel (tick_kernel<2>) instead of the three the
+    // 32 x 32 x 2 front end's 168 registers / 41 KB allow.  Built to test the reading that the SIMDs idle behind latency with three wavefronts
+    // each — and measured (10^6-sample blocks, 200 steps, profiles/r04n_*, r04o_*): the SAME roles at three and at four wavefronts per SIMD take
+    // 55.8 / 55.9 us per tick (768 front-end workgroups; 57.5 / 55.6 with 1 024): occupancy is NOT what limits the tick, and the 16 x 16 x 4 front
+    // end itself costs 5.5 us more than the 32 x 32 x 2 one (49.9 us: twice the LDS reads and twice the vector instructions per matrix cycle).
+    // Bit-identical (tests/test_pipelined.py), off by default: a measurement switch.
+    bool tick_fcm16w = getenv("SDRPP_GPU_TICK_FCM16W") ? atoi(getenv("SDRPP_GPU_TICK_FCM16W")) != 0 : false;
+    int tick_fcm16w_blocks = getenv("SDRPP_GPU_TICK_FCM16W_BLOCKS") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_FCM16W_BLOCKS"))) : 512;
     int tick_land_blocks = getenv("SDRPP_GPU_TICK_LAND_BLOCKS") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_LAND_BLOCKS"))) : 64;  // workgroups of a tick's landing copy (host-fed blocks), at most
     int tick_lds_cap = 24 * 1024;       // LDS window of the many-phase resampler as a role of a tick (launch_polyc)
     int tick_lds_cap_fir = 40 * 1024;   // ... of the register-blocked FIR roles (launch_fir)
@@ -356,7 +365,7 @@ struct sdrpp_ctx {
     bool tick_ev_ext = getenv("SDRPP_GPU_TICK_EVENT_EXT") ? atoi(getenv("SDRPP_GPU_TICK_EVENT_EXT")) != 0 : true;  // (15.8 against 15.2 GS/s with the event as a packet of its own: profiles/r04h_*)
     int tick_ev_skipped = 0;
     // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
-    int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0;
+    int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0, stat_set2 = 0;
     int64_t stat_role_wgs[64] = {};
 
     // timing

@@ -491,6 +491,7 @@ void launch_role(sdrpp_ctx* c, const sdrpp_ctx::RoleLaunch& r) {
     case TR_FCM_10: hipLaunchKernelGGL((vfo_frontcm_kernel<10, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCM_16: hipLaunchKernelGGL((vfo_frontcm_kernel<16, 0, 0>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCM16_132_4: hipLaunchKernelGGL((vfo_frontcm16_kernel<132, 4>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
+    case TR_FCM16W_132_4: hipLaunchKernelGGL((vfo_frontcm16w_kernel<132, 4>), grid, b256, r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCL_0: hipLaunchKernelGGL((vfo_frontcl_kernel<0>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_FCL_PF: hipLaunchKernelGGL((vfo_frontcl_kernel<SDRPP_FCL_PF>), grid, dim3(128), r.lds, st, e.p.src, (const FrontCMJob*)e.jobs); break;
     case TR_TOEP_C: hipLaunchKernelGGL((vfo_toep_kernel<2, 2, false>), grid, b256, r.lds, st, (const ToepJob*)e.jobs); break;

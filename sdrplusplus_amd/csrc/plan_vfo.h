@@ -230,7 +230,7 @@ struct BankPlan {
     // front-end jobs (group_front)
     struct S1Launch { int vt; std::vector<Stage1Job> jobs; int max_nout = 0; int tile = 256; size_t lds = 0; };
     struct F2Launch { int vt; std::vector<Front2Job> jobs; int max_blocks = 0; size_t lds = 0; };
-    struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; };
+    struct FCMLaunch { std::vector<FrontCMJob> jobs; int max_blocks = 0; size_t lds = 0; bool w16 = false; int w16_blocks = 0; };
     S1Launch s1l[4];
     F2Launch f2l[4];
     FCMLaunch fcm[3];  // PF 6 / 10 / 16
@@ -700,6 +700,12 @@ struct BankPlan {
                 }
                 else {
                     FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
+                    if (ticking && c->tick_fcm16w && K == 132 && lgD == 4 && (L.jobs.empty() || L.w16)) {
+                        // the 16 x 16 x 4 shape walking its tiles: the field counts tiles per WORKGROUP there (vfo_frontcm16w_body)
+                        job.tiles_per_wave = std::max(1, (ntiles + c->tick_fcm16w_blocks - 1) / c->tick_fcm16w_blocks);
+                        L.w16 = true;
+                        L.w16_blocks = std::max(L.w16_blocks, (ntiles + job.tiles_per_wave - 1) / job.tiles_per_wave);
+                    }
                     L.jobs.push_back(job);
                     L.max_blocks = std::max(L.max_blocks, (ntiles + 4 * job.tiles_per_wave - 1) / (4 * job.tiles_per_wave));
                     L.lds = std::max(L.lds, (size_t)frontcm_layout(K, lgD).total * 4);
@@ -948,6 +954,10 @@ struct BankPlan {
                 for (auto& jb : fcm[k].jobs) {
                     max_tiles = std::max(max_tiles, (jb.nout + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE);
                     one_tile = one_tile && jb.tiles_per_wave == 1;
+                }
+                if (fcm[k].w16 && role == TR_FCM_132_4 && !(one_tile && max_tiles <= 256 && !c->plan_block_from_host)) {
+                    emit(c, L0 + 1, F_S1, TR_FCM16W_132_4, fcm[k].w16_blocks, (int)fcm[k].jobs.size(), (size_t)frontcm16w_layout(132, 4).total * 4, d_fcm[k], &src);
+                    continue;
                 }
                 const int small_limit = c->fcm16_max_tiles >= 0 ? c->fcm16_max_tiles : ((c->tick_planning && c->plan_block_from_host) ? 0 : 256);
                 if (role == TR_FCM_132_4 && one_tile && max_tiles > 0 && max_tiles <= small_limit) {

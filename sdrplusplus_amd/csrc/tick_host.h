@@ -144,7 +144,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     }
     int blocks = l0.blocks[0] + l0.blocks[1];
     size_t lds = 0;
-    bool set1 = false;
+    bool set1 = false, set2 = true;  // set2: every role of this tick exists in the four-wavefronts-per-SIMD build (tick_kernels.h)
     long long role_wgs = 0;
     bool to_host = false;
     for (auto& r : now) {
@@ -153,6 +153,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         role_wgs += (long long)r.e.gx * r.e.gy;
         lds = std::max(lds, r.lds);
         set1 = set1 || r.e.role == TR_FCL_PF;
+        set2 = set2 && !(r.e.role == TR_FCL_PF || r.e.role == TR_FCL_0 || r.e.role == TR_FCM_132_4 || r.e.role == TR_FCM_6 || r.e.role == TR_FCM_10 || r.e.role == TR_FCM_16 || r.e.role == TR_FFT_S12);
         if (r.e.role >= 0 && r.e.role < 64) { c->stat_role_wgs[r.e.role] += (int64_t)r.e.gx * r.e.gy; }
     }
     if (role_wgs > 3ll * c->num_cus) { c->stat_crowded++; }
@@ -193,11 +194,16 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
             }
         }
         HostScope hs("launch");
+        static const bool allow2 = getenv("SDRPP_GPU_TICK_SET2") ? atoi(getenv("SDRPP_GPU_TICK_SET2")) != 0 : true;  // (measurement switch)
+        const bool use2 = allow2 && set2 && !set1 && c->tick_fcm16w && lds <= (size_t)40 * 1024;
+        if (use2) { c->stat_set2++; }
         if (stop_ev) {
             if (set1) { hipExtLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), (unsigned)lds, c->stream, ea, stop_ev, 0, l0, tab, done); }
+            else if (use2) { hipExtLaunchKernelGGL((tick_kernel<2>), dim3((unsigned)blocks), dim3(256), (unsigned)lds, c->stream, ea, stop_ev, 0, l0, tab, done); }
             else { hipExtLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), (unsigned)lds, c->stream, ea, stop_ev, 0, l0, tab, done); }
         }
         else if (set1) { hipLaunchKernelGGL((tick_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
+        else if (use2) { hipLaunchKernelGGL((tick_kernel<2>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
         else { hipLaunchKernelGGL((tick_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, c->stream, l0, tab, done); }
     }
     if (to_host && !c->tick_ev_ext) {  // measurement switch: the event as a packet of its own behind the launch

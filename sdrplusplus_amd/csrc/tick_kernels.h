@@ -107,6 +107,7 @@ enum TickRole : int {
     TR_FFT_P2_7, TR_FFT_P2_8, TR_FFT_P2_9, TR_FFT_P2_10,             // p.p2
     TR_FFT_P2ROW, TR_FFT_TR,                                         // p.p2 (long transforms: 4096-point rows in place; transpose into bin order, aux = doZoom group size)
     TR_ZOOM_16, TR_ZOOM_4, TR_ZOOM_1,                                // p.z
+    TR_FCM16W_132_4,  // vfo_frontcm16w_body<132, 4>: the ratio-32 front end in 16 x 16 x 4 shape walking `tiles_per_wave` tiles per workgroup (large blocks, SET = 2)
     TR_POLYC,      // PolyJob[gy], aux = LDS window in float2: vfo_polyc_body (many-phase resampler, cycle-major: the AF chain's 96/125)
     TR_DEEMP_P0, TR_DEEMP_P1,  // DeempJob[gy]: vfo_deemph_body<0, 0 / 1> (de-emphasis: segment maps, then the outputs one level later)
     TR_DC_P0, TR_DC_P1,        // DeempJob[gy]: vfo_deemph_body<1, 0 / 1> (the front end's DC blocker)
@@ -219,11 +220,13 @@ __device__ TickTraceRec g_tick_trace[SDRPP_TICK_TRACE_CAP];
 __device__ unsigned g_tick_trace_n;
 #endif
 
-// SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two).
+// SET 0: every role but TR_FCL_PF (168 registers: three wavefronts per SIMD); SET 1: all roles (247 registers: two); SET 2: every role that
+// fits 128 registers and 40 KB of LDS — i.e. all but the 32 x 32 x 2 front ends, the long first stages and the one-pass 4096-point transform —
+// FOUR wavefronts per SIMD: the build a tick runs in when its front end has the 16 x 16 x 4 shape (tick_set_for, tick_host.h).
 // (SET 0 squeezed into 128 registers by the compiler — four wavefronts per SIMD, the matrix front end spilling 668 bytes per lane — was
 // measured slower at every block size: 12.9 against 13.3 GS/s at 10^6 samples, 2.5 against 3.1 at 50 000; profiles/r03e)
 template <int SET>
-__global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, const TickTable* __restrict__ tab, TickDone done) {
+__global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_kernel(TickL0 l0, const TickTable* __restrict__ tab, TickDone done) {
     HIP_DYNAMIC_SHARED(float, smem)
     int b = (int)blockIdx.x;
     const int nb0 = l0.blocks[0] + l0.blocks[1];
@@ -262,12 +265,22 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e_jobs)); break;
             case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e_jobs)); break;
             case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e_jobs)); } break;
-            case TR_FCM_132_4: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
-            case TR_FCM_6: { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
-            case TR_FCM_10: { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
-            case TR_FCM_16: { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCM_132_4:
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                break;
+            case TR_FCM_6:
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                break;
+            case TR_FCM_10:
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                break;
+            case TR_FCM_16:
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                break;
             case TR_FCM16_132_4: { const IqSrc src = e.p.src; vfo_frontcm16_body<132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
-            case TR_FCL_0: { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
+            case TR_FCL_0:
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                break;
             case TR_FCL_PF:
                 if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
@@ -292,7 +305,9 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
                 break;
             case TR_FFT_S10: tick_fft_single<10, 4>(bid, smem, e.p.fs); break;
             case TR_FFT_S11: tick_fft_single<11, 2>(bid, smem, e.p.fs); break;
-            case TR_FFT_S12: tick_fft_single<12, 1>(bid, smem, e.p.fs); break;
+            case TR_FFT_S12:
+                if constexpr (SET != 2) { tick_fft_single<12, 1>(bid, smem, e.p.fs); }
+                break;
             case TR_FFT_P1_5: tick_fft_p1<5, 128>(bid, gdim, smem, e.p.p1); break;
             case TR_FFT_P1_6: tick_fft_p1<6, 64>(bid, gdim, smem, e.p.p1); break;
             case TR_FFT_P1_7: tick_fft_p1<7, 32>(bid, gdim, smem, e.p.p1); break;
@@ -311,6 +326,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : 3) void tick_kernel(TickL0 l0, 
             case TR_ZOOM_16: tick_zoom<16>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_4: tick_zoom<4>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
             case TR_ZOOM_1: tick_zoom<1>(bid, smem, e.p.z, e_aux > 0 ? e_aux : 1); break;
+            case TR_FCM16W_132_4: { const IqSrc src = e.p.src; vfo_frontcm16w_body<132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_POLYC: vfo_polyc_body(bid, reinterpret_cast<float2*>(smem), reinterpret_cast<const PolyJob*>(e_jobs), e_aux); break;
             case TR_DEEMP_P0: vfo_deemph_body<0, 0>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;
             case TR_DEEMP_P1: vfo_deemph_body<0, 1>(bid, smem, reinterpret_cast<const DeempJob*>(e_jobs)); break;

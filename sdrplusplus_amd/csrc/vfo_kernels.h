@@ -1762,6 +1762,152 @@ __global__ __launch_bounds__(256) void vfo_frontcm16_kernel(IqSrc src, const Fro
     vfo_frontcm16_body<KS, LGDS>(kidx(blockIdx), smemf, src, jobs);
 }
 
+// ---- ... and the 16 x 16 x 4 shape for LARGE blocks: every wavefront an independent engine that walks the tiles of its workgroup ------------
+// Why: the 32 x 32 x 2 form needs 168 registers and 41 KB of LDS per workgroup — three workgroups per CU — and in pipelined mode the whole tick
+// kernel inherits that budget: every role of a tick, the Toeplitz filters and the FFT passes included, runs at three wavefronts per SIMD because
+// ONE role needs the registers.  This shape needs ~70 registers and 31 KB: with it as the front end a tick kernel built for FOUR workgroups per CU
+// (tick_kernel<2>) holds every role of the radio path.  Same tap operand table, same k-ordered chains, same tile phasor and in-tile NCO table as
+// vfo_frontcm16_body: bit-identical outputs.  A workgroup takes `tiles_per_wave` consecutive 32-output tiles (the job field counts tiles per
+// WORKGROUP here); its four wavefronts are the four quarters (VFO half x output half) of every tile, each with planes and tile phasors of its own,
+// the next tile's IQ window in flight during the matrix loop, no workgroup barrier after the prologue.
+struct FCM16WLayout { int pl, a_off, pt_off, out_off, total; };
+__host__ __device__ inline FCM16WLayout frontcm16w_layout(int K, int lgD) {
+    FCM16WLayout L;
+    const int nsamp = 15 * (1 << lgD) + K;
+    const int np2 = (((K + 1) >> 1) + 1) & ~1;  // tap pairs, padded to a whole number of matrix steps (two pairs each)
+    L.pl = frontcm_plane(nsamp, lgD);
+    L.a_off = 4 * 2 * L.pl;
+    L.pt_off = L.a_off + np2 * 64;
+    L.out_off = L.pt_off + 4 * 16 * 2;
+    L.total = L.out_off + SDRPP_FCM_VT * 2;
+    return L;
+}
+template <int KS, int LGDS>
+__device__ __forceinline__ void vfo_frontcm16w_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs) {
+    const FrontCMJob& job = jobs[bid.y];
+    constexpr int K = KS, lgD = LGDS, D = 1 << lgD, VT = SDRPP_FCM_VT, tile = SDRPP_FCM_TILE;
+    constexpr int NP = (K + 1) >> 1, NSTEP = (NP + 1) >> 1;
+    constexpr int nsamp = 15 * D + K;
+    constexpr int PF = (nsamp + 63) / 64;
+    static_assert((K & 1) == 0 && (NP & 1) == 0 && NSTEP * 2 == NP, "even filters with an even number of tap pairs");
+    const FCM16WLayout L = frontcm16w_layout(K, lgD);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int vh = wv & 1, nh = wv >> 1;                     // this wavefront's half of the VFOs / of every tile's outputs
+    const int jj = lane & 15, kq = lane >> 4, comp = kq & 1, po = kq >> 1;  // matrix k index kq: pair p + po, sums (0) or differences (1)
+    float* XR = smemf + wv * 2 * L.pl;
+    float* XI = XR + L.pl;
+    float* AL = smemf + L.a_off;
+    float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off) + wv * 16;  // [16]: tile phasors of this wavefront's VFOs
+    float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);          // [VT]
+    {   // tap operand table (exactly NP rows: the unrolled matrix loop reads no padding), all loads of a work-item in flight before the first LDS write
+        constexpr int n4 = NP * 16, NB = (n4 + 255) / 256;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        float4 tv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) { tv[q] = global_load_f32x4(at4, min(tid + q * 256, n4 - 1)); }
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            if (tid + q * 256 < n4) { AL4[tid + q * 256] = tv[q]; }
+        }
+    }
+    if (tid < VT) { outp[tid] = job.out[tid]; }
+    __syncthreads();
+    TICK_MARK(0);
+    const int tile0 = bid.x * job.tiles_per_wave;
+    if (tile0 * tile >= job.nout) { return; }
+    int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
+    if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
+    auto tile_base = [&](int tb) -> long long { return (long long)job.off + (long long)tb * tile * D; };
+    float2 pf[PF];
+    auto fetch = [&](int tb) {
+        const long long base = tile_base(tb) + (long long)nh * 16 * D;
+        if (base >= 0 && base >= job.min_idx && base + nsamp <= src.n_cur) {
+            const float2* p = src.cur + base;
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = lane + q * 64;
+                pf[q] = (sidx < nsamp) ? p[sidx] : make_float2(0.0f, 0.0f);
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < PF; q++) {
+                const int sidx = lane + q * 64;
+                const long long gi = base + sidx;
+                pf[q] = iq_load_nb(src, gi, sidx < nsamp && gi >= job.min_idx);
+            }
+        }
+    };
+    float2 pt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { pt[r] = global_load_f32x2(job.ptab, (vh * 16 + 4 * kq + r) * tile + nh * 16 + jj); }
+    fetch(tile0);
+    const float sgn = comp ? -1.0f : 1.0f;
+    const int ib = jj * D + jj;  // skewed index of IQ sample jj * D
+    const float* P1a = (comp ? XI : XR) + ib + po;
+    const float* P2a = (comp ? XR : XI) + ib + po;
+    const float* P1b = (comp ? XI : XR) + ib - po;
+    const float* P2b = (comp ? XR : XI) + ib - po;
+    const float* Ap = AL + po * 64 + comp * 32 + vh * 16 + jj;
+    for (int it = 0; it < ntl; it++) {
+        const int tb = tile0 + it;
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int sidx = lane + q * 64;
+            if (sidx < nsamp) {
+                const int idx = sidx + (sidx >> lgD);
+                XR[idx] = pf[q].x;
+                XI[idx] = pf[q].y;
+            }
+        }
+        if (lane < 16 && vh * 16 + lane < job.nv) {  // the tile's phasor per VFO: exactly vfo_frontcm_body's tile_phasor
+            const int v = vh * 16 + lane;
+            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[v], job.phi0[v]);
+            ph -= rint(ph);
+            float sn, cs;
+            sincospif(2.0f * (float)ph, &sn, &cs);
+            ptile[lane] = make_float2(cs, sn);
+        }
+        if (it + 1 < ntl) { fetch(tb + 1); }  // in flight during the matrix loop
+        wave_sync();
+        wave_prio_low();
+        f32x4 accR = mfma4_zero(), accI = mfma4_zero();
+#pragma unroll
+        for (int m = 0; m < NSTEP; m++) {
+            const int oa = 2 * m + ((2 * m) >> lgD);
+            const int ob = (K - 1 - 2 * m) + ((K - 1 - 2 * m) >> lgD);
+            const float a1 = P1a[oa], a2 = P2a[oa];
+            const float b1 = P1b[ob], b2 = P2b[ob];
+            const float bre = fmaf(sgn, b1, a1);  // sums: a.re + b.re   differences: a.im - b.im
+            const float bim = fmaf(sgn, a2, b2);  // sums: a.im + b.im   differences: b.re - a.re (-dr: the (gr, -gi) operand serves both products)
+            const float a_op = Ap[2 * m * 64];
+            accR = mfma_16x16x4(a_op, bre, accR);
+            accI = mfma_16x16x4(a_op, bim, accI);
+        }
+        wave_prio_high();
+        {
+            const int n = tb * tile + nh * 16 + jj;
+            const bool live = n < job.nout;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int v = vh * 16 + 4 * kq + r;
+                if (v < job.nv && live) {
+                    const float2 P = ptile[4 * kq + r];
+                    const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                    global_store_f32x2(outp[v], n, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+                }
+            }
+        }
+        wave_sync();  // every lane is done with the planes and tile phasors before the next tile overwrites them
+    }
+}
+template <int KS, int LGDS>
+__global__ __launch_bounds__(256, 4) void vfo_frontcm16w_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float, smemf)
+    vfo_frontcm16w_body<KS, LGDS>(kidx(blockIdx), smemf, src, jobs);
+}
+
 // Long first stages (decimation by 32 or 64 with 143...726 taps: the plans for narrow channels in a very wide capture, e.g. cfg 4's
 // 61.44 MS/s -> 60 kS/s) use the same matrix formulation with the first stage alone as the "composite" filter, in a leaner
 // shape: 2 wavefronts per block (a wavefront's two IQ planes are ~20 KB), the IQ window goes straight from global memory to the

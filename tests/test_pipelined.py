@@ -58,7 +58,7 @@ def _compare(ref, got, fft, what):
             assert np.array_equal(ref["index"], got["index"]), what + " palette index"
 
 
-@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe")])
+@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe"), (16384, "fcm16w")])
 def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatch):
     """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks.  l0_at: the stage-0
@@ -68,6 +68,9 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatc
 
     if l0_at == "pipe":  # the FM back ends as ONE role of the tick (SDRPP_GPU_TICK_PIPE: a measurement switch, off by default) — blocks shorter than
         monkeypatch.setenv("SDRPP_GPU_TICK_PIPE", "1")  # a filter history (the 1031- and 7-sample ones and the one behind each) fall back to ordinary passes
+    elif l0_at == "fcm16w":  # the front end in its 16 x 16 x 4 shape walking its tiles, the tick in the four-wavefronts-per-SIMD build of the kernel
+        monkeypatch.setenv("SDRPP_GPU_TICK_FCM16W", "1")
+        monkeypatch.setenv("SDRPP_GPU_TICK_FCM16W_BLOCKS", "16")  # (several tiles per workgroup at these block sizes)
     elif l0_at is not None:
         monkeypatch.setenv("SDRPP_GPU_TICK_L0_AT", l0_at)
 
@@ -88,6 +91,10 @@ def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatc
             cb.push_staged_late_fill(blk)  # sdrpp_push_staged_when: another thread is still filling the slot while the call plans the block
     assert cb.ticket() == len(pushes)
     assert cb.fft_lines() == len(refs[-1]["raw"])  # host knowledge: no flush needed
+    if l0_at == "fcm16w":
+        cb.pipeline_flush()
+        st = cb.pipeline_stats()
+        assert "fcm16w_132_4" in st["roles"] and st["set2_ticks"] > 0, st
     for t, ref in enumerate(refs, start=1):
         got = cb.result_wait(t)
         _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
