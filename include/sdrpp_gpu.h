@@ -309,6 +309,10 @@ int sdrpp_push_int16(sdrpp_ctx* ctx, const int16_t* iq_host, int64_t count);
  * times slower); NULL on failure.  The host blocks allocate their frame-buffer slots with it. */
 void* sdrpp_host_alloc(size_t bytes);
 void sdrpp_host_free(void* p);
+/* Device memory on the context's GPU for buffers the host hands to sdrpp_fft_copy_device (e.g. the line a several-GPU host keeps per stream for
+ * its RCCL gather, host/sdrpp_gpu_rccl.h) without linking the HIP runtime itself; NULL on failure. */
+void* sdrpp_device_alloc(sdrpp_ctx* ctx, size_t bytes);
+void sdrpp_device_free(sdrpp_ctx* ctx, void* p);
 /* Deferred processing: sdrpp_push* only stage the samples (the H2D copy runs, the caller's buffer is free on return) and the next call
  * that observes results — sdrpp_sync, any *_lines / *_read* / *_count / *_device_buffer(s) / sdrpp_wf_* call — or changes the
  * configuration processes everything staged since the previous one as ONE pass over the device.  The results then cover ALL those

@@ -1679,6 +1679,18 @@ void* sdrpp_host_alloc(size_t bytes) {
 void sdrpp_host_free(void* p) {
     if (p) { (void)hipHostFree(p); }
 }
+void* sdrpp_device_alloc(sdrpp_ctx* c, size_t bytes) {
+    if (!c) { return nullptr; }
+    DeviceScope dev_scope_(c);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { return nullptr; }
+    return p;
+}
+void sdrpp_device_free(sdrpp_ctx* c, void* p) {
+    if (!c || !p) { return; }
+    DeviceScope dev_scope_(c);
+    (void)hipFree(p);
+}
 
 int sdrpp_set_deferred(sdrpp_ctx* c, int on) {
     DeviceScope dev_scope_(c);

@@ -158,6 +158,7 @@ public:
             _block_init = false;  // dsp::block's destructor has nothing left to stop
         }
         for (auto& kv : vfos) { delete kv.second; }
+        for (int k = 0; k < 2; k++) { sdrpp_device_free(ctx, devLine[k]); }
         if (ctx) { sdrpp_destroy(ctx); }
         for (int i = 0; i < FRAME_SLOTS; i++) { sdrpp_host_free(frames[i]); }
         sdrpp_host_free(gatherPin);
@@ -182,6 +183,7 @@ public:
         _release = releaseFFTBuffer;
         _fftCtx = fftCtx;
         if (plans) { _plans = *plans; }
+        _device = device;
         int rc = sdrpp_create(device, SDRPP_GPU_MAX_BLOCK, &ctx);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] ") + sdrpp_strerror(rc)); }
         sdrpp_set_deferred(ctx, 1);  // blocks are staged by stage() and processed by the first read of deliver(): one block or a whole backlog
@@ -319,6 +321,21 @@ public:
         vfos.erase(it);
         tempStart();
     }
+    // A several-GPU host gathers the waterfall lines of its streams on the display GPU over RCCL (sdrpp_gpu_rccl.h: BankLineGather): for that the
+    // newest raw dB line of this stream is kept in DEVICE memory of this front end's GPU, refreshed behind every block that completes one (bypass
+    // and buffered modes; two buffers, the complete one is handed out) — nothing of it crosses the bus until the gather's grouped send / receive.
+    void keepDeviceLine(bool enabled) {
+        std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
+        tempStop();
+        _keepDevLine = enabled;
+        tempStart();
+    }
+    const float* latestLineDevice() const {  // fftSize floats on this front end's device; NULL until a line has been kept
+        const int k = devLineCur.load(std::memory_order_acquire);
+        return k >= 0 ? devLine[k] : nullptr;
+    }
+    int device() const { return _device; }
+
     // The VFO whose `out` stream this is (NULL if none): how a demod::Demodulator-shaped adaptor (sdrpp_gpu_radio.h), which is handed
     // `&vfo->out` as its input stream exactly like a CPU demodulator, finds the channel it is fused into.
     RxVFO* vfoOfStream(dsp::stream<dsp::complex_t>* stream) {
@@ -740,6 +757,20 @@ private:
             return -1;
         }
         SDRPP_BLOCKS_TICK(2)
+        if (_keepDevLine && nlines > 0) {  // the newest line stays on the device as well (keepDeviceLine)
+            if (devLineSize != _fftSize) {
+                for (int k = 0; k < 2; k++) {
+                    sdrpp_device_free(ctx, devLine[k]);
+                    devLine[k] = (float*)sdrpp_device_alloc(ctx, (size_t)_fftSize * sizeof(float));
+                }
+                devLineSize = _fftSize;
+                devLineCur.store(-1, std::memory_order_release);
+            }
+            const int cur = devLineCur.load(std::memory_order_relaxed), nxt = cur == 0 ? 1 : 0;
+            if (devLine[nxt] && sdrpp_fft_copy_device(ctx, nlines - 1, 1, devLine[nxt], nullptr, nullptr) >= 0 && sdrpp_sync(ctx) == 0) {
+                devLineCur.store(nxt, std::memory_order_release);
+            }
+        }
         // all new lines with ONE device-to-host copy into page-locked staging; they are handed out below, next to the VFO blocks
         if (nlines > 0 && _acquire) {
             const size_t need = (size_t)nlines * (size_t)_fftSize;
@@ -1010,6 +1041,11 @@ private:
     std::deque<std::pair<uint64_t, std::vector<dsp::complex_t>>> tapPending;  // pipelined: (ticket, input block) kept for the bound streams until the block's turn
     std::vector<dsp::complex_t> inflightTap;
     int pipeFlags = 0;                      // result flags the context was put into pipelined mode with
+    bool _keepDevLine = false;              // keepDeviceLine
+    float* devLine[2] = { nullptr, nullptr };
+    int devLineSize = 0;
+    std::atomic<int> devLineCur{ -1 };
+    int _device = 0;
     std::mutex ctlMtx;
     std::vector<std::function<void()>> ctlOps;
     std::mutex frameMtx;

@@ -36,6 +36,8 @@ public:
         }
     }
     int size() const { return (int)slots.size(); }
+    int fftSize() const { return _fftSize; }
+    int deviceOf(int i) const { return slots[(size_t)i]->fe.device(); }
     IQFrontEnd& operator[](int i) { return slots[(size_t)i]->fe; }
     void setFFTSize(int size) {
         _fftSize = size;

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include "sdrpp_gpu_multi.h"
+
 namespace sdrpp_gpu {
 
 class LineGather {
@@ -97,6 +99,97 @@ private:
     float* gathered = nullptr;
     size_t cap = 0;
     int root = 0;
+    bool ready = false;
+};
+
+// StreamBank + LineGather: the newest waterfall line of every stream of a bank gathered on the display GPU.  Every front end keeps its newest
+// raw dB line in memory of ITS device (IQFrontEnd::keepDeviceLine); a gather packs the lines of the streams that share a device into that
+// device's block (device-to-device, on the device), then ONE grouped ncclSend / ncclRecv brings the blocks to the root device and one copy takes
+// them to the host — the lines of the other GPUs never travel through host memory.  One RCCL rank per DISTINCT device of the bank (two streams
+// on a one-GPU box: one rank, the collective still runs).
+class BankLineGather {
+public:
+    ~BankLineGather() { destroy(); }
+    void init(StreamBank& bank_, int rootStream = 0) {
+        destroy();
+        bank = &bank_;
+        n = bank->fftSize();
+        const int ns = bank->size();
+        if (ns <= 0 || rootStream < 0 || rootStream >= ns) { throw std::runtime_error("[sdrpp_gpu::BankLineGather] bad bank"); }
+        rankOf.assign((size_t)ns, 0);
+        slotOf.assign((size_t)ns, 0);
+        for (int i = 0; i < ns; i++) {
+            const int d = bank->deviceOf(i);
+            size_t r = 0;
+            while (r < devs.size() && devs[r] != d) { r++; }
+            if (r == devs.size()) {
+                devs.push_back(d);
+                perRank.push_back(0);
+            }
+            rankOf[(size_t)i] = (int)r;
+            slotOf[(size_t)i] = perRank[r]++;
+            (*bank)[i].keepDeviceLine(true);
+        }
+        maxPer = 0;
+        for (int c : perRank) { maxPer = c > maxPer ? c : maxPer; }
+        blocks.assign(devs.size(), nullptr);
+        for (size_t r = 0; r < devs.size(); r++) {
+            hip(hipSetDevice(devs[r]), "hipSetDevice");
+            hip(hipMalloc((void**)&blocks[r], (size_t)maxPer * (size_t)n * sizeof(float)), "hipMalloc");
+            hip(hipMemset(blocks[r], 0, (size_t)maxPer * (size_t)n * sizeof(float)), "hipMemset");
+        }
+        g.init(devs, (size_t)maxPer * (size_t)n, rankOf[(size_t)rootStream]);
+        ready = true;
+    }
+    int ranks() const { return g.ranks(); }
+    // out: [streams][fftSize] floats, the newest line of every stream (zeros for a stream that has none yet).  Returns the streams that had one.
+    int gather(std::vector<float>& out) {
+        if (!ready) { throw std::runtime_error("[sdrpp_gpu::BankLineGather] not initialised"); }
+        const int ns = bank->size();
+        int have = 0;
+        for (int i = 0; i < ns; i++) {
+            const float* line = (*bank)[i].latestLineDevice();
+            if (!line) { continue; }
+            have++;
+            hip(hipSetDevice(devs[(size_t)rankOf[(size_t)i]]), "hipSetDevice");
+            hip(hipMemcpy(blocks[(size_t)rankOf[(size_t)i]] + (size_t)slotOf[(size_t)i] * (size_t)n, line, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+        }
+        std::vector<const float*> send(blocks.begin(), blocks.end());
+        g.gather(send, (size_t)maxPer * (size_t)n);
+        staging.resize(devs.size() * (size_t)maxPer * (size_t)n);
+        g.toHost(staging.data(), (size_t)maxPer * (size_t)n);
+        out.assign((size_t)ns * (size_t)n, 0.0f);
+        for (int i = 0; i < ns; i++) {
+            const float* src = &staging[((size_t)rankOf[(size_t)i] * (size_t)maxPer + (size_t)slotOf[(size_t)i]) * (size_t)n];
+            std::copy(src, src + n, out.begin() + (size_t)i * (size_t)n);
+        }
+        return have;
+    }
+    void destroy() {
+        if (!ready) { return; }
+        for (size_t r = 0; r < blocks.size(); r++) {
+            if (blocks[r]) {
+                (void)hipSetDevice(devs[r]);
+                (void)hipFree(blocks[r]);
+            }
+        }
+        blocks.clear();
+        devs.clear();
+        perRank.clear();
+        g.destroy();
+        ready = false;
+    }
+
+private:
+    static void hip(hipError_t e, const char* what) {
+        if (e != hipSuccess) { throw std::runtime_error(std::string("[sdrpp_gpu::BankLineGather] ") + what + ": " + hipGetErrorString(e)); }
+    }
+    StreamBank* bank = nullptr;
+    LineGather g;
+    std::vector<int> devs, perRank, rankOf, slotOf;
+    std::vector<float*> blocks;
+    std::vector<float> staging;
+    int n = 0, maxPer = 0;
     bool ready = false;
 };
 

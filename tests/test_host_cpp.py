@@ -192,6 +192,25 @@ def test_rccl_line_gather_cpp():
 
 
 @pytest.mark.gpu
+def test_stream_bank_line_gather_over_rccl():
+    """sdrpp_gpu::BankLineGather: StreamBank + LineGather wired together — the newest line of every stream stays on its device
+    (IQFrontEnd::keepDeviceLine) until one grouped RCCL send / receive brings them to the display device; equal, bit for bit, to the lines
+    the bank's handler received.  Degrades to one rank when the streams share the one GPU of the test box."""
+    rocm = "/opt/rocm"
+    if not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        pytest.skip("no RCCL headers")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_bank_gather")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include", "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"), "-o", exe,
+                        os.path.join(ROOT, "tests", "host_cpp", "test_bank_gather.cpp"), "-L" + CSRC, "-lsdrpp_gpu", "-L" + rocm + "/lib", "-lrccl", "-lamdhip64",
+                        "-Wl,-rpath," + rocm + "/lib", "-Wl,-rpath," + CSRC, "-lpthread"], check=True)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "ok" in r.stdout and "ranks" in r.stdout
+
+
+@pytest.mark.gpu
 def test_bench_protocol_over_rccl_with_one_rank():
     """bench.py's N > 1 leg on the one GPU there is: init_process_group("nccl") with a world of one, the pipelined StreamRunner protocol,
     the line batches going through dist.gather on RCCL, barrier + all_reduce(MAX) of the elapsed time — the JSON line says so."""
