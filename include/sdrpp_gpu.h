@@ -387,6 +387,10 @@ int sdrpp_pipeline_flush(sdrpp_ctx* ctx);                    /* launch what is q
 int sdrpp_result_ready(sdrpp_ctx* ctx, uint64_t ticket);     /* 1 / 0 without blocking or flushing; SDRPP_ERR_NOT_FOUND: no slot    */
 int sdrpp_result_wait(sdrpp_ctx* ctx, uint64_t ticket, sdrpp_result* out);   /* flushes if needed, waits, hands the slot out        */
 int sdrpp_result_release(sdrpp_ctx* ctx, uint64_t ticket);
+/* wait + copy + release in one call for a host that only wants a block's zoomed lines / palette indices (result flag 2): up to max_lines lines
+ * of data_width values each go to zoomed_dst / index_dst (either may be NULL); *n_lines = lines the block completed.  SDRPP_ERR_INVALID if it
+ * completed more than max_lines (the slot is released all the same). */
+int sdrpp_result_take_lines(sdrpp_ctx* ctx, uint64_t ticket, float* zoomed_dst, int32_t* index_dst, int max_lines, int* n_lines);
 /* How the blocks of a pipelined run were executed — for tests and bench.py, which assert the mode they mean to measure.
  * out[0] launches ("ticks") so far, [1] blocks that ran as ticks, [2] blocks that fell back to an ordinary pass, [3] ticks with more role
  * workgroups than the device holds at once (3 per CU: "crowded" order of the roles, tick_host.h), [4] levels of the most recent block (its

@@ -217,6 +217,7 @@ def load():
     L.sdrpp_result_ready.argtypes = [vp, C.c_uint64]
     L.sdrpp_result_wait.argtypes = [vp, C.c_uint64, C.POINTER(Result)]
     L.sdrpp_result_release.argtypes = [vp, C.c_uint64]
+    L.sdrpp_result_take_lines.argtypes = [vp, C.c_uint64, vp, vp, C.c_int, c_int_p]
     L.sdrpp_pipeline_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     L.sdrpp_pipeline_role_name.restype = C.c_char_p
     L.sdrpp_pipeline_role_name.argtypes = [C.c_int]
@@ -242,7 +243,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
-    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
+    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
 
@@ -321,6 +322,8 @@ class Context:
         self.data_width = 0
         self.wf_height = 0
         self._res_scratch = Result()
+        self._take_n_val = C.c_int(0)
+        self._take_n = C.byref(self._take_n_val)
 
     def _chk(self, rc):
         if rc < 0:
@@ -642,18 +645,13 @@ class Context:
             th.join()
 
     def result_lines_into(self, ticket, dst_addr, max_lines):
-        """Lean form of result_wait + copy + release for the zoomed lines of a block (result flag 2): the lines go to host address
-        `dst_addr` (room for max_lines x data_width floats) with one memmove.  Returns the number of lines."""
-        r = self._res_scratch
-        self._chk(self.L.sdrpp_result_wait(self.h, int(ticket), C.byref(r)))
-        n = r.n_lines
-        if n > max_lines:
-            self.L.sdrpp_result_release(self.h, int(ticket))
-            raise RuntimeError("block %d completed %d lines, room for %d" % (ticket, n, max_lines))
-        if n > 0 and r.zoomed:
-            C.memmove(dst_addr, r.zoomed, n * r.data_width * 4)
-        self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))
-        return n
+        """sdrpp_result_take_lines: wait + copy + release for the zoomed lines of a block (result flag 2) in ONE call; the lines go to host
+        address `dst_addr` (room for max_lines x data_width floats).  Returns the number of lines."""
+        n = self._take_n
+        rc = self.L.sdrpp_result_take_lines(self.h, ticket, dst_addr, None, max_lines, n)
+        if rc < 0:
+            self._chk(rc)
+        return self._take_n_val.value
 
     def result_release(self, ticket):
         self._chk(self.L.sdrpp_result_release(self.h, int(ticket)))

@@ -364,6 +364,8 @@ struct sdrpp_ctx {
     int tick_ev_every = getenv("SDRPP_GPU_TICK_EVENT_EVERY") ? std::max(1, atoi(getenv("SDRPP_GPU_TICK_EVENT_EVERY"))) : 1;
     bool tick_ev_ext = getenv("SDRPP_GPU_TICK_EVENT_EXT") ? atoi(getenv("SDRPP_GPU_TICK_EVENT_EXT")) != 0 : true;  // (15.8 against 15.2 GS/s with the event as a packet of its own: profiles/r04h_*)
     int tick_ev_skipped = 0;
+    void* bank_plan = nullptr;            // the context's BankPlan (plan_vfo.h), re-used block after block
+    void (*bank_plan_free)(void*) = nullptr;
     // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
     int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0, stat_set2 = 0;
     int64_t stat_role_wgs[64] = {};

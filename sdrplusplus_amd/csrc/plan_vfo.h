@@ -194,15 +194,17 @@ bool arena_push_lev(sdrpp_ctx* c, Lev<T>& L) {
 // (emit_front, emit_levels).  Every job carries the LEVEL of its launch in the block's data flow (level L reads what level L - 1 wrote): the
 // front end is level 1 (level 0 = the block's arrival), every filter behind it one more.  A pass launches level by level; in pipelined mode
 // level L of this block runs L ticks from now (tick_kernels.h).
+// One BankPlan lives with its context and is re-used block after block (begin() empties the lists and keeps their storage: with 128 VFOs a
+// fresh plan per block was ~1 000 small allocations, a third of the 225 us of host time that had become cfg 4's limit once its tick took 135 us).
 struct BankPlan {
     sdrpp_ctx* c;
-    const IqSrc& src;
-    const int n_in;
-    const bool ticking;
-    const int L0;  // levels the pre-processing chain takes in front (pipelined mode): the front end runs at level L0 + 1
+    IqSrc src{};
+    int n_in = 0;
+    bool ticking = false;
+    int L0 = 0;  // levels the pre-processing chain takes in front (pipelined mode): the front end runs at level L0 + 1
     static constexpr int carry_last = kLevels - 1;
     const std::vector<int>& fb;  // reference-block ends of this push (at least one entry: n_in)
-    const bool blocks;
+    bool blocks = false;
     std::vector<S1Member> s1;
     std::vector<RotJob> rot;
     Lev<FirBJob> f_dec;  // register-blocked decimators (tap counts the matrix form does not cover; stage 0 only in reference-rotator mode)
@@ -235,6 +237,7 @@ struct BankPlan {
     F2Launch f2l[4];
     FCMLaunch fcm[3];  // PF 6 / 10 / 16
     FCMLaunch fcl;     // long first stages (vfo_frontcl_kernel)
+    int fcl_nw = 2;    // tile engines per workgroup of that launch: 4 as a role of a tick when four wavefronts' planes fit half a CU's LDS
     const int vts[4] = { 8, 4, 2, 1 };
     // device addresses of the job tables (upload)
     Stage1Job* d_s1[4] = {};
@@ -255,9 +258,50 @@ struct BankPlan {
                                     { &t_af_poly, 2, 2, false, F_AF, TR_TOEP_C },     { &t_af_hpf, 2, 2, false, F_AF, TR_TOEP_C } };
     ToepPlan tplan[kToepLists][kLevels];
 
-    BankPlan(sdrpp_ctx* c_, const IqSrc& src_, int64_t count, const CarryJob& iq_carry)
-        : c(c_), src(src_), n_in((int)count), ticking(c_->tick_planning), L0(c_->tick_planning ? c_->plan_lvl0 : 0), fb(c_->vfo_bounds), blocks(c_->vfo_bounds.size() > 1) {
+    explicit BankPlan(sdrpp_ctx* c_) : c(c_), fb(c_->vfo_bounds) {
         for (int i = 0; i < 4; i++) { s1l[i].vt = vts[i]; f2l[i].vt = vts[i]; }
+    }
+    template <class T>
+    static void lev_reset(Lev<T>& L) {
+        for (int l = 0; l < L.top; l++) {
+            L.at[l].clear();
+            L.dev[l] = nullptr;
+        }
+        L.top = 0;
+    }
+    // a new block: every list empty (storage kept), every per-block scalar back to its initial value
+    void begin(const IqSrc& src_, int64_t count, const CarryJob& iq_carry) {
+        src = src_;
+        n_in = (int)count;
+        ticking = c->tick_planning;
+        L0 = ticking ? c->plan_lvl0 : 0;
+        blocks = fb.size() > 1;
+        s1.clear(); rot.clear(); rotx.clear(); retune.clear(); pipes.clear(); pgroups.clear();
+        lev_reset(f_dec); lev_reset(poly);
+        for (auto& q : polyb) { lev_reset(q); }
+        lev_reset(chan); lev_reset(seq); lev_reset(pre); lev_reset(audio); lev_reset(audio_fm);
+        lev_reset(t_dec); lev_reset(t_poly); lev_reset(t_chan); lev_reset(t_audio); lev_reset(t_audio_fm);
+        lev_reset(t_af_dec); lev_reset(t_af_poly); lev_reset(t_af_hpf); lev_reset(af_dec); lev_reset(af_hpf); lev_reset(af_poly); lev_reset(af_deemp);
+        lev_reset(ssbx_l); lev_reset(carry);
+        pipe_lds = 0;
+        max_rot = 0;
+        pipe_top = 0;
+        fcl_nw = 2;
+        for (int i = 0; i < 4; i++) {
+            s1l[i].jobs.clear(); s1l[i].max_nout = 0; s1l[i].tile = 256; s1l[i].lds = 0;
+            f2l[i].jobs.clear(); f2l[i].max_blocks = 0; f2l[i].lds = 0;
+            d_s1[i] = nullptr;
+            d_f2[i] = nullptr;
+        }
+        for (int i = 0; i < 3; i++) {
+            fcm[i].jobs.clear(); fcm[i].max_blocks = 0; fcm[i].lds = 0; fcm[i].w16 = false; fcm[i].w16_blocks = 0;
+            d_fcm[i] = nullptr;
+        }
+        fcl.jobs.clear(); fcl.max_blocks = 0; fcl.lds = 0; fcl.w16 = false; fcl.w16_blocks = 0;
+        d_fcl = nullptr; d_rotx = nullptr; d_retune = nullptr; d_rot = nullptr; d_fb = nullptr;
+        for (auto& row : tplan) {
+            for (auto& q : row) { q = ToepPlan{}; }
+        }
         carry.add(ticking ? L0 + 1 : carry_last, iq_carry);  // job 0 of its level: the shared IQ stream
     }
     BankPlan(const BankPlan&) = delete;
@@ -598,6 +642,12 @@ struct BankPlan {
             if (a.taph != b.taph) { return a.taph < b.taph; }
             return a.v->id < b.v->id;
         });
+        if (ticking) {
+            fcl_nw = 4;
+            for (auto& m : s1) {
+                if (!m.fused && m.lgD >= 5 && m.K >= 9 && (size_t)frontcl_lds_floats(m.K, m.lgD, 4) * 4 > (size_t)(160 * 1024 / 2)) { fcl_nw = 2; }
+            }
+        }
         size_t i = 0;
         while (i < s1.size()) {
             size_t j = i;
@@ -682,8 +732,8 @@ struct BankPlan {
                 const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
                 // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
                 // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
-                const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD) * 4))) : 0;
-                const int resident = m_long ? 256 * long_blocks * 2 : (c->tick_planning ? c->tick_fcm_waves : 3072);
+                const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD, fcl_nw) * 4))) : 0;
+                const int resident = m_long ? 256 * long_blocks * fcl_nw : (c->tick_planning ? c->tick_fcm_waves : 3072);
                 job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
                 job.atab = reinterpret_cast<const float*>(d_taps);
                 job.ptab = d_taps + (size_t)NP4 * 32;
@@ -695,8 +745,8 @@ struct BankPlan {
                 }
                 if (m_long) {
                     fcl.jobs.push_back(job);
-                    fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + 2 * job.tiles_per_wave - 1) / (2 * job.tiles_per_wave));
-                    fcl.lds = std::max(fcl.lds, (size_t)frontcl_lds_floats(K, lgD) * 4);
+                    fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + fcl_nw * job.tiles_per_wave - 1) / (fcl_nw * job.tiles_per_wave));
+                    fcl.lds = std::max(fcl.lds, (size_t)frontcl_lds_floats(K, lgD, fcl_nw) * 4);
                 }
                 else {
                     FCMLaunch& L = fcm[m_pf == 6 ? 0 : (m_pf == 10 ? 1 : 2)];
@@ -970,7 +1020,7 @@ struct BankPlan {
             if (!fcl.jobs.empty() && fcl.max_blocks > 0) {
                 bool pf_ok = true;  // every window of the launch fits the register prefetch
                 for (auto& jb : fcl.jobs) { pf_ok = pf_ok && (SDRPP_FCM_TILE - 1) * (1 << jb.log2_decim) + jb.ntaps <= 64 * SDRPP_FCL_PF; }
-                emit(c, L0 + 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src);
+                emit(c, L0 + 1, F_S1, pf_ok ? TR_FCL_PF : TR_FCL_0, fcl.max_blocks, (int)fcl.jobs.size(), fcl.lds, d_fcl, &src, fcl_nw);
             }
             if (!rot.empty() && max_rot > 0) { emit(c, L0 + 1, F_S1, TR_ROT, std::min((max_rot + 255) / 256, 4096), (int)rot.size(), 0, d_rot, &src); }
             if (!retune.empty()) {
@@ -1227,16 +1277,34 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     }
 #endif
     const int n_in = (int)count;
-    std::unique_ptr<BankPlan> P(new BankPlan(c, src, count, iq_carry));  // (a few hundred KB of job-list heads: not on the stack)
-    int rc = SDRPP_OK;
-    for (auto& kv : c->vfos) {
-        rc = P->chain(*kv.second);
-        if (rc) { return rc; }
+    HostScope hs_all("plan: vfo bank");
+    if (!c->bank_plan) {
+        c->bank_plan = new BankPlan(c);
+        c->bank_plan_free = [](void* q) { delete static_cast<BankPlan*>(q); };
     }
-    rc = P->group_front();
-    if (!rc) { rc = P->upload(); }
-    if (!rc) { rc = P->emit_front(); }
-    if (!rc) { rc = P->emit_levels(); }
+    BankPlan* P = static_cast<BankPlan*>(c->bank_plan);
+    P->begin(src, count, iq_carry);
+    int rc = SDRPP_OK;
+    {
+        HostScope hs("plan: chains");
+        for (auto& kv : c->vfos) {
+            rc = P->chain(*kv.second);
+            if (rc) { return rc; }
+        }
+    }
+    {
+        HostScope hs("plan: group_front");
+        rc = P->group_front();
+    }
+    if (!rc) {
+        HostScope hs("plan: upload");
+        rc = P->upload();
+    }
+    if (!rc) {
+        HostScope hs("plan: emit");
+        rc = P->emit_front();
+        if (!rc) { rc = P->emit_levels(); }
+    }
     if (rc) { return rc; }
     // flip the ping-pong side of every carried stream
     for (auto& kv : c->vfos) {

@@ -118,6 +118,10 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         snprintf(b, sizeof(b), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
         c->devinfo = b;
         c->num_cus = std::max(1, prop.multiProcessorCount);
+        // the long-first-stage role with four tile engines asks for up to 80 KB of dynamic LDS per workgroup (two workgroups per CU): above the
+        // 64 KB a launch gets without asking
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tick_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
+        (void)hipGetLastError();
     }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -381,6 +385,8 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     for (int i = 0; i < kStageSlots; i++) {
         if (c->stage_host[i]) { (void)hipHostFree(c->stage_host[i]); }
     }
+    if (c->bank_plan && c->bank_plan_free) { c->bank_plan_free(c->bank_plan); }
+    c->bank_plan = nullptr;
     for (int i = 0; i < sdrpp_ctx::kTickEvents; i++) {
         if (c->tick_ev[i]) { (void)hipEventDestroy(c->tick_ev[i]); }
         if (c->tick_ev_start[i]) { (void)hipEventDestroy(c->tick_ev_start[i]); }
@@ -1784,6 +1790,22 @@ int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
     return SDRPP_OK;
 }
 
+int sdrpp_result_take_lines(sdrpp_ctx* c, uint64_t ticket, float* zoomed_dst, int32_t* index_dst, int max_lines, int* n_lines) {
+    sdrpp_result r{};
+    int rc = sdrpp_result_wait(c, ticket, &r);
+    if (rc) { return rc; }
+    if (n_lines) { *n_lines = r.n_lines; }
+    if (r.n_lines > max_lines) {
+        (void)sdrpp_result_release(c, ticket);
+        return fail(c, SDRPP_ERR_INVALID, "block %llu completed %d lines, room for %d", (unsigned long long)ticket, r.n_lines, max_lines);
+    }
+    if (r.n_lines > 0 && r.zoomed) {
+        const size_t bytes = (size_t)r.n_lines * (size_t)r.data_width * 4;
+        if (zoomed_dst) { memcpy(zoomed_dst, r.zoomed, bytes); }
+        if (index_dst) { memcpy(index_dst, r.index, bytes); }
+    }
+    return sdrpp_result_release(c, ticket);
+}
 int sdrpp_pipeline_stats(sdrpp_ctx* c, int64_t* out, int max) {
     if (!c || !out || max < 0) { return SDRPP_ERR_INVALID; }
     const int64_t head[SDRPP_PIPELINE_STATS_HEAD] = { (int64_t)c->ticks, c->stat_tick_blocks, c->stat_pass_blocks, c->stat_crowded, c->stat_last_depth, (int64_t)TR_COUNT, c->stat_set2, 0 };

@@ -91,7 +91,7 @@ enum TickRole : int {
     TR_FCM_10,     // <10, 0, 0>
     TR_FCM_16,     // <16, 0, 0>
     TR_FCM16_132_4,  // vfo_frontcm16_body<132, 4>: the ratio-32 front end in 16 x 16 x 4 shape, one 32-output tile per WORKGROUP (small blocks)
-    TR_FCL_0,      // vfo_frontcl_body<0> (two wavefronts per workgroup)
+    TR_FCL_0,      // vfo_frontcl_body<0>, aux = tile engines per workgroup (2, or 4 when their planes fit)
     TR_FCL_PF,     // vfo_frontcl_body<SDRPP_FCL_PF> (247 registers: only in the SET = 1 build of the kernel)
     TR_TOEP_C,     // ToepJob[gy]: vfo_toep_body<2, 2, false>
     TR_TOEP_R,     // <1, 2, false>
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
                 break;
             case TR_FCM16_132_4: { const IqSrc src = e.p.src; vfo_frontcm16_body<132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCL_0:
-                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcl_body<0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs), e_aux == 4 ? 4 : 2); }
                 break;
             case TR_FCL_PF:
-                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcl_body<SDRPP_FCL_PF>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs), e_aux == 4 ? 4 : 2); }
                 break;
             case TR_TOEP_C: vfo_toep_body<2, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e_jobs)); break;
             case TR_TOEP_R: vfo_toep_body<1, 2, false>(bid, gdim, smem, reinterpret_cast<const ToepJob*>(e_jobs)); break;

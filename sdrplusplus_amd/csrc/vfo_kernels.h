@@ -1913,15 +1913,18 @@ __global__ __launch_bounds__(256, 4) void vfo_frontcm16w_kernel(IqSrc src, const
 // shape: 2 wavefronts per block (a wavefront's two IQ planes are ~20 KB), the IQ window goes straight from global memory to the
 // planes (no register staging: it would need ~70 VGPRs), and the tap operand — up to 363 pairs x 64 lanes — streams from
 // global memory / L2 through a four-deep register ring instead of living in LDS.
-__host__ __device__ inline int frontcl_lds_floats(int K, int lgD) {
+__host__ __device__ inline int frontcl_lds_floats(int K, int lgD, int nw = 2) {
     const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
-    return 2 * 2 * frontcm_plane(nsamp, lgD) + 2 * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // 2 waves x 2 planes + tile phasors + pointers
+    return nw * 2 * frontcm_plane(nsamp, lgD) + nw * SDRPP_FCM_VT * 2 + SDRPP_FCM_VT * 2;  // nw waves x 2 planes + tile phasors + pointers
 }
 // PF: IQ samples prefetched per lane into registers (covers windows of nsamp <= 64 * PF samples: PF = 38 -> first stages up to 448
 // taps at /64); PF = 0: longer windows are loaded in place, unpipelined.
 #define SDRPP_FCL_PF 38
 template <int PF>
-__device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs) {
+// nw: tile engines (wavefronts) per workgroup — 2 for a launch of its own (128 work-items); as a role of the tick kernel, whose workgroups are
+// 256 wide, 4 when four wavefronts' planes fit half a CU's LDS (the build of the tick kernel that holds this role runs two workgroups per CU:
+// with two engines each only ONE wavefront per SIMD was at work, and the long first stages were three quarters of cfg 4's tick).
+__device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs, int nw = 2) {
     const FrontCMJob& job = jobs[bid.y];
     constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
@@ -1932,12 +1935,12 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
     float* XR = smemf + wv * 2 * pl;
     float* XI = XR + pl;
-    float2* ptile = reinterpret_cast<float2*>(smemf + 4 * pl) + wv * VT;
-    float2** outp = reinterpret_cast<float2**>(smemf + 4 * pl + 2 * VT * 2);
+    float2* ptile = reinterpret_cast<float2*>(smemf + 2 * nw * pl) + wv * VT;
+    float2** outp = reinterpret_cast<float2**>(smemf + 2 * nw * pl + nw * VT * 2);
     if (tid < VT) { outp[tid] = job.out[tid]; }
     __syncthreads();  // the only workgroup barrier
-    if (wv >= 2) { return; }  // (a role of the tick kernel: 256-wide workgroups, two tile engines)
-    const int tile0 = (bid.x * 2 + wv) * job.tiles_per_wave;
+    if (wv >= nw) { return; }  // (a role of the tick kernel with two engines: the other two wavefronts of the 256-wide workgroup have nothing to do)
+    const int tile0 = (bid.x * nw + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
     if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }

@@ -69,6 +69,7 @@ class StreamRunner:
         self.batches = 0     # batches handed to the device / gathered
         self.nb = 0
         self.local_elapsed = 0.0
+        self._next_ticket = None
         if self.pipelined:
             assert lines.dim() == 3 and lines.shape[0] == self.gather_every, "pipelined: lines = [gather_every, max_lines + 1, data_width]"
             self.max_lines = lines.shape[1] - 1
@@ -141,7 +142,11 @@ class StreamRunner:
     def step(self, i):
         self.ctx.push_device(self.buf_ptrs[i % len(self.buf_ptrs)], self.push)
         if self.pipelined:
-            self.tickets.append(self.ctx.ticket())
+            if self._next_ticket is None:  # (tickets count the pushes of the context: one call to learn where it stands, then counted here)
+                self._next_ticket = self.ctx.ticket()
+            else:
+                self._next_ticket += 1
+            self.tickets.append(self._next_ticket)
             if len(self.tickets) > self.lag:
                 self._collect(self.tickets.pop(0))
         elif self.collective:

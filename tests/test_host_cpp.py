@@ -183,7 +183,8 @@ def test_rccl_line_gather_cpp():
         pytest.skip("no RCCL headers")
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "test_rccl_gather")
-        subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_rccl_gather.cpp"),
+        subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include", "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"), "-o", exe,
+                        os.path.join(ROOT, "tests", "host_cpp", "test_rccl_gather.cpp"),
                         "-L" + CSRC, "-lsdrpp_gpu", "-L" + rocm + "/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + rocm + "/lib", "-Wl,-rpath," + CSRC, "-lpthread"], check=True)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
