@@ -111,7 +111,7 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
         rc0 = arena_begin(c);
     }
     if (rc0) { return rc0; }
-    PlanSnapshot snap;
+    static thread_local PlanSnapshot snap;  // (re-used: with 128 VFOs a fresh one is a 38 KB allocation per block; a nested pass starts only after the outer plan has been restored)
     plan_snapshot(c, snap);
     c->plan_lvl0 = 0;
     block_bounds(c, count, push_ends);

@@ -491,7 +491,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
     }
     c->pushes++;
     const bool have_slot = as_tick;
-    PlanSnapshot snap;
+    static thread_local PlanSnapshot snap;  // (re-used: with 128 VFOs a fresh one is a 38 KB allocation per block; a nested pass starts only after the outer plan has been restored)
     int rc = SDRPP_OK;
     if (as_tick) {
         HostScope hs("tick plan");
@@ -500,9 +500,12 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             c->pushes--;
             return rc;
         }
-        plan_snapshot(c, snap);
-        for (auto& kv : c->vfos) {
-            for (auto& s : kv.second->st) { stream_rotate(s); }
+        {
+            HostScope hs2("tick: snapshot + rotate");
+            plan_snapshot(c, snap);
+            for (auto& kv : c->vfos) {
+                for (auto& s : kv.second->st) { stream_rotate(s); }
+            }
         }
         fft_ring_rotate(c);
         if (c->pre.on) {
@@ -533,7 +536,10 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
                 }
                 else { rc = do_vfos_plan(c, src, count, iqc); }
             }
-            if (!rc && !c->tick_abort) { rc = tick_results_plan(c); }
+            if (!rc && !c->tick_abort) {
+                HostScope hs2("tick: results plan");
+                rc = tick_results_plan(c);
+            }
         }
         c->tick_planning = false;
         if (!rc && !c->tick_abort && c->plan_top > kTickDepth + 1) { c->tick_abort = true; }
@@ -572,6 +578,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         return rc;
     }
     // queue the roles level by level and launch this block's tick
+    HostScope hs3("tick: queue + launch");
     c->stat_tick_blocks++;
     c->stat_last_depth = c->plan_top;
     if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }

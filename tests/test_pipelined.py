@@ -58,7 +58,7 @@ def _compare(ref, got, fft, what):
             assert np.array_equal(ref["index"], got["index"]), what + " palette index"
 
 
-@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe"), (16384, "fcm16w")])
+@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe"), (4096, "fcm16w")])
 def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatch):
     """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks.  l0_at: the stage-0
@@ -400,6 +400,8 @@ def test_pipelined_equals_ordinary_with_preproc_chain(backend, ratio, dc, conj):
     lines bit-identical to ordinary passes; no block falls back except one the decimator swallows whole."""
     from sdrplusplus_amd import capi, radio, workloads
 
+    if backend == "emu" and (ratio, dc, conj) in ((4, False, False), (1, False, True)):
+        pytest.skip("emulator leg trimmed: the (2, DC, conjugate) and (1, DC) cases cover every role of the chain there; all four run on the device")
     nv = 20 if backend == "gpu" else 17
     eff = 10e6
     scale = 1 if backend == "gpu" else 2
