@@ -610,8 +610,9 @@ struct BankPlan {
         v.phi = p - std::floor(p);
         v.seen += n_in;
         // history carries for every stream that has a consumer with memory
+        const Stream* phantom = (v.fused_front && v.d.n_stages >= 2 && !v.nco_exact) ? &v.st[(size_t)v.i_first] : nullptr;  // stage-1 output of a fused front end: never written, never read
         for (auto& s : v.st) {
-            if (s.hist_len > 0 && s.data) {
+            if (s.hist_len > 0 && s.data && &s != phantom) {
                 // pipelined: at the level of the consumer (its window of the NEXT block reads the new history one tick later, the carry of
                 // the next block overwrites the old one one tick later still); a stream nobody reads with memory: behind the whole chain
                 const int cl = !ticking ? carry_last : (s.clevel > 0 ? s.clevel : lvl + 1);

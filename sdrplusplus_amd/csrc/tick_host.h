@@ -542,6 +542,13 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             }
         }
         c->tick_planning = false;
+        // the block's depth is where its last ROLE stands, not where the planners reserved room (a bank whose outputs stay on the device has
+        // nothing behind its last filter: one tick less until the block is complete, one tick less to drain)
+        if (!rc && !c->tick_abort) {
+            int top = 2;
+            for (auto& r : c->emits) { top = std::max(top, r.level + 1); }
+            c->plan_top = std::min(c->plan_top, top);
+        }
         if (!rc && !c->tick_abort && c->plan_top > kTickDepth + 1) { c->tick_abort = true; }
         if (rc || c->tick_abort) {
             plan_restore(c, snap);

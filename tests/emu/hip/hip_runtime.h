@@ -215,8 +215,18 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return 0;
 }
 
+namespace hipemu {
+// SDRPP_EMU_NO_EXEC: an argument that looks like the tick kernel's completion record gets its flag published, nothing else happens
+template <class T> static inline auto publish_done(const T& d, int) -> decltype((void)d.host_flag, (void)d.value, void()) { *d.host_flag = d.value; }
+template <class T> static inline void publish_done(const T&, long) {}
+}
 template <typename... KArgs, typename... Args>
 static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, Args... args) {
+    static const bool no_exec = getenv("SDRPP_EMU_NO_EXEC") != nullptr;  // host-planner timing runs (tools/plan_time_emu.py): nothing is computed
+    if (no_exec) {
+        (hipemu::publish_done(args, 0), ...);
+        return;
+    }
     std::lock_guard<std::mutex> launch_lck(hipemu::launch_mutex());  // one workgroup at a time PROCESS-wide: host threads take turns
     hipemu::State& s = hipemu::S();
     if (getenv("SDRPP_EMU_TRACE")) { fprintf(stderr, "[hipemu] launch grid=(%u,%u,%u) block=(%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z); }
