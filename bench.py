@@ -191,7 +191,7 @@ def algorithmic_work(push, plan, sr, nvfo, piped=False, fft_n=0, data_width=1024
     return fl, by, bound
 
 
-def pmc_traffic(cfg, push, nvfo, dom):
+def pmc_traffic(cfg, push, nvfo, dom, af=False):
     """HBM bytes per launch set of the dominant family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH_SIZE x2 per MI355X_MICROARCH.md, tools/rocpd_summary.py) — only when that profile was taken on this very workload."""
     for name in ("pmc_traffic_cfg%d_push%d.json" % (cfg, push), "pmc_traffic_cfg%d.json" % cfg, "pmc_traffic.json"):
@@ -201,7 +201,7 @@ def pmc_traffic(cfg, push, nvfo, dom):
         try:
             prof = json.load(open(path))
             meta = prof.get("_meta", {})
-            if int(meta.get("push", 0)) != push or int(meta.get("cfg", 0)) != cfg or int(meta.get("nvfo", -1)) != nvfo:
+            if int(meta.get("push", 0)) != push or int(meta.get("cfg", 0)) != cfg or int(meta.get("nvfo", -1)) != nvfo or bool(int(meta.get("af", 0))) != bool(af):
                 continue
             hits = [v["hbm_bytes_per_launch"] * v.get("launches_per_push", 1) for k, v in prof.items() if k != "_meta" and any(k.startswith(p) for p in FAMILY_KERNELS.get(dom, []))]
             if hits:
@@ -408,7 +408,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         if dom is not None and dom in kernel_ms and dom in by:
             dur = kernel_ms[dom] * 1e-3
             gbs = by[dom] / dur / 1e9
-            traffic = pmc_traffic(base, push, nvfo, dom)
+            traffic = pmc_traffic(base, push, nvfo, dom, af)
             if bound_of.get(dom) == "mfma" and fl.get(dom):
                 tf = fl[dom] / dur / 1e12
                 # pipelined: a timed region of K blocks holds K + depth - 1 launches (the last ones drain the pipeline and carry less than a block's
@@ -437,7 +437,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         for f in ("fft_pass1", "fft_pass2", "fft_single", "zoom_palette"):
             if f in kernel_ms_all and kernel_ms_all[f] > 0:
                 g = by[f] / (kernel_ms_all[f] * 1e-3) / 1e9
-                roof_fft[f] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(base, push, nvfo, f)}
+                roof_fft[f] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(base, push, nvfo, f, af)}
         per_gpu = value * 1e6 / world
         roof_path = {"bound": "hbm", "achieved": round(per_gpu * bps / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(per_gpu * bps / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_sample": bps, "algorithmic_TFLOPs": round(per_gpu * pflops / push / 1e12, 2), "frac_of_fp32_mfma_peak": round(per_gpu * pflops / push / 1e12 / FP32_PEAK_TFLOPS, 5),
@@ -592,6 +592,9 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
         ctx.set_deferred(False)
         pflops, _pb, _bps = path_work(B, info["plan"], sr, nvfo, N)
         entry["frac_of_fp32_mfma_peak"] = {k: round(v * 1e6 * pflops / B / 1e12 / FP32_PEAK_TFLOPS, 5) for k, v in entry.items() if isinstance(v, float) and k not in ("push",)}
+        tr = pmc_traffic(3, B, nvfo, "tick")  # pipelined mode, device-resident blocks (committed PMC passes of exactly this workload, or null)
+        entry["pipelined_tick_traffic_bytes_per_block"] = tr
+        entry["pipelined_tick_traffic_over_algorithmic"] = round(tr / _pb, 2) if tr else None
         for p in ptrs:
             ctx.L.sdrpp_host_free(p)
         ctx.close()

@@ -28,14 +28,17 @@ prof cfg3 ""
 prof cfg2 "--cfg 2"
 prof cfg4 "--cfg 4"
 prof cfg3_sr200 "--push 50000"
-for ctr in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES"; do
-    tag=$(echo $ctr | tr ' ' '_')
-    timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_mix_$tag -o p -- $BENCH --steps 60 --warmup 10 > $R/$O/pmc_mix_$tag.log 2>&1
+MIX=""
+i=0
+for ctr in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU" \
+           "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_mix_$i -o p -- $BENCH --steps 60 --warmup 10 > $R/$O/pmc_mix_$i.log 2>&1
+    MIX="$MIX $(find $R/$O/pmc_mix_$i -name '*.db' | head -1)"
 done
 cd $R
 db() { find $O/$1 -name "*.db" | head -1; }
-python tools/rocpd_summary.py $(db trace) --pmc $(db pmc_cfg3_FETCH_SIZE) $(db pmc_cfg3_WRITE_SIZE) $(db pmc_mix_SQ_INSTS_VALU_SQ_INSTS_SALU) $(db pmc_mix_SQ_INSTS_LDS_SQ_INSTS_VMEM) \
-    $(db pmc_mix_SQ_INSTS_VALU_MFMA_MOPS_F32_SQ_VALU_MFMA_BUSY_CYCLES) $(db pmc_mix_SQ_BUSY_CU_CYCLES_SQ_WAVE_CYCLES) \
+python tools/rocpd_summary.py $(db trace) --pmc $(db pmc_cfg3_FETCH_SIZE) $(db pmc_cfg3_WRITE_SIZE) $MIX \
     --out $O/${TAG}_cfg3_pipelined_1M.md --json $O/pmc_traffic_cfg3_push1000000.json \
     --title "round 4, final state: headline workload (cfg 3, pipelined mode, 10^6-sample blocks, zoomed lines delivered), python bench.py --no-others --no-by-push --no-cpu-baseline --no-self-check" \
     --meta push=1000000 cfg=3 nvfo=32 mode=pipelined 2>&1 | tail -2
@@ -53,4 +56,5 @@ for spec in "3 1000000 80" "3 50000 300" "4 1000000 60" "4 307200 80"; do
   rm -f $O/tt.bin
 done
 head -8 $O/tick_timeline_cfg3_B1000000.txt
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $O/pytest_gpu.log
 ls $O
