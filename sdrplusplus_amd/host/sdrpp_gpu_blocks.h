@@ -444,7 +444,7 @@ public:
                 pendingTickets.push_back(sdrpp_ticket(ctx));
                 if (!tapPending.empty() && tapPending.back().first == 0) { tapPending.back().first = sdrpp_ticket(ctx); }
                 SDRPP_PIPE_TICK(2)
-                // (a block's results are complete `depth` launches after its push — 7 levels for a WFM bank + FFT, 12 with the AF chain, 3 more behind a
+                // (a block's results are complete `depth` launches after its push — 6-7 levels for a WFM bank + FFT, 12 with the AF chain, 3 more behind a
                 // pre-processing chain: asking for them sooner makes the library run the missing stages as launches without new input)
                 int64_t pst[SDRPP_PIPELINE_STATS_HEAD] = {};
                 const int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(14, std::max(_pipeLag, (int)pst[4])) : _pipeLag;
