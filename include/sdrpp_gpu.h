@@ -395,7 +395,7 @@ int sdrpp_result_take_lines(sdrpp_ctx* ctx, uint64_t ticket, float* zoomed_dst, 
  * out[0] launches ("ticks") so far, [1] blocks that ran as ticks, [2] blocks that fell back to an ordinary pass, [3] ticks with more role
  * workgroups than the device holds at once (3 per CU: "crowded" order of the roles, tick_host.h), [4] levels of the most recent block (its
  * results are complete that many launches after its push), [5] number of roles R, [6] ticks launched in the four-wavefronts-per-SIMD build of
- * the tick kernel, [7] reserved; then out[8 + r], r < R: workgroups
+ * the tick kernel, [7] bytes of job tables the most recent block uploaded; then out[8 + r], r < R: workgroups
  * launched so far in role r (sdrpp_pipeline_role_name(r); e.g. "fcm16_132_4" = the front end in its small-block shape).
  * Returns the number of entries written (<= max).  Counters start at sdrpp_create. */
 #define SDRPP_PIPELINE_STATS_HEAD 8

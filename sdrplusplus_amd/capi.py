@@ -665,7 +665,7 @@ class Context:
         for r in range(nroles):
             if 8 + r < n and buf[8 + r]:
                 roles[self.L.sdrpp_pipeline_role_name(r).decode()] = int(buf[8 + r])
-        return dict(ticks=int(buf[0]), tick_blocks=int(buf[1]), pass_blocks=int(buf[2]), crowded_ticks=int(buf[3]), depth=int(buf[4]), set2_ticks=int(buf[6]), roles=roles)
+        return dict(ticks=int(buf[0]), tick_blocks=int(buf[1]), pass_blocks=int(buf[2]), crowded_ticks=int(buf[3]), depth=int(buf[4]), set2_ticks=int(buf[6]), table_bytes=int(buf[7]), roles=roles)
 
     # measurement
     def timing_enable(self, on=True, families=None):

@@ -245,6 +245,7 @@ struct sdrpp_ctx {
 
     // VFOs
     std::map<int, std::unique_ptr<Vfo>> vfos;
+    std::vector<Vfo*> vfo_list;           // the same VFOs in id order (rebuilt on add / remove): what the per-block loops walk
     int next_id = 1;
     // cached stage-1 job tap arrays, keyed by membership signature
     std::map<std::string, float2*> s1_tap_cache;  // key = 16 raw bytes: two independent 64-bit hashes of (kind, member ids, increments)
@@ -367,7 +368,7 @@ struct sdrpp_ctx {
     void* bank_plan = nullptr;            // the context's BankPlan (plan_vfo.h), re-used block after block
     void (*bank_plan_free)(void*) = nullptr;
     // how the blocks of a pipelined run were executed (sdrpp_pipeline_stats: tests and bench.py assert the mode they mean to measure)
-    int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0, stat_set2 = 0;
+    int64_t stat_tick_blocks = 0, stat_pass_blocks = 0, stat_crowded = 0, stat_last_depth = 0, stat_set2 = 0, stat_last_table_bytes = 0;
     int64_t stat_role_wgs[64] = {};
 
     // timing

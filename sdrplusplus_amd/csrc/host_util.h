@@ -105,6 +105,11 @@ struct FamilyTimer {
     }
 };
 
+// ---- the VFOs as a list (per-block loops) ----------------------------------------------------------------------------------------------
+void vfo_list_rebuild(sdrpp_ctx* c) {
+    c->vfo_list.clear();
+    for (auto& kv : c->vfos) { c->vfo_list.push_back(kv.second.get()); }
+}
 // ---- job arena -------------------------------------------------------------------------------------------------------------
 void tick_wait_done(sdrpp_ctx* c, uint64_t nticks);
 int arena_begin(sdrpp_ctx* c) {

@@ -14,17 +14,20 @@ struct PlanSnapshot {
     bool wf_have;
     int pre_soff[SDRPP_MAX_DECIM_STAGES], pre_state, pre_raw_cur, pre_cur[SDRPP_MAX_DECIM_STAGES];
 };
-void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
-    S.v.resize(c->vfos.size());
-    size_t i = 0;
-    for (auto& kv : c->vfos) {
-        Vfo& v = *kv.second;
-        PlanSnapshot::V& q = S.v[i++];
+// `rotate`: pipelined mode — every stream of the VFO moves on to its next ring buffer in the same walk (stream_rotate)
+void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S, bool rotate = false) {
+    S.v.resize(c->vfo_list.size());
+    for (size_t i = 0; i < c->vfo_list.size(); i++) {
+        Vfo& v = *c->vfo_list[i];
+        PlanSnapshot::V& q = S.v[i];
         for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { q.soff[k] = v.soff[k]; q.af_soff[k] = v.af.soff[k]; }
         q.pphase = v.pphase; q.poff = v.poff; q.phi = v.phi; q.phi2 = v.phi2; q.seen = v.seen; q.i_if = v.i_if; q.lvl_if = v.lvl_if; q.lvl_out = v.lvl_out; q.lvl_af = v.lvl_af;
         q.nrecs = v.recs.size();
         q.af_pphase = v.af.pphase; q.af_poff = v.af.poff; q.af_last = v.af.i_last; q.af_state = v.af.state_cur;
         for (size_t k = 0; k < v.st.size() && k < 24; k++) { q.n[k] = v.st[k].n; q.cur[k] = v.st[k].cur; }
+        if (rotate) {
+            for (auto& st : v.st) { stream_rotate(st); }
+        }
     }
     S.fft_pos = c->fft_pos; S.fft_next = c->fft_next; S.n_lines = c->n_lines; S.iq_cur = c->iq_cur;
     S.wf_cur = c->wf.cur; S.wf_lines = c->wf.lines; S.wf_have = c->wf.have_latest;
@@ -35,10 +38,9 @@ void plan_snapshot(sdrpp_ctx* c, PlanSnapshot& S) {
 }
 // (retune records a plan has dropped stay dropped: they were out of every window's reach)
 void plan_restore(sdrpp_ctx* c, const PlanSnapshot& S) {
-    size_t i = 0;
-    for (auto& kv : c->vfos) {
-        Vfo& v = *kv.second;
-        const PlanSnapshot::V& q = S.v[i++];
+    for (size_t i = 0; i < c->vfo_list.size(); i++) {
+        Vfo& v = *c->vfo_list[i];
+        const PlanSnapshot::V& q = S.v[i];
         for (int k = 0; k < SDRPP_MAX_DECIM_STAGES; k++) { v.soff[k] = q.soff[k]; v.af.soff[k] = q.af_soff[k]; }
         v.pphase = q.pphase; v.poff = q.poff; v.phi = q.phi; v.phi2 = q.phi2; v.seen = q.seen; v.i_if = q.i_if; v.lvl_if = q.lvl_if; v.lvl_out = q.lvl_out; v.lvl_af = q.lvl_af;
         v.af.pphase = q.af_pphase; v.af.poff = q.af_poff; v.af.i_last = q.af_last; v.af.state_cur = q.af_state;

@@ -1288,8 +1288,8 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     int rc = SDRPP_OK;
     {
         HostScope hs("plan: chains");
-        for (auto& kv : c->vfos) {
-            rc = P->chain(*kv.second);
+        for (size_t i = 0; i < c->vfo_list.size(); i++) {
+            rc = P->chain(*c->vfo_list[i]);
             if (rc) { return rc; }
         }
     }
@@ -1308,8 +1308,8 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
     }
     if (rc) { return rc; }
     // flip the ping-pong side of every carried stream
-    for (auto& kv : c->vfos) {
-        for (auto& s : kv.second->st) {
+    for (size_t i = 0; i < c->vfo_list.size(); i++) {
+        for (auto& s : c->vfo_list[i]->st) {
             if (s.hist_len > 0 && s.data) { s.cur ^= 1; }
         }
     }

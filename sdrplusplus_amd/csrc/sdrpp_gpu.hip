@@ -915,6 +915,7 @@ int sdrpp_vfo_add(sdrpp_ctx* c, const sdrpp_vfo_desc* d, int* id) {
     const int vid = v->id;  // (the right-hand side of the assignment below is evaluated first)
     *id = vid;
     c->vfos[vid] = std::unique_ptr<Vfo>(v.release());
+    vfo_list_rebuild(c);
     return SDRPP_OK;
 }
 
@@ -927,6 +928,7 @@ int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     vfo_free(*it->second);
     c->vfos.erase(it);
+    vfo_list_rebuild(c);
     return SDRPP_OK;
 }
 
@@ -1808,7 +1810,7 @@ int sdrpp_result_take_lines(sdrpp_ctx* c, uint64_t ticket, float* zoomed_dst, in
 }
 int sdrpp_pipeline_stats(sdrpp_ctx* c, int64_t* out, int max) {
     if (!c || !out || max < 0) { return SDRPP_ERR_INVALID; }
-    const int64_t head[SDRPP_PIPELINE_STATS_HEAD] = { (int64_t)c->ticks, c->stat_tick_blocks, c->stat_pass_blocks, c->stat_crowded, c->stat_last_depth, (int64_t)TR_COUNT, c->stat_set2, 0 };
+    const int64_t head[SDRPP_PIPELINE_STATS_HEAD] = { (int64_t)c->ticks, c->stat_tick_blocks, c->stat_pass_blocks, c->stat_crowded, c->stat_last_depth, (int64_t)TR_COUNT, c->stat_set2, c->stat_last_table_bytes };
     int n = 0;
     for (; n < SDRPP_PIPELINE_STATS_HEAD && n < max; n++) { out[n] = head[n]; }
     for (int r = 0; r < TR_COUNT && n < max; r++, n++) { out[n] = c->stat_role_wgs[r]; }

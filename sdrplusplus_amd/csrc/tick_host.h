@@ -74,10 +74,12 @@ inline int tick_role_weight(int role, bool crowded) {
     // blocks (profiles/r03z_tick_p1_weight.log; SDRPP_GPU_TICK_P1_WEIGHT: measurement switch)
     static const int p1_weight = getenv("SDRPP_GPU_TICK_P1_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_P1_WEIGHT")) : 0;
     if (role >= TR_FFT_P1_5 && role <= TR_FFT_P1_10) { return p1_weight > 0 ? p1_weight : (crowded ? 45 : 70); }
-    // the long first stages (cfg 4): far more workgroups than the GPU holds — behind the sequential recursions and the filters, whose few long
-    // workgroups then run beside them instead of after them (10^6-sample blocks 4.25 -> 4.33 GS/s, 307 200: 3.08 -> 3.24;
-    // profiles/r03zj_tick_fcl_weight.log; SDRPP_GPU_TICK_FCL_WEIGHT: measurement switch)
-    static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 58;
+    // the long first stages (cfg 4): far more workgroups than the GPU holds, 58 us each — behind the sequential recursions (few, long), in front
+    // of everything else: with four tile engines per workgroup they are 60 % of the tick's workgroup time, and started late they ARE its tail
+    // (weight 72 against 58: 10^6-sample blocks 6.02 -> 6.13 GS/s, 307 200: 3.19 -> 3.78; behind the filters, 40 / 15: 5.77 / 5.64 and 3.11 / 3.07;
+    // profiles/r04w_fcl_weight.log — with two engines per workgroup, round 3, the order hardly mattered: profiles/r03zj_*;
+    // SDRPP_GPU_TICK_FCL_WEIGHT: measurement switch)
+    static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 72;
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
@@ -502,10 +504,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         }
         {
             HostScope hs2("tick: snapshot + rotate");
-            plan_snapshot(c, snap);
-            for (auto& kv : c->vfos) {
-                for (auto& s : kv.second->st) { stream_rotate(s); }
-            }
+            plan_snapshot(c, snap, true);  // (and every VFO stream on to its next ring buffer, in the same walk)
         }
         fft_ring_rotate(c);
         if (c->pre.on) {
@@ -588,6 +587,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
     HostScope hs3("tick: queue + launch");
     c->stat_tick_blocks++;
     c->stat_last_depth = c->plan_top;
+    c->stat_last_table_bytes = (int64_t)c->arena_off;  // job tables of this block (the next tick's role table is added at the launch)
     if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }
     for (auto& r : c->emits) { c->tickq[(size_t)r.level].push_back(r); }
     c->emits.clear();

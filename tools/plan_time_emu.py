@@ -23,5 +23,6 @@ t0 = time.perf_counter()
 for t in range(nblk):
     ctx.push_device(ptr, B)
 dt = (time.perf_counter() - t0) / nblk
-print("cfg %d, %d-sample blocks: %.1f us of host work per block (%s)" % (cfg, B, dt * 1e6, ctx.pipeline_stats()["tick_blocks"]))
+st = ctx.pipeline_stats()
+print("cfg %d, %d-sample blocks: %.1f us of host work per block (%d blocks as ticks, %d levels, %d bytes of job tables per block)" % (cfg, B, dt * 1e6, st["tick_blocks"], st["depth"], st["table_bytes"]))
 ctx.close()
