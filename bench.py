@@ -872,7 +872,7 @@ def main():
             try:
                 ocN = workloads.CFG[oc]["fft"]
                 ocv = 0 if oc == 2 else 128
-                r1, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 60, 10, ocv)
+                r1, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 200, 14, ocv)  # (200 steps: fill and drain of a 5 .. 12 level pipeline are 3-6 % of the region, not 10-20 %)
                 del inp
                 torch.cuda.empty_cache()
                 r2, inp = run_workload(torch, np, device, local, oc, max(1, (1 << 24) // ocN) * ocN, "ordinary", 5, 2, ocv, ref_block=0)
@@ -880,7 +880,7 @@ def main():
                 torch.cuda.empty_cache()
                 others["cfg%d" % oc] = {"workload": r1["workload"], "pipelined_stream_cap": compact(r1), "ceiling_2p24_ordinary": compact(r2)}
                 if oc == 2 and cfg == 3:  # the headline workload with the radio module's AF chain behind every VFO (radio_module.h:98-110: the AF resampler is always on)
-                    ra, inp = run_workload(torch, np, device, local, 3, STREAM_CAP, "pipelined", 60, 14, nvfo, af=True)
+                    ra, inp = run_workload(torch, np, device, local, 3, STREAM_CAP, "pipelined", 200, 14, nvfo, af=True)
                     del inp
                     torch.cuda.empty_cache()
                     others["cfg3_af"] = {"workload": ra["workload"] + " + AF chain (resampler to 48 kHz, 50 us de-emphasis) on every VFO", "pipelined_stream_cap": compact(ra),
