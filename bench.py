@@ -205,7 +205,7 @@ def pmc_traffic(cfg, push, nvfo, dom, af=False):
                 continue
             hits = [v["hbm_bytes_per_launch"] * v.get("launches_per_push", 1) for k, v in prof.items() if k != "_meta" and any(k.startswith(p) for p in FAMILY_KERNELS.get(dom, []))]
             if hits:
-                return round(sum(hits))
+                return round(max(hits) if dom == "tick" else sum(hits))  # (a tick is ONE launch; cfg 4's profile holds both builds of the tick kernel: the steady-state one is the larger)
         except Exception:
             pass
     return None
