@@ -339,7 +339,7 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * every sdrpp_push* launches ONE kernel ("tick") that runs the arrival of block n (its copy into device memory, the upload of its job
  * tables) next to the front end / FFT pass 1 of block n - 1, the first decimator / FFT pass 2 of block n - 2, ... — every stage of every
  * block exactly as in an ordinary pass (same kernels' bodies, same arithmetic: results are bit-identical), only not one after the
- * other.  A block's results are complete `depth` launches later (depth <= 18; 7 for a WFM bank + 65536-point FFT, 12 with the AF chain): with the next blocks, or at once when the
+ * other.  A block's results are complete `depth` launches later (depth <= 18: where the block's last role stands; 6 for a WFM bank + 65536-point FFT whose outputs stay on the device, 7 with its VFO blocks delivered, 12 with the AF chain): with the next blocks, or at once when the
  * caller asks (sdrpp_pipeline_flush, sdrpp_result_wait, any observing call such as sdrpp_vfo_read / sdrpp_sync — these run the queued
  * stages without new input; sdrpp_fft_lines and sdrpp_vfo_out_count only report what the host already knows and do not).
  *   sdrpp_push_device        reads the caller's buffer IN PLACE one launch later at the earliest: it must stay valid until sdrpp_sync.
@@ -355,7 +355,12 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * without any copy call: 1 = every VFO's output block (the end of its chain: the AF chain's output where one is attached, else what
  * sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines, 8 = the pre-processed IQ stream of the block (only with a
  * pre-processing chain configured: without one it is the input block itself).
- * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push). */
+ * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push).
+ * HOW FAR BEHIND TO ASK: a streaming host takes block t - lag when it has pushed block t.  With lag >= depth + 1 (sdrpp_pipeline_stats
+ * out[4]: 6-7 levels for a radio bank + FFT, 10 for cfg 4's NFM / AM / SSB chains, 12 with AF chains, + the levels of a pre-processing chain)
+ * sdrpp_result_wait finds the block complete.  With a smaller lag it must run the queued stages and WAIT for the device at every call: host
+ * and device then take turns instead of overlapping (measured: cfg 4, lag 8 against 10 levels, 213 instead of 165 us per block).
+ * sdrpp_gpu::IQFrontEnd and bench.py follow the reported depth (up to 14, leaving two of the 16 slots to the blocks in the making). */
 /* Host blocks in pipelined mode without the library's own copy: sdrpp_push_stage hands out the page-locked staging slot the next block is
  * fetched from (room for max_push samples); the host fills it — with several threads if it likes: a 400 KB memcpy is the largest single
  * item of a 50 000-sample block's host time — and its own buffer is free as soon as it has; sdrpp_push_staged then launches the block

@@ -133,6 +133,10 @@ class StreamRunner:
         """Collect every outstanding block (the first result_wait runs the queued stages), hand over the last partial batch."""
         if not self.pipelined:
             return
+        # end of the stream: everything still queued is launched in one go (sdrpp_pipeline_flush does not wait) — collecting the last blocks
+        # one by one would launch one tick, wait for it, launch the next ...
+        if self.tickets and hasattr(self.ctx, "pipeline_flush"):
+            self.ctx.pipeline_flush()
         while self.tickets:
             self._collect(self.tickets.pop(0))
         self._flush_batch()
