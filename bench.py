@@ -356,8 +356,8 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
     if pipelined:
         # a block's results are complete `depth` launches after its push (sdrpp_pipeline_stats): a host that asks for them EARLIER makes
         # sdrpp_result_wait run the queued stages and wait for the device at every step — host work and device work then take turns instead
-        # of overlapping (cfg 4: 10 levels against a lag of 8 cost 213 instead of 150 us per step).  At most 16 result slots exist.
-        need = min(14, int(ctx.pipeline_stats()["depth"]) + 1)
+        # of overlapping (cfg 4: 10 levels against a lag of 8 cost 213 instead of 165 us per step).  SDRPP_RESULT_SLOTS = 24 result slots exist.
+        need = min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1)
         if need > runner.lag:
             runner.lag = lag = need
     # calibration (untimed): every kernel family bracketed by HIP events to find the dominant one and record the per-kernel split

@@ -355,12 +355,12 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * without any copy call: 1 = every VFO's output block (the end of its chain: the AF chain's output where one is attached, else what
  * sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines, 8 = the pre-processed IQ stream of the block (only with a
  * pre-processing chain configured: without one it is the input block itself).
- * At most 16 blocks' results exist at a time: release them (a block whose slot is still held 16 pushes later fails the push).
+ * At most SDRPP_RESULT_SLOTS (24) blocks' results exist at a time: release them (a block whose slot is still held 24 pushes later fails the push).
  * HOW FAR BEHIND TO ASK: a streaming host takes block t - lag when it has pushed block t.  With lag >= depth + 1 (sdrpp_pipeline_stats
  * out[4]: 6-7 levels for a radio bank + FFT, 10 for cfg 4's NFM / AM / SSB chains, 12 with AF chains, + the levels of a pre-processing chain)
  * sdrpp_result_wait finds the block complete.  With a smaller lag it must run the queued stages and WAIT for the device at every call: host
  * and device then take turns instead of overlapping (measured: cfg 4, lag 8 against 10 levels, 213 instead of 165 us per block).
- * sdrpp_gpu::IQFrontEnd and bench.py follow the reported depth (up to 14, leaving two of the 16 slots to the blocks in the making). */
+ * sdrpp_gpu::IQFrontEnd and bench.py follow the reported depth (up to 22, leaving two of the 24 slots to the blocks in the making). */
 /* Host blocks in pipelined mode without the library's own copy: sdrpp_push_stage hands out the page-locked staging slot the next block is
  * fetched from (room for max_push samples); the host fills it — with several threads if it likes: a 400 KB memcpy is the largest single
  * item of a 50 000-sample block's host time — and its own buffer is free as soon as it has; sdrpp_push_staged then launches the block
@@ -372,6 +372,7 @@ int sdrpp_push_staged(sdrpp_ctx* ctx, int64_t count);
  * reads the slot.  `pending` = the number of unfinished parts of the caller's copy, decremented (release order) by the copying threads;
  * a word that does not reach 0 within 5 s fails the push.  sdrpp_gpu::IQFrontEnd's pipelined worker stages its blocks this way. */
 int sdrpp_push_staged_when(sdrpp_ctx* ctx, int64_t count, const volatile uint32_t* pending);
+#define SDRPP_RESULT_SLOTS 24
 typedef struct sdrpp_result {
     uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
     int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */

@@ -98,7 +98,8 @@ class Result(C.Structure):
     ]
 
 
-ABI_VERSION = 2  # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
+ABI_VERSION = 2
+RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: blocks whose pipelined results can exist at a time  # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
 
 
 class SdrppError(RuntimeError):

@@ -8,7 +8,7 @@ constexpr int kArenaSlots = 24;     // >= kTickDepth + 2: a block's job tables a
 constexpr size_t kArenaBytes = 4u << 20;
 constexpr int kRing = 4;            // pipelined mode: buffers per per-block stream (a consumer runs at most 2 ticks behind its producer; + the gather)
 constexpr int kTickDepth = 18;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit()): pre-processing chain 3 + VFO chain 5 + AF chain 5 + result copy
-constexpr int kResSlots = 16;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
+constexpr int kResSlots = SDRPP_RESULT_SLOTS;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
 constexpr int kStageSlots = 4;      // pipelined mode: page-locked staging buffers for pushes from pageable host memory
 constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
 constexpr size_t kScratchBytes = 64u << 20;

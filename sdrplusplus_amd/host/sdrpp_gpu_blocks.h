@@ -447,7 +447,7 @@ public:
                 // (a block's results are complete `depth` launches after its push — 6-7 levels for a WFM bank + FFT, 12 with the AF chain, 3 more behind a
                 // pre-processing chain: asking for them sooner makes the library run the missing stages as launches without new input)
                 int64_t pst[SDRPP_PIPELINE_STATS_HEAD] = {};
-                const int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(14, std::max(_pipeLag, (int)pst[4])) : _pipeLag;
+                const int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(SDRPP_RESULT_SLOTS - 2, std::max(_pipeLag, (int)pst[4] + 1)) : _pipeLag;
                 if ((int)pendingTickets.size() > lagNow) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
                     const uint64_t t = pendingTickets.front();
                     pendingTickets.erase(pendingTickets.begin());

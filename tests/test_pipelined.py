@@ -212,41 +212,42 @@ def test_pipelined_result_slots_and_modes(backend):
     from sdrplusplus_amd import capi, workloads
 
     nv, B = (20, 4000) if backend == "gpu" else (17, 2000)  # (>= 17 VFOs: the matrix-core front end, i.e. blocks that really run as ticks)
-    x = workloads.synth(3, B * 40, seed=3, nvfo=nv)
+    S = capi.RESULT_SLOTS
+    x = workloads.synth(3, B * (S + 12), seed=3, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 0, flags=1)
     with pytest.raises(capi.SdrppError):
         cb.set_deferred(True)
     refs = []
-    for i in range(20):
+    for i in range(S + 4):
         blk = x[i * B:(i + 1) * B]
         refs.append(_ordinary_results(ca, va, blk, False))
         cb.push(blk)
-    # 16 slots: blocks 1 .. 4 have been overwritten by 17 .. 20
+    # S slots: blocks 1 .. 4 have been overwritten by S + 1 .. S + 4
     with pytest.raises(capi.SdrppError):
         cb.result_wait(2)
     got = cb.result_wait(7)
     _compare({"vfo": dict(zip(vb, refs[6]["vfo"].values()))}, got, False, "block 7")
-    assert cb.result_ready(20) in (True, False)
+    assert cb.result_ready(S + 4) in (True, False)
     cb.pipeline_flush()
     cb.sync()
-    assert cb.result_ready(20)
+    assert cb.result_ready(S + 4)
     # block 7 is still held: pushing on until its slot comes round again must fail, and work again after the release
     with pytest.raises(capi.SdrppError):
-        for i in range(20, 40):
+        for i in range(S + 4, S + 12):
             cb.push(x[i * B:(i + 1) * B])
-    assert cb.ticket() == 22  # block 23 would have needed slot 7
+    assert cb.ticket() == S + 6  # block S + 7 would have needed slot 7
     cb.result_release(7)
-    blk = x[22 * B:23 * B]
-    for i in range(20, 22):
+    blk = x[(S + 6) * B:(S + 7) * B]
+    for i in range(S + 4, S + 6):
         _ordinary_results(ca, va, x[i * B:(i + 1) * B], False)
     ref = _ordinary_results(ca, va, blk, False)
     cb.push(blk)
-    got = cb.result_wait(23)
-    _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block 23")
+    got = cb.result_wait(S + 7)
+    _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block S + 7")
     # leaving the mode flushes; ordinary passes continue the same streams
-    cb.result_release(23)
+    cb.result_release(S + 7)
     cb.set_pipelined(False)
-    blk = x[23 * B:24 * B]
+    blk = x[(S + 7) * B:(S + 8) * B]
     ref = _ordinary_results(ca, va, blk, False)
     cb.push(blk)
     for v_a, v_b in zip(va, vb):
