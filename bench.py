@@ -613,11 +613,18 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
             csrc = os.path.join(ROOT, "sdrplusplus_amd", "csrc")
             subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "bench_blocks.cpp"), "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"),
                             "-L" + csrc, "-lsdrpp_gpu", "-Wl,-rpath," + csrc, "-lpthread"], check=True, capture_output=True)
-            for name, buffered, pipelined in (("bypass_pipelined", 0, 1), ("bypass_per_block", 0, 0), ("buffered", 1, 0)):
-                r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "3", str(buffered), str(pipelined)],
-                                   capture_output=True, text=True, timeout=120)
-                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                res["cpp_iqfrontend_run_%s" % name] = json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]}
+            for name, buffered, pipelined, reps in (("bypass_pipelined", 0, 1, 3), ("bypass_per_block", 0, 0, 1), ("buffered", 1, 0, 1)):
+                runs = []  # (the pipelined figure depends on how the host schedules 34 threads: three runs, median reported, all three listed)
+                for _ in range(reps):
+                    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "2" if reps > 1 else "3", str(buffered), str(pipelined)],
+                                       capture_output=True, text=True, timeout=120)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    runs.append(json.loads(line[-1]) if line else {"error": (r.stdout + r.stderr)[-300:]})
+                good = sorted((q for q in runs if "msps" in q), key=lambda q: q["msps"])
+                entry = dict(good[len(good) // 2]) if good else runs[-1]
+                if len(good) > 1:
+                    entry["msps_runs"] = [q["msps"] for q in good]
+                res["cpp_iqfrontend_run_%s" % name] = entry
     except Exception as e:
         res["cpp_iqfrontend_run"] = {"error": repr(e)[:300]}
     res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push (ordinary pass); pipelined_* = sdrpp_set_pipelined, one launch per "
