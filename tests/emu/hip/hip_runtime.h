@@ -4,10 +4,13 @@
 // It is NOT a fallback: the product library is always the hipcc build, the Python binding refuses to load this file
 // unless a test asks for it explicitly, and no `-m gpu` test, smoke() or bench.py ever touches it.
 //
-// Model: one workgroup at a time; each work-item is a ucontext fiber; __syncthreads() yields round-robin until all
-// fibers of the block have arrived.  Only the HIP subset the product uses is provided.
+// Model: one workgroup at a time; each work-item is a fiber (a stack of its own and a register switch in user space: glibc's swapcontext
+// makes two signal-mask system calls per switch, which was a third of the CPU suite's run time); __syncthreads() yields round-robin until
+// all fibers of the block have arrived.  Only the HIP subset the product uses is provided.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -39,12 +42,31 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 static inline int2 make_int2(int x, int y) { return int2{ x, y }; }
 
 namespace hipemu {
+#if defined(__x86_64__)
+    // switch(from, to): callee-saved registers + the floating-point control words go onto the current stack, its pointer into *from; then
+    // the same in reverse from the stack `to` points at.  A fresh fiber's stack is laid out as if it had once called this function.
+    __attribute__((naked, noinline)) static void fiber_switch(void** /*from_sp*/, void* /*to_sp*/) {
+        asm volatile(
+            "pushq %rbp\n\t" "pushq %rbx\n\t" "pushq %r12\n\t" "pushq %r13\n\t" "pushq %r14\n\t" "pushq %r15\n\t"
+            "subq $8, %rsp\n\t" "stmxcsr (%rsp)\n\t" "fnstcw 4(%rsp)\n\t"
+            "movq %rsp, (%rdi)\n\t"
+            "movq %rsi, %rsp\n\t"
+            "ldmxcsr (%rsp)\n\t" "fldcw 4(%rsp)\n\t" "addq $8, %rsp\n\t"
+            "popq %r15\n\t" "popq %r14\n\t" "popq %r13\n\t" "popq %r12\n\t" "popq %rbx\n\t" "popq %rbp\n\t"
+            "ret\n\t");
+    }
+#endif
     struct State {
         dim3 tIdx, bIdx, bDim, gDim;
+#if defined(__x86_64__)
+        std::vector<void*> sp;
+        void* sched_sp = nullptr;
+#else
         std::vector<ucontext_t> ctx;
+        ucontext_t sched;
+#endif
         std::vector<char*> stacks;
         std::vector<int> done;
-        ucontext_t sched;
         int cur = -1;
         std::function<void()> body;
         alignas(64) char dynshared[160 * 1024];
@@ -57,12 +79,21 @@ namespace hipemu {
     };
     inline State& S() { static State s; return s; }
     inline std::mutex& launch_mutex() { static std::mutex m; return m; }  // (a function-local static: ONE for all kernel templates)
+    inline void to_scheduler() {
+        State& s = S();
+#if defined(__x86_64__)
+        fiber_switch(&s.sp[s.cur], s.sched_sp);
+#else
+        swapcontext(&s.ctx[s.cur], &s.sched);
+#endif
+    }
     inline void trampoline() {
         State& s = S();
         s.body();
         s.done[s.cur] = 1;
         s.ndone++;
-        swapcontext(&s.ctx[s.cur], &s.sched);
+        to_scheduler();  // (never resumed)
+        abort();
     }
     inline void set_tid(int i) {
         State& s = S();
@@ -73,12 +104,16 @@ namespace hipemu {
     inline void run_block(int nthreads) {
         State& s = S();
         const size_t STK = 256 * 1024;
-        if ((int)s.ctx.size() < nthreads) {
-            size_t old = s.ctx.size();
-            s.ctx.resize(nthreads);
+        if ((int)s.stacks.size() < nthreads) {
+            size_t old = s.stacks.size();
             s.stacks.resize(nthreads, nullptr);
             for (size_t i = old; i < (size_t)nthreads; i++) { s.stacks[i] = (char*)malloc(STK); }
         }
+#if defined(__x86_64__)
+        s.sp.resize(s.stacks.size());
+#else
+        s.ctx.resize(s.stacks.size());
+#endif
         s.done.assign(nthreads, 0);
         s.nthreads = nthreads;
         s.ndone = 0;
@@ -89,11 +124,25 @@ namespace hipemu {
         s.wx_count.assign((size_t)nwaves * 2, 0ull);
         s.wx_buf.assign((size_t)nwaves * 2 * 128, 0.0f);
         for (int i = 0; i < nthreads; i++) {
+#if defined(__x86_64__)
+            // [mxcsr | x87 control word] r15 r14 r13 r12 rbx rbp, return address = trampoline; at the `ret` the stack pointer is 8 past a
+            // 16-byte boundary, as at every function entry
+            uintptr_t top = (reinterpret_cast<uintptr_t>(s.stacks[i]) + STK) & ~(uintptr_t)15;
+            uint64_t* q = reinterpret_cast<uint64_t*>(top) - 2;  // q[0]: return address (16-byte aligned slot), q[1]: padding
+            q[0] = reinterpret_cast<uint64_t>(reinterpret_cast<void*>(&trampoline));
+            q[1] = 0;
+            for (int k = 1; k <= 6; k++) { q[-k] = 0; }
+            uint32_t* cw = reinterpret_cast<uint32_t*>(q - 7);
+            cw[0] = 0x1F80u;  // mxcsr: round to nearest, all exceptions masked
+            cw[1] = 0x037Fu;  // x87 control word
+            s.sp[i] = q - 7;
+#else
             getcontext(&s.ctx[i]);
             s.ctx[i].uc_stack.ss_sp = s.stacks[i];
             s.ctx[i].uc_stack.ss_size = STK;
             s.ctx[i].uc_link = &s.sched;
             makecontext(&s.ctx[i], (void (*)())trampoline, 0);
+#endif
         }
         int remaining = nthreads;
         while (remaining > 0) {
@@ -102,7 +151,11 @@ namespace hipemu {
                 if (s.done[i]) { continue; }
                 s.cur = i;
                 set_tid(i);
+#if defined(__x86_64__)
+                fiber_switch(&s.sched_sp, s.sp[i]);
+#else
                 swapcontext(&s.sched, &s.ctx[i]);
+#endif
                 if (!s.done[i]) { remaining++; }
             }
         }
@@ -110,7 +163,7 @@ namespace hipemu {
     inline void yield() {
         State& s = S();
         int me = s.cur;
-        swapcontext(&s.ctx[me], &s.sched);
+        to_scheduler();
         s.cur = me;
         set_tid(me);
     }

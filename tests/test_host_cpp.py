@@ -92,9 +92,9 @@ def test_host_mirror_threaded_graph_on_the_emulator(mode):
     source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
     flushInputBuffer, retune while running.  A logic check of the host code; the device leg is test_threaded_graph_matches_oracle."""
     # (pipelined: the source is decoupled from the emulated launch by one more block and the 20-VFO bank takes seconds per block there,
-    # so "everything handed over has been consumed" needs a longer wait before the change of source)
+    # so "everything handed over has been consumed" needs a longer wait before the change of source; the figures are ~5 x what the emulator needs since its fibers switch in user space)
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=12000 if mode == "pipelined" else 4000)
+        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=6000 if mode == "pipelined" else 3000)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/core/src/dsp"), reason="needs the reference tree")
@@ -105,7 +105,7 @@ def test_host_mirror_links_and_runs_against_the_reference_headers():
     virtual of the real interface."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/demod_iface.h"], check=True)
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp, drain_ms=4000)
+        _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp, drain_ms=3000)
 
 
 def test_device_math_helpers():

@@ -116,8 +116,8 @@ def test_small_block_front_end_shape_is_bit_identical(backend, monkeypatch):
     from sdrplusplus_amd import workloads
 
     sr = 10e6
-    for nv in ((32, 20) if backend == "gpu" else (20,)):  # (the emulator leg: one partly filled job, smaller pushes)
-        pushes = [50000, 1031, 20000, 7, 33333, 50000] if backend == "gpu" else [20000, 1031, 7, 9000]
+    for nv in (32, 20):
+        pushes = [50000, 1031, 20000, 7, 33333, 50000]
         x = workloads.synth(3, sum(pushes), seed=13, nvfo=nv)
         plan = workloads.vfo_plan(3, nv)
         for pipelined in (False, True):
@@ -327,7 +327,7 @@ def test_reference_rotator_four_wavefront_kernel_is_bit_identical(backend, monke
         monkeypatch.setenv("SDRPP_GPU_ROTX_VPW", vpw)
     sr = 10e6
     specs = ARB_SPECS + [("RAW", 123456.0)]
-    pushes = [50000, 63, 1, 120001, 64, 8 * 64 + 5, 70000, 100000] if backend == "gpu" else [50000, 63, 1, 64, 8 * 64 + 5, 20001]
+    pushes = [50000, 63, 1, 120001, 64, 8 * 64 + 5, 70000, 100000]
     x = _two_tone_mix(sr, sum(pushes), specs, 31)
     outs = []
     for single in (True, False):

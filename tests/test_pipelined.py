@@ -58,16 +58,14 @@ def _compare(ref, got, fft, what):
             assert np.array_equal(ref["index"], got["index"]), what + " palette index"
 
 
-@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "pipe"), (4096, "fcm16w")])
+@pytest.mark.parametrize("fft_size,l0_at", [(4096, None), (16384, None), (4096, "37"), (4096, "-1"), (4096, "pipe"), (4096, "fcm16w")])
 def test_pipelined_equals_ordinary_wfm_bank(backend, fft_size, l0_at, monkeypatch):
     """20 WFM VFOs at 10 MS/s (matrix-core front end, four Toeplitz stages behind it) + the FFT branch (one-pass and two-pass sizes):
     uneven blocks — histories, tile and frame boundaries, a block that completes no frame, one-sample-scale blocks.  l0_at: the stage-0
-    copies of a tick (landing copy, job-table upload) behind the first 37 role workgroups instead of in front (SDRPP_GPU_TICK_L0_AT,
-    read when a context is created)."""
+    copies of a tick (landing copy, job-table upload) behind the first 37 role workgroups / behind all roles ("-1") instead of in front
+    (SDRPP_GPU_TICK_L0_AT, read when a context is created)."""
     from sdrplusplus_amd import workloads
 
-    if backend == "emu" and l0_at in ("pipe", "fcm16w"):
-        pytest.skip("measurement switches (off by default): their device legs compare them with the ordinary pass; the emulator legs cost the CPU suite 30 s")
     if l0_at == "pipe":  # the FM back ends as ONE role of the tick (SDRPP_GPU_TICK_PIPE: a measurement switch, off by default) — blocks shorter than
         monkeypatch.setenv("SDRPP_GPU_TICK_PIPE", "1")  # a filter history (the 1031- and 7-sample ones and the one behind each) fall back to ordinary passes
     elif l0_at == "fcm16w":  # the front end in its 16 x 16 x 4 shape walking its tiles, the tick in the four-wavefronts-per-SIMD build of the kernel
@@ -403,8 +401,6 @@ def test_pipelined_equals_ordinary_with_preproc_chain(backend, ratio, dc, conj):
     lines bit-identical to ordinary passes; no block falls back except one the decimator swallows whole."""
     from sdrplusplus_amd import capi, radio, workloads
 
-    if backend == "emu" and (ratio, dc, conj) in ((4, False, False), (1, False, True)):
-        pytest.skip("emulator leg trimmed: the (2, DC, conjugate) and (1, DC) cases cover every role of the chain there; all four run on the device")
     nv = 20 if backend == "gpu" else 17
     eff = 10e6
     scale = 1 if backend == "gpu" else 2
