@@ -8,7 +8,9 @@ so a silent fall-back to ordinary passes or to another front-end shape fails the
   (a) cfg 3 as bench.py sets it up: 32 x WFM + dense 65536-point FFT, 10^6-sample blocks resident on the device, reference block 50 000
   (b) the same at sr/200 = 50 000-sample blocks: device-resident (front end in its small-block shape) and fetched from host memory
   (c) cfg 4: 128 VFOs NFM / AM / USB + 2^20-point FFT, 10^6- and 307 200-sample blocks (long first stages: the SET = 1 build of the kernel)
-  (d) cfg 2: FFT only, 65536 and 2^20 points, 10^6-sample blocks"""
+  (d) cfg 2: FFT only, 65536 and 2^20 points, 10^6-sample blocks
+  (e) cfg 3 + the radio's AF chain on every VFO (`other_configs.cfg3_af`), 10^6-sample and sr/200 blocks: the AF chain's output against the
+      oracle's chain"""
 import numpy as np
 import pytest
 import torch  # BEFORE the product library: torch preloads its own copy of the HIP runtime by path, and the second runtime in a process finds no device
@@ -172,4 +174,47 @@ def test_cfg2_pipelined_vs_oracle(lgn):
     nlines = _check_lines(spec, view, x, cuts, results)
     assert nlines == (B * nblk) // N
     del keep
+    ctx.close()
+
+
+@pytest.mark.parametrize("B,nblk", [(1000000, 8), (50000, 60)])
+def test_cfg3_af_pipelined_bench_geometry_vs_oracle(B, nblk):
+    """(e) `other_configs.cfg3_af` as bench.py sets it up: 32 x WFM + the radio's AF chain on every VFO (resampler to 48 kHz, 50 us
+    de-emphasis: radio_module.h:98-110), 65536-point dense FFT, pipelined, VFO blocks (= the AF chain's output) + zoomed lines delivered, at
+    10^6-sample blocks with the reference block marked and at sr/200 blocks.  AF output of every VFO within 1e-5 RMS of the oracle's chain,
+    lines bit-exact, no block as an ordinary pass, the AF roles present."""
+    from sdrplusplus_amd import capi, radio, workloads
+    from test_parity_vfo import _OracleAf
+
+    x = _synth_threaded(3, B * nblk, seed=0xAF + nblk)
+    ctx = capi.Context(0, max_push=B)
+    info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=32)
+    keep_af = []
+    for vid, (m, r, _bw, _c, _car) in zip(info["vids"], info["plan"]):
+        a, k = radio.af_desc(r, 48000.0, 50e-6, False)
+        ctx.vfo_set_af(vid, a, k)
+        keep_af.append(k)
+    if B > 50000:
+        ctx.set_reference_block(50000)
+    ctx.set_pipelined(True, 1 | 2 | 4)
+    keep, blocks = _device_blocks(x, B)
+    cuts = [B] * nblk
+    results = _run_pipelined(ctx, lambda t, n: ctx.push_device(blocks[t][0], n), cuts, lag=14)
+    st = ctx.pipeline_stats()
+    assert st["tick_blocks"] == nblk and st["pass_blocks"] == 0, st
+    assert "polyc" in st["roles"] and "deemp_p0" in st["roles"] and "deemp_p1" in st["roles"], st
+    spec = S.OracleSpectrum(65536, 65536, 0, capi.design_fft_window(2, 65536))
+    nlines = _check_lines(spec, info["view"], x, cuts, results)
+    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m]) for m, r, bw, c, _ in info["plan"]]
+    ref = _oracle_streams(chains, x, [50000] * (B * nblk // 50000))
+    worst = 0.0
+    for k, (vid, (m, r, _bw, _c, _car)) in enumerate(zip(info["vids"], info["plan"])):
+        oaf = _OracleAf(r, 48000.0, 50e-6, False).process(ref[k][1])
+        got = np.concatenate([q["vfo"][vid] for q in results])
+        assert got.shape == oaf.shape, (k, got.shape, oaf.shape)
+        e = rms(got - oaf) / max(1.0, rms(oaf))
+        worst = max(worst, e)
+        assert e < 1e-5, (k, e)
+    print("cfg3 + AF pipelined B=%d: %d lines bit-exact, worst AF-output error %.2e over %d input samples, %d levels" % (B, nlines, worst, B * nblk, st["depth"]))
+    del keep, keep_af
     ctx.close()
