@@ -452,9 +452,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         mode_names = "/".join(sorted({m for m, _, _, _, _ in info["plan"]})) if nvfo else ""
         out = {
             "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
-            "workload": "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s%s" % (
-                cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else "",
-                ("; zoomed lines + palette indices of every block DELIVERED to page-locked host memory" + (", VFO outputs left in HBM" if nvfo else "")) if pipelined else "; outputs left in HBM"),
+            "workload": workload_string(cfg, sr, N, nvfo, mode_names, pipelined),
             "samples_per_step_per_gpu": push, "mode": mode, "reference_block": ref_block if (ref_block and ref_block < push) else push,
             "input_blocks_rotated": len(bufs), "input_bytes_rotated": len(bufs) * push * 8, "af_chain": bool(af and nvfo), "device": ctx.device_info(),
             "roofline": roof, "roofline_fft": roof_fft, "roofline_path": roof_path,
@@ -687,7 +685,15 @@ def dry_launch(args, np, torch):
     if rank == 0:
         g = runner.gathered
         ok = g is not None and tuple(g.shape) == (world, every, max_lines + 1, width) and all(p["collected"] == args.steps + args.warmup for p in per_rank)
-        print(json.dumps({"dry_launch": True, "ok": bool(ok), "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": dist.get_backend(), "devices": names,
+        from sdrplusplus_amd import workloads
+
+        cfg = default_cfg(args)  # the SAME choice main() makes with devices: the metric and the workload do not depend on the number of GPUs
+        cbase = 4 if cfg == 5 else cfg
+        cnv = 0 if cbase == 2 else (args.nvfo if cbase == 3 else 128)
+        names_ = "/".join(sorted({m for m, _, _, _, _ in workloads.vfo_plan(cbase, cnv)})) if cnv else ""
+        print(json.dumps({"dry_launch": True, "ok": bool(ok), "metric": METRIC[cfg],
+                          "config": {"workload": workload_string(cfg, workloads.CFG[cbase]["sr"], workloads.CFG[cbase]["fft"], cnv, names_, args.mode == "pipelined"), "streams": world},
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "backend": dist.get_backend(), "devices": names,
                           "value": round(world * push * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s (stub context: the protocol, not the hot path)",
                           "per_rank": [{"rank": p["rank"], "Msamples_per_s": round(push * args.steps / max(p["local_s"], 1e-9) / 1e6, 1)} for p in per_rank],
                           "gathered_shape": list(g.shape) if g is not None else None}), flush=True)
@@ -753,6 +759,18 @@ def af_sr200_delivered(torch, capi, workloads, sr, nvfo):
     return {"value": round(best, 1), "unit": "Msamples/s", "push": B, "result_lag_blocks": lag, "blocks_as_ordinary_passes": st["pass_blocks"], "depth_levels": st["depth"]}
 
 
+def default_cfg(args):
+    """The configuration a command line means: --cfg wins, then --fft-only, else the headline workload (cfg 3) at EVERY number of GPUs."""
+    return args.cfg if args.cfg in (2, 3, 4, 5) else (2 if args.fft_only else 3)
+
+
+def workload_string(cfg, sr, N, nvfo, mode_names, pipelined):
+    """config.workload of the JSON line — one function so that the 1-GPU line, the N-GPU line and the dry launch say the same thing."""
+    return "cfg%d: %.2f MS/s-format synthetic IQ (workloads.synth), %d-pt dense FFT + log-power waterfall%s%s" % (
+        cfg, sr / 1e6, N, (" + %d VFO x %s (xlate+FIR+resample+demod)" % (nvfo, mode_names)) if nvfo else "",
+        ("; zoomed lines + palette indices of every block DELIVERED to page-locked host memory" + (", VFO outputs left in HBM" if nvfo else "")) if pipelined else "; outputs left in HBM")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -769,7 +787,7 @@ def main():
     ap.add_argument("--af", action="store_true", help="also run the radio AF chain (resampler to 48 kHz + 50 us de-emphasis) behind every VFO (SURVEY.md 8f row 1; not part of the headline workload; pipelined like everything else)")
     ap.add_argument("--fft-only", action="store_true", help="same as --cfg 2")
     ap.add_argument("--nco", choices=("closed", "ssb-exact"), default="closed", help="ssb-exact: SSB / DSB / raw channels on the reference's float rotator recursion (sdrpp_vfo_desc.nco_mode = 2); runs as ordinary passes")
-    ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3 on one GPU, 5 on several)")
+    ap.add_argument("--cfg", type=int, default=0, help="BASELINE config 2 / 3 / 4 / 5 (default: 3, the headline workload, on ANY number of GPUs — one stream per GPU; 5 = a cfg-4 stream per GPU)")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1 without GPUs: spawn the ranks, rendezvous over gloo, run the StreamRunner protocol on a stub context, print the JSON line (CPU test of the launch path)")
     args = ap.parse_args()
 
@@ -821,7 +839,10 @@ def main():
 
     from sdrplusplus_amd import capi, workloads
 
-    cfg = args.cfg if args.cfg in (2, 3, 4, 5) else (2 if args.fft_only else (3 if world == 1 else 5))
+    # ONE metric across N: the headline workload (cfg 3) on every rank's own stream whatever the number of GPUs, so that the driver's 1/2/4/8 curve
+    # scales one workload; cfg 5 (a cfg-4 stream per rank) only when asked for (--cfg 5).  The reference's graph is one independent IQFrontEnd
+    # per stream (core/src/signal_path/iq_frontend.cpp:140-183).
+    cfg = default_cfg(args)
     base = 4 if cfg == 5 else cfg
     sr, N = workloads.CFG[base]["sr"], workloads.CFG[base]["fft"]
     nvfo = 0 if base == 2 else (args.nvfo if base == 3 else 128)

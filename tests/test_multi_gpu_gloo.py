@@ -228,6 +228,18 @@ def test_bench_spawns_its_ranks_when_started_like_the_one_gpu_run():
     out = json.loads(last)
     assert out["dry_launch"] and out["ok"] and out["n_gpus"] == 2 and out["steps"] == 9 and len(out["devices"]) == 2
     assert [p["rank"] for p in out["per_rank"]] == [0, 1] and out["gathered_shape"][0] == 2
+    # ONE metric across N (BASELINE.json: "... 1/2/4/8 GPU"): the line of --gpus 1 and of --gpus 2 name the same metric and the same per-stream
+    # workload — the headline cfg 3 on every rank's own stream; cfg 5 only on request
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-launch", "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0, (r1.stdout[-2000:], r1.stderr[-2000:])
+    one = json.loads([l for l in r1.stdout.splitlines() if l.strip()][-1])
+    assert one["n_gpus"] == 1 and len(one["per_rank"]) == 1
+    assert one["metric"] == out["metric"] and "32 VFO WFM" in out["metric"] and "cfg5" not in out["metric"]
+    assert one["config"]["workload"] == out["config"]["workload"] and out["config"]["workload"].startswith("cfg3:")
+    assert out["config"]["streams"] == 2 and one["config"]["streams"] == 1
+    r5 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--cfg", "5", "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    five = json.loads([l for l in r5.stdout.splitlines() if l.strip()][-1])
+    assert "cfg5" in five["metric"] and five["config"]["workload"].startswith("cfg5:")
     # a launcher that already set WORLD_SIZE to something else is an error message, not an AssertionError
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120, env=env2)
