@@ -236,6 +236,24 @@ __device__ __forceinline__ f32x16 mfma_zero() {
 }
 __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// Packed FP32 adds on a (re, im) register pair: ONE vector instruction for both components (v_pk_add_f32; the compiler splits a plain
+// two-element vector add into two v_add_f32 as soon as the halves go to different consumers, hence the spelled-out instruction).
+//   pk_add_f32(a, b)         = (a.x + b.x,  a.y + b.y)
+//   pk_add_nlo_nhi_f32(a, b) = (b.x - a.x,  a.y - b.y)     (neg_lo on the first, neg_hi on the second operand)
+// Each component is the correctly rounded sum / difference — bitwise what fmaf(+-1, b, a) or a plain add gives.
+__device__ __forceinline__ f32x2 pk_add_f32(float2 a, float2 b) {
+    f32x2 av, bv, d;
+    av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(av), "v"(bv));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add_nlo_nhi_f32(float2 a, float2 b) {
+    f32x2 av, bv, d;
+    av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(av), "v"(bv));
+    return d;
+}
+
 // D(16x16) += A(16x4) * B(4x16), v_mfma_f32_16x16x4_f32, 32 cycles per instruction (same FLOP rate as the 32x32x2 form).  Lane l
 // supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; register r receives D[i = 4 * (l >> 4) + r][j = l & 15];
 // numerically d = fmaf(A[i][3], B[3][j], fmaf(A[i][2], B[2][j], fmaf(A[i][1], B[1][j], fmaf(A[i][0], B[0][j], c)))).

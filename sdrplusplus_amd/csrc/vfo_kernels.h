@@ -1445,7 +1445,31 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);        // [VT]
 
     // ---- block prologue: tap operand table and output pointers (the only workgroup barrier of the kernel) ----
-    {   // (all loads of a work-item in flight before the first LDS write: a wait per load is a memory round trip each — 8 of them measured)
+    if constexpr (KS > 0) {
+        // pair-per-half form (see the matrix loop): lane (jl, hi) wants (gr, -gi) of VFO jl and pair 2 q + hi as ONE 8-byte read — row p of the
+        // host's table ([pair][64]: gr of the 32 VFOs, then -gi) goes into LDS with its two halves interleaved.  A task = 4 VFOs of one pair:
+        // two 16-byte loads, two 16-byte LDS writes; all loads of a work-item in flight before its first LDS write.
+        constexpr int NPS = (KS + 1) / 2, NT = NPS * 8, NB = (NT + 255) / 256;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        float4 tr[NB], ti[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int t = min(tid + q * 256, NT - 1), pr = t >> 3, j4 = t & 7;  // (index clamped, never a guarded load)
+            tr[q] = global_load_f32x4(at4, pr * 16 + j4);
+            ti[q] = global_load_f32x4(at4, pr * 16 + 8 + j4);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int t = tid + q * 256;
+            if (t < NT) {
+                const int pr = t >> 3, j4 = t & 7;
+                AL4[pr * 16 + 2 * j4] = make_float4(tr[q].x, ti[q].x, tr[q].y, ti[q].y);
+                AL4[pr * 16 + 2 * j4 + 1] = make_float4(tr[q].z, ti[q].z, tr[q].w, ti[q].w);
+            }
+        }
+    }
+    else {   // (all loads of a work-item in flight before the first LDS write: a wait per load is a memory round trip each — 8 of them measured)
         constexpr int NB = 5;  // 68 pairs x 64 lanes = 17 floats per work-item: four rounds of 16-byte loads + a rest
         const int n4 = NP4 * 16;
         const float4* at4 = reinterpret_cast<const float4*>(job.atab);
@@ -1489,14 +1513,18 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
             }
         }
     };
+    float2* X2 = reinterpret_cast<float2*>(XR);  // KS > 0: ONE skewed plane of complex samples in the same 2 * pl floats
     auto planes_store = [&]() {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
             const int sidx = lane + q * 64;
             if (sidx < nsamp) {
                 const int idx = sidx + (sidx >> lgD);
-                XR[idx] = pf[q].x;
-                XI[idx] = pf[q].y;
+                if constexpr (KS > 0) { X2[idx] = pf[q]; }
+                else {
+                    XR[idx] = pf[q].x;
+                    XI[idx] = pf[q].y;
+                }
             }
         }
     };
@@ -1534,33 +1562,51 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
         wave_prio_low();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
         if constexpr (KS > 0) {
-            // software pipeline: the LDS reads of pair p + 2 are issued (and fenced) two pairs = four matrix instructions ahead of
-            // their use, so the wave never waits out an LDS latency in front of a v_mfma
-            constexpr int NPS = (KS + 1) / 2;
-            float ra[3], r1a[3], r1b[3], r2a[3], r2b[3];
-            auto issue = [&](int p, int slot) {
-                const int kb = K - 1 - p;
-                const int ia = ib + p + (p >> lgD), ibb = ib + kb + (kb >> lgD);
-                ra[slot] = AL[p * 64 + lane];
-                r1a[slot] = P1[ia];
-                r1b[slot] = P1[ibb];
-                r2a[slot] = P2[ia];
-                r2b[slot] = P2[ibb];
+            // PAIR-PER-HALF form (round 5).  The 32 x 32 x 2 instruction takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63.  Until round 4
+            // k = 0 / 1 were the sums / differences of ONE tap pair, so every lane needed the pair's four sample components from two planes, a
+            // tap, and formed its B operands with two fmaf: 3 LDS instructions + 2 vector instructions per pair of matrix instructions, and an
+            // LDS read costs the issuing wavefront 12-15 cycles of matrix issue (tools/probe/mfma_operand_probe.hip).  Now k = 0 / 1 are two
+            // CONSECUTIVE pairs: lane (jl, hi) owns pair 2 q + hi of output jl, reads the pair's two complex samples (a, b) and its taps
+            // (gr, -gi) as 8-byte values — consecutive q merge into ds_read2_b64 — and two PACKED adds give all four B operands:
+            //     s = a + b = (sr, si)        d = (b.re - a.re, a.im - b.im) = (-dr, di)
+            //     accR += gr * sr  (pairs 2q, 2q+1);  accR += -gi * di;      accI += gr * si;  accI += -gi * -dr
+            // 0.75 LDS + 0.5 vector instructions per matrix instruction pair instead of 3 + 2.  Every output is still ONE k-ordered fmaf chain,
+            // in the order (sums 2q, sums 2q+1, differences 2q, differences 2q+1) — the order the 16 x 16 x 4 shapes below follow as well.
+            constexpr int NPS = (KS + 1) / 2, NQ = NPS / 2;
+            static_assert((KS & 1) == 0 && (NPS & 1) == 0, "even filters with an even number of tap pairs");
+            const float2* Pa = X2 + ib + hi;   // a of pair 2 q + hi: sample jl * D + 2 q + hi  ((2q + 1) >> lgD == 2q >> lgD)
+            const float2* Pb = X2 + ib - hi;   // b: sample jl * D + K - 1 - 2 q - hi  (K - 1 - 2q is odd: taking hi off never crosses a multiple of D)
+            const float2* Tp = reinterpret_cast<const float2*>(AL) + lane;
+            // operands travel in CHUNKS of two double pairs (the three 8-byte reads of q and q + 1 share their bases: three ds_read2_b64), a
+            // chunk = eight matrix instructions ahead of its use
+            constexpr int NC = (NQ + 1) / 2;
+            float2 ra[2][2], rb[2][2], rg[2][2];
+            auto issue = [&](int c, int slot) {
+                constexpr int K1 = KS - 1;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int q = (2 * c + u < NQ) ? 2 * c + u : NQ - 1;  // (an odd number of double pairs: the last chunk reads its one double pair twice, uses it once)
+                    ra[slot][u] = Pa[2 * q + ((2 * q) >> lgD)];
+                    rb[slot][u] = Pb[(K1 - 2 * q) + ((K1 - 2 * q) >> lgD)];
+                    rg[slot][u] = Tp[q * 64];
+                }
             };
             issue(0, 0);
-            if (NPS > 1) { issue(1, 1); }
 #pragma unroll
-            for (int p = 0; p < NPS; p++) {
-                if (p + 2 < NPS) { issue(p + 2, (p + 2) % 3); }
+            for (int c = 0; c < NC; c++) {
+                if (c + 1 < NC) { issue(c + 1, (c + 1) & 1); }
                 sched_fence();
-                const int sl = p % 3;
-                float b1 = r1b[sl], b2 = r2b[sl];
-                if ((KS & 1) && p == NPS - 1) { b1 = 0.0f; b2 = 0.0f; }  // centre tap of an odd filter: a "pair" with itself
-                const float bre = fmaf(sgn, b1, r1a[sl]);  // lanes 0-31: sr = a.re + b.re   lanes 32-63: di = a.im - b.im
-                const float bim = fmaf(sgn, r2a[sl], b2);  // lanes 0-31: si = a.im + b.im   lanes 32-63: -dr = b.re - a.re
-                const float a_re = ra[sl];                 // (gr, -gi): with -dr in the B operand the SAME tap operand serves both products
-                accR = mfma_32x32x2(a_re, bre, accR);
-                accI = mfma_32x32x2(a_re, bim, accI);
+                const int sl = c & 1;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (2 * c + u < NQ) {
+                        const f32x2 s = pk_add_f32(ra[sl][u], rb[sl][u]), d = pk_add_nlo_nhi_f32(ra[sl][u], rb[sl][u]);
+                        accR = mfma_32x32x2(rg[sl][u].x, s.x, accR);
+                        accR = mfma_32x32x2(rg[sl][u].y, d.y, accR);
+                        accI = mfma_32x32x2(rg[sl][u].x, s.y, accI);
+                        accI = mfma_32x32x2(rg[sl][u].y, d.x, accI);
+                    }
+                }
                 sched_fence();
             }
         }
@@ -1621,9 +1667,9 @@ __global__ __launch_bounds__(256, 3) void vfo_frontcm_kernel(IqSrc src, const Fr
 // At the reference's own block size (sr/200 = 50 000 samples: 98 tiles of 32 outputs for the ratio-32 plan) every wavefront of the kernel
 // above has ONE tile, and its 132 matrix instructions of 64 cycles each are 4 of the 12 us a front-end workgroup lives — the longest role of
 // a 13 us tick.  Here a WORKGROUP takes one 32-output tile and its four wavefronts a quarter each: 16 VFOs x 16 outputs, two tap pairs per
-// v_mfma_f32_16x16x4_f32 (k = 0: gr * sums, 1: -gi * differences of pair p; k = 2, 3: the same of pair p + 1), 66 instructions of 32 cycles
+// v_mfma_f32_16x16x4_f32 (k = 0, 1: gr * sums of pairs p, p + 1; k = 2, 3: -gi * differences of pairs p, p + 1), 66 instructions of 32 cycles
 // instead of 132 of 64.  The matrix instruction accumulates its k in order, so every output is the same chain of fmaf's as in the 32 x 32 x 2
-// form — pair after pair, sums before differences — and the NCO values come from the same tile phasor and the same in-tile table:
+// form — two pairs at a time, their sums before their differences — and the NCO values come from the same tile phasor and the same in-tile table:
 // bit-identical outputs (test_small_block_front_end_shape_is_bit_identical).  Same tap operand table, same job.
 struct FCM16Layout { int pl, a_off, pt_off, out_off, total; };
 __host__ __device__ inline FCM16Layout frontcm16_layout(int K, int lgD) {
@@ -1647,7 +1693,7 @@ __device__ __forceinline__ void vfo_frontcm16_body(const KIdx bid, float* smemf,
     const FCM16Layout L = frontcm16_layout(K, lgD);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int vh = wv & 1, nh = wv >> 1;                     // this wavefront's half of the VFOs / of the tile's outputs
-    const int jj = lane & 15, kq = lane >> 4, comp = kq & 1, po = kq >> 1;  // matrix k index kq: pair p + po, sums (0) or differences (1)
+    const int jj = lane & 15, kq = lane >> 4, comp = kq >> 1, po = kq & 1;  // matrix k index kq: sums of pairs p, p + 1, then their differences (the order of vfo_frontcm_body's pair-per-half form)
     float* XR = smemf + wv * 2 * L.pl;
     float* XI = XR + L.pl;
     float* AL = smemf + L.a_off;
@@ -1793,7 +1839,7 @@ __device__ __forceinline__ void vfo_frontcm16w_body(const KIdx bid, float* smemf
     const FCM16WLayout L = frontcm16w_layout(K, lgD);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int vh = wv & 1, nh = wv >> 1;                     // this wavefront's half of the VFOs / of every tile's outputs
-    const int jj = lane & 15, kq = lane >> 4, comp = kq & 1, po = kq >> 1;  // matrix k index kq: pair p + po, sums (0) or differences (1)
+    const int jj = lane & 15, kq = lane >> 4, comp = kq >> 1, po = kq & 1;  // matrix k index kq: sums of pairs p, p + 1, then their differences (the order of vfo_frontcm_body's pair-per-half form)
     float* XR = smemf + wv * 2 * L.pl;
     float* XI = XR + L.pl;
     float* AL = smemf + L.a_off;
@@ -1928,13 +1974,12 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
     const FrontCMJob& job = jobs[bid.y];
     constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
-    const int NP = (K + 1) >> 1, NP8 = ((NP + 7) >> 3) << 3;
+    const int NP = (K + 1) >> 1;
     const bool odd = (K & 1) != 0;
     const int nsamp = (tile - 1) * D + K;
     const int pl = frontcm_plane(nsamp, lgD);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
-    float* XR = smemf + wv * 2 * pl;
-    float* XI = XR + pl;
+    float2* X2 = reinterpret_cast<float2*>(smemf + wv * 2 * pl);  // ONE skewed plane of complex samples (pair-per-half form, as vfo_frontcm_body)
     float2* ptile = reinterpret_cast<float2*>(smemf + 2 * nw * pl) + wv * VT;
     float2** outp = reinterpret_cast<float2**>(smemf + 2 * nw * pl + nw * VT * 2);
     if (tid < VT) { outp[tid] = job.out[tid]; }
@@ -1966,9 +2011,7 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
             for (int q = 0; q < (PF > 0 ? PF : 1); q++) {
                 const int sidx = lane + q * 64;
                 if (sidx < nsamp) {
-                    const int idx = sidx + (sidx >> lgD);
-                    XR[idx] = pf[q].x;
-                    XI[idx] = pf[q].y;
+                    X2[sidx + (sidx >> lgD)] = pf[q];
                 }
             }
             return;
@@ -1976,16 +2019,28 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
         for (int sidx = lane; sidx < nsamp; sidx += 64) {  // history / end of the push / samples older than the VFO: in place, unpipelined
             const long long gi = base + sidx;
             const float2 v = (gi >= job.min_idx) ? iq_load_clamped(src, gi) : make_float2(0.0f, 0.0f);
-            const int idx = sidx + (sidx >> lgD);
-            XR[idx] = v.x;
-            XI[idx] = v.y;
+            X2[sidx + (sidx >> lgD)] = v;
         }
     };
     fetch(tile_base(tile0));
-    const float sgn = hi ? -1.0f : 1.0f;
-    const float* P1 = hi ? XI : XR;
-    const float* P2 = hi ? XR : XI;
     const int ib = jl * D + jl;
+    // pair-per-half form (round 5, see vfo_frontcm_body): lane (jl, hi) owns tap pair 2 q + hi of output jl — its two complex samples are two
+    // 8-byte LDS reads, two packed adds give (sr, si) and (-dr, di), the taps (gr, -gi) of ITS pair come from rows 2 q + hi of the table:
+    // per FOUR matrix instructions 2 LDS reads + 2 packed adds + 2 tap loads, where the pair-per-instruction form had 8 + 4 + 2 and
+    // twice the index arithmetic.  Accumulation order per output: sums of pairs 2q, 2q + 1, then their differences.
+    const int NQ = (NP + 1) >> 1;               // double pairs (an odd number of pairs: the last one is paired with a zero row of the table)
+    const int c_half = (NP - 1) & 1, c_q = (NP - 1) >> 1;  // odd filters: the centre tap is "pair" NP - 1 with itself — its b operand is zero
+    const float2* Xa = X2 + ib + hi;
+    const float2* Xb = X2 + ib;
+    const float* tg = job.atab + hi * 64 + jl;  // gr of pair 2 q + hi: tg[q * 128]; -gi: tg[q * 128 + 32]
+    auto operands = [&](int q, float2& a, float2& b) {  // q wave-uniform
+        const int p2 = 2 * q, kb = K - 1 - p2;
+        const int oa = p2 + (p2 >> lgD);                                           // (2q + 1) >> lgD == 2q >> lgD
+        const int ob0 = kb + (kb >> lgD), ob1 = (kb - 1) + ((kb - 1) >> lgD);      // scalar; the lane picks its half's
+        a = Xa[oa];
+        b = Xb[hi ? ob1 : ob0];
+        if (odd && q == c_q && hi == c_half) { b = make_float2(0.0f, 0.0f); }
+    };
     for (int it = 0; it < ntl; it++) {
         const int tb = tile0 + it;
         const long long base = tile_base(tb);
@@ -2003,25 +2058,37 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
         wave_sync();
         f32x16 accR = mfma_zero(), accI = mfma_zero();
         {
-            // tap operand ring: eight pairs ahead, coalesced 256-byte rows of the [pair][64] table (rows >= NP are zero padding)
-            float aq[8];
+            // tap operand ring: four double pairs (eight table rows) ahead, coalesced 128-byte half rows of the [pair][64] table.  The loop runs
+            // over whole rings — the table is zero padded to a multiple of eight rows (plan_vfo.h), a padded double pair multiplies VALID
+            // samples (index clamped) by zero taps — so that every ring slot is a fixed register (a uniform branch per slot made the compiler
+            // rotate the ring through moves and wait for every tap load where it was issued)
+            constexpr int RING = 4;
+            const int NQr = ((NQ + RING - 1) / RING) * RING;
+            float gq[RING], hq[RING];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { aq[u] = global_load_f32(job.atab, u * 64 + lane); }
-            for (int p0 = 0; p0 < NP8; p0 += 8) {
+            for (int u = 0; u < RING; u++) {
+                gq[u] = global_load_f32(tg, u * 128);
+                hq[u] = global_load_f32(tg, u * 128 + 32);
+            }
+            float2 a_c, b_c;
+            operands(0, a_c, b_c);
+            for (int q0 = 0; q0 < NQr; q0 += RING) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int p = p0 + u;
-                    const int pe = p < NP ? p : NP - 1;  // padding rows carry zero taps; keep their B operand finite
-                    const int kb = K - 1 - pe;
-                    const int ia = ib + pe + (pe >> lgD), ibb = ib + kb + (kb >> lgD);
-                    const float a1 = P1[ia], a2 = P2[ia];
-                    float b1 = P1[ibb], b2 = P2[ibb];
-                    if (odd && pe == NP - 1) { b1 = 0.0f; b2 = 0.0f; }
-                    const float bre = fmaf(sgn, b1, a1), bim = fmaf(sgn, a2, b2);  // lanes 32-63: di and -dr
-                    const float a_re = aq[u];
-                    aq[u] = global_load_f32(job.atab, (p + 8 < NP8 ? p + 8 : p) * 64 + lane);
-                    accR = mfma_32x32x2(a_re, bre, accR);
-                    accI = mfma_32x32x2(a_re, bim, accI);
+                for (int u = 0; u < RING; u++) {
+                    const int q = q0 + u;
+                    float2 a_n, b_n;
+                    operands(q + 1 < NQ ? q + 1 : NQ - 1, a_n, b_n);  // one double pair = four matrix instructions ahead
+                    const f32x2 sm = pk_add_f32(a_c, b_c), df = pk_add_nlo_nhi_f32(a_c, b_c);
+                    accR = mfma_32x32x2(gq[u], sm.x, accR);
+                    accR = mfma_32x32x2(hq[u], df.y, accR);
+                    accI = mfma_32x32x2(gq[u], sm.y, accI);
+                    accI = mfma_32x32x2(hq[u], df.x, accI);
+                    sched_fence();  // the slot is reloaded BEHIND the matrix instructions that read it: the same registers, no copies, no wait for a load just issued
+                    const int qn = q + RING < NQr ? q + RING : q;
+                    gq[u] = global_load_f32(tg, qn * 128);
+                    hq[u] = global_load_f32(tg, qn * 128 + 32);
+                    a_c = a_n;
+                    b_c = b_n;
                 }
             }
         }
