@@ -313,6 +313,9 @@ void sdrpp_host_free(void* p);
  * its RCCL gather, host/sdrpp_gpu_rccl.h) without linking the HIP runtime itself; NULL on failure. */
 void* sdrpp_device_alloc(sdrpp_ctx* ctx, size_t bytes);
 void sdrpp_device_free(sdrpp_ctx* ctx, void* p);
+/* A synchronous copy on the context's GPU for the same kind of host: kind 0 host -> device, 1 device -> device, 2 device -> host.  Ordered behind
+ * everything enqueued on the context's stream; returns when the bytes have arrived. */
+int sdrpp_device_copy(sdrpp_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
 /* Deferred processing: sdrpp_push* only stage the samples (the H2D copy runs, the caller's buffer is free on return) and the next call
  * that observes results — sdrpp_sync, any *_lines / *_read* / *_count / *_device_buffer(s) / sdrpp_wf_* call — or changes the
  * configuration processes everything staged since the previous one as ONE pass over the device.  The results then cover ALL those

@@ -98,8 +98,8 @@ class Result(C.Structure):
     ]
 
 
-ABI_VERSION = 2
-RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: blocks whose pipelined results can exist at a time  # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
+ABI_VERSION = 2    # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
+RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: blocks whose pipelined results can exist at a time
 
 
 class SdrppError(RuntimeError):
@@ -199,6 +199,8 @@ def load():
     L.sdrpp_device_alloc.argtypes = [vp, C.c_size_t]
     L.sdrpp_device_free.restype = None
     L.sdrpp_device_free.argtypes = [vp, vp]
+    L.sdrpp_device_copy.restype = C.c_int
+    L.sdrpp_device_copy.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     L.sdrpp_pending.restype = C.c_int64
     L.sdrpp_pending.argtypes = [vp]
     L.sdrpp_vfo_read_many.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_float_p, C.c_int64, C.POINTER(C.c_int64), c_int_p]
@@ -242,7 +244,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
     "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
-    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_count",
+    "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_copy", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
     "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",

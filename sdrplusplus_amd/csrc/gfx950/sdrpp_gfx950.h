@@ -236,22 +236,19 @@ __device__ __forceinline__ f32x16 mfma_zero() {
 }
 __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-// Packed FP32 adds on a (re, im) register pair: ONE vector instruction for both components (v_pk_add_f32; the compiler splits a plain
-// two-element vector add into two v_add_f32 as soon as the halves go to different consumers, hence the spelled-out instruction).
-//   pk_add_f32(a, b)         = (a.x + b.x,  a.y + b.y)
-//   pk_add_nlo_nhi_f32(a, b) = (b.x - a.x,  a.y - b.y)     (neg_lo on the first, neg_hi on the second operand)
-// Each component is the correctly rounded sum / difference — bitwise what fmaf(+-1, b, a) or a plain add gives.
-__device__ __forceinline__ f32x2 pk_add_f32(float2 a, float2 b) {
-    f32x2 av, bv, d;
+// Packed FP32 sum and "crossed" difference of two (re, im) register pairs, the B operands of the pair-per-half front ends:
+//     s = (a.x + b.x,  a.y + b.y)            d = (b.x - a.x,  a.y - b.y)     (neg_lo on the first, neg_hi on the second operand)
+// TWO vector instructions for four values (v_pk_add_f32; the compiler splits a plain two-element vector add into two v_add_f32 as soon as the
+// halves go to different consumers, hence the spelled-out instructions).  Each component is the correctly rounded sum / difference — bitwise
+// what fmaf(+-1, b, a) or a plain add gives.
+// The trailing s_nop 1 is REQUIRED: a matrix instruction that reads a register a vector instruction has just written needs two wait states in
+// between (the compiler inserts them for instructions it schedules itself — `v_fmac; v_mfma; s_nop 0; v_mfma` in the round-4 loop — but cannot
+// classify the text of an asm statement: with one wait state the v_mfma behind these adds read the OLD register contents on the device, which
+// the CPU emulator — plain C++ — cannot show; found by the round-5 device run, 23 parity tests).
+__device__ __forceinline__ void pk_sum_diff_f32(float2 a, float2 b, f32x2& s, f32x2& d) {
+    f32x2 av, bv;
     av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(av), "v"(bv));
-    return d;
-}
-__device__ __forceinline__ f32x2 pk_add_nlo_nhi_f32(float2 a, float2 b) {
-    f32x2 av, bv, d;
-    av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(av), "v"(bv));
-    return d;
+    asm("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %2, %3 neg_lo:[1,0] neg_hi:[0,1]\n\ts_nop 1" : "=&v"(s), "=&v"(d) : "v"(av), "v"(bv));
 }
 
 // D(16x16) += A(16x4) * B(4x16), v_mfma_f32_16x16x4_f32, 32 cycles per instruction (same FLOP rate as the 32x32x2 form).  Lane l

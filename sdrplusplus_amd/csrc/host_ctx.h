@@ -32,6 +32,7 @@ struct Stream {
     float* extra[kRing - 1] = {};
     int n_extra = 0, rot = 0;
     int clevel = 0;  // pipelined mode: level of the role that consumes this stream with memory (its history carry runs there)
+    int wlevel = 0;  // pipelined mode: level of the role that WRITES this stream in the current block (0: not written by a role of this plan)
     float* prev_data = nullptr;  // pipelined mode: the data buffer of the block before (stream_rotate) and its sample count — where a piped back end
     int prev_n = 0;              // finds the tail of the previous block (do_vfos_plan: pipe_in)
 };

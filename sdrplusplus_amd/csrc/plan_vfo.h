@@ -311,7 +311,8 @@ struct BankPlan {
     int chain(Vfo& v) {
         Stream* cur = &v.st[(size_t)v.i_first];
         int lvl = L0 + 1;  // level at which `cur` is written
-        for (auto& s : v.st) { s.clevel = 0; }
+        for (auto& s : v.st) { s.clevel = 0; s.wlevel = 0; }
+        cur->wlevel = lvl;
         // reference-block ends carried stage by stage down to the demodulator's rate, for the block-dependent operations there
         // (AGC look-ahead, SSB rotator calls)
         const bool agc_mode = v.d.demod == SDRPP_DEMOD_AM || (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB);
@@ -324,6 +325,7 @@ struct BankPlan {
             Stream* tgt = (v.d.n_stages == 0) ? cur : &v.st[(size_t)v.i_rot];
             rotx.push_back(RotXJob{ (float2*)tgt->data, v.d_rot, v.d.phase_delta_re, v.d.phase_delta_im });
             tgt->n = n_in;
+            tgt->wlevel = lvl;
             cur = tgt;
         }
         else if (v.d.n_stages == 0) {
@@ -404,6 +406,7 @@ struct BankPlan {
                 v.soff[1] = v.soff[1] + mem.nout2 * v.d.stage_decim[1] - nout;
                 cur->n = 0;  // the stage-1 stream is never materialised
                 nxt->n = mem.nout2;
+                nxt->wlevel = lvl;
                 cur = nxt;
             }
         }
@@ -454,6 +457,7 @@ struct BankPlan {
             else { f_dec.add(lvl, FirBJob{ stream_in(*cur), nxt->data, v.d_staps[s], v.d.stage_ntaps[s], ilog2(Ds), v.soff[s], no, v.s_kp[s] }); }
             v.soff[s] = v.soff[s] + no * Ds - cur->n;
             nxt->n = no;
+            nxt->wlevel = lvl;
             cur = nxt;
         }
         if (v.i_poly >= 0) {
@@ -481,6 +485,7 @@ struct BankPlan {
             v.pphase = (int)(A % v.d.interp);
             v.poff = v.poff + (int)(A / v.d.interp) - cur->n;
             nxt->n = no;
+            nxt->wlevel = lvl;
             cur = nxt;
         }
         if (v.i_chan >= 0 && v.chan_ntaps > 0) {
@@ -497,6 +502,7 @@ struct BankPlan {
             else if (v.tp_chan.ok) { t_chan.add(lvl, toep_job(v.tp_chan, 0, stream_in(*cur), nxt->data, -(v.chan_ntaps - 1), cur->n, 0.0f)); }
             else { chan.add(lvl, FirBJob{ stream_in(*cur), nxt->data, v.d_chan, v.chan_ntaps, 0, 0, cur->n, v.chan_kp }); }
             nxt->n = cur->n;
+            nxt->wlevel = lvl;
             cur = nxt;
         }
         v.i_if = (int)(cur - &v.st[0]);
@@ -526,6 +532,7 @@ struct BankPlan {
             else if (v.tp_audio.ok) { t_audio_fm.add(lvl, toep_job(v.tp_audio, 0, stream_in(*cur), out.data, -(v.audio_ntaps - 1), nif, v.d.inv_deviation)); }
             else { audio_fm.add(lvl, FirBJob{ stream_in(*cur), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp, v.d.inv_deviation }); }
             out.n = nif;
+            out.wlevel = lvl;
             v.lvl_out = lvl;
         }
         else if (v.d.demod == SDRPP_DEMOD_AM) {
@@ -534,11 +541,13 @@ struct BankPlan {
             if (!v.d.am_carrier_agc) { pre.add(lvl + 1, PreJob{ 2, nif, (const float2*)cur->data, dem.data, 0.0, 0.0 }); }
             seq.add(lvl + 2, SeqJob{ 2, nif, (const float2*)cur->data, dem.data, nullptr, agc, agc + 1, dc, v.d.dc_block_rate, v.d.am_carrier_agc, d_bnd, nbnd });
             dem.n = nif;
+            dem.wlevel = lvl + 2;
             lvl += 3;
             dem.clevel = lvl;
             if (v.tp_audio.ok) { t_audio.add(lvl, toep_job(v.tp_audio, 0, stream_in(dem), out.data, -(v.audio_ntaps - 1), nif, 0.0f)); }
             else { audio.add(lvl, FirBJob{ stream_in(dem), out.data, v.d_audio, v.audio_ntaps, 0, 0, nif, v.audio_kp }); }
             out.n = nif;
+            out.wlevel = lvl;
             v.lvl_out = lvl;
         }
         else if (v.d.demod >= SDRPP_DEMOD_USB && v.d.demod <= SDRPP_DEMOD_DSB) {
@@ -550,6 +559,7 @@ struct BankPlan {
             lvl += 2;
             dem.n = 0;  // scratch only
             out.n = nif;
+            out.wlevel = lvl;
             v.lvl_out = lvl;
             double p2 = v.phi2 + (double)nif * v.theta2;
             v.phi2 = p2 - std::floor(p2);
@@ -567,6 +577,7 @@ struct BankPlan {
                 else { af_dec.add(lvl, FirBJob{ stream_in(*acur), nxt->data, a.d_staps[s], K, ilog2(Ds), a.soff[s], no, a.s_kp[s] }); }
                 a.soff[s] = a.soff[s] + no * Ds - acur->n;
                 nxt->n = no;
+                nxt->wlevel = lvl;
                 acur = nxt;
             }
             if (a.i_poly >= 0) {
@@ -580,6 +591,7 @@ struct BankPlan {
                 a.pphase = (int)(A % a.interp);
                 a.poff = a.poff + (int)(A / a.interp) - acur->n;
                 nxt->n = no;
+                nxt->wlevel = lvl;
                 acur = nxt;
             }
             if (a.i_hpf >= 0) {
@@ -590,6 +602,7 @@ struct BankPlan {
                 if (a.tp_hpf.ok) { t_af_hpf.add(lvl, toep_job(a.tp_hpf, 0, stream_in(*acur), nxt->data, -(K - 1), acur->n, 0.0f)); }
                 else { af_hpf.add(lvl, FirBJob{ stream_in(*acur), nxt->data, a.d_hpf, K, 0, 0, acur->n, a.hpf_kp }); }
                 nxt->n = acur->n;
+                nxt->wlevel = lvl;
                 acur = nxt;
             }
             if (a.i_deemp >= 0) {
@@ -600,8 +613,9 @@ struct BankPlan {
                                              a.d_seg + (size_t)a.state_cur * ((size_t)a.seg_cap + 1), nseg, 0 });
                 if (nseg > 0) { a.state_cur ^= 1; }  // (a block without audio leaves the state where it is)
                 nxt->n = acur->n;
-                acur = nxt;
                 lvl += 1;  // (the de-emphasis is two dependent launches: segment maps, then the outputs)
+                nxt->wlevel = lvl;
+                acur = nxt;
             }
             a.i_last = (int)(acur - &v.st[0]);
             v.lvl_af = lvl;
@@ -614,8 +628,10 @@ struct BankPlan {
         for (auto& s : v.st) {
             if (s.hist_len > 0 && s.data && &s != phantom) {
                 // pipelined: at the level of the consumer (its window of the NEXT block reads the new history one tick later, the carry of
-                // the next block overwrites the old one one tick later still); a stream nobody reads with memory: behind the whole chain
-                const int cl = !ticking ? carry_last : (s.clevel > 0 ? s.clevel : lvl + 1);
+                // the next block overwrites the old one one tick later still); a stream nobody reads with memory (a consumer may be attached
+                // later: sdrpp_vfo_set_af, a taps change): one level behind the role that WRITES it — not behind the whole chain, which with
+                // an AF chain is up to a dozen levels later, when the stream's ring buffer (kRing = 4) already holds a later block
+                const int cl = !ticking ? carry_last : (s.clevel > 0 ? s.clevel : (s.wlevel > 0 ? s.wlevel + 1 : lvl + 1));
                 carry.add(cl, CarryJob{ s.data, s.hist[s.cur], s.hist[s.cur ^ 1], s.hist_len, s.n, s.width, s.hist_len });
             }
         }

@@ -120,7 +120,10 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
         c->num_cus = std::max(1, prop.multiProcessorCount);
         // the long-first-stage role with four tile engines asks for up to 80 KB of dynamic LDS per workgroup (two workgroups per CU): above the
         // 64 KB a launch gets without asking
+        // (tick_kernel<0> as well: a long first stage whose window does NOT fit the register prefetch — nsamp > 64 * SDRPP_FCL_PF, a custom plan with
+        // a very long /64 stage — goes out as role TR_FCL_0 in the SET = 0 build with the same four-engine LDS request)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tick_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tick_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2);
         (void)hipGetLastError();
     }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1698,6 +1701,16 @@ void sdrpp_device_free(sdrpp_ctx* c, void* p) {
     if (!c || !p) { return; }
     DeviceScope dev_scope_(c);
     (void)hipFree(p);
+}
+int sdrpp_device_copy(sdrpp_ctx* c, void* dst, const void* src, size_t bytes, int kind) {
+    if (!c) { return SDRPP_ERR_INVALID; }
+    DeviceScope dev_scope_(c);
+    if (kind < 0 || kind > 2 || (bytes && (!dst || !src))) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_device_copy: bad arguments"); }
+    if (!bytes) { return SDRPP_OK; }
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, k, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SDRPP_OK;
 }
 
 int sdrpp_set_deferred(sdrpp_ctx* c, int on) {

@@ -165,9 +165,15 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         const int role_blocks = blocks - l0.blocks[0] - l0.blocks[1];
         l0.first = l0_at < 0 ? role_blocks : std::min(l0_at, role_blocks);
     }
-    if (blocks == 0) {  // nothing to do at all (an idle flush)
+    if (blocks == 0) {  // nothing to do at all: a level of the queue without roles (an idle flush; a gap between a block's levels)
         c->next_tab = tab_dev_next;
         c->next_tab_n = tab_n_next;
+        // No launch, so the tick counter the device publishes does not move — but every block still in the queue has just advanced by one level:
+        // a block's completion tick was computed as "ticks now + its remaining levels", one COUNTED tick per level, and would lie one launch past
+        // the end of the drain for every empty level (sdrpp_result_wait: "block cannot complete").  Its remaining levels are one fewer now.
+        for (auto& R : c->res) {
+            if (R.ticket != 0 && R.done_tick > c->ticks) { R.done_tick--; }
+        }
         return SDRPP_OK;
     }
     c->tick_target += (unsigned)blocks;

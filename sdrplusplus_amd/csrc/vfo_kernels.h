@@ -1444,52 +1444,8 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     float2* ptile = reinterpret_cast<float2*>(smemf + L.pt_off) + wv * VT;  // [VT], private to the wavefront
     float2** outp = reinterpret_cast<float2**>(smemf + L.out_off);        // [VT]
 
-    // ---- block prologue: tap operand table and output pointers (the only workgroup barrier of the kernel) ----
-    if constexpr (KS > 0) {
-        // pair-per-half form (see the matrix loop): lane (jl, hi) wants (gr, -gi) of VFO jl and pair 2 q + hi as ONE 8-byte read — row p of the
-        // host's table ([pair][64]: gr of the 32 VFOs, then -gi) goes into LDS with its two halves interleaved.  A task = 4 VFOs of one pair:
-        // two 16-byte loads, two 16-byte LDS writes; all loads of a work-item in flight before its first LDS write.
-        constexpr int NPS = (KS + 1) / 2, NT = NPS * 8, NB = (NT + 255) / 256;
-        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
-        float4* AL4 = reinterpret_cast<float4*>(AL);
-        float4 tr[NB], ti[NB];
-#pragma unroll
-        for (int q = 0; q < NB; q++) {
-            const int t = min(tid + q * 256, NT - 1), pr = t >> 3, j4 = t & 7;  // (index clamped, never a guarded load)
-            tr[q] = global_load_f32x4(at4, pr * 16 + j4);
-            ti[q] = global_load_f32x4(at4, pr * 16 + 8 + j4);
-        }
-#pragma unroll
-        for (int q = 0; q < NB; q++) {
-            const int t = tid + q * 256;
-            if (t < NT) {
-                const int pr = t >> 3, j4 = t & 7;
-                AL4[pr * 16 + 2 * j4] = make_float4(tr[q].x, ti[q].x, tr[q].y, ti[q].y);
-                AL4[pr * 16 + 2 * j4 + 1] = make_float4(tr[q].z, ti[q].z, tr[q].w, ti[q].w);
-            }
-        }
-    }
-    else {   // (all loads of a work-item in flight before the first LDS write: a wait per load is a memory round trip each — 8 of them measured)
-        constexpr int NB = 5;  // 68 pairs x 64 lanes = 17 floats per work-item: four rounds of 16-byte loads + a rest
-        const int n4 = NP4 * 16;
-        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
-        float4* AL4 = reinterpret_cast<float4*>(AL);
-        for (int i0 = tid; i0 < n4; i0 += 256 * NB) {
-            float4 tv[NB];
-#pragma unroll
-            for (int q = 0; q < NB; q++) { tv[q] = global_load_f32x4(at4, min(i0 + q * 256, n4 - 1)); }  // (index clamped, never a guarded load)
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                if (i0 + q * 256 < n4) { AL4[i0 + q * 256] = tv[q]; }
-            }
-        }
-    }
-    if (tid < VT) { outp[tid] = job.out[tid]; }
-    __syncthreads();
-    TICK_MARK(0);
-
     const int tile0 = (bid.x * 4 + wv) * job.tiles_per_wave;
-    if (tile0 * tile >= job.nout) { return; }
+    const bool has_tiles = tile0 * tile < job.nout;
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;  // tiles this wavefront really has
     if (ntl > job.tiles_per_wave) { ntl = job.tiles_per_wave; }
 
@@ -1540,12 +1496,66 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
 
     // ---- wavefront prologue: this lane's slice of the in-tile NCO table, first IQ tile ----
     float2 pt[16];
+    auto wave_prologue = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
+        for (int r = 0; r < 16; r++) {
+            const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
+        }
+        fetch(tile_base(tile0));
+    };
+#ifdef SDRPP_FCM_EARLY_IQ
+    // measurement build: the first IQ tile is requested BEFORE the tap table (at 10^6-sample blocks ~600 workgroups start together and the first
+    // tile arrived ~10 us into a front-end workgroup's life, behind everybody's table and window requests)
+    if (has_tiles) { wave_prologue(); }
+#endif
+    // ---- block prologue: tap operand table and output pointers (the only workgroup barrier of the kernel) ----
+    if constexpr (KS > 0) {
+        // pair-per-half form (see the matrix loop): lane (jl, hi) wants (gr, -gi) of VFO jl and pair 2 q + hi as ONE 8-byte read — row p of the
+        // host's table ([pair][64]: gr of the 32 VFOs, then -gi) goes into LDS with its two halves interleaved.  A task = 4 VFOs of one pair:
+        // two 16-byte loads, two 16-byte LDS writes; all loads of a work-item in flight before its first LDS write.
+        constexpr int NPS = (KS + 1) / 2, NT = NPS * 8, NB = (NT + 255) / 256;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        float4 tr[NB], ti[NB];
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int t = min(tid + q * 256, NT - 1), pr = t >> 3, j4 = t & 7;  // (index clamped, never a guarded load)
+            tr[q] = global_load_f32x4(at4, pr * 16 + j4);
+            ti[q] = global_load_f32x4(at4, pr * 16 + 8 + j4);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int t = tid + q * 256;
+            if (t < NT) {
+                const int pr = t >> 3, j4 = t & 7;
+                AL4[pr * 16 + 2 * j4] = make_float4(tr[q].x, ti[q].x, tr[q].y, ti[q].y);
+                AL4[pr * 16 + 2 * j4 + 1] = make_float4(tr[q].z, ti[q].z, tr[q].w, ti[q].w);
+            }
+        }
     }
-    fetch(tile_base(tile0));
+    else {   // (all loads of a work-item in flight before the first LDS write: a wait per load is a memory round trip each — 8 of them measured)
+        constexpr int NB = 5;  // 68 pairs x 64 lanes = 17 floats per work-item: four rounds of 16-byte loads + a rest
+        const int n4 = NP4 * 16;
+        const float4* at4 = reinterpret_cast<const float4*>(job.atab);
+        float4* AL4 = reinterpret_cast<float4*>(AL);
+        for (int i0 = tid; i0 < n4; i0 += 256 * NB) {
+            float4 tv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) { tv[q] = global_load_f32x4(at4, min(i0 + q * 256, n4 - 1)); }  // (index clamped, never a guarded load)
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                if (i0 + q * 256 < n4) { AL4[i0 + q * 256] = tv[q]; }
+            }
+        }
+    }
+    if (tid < VT) { outp[tid] = job.out[tid]; }
+    __syncthreads();
+    TICK_MARK(0);
+    if (!has_tiles) { return; }
+#ifndef SDRPP_FCM_EARLY_IQ
+    wave_prologue();
+#endif
 
     const float sgn = hi ? -1.0f : 1.0f;
     const float* P1 = hi ? XI : XR;
@@ -1600,7 +1610,8 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     if (2 * c + u < NQ) {
-                        const f32x2 s = pk_add_f32(ra[sl][u], rb[sl][u]), d = pk_add_nlo_nhi_f32(ra[sl][u], rb[sl][u]);
+                        f32x2 s, d;
+                        pk_sum_diff_f32(ra[sl][u], rb[sl][u], s, d);
                         accR = mfma_32x32x2(rg[sl][u].x, s.x, accR);
                         accR = mfma_32x32x2(rg[sl][u].y, d.y, accR);
                         accI = mfma_32x32x2(rg[sl][u].x, s.y, accI);
@@ -2078,7 +2089,8 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
                     const int q = q0 + u;
                     float2 a_n, b_n;
                     operands(q + 1 < NQ ? q + 1 : NQ - 1, a_n, b_n);  // one double pair = four matrix instructions ahead
-                    const f32x2 sm = pk_add_f32(a_c, b_c), df = pk_add_nlo_nhi_f32(a_c, b_c);
+                    f32x2 sm, df;
+                    pk_sum_diff_f32(a_c, b_c, sm, df);
                     accR = mfma_32x32x2(gq[u], sm.x, accR);
                     accR = mfma_32x32x2(hq[u], df.y, accR);
                     accI = mfma_32x32x2(gq[u], sm.y, accI);

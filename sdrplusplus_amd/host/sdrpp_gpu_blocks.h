@@ -20,6 +20,7 @@
 //       returns (decoder_modules/radio/src/demod.h:60); sdrpp_gpu_radio.h wraps that as a demod::Demodulator.
 #pragma once
 #include <atomic>
+#include <climits>
 #include <cassert>
 #include <chrono>
 #include <cmath>
@@ -322,17 +323,29 @@ public:
         tempStart();
     }
     // A several-GPU host gathers the waterfall lines of its streams on the display GPU over RCCL (sdrpp_gpu_rccl.h: BankLineGather): for that the
-    // newest raw dB line of this stream is kept in DEVICE memory of this front end's GPU, refreshed behind every block that completes one (bypass
-    // and buffered modes; two buffers, the complete one is handed out) — nothing of it crosses the bus until the gather's grouped send / receive.
+    // newest raw dB line of this stream is kept in DEVICE memory of this front end's GPU, refreshed behind every block that completes one — in
+    // EVERY mode: bypass and buffered blocks copy it on the device, pipelined blocks (setPipelining) take it out of the block's result slot —
+    // and nothing of it crosses the bus again until the gather's grouped send / receive.  The buffers belong to the worker (they are re-allocated
+    // when the FFT size changes); another thread never gets their address: it asks for a COPY, made under the lock the worker takes to flip or
+    // re-allocate them, so a gather can neither read a freed buffer nor a half-written line.
     void keepDeviceLine(bool enabled) {
         std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
         tempStop();
         _keepDevLine = enabled;
         tempStart();
     }
-    const float* latestLineDevice() const {  // fftSize floats on this front end's device; NULL until a line has been kept
-        const int k = devLineCur.load(std::memory_order_acquire);
-        return k >= 0 ? devLine[k] : nullptr;
+    // Newest raw dB line -> `dstDevice` (memory of THIS front end's device, room for `capacity` floats).  Returns the line's length (= the FFT
+    // size it was computed with), 0 if no line has been kept yet, -(length) if it does not fit `capacity` (nothing copied), INT_MIN on a copy error.
+    int copyLatestLineDevice(float* dstDevice, int capacity) {
+        std::lock_guard<std::mutex> lck(devLineMtx);
+        if (devLineCur < 0 || devLineSize <= 0) { return 0; }
+        if (devLineSize > capacity) { return -devLineSize; }
+        if (sdrpp_device_copy(ctx, dstDevice, devLine[devLineCur], (size_t)devLineSize * sizeof(float), 1)) { return INT_MIN; }
+        return devLineSize;
+    }
+    int deviceLineSize() {  // length of the line copyLatestLineDevice would hand out now (0: none yet)
+        std::lock_guard<std::mutex> lck(devLineMtx);
+        return devLineCur >= 0 ? devLineSize : 0;
     }
     int device() const { return _device; }
 
@@ -652,6 +665,7 @@ private:
             return -1;
         }
         std::vector<std::function<void()>> jobs;
+        if (_keepDevLine && r.n_lines > 0 && r.raw) { refreshDeviceLine(r.raw + (size_t)(r.n_lines - 1) * (size_t)r.fft_size, 0, r.fft_size); }
         if (r.n_lines > 0 && r.raw) {
             jobs.emplace_back([this, r]() {
                 for (int i = 0; i < r.n_lines; i++) {
@@ -737,6 +751,25 @@ private:
         for (auto& op : ops) { op(); }
     }
 
+    // keepDeviceLine: the newest raw line into the buffer that is NOT handed out, then the flip — all under devLineMtx (see copyLatestLineDevice).
+    // hostLine != NULL: the line lies in host memory (a pipelined block's result slot); else line `index` of the ordinary pass's lines on the device.
+    void refreshDeviceLine(const float* hostLine, int index, int fftSize) {
+        std::lock_guard<std::mutex> lck(devLineMtx);
+        if (devLineSize != fftSize) {
+            for (int k = 0; k < 2; k++) {
+                sdrpp_device_free(ctx, devLine[k]);
+                devLine[k] = (float*)sdrpp_device_alloc(ctx, (size_t)fftSize * sizeof(float));
+            }
+            devLineSize = fftSize;
+            devLineCur = -1;
+        }
+        const int nxt = devLineCur == 0 ? 1 : 0;
+        if (!devLine[nxt]) { return; }
+        const bool ok = hostLine ? sdrpp_device_copy(ctx, devLine[nxt], hostLine, (size_t)fftSize * sizeof(float), 0) == 0
+                                 : (sdrpp_fft_copy_device(ctx, index, 1, devLine[nxt], nullptr, nullptr) >= 0 && sdrpp_sync(ctx) == 0);
+        if (ok) { devLineCur = nxt; }
+    }
+
     // one block to the device (copy only; the kernels run with the first read of deliver())
     int stage(const dsp::complex_t* data, int count) {
         int rc = sdrpp_push(ctx, (const float*)data, count);
@@ -757,20 +790,7 @@ private:
             return -1;
         }
         SDRPP_BLOCKS_TICK(2)
-        if (_keepDevLine && nlines > 0) {  // the newest line stays on the device as well (keepDeviceLine)
-            if (devLineSize != _fftSize) {
-                for (int k = 0; k < 2; k++) {
-                    sdrpp_device_free(ctx, devLine[k]);
-                    devLine[k] = (float*)sdrpp_device_alloc(ctx, (size_t)_fftSize * sizeof(float));
-                }
-                devLineSize = _fftSize;
-                devLineCur.store(-1, std::memory_order_release);
-            }
-            const int cur = devLineCur.load(std::memory_order_relaxed), nxt = cur == 0 ? 1 : 0;
-            if (devLine[nxt] && sdrpp_fft_copy_device(ctx, nlines - 1, 1, devLine[nxt], nullptr, nullptr) >= 0 && sdrpp_sync(ctx) == 0) {
-                devLineCur.store(nxt, std::memory_order_release);
-            }
-        }
+        if (_keepDevLine && nlines > 0) { refreshDeviceLine(nullptr, nlines - 1, _fftSize); }  // the newest line stays on the device as well (keepDeviceLine)
         // all new lines with ONE device-to-host copy into page-locked staging; they are handed out below, next to the VFO blocks
         if (nlines > 0 && _acquire) {
             const size_t need = (size_t)nlines * (size_t)_fftSize;
@@ -1042,9 +1062,10 @@ private:
     std::vector<dsp::complex_t> inflightTap;
     int pipeFlags = 0;                      // result flags the context was put into pipelined mode with
     bool _keepDevLine = false;              // keepDeviceLine
-    float* devLine[2] = { nullptr, nullptr };
-    int devLineSize = 0;
-    std::atomic<int> devLineCur{ -1 };
+    float* devLine[2] = { nullptr, nullptr };  // (devLineMtx)
+    int devLineSize = 0;                       // floats per buffer = the FFT size of the line kept
+    int devLineCur = -1;                       // the complete buffer, -1: none
+    std::mutex devLineMtx;
     int _device = 0;
     std::mutex ctlMtx;
     std::vector<std::function<void()>> ctlOps;

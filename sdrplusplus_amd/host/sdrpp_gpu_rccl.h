@@ -5,6 +5,7 @@
 // extension) — lines are a few hundred KB per refresh against ~153 GB/s per xGMI link, so a direct gather is right, not a ring.
 // Needs <rccl/rccl.h> + the HIP runtime (link -lrccl -lamdhip64); kept out of sdrpp_gpu_multi.h so that hosts without RCCL build.
 #pragma once
+#include <climits>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -107,12 +108,16 @@ private:
 // device's block (device-to-device, on the device), then ONE grouped ncclSend / ncclRecv brings the blocks to the root device and one copy takes
 // them to the host — the lines of the other GPUs never travel through host memory.  One RCCL rank per DISTINCT device of the bank (two streams
 // on a one-GPU box: one rank, the collective still runs).
+// The lines are COPIED out of the front ends (IQFrontEnd::copyLatestLineDevice: under the lock their workers flip / re-allocate the buffers
+// with), in any mode of the front end (bypass, buffered, pipelined); a gather checks the bank's FFT size and every line's length and rebuilds
+// its blocks and communicator when the size has changed since init (StreamBank::setFFTSize) instead of reading past buffers of the new size.
 class BankLineGather {
 public:
     ~BankLineGather() { destroy(); }
     void init(StreamBank& bank_, int rootStream = 0) {
         destroy();
         bank = &bank_;
+        root = rootStream;
         n = bank->fftSize();
         const int ns = bank->size();
         if (ns <= 0 || rootStream < 0 || rootStream >= ns) { throw std::runtime_error("[sdrpp_gpu::BankLineGather] bad bank"); }
@@ -145,14 +150,20 @@ public:
     // out: [streams][fftSize] floats, the newest line of every stream (zeros for a stream that has none yet).  Returns the streams that had one.
     int gather(std::vector<float>& out) {
         if (!ready) { throw std::runtime_error("[sdrpp_gpu::BankLineGather] not initialised"); }
+        if (bank->fftSize() != n) { init(*bank, root); }  // the bank's FFT size changed since init: blocks and communicator for the new size
         const int ns = bank->size();
         int have = 0;
         for (int i = 0; i < ns; i++) {
-            const float* line = (*bank)[i].latestLineDevice();
-            if (!line) { continue; }
-            have++;
-            hip(hipSetDevice(devs[(size_t)rankOf[(size_t)i]]), "hipSetDevice");
-            hip(hipMemcpy(blocks[(size_t)rankOf[(size_t)i]] + (size_t)slotOf[(size_t)i] * (size_t)n, line, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+            float* slot = blocks[(size_t)rankOf[(size_t)i]] + (size_t)slotOf[(size_t)i] * (size_t)n;
+            const int got = (*bank)[i].copyLatestLineDevice(slot, n);  // a copy under the front end's lock, never a pointer into its buffers
+            if (got == n) { have++; }
+            else {
+                // no line yet, or a line of another length (this stream's worker has not produced one at the bank's new size yet, or a size
+                // change is on its way through the bank): the stream reports "no line" this time — zeros, as before its first line
+                hip(hipSetDevice(devs[(size_t)rankOf[(size_t)i]]), "hipSetDevice");
+                hip(hipMemset(slot, 0, (size_t)n * sizeof(float)), "hipMemset");
+                if (got == INT_MIN) { throw std::runtime_error("[sdrpp_gpu::BankLineGather] device copy of a stream's line failed"); }
+            }
         }
         std::vector<const float*> send(blocks.begin(), blocks.end());
         g.gather(send, (size_t)maxPer * (size_t)n);
@@ -189,7 +200,7 @@ private:
     std::vector<int> devs, perRank, rankOf, slotOf;
     std::vector<float*> blocks;
     std::vector<float> staging;
-    int n = 0, maxPer = 0;
+    int n = 0, maxPer = 0, root = 0;
     bool ready = false;
 };
 

@@ -137,8 +137,16 @@ class StreamRunner:
         # one by one would launch one tick, wait for it, launch the next ...
         if self.tickets and hasattr(self.ctx, "pipeline_flush"):
             self.ctx.pipeline_flush()
+        # the tickets are counted locally between two finish() calls (one ctypes call less per step); here — once per run, outside the per-step
+        # path — the count is checked against the context: another caller pushing on the same context, or a context whose pipeline was reset,
+        # would otherwise make the runner collect the wrong slots without noticing
+        if self.tickets and self._next_ticket is not None and hasattr(self.ctx, "ticket"):
+            now = self.ctx.ticket()
+            if now != self._next_ticket:
+                raise RuntimeError("StreamRunner: the context stands at ticket %d, the runner counted %d — somebody else pushed on this context or its pipeline was reset" % (now, self._next_ticket))
         while self.tickets:
             self._collect(self.tickets.pop(0))
+        self._next_ticket = None  # re-read from the context at the next step (the context may be re-configured between runs)
         self._flush_batch()
         if self.side is not None:
             self.side.synchronize()

@@ -96,8 +96,10 @@ static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return c;
 }
 struct f32x2 { float x, y; };
-static inline f32x2 pk_add_f32(float2 a, float2 b) { return f32x2{ a.x + b.x, a.y + b.y }; }
-static inline f32x2 pk_add_nlo_nhi_f32(float2 a, float2 b) { return f32x2{ b.x - a.x, a.y - b.y }; }
+static inline void pk_sum_diff_f32(float2 a, float2 b, f32x2& s, f32x2& d) {
+    s = f32x2{ a.x + b.x, a.y + b.y };
+    d = f32x2{ b.x - a.x, a.y - b.y };
+}
 struct f32x4 {
     float v[4];
     float& operator[](int i) { return v[i]; }
