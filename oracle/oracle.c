@@ -507,6 +507,23 @@ static void fir_reserve(orc_fir* f, int count) {
     f->buf = nb;
     f->cap = count;
 }
+/* FIR::setTaps (dsp/filter/fir.h:31-52): the delay line survives a change of the tap count — fewer taps keep the NEWEST ntaps - 1 samples,
+ * more taps put zeros in FRONT of the old ones. */
+static void fir_set_taps(orc_fir* f, const float* taps, int ntaps) {
+    const int old = f->ntaps, w = f->width;
+    if (f->buf) {
+        const size_t nh = (size_t)(ntaps - 1) * w;
+        float* nb = (float*)calloc(nh + (size_t)f->cap * w + 16, sizeof(float));
+        if (ntaps < old) { memcpy(nb, &f->buf[(size_t)(old - ntaps) * w], nh * sizeof(float)); }
+        else { memcpy(&nb[(size_t)(ntaps - old) * w], f->buf, (size_t)(old - 1) * w * sizeof(float)); }
+        free(f->buf);
+        f->buf = nb;
+    }
+    free(f->taps);
+    f->taps = (float*)malloc(sizeof(float) * (size_t)ntaps);
+    memcpy(f->taps, taps, sizeof(float) * (size_t)ntaps);
+    f->ntaps = ntaps;
+}
 static void fir_reset(orc_fir* f) {
     if (f->buf) { memset(f->buf, 0, sizeof(float) * (size_t)(f->ntaps - 1) * f->width); }
     f->offset = 0;
@@ -804,6 +821,18 @@ void orc_rxvfo_destroy(orc_rxvfo* v) {
 void orc_rxvfo_set_offset(orc_rxvfo* v, double offset) { /* rx_vfo.h:72-77: only phaseDelta changes */
     v->offset = offset;
     xlator_set_offset(&v->xl, -offset, v->inSR);
+}
+void orc_rxvfo_set_bandwidth(orc_rxvfo* v, double bandwidth) { /* rx_vfo.h:60-70: taps regenerated only when the filter is needed; FIR::setTaps keeps the delay line */
+    v->bandwidth = bandwidth;
+    v->filterNeeded = (bandwidth != v->outSR);
+    if (!v->filterNeeded) { return; }
+    const double filterWidth = bandwidth / 2.0; /* generateTaps, rx_vfo.h:117-121 */
+    int n = orc_estimate_tap_count(filterWidth * 0.1, v->outSR);
+    float* t = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    n = orc_low_pass(filterWidth, filterWidth * 0.1, v->outSR, 0, t, n);
+    fir_set_taps(&v->chan, t, n);
+    v->chanTaps = n;
+    free(t);
 }
 /* `out` must hold `count` complex samples (it is used as the in-place work buffer, like the reference). */
 int orc_rxvfo_process(orc_rxvfo* v, int count, const float* in, float* out) {

@@ -88,6 +88,7 @@ void ref_rxvfo_destroy(void* h) {
     delete r;
 }
 void ref_rxvfo_set_offset(void* h, double offset) { ((RefRxVFO*)h)->vfo.setOffset(offset); }
+void ref_rxvfo_set_bandwidth(void* h, double bandwidth) { ((RefRxVFO*)h)->vfo.setBandwidth(bandwidth); }  // rx_vfo.h:60-70 (FIR::setTaps keeps the delay line)
 // count <= 1 000 000 (STREAM_BUFFER_SIZE, dsp/stream.h:9); out must hold `count` complex samples.
 int ref_rxvfo_process(void* h, int count, const float* in, float* out) {
     RefRxVFO* r = (RefRxVFO*)h;

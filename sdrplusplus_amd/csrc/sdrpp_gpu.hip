@@ -968,8 +968,17 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     {   // the stream that feeds the channel filter must remember n-1 samples
         const int idx = (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1;
-        int rc = stream_grow_hist(c, v.st[(size_t)idx], n - 1);
+        Stream& fs = v.st[(size_t)idx];
+        int rc = stream_grow_hist(c, fs, n - 1);
         if (rc) { return rc; }
+        // FIR::setTaps (dsp/filter/fir.h:31-52): a LONGER filter starts with zeros in front of the old delay line — its old_n - 1 samples are
+        // all the reference kept, whatever the stream held before them.  The side buffer here holds the stream's true tail (newest last):
+        // everything older than the old filter's reach is cleared.  (A filter switched on from bypass, old_n = 0, starts from an all-zero delay
+        // line like a reference filter that has never run.)
+        const int keep = std::max(v.chan_ntaps - 1, 0);
+        if (n > v.chan_ntaps && fs.hist_len > keep && fs.hist[fs.cur]) {
+            HIPCHK(c, hipMemset(fs.hist[fs.cur], 0, (size_t)(fs.hist_len - keep) * (size_t)fs.width * sizeof(float)));
+        }
     }
     v.ctaps_chan.assign(taps, taps + n);
     v.chan_ntaps = n;

@@ -396,6 +396,19 @@ public:
     // file_source/src/main.cpp:74) or queued in the 32-slot frame buffer and processed by the second worker
     // (SampleFrameBuffer::run / worker, frame_buffer.h:51-98; same index arithmetic, so an overrun drops a whole lap like the reference).
     int run() override {
+        const int rc = runBlock();
+        if (rc >= 0) { _blocksTaken.fetch_add(1, std::memory_order_release); }
+        return rc;
+    }
+    // Addition (not in the reference): blocks the worker has taken from its input stream and finished handling (processed, pushed or queued in the
+    // frame buffer).  A control thread that has handed over block k and sees k + 1 here knows that a setter it calls now takes effect from
+    // block k + 1 on — how tests/host_cpp/test_reconfig.cpp makes a reconfiguration schedule deterministic.
+    uint64_t blocksTaken() const { return _blocksTaken.load(std::memory_order_acquire); }
+    // How long a stop (every setter's tempStop) lets the block in hand and the open hand-over finish before it stops the writers (doStop);
+    // default 250 ms — only a sink that does not read ever waits that long.
+    void setStopGrace(int milliseconds) { _stopGraceMs = milliseconds < 0 ? 0 : milliseconds; }
+
+    int runBlock() {
 #ifdef SDRPP_GPU_BLOCKS_PROF
         pipeT = std::chrono::steady_clock::now();
 #endif
@@ -553,11 +566,27 @@ protected:
         stopFrameWorker = false;
         helpers.start(6);  // hand-overs: 32 stream swaps per block are 32 futex wake-ups (~3 us each for the waker)
         stagers.start(3);
-        workerThread = std::thread(&IQFrontEnd::workerLoop, this);
+        workerDone.store(false, std::memory_order_relaxed);
+        workerThread = std::thread([this]() {
+            workerLoop();
+            workerDone.store(true, std::memory_order_release);
+        });
         frameThread = std::thread(&IQFrontEnd::frameWorker, this);
     }
     void doStop() override {
         for (auto& in : inputs) { in->stopReader(); }
+        // The reference stops readers and writers together: whatever a worker has in flight towards a stream is dropped (its swap() returns
+        // false).  There that is one block of one stage; here the worker's current block AND the hand-over batch on the helpers (30+ swaps: a
+        // whole block's outputs of every VFO) would go — at EVERY setter a GUI calls while blocks flow.  So the writers get a grace period first:
+        // the worker finishes the block it holds (its read() fails next) and the open hand-over completes — microseconds when the sinks read —
+        // and only a sink that does not read (the case stopWriter() exists for) runs into the time-out and loses the block, as in the reference.
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto limit = std::chrono::milliseconds(_stopGraceMs);
+            while ((!workerDone.load(std::memory_order_acquire) || helpers.busy()) && std::chrono::steady_clock::now() - t0 < limit) {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
         for (auto& out : outputs) { out->stopWriter(); }
         {
             std::lock_guard<std::mutex> lck(frameMtx);
@@ -665,8 +694,12 @@ private:
             return -1;
         }
         std::vector<std::function<void()>> jobs;
-        if (_keepDevLine && r.n_lines > 0 && r.raw) { refreshDeviceLine(r.raw + (size_t)(r.n_lines - 1) * (size_t)r.fft_size, 0, r.fft_size); }
-        if (r.n_lines > 0 && r.raw) {
+        // Lines of a block that was pushed BEFORE a setFFTSize and is handed out after it have the old size; the display's buffers (acquire) have
+        // the new one — the reference resizes the display first (gui::waterfall.setRawFFTSize, then IQFrontEnd::setFFTSize).  Such lines are
+        // dropped, like the frame the reference's Reshaper has in progress when it restarts; the block's VFO outputs are delivered as always.
+        const bool linesFit = r.fft_size == _fftSize;
+        if (_keepDevLine && linesFit && r.n_lines > 0 && r.raw) { refreshDeviceLine(r.raw + (size_t)(r.n_lines - 1) * (size_t)r.fft_size, 0, r.fft_size); }
+        if (linesFit && r.n_lines > 0 && r.raw) {
             jobs.emplace_back([this, r]() {
                 for (int i = 0; i < r.n_lines; i++) {
                     float* buf = _acquire ? _acquire(_fftCtx) : nullptr;
@@ -1047,6 +1080,9 @@ private:
     std::atomic<bool> _pipelining{ false };
     int _pipeLag = 8;
     bool pipeOn = false;                    // the context is in pipelined mode (owned by the worker)
+    std::atomic<uint64_t> _blocksTaken{ 0 };
+    std::atomic<bool> workerDone{ true };   // the worker thread has left its loop (doStop's grace period)
+    int _stopGraceMs = 250;                 // how long doStop lets the block in hand and the open hand-over finish before it stops the writers
     std::vector<uint64_t> pendingTickets;   // blocks launched whose results have not been handed out yet
     std::atomic<uint32_t> stageLeft{ 0 }, stagePending{ 0 };  // staging copy of the block being pushed: parts not yet copied / not yet accounted for
     uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
@@ -1161,6 +1197,11 @@ private:
                 std::lock_guard<std::mutex> lck(m);
                 cv.notify_all();
             }
+        }
+        // a batch is open and not all of its jobs have finished (any thread may ask)
+        bool busy() const {
+            const uint32_t total = (uint32_t)(word.load(std::memory_order_acquire) >> 32);
+            return total != 0 && finished.load(std::memory_order_acquire) < total;
         }
         void finish() {
             while (claim_and_run()) {}

@@ -64,6 +64,8 @@ def oracle():
         L.orc_rxvfo_create.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_rxvfo_destroy.argtypes = [C.c_void_p]
         L.orc_rxvfo_set_offset.argtypes = [C.c_void_p, C.c_double]
+        L.orc_rxvfo_set_bandwidth.argtypes = [C.c_void_p, C.c_double]
+        L.orc_rxvfo_set_bandwidth.restype = None
         L.orc_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.orc_rxvfo_info.argtypes = [C.c_void_p] + [c_int_p] * 8
         L.orc_rxvfo_phase_delta.argtypes = [C.c_void_p, c_float_p, c_float_p]
@@ -124,6 +126,8 @@ def ref(fast=False):
         L.ref_rxvfo_create.argtypes = [C.c_double] * 4
         L.ref_rxvfo_destroy.argtypes = [C.c_void_p]
         L.ref_rxvfo_set_offset.argtypes = [C.c_void_p, C.c_double]
+        L.ref_rxvfo_set_bandwidth.argtypes = [C.c_void_p, C.c_double]
+        L.ref_rxvfo_set_bandwidth.restype = None
         L.ref_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.ref_demod_create.restype = C.c_void_p
         L.ref_demod_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -269,6 +273,10 @@ class _Chain:
 
     def set_offset(self, offset):
         getattr(self.lib, self.p + "rxvfo_set_offset")(self.vfo, offset)
+
+    def set_bandwidth(self, bandwidth):
+        """RxVFO::setBandwidth (rx_vfo.h:60-70): new channel taps, the filter's delay line kept (fir.h:31-52)."""
+        getattr(self.lib, self.p + "rxvfo_set_bandwidth")(self.vfo, float(bandwidth))
 
     def close(self):
         if self.vfo:

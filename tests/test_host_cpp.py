@@ -108,6 +108,110 @@ def test_host_mirror_links_and_runs_against_the_reference_headers():
         _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp, drain_ms=3000)
 
 
+def _run_reconfig_and_check(exe, tmp, nextra, wait_ms):
+    """tests/host_cpp/test_reconfig.cpp: setters called between blocks of a RUNNING pipelined graph; the same schedule replayed on the oracle."""
+    from sdrplusplus_amd import capi, workloads
+
+    sr, B, nblk = 2.4e6, 12000, 13
+    x = workloads.synth(1, B * nblk, seed=9)
+    x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
+    r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), tmp, str(nextra), str(wait_ms)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ld = lambda name, dt: np.fromfile(os.path.join(tmp, name), dt)
+    radio, late, victim = (ld(n + ".f32", np.float32).reshape(-1, 2) for n in ("radio", "late", "victim"))
+    rc, lc, vc = (ld(n + "_counts.i32", np.int32) for n in ("radio", "late", "victim"))
+    sizes = ld("line_sizes.i32", np.int32)
+    lines = ld("lines.f32", np.float32)
+    # the oracle under the same schedule
+    o_radio = S.OracleChain(sr, 250e3, 150e3, 300e3, S.MODES["WFM"])
+    o_victim = S.OracleChain(sr, 250e3, 150e3, -200e3, S.MODES["WFM"])
+    o_late = S.OracleChain(sr, 250e3, 150e3, 500e3, S.MODES["WFM"])
+    specs = {}
+    for N in (4096, 2048):
+        nz, skip = capi.design_reshape_params(sr, N, 100.0)
+        specs[N] = S.OracleSpectrum(N, nz, skip, capi.design_fft_window(2, nz))
+    e_radio, e_late, e_victim, e_l4096, e_l2048 = [], [], [], [], []
+    for b in range(nblk):
+        blk = x[b * B:(b + 1) * B]
+        if b == 5:
+            o_radio.set_bandwidth(120e3)  # RxVFO::setBandwidth after block 4
+        e_radio.append(o_radio.process(blk)[1])
+        if b >= 3:
+            e_late.append(o_late.process(blk)[1])  # added after block 2: starts from an all-zero history with block 3
+        if b <= 5:
+            e_victim.append(o_victim.process(blk)[1])  # removed after block 5
+        (e_l4096 if b <= 6 else e_l2048).append(specs[4096 if b <= 6 else 2048].push(blk))  # setFFTSize(2048) after block 6: the framing restarts
+    tol = lambda ref: 1e-5 * max(1.0, float(np.sqrt(np.mean(ref ** 2))))
+    # "radio" and "late": EVERY block exactly once, in order — across addVFO / removeVFO / setBandwidth / setFFTSize / setPipelining off + on / stop + start
+    for name, got, cnt, exp in (("radio", radio, rc, e_radio), ("late", late, lc, e_late)):
+        assert [int(c) for c in cnt] == [len(e) for e in exp], (name, cnt.tolist(), [len(e) for e in exp])
+        ref = np.concatenate(exp)
+        assert got.shape == ref.shape and np.sqrt(np.mean((got - ref) ** 2)) < tol(ref), (name, float(np.sqrt(np.mean((got - ref) ** 2))))
+    # "victim": what it delivered before it was removed is a prefix of its stream, whole blocks, nothing twice
+    nv = len(vc)
+    assert nv <= len(e_victim) and [int(c) for c in vc] == [len(e) for e in e_victim[:nv]], (vc.tolist(), [len(e) for e in e_victim])
+    if nv:
+        ref = np.concatenate(e_victim[:nv])
+        assert victim.shape == ref.shape and np.sqrt(np.mean((victim - ref) ** 2)) < tol(ref)
+    # lines: 4096-point lines in order without a gap up to the change of size (those still in flight at the change are dropped with the display's
+    # old buffers), then EVERY 2048-point line of the restarted framing; bit-exact
+    n_old = int(np.sum(sizes == 4096))
+    assert np.all(sizes[:n_old] == 4096) and np.all(sizes[n_old:] == 2048), sizes.tolist()
+    o4, o2 = np.concatenate(e_l4096), np.concatenate(e_l2048)
+    assert n_old <= len(o4) and len(sizes) - n_old == len(o2), (n_old, len(o4), len(sizes) - n_old, len(o2))
+    g4 = lines[:n_old * 4096].reshape(-1, 4096)
+    g2 = lines[n_old * 4096:].reshape(-1, 2048)
+    assert np.array_equal(g4, o4[:n_old]) and np.array_equal(g2, o2)
+    return r.stdout
+
+
+def test_reconfigure_while_running_on_the_emulator():
+    """addVFO / setBandwidth / removeVFO (blocks in flight) / setFFTSize / setPipelining(false / true) / stop + start between the blocks of a RUNNING
+    pipelined graph (iq_frontend.cpp:105-183, dsp/block.h:46-94): every delivered block equals the oracle under the same schedule, none lost, none
+    twice.  CPU emulator build; three VFOs (the bank's blocks go through the pipelined host path — tickets, result slots, hand-over — as ordinary
+    passes: fewer than 17 VFOs have no matrix front end)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _run_reconfig_and_check(_build(tmp, lib="emu", source="test_reconfig.cpp"), tmp, 0, 60000)
+        assert "blocks 13" in out
+
+
+@pytest.mark.parametrize("san", ["address", "thread"])
+def test_reconfigure_while_running_host_side_under_sanitizers(san):
+    """The same program with the HOST side (the C++ mirror, the test double of dsp::stream / dsp::block, the test) compiled with
+    -fsanitize=address / -fsanitize=thread and linked with the emulator library: no memory error, no data race.  (ThreadSanitizer of GCC 11 does
+    not intercept pthread_cond_clockwait, which std::condition_variable::wait_for calls: it then believes the mutex is still held when the wait
+    returns and reports a "double lock" at the helpers' timed wait — the one report that is filtered out.)"""
+    from sdrplusplus_amd import workloads
+
+    subprocess.run(["make", "-C", EMU, "-s"], check=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_reconfig_" + san)
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-w", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_reconfig.cpp"),
+                            "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"), "-L" + EMU, "-l:libsdrpp_gpu_emu.so", "-Wl,-rpath," + EMU, "-lpthread"], capture_output=True, text=True)
+        if r.returncode != 0 and ("cannot find" in r.stderr or "sanitizer" in r.stderr.lower()):
+            pytest.skip("no %s sanitizer runtime in this toolchain" % san)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sr, B, nblk = 2.4e6, 12000, 13
+        workloads.synth(1, B * nblk, seed=9).view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0")
+        r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), tmp, "0", "120000"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "radio 16250 in 13 blocks, late 12500 in 10" in r.stdout, r.stdout
+        assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        reports = [ln for ln in r.stderr.splitlines() if ln.startswith("WARNING: ThreadSanitizer")]
+        assert all("double lock of a mutex" in ln for ln in reports), "\n".join(reports) + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_reconfigure_while_running_on_the_device():
+    """The same on the device with 18 more radios: the blocks run as ticks (matrix front end), results 7 blocks behind their pushes."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _run_reconfig_and_check(_build(tmp, source="test_reconfig.cpp"), tmp, 18, 20000)
+        assert "blocks 13" in out
+
+
 def test_device_math_helpers():
     """fm_phase (the discriminator's polynomial atan2) against double-precision atan2 over 2.5 M points, normalize_phase's range:
     the kernel header compiled for the host against the emulator's headers (tests/host_cpp/test_device_math.cpp)."""

@@ -76,6 +76,21 @@ def test_retune_mid_stream_bit_exact():
         assert np.array_equal(oi, ri)
 
 
+def test_bandwidth_change_mid_stream_bit_exact():
+    """RxVFO::setBandwidth (rx_vfo.h:60-70) between blocks: fewer taps, more taps, filter bypassed (bandwidth == out rate: the stale delay line
+    stays) and back — FIR::setTaps keeps the delay line (fir.h:31-52).  Oracle restatement vs the compiled reference, bit for bit."""
+    oc = S.OracleChain(10e6, 250e3, 150e3, 0.7e6, None)
+    rc = S.RefChain(10e6, 250e3, 150e3, 0.7e6, None)
+    x = _noise(5 * 50000, 6)
+    for b, bw in enumerate((150e3, 200e3, 90e3, 250e3, 120e3)):
+        if b:
+            oc.set_bandwidth(bw)
+            rc.set_bandwidth(bw)
+        oi, _ = oc.process(x[b * 50000:(b + 1) * 50000])
+        ri, _ = rc.process(x[b * 50000:(b + 1) * 50000])
+        assert oi.shape == ri.shape and np.array_equal(oi, ri), "block %d (bandwidth %g)" % (b, bw)
+
+
 def test_frontend_lines_bit_exact():
     """IQFrontEnd (threads, Splitter, Reshaper, handler — iq_frontend.cpp verbatim) vs the streaming restatement."""
     o, r = S.oracle(), S.ref()
