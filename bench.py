@@ -460,7 +460,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             "realtime_factor": round(per_gpu / sr, 1), "sr": sr, "fft": N, "nvfo": nvfo,
             "nco": ("SSB / DSB / raw channels: the reference's float rotator recursion on the device (nco_mode 2: every channel inside the north-star tolerance against the "
                     "compiled reference at arbitrary offsets); FM / AM channels closed form") if exact_ssb else ("closed form: FM / AM inside the tolerance for any run length; SSB / DSB audio and the raw IF differ from the reference by ITS rotator's rounding drift — "
-                                                         "+1.1e-6 .. 5.6e-6 (audio) / 1.8e-6 .. 9.1e-6 (IF) relative per 10^5 input samples at cfg 4, i.e. inside 1e-5 for the first ~1.8e5 .. 9e5 input samples after a VFO (re)starts, "
+                                                         "measured at cfg 4 (tests/test_bench_geometry_gpu.py::test_closed_form_nco_validity_window_vs_pinned_oracle): +2.8e-8 .. 1.05e-5 (audio, median 1.5e-6) / 1.0e-7 .. 3.1e-5 (IF, median 4.5e-6) relative per 10^5 input samples once the channel filter has filled; the worst channel leaves 1e-5 after ~2e5 input samples, the median one after ~1.2e6; "
                                                          "3e-7 for any length against the reference with an exact NCO (include/sdrpp_gpu.h, DESIGN.md 5); --nco ssb-exact runs those channels on the reference's own recursion"),
         }
         if pipelined:
@@ -611,8 +611,8 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
             csrc = os.path.join(ROOT, "sdrplusplus_amd", "csrc")
             subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "bench_blocks.cpp"), "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"),
                             "-L" + csrc, "-lsdrpp_gpu", "-Wl,-rpath," + csrc, "-lpthread"], check=True, capture_output=True)
-            for name, buffered, pipelined, reps in (("bypass_pipelined", 0, 1, 3), ("bypass_per_block", 0, 0, 1), ("buffered", 1, 0, 1)):
-                runs = []  # (the pipelined figure depends on how the host schedules 34 threads: three runs, median reported, all three listed)
+            for name, buffered, pipelined, reps in (("bypass_pipelined", 0, 1, 5), ("bypass_per_block", 0, 0, 1), ("buffered", 1, 0, 1)):
+                runs = []  # (the pipelined figure depends on how the host schedules 34 threads: five runs, median reported, min / max and all five listed)
                 for _ in range(reps):
                     r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "2" if reps > 1 else "3", str(buffered), str(pipelined)],
                                        capture_output=True, text=True, timeout=120)
@@ -622,6 +622,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
                 entry = dict(good[len(good) // 2]) if good else runs[-1]
                 if len(good) > 1:
                     entry["msps_runs"] = [q["msps"] for q in good]
+                    entry["msps_min"], entry["msps_max"] = good[0]["msps"], good[-1]["msps"]
                 res["cpp_iqfrontend_run_%s" % name] = entry
     except Exception as e:
         res["cpp_iqfrontend_run"] = {"error": repr(e)[:300]}
@@ -629,7 +630,9 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
                    "block: *_no_read leave the outputs on the device, *_results_delivered fetch the block from host memory AND deliver every VFO block + zoomed lines + palette indices into page-locked result slots "
                    "(sdrpp_result_wait / _release `pipelined_result_lag_blocks` blocks behind the push; no deferral, no batching); deferred_read = sdrpp_set_deferred: pushes staged, one ordinary pass + one read per "
                    "`deferred_pushes_per_pass` pushes; cpp_iqfrontend_run = tests/host_cpp/bench_blocks.cpp (SpeedTester-style source thread, one sink thread per VFO) through sdrpp_gpu::IQFrontEnd: bypass_pipelined = "
-                   "one block per launch, results handed to the streams a few blocks late; bypass_per_block = one ordinary pass per block; buffered = 32-slot frame buffer worked off as deferred passes")
+                   "one block per launch, results handed to the streams a few blocks late; bypass_per_block = one ordinary pass per block; buffered = 32-slot frame buffer worked off as deferred passes.  "
+                   "The C++ legs are built against the TEST DOUBLES of dsp/stream.h and dsp/block.h (tests/host_cpp/standalone: the GPU box has no reference tree) — same protocol and locking as the reference's "
+                   "headers, not the reference's own stream<T> object code under load")
     return res
 
 

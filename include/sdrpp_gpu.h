@@ -89,10 +89,13 @@ int sdrpp_set_reference_block(sdrpp_ctx* ctx, int ref_block);
  *   SDRPP_NCO_CLOSED_FORM (default): phase = arg(phaseDelta) * n evaluated in float64, folded into the first filter's taps; exact
  *     frequency, no drift.  FM / AM outputs agree with the reference to ~1e-7 for any run length; the raw IF and an SSB product detector
  *     additionally see the reference rotator's own rounding drift (1e-10 .. 2e-9 rad per sample, linear in time), which this mode does not have.
- *     VALIDITY WINDOW against the reference for SSB / DSB audio and the raw IF (measured at BASELINE cfg 4, 61.44 MS/s, 43 USB channels,
- *     DESIGN.md 5): the difference grows by 1.1e-6 .. 5.6e-6 (audio, relative RMS) resp. 1.8e-6 .. 9.1e-6 (IF) per 10^5 INPUT samples since the
- *     VFO was added / reset, i.e. it is inside BASELINE.json's 1e-5 for the first ~1.8e5 (worst channel) .. 9e5 (best) input samples — 3 to 15 ms
- *     of a 61.44 MS/s stream — and outside it from then on; against the reference with its rotator replaced by an exact NCO it stays at
+ *     VALIDITY WINDOW against the reference for SSB / DSB audio and the raw IF — MEASURED by tests/test_bench_geometry_gpu.py::
+ *     test_closed_form_nco_validity_window_vs_pinned_oracle (BASELINE cfg 4, 61.44 MS/s, 42 USB channels, pipelined, against the oracle pinned to
+ *     the reference's own rotator; windows of 10^5 INPUT samples since the VFO was added / reset, errors relative to the RMS of the reference
+ *     stream): audio inside BASELINE.json's 1e-5 over the first 2e5 input samples for every channel; once the channel filter has filled
+ *     (10^6 samples) the difference grows by 2.8e-8 .. 1.05e-5 per 10^5 samples (median channel 1.5e-6), the raw IF by 1.0e-7 .. 3.1e-5
+ *     (median 4.5e-6): the worst channel leaves 1e-5 in the third window, the median channel after ~1.2e6 input samples (20 ms of the stream);
+ *     against the reference with its rotator replaced by an exact NCO it stays at
  *     3e-7 for any length.  A host that needs SSB / raw-IF parity with the reference's OWN phase sequence beyond that window selects
  *     SDRPP_NCO_REFERENCE_ROTATOR for those channels (sdrpp_vfo_desc.nco_mode = 2: per VFO, the FM / AM channels of the bank stay on the fast path).
  *   SDRPP_NCO_REFERENCE_ROTATOR: the reference's float recursion itself (VOLK generic rotator2: phase *= phaseDelta in float, renormalised

@@ -95,6 +95,16 @@ __device__ __forceinline__ void global_store_f32x4(float* p, long long i, float4
     *((f32x4_a16 __attribute__((address_space(1)))*)(uintptr_t)(p + i)) = t;
 }
 
+// ... and only 4-byte aligned (one global_store_dwordx4 all the same)
+__device__ __forceinline__ void global_store_f32x4_unaligned(float* p, long long i, float4 v) {
+    f32x4_a4 t;
+    t.x = v.x;
+    t.y = v.y;
+    t.z = v.z;
+    t.w = v.w;
+    *((f32x4_a4 __attribute__((address_space(1)))*)(uintptr_t)(p + i)) = t;
+}
+
 // Scheduling fence: the instruction scheduler does not move anything across it.  Used to keep LDS reads issued two steps ahead
 // of the matrix instructions that consume them (left alone, the scheduler sinks them next to their use and the wave then
 // waits out the full LDS latency in front of every v_mfma).

@@ -315,7 +315,7 @@ struct sdrpp_ctx {
     // 32-output tiles per front-end job up to which the ratio-32 front end runs in its small-block shape (vfo_frontcm16_body); 0: never.
     // Unset: 256 for ordinary passes (sr/200 pushes 764 -> 814 MS/s) and for pipelined blocks that are read where they lie in device memory
     // (3.48 -> 3.96 GS/s), never for blocks the tick's landing copy fetches from host memory — workgroups that share a CU with a landing-copy
-    // workgroup start 8 us late, which the longer front end hides and the short one does not (profiles/r03zl-r03zn).
+    // workgroup start 8 us late, which the longer front end hides and the short one does not (DESIGN_HISTORY.md 4b, profiles/r03zl-r03zn).
     int fcm16_max_tiles = getenv("SDRPP_GPU_FCM16_MAX_TILES") ? atoi(getenv("SDRPP_GPU_FCM16_MAX_TILES")) : -1;
     bool plan_block_from_host = false;    // the block being planned reaches the device through a landing copy
     // phases handed over per full chunk: every 4th / 8th / 16th (cfg 4's 43 SSB channels, the family's time per 2^20 samples: 14.2 / 13.4 / 13.0 ms,

@@ -1165,18 +1165,19 @@ struct BankPlan {
             const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
             int mx = 0;
             for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }
+            // (carry_body moves 4 floats per access and up to 8 accesses per work-item: 8 192 floats per workgroup and round)
             if (iq_elems > 128 * 1024 * 2 && cj.size() > 1) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1, 0, carry.dev[l]);
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 255) / 256, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 8191) / 8192, 512)), 1, 0, carry.dev[l]);
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
             }
             else if (iq_elems > 16384 && cj.size() > 1) {
                 // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
                 // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
-                emit(c, l, F_MISC, TR_CARRY, 128, (int)cj.size(), 0, carry.dev[l]);
+                emit(c, l, F_MISC, TR_CARRY, 32, (int)cj.size(), 0, carry.dev[l]);
             }
             else {
                 mx = std::max(mx, iq_elems);
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 2048)), (int)cj.size(), 0, carry.dev[l]);
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 512)), (int)cj.size(), 0, carry.dev[l]);
             }
     }
 

@@ -160,7 +160,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
     }
     if (role_wgs > 3ll * c->num_cus) { c->stat_crowded++; }
     {   // where the stage-0 copies stand among the tick's workgroups (SDRPP_GPU_TICK_L0_AT: 0 = in front (default), -1 = behind all roles, n = behind
-        // the first n role workgroups): a switch for the measurement DESIGN.md 4b names as the next step
+        // the first n role workgroups): a switch for the measurement DESIGN_HISTORY.md 4b names as the next step
         const int l0_at = c->tick_l0_at;
         const int role_blocks = blocks - l0.blocks[0] - l0.blocks[1];
         l0.first = l0_at < 0 ? role_blocks : std::min(l0_at, role_blocks);
@@ -537,7 +537,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
                     std::vector<CarryJob> carry{ iqc };
                     CarryJob* d_carry = arena_push(c, carry);
                     if (!d_carry) { rc = fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
-                    else { emit(c, 1 + c->plan_lvl0, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 1023) / 1024, 2048)), 1, 0, d_carry); }
+                    else { emit(c, 1 + c->plan_lvl0, F_MISC, TR_CARRY, std::max(1, std::min((iqc.need * 2 + 8191) / 8192, 512)), 1, 0, d_carry); }
                 }
                 else { rc = do_vfos_plan(c, src, count, iqc); }
             }

@@ -3,7 +3,7 @@
 //
 // At that size every kernel of the path is latency-bound (a 50 000-sample block of the 32-VFO bank is less than one wave of work for
 // 256 CUs) and a block costs the SUM of its ~8 dependent launches + 2 cross-stream joins: 65 us per block, 0.75 GS/s, 1 % of the
-// roofline.  The stages of the path form a pipeline, though, and nothing but the data flow orders them: stage s of
+// roofline (DESIGN_HISTORY.md 6b).  The stages of the path form a pipeline, though, and nothing but the data flow orders them: stage s of
 // block n needs stage s-1 of block n (and, as filter history, of block n-1).  So the stages are SKEWED over consecutive launches:
 // tick t runs stage 0 (landing copy of the samples, upload of the job tables) of block t, stage 1 (front end, FFT pass 1, IQ history)
 // of block t-1, stage 2 (first separate decimator, FFT pass 2) of block t-2, ... — all of them independent inside one tick, every
@@ -55,7 +55,7 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
             uint4* d = reinterpret_cast<uint4*>(job.dst);
             const long long n16 = job.bytes / 16;
             // eight loads in flight per work-item before the first store: a copy out of page-locked host memory is a round trip over the bus per
-            // load, and FEW workgroups with many loads each disturb fewer CUs than many with one (whoever shares a CU with such a
+            // load, and FEW workgroups with many loads each disturb fewer CUs than many with one (DESIGN_HISTORY.md 4b: whoever shares a CU with such a
             // workgroup waits behind its reads)
             constexpr int U = 8;
             long long i = tid;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
     int b = (int)blockIdx.x;
     const int nb0 = l0.blocks[0] + l0.blocks[1];
     // (where in the grid the stage-0 copies stand is the host's choice — workgroups are handed out round the CUs in index order, and a
-    // workgroup that shares a CU with a landing copy from host memory waits behind its reads over the bus: DESIGN.md 4b)
+    // workgroup that shares a CU with a landing copy from host memory waits behind its reads over the bus: DESIGN_HISTORY.md 4b)
     const bool is_l0 = b >= l0.first && b < l0.first + nb0;
     if (is_l0) { b -= l0.first; }
     else if (b >= l0.first + nb0) { b -= nb0; }

@@ -962,23 +962,47 @@ __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, cons
     const CarryJob job = jobs[bid.y];
     const int first = (job.hist_len - job.need) * job.width;
     const int total = job.hist_len * job.width;
-    const int stride = gdim.x * 256;
-    // four independent elements per work-item and round, the loads branch-free and all in flight before the stores
-    for (int e0 = first + bid.x * 256 + (int)threadIdx.x; e0 < total; e0 += 4 * stride) {
-        float v[4];
+    // new_hist[e] = (old_hist ++ data)[n * width + e]: elements below `eb` still come from the old history (a push shorter than the history),
+    // the rest from the data of this push at data[e - eb]
+    const long long nw = (long long)job.n * job.width;
+    const long long ebl = (long long)total - nw;
+    const int eb = ebl < 0 ? 0 : (ebl > total ? total : (int)ebl);
+    // Round 5: FOUR floats per access (one dwordx4 load / store, 4-byte alignment is all global memory asks for) and eight accesses in flight per
+    // work-item before the first store — the carries of a tick were thousands of workgroups of one 4-byte load per work-item each (cfg 4: ~2 300
+    // workgroups of 3.9 us, the whole tail of the tick), their life a memory round trip whatever they carry: fewer, fatter workgroups.
+    const int first4 = (first + 3) & ~3;
+    const int nthreads = gdim.x * 256, t = bid.x * 256 + (int)threadIdx.x;
+    for (int e = first + t; e < first4 && e < total; e += nthreads) {  // (the up to three elements in front of the first whole quad)
+        const long long sx = nw + e;
+        job.new_hist[e] = global_load_f32(e < eb ? job.old_hist : job.data, e < eb ? sx : (long long)e - ebl);
+    }
+    constexpr int U = 8;
+    for (int q0 = first4 + 4 * t; q0 < total; q0 += 4 * nthreads * U) {
+        float4 v[U];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = min(e0 + q * stride, total - 1);  // (index clamped, never a guarded load)
-            const int i = e / job.width, c = e % job.width;
-            const long long sx = (long long)job.n + i;  // index into old_hist ++ data
-            const bool old = sx < job.hist_len;
-            const long long idx = old ? sx * job.width + c : (sx - job.hist_len) * job.width + c;
-            v[q] = global_load_f32(old ? job.old_hist : job.data, idx);
+        for (int u = 0; u < U; u++) {
+            int e = q0 + 4 * nthreads * u;
+            if (e >= total) { e = first4; }  // (beyond the end: some quad that exists — never a guarded load; nothing is stored for it below)
+            if (e + 3 < eb) { v[u] = global_load_f32x4_unaligned(job.old_hist, nw + e); }
+            else if (e >= eb && e + 3 < total) { v[u] = global_load_f32x4_unaligned(job.data, (long long)e - ebl); }
+            else {  // the quad that straddles the seam between the two sources, or the last, partial one: element by element
+                float w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ek = e + k < total ? e + k : total - 1;
+                    w4[k] = global_load_f32(ek < eb ? job.old_hist : job.data, ek < eb ? nw + ek : (long long)ek - ebl);
+                }
+                v[u] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = e0 + q * stride;
-            if (e < total) { job.new_hist[e] = v[q]; }
+        for (int u = 0; u < U; u++) {
+            const int e = q0 + 4 * nthreads * u;
+            if (e + 3 < total) { global_store_f32x4_unaligned(job.new_hist, e, v[u]); }
+            else if (e < total) {  // the last, partial quad
+                const float w4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+                for (int k = 0; k < 4 && e + k < total; k++) { job.new_hist[e + k] = w4[k]; }
+            }
         }
     }
 }
@@ -2155,7 +2179,7 @@ struct ToepJob {
 };
 
 // -DSDRPP_TOEP_KNOCK builds only (`make knock`, diagnostic, results are WRONG by design): g_toep_knock bit 0 drops the output stores,
-// bit 1 the window loads, bit 2 the matrix loop — the timing of what is left shows what each part costs.
+// bit 1 the window loads, bit 2 the matrix loop — the timing of what is left shows what each part costs (DESIGN_HISTORY.md §4).
 #ifdef SDRPP_TOEP_KNOCK
 __device__ int g_toep_knock;
 #endif

@@ -24,6 +24,7 @@ static inline float2 global_load_f32x2_boff(const void* base, unsigned byte_off)
 static inline void global_store_f32x2_boff(void* base, unsigned byte_off, float2 v) { *(float2*)((char*)base + byte_off) = v; }
 static inline void global_store_f32_boff(void* base, unsigned byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
+static inline void global_store_f32x4_unaligned(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline int opaque(int v) {

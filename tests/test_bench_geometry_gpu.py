@@ -277,8 +277,8 @@ def test_closed_form_nco_validity_window_vs_pinned_oracle():
         ctx.push(x[b * RB:(b + 1) * RB])
         for k, vid in enumerate(vids):
             got[k].append(ctx.vfo_read_if(vid).copy())
-    refi = _oracle_streams(raw, x, [RB] * nblk)
-    EI = np.stack([windows(np.concatenate(g).view(np.float32), oi.view(np.float32)) for g, (oi, _) in zip(got, refi)])
+    refi = [np.concatenate([ch.process(x[b * RB:(b + 1) * RB])[0] for b in range(nblk)]) for ch in raw]  # (a raw chain has no audio: not _oracle_streams)
+    EI = np.stack([windows(np.concatenate(g).view(np.float32), oi.view(np.float32)) for g, oi in zip(got, refi)])
     assert np.all(EI[:, 10:] <= 4e-5 * (np.arange(10, nw) + 1)), ("IF growth", float((EI[:, 10:] / (np.arange(10, nw) + 1)).max()))
     ratei = np.median(EI[:, 10:] / t[10:])
     assert 1e-6 < ratei < 1.2e-5, ("median IF growth per 1e5 input samples", float(ratei))

@@ -6,7 +6,11 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NM, int NLD>
+// ACC: 0 = the compiler's choice for the accumulators (in THIS small kernel: accumulation registers a[...]; in the product kernels, whose
+// accumulators are read by vector code, architectural VGPRs), 1 = pinned to a[...] (the upper half of gfx950's unified file), 2 = pinned to
+// v[...] through an asm constraint — round 5's question: does it matter to the overlap of matrix work and returning loads WHICH half of the
+// register file the accumulators live in (the product kernels use v[...], this probe had always measured a[...])?
+template <int NM, int NLD, int ACC = 0>
 __global__ __launch_bounds__(256) void probe(const float4* __restrict__ buf, size_t nvec, float* out, int iters, float seed) {
     f32x4 acc[4];
     for (int i = 0; i < 4; i++) { acc[i] = f32x4{ 0, 0, 0, 0 }; }
@@ -25,7 +29,11 @@ __global__ __launch_bounds__(256) void probe(const float4* __restrict__ buf, siz
             if (pos >= nvec) { pos -= nvec; }
         }
 #pragma unroll
-        for (int m = 0; m < NM; m++) { acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m & 3], 0, 0, 0); }
+        for (int m = 0; m < NM; m++) {
+            if constexpr (ACC == 1) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "v"(b)); }
+            else if constexpr (ACC == 2) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(a), "v"(b)); }
+            else { acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m & 3], 0, 0, 0); }
+        }
     }
     float s = 0.0f;
     for (int i = 0; i < 4; i++) { s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; }
@@ -33,16 +41,16 @@ __global__ __launch_bounds__(256) void probe(const float4* __restrict__ buf, siz
     if (s == 12345.678f) { out[threadIdx.x] = s; }
 }
 
-template <int NM, int NLD>
+template <int NM, int NLD, int ACC = 0>
 double run(const char* name, const float4* d_buf, size_t nvec, float* d_out, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const dim3 grid(256 * 4);  // 4 wavefronts per SIMD
-    hipLaunchKernelGGL((probe<NM, NLD>), grid, dim3(256), 0, 0, d_buf, nvec, d_out, 50, 1.0f);
+    hipLaunchKernelGGL((probe<NM, NLD, ACC>), grid, dim3(256), 0, 0, d_buf, nvec, d_out, 50, 1.0f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<NM, NLD>), grid, dim3(256), 0, 0, d_buf, nvec, d_out, iters, 1.0f);
+    hipLaunchKernelGGL((probe<NM, NLD, ACC>), grid, dim3(256), 0, 0, d_buf, nvec, d_out, iters, 1.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -71,5 +79,17 @@ int main() {
     run<16, 4>("16 mfma + 4 loads", d_buf, nvec, d_out, iters);
     run<8, 4>("8 mfma + 4 loads", d_buf, nvec, d_out, iters);
     run<32, 4>("32 mfma + 4 loads", d_buf, nvec, d_out, iters);
+    printf("-- accumulators in AGPRs --\n");
+    run<16, 0, 1>("16 mfma (agpr)", d_buf, nvec, d_out, iters);
+    run<16, 1, 1>("16 mfma (agpr) + 1 load", d_buf, nvec, d_out, iters);
+    run<16, 2, 1>("16 mfma (agpr) + 2 loads", d_buf, nvec, d_out, iters);
+    run<16, 4, 1>("16 mfma (agpr) + 4 loads", d_buf, nvec, d_out, iters);
+    run<32, 4, 1>("32 mfma (agpr) + 4 loads", d_buf, nvec, d_out, iters);
+    printf("-- accumulators in architectural VGPRs (what the product kernels use) --\n");
+    run<16, 0, 2>("16 mfma (vgpr)", d_buf, nvec, d_out, iters);
+    run<16, 1, 2>("16 mfma (vgpr) + 1 load", d_buf, nvec, d_out, iters);
+    run<16, 2, 2>("16 mfma (vgpr) + 2 loads", d_buf, nvec, d_out, iters);
+    run<16, 4, 2>("16 mfma (vgpr) + 4 loads", d_buf, nvec, d_out, iters);
+    run<32, 4, 2>("32 mfma (vgpr) + 4 loads", d_buf, nvec, d_out, iters);
     return 0;
 }

@@ -1,4 +1,4 @@
-// Stand-alone micro-benchmark behind the per-block ("tick") execution path: what does the runtime /
+// Stand-alone micro-benchmark behind the per-block ("tick") execution path (DESIGN_HISTORY.md section 6c): what does the runtime /
 // hardware charge for (A) a chain of small dependent launches on one stream, (B) a kernel that fetches its input from page-locked
 // host memory itself / writes results there, (C) completion signalled through a flag in host memory instead of an event wait,
 // (D) the same chain as a hipGraph with a fork / join.  Build: hipcc --offload-arch=gfx950 -O2 -o tick_probe tick_probe.hip
