@@ -690,7 +690,7 @@ struct BankPlan {
                 }
                 const int D1 = 1 << h.lgD;
                 const int K = h.K + (h.K2 - 1) * D1, lgD = h.lgD + h.lgD2;
-                const int NP = (K + 1) / 2, NP4 = (NP + 7) / 8 * 8;  // rows of the tap operand table, zero padded (the kernels read 4 / 8 rows at a time)
+                const int NP = (K + 1) / 2, NP4 = (NP + 15) / 16 * 16;  // rows of the tap operand table, zero padded (the kernels read up to 16 rows — a ring of four steps of four pairs — at a time)
                 const std::string key = member_key(m_long ? 'L' : 'M', &s1[g], vt);
                 float2* d_taps = nullptr;
                 auto it = c->s1_tap_cache.find(key);
@@ -746,7 +746,9 @@ struct BankPlan {
                 job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1);
                 job.nout = h.nout2;
                 job.min_idx = h.min_idx;
-                const int ntiles = (h.nout2 + SDRPP_FCM_TILE - 1) / SDRPP_FCM_TILE;
+                // (a long first stage with at most 16 VFOs runs in the 16 x 16 x 4 shape: 16 outputs per tile, vfo_frontcl_impl<PF, true>)
+                const int tile_n = (m_long && vt <= 16) ? 16 : SDRPP_FCM_TILE;
+                const int ntiles = (h.nout2 + tile_n - 1) / tile_n;
                 // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
                 // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
                 const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD, fcl_nw) * 4))) : 0;
@@ -884,6 +886,28 @@ struct BankPlan {
             if (!f2l[k].jobs.empty()) {
                 d_f2[k] = arena_push(c, f2l[k].jobs);
                 if (!d_f2[k]) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+            }
+        }
+        if (!fcl.jobs.empty()) {
+            // Tiles per wavefront of the long first stages, chosen over ALL their jobs (round 5, profiles/r05h_fcl_tiles_per_wave*.log): a tile is
+            // mostly start-up (window fetch, tile phasor, epilogue) around a matrix loop of 3 us (16 rows) .. 12 us (32 rows), and a wavefront that
+            // walks several tiles fetches the next window under the current loop — but the walks must still fill the device: the best setting
+            // put ~0.7 of the resident wavefront slots to work (cfg 4 at 10^6-sample blocks: 2 tiles per 32-row, 4 per 16-row wavefront, 8.29 ->
+            // 8.89 GS/s; at 307 200: 1 and 2, 5.11 -> 5.26; twice that was 15 % slower at either size).  SDRPP_GPU_FCL_TPW / _TPW16 override.
+            static const int tpw32_env = getenv("SDRPP_GPU_FCL_TPW") ? atoi(getenv("SDRPP_GPU_FCL_TPW")) : 0;
+            static const int tpw16_env = getenv("SDRPP_GPU_FCL_TPW16") ? atoi(getenv("SDRPP_GPU_FCL_TPW16")) : 0;
+            size_t lds_max = 0;
+            for (auto& jb : fcl.jobs) { lds_max = std::max(lds_max, (size_t)frontcl_lds_floats(jb.ntaps, jb.log2_decim, fcl_nw) * 4); }
+            const int long_blocks = std::max(1, (int)((size_t)(160 * 1024) / std::max<size_t>(lds_max, 1)));
+            const double target = 0.7 * 256.0 * (double)long_blocks * (double)fcl_nw;
+            fcl.max_blocks = 0;
+            for (auto& jb : fcl.jobs) {
+                const int tile_n = jb.nv <= 16 ? 16 : SDRPP_FCM_TILE;
+                const int ntiles = (jb.nout + tile_n - 1) / tile_n;
+                const int env = tile_n == 16 ? tpw16_env : tpw32_env;
+                const int tpw = env > 0 ? env : std::max(1, (int)((double)ntiles * (double)fcl.jobs.size() / target + 0.75));
+                jb.tiles_per_wave = tpw;
+                fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + fcl_nw * tpw - 1) / (fcl_nw * tpw));
             }
         }
         d_fcl = arena_push(c, fcl.jobs);

@@ -2001,19 +2001,23 @@ __host__ __device__ inline int frontcl_lds_floats(int K, int lgD, int nw = 2) {
 // PF: IQ samples prefetched per lane into registers (covers windows of nsamp <= 64 * PF samples: PF = 38 -> first stages up to 448
 // taps at /64); PF = 0: longer windows are loaded in place, unpipelined.
 #define SDRPP_FCL_PF 38
-template <int PF>
+// NARROW (round 5): jobs of at most 16 VFOs — cfg 4's 43 channels per mode are a job of 32 and a job of 11 — in the 16 x 16 x 4 shape: 16 VFO rows x 16
+// outputs per tile, the instruction's k = 0 .. 3 (lanes 16 kq .. 16 kq + 15) are FOUR consecutive tap pairs, each lane owning the pair 4 Q + kq of
+// output n = lane & 15.  Same pair-per-lane operands, same table, half the matrix cycles of a 32-row tile that would be two thirds empty.
+template <int PF, bool NARROW>
 // nw: tile engines (wavefronts) per workgroup — 2 for a launch of its own (128 work-items); as a role of the tick kernel, whose workgroups are
 // 256 wide, 4 when four wavefronts' planes fit half a CU's LDS (the build of the tick kernel that holds this role runs two workgroups per CU:
 // with two engines each only ONE wavefront per SIMD was at work, and the long first stages were three quarters of cfg 4's tick).
-__device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs, int nw = 2) {
+__device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs, int nw) {
     const FrontCMJob& job = jobs[bid.y];
-    constexpr int tile = SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
+    constexpr int tile = NARROW ? 16 : SDRPP_FCM_TILE, VT = SDRPP_FCM_VT;
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
     const int NP = (K + 1) >> 1;
     const bool odd = (K & 1) != 0;
     const int nsamp = (tile - 1) * D + K;
     const int pl = frontcm_plane(nsamp, lgD);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, jl = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int jl = NARROW ? (lane & 15) : (lane & 31), hi = NARROW ? (lane >> 4) : (lane >> 5);  // output inside the tile; which pair of a step this lane owns (kq for NARROW)
     float2* X2 = reinterpret_cast<float2*>(smemf + wv * 2 * pl);  // ONE skewed plane of complex samples (pair-per-half form, as vfo_frontcm_body)
     float2* ptile = reinterpret_cast<float2*>(smemf + 2 * nw * pl) + wv * VT;
     float2** outp = reinterpret_cast<float2**>(smemf + 2 * nw * pl + nw * VT * 2);
@@ -2063,17 +2067,24 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
     // 8-byte LDS reads, two packed adds give (sr, si) and (-dr, di), the taps (gr, -gi) of ITS pair come from rows 2 q + hi of the table:
     // per FOUR matrix instructions 2 LDS reads + 2 packed adds + 2 tap loads, where the pair-per-instruction form had 8 + 4 + 2 and
     // twice the index arithmetic.  Accumulation order per output: sums of pairs 2q, 2q + 1, then their differences.
-    const int NQ = (NP + 1) >> 1;               // double pairs (an odd number of pairs: the last one is paired with a zero row of the table)
-    const int c_half = (NP - 1) & 1, c_q = (NP - 1) >> 1;  // odd filters: the centre tap is "pair" NP - 1 with itself — its b operand is zero
+    constexpr int PPS = NARROW ? 4 : 2;         // tap pairs per matrix step (the k of the instruction)
+    const int NQ = (NP + PPS - 1) / PPS;        // steps (a last step that is not full multiplies valid samples by zero rows of the table)
+    const int c_half = (NP - 1) % PPS, c_q = (NP - 1) / PPS;  // odd filters: the centre tap is "pair" NP - 1 with itself — its b operand is zero
     const float2* Xa = X2 + ib + hi;
     const float2* Xb = X2 + ib;
-    const float* tg = job.atab + hi * 64 + jl;  // gr of pair 2 q + hi: tg[q * 128]; -gi: tg[q * 128 + 32]
+    const float* tg = job.atab + hi * 64 + jl;  // gr of pair PPS q + hi: tg[q * 64 * PPS]; -gi: 32 floats behind it
     auto operands = [&](int q, float2& a, float2& b) {  // q wave-uniform
-        const int p2 = 2 * q, kb = K - 1 - p2;
-        const int oa = p2 + (p2 >> lgD);                                           // (2q + 1) >> lgD == 2q >> lgD
-        const int ob0 = kb + (kb >> lgD), ob1 = (kb - 1) + ((kb - 1) >> lgD);      // scalar; the lane picks its half's
+        const int p2 = PPS * q, kb = K - 1 - p2;
+        const int oa = p2 + (p2 >> lgD);                                           // (p2 + hi) >> lgD == p2 >> lgD: PPS divides D
         a = Xa[oa];
-        b = Xb[hi ? ob1 : ob0];
+        if constexpr (NARROW) {
+            const int kbl = kb - hi;                                               // this lane's own b index: may cross a multiple of D inside the step
+            b = Xb[kbl + (kbl >> lgD)];
+        }
+        else {
+            const int ob0 = kb + (kb >> lgD), ob1 = (kb - 1) + ((kb - 1) >> lgD);  // scalar; the lane picks its half's
+            b = Xb[hi ? ob1 : ob0];
+        }
         if (odd && q == c_q && hi == c_half) { b = make_float2(0.0f, 0.0f); }
     };
     for (int it = 0; it < ntl; it++) {
@@ -2091,19 +2102,21 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
         if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop (spreading these loads over the loop — vector memory
                                                          // operations retire in order, the tap loads queue behind them — measured no faster)
         wave_sync();
-        f32x16 accR = mfma_zero(), accI = mfma_zero();
+        typename std::conditional<NARROW, f32x4, f32x16>::type accR, accI;
+        if constexpr (NARROW) { accR = mfma4_zero(); accI = mfma4_zero(); }
+        else { accR = mfma_zero(); accI = mfma_zero(); }
         {
-            // tap operand ring: four double pairs (eight table rows) ahead, coalesced 128-byte half rows of the [pair][64] table.  The loop runs
-            // over whole rings — the table is zero padded to a multiple of eight rows (plan_vfo.h), a padded double pair multiplies VALID
-            // samples (index clamped) by zero taps — so that every ring slot is a fixed register (a uniform branch per slot made the compiler
-            // rotate the ring through moves and wait for every tap load where it was issued)
+            // tap operand ring: four steps ahead, coalesced half rows of the [pair][64] table.  The loop runs over whole rings — the table is
+            // zero padded to a multiple of SIXTEEN rows (plan_vfo.h), a padded step multiplies VALID samples (index clamped) by zero taps — so
+            // that every ring slot is a fixed register (a uniform branch per slot made the compiler rotate the ring through moves and wait for
+            // every tap load where it was issued)
             constexpr int RING = 4;
             const int NQr = ((NQ + RING - 1) / RING) * RING;
             float gq[RING], hq[RING];
 #pragma unroll
             for (int u = 0; u < RING; u++) {
-                gq[u] = global_load_f32(tg, u * 128);
-                hq[u] = global_load_f32(tg, u * 128 + 32);
+                gq[u] = global_load_f32(tg, u * 64 * PPS);
+                hq[u] = global_load_f32(tg, u * 64 * PPS + 32);
             }
             float2 a_c, b_c;
             operands(0, a_c, b_c);
@@ -2112,17 +2125,25 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
                 for (int u = 0; u < RING; u++) {
                     const int q = q0 + u;
                     float2 a_n, b_n;
-                    operands(q + 1 < NQ ? q + 1 : NQ - 1, a_n, b_n);  // one double pair = four matrix instructions ahead
+                    operands(q + 1 < NQ ? q + 1 : NQ - 1, a_n, b_n);  // one step = four matrix instructions ahead
                     f32x2 sm, df;
                     pk_sum_diff_f32(a_c, b_c, sm, df);
-                    accR = mfma_32x32x2(gq[u], sm.x, accR);
-                    accR = mfma_32x32x2(hq[u], df.y, accR);
-                    accI = mfma_32x32x2(gq[u], sm.y, accI);
-                    accI = mfma_32x32x2(hq[u], df.x, accI);
+                    if constexpr (NARROW) {
+                        accR = mfma_16x16x4(gq[u], sm.x, accR);
+                        accI = mfma_16x16x4(gq[u], sm.y, accI);
+                        accR = mfma_16x16x4(hq[u], df.y, accR);
+                        accI = mfma_16x16x4(hq[u], df.x, accI);
+                    }
+                    else {
+                        accR = mfma_32x32x2(gq[u], sm.x, accR);
+                        accR = mfma_32x32x2(hq[u], df.y, accR);
+                        accI = mfma_32x32x2(gq[u], sm.y, accI);
+                        accI = mfma_32x32x2(hq[u], df.x, accI);
+                    }
                     sched_fence();  // the slot is reloaded BEHIND the matrix instructions that read it: the same registers, no copies, no wait for a load just issued
                     const int qn = q + RING < NQr ? q + RING : q;
-                    gq[u] = global_load_f32(tg, qn * 128);
-                    hq[u] = global_load_f32(tg, qn * 128 + 32);
+                    gq[u] = global_load_f32(tg, qn * 64 * PPS);
+                    hq[u] = global_load_f32(tg, qn * 64 * PPS + 32);
                     a_c = a_n;
                     b_c = b_n;
                 }
@@ -2131,12 +2152,13 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
         {
             const int j0 = tb * tile;
             const bool live = j0 + jl < job.nout;
+            constexpr int NR = NARROW ? 4 : 16;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            for (int r = 0; r < NR; r++) {
+                const int v = NARROW ? (4 * hi + r) : ((r & 3) + 8 * (r >> 2) + 4 * hi);  // the VFO row this lane holds in register r (sdrpp_gfx950.h)
                 if (v < job.nv && live) {
                     const float2 P = ptile[v];
-                    const float2 T = global_load_f32x2(job.ptab, v * tile + jl);  // in-tile NCO advance (L2-resident table; keeping it in 32 registers would spill the prefetch)
+                    const float2 T = global_load_f32x2(job.ptab, v * SDRPP_FCM_TILE + jl);  // in-tile NCO advance (L2-resident table; keeping it in 32 registers would spill the prefetch)
                     const float qr = fmaf(P.x, T.x, -(P.y * T.y)), qi = fmaf(P.x, T.y, P.y * T.x);
                     global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
                 }
@@ -2144,6 +2166,11 @@ __device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, c
         }
         wave_sync();
     }
+}
+template <int PF>
+__device__ __forceinline__ void vfo_frontcl_body(const KIdx bid, float* smemf, const IqSrc& src, const FrontCMJob* __restrict__ jobs, int nw = 2) {
+    if (jobs[bid.y].nv <= 16) { vfo_frontcl_impl<PF, true>(bid, smemf, src, jobs, nw); }  // (wave-uniform: a job is one geometry and one row count)
+    else { vfo_frontcl_impl<PF, false>(bid, smemf, src, jobs, nw); }
 }
 template <int PF>
 __global__ __launch_bounds__(128, 2) void vfo_frontcl_kernel(IqSrc src, const FrontCMJob* __restrict__ jobs) {

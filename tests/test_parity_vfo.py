@@ -146,13 +146,14 @@ def test_small_block_front_end_shape_is_bit_identical(backend, monkeypatch):
             assert sum(len(a) for a in outs[0][0]) > 0
 
 
-def test_long_first_stage_bank(backend):
+@pytest.mark.parametrize("nv,pushes", [(54, [307200, 100003, 204397]), (33, [153600, 70003, 83597])], ids=["18_per_mode", "11_per_mode_16_row_shape"])
+def test_long_first_stage_bank(backend, nv, pushes):
     """cfg 4 geometry (61.44 MS/s; plans 1024 / 4096 / 2048 with a /64 first stage of 257 / 400 / 329 taps): 18 VFOs per mode take
-    the matrix-core kernel for long first stages (vfo_frontcl_kernel), the stages behind it the Toeplitz kernels."""
+    the matrix-core kernel for long first stages (vfo_frontcl_kernel), the stages behind it the Toeplitz kernels; 11 per mode (what is left of
+    cfg 4's 43 channels per mode behind a job of 32) take its 16 x 16 x 4 shape (round 5: vfo_frontcl_impl<PF, true>, odd and even tap counts)."""
     from sdrplusplus_amd import workloads
 
-    sr, nv = 61.44e6, 54
-    pushes = [307200, 100003, 204397]
+    sr = 61.44e6
     x = workloads.synth(4, sum(pushes), seed=13, nvfo=nv)
     plan = workloads.vfo_plan(4, nv)
     ctx, vids, chains, _ = _setup(sr, [(m, c) for m, _, _, c, _ in plan], max(pushes))
