@@ -905,7 +905,10 @@ struct BankPlan {
                 const int tile_n = jb.nv <= 16 ? 16 : SDRPP_FCM_TILE;
                 const int ntiles = (jb.nout + tile_n - 1) / tile_n;
                 const int env = tile_n == 16 ? tpw16_env : tpw32_env;
-                const int tpw = env > 0 ? env : std::max(1, (int)((double)ntiles * (double)fcl.jobs.size() / target + 0.75));
+                // (ticks: the rule above.  An ordinary pass has the device to itself and its pushes are long: one resident round per JOB as before —
+                // the 0.7 rule gave walks of 34 tiles at 2^24-sample pushes and lost 17 % there, profiles/r05z_bench_default.json vs r05d)
+                const int resident = 256 * long_blocks * fcl_nw;
+                const int tpw = env > 0 ? env : (ticking ? std::max(1, (int)((double)ntiles * (double)fcl.jobs.size() / target + 0.75)) : std::max(1, (ntiles + resident - 1) / resident));
                 jb.tiles_per_wave = tpw;
                 fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + fcl_nw * tpw - 1) / (fcl_nw * tpw));
             }
