@@ -71,6 +71,7 @@ struct Vfo {
     int chan_kp = 0, audio_kp = 0;
     float* d_chan = nullptr;
     int chan_ntaps = 0;
+    std::vector<float> chan_stale;  // what the channel filter's delay line held when the filter was last bypassed (sdrpp_vfo_set_channel_taps)
     float* d_audio = nullptr;
     int audio_ntaps = 0;
     // device loop state: [AgcState agc][AgcState carrier][float dc]

@@ -969,15 +969,50 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
     {   // the stream that feeds the channel filter must remember n-1 samples
         const int idx = (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1;
         Stream& fs = v.st[(size_t)idx];
-        int rc = stream_grow_hist(c, fs, n - 1);
-        if (rc) { return rc; }
-        // FIR::setTaps (dsp/filter/fir.h:31-52): a LONGER filter starts with zeros in front of the old delay line — its old_n - 1 samples are
-        // all the reference kept, whatever the stream held before them.  The side buffer here holds the stream's true tail (newest last):
-        // everything older than the old filter's reach is cleared.  (A filter switched on from bypass, old_n = 0, starts from an all-zero delay
-        // line like a reference filter that has never run.)
-        const int keep = std::max(v.chan_ntaps - 1, 0);
-        if (n > v.chan_ntaps && fs.hist_len > keep && fs.hist[fs.cur]) {
-            HIPCHK(c, hipMemset(fs.hist[fs.cur], 0, (size_t)(fs.hist_len - keep) * (size_t)fs.width * sizeof(float)));
+        const int old_n = v.chan_ntaps, w = fs.width;
+        const bool was_on = old_n > 0, now_on = n > 0;
+        // ---- the filter's BYPASS switched (bandwidth == IF rate exactly, rx_vfo.h:60-70 / :89-100) ----
+        // (a) The consumers behind the filter read "the IF stream" with memory (the demodulator's audio low-pass): their delay line holds the last
+        //     samples they were FED — the filter's outputs until now, its input from now on, or the other way round.  The IF stream changes its
+        //     identity here (st[i_chan] <-> the filter's input stream), so the newest history goes with it.
+        // (b) The reference does not touch a bypassed filter: its delay line keeps what it held when it last ran, and a filter switched on again
+        //     continues from that stale content (FIR::setTaps moves it like any other change of the tap count, fir.h:31-52).  The stream's side
+        //     buffer here keeps being refreshed for consumer (a), so the filter's own last history is set aside when it goes to sleep and put
+        //     back — under the new tap count — when it wakes up.
+        if (was_on != now_on && v.i_chan >= 0) {
+            Stream& cs = v.st[(size_t)v.i_chan];
+            if (was_on && old_n > 1 && fs.hist[fs.cur] && fs.hist_len >= old_n - 1) {  // going to sleep: (b) first, (a) overwrites the buffer
+                v.chan_stale.resize((size_t)(old_n - 1) * (size_t)w);
+                HIPCHK(c, hipMemcpy(v.chan_stale.data(), fs.hist[fs.cur] + (size_t)(fs.hist_len - (old_n - 1)) * w, v.chan_stale.size() * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            if (now_on) {  // waking up: the buffer must be long enough for the new filter before anything is put into it
+                int rc = stream_grow_hist(c, fs, n - 1);
+                if (rc) { return rc; }
+            }
+            Stream& from = was_on ? cs : fs;
+            Stream& to = was_on ? fs : cs;
+            const int H = std::min(from.hist_len, to.hist_len);
+            if (H > 0 && from.hist[from.cur] && to.hist[to.cur] && from.width == to.width) {
+                HIPCHK(c, hipMemcpy(to.hist[to.cur] + (size_t)(to.hist_len - H) * w, from.hist[from.cur] + (size_t)(from.hist_len - H) * w, (size_t)H * w * sizeof(float), hipMemcpyDeviceToDevice));
+            }
+            if (now_on && fs.hist[fs.cur]) {  // (b): zeros, then the newest part of what the filter held when it last ran (all zeros for one that never ran)
+                HIPCHK(c, hipMemset(fs.hist[fs.cur], 0, (size_t)fs.hist_len * (size_t)w * sizeof(float)));
+                const int have = (int)(v.chan_stale.size() / (size_t)w), m = std::min(have, std::min(n - 1, fs.hist_len));
+                if (m > 0) {
+                    HIPCHK(c, hipMemcpy(fs.hist[fs.cur] + (size_t)(fs.hist_len - m) * w, v.chan_stale.data() + (size_t)(have - m) * w, (size_t)m * w * sizeof(float), hipMemcpyHostToDevice));
+                }
+            }
+        }
+        else {
+            int rc = stream_grow_hist(c, fs, n - 1);
+            if (rc) { return rc; }
+            // FIR::setTaps (dsp/filter/fir.h:31-52): a LONGER filter starts with zeros in front of the old delay line — its old_n - 1 samples are
+            // all the reference kept, whatever the stream held before them.  The side buffer here holds the stream's true tail (newest last):
+            // everything older than the old filter's reach is cleared.
+            const int keep = std::max(old_n - 1, 0);
+            if (n > old_n && fs.hist_len > keep && fs.hist[fs.cur]) {
+                HIPCHK(c, hipMemset(fs.hist[fs.cur], 0, (size_t)(fs.hist_len - keep) * (size_t)w * sizeof(float)));
+            }
         }
     }
     v.ctaps_chan.assign(taps, taps + n);
