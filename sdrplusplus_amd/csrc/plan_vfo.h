@@ -1321,7 +1321,6 @@ int do_vfos_plan(sdrpp_ctx* c, const IqSrc& src, int64_t count, const CarryJob& 
         }
     }
 #endif
-    const int n_in = (int)count;
     HostScope hs_all("plan: vfo bank");
     if (!c->bank_plan) {
         c->bank_plan = new BankPlan(c);
