@@ -347,7 +347,7 @@ __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float
     const int tiles = N2 / C;
     const int c_ = threadIdx.x % C;
     const int t_ = threadIdx.x / C;
-    for (int e = threadIdx.x; e < L1 / 2; e += TPF * C) { tw[e] = tw1_g[e]; }
+    for (int e = threadIdx.x; e < L1 / 2; e += TPF * C) { tw[e] = global_load_f32x2(tw1_g, e); }
     using R0 = FftRound<LG1, 0, 4>;
     using RL = typename FftLast<LG1>::Round;
     // raw samples of a tile (branch-free: the 16 loads of a work-item are in flight together; beyond the frame's nz samples the FFT input is zero).
@@ -387,7 +387,7 @@ __device__ __forceinline__ void fft_pass1_body(const KIdx bid, float2* tw, float
             for (int j = 0; j < 16; j++) {
                 const int n1 = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG1));
                 const int i = (n1 << lg2) + n2;
-                wv[j] = window[i < g.nz ? i : 0];
+                wv[j] = global_load_f32(window, i < g.nz ? i : 0);
             }
             wv_n2 = n2;
         }
@@ -473,7 +473,7 @@ __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float
     const int tiles = N1 / R;
     const int t_ = threadIdx.x % TPF;
     const int row_ = threadIdx.x / TPF;
-    for (int e = threadIdx.x; e < L2 / 2; e += TPF * R) { tw[e] = tw2_g[e]; }
+    for (int e = threadIdx.x; e < L2 / 2; e += TPF * R) { tw[e] = global_load_f32x2(tw2_g, e); }
     using R0 = FftRound<LG2, 0, 4>;
     using RL = typename FftLast<LG2>::Round;
     auto fetch = [&](float2 (&x)[16], int tile) {
@@ -483,7 +483,8 @@ __device__ __forceinline__ void fft_pass2_body(const KIdx bid, float2* tw, float
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int n = (int)(__brev((unsigned)R0::pos(t, 0, j)) >> (32 - LG2));
-            x[j] = srcrow[n];
+            x[j] = global_load_f32x2(srcrow, n);  // (explicit GLOBAL: as a tick role the pointer comes out of a table in memory and a plain dereference is a FLAT
+                                                  // load, which the LDS wait counter counts too — every LDS wait of the transform then waited for the NEXT tile's rows)
         }
     };
     const float inv = 1.0f / (float)((size_t)1 << (LG2 + lg1));
@@ -586,7 +587,7 @@ __device__ __forceinline__ void fft_pass2row_body(const KIdx bid, float2* tw, fl
     constexpr int L2 = 1 << LG2;
     constexpr int TPF = L2 / 16;
     const int t = threadIdx.x;
-    for (int e = threadIdx.x; e < L2 / 2; e += TPF) { tw[e] = tw2_g[e]; }
+    for (int e = threadIdx.x; e < L2 / 2; e += TPF) { tw[e] = global_load_f32x2(tw2_g, e); }
     float2* row = scratch + ((size_t)bid.x << LG2);  // bid.x = frame * N1 + k1
     float2 r[16];
     using R0 = FftRound<LG2, 0, 4>;
@@ -594,7 +595,7 @@ __device__ __forceinline__ void fft_pass2row_body(const KIdx bid, float2* tw, fl
     for (int j = 0; j < 16; j++) {
         const int p = R0::pos(t, 0, j);
         const int n = (int)(__brev((unsigned)p) >> (32 - LG2));
-        r[j] = row[n];
+        r[j] = global_load_f32x2(row, n);  // (explicit GLOBAL accesses throughout: FLAT ones as a tick role, see fft_pass2_body)
     }
     __syncthreads();
     R0::compute(r, t, tw);
@@ -618,7 +619,7 @@ __device__ __forceinline__ void fft_pass2row_body(const KIdx bid, float2* tw, fl
     }
     __syncthreads();
     float* dst = reinterpret_cast<float*>(row);
-    for (int e = threadIdx.x; e < L2; e += TPF) { dst[e] = tile[e]; }
+    for (int e = threadIdx.x; e < L2; e += TPF) { global_store_f32_boff(dst, (unsigned)e * 4u, tile[e]); }
 }
 template <int LG2>
 __global__ __launch_bounds__((1 << LG2) / 16) void fft_pass2row_kernel(float2* __restrict__ scratch, const float2* __restrict__ tw2_g, int lg1) {
@@ -642,13 +643,13 @@ __device__ __forceinline__ void fft_transpose_body(const KIdx bid, float* tile, 
     const int lgt = 13 - lg1;  // log2(TK2)
     for (int e = threadIdx.x; e < SDRPP_FFT_TR_TILE; e += 256) {
         const int k1 = e >> lgt, kk = e & (TK2 - 1);
-        tile[kk * pitch + k1] = src[((size_t)k1 << (lg2 + 1)) + kk];
+        tile[kk * pitch + k1] = global_load_f32(src, ((size_t)k1 << (lg2 + 1)) + kk);
     }
     __syncthreads();
     float* dst = out_db + ((size_t)frame << (lg1 + lg2)) + ((size_t)k2_0 << lg1);
     for (int e = threadIdx.x; e < SDRPP_FFT_TR_TILE; e += 256) {
         const int kk = e >> lg1, k1 = e & (N1 - 1);
-        dst[e] = tile[kk * pitch + k1];
+        global_store_f32_boff(dst, (unsigned)e * 4u, tile[kk * pitch + k1]);
     }
     if (grp_max) {
         const int gpr = N1 / gsz;  // groups per k2
@@ -660,7 +661,7 @@ __device__ __forceinline__ void fft_transpose_body(const KIdx bid, float* tile, 
                 const float v = tile[kk * pitch + gi * gsz + q];
                 if (v > m) { m = v; }
             }
-            gdst[g] = m;
+            global_store_f32_boff(gdst, (unsigned)g * 4u, m);
         }
     }
 }
@@ -686,20 +687,20 @@ __device__ __forceinline__ void zoom_palette_body(const KIdx bid, float* part, c
     const float* in = lines + (size_t)line * fft_size;
     float m = __uint_as_float(0xff800000u);  // -inf
     if (px < data_width) {
-        const int s = zstart[px], e = s + zcount[px];
+        const int s = global_load_i32(zstart, px), e = s + global_load_i32(zcount, px);
         if (grp_max && e - s >= 2 * gsz) {
             // pass 2 left the maximum of every aligned group of gsz bins: the pixel's range = ragged head + whole groups + ragged tail
             const int a = ((s + gsz - 1) / gsz) * gsz, bnd = (e / gsz) * gsz;
             const int nh = a - s, ng = (bnd - a) / gsz, nt = e - bnd;
             const float* g = grp_max + (size_t)line * (fft_size / gsz) + a / gsz;
             for (int i = q; i < nh + ng + nt; i += TP) {
-                const float v = (i < nh) ? in[s + i] : ((i < nh + ng) ? g[i - nh] : in[bnd + (i - nh - ng)]);
+                const float v = (i < nh) ? global_load_f32(in, s + i) : ((i < nh + ng) ? global_load_f32(g, i - nh) : global_load_f32(in, bnd + (i - nh - ng)));
                 if (v > m) { m = v; }
             }
         }
         else {
             for (int b = s + q; b < e; b += TP) {
-                const float v = in[b];
+                const float v = global_load_f32(in, b);
                 if (v > m) { m = v; }
             }
         }
@@ -716,11 +717,11 @@ __device__ __forceinline__ void zoom_palette_body(const KIdx bid, float* part, c
                 if (v > m) { m = v; }
             }
         }
-        zoomed[(size_t)line * data_width + px] = m;
+        global_store_f32_boff(zoomed, (unsigned)(((size_t)line * data_width + px) * 4u), m);
         const float range = wf_max - wf_min;
         const float v = (m < wf_min) ? wf_min : ((wf_max < m) ? wf_max : m);
         const float pixel = (v - wf_min) / range;
-        index[(size_t)line * data_width + px] = (int32_t)(pixel * 999999.0f);
+        global_store_f32_boff(index, (unsigned)(((size_t)line * data_width + px) * 4u), __int_as_float((int32_t)(pixel * 999999.0f)));
     }
 }
 template <int TP>

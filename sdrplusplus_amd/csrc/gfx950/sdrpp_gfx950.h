@@ -95,6 +95,22 @@ __device__ __forceinline__ void global_store_f32x4(float* p, long long i, float4
     *((f32x4_a16 __attribute__((address_space(1)))*)(uintptr_t)(p + i)) = t;
 }
 
+// 16 bytes as four dwords through the GLOBAL address space (copies: tick_kernels.h copy_one).  A generic `const void*` makes every access FLAT, and a
+// flat store may alias private memory — so the compiler kept a copy loop's in-flight values in SCRATCH and reloaded each one behind the store before
+// it (round 5: 8 scratch stores + 8 scratch loads per 8 copied vectors in the landing copy, the job-table upload and the result copies of every tick).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 global_load_u32x4(const void* p, long long i) {
+    const u32x4_t v = ((const u32x4_t __attribute__((address_space(1)))*)(uintptr_t)p)[i];
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void global_store_u32x4(void* p, long long i, uint4 v) {
+    u32x4_t t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    ((u32x4_t __attribute__((address_space(1)))*)(uintptr_t)p)[i] = t;
+}
+__device__ __forceinline__ unsigned global_load_u32(const void* p, long long i) { return ((const unsigned __attribute__((address_space(1)))*)(uintptr_t)p)[i]; }
+__device__ __forceinline__ void global_store_u32(void* p, long long i, unsigned v) { ((unsigned __attribute__((address_space(1)))*)(uintptr_t)p)[i] = v; }
+
 // ... and only 4-byte aligned (one global_store_dwordx4 all the same)
 __device__ __forceinline__ void global_store_f32x4_unaligned(float* p, long long i, float4 v) {
     f32x4_a4 t;

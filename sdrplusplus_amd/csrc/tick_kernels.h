@@ -50,9 +50,9 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
     else {
         const bool al16 = ((((unsigned long long)job.src) | ((unsigned long long)job.dst)) & 15ull) == 0ull;
         long long done = 0;
+        // (explicit GLOBAL loads / stores: through the generic pointers of the job every access was FLAT, and the eight in-flight vectors below
+        // lived in scratch memory — stored and reloaded around every store, because a flat store may alias private memory: sdrpp_gfx950.h)
         if (al16) {
-            const uint4* s = reinterpret_cast<const uint4*>(job.src);
-            uint4* d = reinterpret_cast<uint4*>(job.dst);
             const long long n16 = job.bytes / 16;
             // eight loads in flight per work-item before the first store: a copy out of page-locked host memory is a round trip over the bus per
             // load, and FEW workgroups with many loads each disturb fewer CUs than many with one (DESIGN_HISTORY.md 4b: whoever shares a CU with such a
@@ -62,17 +62,15 @@ __device__ __forceinline__ void copy_one(const CopyJob& job, int bx, int gx) {
             for (; i + (U - 1) * nth < n16; i += U * nth) {
                 uint4 v[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) { v[u] = s[i + u * nth]; }
+                for (int u = 0; u < U; u++) { v[u] = global_load_u32x4(job.src, i + u * nth); }
 #pragma unroll
-                for (int u = 0; u < U; u++) { d[i + u * nth] = v[u]; }
+                for (int u = 0; u < U; u++) { global_store_u32x4(job.dst, i + u * nth, v[u]); }
             }
-            for (; i < n16; i += nth) { d[i] = s[i]; }
+            for (; i < n16; i += nth) { global_store_u32x4(job.dst, i, global_load_u32x4(job.src, i)); }
             done = n16 * 4;
         }
-        const unsigned* s = reinterpret_cast<const unsigned*>(job.src);
-        unsigned* d = reinterpret_cast<unsigned*>(job.dst);
         const long long n4 = job.bytes / 4;
-        for (long long i = done + tid; i < n4; i += nth) { d[i] = s[i]; }
+        for (long long i = done + tid; i < n4; i += nth) { global_store_u32(job.dst, i, global_load_u32(job.src, i)); }
     }
     // (results for the host: page-locked memory is not cached on the device, the stores are complete — tick_finish waits for them — before
     // this wavefront counts itself done)

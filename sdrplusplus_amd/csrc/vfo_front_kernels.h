@@ -164,7 +164,7 @@ __host__ __device__ inline int frontcm_plane(int nsamp, int lgD) {
     return ((sk + 31) / 64) * 64 + 32;
 }
 // LDS map (float offsets): [4 wavefronts x (XR, XI planes) | tap operand table | 4 x 32 tile phasors | 32 output pointers]
-struct FCMLayout { int pl, a_off, pt_off, out_off, total; };
+struct FCMLayout { int pl, a_off, pt_off, out_off, total, nco_off; };
 __host__ __device__ inline FCMLayout frontcm_layout(int K, int lgD) {
     FCMLayout L;
     const int nsamp = (SDRPP_FCM_TILE - 1) * (1 << lgD) + K;
@@ -174,6 +174,11 @@ __host__ __device__ inline FCMLayout frontcm_layout(int K, int lgD) {
     L.pt_off = L.a_off + np4 * 64;
     L.out_off = L.pt_off + 4 * SDRPP_FCM_VT * 2;
     L.total = L.out_off + SDRPP_FCM_VT * 2;
+    // (round 5) the in-tile NCO table [32 VFOs][32 outputs] for the epilogue: held in 32 registers per lane until now, it pushed the kernel over its
+    // 168 registers — ten 8-byte spill stores and reloads per lane and TILE (the next tile's prefetched IQ samples), 10 MB of scratch writes per
+    // 10^6-sample block on top of the 16 MB the front end has to write (profiles/r05p_per_role_instruction_mix.md: WRITE_SIZE 26.5 MB)
+    L.nco_off = L.total;
+    L.total += SDRPP_FCM_VT * SDRPP_FCM_TILE * 2;
     return L;
 }
 
@@ -249,15 +254,8 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     };
 
     // ---- wavefront prologue: this lane's slice of the in-tile NCO table, first IQ tile ----
-    float2 pt[16];
-    auto wave_prologue = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            pt[r] = global_load_f32x2(job.ptab, v * tile + jl);
-        }
-        fetch(tile_base(tile0));
-    };
+    const float2* PT = reinterpret_cast<const float2*>(smemf + L.nco_off) + jl;  // [v * tile]: exp(j 2 pi theta_v D n) of this lane's output n
+    auto wave_prologue = [&]() { fetch(tile_base(tile0)); };
 #ifdef SDRPP_FCM_EARLY_IQ
     // measurement build: the first IQ tile is requested BEFORE the tap table (at 10^6-sample blocks ~600 workgroups start together and the first
     // tile arrived ~10 us into a front-end workgroup's life, behind everybody's table and window requests)
@@ -304,6 +302,13 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
         }
     }
     if (tid < VT) { outp[tid] = job.out[tid]; }
+    {   // in-tile NCO table -> LDS: 2 048 floats, two 16-byte loads per work-item
+        const float4* pg = reinterpret_cast<const float4*>(job.ptab);
+        float4* pl4 = reinterpret_cast<float4*>(smemf + L.nco_off);
+        const float4 t0 = global_load_f32x4(pg, tid), t1 = global_load_f32x4(pg, tid + 256);
+        pl4[tid] = t0;
+        pl4[tid + 256] = t1;
+    }
     __syncthreads();
     TICK_MARK(0);
     if (!has_tiles) { return; }
@@ -413,8 +418,8 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
             for (int r = 0; r < 16; r++) {
                 const int v = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (v < job.nv && live) {
-                    const float2 P = ptile[v];
-                    const float qr = fmaf(P.x, pt[r].x, -(P.y * pt[r].y)), qi = fmaf(P.x, pt[r].y, P.y * pt[r].x);
+                    const float2 P = ptile[v], T = PT[v * tile];
+                    const float qr = fmaf(P.x, T.x, -(P.y * T.y)), qi = fmaf(P.x, T.y, P.y * T.x);
                     global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
                 }
             }

@@ -31,11 +31,11 @@ __device__ __forceinline__ float2 stream_load2(const StreamIn& s, int i) {
     const float2* d = reinterpret_cast<const float2*>(s.data);
     const float2* h = reinterpret_cast<const float2*>(s.hist);
     if (i >= s.n) { return make_float2(0.0f, 0.0f); }  // tile over-read past the end of this push
-    return (i >= 0) ? d[i] : h[s.hist_len + i];
+    return (i >= 0) ? global_load_f32x2(d, i) : global_load_f32x2(h, s.hist_len + i);  // (explicit GLOBAL loads: a plain dereference of a job-table pointer is FLAT)
 }
 __device__ __forceinline__ float stream_load1(const StreamIn& s, int i) {
     if (i >= s.n) { return 0.0f; }
-    return (i >= 0) ? s.data[i] : s.hist[s.hist_len + i];
+    return (i >= 0) ? global_load_f32(s.data, i) : global_load_f32(s.hist, s.hist_len + i);
 }
 // The same without a branch, for loops that fetch several samples per lane: the load is unconditional (the address is clamped into the
 // stream, the value selected afterwards), so the compiler issues all loads of the loop before the first wait — behind a per-element
@@ -363,14 +363,14 @@ struct PreJob {
 __device__ __forceinline__ void vfo_demod_pre_body(const KIdx bid, const KIdx gdim, const PreJob* __restrict__ jobs) {
     const PreJob& job = jobs[bid.y];
     for (int i = bid.x * blockDim.x + threadIdx.x; i < job.n; i += gdim.x * blockDim.x) {
-        const float2 x = job.in[i];
-        if (job.mode == 2) { job.out[i] = sqrtf((x.x * x.x) + (x.y * x.y)); }
+        const float2 x = global_load_f32x2(job.in, i);  // (explicit GLOBAL accesses: FLAT ones as a tick role)
+        if (job.mode == 2) { global_store_f32_boff(job.out, (unsigned)i * 4u, sqrtf((x.x * x.x) + (x.y * x.y))); }
         else {
             double ph = fma((double)i, job.theta2, job.phi2);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);
-            job.out[i] = fmaf(x.x, cs, -(x.y * sn));
+            global_store_f32_boff(job.out, (unsigned)i * 4u, fmaf(x.x, cs, -(x.y * sn)));
         }
     }
 }
@@ -616,7 +616,7 @@ __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, cons
     const int nthreads = gdim.x * 256, t = bid.x * 256 + (int)threadIdx.x;
     for (int e = first + t; e < first4 && e < total; e += nthreads) {  // (the up to three elements in front of the first whole quad)
         const long long sx = nw + e;
-        job.new_hist[e] = global_load_f32(e < eb ? job.old_hist : job.data, e < eb ? sx : (long long)e - ebl);
+        global_store_f32_boff(job.new_hist, (unsigned)e * 4u, global_load_f32(e < eb ? job.old_hist : job.data, e < eb ? sx : (long long)e - ebl));
     }
     constexpr int U = 8;
     for (int q0 = first4 + 4 * t; q0 < total; q0 += 4 * nthreads * U) {
@@ -643,7 +643,7 @@ __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, cons
             if (e + 3 < total) { global_store_f32x4_unaligned(job.new_hist, e, v[u]); }
             else if (e < total) {  // the last, partial quad
                 const float w4[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
-                for (int k = 0; k < 4 && e + k < total; k++) { job.new_hist[e + k] = w4[k]; }
+                for (int k = 0; k < 4 && e + k < total; k++) { global_store_f32_boff(job.new_hist, (unsigned)(e + k) * 4u, w4[k]); }
             }
         }
     }
@@ -829,9 +829,9 @@ __device__ __forceinline__ void vfo_firb_body(const KIdx bid, float* smem, const
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if (jo + r < job.nout) {
-            if constexpr (WIDTH == 2) { reinterpret_cast<float2*>(job.out)[jo + r] = acc[r]; }
-            else if constexpr (STEREO) { reinterpret_cast<float2*>(job.out)[jo + r] = make_float2(acc[r], acc[r]); }
-            else { job.out[jo + r] = acc[r]; }
+            if constexpr (WIDTH == 2) { global_store_f32x2(reinterpret_cast<float2*>(job.out), jo + r, acc[r]); }  // (explicit GLOBAL stores: FLAT ones as a tick role)
+            else if constexpr (STEREO) { global_store_f32x2(reinterpret_cast<float2*>(job.out), jo + r, make_float2(acc[r], acc[r])); }
+            else { global_store_f32_boff(job.out, (unsigned)(jo + r) * 4u, acc[r]); }
         }
     }
 }

@@ -25,6 +25,10 @@ static inline void global_store_f32x2_boff(void* base, unsigned byte_off, float2
 static inline void global_store_f32_boff(void* base, unsigned byte_off, float v) { *(float*)((char*)base + byte_off) = v; }
 static inline void global_store_f32x4(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
 static inline void global_store_f32x4_unaligned(float* p, long long i, float4 v) { p[i] = v.x; p[i + 1] = v.y; p[i + 2] = v.z; p[i + 3] = v.w; }
+static inline uint4 global_load_u32x4(const void* p, long long i) { return ((const uint4*)p)[i]; }
+static inline void global_store_u32x4(void* p, long long i, uint4 v) { ((uint4*)p)[i] = v; }
+static inline unsigned global_load_u32(const void* p, long long i) { return ((const unsigned*)p)[i]; }
+static inline void global_store_u32(void* p, long long i, unsigned v) { ((unsigned*)p)[i] = v; }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline void sched_fence() {}
 static inline int opaque(int v) {

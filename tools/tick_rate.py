@@ -19,6 +19,9 @@ def main():
 
     from sdrplusplus_amd import capi, workloads
 
+    if os.environ.get("SDRPP_TOOL_LIB"):  # (a switch of this TOOL for A / B runs of library builds; the package itself has no override)
+        capi.DEFAULT_LIB = os.path.join(ROOT, "sdrplusplus_amd", "csrc", os.environ["SDRPP_TOOL_LIB"])
+
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     sizes = [int(a) for a in sys.argv[2:]] or [int(workloads.CFG[cfg]["sr"] / 200), 1000000]
     nvfo = workloads.CFG[cfg]["nvfo"]
