@@ -3,7 +3,7 @@
 # passes (FETCH_SIZE / WRITE_SIZE, one pass each) of the headline workload AND of cfg 2, cfg 4 and the sr/200 blocks (pipelined mode), the
 # instruction mix of the headline tick, tick timelines.   usage: bash tools/profile_r04.sh [tag]
 set -u
-TAG=${1:-r05z}
+TAG=${1:-r05zc}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
