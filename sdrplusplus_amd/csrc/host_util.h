@@ -390,6 +390,7 @@ int vfo_reset_state(sdrpp_ctx* c, Vfo& v) {
     v.phi2 = 0.0;
     v.seen = 0;
     v.recs.clear();
+    std::fill(v.chan_stale.begin(), v.chan_stale.end(), 0.0f);  // RxVFO::reset clears the channel filter's delay line whether it is bypassed or not (rx_vfo.h:79-87)
     for (int i = 0; i < SDRPP_MAX_DECIM_STAGES; i++) { v.soff[i] = 0; }
     v.pphase = 0;
     v.poff = 0;

@@ -639,6 +639,40 @@ def test_bandwidth_change_mid_stream(backend):
     ctx.close()
 
 
+def test_reset_while_channel_filter_is_bypassed(backend):
+    """RxVFO::reset (rx_vfo.h:79-87) clears the channel filter's delay line whether the filter is in the chain or bypassed: a filter that ran, was
+    bypassed, was RESET while bypassed and is switched on again starts from zeros — not from the stale delay line a bypass alone would keep
+    (test_bandwidth_change_mid_stream).  After the reset the chain equals a brand-new one bypassed before its first block."""
+    from sdrplusplus_amd import capi
+
+    sr, B, if_rate = 10e6, 50000, 250e3
+    ctx, vids, chains, _ = _setup(sr, [("WFM", sr / 8)], B)
+    r = np.random.default_rng(22)
+    t = np.arange(5 * B) / sr
+    x = (0.3 * np.exp(2j * np.pi * (sr / 8 * t + 75e3 / (2 * np.pi * 1e3) * np.sin(2 * np.pi * 1e3 * t)))
+         + 0.01 * (r.standard_normal(len(t)) + 1j * r.standard_normal(len(t)))).astype(np.complex64)
+    vid, ch = vids[0], chains[0]
+
+    def taps(bw):
+        return capi.design_low_pass(bw / 2.0, bw / 2.0 * 0.1, if_rate) if bw != if_rate else np.zeros(0, np.float32)
+
+    for b, bw in enumerate((150e3, 250e3, 250e3, 120e3, 120e3)):
+        if b in (1, 3):
+            ch.set_bandwidth(bw)
+            ctx.vfo_set_channel_taps(vid, taps(bw))
+        if b == 2:  # reset with the filter asleep
+            ctx.vfo_reset(vid)
+            ch = S.OracleChain(sr, if_rate, 150e3, sr / 8, S.MODES["WFM"])  # (the demodulator keeps the deviation it was built with: only the VFO's bandwidth moves)
+            ch.set_bandwidth(if_rate)
+        blk = x[b * B:(b + 1) * B]
+        ctx.push(blk)
+        oi, oa = ch.process(blk)
+        gi, ga = ctx.vfo_read_if(vid), ctx.vfo_read(vid)
+        assert gi.shape == oi.shape and rms(gi - oi) / rms(oi) < 2e-6 and rms(gi[:300] - oi[:300]) / rms(oi) < 2e-6, (b, bw, rms(gi - oi) / rms(oi), rms(gi[:300] - oi[:300]) / rms(oi))
+        assert ga.shape == oa.shape and rms(ga - oa) < _audio_tol(oa) and rms(ga[:600] - oa[:600]) < _audio_tol(oa), (b, bw, rms(ga - oa))
+    ctx.close()
+
+
 def test_am_carrier_agc_and_fm_without_lowpass(backend):
     from sdrplusplus_amd import capi, radio
 
