@@ -69,7 +69,7 @@ int run_preproc(sdrpp_ctx* c, const float** d_iq, int64_t* count) {
         if (level >= carry.top || carry.at[level].empty()) { return; }
         int mx = 0;
         for (auto& k : carry.at[level]) { mx = std::max(mx, k.need * k.width); }
-        emit(c, level, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 64)), (int)carry.at[level].size(), 0, carry.dev[level]);
+        emit(c, level, F_MISC, TR_CARRY, std::max(1, std::min((mx + 8191) / 8192, 64)), (int)carry.at[level].size(), 0, carry.dev[level]);
     };
     {
         FamilyTimer t(c, F_MISC);

@@ -203,6 +203,7 @@ struct BankPlan {
     bool ticking = false;
     int L0 = 0;  // levels the pre-processing chain takes in front (pipelined mode): the front end runs at level L0 + 1
     static constexpr int carry_last = kLevels - 1;
+    static constexpr int carry_wave_max = 8192;  // floats: up to four rounds of a wavefront
     const std::vector<int>& fb;  // reference-block ends of this push (at least one entry: n_in)
     bool blocks = false;
     std::vector<S1Member> s1;
@@ -1192,19 +1193,26 @@ struct BankPlan {
             const int iq_elems = has_iq ? cj[0].need * cj[0].width : 0;
             int mx = 0;
             for (size_t k = has_iq ? 1 : 0; k < cj.size(); k++) { mx = std::max(mx, cj[k].need * cj[k].width); }
-            // (carry_body moves 4 floats per access and up to 8 accesses per work-item: 8 192 floats per workgroup and round)
-            if (iq_elems > 128 * 1024 * 2 && cj.size() > 1) {  // a very long IQ carry (FFT frames of 2^18 points and more): its own wide grid
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 8191) / 8192, 512)), 1, 0, carry.dev[l]);
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 64)), (int)cj.size() - 1, 0, carry.dev[l] + 1);
-            }
-            else if (iq_elems > 16384 && cj.size() > 1) {
-                // one launch for the IQ history (up to a 65 536-point frame: 128 workgroups stride over it) and the per-VFO histories (their
-                // workgroups beyond the first find nothing to do): one kernel and one dispatch bubble less per push
+            // (carry_body moves 4 floats per access and up to 8 accesses per work-item: 8 192 floats per workgroup and round, 2 048 per wavefront)
+            // The per-VFO histories, a few hundred samples each: one WAVEFRONT per job, four jobs per workgroup (carry_body, njw > 0) unless a
+            // history is long enough to want a workgroup's worth of loads in flight; the shared IQ history: an entry of its own.
+            auto per_vfo = [&](const CarryJob* dev, int njobs) {
+                if (njobs <= 0) { return; }
+                if (mx <= carry_wave_max) { emit(c, l, F_MISC, TR_CARRY, 1, (njobs + 3) / 4, 0, dev, nullptr, njobs); }
+                else { emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 8191) / 8192, 64)), njobs, 0, dev); }
+            };
+            if (!ticking && iq_elems > carry_wave_max && iq_elems <= 128 * 1024 * 2 && cj.size() > 1) {
+                // an ordinary pass: one launch for the IQ history (up to a 65 536-point frame: 32 workgroups stride over it) and the per-VFO histories
+                // (their workgroups beyond the first find nothing to do) — a kernel and its dispatch bubble less per push
                 emit(c, l, F_MISC, TR_CARRY, 32, (int)cj.size(), 0, carry.dev[l]);
             }
-            else {
+            else if (has_iq && (iq_elems > carry_wave_max || cj.size() == 1)) {
+                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((iq_elems + 8191) / 8192, 512)), 1, 0, carry.dev[l]);
+                per_vfo(carry.dev[l] + 1, (int)cj.size() - 1);
+            }
+            else {  // (no IQ history at this level, or one as short as the others)
                 mx = std::max(mx, iq_elems);
-                emit(c, l, F_MISC, TR_CARRY, std::max(1, std::min((mx + 1023) / 1024, 512)), (int)cj.size(), 0, carry.dev[l]);
+                per_vfo(carry.dev[l], (int)cj.size());
             }
     }
 

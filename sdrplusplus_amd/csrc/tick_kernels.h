@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const CopyJob* __restrict__ j
 enum TickRole : int {
     TR_NONE = 0,
     TR_COPY,       // CopyJob[gy]
-    TR_CARRY,      // CarryJob[gy]
+    TR_CARRY,      // CarryJob[gy]; aux = njobs > 0: one wavefront per job, gy = ceil(njobs / 4)
     TR_ROT,        // RotJob[gy], p.src
     TR_FCM_132_4,  // FrontCMJob[gy], p.src: vfo_frontcm_body<10, 132, 4>
     TR_FCM_6,      // <6, 0, 0>
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
             const KIdx bid{ lb % gx, lb / gx }, gdim{ gx, e_gy };
             switch (e_role) {
             case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e_jobs)); break;
-            case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e_jobs)); break;
+            case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e_jobs), e_aux); break;
             case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e_jobs)); } break;
             case TR_FCM_132_4:
                 if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }

@@ -45,14 +45,14 @@ __device__ __forceinline__ float2 stream_load2_nb(const StreamIn& s, int i, bool
     const bool use = ok && i < s.n, cur = i >= 0;
     int ic = cur ? i : (s.hist_len + i);
     ic = (use && ic >= 0) ? ic : 0;
-    const float2 v = global_load_f32x2(reinterpret_cast<const float2*>((cur && use) ? s.data : s.hist), ic);
+    const float2 v = global_load_f32x2(reinterpret_cast<const float2*>((cur || !use) ? s.data : s.hist), ic);  // (not wanted: element 0 of the data buffer, which always exists)
     return use ? v : make_float2(0.0f, 0.0f);
 }
 __device__ __forceinline__ float stream_load1_nb(const StreamIn& s, int i, bool ok = true) {
     const bool use = ok && i < s.n, cur = i >= 0;
     int ic = cur ? i : (s.hist_len + i);
     ic = (use && ic >= 0) ? ic : 0;
-    const float v = global_load_f32((cur && use) ? s.data : s.hist, ic);
+    const float v = global_load_f32((cur || !use) ? s.data : s.hist, ic);
     return use ? v : 0.0f;
 }
 
@@ -600,8 +600,13 @@ struct CarryJob {
     int hist_len, n, width;
     int need;  // only the most recent `need` samples will be read by the next push: older entries are not copied
 };
-__device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, const CarryJob* __restrict__ jobs) {
-    const CarryJob job = jobs[bid.y];
+// njw > 0: ONE WAVEFRONT per job (job 4 bid.y + wavefront of njw) — the per-VFO histories are a few hundred samples, a workgroup's life is
+// the chain of round trips to its job and back whatever it moves, and in a tick workgroup SLOTS are what the roles compete for (cfg 4:
+// 1 300-1 500 carry workgroups of 4.5 us were an eighth of the tick's slot time); njw = 0: grid.x workgroups stride over job bid.y.
+__device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, const CarryJob* __restrict__ jobs, int njw) {
+    const int jidx = njw > 0 ? bid.y * 4 + ((int)threadIdx.x >> 6) : bid.y;
+    if (njw > 0 && jidx >= njw) { return; }
+    const CarryJob job = jobs[jidx];
     const int first = (job.hist_len - job.need) * job.width;
     const int total = job.hist_len * job.width;
     // new_hist[e] = (old_hist ++ data)[n * width + e]: elements below `eb` still come from the old history (a push shorter than the history),
@@ -613,7 +618,7 @@ __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, cons
     // work-item before the first store — the carries of a tick were thousands of workgroups of one 4-byte load per work-item each (cfg 4: ~2 300
     // workgroups of 3.9 us, the whole tail of the tick), their life a memory round trip whatever they carry: fewer, fatter workgroups.
     const int first4 = (first + 3) & ~3;
-    const int nthreads = gdim.x * 256, t = bid.x * 256 + (int)threadIdx.x;
+    const int nthreads = njw > 0 ? 64 : gdim.x * 256, t = njw > 0 ? ((int)threadIdx.x & 63) : bid.x * 256 + (int)threadIdx.x;
     for (int e = first + t; e < first4 && e < total; e += nthreads) {  // (the up to three elements in front of the first whole quad)
         const long long sx = nw + e;
         global_store_f32_boff(job.new_hist, (unsigned)e * 4u, global_load_f32(e < eb ? job.old_hist : job.data, e < eb ? sx : (long long)e - ebl));
@@ -648,7 +653,7 @@ __device__ __forceinline__ void carry_body(const KIdx bid, const KIdx gdim, cons
         }
     }
 }
-__global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs) { carry_body(kidx(blockIdx), kidx(gridDim), jobs); }
+__global__ __launch_bounds__(256) void carry_kernel(const CarryJob* __restrict__ jobs, int njw) { carry_body(kidx(blockIdx), kidx(gridDim), jobs, njw); }
 
 // =====================================================================================================================
 // Output gather (sdrpp_vfo_read_many): the per-VFO output blocks of one push packed back to back, so that the host gets all of them
@@ -771,9 +776,15 @@ __device__ __forceinline__ void vfo_firb_body(const KIdx bid, float* smem, const
     T* xs = reinterpret_cast<T*>(smem);
     if constexpr (QUAD) {
         float* phase = smem + ncomp;  // phase[i] = atan2f(x[base - 1 + i]), i = 0 .. nvalid
-        for (int s = threadIdx.x; s <= nvalid; s += nall) {
-            const float2 x = stream_load2(job.in, base - 1 + s);
-            phase[s] = fm_phase(x.y, x.x);
+        constexpr int UQ = 4;
+        for (int s0 = threadIdx.x; s0 <= nvalid; s0 += nall * UQ) {
+            float2 x[UQ];
+#pragma unroll
+            for (int u = 0; u < UQ; u++) { x[u] = stream_load2_nb(job.in, base - 1 + s0 + u * nall, s0 + u * nall <= nvalid); }
+#pragma unroll
+            for (int u = 0; u < UQ; u++) {
+                if (s0 + u * nall <= nvalid) { phase[s0 + u * nall] = fm_phase(x[u].y, x[u].x); }
+            }
         }
         __syncthreads();
         for (int s = threadIdx.x; s < ncomp; s += nall) {
@@ -782,12 +793,26 @@ __device__ __forceinline__ void vfo_firb_body(const KIdx bid, float* smem, const
         }
     }
     else {
-        for (int s = threadIdx.x; s < ncomp * D; s += nall) {
-            const int p = s & (D - 1), e = s >> lgD;
-            T v;
-            if constexpr (WIDTH == 2) { v = (s < nvalid) ? stream_load2(job.in, base + s) : make_float2(0.0f, 0.0f); }
-            else { v = (s < nvalid) ? stream_load1(job.in, base + s) : 0.0f; }
-            xs[p * P2 + (e & (R - 1)) * P1 + (e >> 3)] = v;
+        // Eight loads in flight per work-item before the first LDS store, none behind a branch (stream_load*_nb): a tile of a decimator by 8 is
+        // ~17 samples per work-item, and one guarded load per loop iteration made that 17 memory round trips one after the other — the whole
+        // 18 us life of this role's workgroups in cfg 4's tick, 512 of them (round 5; same values, same order of everything that is rounded).
+        constexpr int U = 8;
+        for (int s0 = threadIdx.x; s0 < ncomp * D; s0 += nall * U) {
+            T v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u * nall;
+                if constexpr (WIDTH == 2) { v[u] = stream_load2_nb(job.in, base + s, s < nvalid); }
+                else { v[u] = stream_load1_nb(job.in, base + s, s < nvalid); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u * nall;
+                if (s < ncomp * D) {
+                    const int p = s & (D - 1), e = s >> lgD;
+                    xs[p * P2 + (e & (R - 1)) * P1 + (e >> 3)] = v[u];
+                }
+            }
         }
     }
     __syncthreads();
