@@ -736,6 +736,9 @@ __host__ __device__ inline int frontcl_lds_floats(int K, int lgD, int nw = 2) {
 // PF: IQ samples prefetched per lane into registers (covers windows of nsamp <= 64 * PF samples: PF = 38 -> first stages up to 448
 // taps at /64); PF = 0: longer windows are loaded in place, unpipelined.
 #define SDRPP_FCL_PF 38
+#ifndef SDRPP_FCL_RING_NARROW
+#define SDRPP_FCL_RING_NARROW 4
+#endif
 // NARROW (round 5): jobs of at most 16 VFOs — cfg 4's 43 channels per mode are a job of 32 and a job of 11 — in the 16 x 16 x 4 shape: 16 VFO rows x 16
 // outputs per tile, the instruction's k = 0 .. 3 (lanes 16 kq .. 16 kq + 15) are FOUR consecutive tap pairs, each lane owning the pair 4 Q + kq of
 // output n = lane & 15.  Same pair-per-lane operands, same table, half the matrix cycles of a 32-row tile that would be two thirds empty.
@@ -759,6 +762,7 @@ __device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, c
     if (tid < VT) { outp[tid] = job.out[tid]; }
     __syncthreads();  // the only workgroup barrier
     if (wv >= nw) { return; }  // (a role of the tick kernel with two engines: the other two wavefronts of the 256-wide workgroup have nothing to do)
+    TICK_MARK(0);
     const int tile0 = (bid.x * nw + wv) * job.tiles_per_wave;
     if (tile0 * tile >= job.nout) { return; }
     int ntl = (job.nout - tile0 * tile + tile - 1) / tile;
@@ -837,6 +841,7 @@ __device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, c
         if (it + 1 < ntl) { fetch(tile_base(tb + 1)); }  // in flight during the matrix loop (spreading these loads over the loop — vector memory
                                                          // operations retire in order, the tap loads queue behind them — measured no faster)
         wave_sync();
+        if (it == 0) { TICK_MARK(1); }
         typename std::conditional<NARROW, f32x4, f32x16>::type accR, accI;
         if constexpr (NARROW) { accR = mfma4_zero(); accI = mfma4_zero(); }
         else { accR = mfma_zero(); accI = mfma_zero(); }
@@ -845,7 +850,7 @@ __device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, c
             // zero padded to a multiple of SIXTEEN rows (plan_vfo.h), a padded step multiplies VALID samples (index clamped) by zero taps — so
             // that every ring slot is a fixed register (a uniform branch per slot made the compiler rotate the ring through moves and wait for
             // every tap load where it was issued)
-            constexpr int RING = 4;
+            constexpr int RING = NARROW ? SDRPP_FCL_RING_NARROW : 4;
             const int NQr = ((NQ + RING - 1) / RING) * RING;
             float gq[RING], hq[RING];
 #pragma unroll
@@ -884,22 +889,38 @@ __device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, c
                 }
             }
         }
+        if (it == 0) { TICK_MARK(2); }
         {
             const int j0 = tb * tile;
             const bool live = j0 + jl < job.nout;
             constexpr int NR = NARROW ? 4 : 16;
+            // in-tile NCO advance (L2-resident table; keeping it in 32 registers would spill the prefetch).  Its loads go out in batches of
+            // four (eight spilled) IN FRONT of the stores they feed: a store through a pointer out of the job table may alias the table for all the compiler
+            // knows, so load / store pairs written one after the other were sixteen memory round trips in a row (3-5 us per tile in cfg 4's tick).
+            constexpr int EB = 4;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const int v = NARROW ? (4 * hi + r) : ((r & 3) + 8 * (r >> 2) + 4 * hi);  // the VFO row this lane holds in register r (sdrpp_gfx950.h)
-                if (v < job.nv && live) {
-                    const float2 P = ptile[v];
-                    const float2 T = global_load_f32x2(job.ptab, v * SDRPP_FCM_TILE + jl);  // in-tile NCO advance (L2-resident table; keeping it in 32 registers would spill the prefetch)
-                    const float qr = fmaf(P.x, T.x, -(P.y * T.y)), qi = fmaf(P.x, T.y, P.y * T.x);
-                    global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+            for (int r0 = 0; r0 < NR; r0 += EB) {
+                float2 T[EB];
+#pragma unroll
+                for (int e = 0; e < EB; e++) {
+                    const int r = r0 + e;
+                    const int v = NARROW ? (4 * hi + r) : ((r & 3) + 8 * (r >> 2) + 4 * hi);  // the VFO row this lane holds in register r (sdrpp_gfx950.h)
+                    T[e] = global_load_f32x2(job.ptab, (v < job.nv ? v : 0) * SDRPP_FCM_TILE + jl);
+                }
+#pragma unroll
+                for (int e = 0; e < EB; e++) {
+                    const int r = r0 + e;
+                    const int v = NARROW ? (4 * hi + r) : ((r & 3) + 8 * (r >> 2) + 4 * hi);
+                    if (v < job.nv && live) {
+                        const float2 P = ptile[v];
+                        const float qr = fmaf(P.x, T[e].x, -(P.y * T[e].y)), qi = fmaf(P.x, T[e].y, P.y * T[e].x);
+                        global_store_f32x2(outp[v], j0 + jl, make_float2(fmaf(accR[r], qr, -(accI[r] * qi)), fmaf(accR[r], qi, accI[r] * qr)));
+                    }
                 }
             }
         }
         wave_sync();
+        if (it == 0) { TICK_MARK(3); }
     }
 }
 template <int PF>

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the tick kernel from a `make ticktrace` build (SDRPP_TICK_TRACE_FILE dump): per role, when its workgroups start and end
-inside a tick (100 MHz wall clock), averaged over the steady-state ticks.   tools/tick_trace.py dump.bin [skip_ticks]"""
+inside a tick (100 MHz wall clock), averaged over the steady-state ticks.   tools/tick_trace.py dump.bin [skip_ticks] [role:grid_x]
+(role:grid_x, e.g. fcl_pf:62 — that role's workgroups also per JOB, job = workgroup index // grid_x)"""
 import sys
 
 import numpy as np
@@ -41,3 +42,16 @@ for key in sorted(rows, key=lambda k: (k[1], k[0])):
     v = np.array(rows[key])
     print("%-12s %5d %6.0f | %10.2f %11.2f %9.2f | %8.2f   (in %d ticks) | %s" % (ROLES[key[0]] if 0 <= key[0] < len(ROLES) else ("L0" if key[0] < 0 else str(key[0])), key[1], v[:, 4].mean(), v[:, 0].mean(), v[:, 1].mean(), v[:, 2].mean(), v[:, 3].mean(), len(v),
           "  ".join("%6.2f" % x for x in np.nanmean(v[:, 5:9], axis=0))))
+
+if len(sys.argv) > 3:  # one role per job (grid.y index): life and marks of its workgroups
+    rname, gx = sys.argv[3].split(":")
+    ri, gx = ROLES.index(rname), int(gx)
+    sel = a[(a["role"] == ri) & np.isin(a["tick"], ticks)]
+    t0s = {int(t): int(a[a["tick"] == t]["t0"].min()) for t in ticks}
+    print("%s per job (grid.x = %d):  job  wgs/tick | mean life  max life  last end | marks" % (rname, gx))
+    for j in sorted(set((sel["block"] // gx).tolist())):
+        m = sel[sel["block"] // gx == j]
+        life = (m["t1"] - m["t0"]) / 100.0
+        ends = np.array([(int(x["t1"]) - t0s[int(x["tick"])]) / 100.0 for x in m])
+        mk = [float(np.mean((m["m"][:, q].astype(np.int64) - m["t0"].astype(np.int64))[m["m"][:, q] > 0])) / 100.0 if np.any(m["m"][:, q] > 0) else float("nan") for q in range(4)]
+        print("   %3d  %7.1f | %8.2f %9.2f %9.2f | %s" % (j, len(m) / max(1, len(ticks)), life.mean(), life.max(), ends.max(), "  ".join("%6.2f" % x for x in mk)))
