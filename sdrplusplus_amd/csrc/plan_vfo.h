@@ -1090,10 +1090,7 @@ struct BankPlan {
                 max_nout = std::max(max_nout, jb.nout);
                 int nt = 256;
                 // (a role of a tick: every workgroup of the launch gets the largest role's LDS — stay near the other roles' ~40 KB where the filter allows)
-                // ... unless the tick holds the long first stages anyway (cfg 4: every workgroup of such a tick has their ~78 KB): then a wider tile is free,
-                // and halves the number of workgroups whose life is mostly the round trips of their start (512 of 14 us were 7 k of the tick's 47 k slot-us)
-                const size_t lds_cap = std::max((size_t)c->tick_lds_cap_fir, fcl.jobs.empty() ? (size_t)0 : fcl.lds);
-                while (ticking && nt > 64 && lds_for(jb, nt) > lds_cap) { nt >>= 1; }
+                while (ticking && nt > 64 && lds_for(jb, nt) > (size_t)c->tick_lds_cap_fir) { nt >>= 1; }
                 while (nt >= 32 && lds_for(jb, nt) > (size_t)kMaxLds) { nt >>= 1; }
                 if (nt < 32) {
                     if (width != 2 || quad || stereo) { return fail(c, SDRPP_ERR_UNSUPPORTED, "FIR (decim %d, %d taps) does not fit in LDS", 1 << jb.log2_decim, jb.ntaps); }
@@ -1109,8 +1106,8 @@ struct BankPlan {
             }
             if (max_nout == 0) { return SDRPP_OK; }
             // enough blocks to load-balance 256 CUs: shrink the tile while the grid has fewer than ~8 blocks per CU
-            // (an ordinary pass; a tick's workgroups are 256 wide whatever the tile, and what its roles compete for is workgroup slots: the widest tile that fits)
-            while (!ticking && threads > 64 && (size_t)((max_nout + threads * R - 1) / (threads * R)) * jobs.size() < 2048) { threads >>= 1; }
+            // (also as a role of a tick: a wider tile — fewer, longer workgroups in a tick that holds the long first stages' LDS anyway — measured neutral, profiles/r05zk)
+            while (threads > 64 && (size_t)((max_nout + threads * R - 1) / (threads * R)) * jobs.size() < 2048) { threads >>= 1; }
             size_t lds = 0;
             for (auto& jb : jobs) { lds = std::max(lds, lds_for(jb, threads)); }
             const int tile = threads * R;

@@ -1,8 +1,7 @@
 #!/bin/bash
-# A / B of the base build (libsdrpp_gpu_base.so) against the working build on one box
+# A / B on one box (tools/ab_tick.py): variants as arguments after the tag, cfg 4 at both block sizes
 mkdir -p gpurun_out
-T=${1:-r05ze}
-timeout 400 python tools/ab_tick.py --cfg 4 --push 1000000 307200 --rounds 2 base=libsdrpp_gpu_base.so new=libsdrpp_gpu.so > gpurun_out/${T}_ab_cfg4.log 2>&1
-timeout 300 python tools/ab_tick.py --cfg 3 --push 1000000 50000 --rounds 2 base=libsdrpp_gpu_base.so new=libsdrpp_gpu.so > gpurun_out/${T}_ab_cfg3.log 2>&1
-timeout 300 python tools/ab_tick.py --cfg 4 --push 1000000 --af --rounds 1 base=libsdrpp_gpu_base.so new=libsdrpp_gpu.so > gpurun_out/${T}_ab_cfg4_af.log 2>&1
-tail -4 gpurun_out/${T}_ab_cfg4.log gpurun_out/${T}_ab_cfg3.log gpurun_out/${T}_ab_cfg4_af.log
+T=${1:-r05zk}
+L=libsdrpp_gpu.so
+timeout 500 python tools/ab_tick.py --cfg 4 --push 1000000 307200 --rounds 3 wide=$L narrow=$L,SDRPP_GPU_TICK_FIR_WIDE=0 > gpurun_out/${T}_ab_cfg4.log 2>&1
+grep -A6 summary gpurun_out/${T}_ab_cfg4.log
