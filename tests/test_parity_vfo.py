@@ -639,6 +639,37 @@ def test_bandwidth_change_mid_stream(backend):
     ctx.close()
 
 
+def test_very_long_channel_filter_histories(backend):
+    """Channel filters of thousands of taps (16 kHz, then 5 kHz of bandwidth at a 250 kHz IF: 1 187 and 3 800 taps; the C-ABI takes up to 4 096): the filter runs in
+    the VALU form and its delay line — the stream's history, up to 8 190 floats — is carried block to block by the one-wavefront-per-job form of the carry role
+    in TWO and FOUR rounds of 2 048 floats; the IF against the oracle from the first sample of every block."""
+    from sdrplusplus_amd import capi
+
+    sr, B, if_rate = 10e6, 50000, 250e3
+    ctx, vids, chains, _ = _setup(sr, [("WFM", sr / 8), ("WFM", -sr / 4)], B)
+    r = np.random.default_rng(23)
+    seq = (150e3, 16e3, 16e3, 5e3, 5e3, 150e3)
+    t = np.arange(len(seq) * B) / sr
+    x = (0.3 * np.exp(2j * np.pi * (sr / 8 + 1.0e3) * t) + 0.2 * np.exp(2j * np.pi * (-sr / 4 - 0.7e3) * t)
+         + 0.01 * (r.standard_normal(len(t)) + 1j * r.standard_normal(len(t)))).astype(np.complex64)
+    lens = set()
+    for b, bw in enumerate(seq):
+        if b and bw != seq[b - 1]:
+            taps = capi.design_low_pass(bw / 2.0, bw / 2.0 * 0.1, if_rate)
+            lens.add(len(taps))
+            for vid, ch in zip(vids, chains):
+                ch.set_bandwidth(bw)
+                ctx.vfo_set_channel_taps(vid, taps)
+        blk = x[b * B:(b + 1) * B]
+        ctx.push(blk)
+        for vid, ch in zip(vids, chains):
+            oi, _ = ch.process(blk)
+            gi = ctx.vfo_read_if(vid)
+            assert gi.shape == oi.shape and rms(gi - oi) / rms(oi) < 3e-6 and rms(gi[:300] - oi[:300]) / rms(oi) < 3e-6, (b, bw, rms(gi - oi) / rms(oi), rms(gi[:300] - oi[:300]) / rms(oi))
+    assert 3072 < max(lens) <= 4096 and any(1024 < n <= 2048 for n in lens), lens  # (complex samples: twice that many floats)
+    ctx.close()
+
+
 def test_reset_while_channel_filter_is_bypassed(backend):
     """RxVFO::reset (rx_vfo.h:79-87) clears the channel filter's delay line whether the filter is in the chain or bypassed: a filter that ran, was
     bypassed, was RESET while bypassed and is switched on again starts from zeros — not from the stale delay line a bypass alone would keep
