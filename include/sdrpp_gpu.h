@@ -352,7 +352,9 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  *   sdrpp_push / _push_int16 copy into a page-locked staging slot (the caller's buffer is free on return), fetched by the next launch.
  *   sdrpp_push_pinned_async  page-locked memory is fetched by the launch itself; sdrpp_push_wait returns when all such fetches have run.
  * The pre-processing chain (sdrpp_preproc_configure, default arithmetic), the radio's AF chain (sdrpp_vfo_set_af) and the waterfall display
- * state (sdrpp_wf_configure) run that way too — their stages are further levels of the block.  What cannot (the reference-rotator NCO, the
+ * state (sdrpp_wf_configure) run that way too — their stages are further levels of the block; so do VFOs on the reference-rotator NCO
+ * (nco_mode = 2: the recursion over the whole block is one of the launch's work items — such a stream is bound by that chain, ~26 cycles per
+ * sample, but every VFO's results stay pipelined).  What cannot (the
  * reference-order arithmetic of the pre-processing chain, VFO groups without the matrix-core front end, a retune hand-over in progress, more
  * FFT frames than one scratch chunk, a block the pre-processing decimator swallows whole) is processed as an ordinary
  * pass behind everything queued: always correct, pipelined where possible — and its results are delivered into the block's result slot

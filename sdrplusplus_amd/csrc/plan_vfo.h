@@ -246,6 +246,7 @@ struct BankPlan {
     FrontCMJob* d_fcl = nullptr;
     FrontCMJob* d_fcm[3] = {};
     RotXJob* d_rotx = nullptr;
+    RotXHead* d_rotx_head = nullptr;  // pipelined: what the TR_ROTX16 role finds behind its job pointer
     RetuneJob* d_retune = nullptr;
     RotJob* d_rot = nullptr;
     const int* d_fb = nullptr;
@@ -926,6 +927,12 @@ struct BankPlan {
         d_retune = arena_push(c, retune);
         d_rot = arena_push(c, rot);
         d_fb = (!rotx.empty()) ? arena_push(c, fb) : nullptr;
+        d_rotx_head = nullptr;
+        if (!rotx.empty() && d_rotx && d_fb && c->tick_planning) {
+            std::vector<RotXHead> head{ RotXHead{ d_rotx, d_fb, (int)rotx.size(), (int)fb.size(), c->rot_exact_vpw, 0 } };
+            d_rotx_head = arena_push(c, head);
+            if (!d_rotx_head) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
+        }
         if ((!rotx.empty() && (!d_rotx || !d_fb)) || (!retune.empty() && !d_retune) || (!rot.empty() && !d_rot)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
         // Pipelined back ends.  An ordinary pass: ONE launch, at the latest level any of its jobs starts at (levels only order the launches of a
         // pass) — or none, when this push is better served by the separate launches.  Pipelined mode: one role per LEVEL (a role that ran later
@@ -988,6 +995,9 @@ struct BankPlan {
             FamilyTimer t(c, F_S1);
             if (!rotx.empty() && n_in > 0) {
                 if (c->rot_exact_single) { launch(c, vfo_rotate_exact_kernel, dim3(((unsigned)rotx.size() + 63) / 64), dim3(64), (size_t)64 * 65 * sizeof(float2), src, (const RotXJob*)d_rotx, (int)rotx.size(), d_fb, (int)fb.size()); }
+                else if (c->tick_planning && c->rot_exact_skip >= 16) {  // pipelined: the chain as a role of the tick (level 1: its VFOs' first stages follow at level 2)
+                    emit(c, L0 + 1, F_S1, TR_ROTX16, ((int)rotx.size() + c->rot_exact_vpw - 1) / c->rot_exact_vpw, 1, SDRPP_ROTX4_LDS_BYTES, d_rotx_head, &src);
+                }
                 else {
                     const int vpw = c->rot_exact_vpw;
                     const dim3 grid(((unsigned)rotx.size() + vpw - 1) / vpw);
@@ -1101,7 +1111,10 @@ struct BankPlan {
             }
             if (threads == 0) {
                 for (auto& jb : jobs) { max_nout = std::max(max_nout, jb.nout); }
-                if (max_nout > 0) { launch(c, vfo_fir_direct_kernel<false>, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
+                if (max_nout > 0) {
+                    if (c->tick_planning) { emit(c, level, fam, TR_FIRD, std::min((max_nout + 255) / 256, 1024), (int)jobs.size(), 0, d_jobs); }
+                    else { launch(c, vfo_fir_direct_kernel<false>, dim3((unsigned)std::min((max_nout + 255) / 256, 1024), (unsigned)jobs.size()), dim3(256), 0, (const FirBJob*)d_jobs); }
+                }
                 return SDRPP_OK;
             }
             if (max_nout == 0) { return SDRPP_OK; }
@@ -1262,7 +1275,11 @@ struct BankPlan {
             }
             if ((l < pre.top && !pre.at[l].empty()) || (l < seq.top && !seq.at[l].empty()) || (l < ssbx_l.top && !ssbx_l.at[l].empty())) {
                 FamilyTimer t(c, F_DEMOD);
-                if (l < ssbx_l.top && !ssbx_l.at[l].empty()) { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)ssbx_l.at[l].size()), dim3(64), 0, (const SsbRotXJob*)ssbx_l.dev[l]); }
+                if (l < ssbx_l.top && !ssbx_l.at[l].empty()) {
+                    const int nj = (int)ssbx_l.at[l].size();
+                    if (c->tick_planning) { emit(c, l, F_DEMOD, TR_SSBX, (nj + 3) / 4, 1, 0, ssbx_l.dev[l], nullptr, nj); }
+                    else { launch(c, vfo_ssb_rotate_exact_kernel, dim3((unsigned)nj), dim3(64), 0, (const SsbRotXJob*)ssbx_l.dev[l]); }
+                }
                 if (l < pre.top && !pre.at[l].empty()) {
                     int mx = 0;
                     for (auto& q : pre.at[l]) { mx = std::max(mx, q.n); }

@@ -66,6 +66,7 @@ inline int tick_role_weight(int role, bool crowded) {
     // result copies write page-locked host memory over the bus: few workgroups whose life is mostly that round trip — started last they are the
     // tail of the tick, started first they finish in its shadow (SDRPP_GPU_TICK_COPY_FIRST=0: the old order, for measurements)
     static const bool copy_first = getenv("SDRPP_GPU_TICK_COPY_FIRST") ? atoi(getenv("SDRPP_GPU_TICK_COPY_FIRST")) != 0 : true;
+    if (role == TR_ROTX16) { return 120; }  // the reference's rotator recursion over the whole block: milliseconds — it IS the tick, everything else runs in its shadow
     if (role == TR_COPY && copy_first) { return 110; }
     // FFT pass 1: since its workgroups walk their tiles and take the lean loader they live ~12 us at 10^6-sample blocks, shorter than the
     // Toeplitz roles' 17-33 us.  In a CROWDED tick (more workgroups than the GPU holds at once: they are handed out in index order) they go
@@ -83,7 +84,7 @@ inline int tick_role_weight(int role, bool crowded) {
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
     case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
-    case TR_SEQ: return 85;
+    case TR_SEQ: case TR_SSBX: return 85;
     case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
     case TR_POLYC: return 55;
     case TR_DEEMP_P1: case TR_DC_P1: return 52;
@@ -155,7 +156,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         role_wgs += (long long)r.e.gx * r.e.gy;
         lds = std::max(lds, r.lds);
         set1 = set1 || r.e.role == TR_FCL_PF;
-        set2 = set2 && !(r.e.role == TR_FCL_PF || r.e.role == TR_FCL_0 || r.e.role == TR_FCM_132_4 || r.e.role == TR_FCM_6 || r.e.role == TR_FCM_10 || r.e.role == TR_FCM_16 || r.e.role == TR_FFT_S12);
+        set2 = set2 && !(r.e.role == TR_ROTX16 || r.e.role == TR_FCL_PF || r.e.role == TR_FCL_0 || r.e.role == TR_FCM_132_4 || r.e.role == TR_FCM_6 || r.e.role == TR_FCM_10 || r.e.role == TR_FCM_16 || r.e.role == TR_FFT_S12);
         if (r.e.role >= 0 && r.e.role < 64) { c->stat_role_wgs[r.e.role] += (int64_t)r.e.gx * r.e.gy; }
     }
     if (role_wgs > 3ll * c->num_cus) { c->stat_crowded++; }
@@ -246,7 +247,8 @@ bool tick_eligible(sdrpp_ctx* c) {
     if ((c->pre.on && c->pre.ref_order) || c->deferred) { return false; }  // (the reference-order arithmetic of the pre-processing chain has no roles)
     for (auto& kv : c->vfos) {
         const Vfo& v = *kv.second;
-        if (v.nco_exact || !v.recs.empty() || v.st.size() > 24) { return false; }
+        // (reference-rotator VFOs have their roles since round 5 — TR_ROTX16 / TR_FIRD / TR_SSBX; the measurement forms of that rotator have not)
+        if ((v.nco_exact && (c->rot_exact_single || c->rot_exact_skip < 16)) || !v.recs.empty() || v.st.size() > 24) { return false; }
     }
     return true;
 }

@@ -111,6 +111,10 @@ enum TickRole : int {
     TR_DC_P0, TR_DC_P1,        // DeempJob[gy]: vfo_deemph_body<1, 0 / 1> (the front end's DC blocker)
     TR_WF_RING, TR_WF_TRACE,   // p.wf: raw lines into the waterfall's ring; FFT trace smoothing / hold over the block's zoomed lines
     TR_PIPE,       // PipeJob[gy], gx = segments per VFO: vfo_pipe_body<1> — an FM back end (last decimator, resampler, channel filter, discriminator + audio low-pass) as ONE role
+    // reference-rotator VFOs (sdrpp_vfo_desc.nco_mode = 2) inside a pipelined bank (round 5): the chain bounds the tick, every VFO's results stay pipelined
+    TR_ROTX16,     // RotXHead (jobs), p.src, gx = workgroups of `vpw` VFOs: vfo_rotate_exact4_body<16> — the reference's float rotator recursion at the full rate
+    TR_FIRD,       // FirBJob[gy]: vfo_fir_direct_body<false> (plain decimators whose window fits no LDS tile: the first stages behind that rotator)
+    TR_SSBX,       // SsbRotXJob[aux], one wavefront per job (gx = ceil(aux / 4)): SSB's second translation as the same recursion at the IF rate
     TR_COUNT
 };
 struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, ntiles; };
@@ -262,6 +266,18 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
             switch (e_role) {
             case TR_COPY: copy_body(bid, gdim, reinterpret_cast<const CopyJob*>(e_jobs)); break;
             case TR_CARRY: carry_body(bid, gdim, reinterpret_cast<const CarryJob*>(e_jobs), e_aux); break;
+            case TR_ROTX16:
+                if constexpr (SET != 2) {  // (71 KB of LDS: not in the four-wavefronts-per-SIMD build)
+                    const IqSrc src = e.p.src;
+                    const RotXHead h = *reinterpret_cast<const RotXHead*>(e_jobs);
+                    vfo_rotate_exact4_body<16>(bid.x, reinterpret_cast<float2*>(smem), src, h.jobs, h.njobs, h.bounds, h.nb, h.vpw);
+                }
+                break;
+            case TR_FIRD: vfo_fir_direct_body<false>(bid, gdim, reinterpret_cast<const FirBJob*>(e_jobs)); break;
+            case TR_SSBX: {
+                const int j = bid.x * 4 + ((int)threadIdx.x >> 6);
+                if (j < e_aux) { vfo_ssb_rotate_exact_body(j, reinterpret_cast<const SsbRotXJob*>(e_jobs)); }
+            } break;
             case TR_ROT: { const IqSrc src = e.p.src; vfo_rotate_body(bid, gdim, src, reinterpret_cast<const RotJob*>(e_jobs)); } break;
             case TR_FCM_132_4:
                 if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }

@@ -706,10 +706,10 @@ struct FirBJob {
 // taps in order, product rounded, then added (two roundings per tap, no fused multiply-add).  The parity mode of the front end's
 // pre-processing decimator (sdrpp_preproc_set_reference_order): bit-identical to the compiled reference.
 template <bool REFORDER>
-__global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __restrict__ jobs) {
-    const FirBJob& job = jobs[blockIdx.y];
+__device__ __forceinline__ void vfo_fir_direct_body(const KIdx bid, const KIdx gdim, const FirBJob* __restrict__ jobs) {
+    const FirBJob& job = jobs[bid.y];
     const int D = 1 << job.log2_decim, kp = job.kp_pad;
-    for (int j = (int)(blockIdx.x * blockDim.x + threadIdx.x); j < job.nout; j += (int)(gridDim.x * blockDim.x)) {
+    for (int j = bid.x * 256 + (int)threadIdx.x; j < job.nout; j += gdim.x * 256) {
         const int i0 = job.off0 + (j << job.log2_decim) - (job.ntaps - 1);
         float2 acc = make_float2(0.0f, 0.0f);
         for (int k = 0; k < job.ntaps; k++) {
@@ -728,6 +728,8 @@ __global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __re
         reinterpret_cast<float2*>(job.out)[j] = acc;
     }
 }
+template <bool REFORDER>
+__global__ __launch_bounds__(256) void vfo_fir_direct_kernel(const FirBJob* __restrict__ jobs) { vfo_fir_direct_body<REFORDER>(kidx(blockIdx), kidx(gridDim), jobs); }
 
 // The reference's DC blocker recursion itself (dc_blocker.h:54-60: out = in - offset; offset += out * rate, product rounded, then added)
 // over the wideband stream, for the parity mode of the pre-processing chain: ONE wavefront walks the block, 64 samples per coalesced

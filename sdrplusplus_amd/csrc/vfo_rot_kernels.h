@@ -116,9 +116,12 @@ typedef float rot_v2f __attribute__((vector_size(8)));
 #define SDRPP_ROTX4_TRIP 4  // chunks per request round of the chain wavefront
 // (SKIP, a template parameter: in a full chunk the chain publishes every SKIP-th phase; the applying wavefronts take the steps in between themselves)
 #define SDRPP_ROTX4_LDS_BYTES ((size_t)2 * 64 * 65 * sizeof(float2) + (size_t)2 * SDRPP_ROTX4_TRIP * 64 * sizeof(float2) + 64 * sizeof(float2*) + 64 * sizeof(float2) + 2 * sizeof(int))
+// (a role of the tick kernel too — TR_ROTX16, round 5: a bank with a few reference-rotator VFOs keeps the results of all its VFOs pipelined; the
+// tick then lasts as long as this chain, which is what bounds such a stream anyway)
+struct RotXHead { const RotXJob* jobs; const int* bounds; int njobs, nb, vpw, pad; };  // what the role finds behind its entry's job pointer
 template <int SKIP>
-__global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds_g, int nb, int vpw) {
-    HIP_DYNAMIC_SHARED(float2, ph_tile)  // [2][64 samples][65]: column = VFO; then [2 * TRIP][64] samples; then the 64 output pointers
+__device__ __forceinline__ void vfo_rotate_exact4_body(const int bx, float2* ph_tile, const IqSrc& src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds_g, int nb, int vpw) {
+    // ph_tile: [2][64 samples][65]: column = VFO; then [2 * TRIP][64] samples; then the 64 output pointers
     constexpr int TRIP = SDRPP_ROTX4_TRIP;
     float2* x_tile = ph_tile + (size_t)2 * 64 * 65;
     float2** outp = reinterpret_cast<float2**>(x_tile + 2 * TRIP * 64);
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
     int* sparse = reinterpret_cast<int*>(dtab + 64);       // [2]: the chunk in this buffer carries every SKIP-th phase only
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wv = wave_uniform(tid >> 6);  // (known to be uniform: the roles are scalar branches and the chunk walk stays in scalar registers)
-    const int j0 = (int)blockIdx.x * vpw;  // vpw <= 64 VFOs per workgroup (the host's choice: see rot_exact_vpw)
+    const int j0 = bx * vpw;  // vpw <= 64 VFOs per workgroup (the host's choice: see rot_exact_vpw)
     const int nrows = min(vpw, njobs - j0);
     const UniformI32 bounds = as_uniform_i32(bounds_g);
     RotChunkIt cit;  // the chunk every wavefront of the workgroup is at (one barrier per chunk)
@@ -269,6 +272,11 @@ __global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const
         }
     }
 }
+template <int SKIP>
+__global__ __launch_bounds__(256) void vfo_rotate_exact4_kernel(IqSrc src, const RotXJob* __restrict__ jobs, int njobs, const int* __restrict__ bounds_g, int nb, int vpw) {
+    HIP_DYNAMIC_SHARED(float2, ph_tile)
+    vfo_rotate_exact4_body<SKIP>((int)blockIdx.x, ph_tile, src, jobs, njobs, bounds_g, nb, vpw);
+}
 
 // SSB's second translation (ssb.h:78, a FrequencyXlator at the IF rate) in reference-rotator mode: one wavefront per VFO, every lane
 // evaluates the same (uniform) recursion, lane i keeps Re{x[i] * phase} of sample i of the 64-sample chunk.
@@ -280,9 +288,9 @@ struct SsbRotXJob {
     const int* bounds;
     int nb;
 };
-__global__ __launch_bounds__(64) void vfo_ssb_rotate_exact_kernel(const SsbRotXJob* __restrict__ jobs) {
-    const SsbRotXJob job = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void vfo_ssb_rotate_exact_body(const int jidx, const SsbRotXJob* __restrict__ jobs) {  // one WAVEFRONT per job
+    const SsbRotXJob job = jobs[jidx];
+    const int lane = (int)threadIdx.x & 63;
     float pr = job.state->x, pi = job.state->y;
     int b0 = 0;
     for (int blk = 0; blk < job.nb; blk++) {
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(64) void vfo_ssb_rotate_exact_kernel(const SsbRotXJ
     }
     if (lane == 0) { *job.state = make_float2(pr, pi); }
 }
+__global__ __launch_bounds__(64) void vfo_ssb_rotate_exact_kernel(const SsbRotXJob* __restrict__ jobs) { vfo_ssb_rotate_exact_body((int)blockIdx.x, jobs); }
 
 // =====================================================================================================================
 // Retune hand-over of the closed-form NCO (RxVFO::setOffset, rx_vfo.h:72-77).  In the reference only phaseDelta changes: the

@@ -157,6 +157,52 @@ def test_pipelined_long_fft(backend):
     cb.close()
 
 
+def test_reference_rotator_vfos_stay_in_the_tick(backend):
+    """sdrpp_vfo_desc.nco_mode = 2 (the reference's float rotator recursion, frequency_xlator.h:43-50) on the USB channels of a cfg 4 bank, pipelined: the
+    recursion over the block, the plain first stages behind it and SSB's second rotator are roles of the tick (TR_ROTX16 / TR_FIRD / TR_SSBX) — no block
+    falls back to an ordinary pass, every VFO's results (the closed-form NFM / AM channels' too) arrive through the result slots, bit-identical to the
+    ordinary pass; a retune of such a channel between blocks (only phaseDelta changes: rx_vfo.h:72-77) included."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr, nv = workloads.CFG[4]["sr"], 54
+    pushes = [307200, 100003, 204397, 307200, 307200] if backend == "gpu" else [38400, 12503, 25597, 38400, 38400]
+    x = workloads.synth(4, sum(pushes), seed=11, nvfo=nv)
+    pair = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=max(pushes))
+        vids, usb = [], []
+        for mode, if_rate, bw, centre, _ in workloads.vfo_plan(4, nv):
+            d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode, nco_mode=2 if mode == "USB" else 1)
+            vids.append(ctx.vfo_add(d, keep))
+            if mode == "USB":
+                usb.append(vids[-1])
+        ctx.set_reference_block(50000)
+        if pipelined:
+            ctx.set_pipelined(True, 1)
+        pair.append((ctx, vids, usb))
+    (ca, va, ua), (cb, vb, ub) = pair
+    assert len(ua) == 18
+    refs, pos = [], 0
+    for i, n in enumerate(pushes):
+        blk = x[pos:pos + n]
+        pos += n
+        if i == 3:
+            re, im = capi.design_phase_delta(-3.21e6, sr)
+            ca.vfo_set_phase_delta(ua[2], re, im)
+            cb.vfo_set_phase_delta(ub[2], re, im)
+        refs.append(_ordinary_results(ca, va, blk, False))
+        cb.push(blk)
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block %d" % t)
+        cb.result_release(t)
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] == 0 and st["tick_blocks"] == len(pushes), st
+    assert all(st["roles"].get(k, 0) > 0 for k in ("rotx16", "fird", "ssbx")), st["roles"]
+    ca.close()
+    cb.close()
+
+
 def test_pipelined_falls_back_to_ordinary_passes(backend):
     """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
