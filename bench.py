@@ -917,7 +917,8 @@ def main():
                     others["cfg3_af"] = {"workload": ra["workload"] + " + AF chain (resampler to 48 kHz, 50 us de-emphasis) on every VFO", "pipelined_stream_cap": compact(ra),
                                          "sr200_pinned_results_delivered": af_sr200_delivered(torch, capi, workloads, sr, nvfo)}
                 if oc == 4:  # the setting in which cfg 4's SSB channels follow the reference's own rotator (parity at arbitrary offsets): chain-bound
-                    r3, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "ordinary", 12, 3, ocv, exact_ssb=True)
+                    # (pipelined since round 5: the rotator recursion is a role of the tick — TR_ROTX16 — and bounds it; the other stages run in its shadow)
+                    r3, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 24, 4, ocv, exact_ssb=True)
                     del inp
                     torch.cuda.empty_cache()
                     others["cfg4"]["ssb_channels_on_reference_rotator_stream_cap"] = compact(r3)
