@@ -203,6 +203,43 @@ def test_reference_rotator_vfos_stay_in_the_tick(backend):
     cb.close()
 
 
+def test_reference_rotator_context_runs_as_ticks(backend):
+    """sdrpp_set_nco_mode(SDRPP_NCO_REFERENCE_ROTATOR) for the whole context, cfg 3 geometry (20 WFM VFOs at 10 MS/s): no matrix front end is left, the
+    rotator role (71 KB of LDS in the three-wavefronts-per-SIMD build of the tick kernel) feeds plain first stages — still one launch per block, bit-identical
+    to the ordinary pass."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr, nv = workloads.CFG[3]["sr"], 20
+    pushes = [50000, 12345, 50000, 50000] if backend == "gpu" else [20000, 12345, 20000]
+    x = workloads.synth(3, sum(pushes), seed=12, nvfo=nv)
+    pair = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=max(pushes))
+        ctx.set_nco_mode(1)
+        vids = []
+        for mode, if_rate, bw, centre, _ in workloads.vfo_plan(3, nv):
+            d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        if pipelined:
+            ctx.set_pipelined(True, 1)
+        pair.append((ctx, vids))
+    (ca, va), (cb, vb) = pair
+    refs, pos = [], 0
+    for n in pushes:
+        blk = x[pos:pos + n]
+        pos += n
+        refs.append(_ordinary_results(ca, va, blk, False))
+        cb.push(blk)
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block %d" % t)
+        cb.result_release(t)
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] == 0 and st["tick_blocks"] == len(pushes) and st["roles"].get("rotx16", 0) > 0, st
+    ca.close()
+    cb.close()
+
+
 def test_pipelined_falls_back_to_ordinary_passes(backend):
     """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
