@@ -354,8 +354,9 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * The pre-processing chain (sdrpp_preproc_configure, default arithmetic), the radio's AF chain (sdrpp_vfo_set_af) and the waterfall display
  * state (sdrpp_wf_configure) run that way too — their stages are further levels of the block; so do VFOs on the reference-rotator NCO
  * (nco_mode = 2: the recursion over the whole block is one of the launch's work items — such a stream is bound by that chain, ~26 cycles per
- * sample, but every VFO's results stay pipelined).  What cannot (the
- * reference-order arithmetic of the pre-processing chain, VFO groups without the matrix-core front end, a retune hand-over in progress, more
+ * sample, but every VFO's results stay pipelined) and banks of any size, a single VFO included (the vector-unit front ends, one VFO per work
+ * item of the launch).  What cannot (the
+ * reference-order arithmetic of the pre-processing chain, a resampler in its register-blocked vector form, a retune hand-over in progress, more
  * FFT frames than one scratch chunk, a block the pre-processing decimator swallows whole) is processed as an ordinary
  * pass behind everything queued: always correct, pipelined where possible — and its results are delivered into the block's result slot
  * like any other block's (by plain copies and a wait inside the push: the slow path).

@@ -786,6 +786,7 @@ struct BankPlan {
             while (g < j) {
                 const size_t left = j - g;
                 int li = left >= 8 ? 0 : (left >= 4 ? 1 : (left >= 2 ? 2 : 3));
+                if (ticking) { li = 3; }  // (pipelined: one VFO per job — the forms that are roles of the tick kernel, TR_S1_1 / TR_S1D_1 / TR_F2_1; same sums per VFO)
                 const int vt = vts[li];
                 // tap array for this membership (cached on the device)
                 const std::string key = member_key('V', &s1[g], vt);
@@ -1011,6 +1012,10 @@ struct BankPlan {
                 bool direct = true;  // every job of the class decimates by >= 32: stream from global memory, no LDS tile
                 for (auto& jb : s1l[k].jobs) { direct = direct && jb.log2_decim >= 5; }
                 if (direct) {
+                    if (c->tick_planning && s1l[k].vt == 1) {
+                        emit(c, L0 + 1, F_S1, TR_S1D_1, (s1l[k].max_nout + 255) / 256, (int)s1l[k].jobs.size(), 0, d_s1[k], &src);
+                        continue;
+                    }
                     const dim3 grid((s1l[k].max_nout + 255) / 256, (unsigned)s1l[k].jobs.size());
                     switch (s1l[k].vt) {
                     case 8: launch(c, vfo_stage1_direct_kernel<8>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
@@ -1018,6 +1023,10 @@ struct BankPlan {
                     case 2: launch(c, vfo_stage1_direct_kernel<2>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
                     default: launch(c, vfo_stage1_direct_kernel<1>, grid, dim3(256), 0, src, (const Stage1Job*)d_s1[k]); break;
                     }
+                    continue;
+                }
+                if (c->tick_planning && s1l[k].vt == 1) {
+                    emit(c, L0 + 1, F_S1, TR_S1_1, (s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (int)s1l[k].jobs.size(), s1l[k].lds, d_s1[k], &src, s1l[k].tile);
                     continue;
                 }
                 const dim3 grid((s1l[k].max_nout + s1l[k].tile - 1) / s1l[k].tile, (unsigned)s1l[k].jobs.size());
@@ -1031,6 +1040,10 @@ struct BankPlan {
             }
             for (int k = 0; k < 4; k++) {
                 if (f2l[k].jobs.empty() || f2l[k].max_blocks == 0) { continue; }
+                if (c->tick_planning && f2l[k].vt == 1) {
+                    emit(c, L0 + 1, F_S1, TR_F2_1, f2l[k].max_blocks, (int)f2l[k].jobs.size(), f2l[k].lds, d_f2[k], &src);
+                    continue;
+                }
                 const dim3 grid((unsigned)f2l[k].max_blocks, (unsigned)f2l[k].jobs.size());
                 const dim3 block(256);
                 // all jobs of a launch class share VT; the (44 taps, /8) first stage of the ratio-32 plan (10 MS/s -> 312.5 kS/s) has a
@@ -1168,7 +1181,8 @@ struct BankPlan {
                 lds = std::max(lds, ns * sizeof(float2));
             }
             if (lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "polyphase tile does not fit in LDS"); }
-            launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs);
+            if (c->tick_planning) { emit(c, level, fam, TR_POLY, (max_nout + tile - 1) / tile, (int)jobs.size(), lds, d_jobs); }
+            else { launch(c, vfo_poly_kernel, dim3((max_nout + tile - 1) / tile, (unsigned)jobs.size()), dim3(tile), lds, (const PolyJob*)d_jobs); }
             return SDRPP_OK;
     }
     int launch_polyb(int li, std::vector<PolyBJob>& jobs, PolyBJob* d_jobs) {

@@ -1877,7 +1877,7 @@ const char* sdrpp_pipeline_role_name(int role) {
     static const char* const names[] = { "none", "copy", "carry", "rot", "fcm_132_4", "fcm_6", "fcm_10", "fcm_16", "fcm16_132_4", "fcl_0", "fcl_pf", "toep_c", "toep_r", "toep_q",
                                          "firb_c", "firb_r", "firb_s", "firb_q", "pre", "seq", "fft_s10", "fft_s11", "fft_s12", "fft_p1_5", "fft_p1_6", "fft_p1_7", "fft_p1_8", "fft_p1_9",
                                          "fft_p1_10", "fft_p2_7", "fft_p2_8", "fft_p2_9", "fft_p2_10", "fft_p2row", "fft_tr", "zoom_16", "zoom_4", "zoom_1", "fcm16w_132_4", "polyc", "deemp_p0", "deemp_p1",
-                                         "dc_p0", "dc_p1", "wf_ring", "wf_trace", "pipe", "rotx16", "fird", "ssbx" };
+                                         "dc_p0", "dc_p1", "wf_ring", "wf_trace", "pipe", "rotx16", "fird", "ssbx", "s1_1", "s1d_1", "f2_1", "poly" };
     static_assert(sizeof(names) / sizeof(names[0]) == TR_COUNT, "role names out of step with TickRole");
     return (role >= 0 && role < TR_COUNT) ? names[role] : nullptr;
 }

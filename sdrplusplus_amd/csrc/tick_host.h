@@ -83,7 +83,7 @@ inline int tick_role_weight(int role, bool crowded) {
     static const int fcl_weight = getenv("SDRPP_GPU_TICK_FCL_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_FCL_WEIGHT")) : 72;
     switch (role) {
     case TR_FCL_0: case TR_FCL_PF: return fcl_weight;
-    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: return 90;
+    case TR_FCM_132_4: case TR_FCM_6: case TR_FCM_10: case TR_FCM_16: case TR_FCM16_132_4: case TR_S1_1: case TR_S1D_1: case TR_F2_1: return 90;
     case TR_SEQ: case TR_SSBX: return 85;
     case TR_FFT_P1_5: case TR_FFT_P1_6: case TR_FFT_P1_7: case TR_FFT_P1_8: case TR_FFT_P1_9: case TR_FFT_P1_10: case TR_FIRB_C: case TR_FIRB_R: case TR_FIRB_S: case TR_FIRB_Q: return 70;
     case TR_POLYC: return 55;

@@ -115,6 +115,11 @@ enum TickRole : int {
     TR_ROTX16,     // RotXHead (jobs), p.src, gx = workgroups of `vpw` VFOs: vfo_rotate_exact4_body<16> — the reference's float rotator recursion at the full rate
     TR_FIRD,       // FirBJob[gy]: vfo_fir_direct_body<false> (plain decimators whose window fits no LDS tile: the first stages behind that rotator)
     TR_SSBX,       // SsbRotXJob[aux], one wavefront per job (gx = ceil(aux / 4)): SSB's second translation as the same recursion at the IF rate
+    // banks too small for the matrix front end (fewer than 17 VFOs of one geometry — what a user's session usually is), one VFO per job (round 5)
+    TR_S1_1,       // Stage1Job[gy], p.src, aux = tile (work-items that compute): vfo_stage1_body<1> (first stage alone, window in LDS)
+    TR_S1D_1,      // Stage1Job[gy], p.src: vfo_stage1_direct_body<1> (first stage alone, decimation >= 32: straight from memory)
+    TR_F2_1,       // Front2Job[gy], p.src: vfo_front2_body<1, 0, 0> (first two stages fused, VALU form)
+    TR_POLY,       // PolyJob[gy]: vfo_poly_body (a resampler neither the matrix nor the cycle-major form takes: one output per work-item)
     TR_COUNT
 };
 struct TickP1 { IqSrc src; FrameGeom g; const float* window; const float2* tw1; const float2* twn; float2* scratch; int lg2, ntiles; };
@@ -274,6 +279,10 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
                 }
                 break;
             case TR_FIRD: vfo_fir_direct_body<false>(bid, gdim, reinterpret_cast<const FirBJob*>(e_jobs)); break;
+            case TR_POLY: vfo_poly_body(bid, reinterpret_cast<float2*>(smem), reinterpret_cast<const PolyJob*>(e_jobs)); break;
+            case TR_S1_1: { const IqSrc src = e.p.src; vfo_stage1_body<1>(bid, reinterpret_cast<float2*>(smem), e_aux, 256, src, reinterpret_cast<const Stage1Job*>(e_jobs)); } break;
+            case TR_S1D_1: { const IqSrc src = e.p.src; vfo_stage1_direct_body<1>(bid, src, reinterpret_cast<const Stage1Job*>(e_jobs)); } break;
+            case TR_F2_1: { const IqSrc src = e.p.src; vfo_front2_body<1, 0, 0>(bid, reinterpret_cast<float2*>(smem), src, reinterpret_cast<const Front2Job*>(e_jobs)); } break;
             case TR_SSBX: {
                 const int j = bid.x * 4 + ((int)threadIdx.x >> 6);
                 if (j < e_aux) { vfo_ssb_rotate_exact_body(j, reinterpret_cast<const SsbRotXJob*>(e_jobs)); }

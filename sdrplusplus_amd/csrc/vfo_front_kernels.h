@@ -27,13 +27,13 @@ struct Front2Job {
 // NCO bookkeeping: the phasor of stage-1 output j of a tile is P_tile * ptab[j], P_tile = exp(j*2*pi*(phi0 + theta*(base + kc)))
 // evaluated once per block and VFO in double precision.  ptab[j] is applied to the stage-1 output; P_tile is constant over the
 // tile, so by linearity it is applied AFTER stage 2 (T2 instead of 256 complex multiplies per VFO).
+// (also a role of the tick kernel — TR_F2_1, round 5: banks too small for the matrix front end stay pipelined)
 template <int VT, int K1S, int LGD1S>  // K1S > 0: stage-1 geometry known at compile time (fully unrolled)
-__global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Front2Job* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float2, smem2)
-    const Front2Job& job = jobs[blockIdx.y];
+__device__ __forceinline__ void vfo_front2_body(const KIdx bid, float2* smem2, const IqSrc& src, const Front2Job* __restrict__ jobs) {
+    const Front2Job& job = jobs[bid.y];
     constexpr int tile = 256;  // stage-1 outputs computed per block (one per work-item); blockDim.x == 256
     const int T2 = job.t2;
-    const int j2_0 = blockIdx.x * T2;
+    const int j2_0 = bid.x * T2;
     if (j2_0 >= job.nout2) { return; }
     const int K1 = (K1S > 0) ? K1S : job.ntaps1, lgD1 = (K1S > 0) ? LGD1S : job.log2_decim1, D1 = 1 << lgD1;
     const int K2 = job.ntaps2, lgD2 = job.log2_decim2, D2 = 1 << lgD2;
@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Fro
             if (jj < n2) { o[jj] = make_float2(fmaf(a[r].x, P.x, -(a[r].y * P.y)), fmaf(a[r].x, P.y, a[r].y * P.x)); }
         }
     }
+}
+template <int VT, int K1S, int LGD1S>
+__global__ __launch_bounds__(256, 8) void vfo_front2_kernel(IqSrc src, const Front2Job* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, smem2)
+    vfo_front2_body<VT, K1S, LGD1S>(kidx(blockIdx), smem2, src, jobs);
 }
 
 // =====================================================================================================================

@@ -134,24 +134,25 @@ __device__ __forceinline__ void stage1_accumulate_static(const float2* xs, int p
 // grid = (ceil(max nout / TILE), njobs); block = TILE work-items; dynamic LDS = D * pitch float2 with
 // pitch = TILE + ceil((K-1)/D) + 1.  LDS image is de-interleaved by decimation phase: sample s of the tile lives at
 // [s mod D][s div D], so lane j reads x[j*D + k] at [k mod D][j + k div D] — consecutive lanes, consecutive addresses.
+// (also a role of the tick kernel — TR_S1_1, round 5: banks too small for the matrix front end stay pipelined; `tile` work-items compute, all `nall` of the
+// workgroup load)
 template <int VT>
-__global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float2, xs)
-    const Stage1Job& job = jobs[blockIdx.y];
-    const int tile = blockDim.x;
-    const int j0 = blockIdx.x * tile;
+__device__ __forceinline__ void vfo_stage1_body(const KIdx bid, float2* xs, const int tile, const int nall, const IqSrc& src, const Stage1Job* __restrict__ jobs) {
+    const Stage1Job& job = jobs[bid.y];
+    const int j0 = bid.x * tile;
     if (j0 >= job.nout) { return; }
     const int K = job.ntaps, lgD = job.log2_decim, D = 1 << lgD;
     const int extra = (K - 1 + D - 1) >> lgD;
     const int pitch = tile + extra + 1;
     const int nsamp = (tile - 1) * D + K;
     const long long base = (long long)job.off0 + (long long)j0 * D - (K - 1);  // push-relative index of tile sample 0
-    for (int s = threadIdx.x; s < nsamp; s += tile) {
+    for (int s = threadIdx.x; s < nsamp; s += nall) {
         const long long gi = base + s;
         xs[(s & (D - 1)) * pitch + (s >> lgD)] = (gi < job.min_idx) ? make_float2(0.0f, 0.0f) : iq_load_clamped(src, gi);
     }
     __syncthreads();
     const int j = threadIdx.x;
+    if (j >= tile) { return; }
     float2 acc[VT];
 #pragma unroll
     for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
@@ -172,6 +173,11 @@ __global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1
         }
     }
 }
+template <int VT>
+__global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, xs)
+    vfo_stage1_body<VT>(kidx(blockIdx), xs, (int)blockDim.x, (int)blockDim.x, src, jobs);
+}
 
 // Large first-stage decimation (D >= 32: the 61.44 MS/s plans decimate by 64 with 257..400 taps).  An LDS tile for even 64
 // outputs would be ~36 KiB, leaving one wavefront per SIMD.  Consecutive outputs start D samples apart, so there is almost
@@ -179,9 +185,9 @@ __global__ __launch_bounds__(256) void vfo_stage1_kernel(IqSrc src, const Stage1
 // global memory (each 64-byte line is consumed over 8 iterations and stays in L1), no LDS, full occupancy.  Reuse is across
 // the VT VFOs of the work-item, exactly as in the tiled kernel.
 template <int VT>
-__global__ __launch_bounds__(256) void vfo_stage1_direct_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) {
-    const Stage1Job& job = jobs[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void vfo_stage1_direct_body(const KIdx bid, const IqSrc& src, const Stage1Job* __restrict__ jobs) {  // (256 work-items; role TR_S1D_1)
+    const Stage1Job& job = jobs[bid.y];
+    const int j = bid.x * 256 + (int)threadIdx.x;
     const int K = job.ntaps, lgD = job.log2_decim;
     const int jc = (j < job.nout) ? j : (job.nout - 1);  // lanes past the end redo the last output (no divergence), never store
     if (job.nout <= 0) { return; }
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) void vfo_stage1_direct_kernel(IqSrc src, const
 #pragma unroll
     for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
     // block-uniform fast path: every window of this block lies inside the current push
-    const long long blk_first = (long long)job.off0 + ((long long)(blockIdx.x * blockDim.x) << lgD) - (K - 1);
-    const long long blk_last = (long long)job.off0 + ((long long)min((int)(blockIdx.x * blockDim.x + blockDim.x - 1), job.nout - 1) << lgD);
+    const long long blk_first = (long long)job.off0 + ((long long)(bid.x * 256) << lgD) - (K - 1);
+    const long long blk_last = (long long)job.off0 + ((long long)min(bid.x * 256 + 255, job.nout - 1) << lgD);
     const bool inside = blk_first >= 0 && blk_first >= job.min_idx && blk_last < src.n_cur;
     if (inside) {
         const float2* __restrict__ xa = src.cur + i0;
@@ -243,6 +249,8 @@ __global__ __launch_bounds__(256) void vfo_stage1_direct_kernel(IqSrc src, const
         }
     }
 }
+template <int VT>
+__global__ __launch_bounds__(256) void vfo_stage1_direct_kernel(IqSrc src, const Stage1Job* __restrict__ jobs) { vfo_stage1_direct_body<VT>(kidx(blockIdx), src, jobs); }
 
 // Rotation only (VFOs whose output rate is above half the input rate have no decimation stage: power_decimator.h:53-56).
 struct RotJob {
@@ -277,11 +285,10 @@ struct PolyJob {
     int interp, decim, tpp, phase0, off0, nout;
 };
 
-__global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict__ jobs) {
-    HIP_DYNAMIC_SHARED(float2, xs)
-    const PolyJob& job = jobs[blockIdx.y];
-    const int tile = blockDim.x;
-    const int n0 = blockIdx.x * tile;
+__device__ __forceinline__ void vfo_poly_body(const KIdx bid, float2* xs, const PolyJob* __restrict__ jobs) {  // 256 work-items, one output each (role TR_POLY)
+    const PolyJob& job = jobs[bid.y];
+    constexpr int tile = 256;
+    const int n0 = bid.x * tile;
     if (n0 >= job.nout) { return; }
     const int L = job.interp, M = job.decim, tpp = job.tpp;
     const long long a0 = (long long)job.phase0 + (long long)n0 * M;
@@ -306,6 +313,10 @@ __global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict
         acc.y = fmaf(h, x.y, acc.y);
     }
     job.out[n] = acc;
+}
+__global__ __launch_bounds__(256) void vfo_poly_kernel(const PolyJob* __restrict__ jobs) {
+    HIP_DYNAMIC_SHARED(float2, xs)
+    vfo_poly_body(kidx(blockIdx), xs, jobs);
 }
 
 // =====================================================================================================================

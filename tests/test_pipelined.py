@@ -240,6 +240,55 @@ def test_reference_rotator_context_runs_as_ticks(backend):
     cb.close()
 
 
+@pytest.mark.parametrize("sr,modes", [(2.4e6, ("WFM",)), (2.4e6, ("WFM", "NFM", "AM", "USB")), (10e6, ("WFM", "WFM", "NFM", "AM", "USB", "RAW")),
+                                      (20e6, ("WFM", "AM", "DSB", "LSB")), (1e6, ("NFM", "USB"))])
+def test_small_banks_stay_pipelined(backend, sr, modes):
+    """What a user's session usually is — one to a handful of VFOs, far too few for the matrix front end: the VALU front ends (first stage alone, from an
+    LDS window or straight from memory; first two stages fused), one VFO per job, and the one-output-per-work-item resampler are roles of the tick too
+    (TR_S1_1 / TR_S1D_1 / TR_F2_1 / TR_POLY, round 5).  One launch per block, no ordinary pass, VFO outputs and waterfall lines bit-identical to the
+    ordinary pass (whose jobs take up to eight VFOs each: the sums per VFO are the same)."""
+    from sdrplusplus_amd import capi, radio
+
+    B = int(sr / 200)
+    pushes = [B, B // 3 + 1, B, B]
+    r = np.random.default_rng(31)
+    n = sum(pushes)
+    t = np.arange(n) / sr
+    x = (0.05 * (r.standard_normal(n) + 1j * r.standard_normal(n))).astype(np.complex64)
+    offs = [(i - len(modes) / 2.0) * sr / (2 * len(modes) + 2) for i in range(len(modes))]
+    for o in offs:
+        x = (x + 0.2 * np.exp(2j * np.pi * ((o + 3e3) * t + 0.5 * np.sin(2 * np.pi * 700.0 * t)))).astype(np.complex64)
+    pair = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=B)
+        ctx.fft_configure(4096, 4096, 0, capi.design_fft_window(2, 4096))
+        start, size = capi.design_waterfall_view(0.0, sr, sr, 4096)
+        ctx.fft_set_view(start, size, 600, -120.0, 0.0)
+        vids = []
+        for mode, o in zip(modes, offs):
+            if_rate, bw = radio.RADIO_DEFAULTS.get(mode, (250e3, 250e3))
+            d, keep = radio.vfo_desc(sr, if_rate, bw, o, mode)
+            vids.append(ctx.vfo_add(d, keep))
+        if pipelined:
+            ctx.set_pipelined(True, 7)
+        pair.append((ctx, vids))
+    (ca, va), (cb, vb) = pair
+    refs, pos = [], 0
+    for k in pushes:
+        blk = x[pos:pos + k]
+        pos += k
+        refs.append(_ordinary_results(ca, va, blk, True))
+        cb.push(blk)
+    for tkt, ref in enumerate(refs, start=1):
+        got = cb.result_wait(tkt)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), "raw": ref["raw"], "zoomed": ref["zoomed"], "index": ref["index"]}, got, True, "block %d" % tkt)
+        cb.result_release(tkt)
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] == 0 and st["tick_blocks"] == len(pushes), st
+    ca.close()
+    cb.close()
+
+
 def test_pipelined_falls_back_to_ordinary_passes(backend):
     """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""

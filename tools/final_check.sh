@@ -17,3 +17,5 @@ for k,v in oc.items():
 print(d.get('by_push',{}).get('cpp_iqfrontend_run_bypass_pipelined'))
 PY
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+# what pipelined mode gives a small bank (cfg 1: 2.4 MS/s, one WFM VFO, 4096-point FFT) at the reference's block size
+( timeout 200 python tools/tick_rate.py 1 12000 2>&1 | grep '^{' ) | tee gpurun_out/${TAG}_tick_rate_cfg1.json

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 ROLES = ["none", "copy", "carry", "rot", "fcm_132_4", "fcm_6", "fcm_10", "fcm_16", "fcm16_132_4", "fcl_0", "fcl_pf", "toep_c", "toep_r", "toep_q", "firb_c", "firb_r", "firb_s", "firb_q",
-         "pre", "seq", "fft_s10", "fft_s11", "fft_s12", "p1_5", "p1_6", "p1_7", "p1_8", "p1_9", "p1_10", "p2_7", "p2_8", "p2_9", "p2_10", "p2row", "transp", "zoom16", "zoom4", "zoom1", "fcm16w_132_4", "polyc", "deemp_p0", "deemp_p1", "dc_p0", "dc_p1", "wf_ring", "wf_trace", "pipe", "rotx16", "fird", "ssbx"]
+         "pre", "seq", "fft_s10", "fft_s11", "fft_s12", "p1_5", "p1_6", "p1_7", "p1_8", "p1_9", "p1_10", "p2_7", "p2_8", "p2_9", "p2_10", "p2row", "transp", "zoom16", "zoom4", "zoom1", "fcm16w_132_4", "polyc", "deemp_p0", "deemp_p1", "dc_p0", "dc_p1", "wf_ring", "wf_trace", "pipe", "rotx16", "fird", "ssbx", "s1_1", "s1d_1", "f2_1", "poly"]
 dt = np.dtype({"names": ["tick", "role", "entry", "block", "t0", "t1", "hwid", "xcc", "m"], "formats": ["<u4", "<i2", "<i2", "<i4", "<u8", "<u8", "<u4", "<u4", ("<u8", 4)], "offsets": [0, 4, 6, 8, 16, 24, 32, 36, 40], "itemsize": 72})
 a = np.fromfile(sys.argv[1], dtype=dt)
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 50
