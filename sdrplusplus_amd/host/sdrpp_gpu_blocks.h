@@ -211,7 +211,8 @@ public:
     // ONE kernel launch; its dB lines and VFO blocks are handed to the callback pair / output streams `lagBlocks` blocks later (the
     // reference's own graph is a pipeline of one thread per block with a stream hand-over between each pair, a few blocks deep as well).
     // Same results, bit for bit; at the reference's block size the front end takes blocks 3-4x faster than with one pass per block.
-    // What the device cannot pipeline (pre-processing, bound IQ streams, an AF chain) falls back to one pass per block by itself.
+    // What the device cannot pipeline (the reference-order arithmetic of the pre-processing chain, a retune hand-over in progress: include/sdrpp_gpu.h)
+    // falls back to one pass per block by itself; banks of any size — a single VFO too — run pipelined.
     // lagBlocks should not be smaller than the depth of the device pipeline (6-8 launches for a radio bank + FFT): asking for a block's
     // results earlier makes the library run the missing stages without new input, launch by launch.
     // Takes effect with the next block.  The tail still in flight when the input stops is handed out by drainPipeline() (worker stopped)

@@ -169,8 +169,8 @@ def _run_reconfig_and_check(exe, tmp, nextra, wait_ms):
 def test_reconfigure_while_running_on_the_emulator():
     """addVFO / setBandwidth / removeVFO (blocks in flight) / setFFTSize / setPipelining(false / true) / stop + start between the blocks of a RUNNING
     pipelined graph (iq_frontend.cpp:105-183, dsp/block.h:46-94): every delivered block equals the oracle under the same schedule, none lost, none
-    twice.  CPU emulator build; three VFOs (the bank's blocks go through the pipelined host path — tickets, result slots, hand-over — as ordinary
-    passes: fewer than 17 VFOs have no matrix front end)."""
+    twice.  CPU emulator build; three VFOs (a small bank: the vector-unit front ends as roles of the tick since round 5 — ordinary passes before; the
+    device leg adds 17 radios for the matrix front end)."""
     with tempfile.TemporaryDirectory() as tmp:
         out = _run_reconfig_and_check(_build(tmp, lib="emu", source="test_reconfig.cpp"), tmp, 0, 60000)
         assert "blocks 13" in out
