@@ -17,13 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _make(*args):
+    from support import locked_make  # (tests/support.py: one lock for every build a test may trigger)
+
+    locked_make(*args)
+
+
 def _ensure_built():
     """CPU-side artefacts: oracle (+ compiled reference where /root/reference exists), product library (cross-compiled),
     and the test-only emulator build of the same kernel sources."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")) or os.path.isdir("/root/reference"):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "all"], check=True)
+        _make("-C", os.path.join(ROOT, "oracle"), "-s", "all")
     # always through make: a no-op when the library is newer than its sources (on the GPU box hipcc is present as well)
-    subprocess.run(["make", "-C", os.path.join(ROOT, "sdrplusplus_amd", "csrc"), "-s", "all"], check=True)
+    _make("-C", os.path.join(ROOT, "sdrplusplus_amd", "csrc"), "-s", "all")
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -42,7 +48,7 @@ def backend(request):
     from sdrplusplus_amd import capi
 
     if request.param == "emu":
-        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s"], check=True)
+        _make("-C", os.path.join(ROOT, "tests", "emu"), "-s")
         capi.DEFAULT_LIB = EMU_LIB  # test-only: the product binding itself has no override
     else:
         capi.DEFAULT_LIB = REAL_LIB

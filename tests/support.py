@@ -18,9 +18,21 @@ def _fp(a):
     return a.ctypes.data_as(c_float_p)
 
 
+def locked_make(*args):
+    """`make` under a file lock: the workers of a parallel run (pytest-xdist) on a fresh tree would otherwise build — and load — the same library at once."""
+    import fcntl
+
+    with open(os.path.join(ROOT, "tests", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make"] + list(args), check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build_oracle():
     """(Re)build oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
-    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "all"], check=True)
+    locked_make("-C", ORACLE_DIR, "-s", "all")
 
 
 _oracle = None

@@ -29,7 +29,7 @@ def _build(tmp, lib="product", headers="standalone", source="test_blocks.cpp"):
     else:
         cmd += ["-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone")]
     if lib == "emu":
-        subprocess.run(["make", "-C", EMU, "-s"], check=True)
+        S.locked_make("-C", EMU, "-s")
         cmd += ["-L" + EMU, "-l:libsdrpp_gpu_emu.so", "-Wl,-rpath," + EMU]
     else:
         cmd += ["-L" + CSRC, "-lsdrpp_gpu", "-Wl,-rpath," + CSRC]
@@ -103,7 +103,7 @@ def test_host_mirror_links_and_runs_against_the_reference_headers():
     module's demod::Demodulator interface (decoder_modules/radio/src/demod.h, cut out at build time), LINKED and RUN (CPU emulator
     library): IQFrontEnd derives from the real dsp::block, speaks the real dsp::stream<T>, FusedDemodulator overrides every pure
     virtual of the real interface."""
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/demod_iface.h"], check=True)
+    S.locked_make("-C", os.path.join(ROOT, "oracle"), "-s", "_ref/demod_iface.h")
     with tempfile.TemporaryDirectory() as tmp:
         _run_graph_and_check(_build(tmp, lib="emu", headers="reference"), "bypass", tmp, drain_ms=3000)
 
@@ -184,7 +184,7 @@ def test_reconfigure_while_running_host_side_under_sanitizers(san):
     returns and reports a "double lock" at the helpers' timed wait — the one report that is filtered out.)"""
     from sdrplusplus_amd import workloads
 
-    subprocess.run(["make", "-C", EMU, "-s"], check=True)
+    S.locked_make("-C", EMU, "-s")
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "test_reconfig_" + san)
         r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-w", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_reconfig.cpp"),

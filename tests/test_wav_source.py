@@ -53,7 +53,7 @@ def _build(tmp, lib):
     exe = os.path.join(tmp, "test_wav_" + lib)
     cmd = ["g++", "-std=c++17", "-O2", "-w", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_wav.cpp"), "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone")]
     if lib == "emu":
-        subprocess.run(["make", "-C", EMU, "-s"], check=True)
+        S.locked_make("-C", EMU, "-s")
         cmd += ["-L" + EMU, "-l:libsdrpp_gpu_emu.so", "-Wl,-rpath," + EMU]
     else:
         cmd += ["-L" + CSRC, "-lsdrpp_gpu", "-Wl,-rpath," + CSRC]
