@@ -26,10 +26,11 @@ def _make(*args):
 def _ensure_built():
     """CPU-side artefacts: oracle (+ compiled reference where /root/reference exists), product library (cross-compiled),
     and the test-only emulator build of the same kernel sources."""
+    # always through make: a no-op when the library is newer than its sources (on the GPU box hipcc is present as well).  The product library
+    # first: oracle/_ref links one of its reference-side test programs against it.
+    _make("-C", os.path.join(ROOT, "sdrplusplus_amd", "csrc"), "-s", "all")
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")) or os.path.isdir("/root/reference"):
         _make("-C", os.path.join(ROOT, "oracle"), "-s", "all")
-    # always through make: a no-op when the library is newer than its sources (on the GPU box hipcc is present as well)
-    _make("-C", os.path.join(ROOT, "sdrplusplus_amd", "csrc"), "-s", "all")
 
 
 @pytest.fixture(scope="session", autouse=True)
