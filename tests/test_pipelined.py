@@ -289,6 +289,66 @@ def test_small_banks_stay_pipelined(backend, sr, modes):
     cb.close()
 
 
+def test_a_user_session_stays_pipelined(backend):
+    """Everything a session switches on at once, on a bank as small as sessions are: the front end's decimation + DC blocking in front (iq_frontend.cpp:
+    105-130), four radios of four modes — the USB one on the reference's rotator recursion — each with the radio module's AF chain (radio_module.h:98-110),
+    waterfall lines of every block.  One launch per block throughout; AF output, lines and the pre-processed stream bit-identical to ordinary passes."""
+    from sdrplusplus_amd import capi, radio
+
+    sr_in, ratio = 9.6e6, 4
+    eff = sr_in / ratio
+    modes = ("WFM", "NFM", "AM", "USB")
+    B = int(sr_in / 200) if backend == "gpu" else int(sr_in / 400)
+    pushes = [B, B // 3 + 2, B, B, B]
+    r = np.random.default_rng(33)
+    n = sum(pushes)
+    t = np.arange(n) / sr_in
+    x = (0.05 * (r.standard_normal(n) + 1j * r.standard_normal(n)) + (0.02 + 0.01j)).astype(np.complex64)
+    offs = [(i - 1.5) * eff / 6 for i in range(len(modes))]
+    for o in offs:
+        x = (x + 0.2 * np.exp(2j * np.pi * ((o + 2e3) * t + 0.4 * np.sin(2 * np.pi * 600.0 * t)))).astype(np.complex64)
+    pair = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=max(pushes))
+        ctx.preproc_configure(radio.plans().stages(ratio), 50.0 / eff, False)
+        ctx.fft_configure(4096, 4096, 0, capi.design_fft_window(2, 4096))
+        start, size = capi.design_waterfall_view(0.0, eff, eff, 4096)
+        ctx.fft_set_view(start, size, 600, -120.0, 0.0)
+        vids = []
+        for mode, o in zip(modes, offs):
+            if_rate, bw = radio.RADIO_DEFAULTS.get(mode, (250e3, 250e3))
+            d, keep = radio.vfo_desc(eff, if_rate, bw, o, mode, nco_mode=2 if mode == "USB" else 0)
+            vid = ctx.vfo_add(d, keep)
+            a, akeep = radio.af_desc(if_rate, 48000.0, 50e-6 if mode == "WFM" else None, mode == "NFM")
+            ctx.vfo_set_af(vid, a, akeep)
+            vids.append(vid)
+        if pipelined:
+            ctx.set_pipelined(True, 15)
+        pair.append((ctx, vids))
+    (ca, va), (cb, vb) = pair
+    refs, pos = [], 0
+    for k in pushes:
+        blk = x[pos:pos + k]
+        pos += k
+        ca.push(blk)
+        ref = {"vfo": {v: ca.vfo_af_read(v).copy() for v in va}, "iq": ca.preproc_read().copy()}
+        raw, zo, ix = ca.fft_read()
+        ref.update(raw=raw, zoomed=zo, index=ix)
+        refs.append(ref)
+        cb.push(blk)
+    for tkt, ref in enumerate(refs, start=1):
+        got = cb.result_wait(tkt)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{q: ref[q] for q in ("raw", "zoomed", "index")}}, got, True, "block %d" % tkt)
+        if len(ref["iq"]):
+            _same(ref["iq"].view(np.float32), got["iq"].view(np.float32), "block %d pre-processed IQ" % tkt)
+        cb.result_release(tkt)
+    st = cb.pipeline_stats()
+    assert st["pass_blocks"] == 0 and st["tick_blocks"] == len(pushes), st
+    assert st["roles"].get("rotx16", 0) > 0 and st["roles"].get("ssbx", 0) > 0, st["roles"]
+    ca.close()
+    cb.close()
+
+
 def test_pipelined_falls_back_to_ordinary_passes(backend):
     """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
     the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
