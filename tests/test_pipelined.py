@@ -350,8 +350,9 @@ def test_a_user_session_stays_pipelined(backend):
 
 
 def test_pipelined_falls_back_to_ordinary_passes(backend):
-    """What has no role in the tick kernel runs as an ordinary pass behind everything queued: two VFOs (VALU front end), then a retune in
-    the middle of a 20-VFO run (the hand-over kernel), then pipelined again — same results throughout."""
+    """What has no role in the tick kernel runs as an ordinary pass behind everything queued: a retune in the middle of a 20-VFO run (the hand-over
+    kernel), then pipelined again — same results throughout; in front of it a two-VFO bank read back call by call after every push (its vector-unit
+    front end was the other case until round 5: a role of the tick now, test_small_banks_stay_pipelined)."""
     from sdrplusplus_amd import capi, workloads
 
     pushes = [50000, 12345, 50000] if backend == "gpu" else [20000, 12345, 20000]
