@@ -111,3 +111,24 @@ def test_binding_constants_match_header():
     assert int(re.search(r"#define\s+SDRPP_MAX_DECIM_STAGES\s+(\d+)", hdr).group(1)) == capi.MAX_DECIM_STAGES
     names = [capi.load().sdrpp_kernel_family_name(i).decode() for i in range(capi.NUM_KERNEL_FAMILIES)]
     assert len(set(names)) == capi.NUM_KERNEL_FAMILIES and "?" not in names
+
+
+def test_timeline_tool_knows_every_role_of_the_tick_kernel():
+    """tools/tick_trace.py labels a dump's records by role index: its table has to follow the library's (sdrpp_pipeline_role_name — itself pinned to the
+    kernel's enum by a static_assert); it had fallen one role behind once."""
+    lib = _real_capi().load()
+    names = []
+    while lib.sdrpp_pipeline_role_name(len(names)) is not None:
+        names.append(lib.sdrpp_pipeline_role_name(len(names)).decode())
+    src = open(os.path.join(ROOT, "tools", "tick_trace.py")).read()
+    roles = eval(src[src.index("ROLES = ") + 8:src.index("]", src.index("ROLES = ")) + 1])
+
+    def tool_name(n):  # (the tool abbreviates a few)
+        if re.fullmatch(r"fft_s1[0-2]", n):
+            return n
+        n = n.replace("fft_", "")
+        return {"tr": "transp"}.get(n, n).replace("zoom_", "zoom")
+
+    assert len(names) > 40 and [tool_name(n) for n in names] == roles, [(a, b) for a, b in zip(names, roles) if tool_name(a) != b]
+    buf_len = 128  # capi.Context.pipeline_stats: head + one count per role must fit its buffer
+    assert 8 + len(names) <= buf_len
