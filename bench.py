@@ -242,7 +242,7 @@ def make_inputs(torch, np, device, base, push, seed, nvfo, min_bytes=384 << 20):
     return bufs, copies
 
 
-def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=1024, nblocks=3, af=False):
+def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=1024, nblocks=3, af=False, group=1):
     """Before anything is timed: the first `nblocks` input blocks through a PIPELINED context (result flags 7) and through an ORDINARY-pass
     context of the same configuration — every VFO block, raw dB line, zoomed line and palette index of every block must be bit-identical
     (the ordinary pass is what the parity tests compare with the oracle at every size; tests/test_bench_geometry_gpu.py compares the
@@ -252,10 +252,12 @@ def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=10
     from sdrplusplus_amd import capi, workloads
 
     base = 4 if cfg == 5 else cfg
-    out = {"blocks": nblocks, "samples_per_block": push}
+    if group > 1:
+        nblocks = 2 * group + 1  # two full launch groups and a block that goes out alone
+    out = {"blocks": nblocks, "samples_per_block": push, "blocks_per_launch": group}
     digests = []
     for pipelined in (True, False):
-        ctx = capi.Context(local, max_push=push)
+        ctx = capi.Context(local, max_push=push * (group if pipelined else 1))
         info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo)
         if ref_block and ref_block < push:
             ctx.set_reference_block(ref_block)
@@ -270,8 +272,15 @@ def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=10
         counts = [0, 0]
         if pipelined:
             ctx.set_pipelined(True, 7)
+            if group > 1:
+                ctx.set_pipeline_group(group, False)
             for b in range(nblocks):
                 ctx.push_device(bufs[b % len(bufs)].data_ptr(), push)
+            if group > 1:
+                gs = ctx.pipeline_group_stats()
+                out["launch_groups"] = {"of_several_blocks": gs["multi_groups"], "largest": gs["largest"]}
+                if gs["multi_groups"] < 2 or gs["largest"] != group:
+                    raise RuntimeError("self check: the blocks did not go out as launch groups of %d: %r" % (group, gs))
             for t in range(1, nblocks + 1):
                 r = ctx.result_wait(t, copy=False)
                 for vid in info["vids"]:
@@ -308,7 +317,8 @@ def self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=10
     return out
 
 
-def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4, exact_ssb=False, check=False):
+def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo, world=1, rank=0, af=False, ref_block=None, inputs=None, data_width=1024, lag=8, gather_every=4, exact_ssb=False, check=False,
+                 group=1, adaptive=True, regions=1):
     """One measured run of a configuration.  mode 'pipelined': sdrpp_set_pipelined, one launch per block; 'ordinary': one launch per
     stage.  Returns (result dict for rank 0, inputs) — the inputs can be handed to a second run of the same configuration."""
     from sdrplusplus_amd import capi, multi, workloads
@@ -321,7 +331,9 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         bufs, keep = make_inputs(torch, np, device, base, push, seed0 * 1000 + 1, nvfo)
         inputs = (bufs, keep, (base, push, nvfo))
     bufs = inputs[0]
-    ctx = capi.Context(local, max_push=push)
+    pipelined = mode == "pipelined"
+    group = max(1, min(int(group), capi.GROUP_MAX)) if pipelined else 1
+    ctx = capi.Context(local, max_push=push * group)  # (a launch group of `group` blocks is planned as one block: the buffers are sized for it)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one ordering domain with torch / RCCL
     info = workloads.setup(ctx, base, dense_fft=True, data_width=data_width, nvfo=nvfo, exact_ssb=exact_ssb)
     if ref_block is None:
@@ -335,15 +347,18 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
             ctx.vfo_set_af(vid, a_, k_)
             af_keep.append(k_)
-    pipelined = mode == "pipelined"
     checked = None
     if check and pipelined and rank == 0 and not exact_ssb:
-        checked = self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=data_width, af=af)
+        checked = self_check(torch, np, local, cfg, push, nvfo, bufs, ref_block, data_width=data_width, af=af, group=1 if af else group)
     if af and nvfo and pipelined:
         lag = max(lag, 13)  # (the AF chain's five levels behind the demodulator: a block's lines and audio are complete 12 launches after its push)
     max_lines = (push + N - 1) // N + 1
     if pipelined:
         ctx.set_pipelined(True, 2)  # zoomed lines + palette indices of every block into page-locked result slots
+        if group > 1:
+            # up to `group` blocks per launch (include/sdrpp_gpu.h: sdrpp_set_pipeline_group): the pushes keep their tickets and results, consecutive resident
+            # blocks (contiguous in HBM) go out as one launch; adaptive = the group follows what is queued on the device
+            ctx.set_pipeline_group(group, adaptive)
         lines = torch.zeros((gather_every, max_lines + 1, data_width), dtype=torch.float32, device=device)
     else:
         lines = torch.empty((max(1, push // N), data_width), dtype=torch.float32, device=device)
@@ -357,7 +372,8 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         # a block's results are complete `depth` launches after its push (sdrpp_pipeline_stats): a host that asks for them EARLIER makes
         # sdrpp_result_wait run the queued stages and wait for the device at every step — host work and device work then take turns instead
         # of overlapping (cfg 4: 10 levels against a lag of 8 cost 213 instead of 165 us per step).  SDRPP_RESULT_SLOTS = 24 result slots exist.
-        need = min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1)
+        # (with launch groups: `depth` LAUNCHES of up to `group` blocks each; the result slots count launches)
+        need = min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1) * group
         if need > runner.lag:
             runner.lag = lag = need
     # calibration (untimed): every kernel family bracketed by HIP events to find the dominant one and record the per-kernel split
@@ -378,9 +394,18 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
     # timed region: only the dominant family keeps its event pair (two event records per launch on its launch stream)
     ctx.timing_enable(True, families=[ctx.family_index(dom)] if dom else [])
     blocks0 = runner.collected
+    gs0 = ctx.pipeline_group_stats() if pipelined else None
+    ticks0 = ctx.pipeline_stats()["ticks"] if pipelined else 0
+    # `regions` timed regions of EXACTLY `steps` steps each (median of 5); the first one carries the dominant family's event pairs
     elapsed = runner.timed(steps, first=warmup)
     fam = ctx.timing_read()
     ctx.timing_enable(False)
+    gs1 = ctx.pipeline_group_stats() if pipelined else None
+    ticks1 = ctx.pipeline_stats()["ticks"] if pipelined else 0
+    region_s = [elapsed]
+    for q in range(1, max(1, int(regions))):
+        region_s.append(runner.timed(steps, first=warmup + q * steps))
+    elapsed = sorted(region_s)[len(region_s) // 2]
     # a short timed region (the driver's 20 steps) is a third pipeline fill and drain — depth - 1 launches at either end carry less than a block's
     # work: the same loop over 200 blocks next to it, so that both numbers come from the same process on the same box
     steady = None
@@ -391,7 +416,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
 
     # sanity: the work was really done
     if pipelined:
-        assert runner.collected - blocks0 == steps + (steady["steps"] if steady else 0) and not runner.tickets, (runner.collected, blocks0, steps)
+        assert runner.collected - blocks0 == steps * len(region_s) + (steady["steps"] if steady else 0) and not runner.tickets, (runner.collected, blocks0, steps)
         assert runner.gathered is not None or rank != 0
     else:
         assert ctx.fft_lines() == push // N if push % N == 0 else ctx.fft_lines() in (push // N, push // N + 1), (ctx.fft_lines(), push, N)
@@ -452,6 +477,8 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         mode_names = "/".join(sorted({m for m, _, _, _, _ in info["plan"]})) if nvfo else ""
         out = {
             "value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
+            "timed_regions": {"n": len(region_s), "value": "median", "Msamples_per_s": [round(world * push * steps / t / 1e6, 1) for t in region_s],
+                              "note": "every region = exactly `steps` pushes AND the delivery of all their results, bracketed by device synchronisation; roofline.* comes from the first region (the one with HIP events on the launches)"},
             "workload": workload_string(cfg, sr, N, nvfo, mode_names, pipelined),
             "samples_per_step_per_gpu": push, "mode": mode, "reference_block": ref_block if (ref_block and ref_block < push) else push,
             "input_blocks_rotated": len(bufs), "input_bytes_rotated": len(bufs) * push * 8, "af_chain": bool(af and nvfo), "device": ctx.device_info(),
@@ -470,6 +497,11 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             st = ctx.pipeline_stats()
             out["pipeline"] = {"ticks": st["ticks"], "blocks_as_ticks": st["tick_blocks"], "blocks_as_ordinary_passes": st["pass_blocks"], "crowded_ticks": st["crowded_ticks"], "depth_levels": st["depth"],
                                "roles": sorted(st["roles"])}
+            out["blocks_per_launch"] = {"max": group, "adaptive": bool(adaptive and group > 1),
+                                        "first_timed_region": {"blocks": steps, "launches": ticks1 - ticks0, "launch_groups": gs1["groups"] - gs0["groups"],
+                                                               "groups_of_several_blocks": gs1["multi_groups"] - gs0["multi_groups"], "blocks_in_those": gs1["multi_blocks"] - gs0["multi_blocks"]},
+                                        "note": "sdrpp_set_pipeline_group: consecutive pushes go out as ONE launch (planned as one block whose reference-block ends are the push ends; every push keeps its ticket "
+                                                "and its results, bit-identical to one launch per block: self_check); adaptive: a push goes out at once while the device has fewer than two launches in flight"}
         if checked is not None:
             out["self_check"] = checked
         if steady is not None:
@@ -484,7 +516,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
 def compact(r):
     if r is None:
         return None
-    keep = ("value", "ms_per_step", "steps", "samples_per_step_per_gpu", "mode", "reference_block", "kernel_ms_per_step", "realtime_factor", "nco")
+    keep = ("value", "ms_per_step", "steps", "samples_per_step_per_gpu", "mode", "reference_block", "kernel_ms_per_step", "realtime_factor", "nco", "blocks_per_launch")
     o = {k: r[k] for k in keep if k in r}
     o["unit"] = "Msamples/s"
     if r.get("roofline"):
@@ -495,7 +527,7 @@ def compact(r):
     return o
 
 
-def by_push_report(torch, capi, workloads, sr, nvfo, N):
+def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
     """cfg 3 ingest rate against the block size and the way the host drives the C-ABI.  Host buffers are page-locked (sdrpp_host_alloc —
     what the C++ blocks use for their frame-buffer slots) unless marked pageable.  `*_no_read` leave the outputs on the device; every other
     mode DELIVERS all VFO blocks + the lines of every block to the host.  frac = rate x SURVEY.md 8(d) path flops / FP32 matrix peak."""
@@ -505,18 +537,22 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
     dev = torch.device("cuda", torch.cuda.current_device())
     for B in (int(sr / 200), STREAM_CAP):
         per_pass = max(1, STREAM_CAP // B)
-        ctx = capi.Context(dev.index or 0, max_push=B * per_pass)
+        # blocks per launch of the grouped legs: what the headline uses at the stream cap, SDRPP_GROUP_MAX at the reference's block size (a launch of
+        # 8 x 50 000 samples is still a fraction of one at 10^6)
+        G = max(1, min(capi.GROUP_MAX, group if B >= STREAM_CAP else capi.GROUP_MAX))
+        ctx = capi.Context(dev.index or 0, max_push=B * max(per_pass, G))
         info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=nvfo)
         vids = info["vids"]
-        nb = 4
+        nb = 8  # consecutive blocks of ONE allocation (device and page-locked host): contiguous, so that they can share a launch; the wrap-around starts a new group
         xs = [workloads.synth(3, B, seed=7 + i, nvfo=nvfo) for i in range(nb)]
+        pin_base = ctx.L.sdrpp_host_alloc(nb * B * 8)
         ptrs = []
-        for x in xs:
-            p = ctx.L.sdrpp_host_alloc(B * 8)
-            C.memmove(p, x.ctypes.data, B * 8)
-            ptrs.append(p)
-        xd = [torch.from_numpy(x.view(np.float32)).to(dev) for x in xs]
-        entry = {"push": B}
+        for i, x in enumerate(xs):
+            C.memmove(pin_base + i * B * 8, x.ctypes.data, B * 8)
+            ptrs.append(pin_base + i * B * 8)
+        xd_all = torch.from_numpy(np.concatenate(xs).view(np.float32)).to(dev)
+        xd = [xd_all[2 * i * B:2 * (i + 1) * B] for i in range(nb)]
+        entry = {"push": B, "blocks_per_launch_max": G}
 
         def rate(fn, npush, end=None):
             end = end or ctx.sync
@@ -547,10 +583,16 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
         entry["per_push_read_pinned"] = rate(sync_pinned, min(npush, 200))
         entry["per_push_read_pageable"] = rate(sync_pageable, min(npush, 200))
         entry["device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
-        # ---- pipelined: one launch per block ----
+        # ---- pipelined: one launch per block (rounds 3-5), then up to G blocks per launch (sdrpp_set_pipeline_group, adaptive) ----
         ctx.set_pipelined(True, 0)
+        entry["pipelined_device_no_read_one_block_per_launch"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        entry["pipelined_pinned_no_read_one_block_per_launch"] = rate(lambda i: ctx.push_host_ptr_async(ptrs[i % nb], B), npush)
+        ctx.set_pipeline_group(G, True)
         entry["pipelined_device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
         entry["pipelined_pinned_no_read"] = rate(lambda i: ctx.push_host_ptr_async(ptrs[i % nb], B), npush)
+        gs = ctx.pipeline_group_stats()
+        entry["pipelined_blocks_per_launch_seen"] = round(gs["multi_blocks"] / max(1, gs["multi_groups"]), 2)
+        ctx.set_pipeline_group(1, False)
         ctx.set_pipelined(False)
         ctx.set_pipelined(True, 3)  # every VFO block + zoomed lines / palette indices of every block into page-locked result slots
         lag = 8
@@ -572,9 +614,21 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
             ctx.push(xs[i % nb])
             collect(ctx.ticket() - lag)
 
+        entry["pipelined_pinned_results_delivered_one_block_per_launch"] = rate(with_results, npush, lambda: collect(ctx.ticket()))
+        entry["pipelined_result_lag_blocks_one_block_per_launch"] = lag
+        # the same with launch groups: a block's results are complete `depth` LAUNCHES after its group went out — the host asks (depth + 1) * G blocks behind
+        ctx.set_pipeline_group(G, True)
+        lag = min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1) * G
+
+        def with_results_device(i):
+            ctx.push_device(xd[i % nb].data_ptr(), B)
+            collect(ctx.ticket() - lag)
+
         entry["pipelined_pinned_results_delivered"] = rate(with_results, npush, lambda: collect(ctx.ticket()))
         entry["pipelined_pageable_results_delivered"] = rate(with_results_pageable, npush, lambda: collect(ctx.ticket()))
+        entry["pipelined_device_results_delivered"] = rate(with_results_device, npush, lambda: collect(ctx.ticket()))
         entry["pipelined_result_lag_blocks"] = lag
+        ctx.set_pipeline_group(1, False)
         ctx.set_pipelined(False)
         # ---- deferred: many blocks staged, one ordinary pass ----
         ctx.set_deferred(True)
@@ -600,8 +654,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
         tr = pmc_traffic(3, B, nvfo, "tick")  # pipelined mode, device-resident blocks (committed PMC passes of exactly this workload, or null)
         entry["pipelined_tick_traffic_bytes_per_block"] = tr
         entry["pipelined_tick_traffic_over_algorithmic"] = round(tr / _pb, 2) if tr else None
-        for p in ptrs:
-            ctx.L.sdrpp_host_free(p)
+        ctx.L.sdrpp_host_free(pin_base)
         ctx.close()
         res["B=%d" % B] = entry
     # through the C++ host mirror (source thread -> dsp::stream -> IQFrontEnd::run -> one sink thread per VFO), reference block size
@@ -626,9 +679,10 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N):
                 res["cpp_iqfrontend_run_%s" % name] = entry
     except Exception as e:
         res["cpp_iqfrontend_run"] = {"error": repr(e)[:300]}
-    res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push (ordinary pass); pipelined_* = sdrpp_set_pipelined, one launch per "
-                   "block: *_no_read leave the outputs on the device, *_results_delivered fetch the block from host memory AND deliver every VFO block + zoomed lines + palette indices into page-locked result slots "
-                   "(sdrpp_result_wait / _release `pipelined_result_lag_blocks` blocks behind the push; no deferral, no batching); deferred_read = sdrpp_set_deferred: pushes staged, one ordinary pass + one read per "
+    res["note"] = ("Msamples/s; per_push_read = sdrpp_push (host pointer, H2D included) + sdrpp_vfo_read_many + sdrpp_fft_lines after EVERY push (ordinary pass); pipelined_* = sdrpp_set_pipelined + "
+                   "sdrpp_set_pipeline_group(blocks_per_launch_max, adaptive): consecutive blocks share a launch while the device has two launches in flight (`*_one_block_per_launch`: the mode of rounds 3-5); "
+                   "*_no_read leave the outputs on the device, *_results_delivered deliver EVERY VFO's block + zoomed lines + palette indices of every push into page-locked result slots (pinned / pageable: the "
+                   "block is also fetched from host memory; device: resident in HBM), collected with sdrpp_result_wait / _release `pipelined_result_lag_blocks` blocks behind the push; deferred_read = sdrpp_set_deferred: pushes staged, one ordinary pass + one read per "
                    "`deferred_pushes_per_pass` pushes; cpp_iqfrontend_run = tests/host_cpp/bench_blocks.cpp (SpeedTester-style source thread, one sink thread per VFO) through sdrpp_gpu::IQFrontEnd: bypass_pipelined = "
                    "one block per launch, results handed to the streams a few blocks late; bypass_per_block = one ordinary pass per block; buffered = 32-slot frame buffer worked off as deferred passes.  "
                    "The C++ legs are built against the TEST DOUBLES of dsp/stream.h and dsp/block.h (tests/host_cpp/standalone: the GPU box has no reference tree) — same protocol and locking as the reference's "
@@ -781,6 +835,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--push", type=int, default=STREAM_CAP, help="complex samples per step = per block handed to the hot path (default: the dsp::stream cap, 10^6)")
     ap.add_argument("--mode", choices=("pipelined", "ordinary"), default="pipelined", help="pipelined: one launch per block (sdrpp_set_pipelined); ordinary: one launch per stage")
+    ap.add_argument("--group", type=int, default=4, help="pipelined mode: blocks one launch may carry (sdrpp_set_pipeline_group; 1 = one launch per block, as in rounds 3-5)")
+    ap.add_argument("--group-fixed", action="store_true", help="always wait for --group blocks (default: adaptive — a push goes out at once while the device has fewer than two launches in flight)")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; value = their median (SURVEY.md 8d)")
     ap.add_argument("--ref-block", type=int, default=-1, help="reference block inside a push (default sr/200, what the file source cuts; 0: the push is one block)")
     ap.add_argument("--nvfo", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -855,7 +912,7 @@ def main():
         push = max(1, push // N) * N  # whole frames per step (the ordinary protocol copies a fixed number of lines)
     ref_block = None if args.ref_block < 0 else args.ref_block
     head, inputs = run_workload(torch, np, device, local, cfg, push, mode, args.steps, args.warmup, nvfo, world=world, rank=rank, af=args.af, ref_block=ref_block, exact_ssb=args.nco == "ssb-exact",
-                                check=not args.no_self_check)
+                                check=not args.no_self_check, group=args.group, adaptive=not args.group_fixed, regions=args.regions)
     per_rank = None
     if dist is not None:  # every rank's own rate (its K blocks over its own wall time, before it waits for the slowest rank)
         mine = {"rank": rank, "device": "cuda:%d" % local, "local_s": head["rank_local_s"]}
@@ -868,7 +925,10 @@ def main():
     out = {
         "metric": METRIC[cfg], "value": head["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": head["workload"], "samples_per_step_per_gpu": push, "mode": head["mode"] + (" (sdrpp_set_pipelined: one launch per block, results %d blocks late)" % head.get("result_lag_blocks", 0) if mode == "pipelined" else ""),
+        "config": {"workload": head["workload"], "samples_per_step_per_gpu": push,
+                   "mode": head["mode"] + ((" (sdrpp_set_pipelined + sdrpp_set_pipeline_group: up to %d consecutive blocks per launch%s, every block with its own ticket and results, collected %d blocks behind the push)"
+                                            % (args.group, "" if args.group_fixed else ", fewer while the device would run dry", head.get("result_lag_blocks", 0))) if (mode == "pipelined" and args.group > 1) else
+                                           (" (sdrpp_set_pipelined: one launch per block, results %d blocks late)" % head.get("result_lag_blocks", 0) if mode == "pipelined" else "")),
                    "reference_block": head["reference_block"], "streams": world, "parallelism": "one independent IQ stream per GPU" + ("; RCCL gather of zoomed waterfall lines to rank 0" if world > 1 else ""),
                    "input_blocks_rotated": head["input_blocks_rotated"], "input_bytes_rotated": head["input_bytes_rotated"], "af_chain": head["af_chain"], "device": head["device"],
                    "results_delivered": head.get("results_delivered"), "nco": head["nco"]},
@@ -882,7 +942,7 @@ def main():
         out["rccl"] = rccl
     if per_rank:
         out["per_rank"] = [{"rank": r["rank"], "device": r["device"], "Msamples_per_s": round(push * args.steps / r["local_s"] / 1e6, 1) if r.get("local_s") else None} for r in per_rank]
-    for k in ("pipeline", "self_check", "steady_state"):
+    for k in ("pipeline", "blocks_per_launch", "timed_regions", "self_check", "steady_state"):
         if head.get(k) is not None:
             out[k] = head[k]
     del inputs
@@ -903,7 +963,7 @@ def main():
             try:
                 ocN = workloads.CFG[oc]["fft"]
                 ocv = 0 if oc == 2 else 128
-                r1, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 200, 14, ocv)  # (200 steps: fill and drain of a 5 .. 12 level pipeline are 3-6 % of the region, not 10-20 %)
+                r1, inp = run_workload(torch, np, device, local, oc, STREAM_CAP, "pipelined", 200, 14, ocv, group=args.group, adaptive=not args.group_fixed)  # (200 steps: fill and drain of a 5 .. 12 level pipeline are 3-6 % of the region, not 10-20 %)
                 del inp
                 torch.cuda.empty_cache()
                 r2, inp = run_workload(torch, np, device, local, oc, max(1, (1 << 24) // ocN) * ocN, "ordinary", 5, 2, ocv, ref_block=0)
@@ -911,7 +971,7 @@ def main():
                 torch.cuda.empty_cache()
                 others["cfg%d" % oc] = {"workload": r1["workload"], "pipelined_stream_cap": compact(r1), "ceiling_2p24_ordinary": compact(r2)}
                 if oc == 2 and cfg == 3:  # the headline workload with the radio module's AF chain behind every VFO (radio_module.h:98-110: the AF resampler is always on)
-                    ra, inp = run_workload(torch, np, device, local, 3, STREAM_CAP, "pipelined", 200, 14, nvfo, af=True)
+                    ra, inp = run_workload(torch, np, device, local, 3, STREAM_CAP, "pipelined", 200, 14, nvfo, af=True, group=args.group, adaptive=not args.group_fixed)
                     del inp
                     torch.cuda.empty_cache()
                     others["cfg3_af"] = {"workload": ra["workload"] + " + AF chain (resampler to 48 kHz, 50 us de-emphasis) on every VFO", "pipelined_stream_cap": compact(ra),
@@ -934,7 +994,7 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
     if world == 1 and base == 3 and not args.no_by_push:
         try:
-            out["by_push"] = by_push_report(torch, capi, workloads, sr, nvfo, N)
+            out["by_push"] = by_push_report(torch, capi, workloads, sr, nvfo, N, group=args.group)
         except Exception as e:
             out["by_push"] = {"error": repr(e)[:400]}
     try:  # C stdio of anything loaded into this process goes out BEFORE the JSON line, which must be the last line on stdout

@@ -364,7 +364,8 @@ int64_t sdrpp_pending(sdrpp_ctx* ctx);   /* samples staged and not yet processed
  * without any copy call: 1 = every VFO's output block (the end of its chain: the AF chain's output where one is attached, else what
  * sdrpp_vfo_read returns), 2 = zoomed lines + palette indices, 4 = raw dB lines, 8 = the pre-processed IQ stream of the block (only with a
  * pre-processing chain configured: without one it is the input block itself).
- * At most SDRPP_RESULT_SLOTS (24) blocks' results exist at a time: release them (a block whose slot is still held 24 pushes later fails the push).
+ * At most SDRPP_RESULT_SLOTS (24) launches' results exist at a time (one block per launch unless sdrpp_set_pipeline_group says otherwise): release
+ * them (a block whose slot is still held 24 launches later fails the push).
  * HOW FAR BEHIND TO ASK: a streaming host takes block t - lag when it has pushed block t.  With lag >= depth + 1 (sdrpp_pipeline_stats
  * out[4]: 6-7 levels for a radio bank + FFT, 10 for cfg 4's NFM / AM / SSB chains, 12 with AF chains, + the levels of a pre-processing chain)
  * sdrpp_result_wait finds the block complete.  With a smaller lag it must run the queued stages and WAIT for the device at every call: host
@@ -382,6 +383,7 @@ int sdrpp_push_staged(sdrpp_ctx* ctx, int64_t count);
  * a word that does not reach 0 within 5 s fails the push.  sdrpp_gpu::IQFrontEnd's pipelined worker stages its blocks this way. */
 int sdrpp_push_staged_when(sdrpp_ctx* ctx, int64_t count, const volatile uint32_t* pending);
 #define SDRPP_RESULT_SLOTS 24
+#define SDRPP_GROUP_MAX 8
 typedef struct sdrpp_result {
     uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
     int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */
@@ -397,6 +399,29 @@ typedef struct sdrpp_result {
     const float* iq;          /* [n_iq] complex: what streams bound with bindIQStream receive (iq_frontend.cpp:32-39 -> Splitter)    */
 } sdrpp_result;
 int sdrpp_set_pipelined(sdrpp_ctx* ctx, int on, int result_flags);
+/* SEVERAL BLOCKS PER LAUNCH.  A launch costs the device a start ramp, a tail and the gap to the next one whatever the block holds, and the host one
+ * plan: at the reference's block size (sample_rate / 200) that is most of a block's time, and a host that pushes faster than the device works
+ * only makes the launch queue longer.  With max_blocks > 1 a push is HELD — nothing planned, nothing launched — until max_blocks pushes have come
+ * together (or the next push cannot join: another kind of push, device / page-locked memory that does not continue where the last block ended,
+ * more than max_push samples in all; or any call that observes results or changes the configuration, sdrpp_pipeline_flush, sdrpp_result_wait
+ * for one of them).  The group then goes out as ONE launch: its blocks are planned as one block of the stream whose reference-block ends
+ * (sdrpp_set_reference_block: AGC look-ahead, rotator calls) are the ends of the pushes — exactly what a deferred pass does with its staged
+ * pushes — so every sample of every output is the one block-by-block processing gives (bit-identical: tests/test_pipelined.py::
+ * test_grouped_launches_equal_block_by_block), and EVERY PUSH KEEPS ITS OWN TICKET AND RESULTS: sdrpp_result_wait(ticket) hands out that push's
+ * share of every VFO's output block and the lines its samples completed (views into the group's result slot; SDRPP_RESULT_SLOTS now counts launch
+ * groups, of up to SDRPP_GROUP_MAX blocks each).  Host pushes of a group land back to back in ONE page-locked staging slot and are fetched by
+ * one landing copy; device / page-locked blocks must be contiguous to share a launch (a ring of blocks in one allocation is; the wrap-around
+ * starts a new group).  The sum of a group's blocks is limited by max_push (sdrpp_create): size it for max_blocks blocks.
+ * adaptive = 1: a push also goes out at once — with whatever is held — when the device has fewer than two launches in flight, i.e. the group size
+ * follows what is queued: 1 while the host is the slower side (no added latency), max_blocks when the device is.  adaptive = 0: always wait for
+ * max_blocks (deterministic: tests, benchmarks).  What it costs: a held block waits for its group, and a block's results are complete `depth`
+ * LAUNCHES after its group went out — a streaming host asks (depth + 1) * max_blocks blocks behind (sdrpp_pipeline_stats out[4] is still the
+ * depth in launches).  max_blocks = 1 (default): one launch per push, as before.  Groups do not form behind a pre-processing chain
+ * (sdrpp_preproc_configure) or while a block cannot run as a launch of the pipeline at all: such pushes go out one by one. */
+int sdrpp_set_pipeline_group(sdrpp_ctx* ctx, int max_blocks, int adaptive);
+/* out[0] launch groups so far (single blocks included), [1] groups of more than one block, [2] the blocks in those, [3] the largest group,
+ * [4] pushes held right now.  Returns the number of entries written. */
+int sdrpp_pipeline_group_stats(sdrpp_ctx* ctx, int64_t* out, int max);
 uint64_t sdrpp_ticket(sdrpp_ctx* ctx);                       /* ticket of the most recent push (pushes so far in pipelined mode)    */
 int sdrpp_pipeline_flush(sdrpp_ctx* ctx);                    /* launch what is queued, no new input; does not wait                  */
 int sdrpp_result_ready(sdrpp_ctx* ctx, uint64_t ticket);     /* 1 / 0 without blocking or flushing; SDRPP_ERR_NOT_FOUND: no slot    */

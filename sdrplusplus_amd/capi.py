@@ -99,7 +99,8 @@ class Result(C.Structure):
 
 
 ABI_VERSION = 2    # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
-RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: blocks whose pipelined results can exist at a time
+RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: launches (one block each, or a group of up to GROUP_MAX: sdrpp_set_pipeline_group) whose pipelined results can exist at a time
+GROUP_MAX = 8      # SDRPP_GROUP_MAX
 
 
 class SdrppError(RuntimeError):
@@ -214,6 +215,8 @@ def load():
     L.sdrpp_push_device.argtypes = [vp, vp, C.c_int64]
     L.sdrpp_push_int16.argtypes = [vp, C.POINTER(C.c_int16), C.c_int64]
     L.sdrpp_set_pipelined.argtypes = [vp, C.c_int, C.c_int]
+    L.sdrpp_set_pipeline_group.argtypes = [vp, C.c_int, C.c_int]
+    L.sdrpp_pipeline_group_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     L.sdrpp_ticket.restype = C.c_uint64
     L.sdrpp_ticket.argtypes = [vp]
     L.sdrpp_pipeline_flush.argtypes = [vp]
@@ -246,7 +249,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_copy", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
-    "sdrpp_set_pipelined", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
+    "sdrpp_set_pipelined", "sdrpp_set_pipeline_group", "sdrpp_pipeline_group_stats", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
 
@@ -578,6 +581,16 @@ class Context:
         """result_flags: 1 = every VFO's output block (AF output where a chain is attached), 2 = zoomed lines + palette indices, 4 = raw dB lines,
         8 = the pre-processed IQ stream (with a pre-processing chain) into page-locked result slots."""
         self._chk(self.L.sdrpp_set_pipelined(self.h, int(bool(on)), int(result_flags)))
+
+    def set_pipeline_group(self, max_blocks, adaptive=False):
+        """sdrpp_set_pipeline_group: up to `max_blocks` pushes per launch (every push keeps its own ticket and results); adaptive: the group follows
+        what is queued on the device (1 while the host is the slower side)."""
+        self._chk(self.L.sdrpp_set_pipeline_group(self.h, int(max_blocks), int(bool(adaptive))))
+
+    def pipeline_group_stats(self):
+        buf = (C.c_int64 * 8)()
+        self._chk(self.L.sdrpp_pipeline_group_stats(self.h, buf, 8))
+        return dict(groups=int(buf[0]), multi_groups=int(buf[1]), multi_blocks=int(buf[2]), largest=int(buf[3]), held=int(buf[4]))
 
     def ticket(self):
         return int(self.L.sdrpp_ticket(self.h))

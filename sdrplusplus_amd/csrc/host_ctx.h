@@ -8,7 +8,9 @@ constexpr int kArenaSlots = 24;     // >= kTickDepth + 2: a block's job tables a
 constexpr size_t kArenaBytes = 4u << 20;
 constexpr int kRing = 4;            // pipelined mode: buffers per per-block stream (a consumer runs at most 2 ticks behind its producer; + the gather)
 constexpr int kTickDepth = 18;      // pipelined mode: levels 0 .. kTickDepth of a block (see the level table at emit()): pre-processing chain 3 + VFO chain 5 + AF chain 5 + result copy
-constexpr int kResSlots = SDRPP_RESULT_SLOTS;       // pipelined mode: page-locked result slots (blocks whose results the host has not released yet)
+constexpr int kResSlots = SDRPP_RESULT_SLOTS;       // pipelined mode: page-locked result slots, one per LAUNCH GROUP (sdrpp_set_pipeline_group: 1 .. kGroupMax blocks) whose results the host has not released yet
+constexpr int kGroupMax = SDRPP_GROUP_MAX;          // pipelined mode: blocks one launch may carry
+constexpr int kResMeta = kResSlots * kGroupMax;     // ... and what the host knows about every block of those groups (ring by ticket)
 constexpr int kStageSlots = 4;      // pipelined mode: page-locked staging buffers for pushes from pageable host memory
 constexpr int kChanHistCap = 4095;  // channel filter may be re-designed up to 4096 taps without reallocating (rx_vfo.h:60-70)
 constexpr size_t kScratchBytes = 64u << 20;
@@ -81,6 +83,7 @@ struct Vfo {
     std::vector<Stream> st;
     int i_first = 0, i_poly = -1, i_chan = -1, i_dem = -1, i_out = -1, i_if = 0;
     int lvl_if = 1, lvl_out = 1, lvl_af = 1;  // levels (do_vfos_plan) at which the IF stream / the demodulator's output / the AF chain's output of the most recent block are written
+    std::vector<int> tk_if, tk_af;  // a launch group of several pushes: cumulative sample counts of the IF / demodulator stream and of the AF chain's output at every push end
     ToepTab tp_stage[SDRPP_MAX_DECIM_STAGES], tp_poly, tp_chan, tp_audio;
     // front end as one filter (what the fused translate + filter kernels evaluate): stages 0 (+ 1) of the plan
     bool fused_front = false;      // stages 0 and 1 run as one composite filter (front2_t2 > 0)
@@ -255,10 +258,13 @@ struct sdrpp_ctx {
     // ---- pipelined ("tick") execution: one launch per block, the stages of consecutive blocks skewed over consecutive launches
     //      (tick_kernels.h; sdrpp_set_pipelined) ----
     struct RoleLaunch { TickEntry e; size_t lds; int level; int fam; bool to_host; };  // to_host: a copy into a page-locked result slot
-    struct Result {                       // what the host knows about the block in a result slot
-        uint64_t ticket = 0;              // 0: slot free
+    struct Result {                       // what the host knows about one block's results (ring by ticket); the bytes live in its group's slot
+        uint64_t ticket = 0;              // 0: entry free
         uint64_t done_tick = 0;           // its last level has run when this many ticks have completed
         bool held = false;                // handed out by sdrpp_result_wait, not yet released
+        int buf = 0;                      // result slot of its launch group
+        uint64_t group = 0;               // the group (res_group[buf] == group while the slot still holds its bytes)
+        const char* base = nullptr;       // host address of that slot's buffer when the results were planned (a held block keeps it across tick_results_ensure)
         std::vector<int> ids, counts;
         std::vector<int64_t> offsets;
         int n_lines = 0;
@@ -308,7 +314,7 @@ struct sdrpp_ctx {
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
     int test_fail_alloc = 0;
     bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
-    const volatile uint32_t* stage_pending = nullptr;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for this word to reach 0
+    std::vector<const volatile uint32_t*> stage_pend;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for these words to reach 0
     bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three
     // wavefronts that apply the phases take ~100 cycles per VFO and chunk: beyond ~16 VFOs they, not the chain, set the pace of the workgroup
@@ -350,7 +356,24 @@ struct sdrpp_ctx {
     size_t res_cap = 0;                   // bytes per slot
     size_t res_cap_slot[kResSlots] = {};  // ... of each slot's current buffer (they grow one by one, tick_results_ensure)
     std::vector<char*> res_retired[kResSlots];  // smaller buffers of slots that were HELD when the slots grew: the host's pointers into them stay valid until it releases
-    Result res[kResSlots];
+    uint64_t res_group[kResSlots] = {};   // the launch group whose results the slot holds (0: none)
+    int res_held[kResSlots] = {};         // blocks of that group handed out by sdrpp_result_wait and not yet released
+    Result res[kResMeta];
+    // ---- several blocks per launch (sdrpp_set_pipeline_group): pushes are HELD — nothing planned, nothing launched — until the group goes out as ONE
+    //      block of the tick queue whose reference-block ends are the push ends (what a deferred pass does with its staged pushes, plan_push.h) ----
+    int group_max = 1;                    // blocks per launch, at most
+    int group_adaptive = 0;               // 1: a group goes out as soon as the device has fewer than two launches in flight (a host slower than the device: one block per launch)
+    struct Held {
+        int kind = -1;                    // -1: nothing held; 0: device memory read in place; 1 / 2: float / int16 samples in a page-locked staging slot; 3: the caller's page-locked memory
+        const char* base = nullptr;       // kind 0 / 3: address of the first block (the following ones are contiguous with it)
+        int stage_slot = -1;              // kind 1 / 2
+        int64_t total = 0;                // samples held
+        std::vector<int> ends;            // cumulative end of every held push
+    } held;
+    std::vector<int> grp_ends;            // push ends of the group being planned (empty / one entry: a single block)
+    int64_t plan_fft_pos0 = 0, plan_fft_next0 = 0;  // frame position in front of the block being planned (do_fft): which push of a group completes which line
+    uint64_t groups = 0;                  // launch groups planned so far (a group's result slot: groups % kResSlots)
+    int64_t stat_groups = 0, stat_group_blocks = 0, stat_group_max = 0;  // groups of more than one block, the blocks in them, the largest
     // Completion of a tick whose roles wrote RESULTS into page-locked host memory, as the host may rely on it: an event recorded behind the
     // launch.  The flag the kernel itself publishes (h_tick_flag) says that every workgroup has finished and its stores are acknowledged — but
     // a result block is megabytes of posted writes over the bus from every XCD, and the four bytes of the flag were measured to overtake them by

@@ -316,6 +316,8 @@ int plan_wf_state(sdrpp_ctx* c, int nframes, int level) {
 int do_fft(sdrpp_ctx* c, const IqSrc& src, int64_t count) {
     c->n_lines = 0;
     if (!c->fft_on) { return SDRPP_OK; }
+    c->plan_fft_pos0 = c->fft_pos;
+    c->plan_fft_next0 = c->fft_next;
     const int64_t P = (int64_t)c->nz + c->skip;
     const int64_t end = c->fft_pos + count;
     int64_t nframes = 0;

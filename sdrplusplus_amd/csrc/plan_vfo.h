@@ -5,7 +5,8 @@
 namespace {
 
 // ---- VFO bank: one push ------------------------------------------------------------------------------------------------------------
-struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; unsigned long long taph; };
+struct S1Member { Vfo* v; int K, lgD, off0, nout; double phi0; int min_idx; int fused, K2, lgD2, off2, nout2; unsigned long long taph;
+                  int shift = 0, oshift = 0; };  // a push of a launch group: where its samples start in the group's block, where its outputs start in the group's output block
 
 // Cache key of a front-end job's tap operand: membership (VFO ids) and NCO increments, as two independent 64-bit hashes (the job
 // tables are rebuilt on every push: formatting 32 ids and doubles into a string cost more host time than the launch itself)
@@ -321,7 +322,16 @@ struct BankPlan {
         const bool need_bnd = agc_mode && (blocks || v.nco_exact);
         std::vector<int> bnd;
         if (need_bnd) { bnd = fb; }
+        // a launch group of several pushes (sdrpp_set_pipeline_group): the PUSH ends carried the same way, through every rate change down to the
+        // stream the results are read from — which samples of the group's output block belong to which push (tick_results_describe)
+        const bool split = c->grp_ends.size() > 1;
+        std::vector<int>& tk = v.tk_if;
+        tk.clear();
+        v.tk_af.clear();
+        if (split) { tk = c->grp_ends; }
         int first_sep = 0;  // first decimator stage that runs as its own FIR launch
+        double phi_end = 0.0;
+        bool have_phi_end = false;  // (a launch group: the NCO phase after its last push, advanced push by push as block-by-block processing does)
         if (v.nco_exact) {
             // the reference's own data flow: rotate at the full rate (float recursion), then every stage of the plan as a plain FIR
             Stream* tgt = (v.d.n_stages == 0) ? cur : &v.st[(size_t)v.i_rot];
@@ -344,6 +354,7 @@ struct BankPlan {
             int need = K0 - 1;
             first_sep = 1;
             if (need_bnd) { bounds_decim(bnd, v.soff[0], D); }
+            if (split) { bounds_decim(tk, v.soff[0], D); }
             if (v.fused_front) {
                 const int D2 = v.d.stage_decim[1];
                 mem.fused = 1;
@@ -354,9 +365,45 @@ struct BankPlan {
                 need = K0 - 1 + D * (mem.K2 - 1);
                 first_sep = 2;
                 if (need_bnd) { bounds_decim(bnd, v.soff[1], D2); }
+                if (split) { bounds_decim(tk, v.soff[1], D2); }
             }
             mem.min_idx = (v.seen >= need) ? -need : -(int)v.seen;  // older samples predate this VFO: zero
-            s1.push_back(mem);
+            if (!split) { s1.push_back(mem); }
+            else {
+                // A launch group: ONE front-end job per push, with the offsets, the NCO phase and the history bound block-by-block processing would
+                // have given that push (the closed-form NCO is anchored at the start of a job: tile phasor x in-tile table — one job over the whole
+                // group would round the same samples differently), reading its samples where they lie in the group's block and writing its outputs
+                // behind those of the pushes in front.  Everything behind the front end is a plain FIR over the stream, indifferent to the cuts.
+                int so0 = v.soff[0], so1 = v.soff[1], prev_e = 0, oshift = 0;
+                long long seen = v.seen;
+                double ph = v.phi;
+                for (size_t j = 0; j < c->grp_ends.size(); j++) {
+                    const int nj = c->grp_ends[j] - prev_e;
+                    S1Member m = mem;
+                    m.off0 = so0;
+                    m.nout = decim_nout(nj, so0, D);
+                    m.phi0 = ph;
+                    int outs = m.nout;
+                    if (mem.fused) {
+                        m.off2 = so1;
+                        m.nout2 = decim_nout(m.nout, so1, v.d.stage_decim[1]);
+                        outs = m.nout2;
+                    }
+                    m.min_idx = ((seen >= need) ? -need : -(int)seen) + prev_e;
+                    m.shift = prev_e;
+                    m.oshift = oshift;
+                    if (outs > 0) { s1.push_back(m); }
+                    so0 = so0 + m.nout * D - nj;
+                    if (mem.fused) { so1 = so1 + m.nout2 * v.d.stage_decim[1] - m.nout; }
+                    const double pj = ph + (double)nj * v.theta;
+                    ph = pj - std::floor(pj);
+                    seen += nj;
+                    oshift += outs;
+                    prev_e = c->grp_ends[j];
+                }
+                phi_end = ph;
+                have_phi_end = true;
+            }
             // setOffset hand-over: outputs whose window still reaches in front of the latest retune point are recomputed with the
             // piecewise phase (vfo_retune_fix_kernel); retune points no window can reach any more are forgotten
             {
@@ -447,6 +494,7 @@ struct BankPlan {
             const int Ds = v.d.stage_decim[s];
             const int no = decim_nout(cur->n, v.soff[s], Ds);
             if (need_bnd) { bounds_decim(bnd, v.soff[s], Ds); }
+            if (split) { bounds_decim(tk, v.soff[s], Ds); }
             lvl++;
             cur->clevel = lvl;
             if (piped_be && s == last_dec) {
@@ -466,6 +514,7 @@ struct BankPlan {
             Stream* nxt = &v.st[(size_t)v.i_poly];
             const int no = poly_nout(cur->n, v.poff, v.pphase, v.d.interp, v.d.decim);
             if (need_bnd) { bounds_poly(bnd, v.poff, v.pphase, v.d.interp, v.d.decim); }
+            if (split) { bounds_poly(tk, v.poff, v.pphase, v.d.interp, v.d.decim); }
             if (piped_be && tick_piped) { cur->clevel = lvl + 1; }  // (its tail is carried one level behind the role that writes it)
             else {
                 lvl++;
@@ -556,6 +605,16 @@ struct BankPlan {
             Stream& dem = v.st[(size_t)v.i_dem];
             Stream& out = v.st[(size_t)v.i_out];
             if (v.nco_exact) { ssbx_l.add(lvl + 1, SsbRotXJob{ (const float2*)cur->data, dem.data, v.d_rot + 1, v.d.ssb_phase_delta_re, v.d.ssb_phase_delta_im, d_bnd, nbnd }); }
+            else if (split) {  // a launch group: the second translation anchored push by push, like the first (its phase advances as block-by-block processing advances it)
+                int lo = 0;
+                for (size_t j = 0; j < tk.size(); j++) {
+                    const int nj = tk[j] - lo;
+                    if (nj > 0) { pre.add(lvl + 1, PreJob{ v.d.demod, nj, (const float2*)cur->data + lo, dem.data + (size_t)lo * (size_t)dem.width, v.theta2, v.phi2 }); }
+                    const double q2 = v.phi2 + (double)nj * v.theta2;
+                    v.phi2 = q2 - std::floor(q2);
+                    lo = tk[j];
+                }
+            }
             else { pre.add(lvl + 1, PreJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, v.theta2, v.phi2 }); }
             seq.add(lvl + 2, SeqJob{ v.d.demod, nif, (const float2*)cur->data, dem.data, out.data, agc, agc + 1, dc, 0.0f, 0, d_bnd, nbnd });
             lvl += 2;
@@ -563,16 +622,20 @@ struct BankPlan {
             out.n = nif;
             out.wlevel = lvl;
             v.lvl_out = lvl;
-            double p2 = v.phi2 + (double)nif * v.theta2;
-            v.phi2 = p2 - std::floor(p2);
+            if (!split || v.nco_exact) {
+                const double p2 = v.phi2 + (double)nif * v.theta2;
+                v.phi2 = p2 - std::floor(p2);
+            }
         }
         if (v.af.on && v.i_out >= 0) {  // radio AF chain on the demodulator's stereo output
             Vfo::Af& a = v.af;
             Stream* acur = &v.st[(size_t)v.i_out];
+            if (split) { v.tk_af = tk; }
             for (int s = 0; s < a.n_stages; s++) {
                 Stream* nxt = &v.st[(size_t)a.i_stage0 + s];
                 const int Ds = a.decim_s[s], K = (int)a.staps[s].size();
                 const int no = decim_nout(acur->n, a.soff[s], Ds);
+                if (split) { bounds_decim(v.tk_af, a.soff[s], Ds); }
                 lvl++;
                 acur->clevel = lvl;
                 if (a.tp_stage[s].ok) { t_af_dec.add(lvl, toep_job(a.tp_stage[s], 0, stream_in(*acur), nxt->data, a.soff[s] - (K - 1), no, 0.0f)); }
@@ -585,6 +648,7 @@ struct BankPlan {
             if (a.i_poly >= 0) {
                 Stream* nxt = &v.st[(size_t)a.i_poly];
                 const int no = poly_nout(acur->n, a.poff, a.pphase, a.interp, a.decim);
+                if (split) { bounds_poly(v.tk_af, a.poff, a.pphase, a.interp, a.decim); }
                 lvl++;
                 acur->clevel = lvl;
                 if (a.tp_poly.ok) { t_af_poly.add(lvl, toep_job(a.tp_poly, a.pphase, stream_in(*acur), nxt->data, a.poff - (a.tpp - 1), no, 0.0f)); }
@@ -622,8 +686,11 @@ struct BankPlan {
             a.i_last = (int)(acur - &v.st[0]);
             v.lvl_af = lvl;
         }
-        double p = v.phi + (double)n_in * v.theta;
-        v.phi = p - std::floor(p);
+        if (have_phi_end) { v.phi = phi_end; }
+        else {
+            const double p = v.phi + (double)n_in * v.theta;
+            v.phi = p - std::floor(p);
+        }
         v.seen += n_in;
         // history carries for every stream that has a consumer with memory
         const Stream* phantom = (v.fused_front && v.d.n_stages >= 2 && !v.nco_exact) ? &v.st[(size_t)v.i_first] : nullptr;  // stage-1 output of a fused front end: never written, never read
@@ -645,7 +712,7 @@ struct BankPlan {
     int group_front() {
         auto same = [](const S1Member& a, const S1Member& b) {
             return a.fused == b.fused && a.K == b.K && a.lgD == b.lgD && a.off0 == b.off0 && a.nout == b.nout && a.min_idx == b.min_idx && a.K2 == b.K2 &&
-                   a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2 && a.taph == b.taph;
+                   a.lgD2 == b.lgD2 && a.off2 == b.off2 && a.nout2 == b.nout2 && a.taph == b.taph && a.shift == b.shift && a.oshift == b.oshift;
         };
         std::sort(s1.begin(), s1.end(), [](const S1Member& a, const S1Member& b) {
             if (a.fused != b.fused) { return a.fused < b.fused; }
@@ -659,6 +726,8 @@ struct BankPlan {
             if (a.off2 != b.off2) { return a.off2 < b.off2; }
             if (a.nout2 != b.nout2) { return a.nout2 < b.nout2; }
             if (a.taph != b.taph) { return a.taph < b.taph; }
+            if (a.shift != b.shift) { return a.shift < b.shift; }
+            if (a.oshift != b.oshift) { return a.oshift < b.oshift; }
             return a.v->id < b.v->id;
         });
         if (ticking) {
@@ -745,16 +814,19 @@ struct BankPlan {
                 job.nv = vt;
                 job.ntaps = K;
                 job.log2_decim = lgD;
-                job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1);
+                job.off = h.off0 + (h.off2 - (h.K2 - 1)) * D1 - (h.K - 1) + h.shift;
                 job.nout = h.nout2;
                 job.min_idx = h.min_idx;
+                job.anchor = h.shift;
                 // (a long first stage with at most 16 VFOs runs in the 16 x 16 x 4 shape: 16 outputs per tile, vfo_frontcl_impl<PF, true>)
                 const int tile_n = (m_long && vt <= 16) ? 16 : SDRPP_FCM_TILE;
                 const int ntiles = (h.nout2 + tile_n - 1) / tile_n;
                 // one resident round: 256 CUs x 3 blocks x 4 wavefronts (a second, partly filled round would cost as much as the first);
                 // the long-stage kernel runs 2 wavefronts per block, its LDS footprint decides how many blocks fit
                 const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD, fcl_nw) * 4))) : 0;
-                const int resident = m_long ? 256 * long_blocks * fcl_nw : (c->tick_planning ? c->tick_fcm_waves : 3072);
+                // (a launch group brings one job per push: together they get the wavefronts one job of the whole block would)
+                const int nsub = std::max<int>(1, (int)c->grp_ends.size());
+                const int resident = std::max(64, (m_long ? 256 * long_blocks * fcl_nw : (c->tick_planning ? c->tick_fcm_waves : 3072)) / nsub);
                 job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
                 job.atab = reinterpret_cast<const float*>(d_taps);
                 job.ptab = d_taps + (size_t)NP4 * 32;
@@ -762,7 +834,7 @@ struct BankPlan {
                     Vfo* v = s1[g + std::min(m, vt - 1)].v;
                     job.theta[m] = v->theta;
                     job.phi0[m] = s1[g + std::min(m, vt - 1)].phi0;
-                    job.out[m] = (float2*)v->st[(size_t)v->i_first + (m_long ? 0 : 1)].data;
+                    job.out[m] = (float2*)v->st[(size_t)v->i_first + (m_long ? 0 : 1)].data + h.oshift;
                 }
                 if (m_long) {
                     fcl.jobs.push_back(job);
@@ -826,13 +898,14 @@ struct BankPlan {
                     job.nv = vt;
                     job.ntaps1 = h.K;
                     job.log2_decim1 = h.lgD;
-                    job.off1 = h.off0;
+                    job.off1 = h.off0 + h.shift;
                     job.ntaps2 = h.K2;
                     job.log2_decim2 = h.lgD2;
                     job.off2 = h.off2;
                     job.nout2 = h.nout2;
                     job.t2 = front2_t2(h.K, 1 << h.lgD, h.K2, 1 << h.lgD2, 8);
                     job.min_idx = h.min_idx;
+                    job.anchor = h.shift;
                     job.ctaps = d_taps;
                     job.ptab = d_taps + (size_t)((h.K + 1) / 2) * vt;
                     job.taps2 = h.v->d_staps_nat[1];
@@ -840,7 +913,7 @@ struct BankPlan {
                         Vfo* v = s1[g + m].v;
                         job.theta[m] = v->theta;
                         job.phi0[m] = s1[g + m].phi0;
-                        job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data;
+                        job.out[m] = (float2*)v->st[(size_t)v->i_first + 1].data + h.oshift;
                     }
                     f2l[li].jobs.push_back(job);
                     f2l[li].max_blocks = std::max(f2l[li].max_blocks, (job.nout2 + job.t2 - 1) / job.t2);
@@ -852,15 +925,16 @@ struct BankPlan {
                     job.nv = vt;
                     job.ntaps = h.K;
                     job.log2_decim = h.lgD;
-                    job.off0 = h.off0;
+                    job.off0 = h.off0 + h.shift;
                     job.nout = h.nout;
                     job.min_idx = h.min_idx;
+                    job.anchor = h.shift;
                     job.ctaps = d_taps;
                     for (int m = 0; m < vt; m++) {
                         Vfo* v = s1[g + m].v;
                         job.theta[m] = v->theta;
                         job.phi0[m] = s1[g + m].phi0;  // phase (turns) of push-relative sample 0
-                        job.out[m] = (float2*)v->st[(size_t)v->i_first].data;
+                        job.out[m] = (float2*)v->st[(size_t)v->i_first].data + h.oshift;
                     }
                     s1l[li].jobs.push_back(job);
                     s1l[li].max_nout = std::max(s1l[li].max_nout, job.nout);

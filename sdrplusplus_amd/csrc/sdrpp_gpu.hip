@@ -1495,6 +1495,10 @@ static int landing_process(sdrpp_ctx* c, int64_t count, const std::vector<int>* 
 }
 int flush_pending(sdrpp_ctx* c) { return flush_pending_opt(c, 1); }
 int flush_pending_opt(sdrpp_ctx* c, int drain) {
+    if (c->pipelined && c->held.kind >= 0) {  // pushes held for a launch group: the group goes out as it stands (what the host "knows" about the last push needs its plan)
+        int rc = tick_group_launch(c);
+        if (rc) { return rc; }
+    }
     if (drain && c->pipelined && !c->tickq.empty()) {  // pipelined mode: run what the last blocks still have queued
         int rc = tick_drain(c);
         if (rc) { return rc; }
@@ -1520,90 +1524,58 @@ static int push_args_ok(sdrpp_ctx* c, const void* p, int64_t count) {
     return SDRPP_OK;
 }
 
-// pipelined mode: a block from host memory.  `src_dev`: device address of page-locked memory the samples can be fetched from in place
-// (sdrpp_push_pinned_async); nullptr: `src_host` is copied into a page-locked staging slot first (the caller's buffer is free on return).
-// `bytes_per_sample`: 8 (complex float) or 4 (interleaved int16).
-static int tick_push_host(sdrpp_ctx* c, const void* src_host, const void* src_dev, int64_t count, int bytes_per_sample) {
-    const int li = (int)((c->pushes + 1) % 3);
-    if (!c->tick_land[li]) {
-        int rc = dev_alloc(c, &c->tick_land[li], (size_t)c->max_push * 2 + 32);
-        if (rc) { return rc; }
-    }
-    const size_t bytes = (size_t)count * (size_t)bytes_per_sample;
-    if (!src_dev) {
-        const int si = c->stage_cur;
-        c->stage_cur = (c->stage_cur + 1) % kStageSlots;
-        if (!c->stage_host[si]) {
-            if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer"); }
-        }
-        if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
-        memcpy(c->stage_host[si], src_host, bytes);
-        void* d = nullptr;
-        if (hipHostGetDevicePointer(&d, c->stage_host[si], 0) != hipSuccess || !d) { return fail(c, SDRPP_ERR_HIP, "hipHostGetDevicePointer(staging) failed"); }
-        src_dev = d;
-        const CopyJob land{ src_dev, c->tick_land[li], (long long)bytes, bytes_per_sample == 4 ? 1 : 0, 0 };
-        int rc = tick_push(c, c->tick_land[li], count, &land);
-        c->stage_tick[si] = c->ticks;
-        return rc;
-    }
-    const CopyJob land{ src_dev, c->tick_land[li], (long long)bytes, bytes_per_sample == 4 ? 1 : 0, 0 };
-    return tick_push(c, c->tick_land[li], count, &land);
-}
-
-// The staging slot of the next block handed to the HOST to fill (pipelined mode): what tick_push_host's memcpy does, in the caller's hands
+// The staging slot of the next block handed to the HOST to fill (pipelined mode): what tick_hold's memcpy does, in the caller's hands.  With
+// several blocks per launch (sdrpp_set_pipeline_group) the slot is the launch group's: the block lands behind the ones already held.
 int sdrpp_push_stage(sdrpp_ctx* c, int64_t count, float** slot) {
     DeviceScope dev_scope_(c);
     if (!c || !slot) { return SDRPP_ERR_INVALID; }
     if (!c->pipelined) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_stage: the context is not in pipelined mode"); }
     if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_stage: count %lld out of range (max_push %lld)", (long long)count, (long long)c->max_push); }
-    const int si = c->stage_cur;
-    if (!c->stage_host[si]) {
-        if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer"); }
+    sdrpp_ctx::Held& H = c->held;
+    if (H.kind >= 0 && !H.ends.empty()) {
+        const bool fits = H.kind == 1 && (int)H.ends.size() < c->group_max && H.total + count <= c->max_push && group_eligible(c);
+        if (!fits) {
+            int rc = tick_group_launch(c);
+            if (rc) { return rc; }
+        }
     }
-    if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
-    c->stage_open = si;
-    *slot = reinterpret_cast<float*>(c->stage_host[si]);
+    if (H.kind != 1) {  // open a group with a fresh slot
+        H = sdrpp_ctx::Held{};
+        const int si = c->stage_cur;
+        if (!c->stage_host[si]) {
+            if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) { return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer"); }
+        }
+        c->stage_cur = (c->stage_cur + 1) % kStageSlots;
+        if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
+        H.kind = 1;
+        H.stage_slot = si;
+    }
+    c->stage_open = H.stage_slot;
+    *slot = reinterpret_cast<float*>(c->stage_host[H.stage_slot]) + (size_t)2 * (size_t)H.total;
     return SDRPP_OK;
 }
-static int push_staged_impl(sdrpp_ctx* c, int64_t count);
+static int push_staged_impl(sdrpp_ctx* c, int64_t count, const volatile uint32_t* pending) {
+    if (!c->pipelined || c->stage_open < 0 || c->held.kind != 1 || c->held.stage_slot != c->stage_open) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged without an open staging slot (sdrpp_push_stage)"); }
+    if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged: count out of range"); }
+    c->stage_open = -1;
+    return tick_hold(c, 1, nullptr, count, pending);
+}
 int sdrpp_push_staged(sdrpp_ctx* c, int64_t count) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    c->stage_pending = nullptr;
-    return push_staged_impl(c, count);
+    return push_staged_impl(c, count, nullptr);
 }
 int sdrpp_push_staged_when(sdrpp_ctx* c, int64_t count, const volatile uint32_t* pending) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    c->stage_pending = pending;
-    const int rc = push_staged_impl(c, count);
-    c->stage_pending = nullptr;  // (a failed plan returns without having waited: the caller joins its own threads)
-    return rc;
-}
-static int push_staged_impl(sdrpp_ctx* c, int64_t count) {
-    if (!c->pipelined || c->stage_open < 0 || c->stage_open != c->stage_cur) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged without an open staging slot (sdrpp_push_stage)"); }
-    if (count <= 0 || count > c->max_push) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged: count out of range"); }
-    const int si = c->stage_open;
-    c->stage_open = -1;
-    c->stage_cur = (c->stage_cur + 1) % kStageSlots;
-    const int li = (int)((c->pushes + 1) % 3);
-    if (!c->tick_land[li]) {
-        int rc = dev_alloc(c, &c->tick_land[li], (size_t)c->max_push * 2 + 32);
-        if (rc) { return rc; }
-    }
-    void* d = nullptr;
-    if (hipHostGetDevicePointer(&d, c->stage_host[si], 0) != hipSuccess || !d) { return fail(c, SDRPP_ERR_HIP, "hipHostGetDevicePointer(staging) failed"); }
-    const CopyJob land{ d, c->tick_land[li], (long long)((size_t)count * 8), 0, 0 };
-    int rc = tick_push(c, c->tick_land[li], count, &land);
-    c->stage_tick[si] = c->ticks;
-    return rc;
+    return push_staged_impl(c, count, pending);  // (a failed plan returns without having waited: the caller joins its own threads)
 }
 
 int sdrpp_push(sdrpp_ctx* c, const float* iq_host, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
-    if (c->pipelined) { return count == 0 ? SDRPP_OK : tick_push_host(c, iq_host, nullptr, count, 8); }
+    if (c->pipelined) { return tick_hold(c, 1, iq_host, count, nullptr); }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
     rc = landing_acquire(c, false);
     if (rc) { return rc; }
@@ -1646,9 +1618,9 @@ int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count)
         if (count == 0) { return SDRPP_OK; }
         if (hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
             (void)hipGetLastError();
-            return tick_push_host(c, iq_pinned, nullptr, count, 8);
+            return tick_hold(c, 1, iq_pinned, count, nullptr);
         }
-        return tick_push_host(c, iq_pinned, dptr, count, 8);
+        return tick_hold(c, 3, iq_pinned, count, nullptr);
     }
     if (!c->deferred || count <= 0 || !iq_pinned || hipHostGetDevicePointer(&dptr, (void*)iq_pinned, 0) != hipSuccess || !dptr) {
         (void)hipGetLastError();
@@ -1671,8 +1643,10 @@ int sdrpp_push_pinned_async(sdrpp_ctx* c, const float* iq_pinned, int64_t count)
 int sdrpp_push_wait(sdrpp_ctx* c) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    if (c->pipelined && c->land_tick) {  // every landing copy so far has run once its tick is complete
-        tick_wait_done(c, c->land_tick);
+    if (c->pipelined) {  // every landing copy so far has run once its tick is complete (what is still held goes out first)
+        int rc = tick_group_launch(c);
+        if (rc) { return rc; }
+        if (c->land_tick) { tick_wait_done(c, c->land_tick); }
         return SDRPP_OK;
     }
     // (not `async_staged`: a flushing call that does not host-synchronise — sdrpp_fft_lines, sdrpp_vfo_out_count, a setter — clears that
@@ -1688,7 +1662,7 @@ int sdrpp_push_device(sdrpp_ctx* c, const float* iq_dev, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_dev, count);
     if (rc) { return rc; }
-    if (c->pipelined) { return tick_push(c, iq_dev, count, nullptr); }  // read in place, one tick from now at the earliest
+    if (c->pipelined) { return tick_hold(c, 0, iq_dev, count, nullptr); }  // read in place, one tick from now at the earliest
     if (!c->deferred) { return push_common(c, iq_dev, count); }  // read in place
     if (count == 0) { return SDRPP_OK; }
     rc = landing_acquire(c, false);
@@ -1703,7 +1677,7 @@ int sdrpp_push_int16(sdrpp_ctx* c, const int16_t* iq_host, int64_t count) {
     DeviceScope dev_scope_(c);
     int rc = push_args_ok(c, iq_host, count);
     if (rc) { return rc; }
-    if (c->pipelined) { return count == 0 ? SDRPP_OK : tick_push_host(c, iq_host, nullptr, count, 4); }
+    if (c->pipelined) { return tick_hold(c, 2, iq_host, count, nullptr); }
     if (count == 0) { return c->deferred ? SDRPP_OK : push_common(c, nullptr, 0); }
     rc = landing_acquire(c, true);
     if (rc) { return rc; }
@@ -1774,25 +1748,51 @@ int sdrpp_set_pipelined(sdrpp_ctx* c, int on, int result_flags) {
     if (on && c->deferred) { return fail(c, SDRPP_ERR_INVALID, "deferred and pipelined processing exclude each other"); }
     int rc = flush_pending(c);  // (drains the queue when the mode is being left)
     if (rc) { return rc; }
-    for (int i = 0; i < kResSlots; i++) {
-        if (c->res[i].held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held", (unsigned long long)c->res[i].ticket); }
+    for (auto& R : c->res) {
+        if (R.held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held", (unsigned long long)R.ticket); }
     }
+    c->held = sdrpp_ctx::Held{};
+    c->stage_open = -1;
     c->pipelined = on != 0;
     c->res_flags = on ? result_flags : 0;
     return SDRPP_OK;
+}
+int sdrpp_set_pipeline_group(sdrpp_ctx* c, int max_blocks, int adaptive) {
+    DeviceScope dev_scope_(c);
+    if (!c || max_blocks < 1 || max_blocks > kGroupMax) { return c ? fail(c, SDRPP_ERR_INVALID, "sdrpp_set_pipeline_group: 1 .. %d blocks per launch", kGroupMax) : SDRPP_ERR_INVALID; }
+    if (c->pipelined) {
+        int rc = tick_group_launch(c);  // what is held goes out under the old rule
+        if (rc) { return rc; }
+    }
+    c->group_max = max_blocks;
+    c->group_adaptive = adaptive != 0;
+    return SDRPP_OK;
+}
+int sdrpp_pipeline_group_stats(sdrpp_ctx* c, int64_t* out, int max) {
+    if (!c || !out || max < 0) { return SDRPP_ERR_INVALID; }
+    const int64_t v[5] = { (int64_t)c->groups, c->stat_groups, c->stat_group_blocks, c->stat_group_max, (int64_t)c->held.ends.size() };
+    int n = 0;
+    for (; n < 5 && n < max; n++) { out[n] = v[n]; }
+    return n;
 }
 uint64_t sdrpp_ticket(sdrpp_ctx* c) { return c ? c->pushes : 0; }
 int sdrpp_pipeline_flush(sdrpp_ctx* c) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
-    return c->pipelined ? tick_drain(c) : SDRPP_OK;
+    if (!c->pipelined) { return SDRPP_OK; }
+    int rc = tick_group_launch(c);
+    return rc ? rc : tick_drain(c);
+}
+static bool ticket_is_held_back(const sdrpp_ctx* c, uint64_t ticket) {  // pushed, but its launch group has not gone out yet
+    return c->held.kind >= 0 && !c->held.ends.empty() && ticket <= c->pushes && ticket + c->held.ends.size() > c->pushes;
 }
 static sdrpp_ctx::Result* result_of(sdrpp_ctx* c, uint64_t ticket) {
     if (!c || ticket == 0 || ticket > c->pushes) { return nullptr; }
-    sdrpp_ctx::Result& R = c->res[ticket % kResSlots];
-    return R.ticket == ticket ? &R : nullptr;
+    sdrpp_ctx::Result& R = c->res[ticket % kResMeta];
+    return (R.ticket == ticket && c->res_group[R.buf] == R.group) ? &R : nullptr;  // (the second half: its group's slot has not gone to a later group)
 }
 int sdrpp_result_ready(sdrpp_ctx* c, uint64_t ticket) {
+    if (c && ticket_is_held_back(c, ticket)) { return 0; }
     sdrpp_ctx::Result* R = result_of(c, ticket);
     if (!R) { return c ? fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (not gathered, overwritten, or processed as an ordinary pass)", (unsigned long long)ticket) : SDRPP_ERR_INVALID; }
     if (R->done_tick > c->ticks) { return 0; }
@@ -1802,10 +1802,16 @@ int sdrpp_result_ready(sdrpp_ctx* c, uint64_t ticket) {
 int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     DeviceScope dev_scope_(c);
     if (!c || !out) { return SDRPP_ERR_INVALID; }
+    if (ticket_is_held_back(c, ticket)) {  // nothing more is coming for its group: it goes out as it stands
+        int rc = tick_group_launch(c);
+        if (rc) { return rc; }
+    }
     sdrpp_ctx::Result* R = result_of(c, ticket);
     if (!R) { return fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (not gathered, overwritten, or processed as an ordinary pass)", (unsigned long long)ticket); }
     while (R->done_tick > c->ticks) {  // its last levels have not been launched yet: nothing more is coming, run them without new input
-        int rc = arena_begin(c);
+        int rc = tick_group_launch(c);  // (younger pushes held for a group ride along: their first level shares the launch)
+        if (!rc && R->done_tick <= c->ticks) { break; }
+        if (!rc) { rc = arena_begin(c); }
         if (!rc) { rc = tick_launch(c, nullptr); }
         if (rc) { return rc; }
         if (c->tickq.empty() && R->done_tick > c->ticks) { return fail(c, SDRPP_ERR_HIP, "internal: block %llu cannot complete", (unsigned long long)ticket); }
@@ -1815,8 +1821,12 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
         if (vis < 0) { return vis; }
     }
     if (!tick_is_done(c, R->done_tick)) { return fail(c, SDRPP_ERR_HIP, "tick %llu did not complete", (unsigned long long)R->done_tick); }
-    R->held = true;
-    const char* base = c->res_host[ticket % kResSlots];
+    if (!R->held) {
+        R->held = true;
+        R->base = c->res_host[R->buf];
+        c->res_held[R->buf]++;
+    }
+    const char* base = R->base;
     out->ticket = ticket;
     out->n_vfo = (int)R->ids.size();
     out->ids = R->ids.data();
@@ -1836,12 +1846,15 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     return SDRPP_OK;
 }
 int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
-    sdrpp_ctx::Result* R = result_of(c, ticket);
-    if (!R) { return c ? SDRPP_ERR_NOT_FOUND : SDRPP_ERR_INVALID; }
-    R->held = false;
-    R->ticket = 0;
-    std::vector<char*>& old = c->res_retired[ticket % kResSlots];  // (buffers this slot outgrew while the host held it)
-    if (!old.empty()) {
+    if (!c || ticket == 0 || ticket > c->pushes) { return c ? SDRPP_ERR_NOT_FOUND : SDRPP_ERR_INVALID; }
+    sdrpp_ctx::Result& R = c->res[ticket % kResMeta];
+    if (R.ticket != ticket) { return SDRPP_ERR_NOT_FOUND; }
+    const int buf = R.buf;
+    if (R.held && c->res_held[buf] > 0) { c->res_held[buf]--; }
+    R.held = false;
+    R.ticket = 0;
+    std::vector<char*>& old = c->res_retired[buf];  // (buffers this slot outgrew while the host held blocks of it)
+    if (c->res_held[buf] == 0 && !old.empty()) {
         DeviceScope dev_scope_(c);
         for (char* q : old) { (void)hipHostFree(q); }
         old.clear();

@@ -291,8 +291,8 @@ int tick_results_ensure(sdrpp_ctx* c) {
     if (need <= c->res_cap) { return SDRPP_OK; }
     // The slots grow (a VFO was added, a larger view / FFT configured) in the middle of a run: results that are complete or on their way
     // but not yet collected must survive — a host keeps tickets across such a change (IQFrontEnd: pendingTickets across tempStop / addVFO).
-    // Everything queued runs to its end first, then every live slot moves into its larger buffer; a slot the host is holding (handed out by
-    // sdrpp_result_wait) keeps its old buffer alive until it is released — the pointers the host was given stay valid.
+    // Everything queued runs to its end first, then every live slot moves into its larger buffer; a slot the host is holding (a block of it handed
+    // out by sdrpp_result_wait) keeps its old buffer alive until it is released — the pointers the host was given stay valid.
     int rc = tick_drain(c);
     if (rc) { return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -306,9 +306,9 @@ int tick_results_ensure(sdrpp_ctx* c) {
             return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);  // (slots < i are already the larger ones: res_cap stays, the next push tries again)
         }
         char* old = c->res_host[i];
-        if (old && c->res[i].ticket != 0 && c->res_cap_slot[i] > 0) { memcpy(nh, old, std::min(cap, c->res_cap_slot[i])); }
+        if (old && c->res_group[i] != 0 && c->res_cap_slot[i] > 0) { memcpy(nh, old, std::min(cap, c->res_cap_slot[i])); }
         if (old) {
-            if (c->res[i].held) { c->res_retired[i].push_back(old); }  // freed at sdrpp_result_release / sdrpp_destroy
+            if (c->res_held[i] > 0) { c->res_retired[i].push_back(old); }  // freed when the slot's last held block is released / at sdrpp_destroy
             else { (void)hipHostFree(old); }
         }
         c->res_host[i] = nh;
@@ -318,63 +318,100 @@ int tick_results_ensure(sdrpp_ctx* c) {
     c->res_cap = cap;
     return SDRPP_OK;
 }
-// gather roles of the block just planned -> c->emits; fills its result slot's description
-int tick_results_plan(sdrpp_ctx* c) {
-    const int slot = (int)(c->pushes % kResSlots);
-    sdrpp_ctx::Result& R = c->res[slot];
+
+// ---- what a block's results consist of: one push — or a launch group of k pushes (c->grp_ends: their cumulative ends), planned as ONE block ----
+// Every VFO's output block of the group lies in the group's result slot in one piece; push j's share of it is the samples between the push ends
+// carried down the VFO's chain (Vfo::tk_if / tk_af, plan_vfo.h), its lines the frames whose last sample arrived with it.
+struct ResCopy { const void* src; size_t off; size_t bytes; int level; };
+int64_t tick_frames_by(const sdrpp_ctx* c, int64_t e) {  // lines complete once the first `e` samples of the block just planned are in (do_fft's own count)
+    const int64_t P = (int64_t)c->nz + c->skip;
+    const int64_t a = c->plan_fft_pos0 + e - c->nz - c->plan_fft_next0 * P;
+    return a >= 0 ? a / P + 1 : 0;
+}
+int tick_results_describe(sdrpp_ctx* c, uint64_t first_ticket, int k, std::vector<ResCopy>& copies) {
+    copies.clear();
+    const int slot = (int)(c->groups % kResSlots);
     if (!c->res_flags) {
-        R = sdrpp_ctx::Result{};
+        for (int j = 0; j < k; j++) { c->res[(first_ticket + (uint64_t)j) % kResMeta] = sdrpp_ctx::Result{}; }
         return SDRPP_OK;
     }
-    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
-    R = sdrpp_ctx::Result{};
-    R.ticket = c->pushes;
-    R.fft_size = c->fft_size;
-    R.data_width = c->data_width;
-    R.flags = c->res_flags;
-    Lev<CopyJob> jobs;
+    if (c->res_held[slot] > 0) {
+        return fail(c, SDRPP_ERR_INVALID, "a result slot is still held (%d blocks of launch group %llu: release results before %d more groups are pushed)", c->res_held[slot], (unsigned long long)c->res_group[slot], kResSlots);
+    }
+    c->res_group[slot] = c->groups;
+    const bool split = k > 1;
+    if (split && (int)c->grp_ends.size() != k) { return fail(c, SDRPP_ERR_INVALID, "internal: %d blocks, %zu push ends", k, c->grp_ends.size()); }
+    sdrpp_ctx::Result* R[kGroupMax];
+    for (int j = 0; j < k; j++) {
+        R[j] = &c->res[(first_ticket + (uint64_t)j) % kResMeta];
+        *R[j] = sdrpp_ctx::Result{};
+        R[j]->ticket = first_ticket + (uint64_t)j;
+        R[j]->buf = slot;
+        R[j]->group = c->groups;
+        R[j]->fft_size = c->fft_size;
+        R[j]->data_width = c->data_width;
+        R[j]->flags = c->res_flags;
+    }
     size_t off = 0;
-    char* base = c->res_dev[slot];
     if (c->res_flags & 1) {
         for (auto& kv : c->vfos) {
             const Vfo& v = *kv.second;
             int lvl = 1;
             const Stream& s = result_stream(v, &lvl);
-            R.ids.push_back(v.id);
-            R.offsets.push_back((int64_t)(off / 8));
-            R.counts.push_back(s.n);
+            const std::vector<int>& tk = (&s == &v.st[(size_t)v.i_if] || (v.i_out >= 0 && &s == &v.st[(size_t)v.i_out])) ? v.tk_if : v.tk_af;
+            if (split && ((int)tk.size() != k || tk[(size_t)k - 1] != s.n)) { return fail(c, SDRPP_ERR_INVALID, "internal: push ends of VFO %d do not add up (%zu ends, %d samples)", v.id, tk.size(), s.n); }
+            for (int j = 0; j < k; j++) {
+                const int lo = (split && j > 0) ? tk[(size_t)j - 1] : 0, hi = split ? tk[(size_t)j] : s.n;
+                R[j]->ids.push_back(v.id);
+                R[j]->offsets.push_back((int64_t)(off / 8) + lo);
+                R[j]->counts.push_back(hi - lo);
+            }
             const size_t bytes = (size_t)s.n * 8;
-            if (bytes) { jobs.add(lvl + 1, CopyJob{ s.data, base + off, (long long)bytes, 0x100, 0 }); }
+            if (bytes) { copies.push_back(ResCopy{ s.data, off, bytes, lvl + 1 }); }
             off += (bytes + 15) & ~(size_t)15;
         }
     }
-    if ((c->res_flags & 8) && c->pre.on && c->pre.last_n > 0) {  // the pre-processed stream of the block (what streams bound with bindIQStream receive)
+    if ((c->res_flags & 8) && c->pre.on && c->pre.last_n > 0 && !split) {  // the pre-processed stream of the block (what streams bound with bindIQStream receive); groups never form behind a pre-processing chain
         const size_t bytes = (size_t)c->pre.last_n * 8;
-        R.off_iq = off;
-        R.n_iq = c->pre.last_n;
-        jobs.add(c->plan_lvl0 + 1, CopyJob{ c->pre.last, base + off, (long long)bytes, 0x100, 0 });
+        R[0]->off_iq = off;
+        R[0]->n_iq = c->pre.last_n;
+        copies.push_back(ResCopy{ c->pre.last, off, bytes, c->plan_lvl0 + 1 });
         off += (bytes + 15) & ~(size_t)15;
     }
-    R.n_lines = c->fft_on ? c->n_lines : 0;
-    if (R.n_lines > 0) {
+    const int n_lines = c->fft_on ? c->n_lines : 0;
+    int64_t lo_lines[kGroupMax + 1] = { 0 };
+    for (int j = 0; j < k; j++) { lo_lines[j + 1] = (split && n_lines > 0) ? std::min<int64_t>(n_lines, tick_frames_by(c, c->grp_ends[(size_t)j])) : n_lines; }
+    if (split && lo_lines[k] != n_lines) { return fail(c, SDRPP_ERR_INVALID, "internal: lines of the group do not add up (%lld of %d)", (long long)lo_lines[k], n_lines); }
+    for (int j = 0; j < k; j++) { R[j]->n_lines = (int)(lo_lines[j + 1] - lo_lines[j]); }
+    if (n_lines > 0) {
         const int lines_level = c->plan_lvl0 + (c->fft_lg <= 12 ? 1 : (c->fft_lg <= 16 ? 2 : 3));
         if ((c->res_flags & 2) && c->data_width > 0) {
-            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
-            R.off_zoomed = off;
-            jobs.add(lines_level + 2, CopyJob{ c->d_zoomed, base + off, (long long)bytes, 0x100, 0 });
+            const size_t row = (size_t)c->data_width * 4, bytes = (size_t)n_lines * row;
+            for (int j = 0; j < k; j++) { R[j]->off_zoomed = off + (size_t)lo_lines[j] * row; }
+            copies.push_back(ResCopy{ c->d_zoomed, off, bytes, lines_level + 2 });
             off += (bytes + 15) & ~(size_t)15;
-            R.off_index = off;
-            jobs.add(lines_level + 2, CopyJob{ c->d_index, base + off, (long long)bytes, 0x100, 0 });
+            for (int j = 0; j < k; j++) { R[j]->off_index = off + (size_t)lo_lines[j] * row; }
+            copies.push_back(ResCopy{ c->d_index, off, bytes, lines_level + 2 });
             off += (bytes + 15) & ~(size_t)15;
         }
         if (c->res_flags & 4) {
-            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
-            R.off_raw = off;
-            jobs.add(lines_level + 1, CopyJob{ c->d_lines, base + off, (long long)bytes, 0x100, 0 });
+            const size_t row = (size_t)c->fft_size * 4, bytes = (size_t)n_lines * row;
+            for (int j = 0; j < k; j++) { R[j]->off_raw = off + (size_t)lo_lines[j] * row; }
+            copies.push_back(ResCopy{ c->d_lines, off, bytes, lines_level + 1 });
             off += (bytes + 15) & ~(size_t)15;
         }
     }
     if (off > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes exceed the slot (%zu)", off, c->res_cap); }
+    return SDRPP_OK;
+}
+// gather roles of the block just planned -> c->emits (one level behind the producers); fills the result entries of its pushes
+int tick_results_plan(sdrpp_ctx* c, uint64_t first_ticket, int k) {
+    static thread_local std::vector<ResCopy> copies;
+    int rc = tick_results_describe(c, first_ticket, k, copies);
+    if (rc || copies.empty()) { return rc; }
+    Lev<CopyJob> jobs;
+    char* base = c->res_dev[c->groups % kResSlots];
+    for (auto& q : copies) { jobs.add(q.level, CopyJob{ q.src, base + q.off, (long long)q.bytes, 0x100, 0 }); }
     if (!arena_push_lev(c, jobs)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     for (int l = 0; l < jobs.top; l++) {
         if (jobs.at[l].empty()) { continue; }
@@ -390,86 +427,53 @@ int tick_results_plan(sdrpp_ctx* c) {
 // results of a block that ran as an ORDINARY pass inside a pipelined run (something the device cannot pipeline: a pre-processing chain, a
 // VFO group without the matrix front end, a retune hand-over ...): the same slot layout, filled by plain copies behind the pass and waited
 // for here — the slow path, but sdrpp_result_wait / _release then work for EVERY block of a pipelined run, whichever way it was processed
-int tick_results_direct(sdrpp_ctx* c) {
+int tick_results_direct(sdrpp_ctx* c, uint64_t first_ticket, int k) {
     int rc = tick_results_ensure(c);
     if (rc) { return rc; }
-    const int slot = (int)(c->pushes % kResSlots);
-    sdrpp_ctx::Result& R = c->res[slot];
-    if (R.held) { return fail(c, SDRPP_ERR_INVALID, "result slot of block %llu is still held (release results before %d more blocks are pushed)", (unsigned long long)R.ticket, kResSlots); }
-    R = sdrpp_ctx::Result{};
-    R.ticket = c->pushes;
-    R.fft_size = c->fft_size;
-    R.data_width = c->data_width;
-    R.flags = c->res_flags;
-    size_t off = 0;
-    char* base = c->res_host[slot];
-    if (c->res_flags & 1) {
-        for (auto& kv : c->vfos) {
-            const Vfo& v = *kv.second;
-            const Stream& s = result_stream(v);
-            R.ids.push_back(v.id);
-            R.offsets.push_back((int64_t)(off / 8));
-            R.counts.push_back(s.n);
-            const size_t bytes = (size_t)s.n * 8;
-            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
-            if (bytes) { HIPCHK(c, hipMemcpyAsync(base + off, s.data, bytes, hipMemcpyDeviceToHost, c->stream)); }
-            off += (bytes + 15) & ~(size_t)15;
-        }
-    }
-    if ((c->res_flags & 8) && c->pre.on && c->pre.last_n > 0) {
-        const size_t bytes = (size_t)c->pre.last_n * 8;
-        if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
-        R.off_iq = off;
-        R.n_iq = c->pre.last_n;
-        HIPCHK(c, hipMemcpyAsync(base + off, c->pre.last, bytes, hipMemcpyDeviceToHost, c->stream));
-        off += (bytes + 15) & ~(size_t)15;
-    }
-    R.n_lines = c->fft_on ? c->n_lines : 0;
-    if (R.n_lines > 0) {
-        if ((c->res_flags & 2) && c->data_width > 0) {
-            const size_t bytes = (size_t)R.n_lines * c->data_width * 4;
-            if (off + 2 * ((bytes + 15) & ~(size_t)15) > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
-            R.off_zoomed = off;
-            HIPCHK(c, hipMemcpyAsync(base + off, c->d_zoomed, bytes, hipMemcpyDeviceToHost, c->stream));
-            off += (bytes + 15) & ~(size_t)15;
-            R.off_index = off;
-            HIPCHK(c, hipMemcpyAsync(base + off, c->d_index, bytes, hipMemcpyDeviceToHost, c->stream));
-            off += (bytes + 15) & ~(size_t)15;
-        }
-        if (c->res_flags & 4) {
-            const size_t bytes = (size_t)R.n_lines * c->fft_size * 4;
-            if (off + bytes > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results exceed the slot"); }
-            R.off_raw = off;
-            HIPCHK(c, hipMemcpyAsync(base + off, c->d_lines, bytes, hipMemcpyDeviceToHost, c->stream));
-            off += (bytes + 15) & ~(size_t)15;
-        }
-    }
+    static thread_local std::vector<ResCopy> copies;
+    rc = tick_results_describe(c, first_ticket, k, copies);
+    if (rc) { return rc; }
+    char* base = c->res_host[c->groups % kResSlots];
+    for (auto& q : copies) { HIPCHK(c, hipMemcpyAsync(base + q.off, q.src, q.bytes, hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    R.done_tick = c->ticks;  // nothing queued is left: complete as it stands
+    for (int j = 0; j < k; j++) {
+        sdrpp_ctx::Result& R = c->res[(first_ticket + (uint64_t)j) % kResMeta];
+        if (R.ticket == first_ticket + (uint64_t)j) { R.done_tick = c->ticks; }  // nothing queued is left: complete as it stands
+    }
     return SDRPP_OK;
 }
 
 // sdrpp_push_staged_when: the host is still filling the staging slot with other threads while this thread plans the block; nothing that
 // reads the slot may be launched before they are through (the word counts their unfinished parts).
 int stage_pending_wait(sdrpp_ctx* c) {
-    const volatile uint32_t* w = c->stage_pending;
-    if (!w) { return SDRPP_OK; }
-    c->stage_pending = nullptr;
+    if (c->stage_pend.empty()) { return SDRPP_OK; }
+    std::vector<const volatile uint32_t*> words;
+    words.swap(c->stage_pend);
     HostScope hs("staging wait");
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0; *w != 0u; spins++) {
+    for (const volatile uint32_t* w : words) {
+        for (unsigned spins = 0; *w != 0u; spins++) {
 #if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
-        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged_when: the staging slot was not completed within 5 s"); }
+            if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged_when: the staging slot was not completed within 5 s"); }
+        }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return SDRPP_OK;
 }
 
-// One block in pipelined mode.  `d_iq`: where the samples are (caller's device buffer) or will be once `land` has run (landing ring).
-int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land) {
+// One block in pipelined mode — one push, or a launch group of k pushes (`ends`: their cumulative ends, `count` samples in all; tickets
+// first_ticket .. first_ticket + k - 1, already counted in c->pushes: the caller takes them back if this fails).  `d_iq`: where the samples are
+// (caller's device buffer) or will be once `land` has run (landing ring).
+int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* land, const std::vector<int>* ends, uint64_t first_ticket) {
     if (count == 0) { return SDRPP_OK; }
+    const int k = (ends && ends->size() > 1) ? (int)ends->size() : 1;
+    struct GroupScope {  // the push ends are visible to the planners (plan_vfo.h: chain) for the duration of this block only
+        sdrpp_ctx* c;
+        GroupScope(sdrpp_ctx* c_, const std::vector<int>* e, int k_) : c(c_) { if (k_ > 1) { c->grp_ends = *e; } else { c->grp_ends.clear(); } }
+        ~GroupScope() { c->grp_ends.clear(); }
+    } group_scope(c, ends, k);
     const float* const d_iq_raw = d_iq;  // (planning a pre-processing chain moves d_iq / count on to the pre-processed stream)
     const int64_t count_raw = count;
     c->plan_block_from_host = land != nullptr && land->bytes > 0;
@@ -499,7 +503,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         if (!rc && c->res_flags) { rc = tick_results_ensure(c); }
         if (rc) { return rc; }
     }
-    c->pushes++;
+    c->groups++;
     const bool have_slot = as_tick;
     static thread_local PlanSnapshot snap;  // (re-used: with 128 VFOs a fresh one is a 38 KB allocation per block; a nested pass starts only after the outer plan has been restored)
     int rc = SDRPP_OK;
@@ -507,7 +511,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         HostScope hs("tick plan");
         rc = arena_begin(c);
         if (rc) {
-            c->pushes--;
+            c->groups--;
             return rc;
         }
         {
@@ -524,7 +528,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         c->emits.clear();
         c->plan_top = 2;
         c->plan_lvl0 = 0;
-        block_bounds(c, count, nullptr);
+        block_bounds(c, count, k > 1 ? ends : nullptr);
         if (c->pre.on) {  // levels 1 .. plan_lvl0 of the block: from here on `d_iq` / `count` are the pre-processed stream
             rc = run_preproc(c, &d_iq, &count);
             if (!rc && count == 0) { c->tick_abort = true; }  // (the decimator swallowed the whole block: an ordinary pass sorts that out)
@@ -545,7 +549,7 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             }
             if (!rc && !c->tick_abort) {
                 HostScope hs2("tick: results plan");
-                rc = tick_results_plan(c);
+                rc = tick_results_plan(c, first_ticket, k);
             }
         }
         c->tick_planning = false;
@@ -560,40 +564,49 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         if (rc || c->tick_abort) {
             plan_restore(c, snap);
             c->emits.clear();
-            if (!c->res[c->pushes % kResSlots].held) { c->res[c->pushes % kResSlots].ticket = 0; }
+            for (int j = 0; j < k; j++) {
+                sdrpp_ctx::Result& R = c->res[(first_ticket + (uint64_t)j) % kResMeta];
+                if (!R.held) { R.ticket = 0; }
+            }
             as_tick = false;
             if (rc) {
-                c->pushes--;
+                c->groups--;
                 return rc;
             }
             c->arena_off = 0;  // (the slot stays this tick's: only the next role table goes in)
         }
     }
     if (!as_tick) {
-        c->stat_pass_blocks++;
+        c->stat_pass_blocks += k;
         // this block runs as an ordinary pass: everything queued first (the first of those ticks carries the landing copy), then the pass
         // behind them on the same stream
         if (!have_slot) {
             rc = arena_begin(c);
-            if (rc) { return rc; }
+            if (rc) {
+                c->groups--;
+                return rc;
+            }
         }
         rc = stage_pending_wait(c);
         if (!rc) { rc = tick_launch(c, land); }
         if (!rc) { rc = tick_drain(c); }
         if (land) { c->land_tick = c->ticks; }
-        if (!rc) { rc = push_common(c, d_iq_raw, count_raw, nullptr); }
+        if (!rc) { rc = push_common(c, d_iq_raw, count_raw, k > 1 ? ends : nullptr); }
         // its results are where an ordinary pass leaves them (device buffers, readable after a synchronisation) and — with result flags —
         // also in the block's result slot like every other block's
-        if (!rc && c->res_flags) { rc = tick_results_direct(c); }
+        if (!rc && c->res_flags) { rc = tick_results_direct(c, first_ticket, k); }
         else {
-            sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
-            if (!R.held) { R = sdrpp_ctx::Result{}; }
+            for (int j = 0; j < k; j++) {
+                sdrpp_ctx::Result& R = c->res[(first_ticket + (uint64_t)j) % kResMeta];
+                if (!R.held) { R = sdrpp_ctx::Result{}; }
+            }
         }
+        if (rc) { c->groups--; }
         return rc;
     }
     // queue the roles level by level and launch this block's tick
     HostScope hs3("tick: queue + launch");
-    c->stat_tick_blocks++;
+    c->stat_tick_blocks += k;
     c->stat_last_depth = c->plan_top;
     c->stat_last_table_bytes = (int64_t)c->arena_off;  // job tables of this block (the next tick's role table is added at the launch)
     if ((int)c->tickq.size() < c->plan_top) { c->tickq.resize((size_t)c->plan_top); }
@@ -607,9 +620,114 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
         rc = tick_launch(c, land);
     }
     if (land) { c->land_tick = c->ticks; }
-    sdrpp_ctx::Result& R = c->res[c->pushes % kResSlots];
-    if (R.ticket == c->pushes) { R.done_tick = c->ticks + (uint64_t)(c->plan_top - 1); }
+    for (int j = 0; j < k; j++) {
+        sdrpp_ctx::Result& R = c->res[(first_ticket + (uint64_t)j) % kResMeta];
+        if (R.ticket == first_ticket + (uint64_t)j) { R.done_tick = c->ticks + (uint64_t)(c->plan_top - 1); }
+    }
     return rc;
+}
+
+// ---- several blocks per launch (sdrpp_set_pipeline_group) ---------------------------------------------------------------------------------
+// May pushes share a launch at all right now?  Not behind a pre-processing chain (its decimator changes the rate the push ends live at), not while a
+// block cannot run as a tick, and not with a VFO that only rotates (no decimation plan: its NCO is anchored at the start of a launch, the results
+// would differ from block-by-block processing in the last bit).
+bool group_eligible(sdrpp_ctx* c) {
+    if (c->group_max <= 1 || c->pre.on || !tick_eligible(c)) { return false; }
+    for (Vfo* v : c->vfo_list) {
+        if (!v->nco_exact && v->d.n_stages == 0) { return false; }
+    }
+    return true;
+}
+// Whatever is held goes out as ONE block of the tick queue (nothing held: nothing happens).  On failure the held pushes did not happen: their
+// tickets are taken back.
+int tick_group_launch(sdrpp_ctx* c) {
+    if (c->held.kind < 0 || c->held.ends.empty()) { return SDRPP_OK; }  // (a staging slot handed out by sdrpp_push_stage and not yet pushed stays open)
+    sdrpp_ctx::Held H;
+    std::swap(H, c->held);
+    const int k = (int)H.ends.size();
+    const uint64_t first_ticket = c->pushes - (uint64_t)k + 1;
+    int rc = SDRPP_OK;
+    if (H.kind == 0) { rc = tick_push(c, reinterpret_cast<const float*>(H.base), H.total, nullptr, &H.ends, first_ticket); }  // read in place, one tick from now at the earliest
+    else {
+        const int li = (int)((c->groups + 1) % 3);
+        if (!c->tick_land[li]) { rc = dev_alloc(c, &c->tick_land[li], (size_t)c->max_push * 2 + 32); }
+        void* d = nullptr;
+        if (!rc && (hipHostGetDevicePointer(&d, H.kind == 3 ? (void*)H.base : (void*)c->stage_host[H.stage_slot], 0) != hipSuccess || !d)) { rc = fail(c, SDRPP_ERR_HIP, "hipHostGetDevicePointer(staging) failed"); }
+        if (!rc) {
+            const CopyJob land{ d, c->tick_land[li], (long long)((size_t)H.total * (H.kind == 2 ? 4 : 8)), H.kind == 2 ? 1 : 0, 0 };
+            rc = tick_push(c, c->tick_land[li], H.total, &land, &H.ends, first_ticket);
+            if (H.kind != 3) { c->stage_tick[H.stage_slot] = c->ticks; }
+        }
+    }
+    c->stage_pend.clear();
+    if (rc) { c->pushes -= (uint64_t)k; }
+    else if (k > 1) {
+        c->stat_groups++;
+        c->stat_group_blocks += k;
+        c->stat_group_max = std::max<int64_t>(c->stat_group_max, k);
+    }
+    return rc;
+}
+// One push of a pipelined run: joins the held group, or — the group full, the push of another kind or not contiguous with it, grouping off — sends
+// what is held on its way first.  kind 0: `p` = device address (read in place); 1 / 2: float / int16 samples in host memory, copied into the
+// group's page-locked staging slot (p == nullptr: the host has filled the slot itself, sdrpp_push_stage); 3: the caller's page-locked memory.
+int tick_hold(sdrpp_ctx* c, int kind, const void* p, int64_t count, const volatile uint32_t* pending) {
+    if (count == 0) { return SDRPP_OK; }
+    sdrpp_ctx::Held& H = c->held;
+    const bool groupable = group_eligible(c);
+    const size_t bps = kind == 2 ? 4 : 8;
+    if (H.kind >= 0) {
+        bool fits = groupable && H.kind == kind && (int)H.ends.size() < c->group_max && H.total + count <= c->max_push;
+        if (fits && (kind == 0 || kind == 3)) { fits = reinterpret_cast<const char*>(p) == H.base + (size_t)8 * (size_t)H.total; }
+        if (H.ends.empty() && H.kind == kind && (kind == 1 || kind == 2) && H.total == 0) { fits = true; }  // (a slot opened by sdrpp_push_stage, nothing in it yet)
+        if (!fits) {
+            if ((kind == 1 || kind == 2) && !p) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged: %lld samples do not fit the open staging slot", (long long)count); }
+            int rc = tick_group_launch(c);
+            if (rc) { return rc; }
+            c->held = sdrpp_ctx::Held{};
+        }
+    }
+    if (H.kind < 0) {
+        if ((kind == 1 || kind == 2) && !p) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_push_staged without an open staging slot (sdrpp_push_stage)"); }
+        H.kind = kind;
+        H.base = reinterpret_cast<const char*>(p);
+        H.total = 0;
+        H.ends.clear();
+        if (kind == 1 || kind == 2) {
+            const int si = c->stage_cur;
+            c->stage_cur = (c->stage_cur + 1) % kStageSlots;
+            if (!c->stage_host[si]) {
+                if (hipHostMalloc((void**)&c->stage_host[si], (size_t)c->max_push * 8 + 64, hipHostMallocMapped) != hipSuccess) {
+                    H.kind = -1;
+                    return fail(c, SDRPP_ERR_NOMEM, "page-locked staging buffer");
+                }
+            }
+            if (c->stage_tick[si]) { tick_wait_done(c, c->stage_tick[si]); }  // its last landing copy has run
+            H.stage_slot = si;
+        }
+    }
+    if ((kind == 1 || kind == 2) && p) { memcpy(reinterpret_cast<char*>(c->stage_host[H.stage_slot]) + (size_t)H.total * bps, p, (size_t)count * bps); }
+    H.total += count;
+    H.ends.push_back((int)H.total);
+    c->pushes++;
+    bool go = !groupable || (int)H.ends.size() >= c->group_max;
+    if (!go && c->group_adaptive && c->h_tick_flag) { go = (int)((unsigned)c->ticks - *(const volatile unsigned*)c->h_tick_flag) < 2; }  // the device would run dry: do not wait for more
+    if (pending) {
+        // sdrpp_push_staged_when: the word belongs to the caller and is only promised to live for the call.  The push that sends the group on its
+        // way is planned while its copy threads are still at work (the wait comes just before the launch, stage_pending_wait); one that is merely
+        // held has nothing to overlap with: it waits here.
+        c->stage_pend.push_back(pending);
+        if (!go) {
+            int rc = stage_pending_wait(c);
+            if (rc) {  // the block did not arrive: it is not part of the group
+                H.ends.pop_back();
+                H.total -= count;
+                c->pushes--;
+                return rc;
+            }
+        }
+    }
+    return go ? tick_group_launch(c) : SDRPP_OK;
 }
 
 }  // namespace

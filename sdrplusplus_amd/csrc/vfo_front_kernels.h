@@ -16,6 +16,7 @@ struct Front2Job {
     int nout2;                       // stage-2 outputs of this push
     int t2;                          // stage-2 outputs per block
     int min_idx;                     // IQ samples before this push-relative index read as zero
+    int anchor;                      // the index phi0 belongs to (0 = the block's first sample; a push of a launch group: where ITS samples start, so that its phases round as they do block by block)
     const float2* ctaps;             // [(ntaps1+1)/2][VT] modulated stage-1 tap pairs
     const float2* ptab;              // [256][VT] exp(j*2*pi*theta_v*D1*j): NCO advance inside a tile (host, double -> float)
     const float* taps2;              // [ntaps2] real taps, natural order
@@ -62,7 +63,7 @@ __device__ __forceinline__ void vfo_front2_body(const KIdx bid, float2* smem2, c
     }
     if (threadIdx.x < VT && (int)threadIdx.x < job.nv) {
         const int v = threadIdx.x;
-        double ph = fma((double)base + 0.5 * (double)(K1 - 1), job.theta[v], job.phi0[v]);
+        double ph = fma((double)(base - job.anchor) + 0.5 * (double)(K1 - 1), job.theta[v], job.phi0[v]);
         ph -= rint(ph);
         float sn, cs;
         sincospif(2.0f * (float)ph, &sn, &cs);
@@ -156,6 +157,7 @@ struct FrontCMJob {
     int nout;         // outputs of this push (= stage-2 outputs)
     int min_idx;      // IQ samples before this push-relative index read as zero
     int tiles_per_wave;
+    int anchor;       // the index phi0 belongs to (0 = the block's first sample; a push of a launch group: where ITS samples start — the tile phasors then round as they do block by block)
     const float* atab;    // [npad][64]: lane l -> (l < 32 ? gr : -gi) of VFO l & 31 (0 for unused VFO slots and padding rows)
     const float2* ptab;   // [32][32] exp(j*2*pi*theta_v*D*n): NCO advance inside a tile
     double theta[SDRPP_FCM_VT];
@@ -250,7 +252,7 @@ __device__ __forceinline__ void vfo_frontcm_body(const KIdx bid, float* smemf, c
     };
     auto tile_phasor = [&](int tb) {
         if (lane < VT && lane < job.nv) {
-            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
+            double ph = fma((double)(tile_base(tb) - job.anchor) + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);
@@ -518,7 +520,7 @@ __device__ __forceinline__ void vfo_frontcm16_body(const KIdx bid, float* smemf,
     if (tid < VT) {
         outp[tid] = job.out[tid];
         if (tid < job.nv) {  // the tile's phasor per VFO: exactly vfo_frontcm_body's tile_phasor
-            double ph = fma((double)tbase + 0.5 * (double)(K - 1), job.theta[tid], job.phi0[tid]);
+            double ph = fma((double)(tbase - job.anchor) + 0.5 * (double)(K - 1), job.theta[tid], job.phi0[tid]);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);
@@ -684,7 +686,7 @@ __device__ __forceinline__ void vfo_frontcm16w_body(const KIdx bid, float* smemf
         }
         if (lane < 16 && vh * 16 + lane < job.nv) {  // the tile's phasor per VFO: exactly vfo_frontcm_body's tile_phasor
             const int v = vh * 16 + lane;
-            double ph = fma((double)tile_base(tb) + 0.5 * (double)(K - 1), job.theta[v], job.phi0[v]);
+            double ph = fma((double)(tile_base(tb) - job.anchor) + 0.5 * (double)(K - 1), job.theta[v], job.phi0[v]);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);
@@ -836,7 +838,7 @@ __device__ __forceinline__ void vfo_frontcl_impl(const KIdx bid, float* smemf, c
         const long long base = tile_base(tb);
         planes_store(base);  // the previous tile's reads are complete (wave_sync at the end of the loop body)
         if (lane < VT && lane < job.nv) {
-            double ph = fma((double)base + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
+            double ph = fma((double)(base - job.anchor) + 0.5 * (double)(K - 1), job.theta[lane], job.phi0[lane]);
             ph -= rint(ph);
             float sn, cs;
             sincospif(2.0f * (float)ph, &sn, &cs);

@@ -69,6 +69,7 @@ struct Stage1Job {
     int ntaps, log2_decim, off0, nout;
     int min_idx;             // samples before this push-relative index read as zero (a VFO added or reset mid-stream starts
                              // from an all-zero history: fir.h:24-26 clears the delay line)
+    int anchor;              // the index phi0 belongs to (0 = the block's first sample; a push of a launch group: where ITS samples start)
     const float2* ctaps;     // [(ntaps+1)/2][VT] modulated tap pairs (see stage1_accumulate), VFO index fastest
     double theta[SDRPP_S1_MAX_VT];  // turns per input sample
     double phi0[SDRPP_S1_MAX_VT];   // turns at push-relative sample index 0
@@ -158,7 +159,7 @@ __device__ __forceinline__ void vfo_stage1_body(const KIdx bid, float2* xs, cons
     for (int v = 0; v < VT; v++) { acc[v] = make_float2(0.0f, 0.0f); }
     stage1_accumulate<VT>(xs, pitch, lgD, K, j, as_uniform(job.ctaps), acc);  // taps are wave-uniform: scalar loads
     if (j0 + j >= job.nout) { return; }
-    const double centre = (double)(base + (long long)j * D) + 0.5 * (double)(K - 1);
+    const double centre = (double)(base + (long long)j * D - job.anchor) + 0.5 * (double)(K - 1);
 #pragma unroll
     for (int v = 0; v < VT; v++) {
         if (v < job.nv) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ void vfo_stage1_direct_body(const KIdx bid, const IqS
         }
     }
     if (j >= job.nout) { return; }
-    const double centre = (double)i0 + 0.5 * (double)(K - 1);
+    const double centre = (double)(i0 - job.anchor) + 0.5 * (double)(K - 1);
 #pragma unroll
     for (int v = 0; v < VT; v++) {
         if (v < job.nv) {

@@ -640,3 +640,181 @@ def test_pipelined_equals_ordinary_with_preproc_chain(backend, ratio, dc, conj):
         assert "dc_p0" in st["roles"] and "dc_p1" in st["roles"], st
     ca.close()
     cb.close()
+
+
+# ---- several blocks per launch (sdrpp_set_pipeline_group) -----------------------------------------------------------------------------------
+def _device_copy_of(ctx, x):
+    """x (complex64) in memory of the context's device, through the C-ABI's own allocator / copy (works on the emulator build too)."""
+    import ctypes as C
+
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    p = ctx.L.sdrpp_device_alloc(ctx.h, x.nbytes)
+    assert p
+    ctx._chk(ctx.L.sdrpp_device_copy(ctx.h, C.c_void_p(p), C.c_void_p(x.ctypes.data), x.nbytes, 0))
+    return p
+
+
+@pytest.mark.parametrize("feed", ["host", "device", "staged", "int16"])
+def test_grouped_launches_equal_block_by_block(backend, feed):
+    """sdrpp_set_pipeline_group(3): the pushes of a group are planned as ONE block whose reference-block ends are the push ends and go out as ONE
+    launch — and every push still has its own ticket and results, bit-identical to the ordinary pass block by block: 20 / 17 WFM VFOs + FFT, uneven
+    blocks (a block that completes no frame, a 7-sample block, a group the next block does not fit into: max_push), every way a block can arrive."""
+    from sdrplusplus_amd import workloads
+
+    nv = 20 if backend == "gpu" else 17
+    pushes = [50000, 1031, 20000, 7, 33333, 50000, 50000, 12000] if backend == "gpu" else [25000, 1031, 10000, 7, 16667, 25000, 25000, 6000]
+    x = workloads.synth(3, sum(pushes), seed=5, nvfo=nv)
+    if feed == "int16":  # (what file_source reads: int16 pairs, converted by the landing copy — the ordinary pass gets the same samples)
+        xi = np.round(x.view(np.float32) * 20000.0).astype(np.int16)
+        x = (xi.astype(np.float32) / 32768.0).view(np.complex64)
+    cap = max(pushes) * 2 + 2000  # room for two large blocks: the third of a would-be group of three goes out with the next one
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, cap, 4096)
+    cb.set_pipeline_group(3)
+    dev = _device_copy_of(cb, x) if feed == "device" else None
+    refs, pos = [], 0
+    for i, n in enumerate(pushes):
+        blk = x[pos:pos + n]
+        refs.append(_ordinary_results(ca, va, blk, True))
+        if feed == "host":
+            cb.push(blk)
+        elif feed == "device":
+            cb.push_device(dev + 8 * pos, n)
+        elif feed == "int16":
+            cb.push_int16(xi[2 * pos:2 * (pos + n)])
+        elif i % 2 == 0:
+            cb.push_staged_from(blk)
+        else:
+            cb.push_staged_late_fill(blk)
+        pos += n
+        assert cb.ticket() == i + 1
+    gs = cb.pipeline_group_stats()
+    assert gs["held"] > 0 and gs["multi_groups"] >= 2, gs  # (8 pushes: the last group is still open)
+    assert not cb.result_ready(len(pushes))  # held back: not planned yet
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)  # (the last tickets: the open group goes out as it stands)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    gs = cb.pipeline_group_stats()
+    st = cb.pipeline_stats()
+    assert gs["held"] == 0 and gs["largest"] == 3 and gs["groups"] < len(pushes), gs
+    assert st["pass_blocks"] == 0 and st["tick_blocks"] == len(pushes) and st["ticks"] < 2 * len(pushes) + 12, st
+    if dev:
+        cb.L.sdrpp_device_free(cb.h, dev)
+    ca.close()
+    cb.close()
+
+
+def test_grouped_launches_mixed_modes_af_and_reference_blocks(backend):
+    """Groups of four over a cfg 4 bank (NFM / AM / USB: chains of different depth and rate, AGC look-ahead that follows the reference's blocks inside every
+    push) with the radio's AF chain on some VFOs: per-push shares of every output — the AF chain's 48 kHz stream included — identical to the ordinary pass;
+    a retune and a bandwidth change between pushes send the open group on its way first."""
+    from sdrplusplus_amd import capi, radio, workloads
+
+    sr, nv = workloads.CFG[4]["sr"], 27
+    pushes = [153600, 50003, 102197, 153600, 80000, 153600, 153600] if backend == "gpu" else [38400, 12503, 25597, 38400, 20000, 38400, 38400]
+    x = workloads.synth(4, sum(pushes), seed=9, nvfo=nv)
+    pair = []
+    for pipelined in (False, True):
+        ctx = capi.Context(0, max_push=sum(pushes))
+        vids, with_af, with_deemph = [], set(), set()
+        for i, (mode, if_rate, bw, centre, _) in enumerate(workloads.vfo_plan(4, nv)):
+            d, keep = radio.vfo_desc(sr, if_rate, bw, centre, mode)
+            vids.append(ctx.vfo_add(d, keep))
+            if i % 4 == 1:
+                a, akeep = radio.af_desc(if_rate, 48000.0, 50e-6 if mode == "NFM" else None, high_pass=(mode == "NFM"))
+                ctx.vfo_set_af(vids[-1], a, akeep)
+                with_af.add(vids[-1])
+                if mode == "NFM":
+                    with_deemph.add(vids[-1])
+        ctx.set_reference_block(int(sr / 400))
+        if pipelined:
+            ctx.set_pipelined(True, 1)
+            ctx.set_pipeline_group(4)
+        pair.append((ctx, vids, with_af, with_deemph))
+    (ca, va, afa, _), (cb, vb, _, deb) = pair
+    assert len(afa) >= 6 and len(deb) >= 2 and len(deb) < len(afa)
+    refs, pos = [], 0
+    for i, n in enumerate(pushes):
+        blk = x[pos:pos + n]
+        pos += n
+        if i == 2:
+            re, im = capi.design_phase_delta(-1.234e6, sr)
+            ca.vfo_set_phase_delta(va[3], re, im)
+            cb.vfo_set_phase_delta(vb[3], re, im)
+        if i == 5:
+            taps = capi.design_low_pass(3000.0, 600.0, 50000.0)
+            ca.vfo_set_channel_taps(va[0], taps)
+            cb.vfo_set_channel_taps(vb[0], taps)
+        ca.push(blk)
+        r = {}
+        for v_a, v_b in zip(va, vb):
+            r[v_b] = (ca.vfo_af_read(v_a) if v_a in afa else ca.vfo_read(v_a)).copy()
+        refs.append(r)
+        cb.push(blk)
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        for v, a in ref.items():
+            if v in deb:
+                # the de-emphasis is a recursion evaluated as a two-level scan whose segments start where a LAUNCH starts (vfo_deemph_body): the carry into a
+                # segment rounds differently when the cuts move — equal to the last bits, not bit for bit (the same holds for a deferred pass)
+                b = got["vfo"][v]
+                assert a.shape == b.shape and np.max(np.abs(a - b), initial=0.0) <= 2e-6 * max(1e-6, float(np.max(np.abs(a), initial=0.0))), ("block %d vfo %d (de-emphasis)" % (t, v))
+            else:
+                _same(a, got["vfo"][v], "block %d vfo %d" % (t, v))
+        cb.result_release(t)
+    gs = cb.pipeline_group_stats()
+    assert gs["multi_groups"] >= 2 and gs["largest"] <= 4, gs
+    ca.close()
+    cb.close()
+
+
+def test_grouped_results_hold_release_and_adaptive(backend):
+    """The result slots belong to launch groups: blocks of a group can be held and released in any order, a slot still held when its turn comes round again
+    fails the push (and nothing else); adaptive grouping on an idle device sends every push at once."""
+    from sdrplusplus_amd import capi, workloads
+
+    nv, B = 17, 12000
+    x = workloads.synth(3, 8 * B, seed=3, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, 4 * B, 4096, flags=3)
+    cb.set_pipeline_group(2)
+    for i in range(4):
+        cb.push(x[i * B:(i + 1) * B])
+    r2 = cb.result_wait(2, copy=False)
+    r1 = cb.result_wait(1, copy=False)
+    a1 = {v: a.copy() for v, a in r1["vfo"].items()}
+    cb.result_release(2)
+    # 24 groups later the slot of group 1 comes round: block 1 is still held -> the push that sends that group out fails (and takes the group's
+    # tickets back), the stream goes on once the block is released
+    i = 4
+    while cb.pipeline_group_stats()["groups"] < capi.RESULT_SLOTS or cb.pipeline_group_stats()["held"]:
+        cb.push(x[(i % 8) * B:(i % 8 + 1) * B])
+        i += 1
+        if i >= 8 and not cb.pipeline_group_stats()["held"]:
+            for t in (i - 5, i - 4):  # (blocks of groups that have gone out: asking for them flushes nothing that is held)
+                cb.result_wait(t)
+                cb.result_release(t)
+    assert cb.pipeline_group_stats()["groups"] == capi.RESULT_SLOTS
+    for v in vb:
+        assert np.array_equal(a1[v], r1["vfo"][v])  # untouched while held
+    t0 = cb.ticket()
+    cb.push(x[0:B])
+    with pytest.raises(capi.SdrppError):
+        cb.push(x[B:2 * B])
+    assert cb.ticket() == t0 and cb.pipeline_group_stats()["held"] == 0  # the group did not happen
+    cb.result_release(1)
+    cb.push(x[0:B])
+    cb.push(x[B:2 * B])
+    t = cb.ticket()
+    assert t == t0 + 2
+    cb.result_wait(t)
+    cb.result_release(t)
+    # adaptive: the emulator / an idle device has nothing in flight -> every push is its own launch
+    g0 = cb.pipeline_group_stats()
+    cb.set_pipeline_group(4, adaptive=True)
+    for i in range(3):
+        cb.push(x[i * B:(i + 1) * B])
+        cb.sync()
+    g1 = cb.pipeline_group_stats()
+    assert g1["groups"] - g0["groups"] == 3 and g1["multi_groups"] == g0["multi_groups"], (g0, g1)
+    ca.close()
+    cb.close()
