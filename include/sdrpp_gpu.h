@@ -316,8 +316,12 @@ void sdrpp_host_free(void* p);
  * its RCCL gather, host/sdrpp_gpu_rccl.h) without linking the HIP runtime itself; NULL on failure. */
 void* sdrpp_device_alloc(sdrpp_ctx* ctx, size_t bytes);
 void sdrpp_device_free(sdrpp_ctx* ctx, void* p);
-/* A synchronous copy on the context's GPU for the same kind of host: kind 0 host -> device, 1 device -> device, 2 device -> host.  Ordered behind
- * everything enqueued on the context's stream; returns when the bytes have arrived. */
+/* A synchronous copy on the context's GPU for the same kind of host: kind 0 host -> device, 1 device -> device, 2 device -> host; returns when the
+ * bytes have arrived.  THE ONE CALL OF A CONTEXT THAT IS THREAD-SAFE: it may come from another thread while the context's own thread is inside any
+ * other call (a several-GPU host's gather thread copies a front end's newest line while its worker pushes blocks).  It runs on a stream of its own
+ * and is therefore NOT ordered with the work queued on the context's stream: use it for buffers whose content is complete (filled by an earlier
+ * sdrpp_device_copy, or by sdrpp_fft_copy_device followed by sdrpp_sync), not to read what a push has just been asked to compute.  It never waits
+ * for queued launches and sets no error text (sdrpp_last_error belongs to the context's thread): the return code is all there is. */
 int sdrpp_device_copy(sdrpp_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
 /* Deferred processing: sdrpp_push* only stage the samples (the H2D copy runs, the caller's buffer is free on return) and the next call
  * that observes results — sdrpp_sync, any *_lines / *_read* / *_count / *_device_buffer(s) / sdrpp_wf_* call — or changes the

@@ -145,6 +145,8 @@ struct sdrpp_ctx {
     bool land_used[2] = { false, false };
     int land_cur = 0;
     hipStream_t copy_stream = nullptr;
+    hipStream_t side_stream = nullptr;   // sdrpp_device_copy: copies that may come from ANOTHER thread than the one driving the context (created with the context, never changed)
+    std::mutex side_mtx;                  // ... one at a time
     bool async_staged = false;     // sdrpp_push_pinned_async copies enqueued since the last pass (the pass waits for them on the device)
     bool async_inflight = false;   // ... and not yet known to have landed: cleared only by a HOST synchronisation of the copy stream (sdrpp_push_wait)
     hipEvent_t ev_copy = nullptr;
@@ -262,9 +264,9 @@ struct sdrpp_ctx {
         uint64_t ticket = 0;              // 0: entry free
         uint64_t done_tick = 0;           // its last level has run when this many ticks have completed
         bool held = false;                // handed out by sdrpp_result_wait, not yet released
-        int buf = 0;                      // result slot of its launch group
-        uint64_t group = 0;               // the group (res_group[buf] == group while the slot still holds its bytes)
-        const char* base = nullptr;       // host address of that slot's buffer when the results were planned (a held block keeps it across tick_results_ensure)
+        uint64_t group = 0;               // its launch group (alive while res_live still holds a region of that id)
+        const char* base = nullptr;       // host address of the group's region in the result ring (stays valid for a held block when the ring is replaced by a larger one)
+        int epoch = 0;                    // which ring `base` points into (res_epoch when the results were planned)
         std::vector<int> ids, counts;
         std::vector<int64_t> offsets;
         int n_lines = 0;
@@ -351,13 +353,20 @@ struct sdrpp_ctx {
     uint64_t stage_tick[kStageSlots] = {};  // the tick whose landing copy reads the slot (+1)
     int stage_cur = 0;
     int stage_open = -1;                  // slot handed out by sdrpp_push_stage and not yet pushed
-    char* res_host[kResSlots] = {};       // page-locked result slots
-    char* res_dev[kResSlots] = {};        // their device addresses
-    size_t res_cap = 0;                   // bytes per slot
-    size_t res_cap_slot[kResSlots] = {};  // ... of each slot's current buffer (they grow one by one, tick_results_ensure)
-    std::vector<char*> res_retired[kResSlots];  // smaller buffers of slots that were HELD when the slots grew: the host's pointers into them stay valid until it releases
-    uint64_t res_group[kResSlots] = {};   // the launch group whose results the slot holds (0: none)
-    int res_held[kResSlots] = {};         // blocks of that group handed out by sdrpp_result_wait and not yet released
+    // Results in page-locked host memory: ONE ring of kResSlots x (what a launch of max_push samples can deliver), handed out in allocation order, a
+    // region per launch group sized for what that group really delivers — 24 launches at the stream cap, ten times as many at the reference's block
+    // size (a host that collects a fixed number of BLOCKS behind its pushes must not lose results because the groups happened to be small).  A region
+    // is taken back, oldest first, when the ring comes round to it; one the host still holds fails the push that needs it.
+    char* res_ring = nullptr;             // host address
+    char* res_ring_dev = nullptr;         // ... and as the device sees it
+    size_t res_ring_bytes = 0;
+    size_t res_cap = 0;                   // what the largest possible launch delivers (tick_results_need)
+    size_t res_head = 0;                  // next free byte
+    int res_epoch = 0;                    // counts the rings (tick_results_ensure replaces the ring by a larger one)
+    struct ResRegion { uint64_t gid; size_t off, bytes; int held; };
+    std::deque<ResRegion> res_live;       // regions in use, in allocation order (front = oldest)
+    struct ResRetired { char* ring; int epoch; int held; };
+    std::vector<ResRetired> res_retired;  // smaller rings that held blocks the host had not released when the ring grew: its pointers stay valid until it does
     Result res[kResMeta];
     // ---- several blocks per launch (sdrpp_set_pipeline_group): pushes are HELD — nothing planned, nothing launched — until the group goes out as ONE
     //      block of the tick queue whose reference-block ends are the push ends (what a deferred pass does with its staged pushes, plan_push.h) ----

@@ -167,7 +167,7 @@ int push_common(sdrpp_ctx* c, const float* d_iq, int64_t count, const std::vecto
             if (!rc) {
                 FamilyTimer t(c, F_MISC);
                 const int iq_elems = carry[0].need * 2;
-                launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 1023) / 1024, 2048)), 1), dim3(256), 0, (const CarryJob*)d_carry, 0);
+                launch(c, carry_kernel, dim3((unsigned)std::max(1, std::min((iq_elems + 8191) / 8192, 512)), 1), dim3(256), 0, (const CarryJob*)d_carry, 0);  // (carry_body: 8 192 floats per workgroup and round)
             }
         }
         else {

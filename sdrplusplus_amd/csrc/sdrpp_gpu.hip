@@ -14,6 +14,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -149,6 +150,10 @@ int sdrpp_create(int device, int64_t max_push, sdrpp_ctx** out) {
             sdrpp_destroy(c);
             return SDRPP_ERR_NOMEM;
         }
+    }
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
+        sdrpp_destroy(c);
+        return SDRPP_ERR_NO_DEVICE;
     }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_copy) != hipSuccess ||
         hipEventCreate(&c->land_ev[0]) != hipSuccess || hipEventCreate(&c->land_ev[1]) != hipSuccess) {
@@ -394,11 +399,9 @@ int sdrpp_destroy(sdrpp_ctx* c) {
         if (c->tick_ev[i]) { (void)hipEventDestroy(c->tick_ev[i]); }
         if (c->tick_ev_start[i]) { (void)hipEventDestroy(c->tick_ev_start[i]); }
     }
-    for (int i = 0; i < kResSlots; i++) {
-        if (c->res_host[i]) { (void)hipHostFree(c->res_host[i]); }
-        for (char* q : c->res_retired[i]) { (void)hipHostFree(q); }
-        c->res_retired[i].clear();
-    }
+    if (c->res_ring) { (void)hipHostFree(c->res_ring); }
+    for (auto& q : c->res_retired) { (void)hipHostFree(q.ring); }
+    c->res_retired.clear();
     fft_ring_drop(c);
     for (int i = 0; i < 2; i++) {
         dev_free(c->iq_land[i]);
@@ -407,6 +410,7 @@ int sdrpp_destroy(sdrpp_ctx* c) {
     }
     if (c->ev_copy) { (void)hipEventDestroy(c->ev_copy); }
     if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); }
+    if (c->side_stream) { (void)hipStreamDestroy(c->side_stream); }
     dev_free(c->iq_hist[0]);
     dev_free(c->iq_hist[1]);
     dev_free(c->d_window);
@@ -981,9 +985,13 @@ int sdrpp_vfo_set_channel_taps(sdrpp_ctx* c, int id, const float* taps, int n) {
         //     back — under the new tap count — when it wakes up.
         if (was_on != now_on && v.i_chan >= 0) {
             Stream& cs = v.st[(size_t)v.i_chan];
-            if (was_on && old_n > 1 && fs.hist[fs.cur] && fs.hist_len >= old_n - 1) {  // going to sleep: (b) first, (a) overwrites the buffer
-                v.chan_stale.resize((size_t)(old_n - 1) * (size_t)w);
-                HIPCHK(c, hipMemcpy(v.chan_stale.data(), fs.hist[fs.cur] + (size_t)(fs.hist_len - (old_n - 1)) * w, v.chan_stale.size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (was_on) {  // going to sleep: (b) first, (a) overwrites the buffer
+                // exactly the old filter's old_n - 1 samples, whatever an EARLIER bypass left here (a one-tap filter has no delay line: nothing; a
+                // stream without history yet: zeros, which is what FIR's cleared buffer holds, fir.h:24-26)
+                v.chan_stale.assign((size_t)std::max(old_n - 1, 0) * (size_t)w, 0.0f);
+                if (old_n > 1 && fs.hist[fs.cur] && fs.hist_len >= old_n - 1) {
+                    HIPCHK(c, hipMemcpy(v.chan_stale.data(), fs.hist[fs.cur] + (size_t)(fs.hist_len - (old_n - 1)) * w, v.chan_stale.size() * sizeof(float), hipMemcpyDeviceToHost));
+                }
             }
             if (now_on) {  // waking up: the buffer must be long enough for the new filter before anything is put into it
                 int rc = stream_grow_hist(c, fs, n - 1);
@@ -1720,14 +1728,20 @@ void sdrpp_device_free(sdrpp_ctx* c, void* p) {
     DeviceScope dev_scope_(c);
     (void)hipFree(p);
 }
+// THREAD-SAFE, unlike the rest of a context: a several-GPU host copies a front end's newest line from its gather thread while the worker thread
+// is inside sdrpp_push / sdrpp_result_wait on the same context (host/sdrpp_gpu_blocks.h: copyLatestLineDevice).  So the call touches nothing of
+// the context that ever changes: a stream of its own (created with the context), its own lock, no error text (the code is all the caller gets).
+// It is therefore NOT ordered with the work on the context's stream — it is for buffers whose content is complete (written by an earlier
+// sdrpp_device_copy, or by sdrpp_fft_copy_device followed by sdrpp_sync) and it does not wait for the launches queued there.
 int sdrpp_device_copy(sdrpp_ctx* c, void* dst, const void* src, size_t bytes, int kind) {
     if (!c) { return SDRPP_ERR_INVALID; }
-    DeviceScope dev_scope_(c);
-    if (kind < 0 || kind > 2 || (bytes && (!dst || !src))) { return fail(c, SDRPP_ERR_INVALID, "sdrpp_device_copy: bad arguments"); }
+    if (kind < 0 || kind > 2 || (bytes && (!dst || !src))) { return SDRPP_ERR_INVALID; }
     if (!bytes) { return SDRPP_OK; }
+    DeviceScope dev_scope_(c);
     const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
-    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, k, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lck(c->side_mtx);
+    if (hipMemcpyAsync(dst, src, bytes, k, c->side_stream) != hipSuccess) { return SDRPP_ERR_HIP; }
+    if (hipStreamSynchronize(c->side_stream) != hipSuccess) { return SDRPP_ERR_HIP; }
     return SDRPP_OK;
 }
 
@@ -1789,7 +1803,9 @@ static bool ticket_is_held_back(const sdrpp_ctx* c, uint64_t ticket) {  // pushe
 static sdrpp_ctx::Result* result_of(sdrpp_ctx* c, uint64_t ticket) {
     if (!c || ticket == 0 || ticket > c->pushes) { return nullptr; }
     sdrpp_ctx::Result& R = c->res[ticket % kResMeta];
-    return (R.ticket == ticket && c->res_group[R.buf] == R.group) ? &R : nullptr;  // (the second half: its group's slot has not gone to a later group)
+    if (R.ticket != ticket) { return nullptr; }
+    if (R.held) { return &R; }  // (its bytes are where the host was told, whatever has happened to the ring since)
+    return (R.epoch == c->res_epoch && tick_results_region(c, R.group)) ? &R : nullptr;  // (the ring has not come round to its group's region)
 }
 int sdrpp_result_ready(sdrpp_ctx* c, uint64_t ticket) {
     if (c && ticket_is_held_back(c, ticket)) { return 0; }
@@ -1822,9 +1838,10 @@ int sdrpp_result_wait(sdrpp_ctx* c, uint64_t ticket, sdrpp_result* out) {
     }
     if (!tick_is_done(c, R->done_tick)) { return fail(c, SDRPP_ERR_HIP, "tick %llu did not complete", (unsigned long long)R->done_tick); }
     if (!R->held) {
+        sdrpp_ctx::ResRegion* g = tick_results_region(c, R->group);
+        if (!g) { return fail(c, SDRPP_ERR_NOT_FOUND, "no results for block %llu (overwritten)", (unsigned long long)ticket); }
         R->held = true;
-        R->base = c->res_host[R->buf];
-        c->res_held[R->buf]++;
+        g->held++;
     }
     const char* base = R->base;
     out->ticket = ticket;
@@ -1849,16 +1866,23 @@ int sdrpp_result_release(sdrpp_ctx* c, uint64_t ticket) {
     if (!c || ticket == 0 || ticket > c->pushes) { return c ? SDRPP_ERR_NOT_FOUND : SDRPP_ERR_INVALID; }
     sdrpp_ctx::Result& R = c->res[ticket % kResMeta];
     if (R.ticket != ticket) { return SDRPP_ERR_NOT_FOUND; }
-    const int buf = R.buf;
-    if (R.held && c->res_held[buf] > 0) { c->res_held[buf]--; }
+    if (R.held) {
+        if (sdrpp_ctx::ResRegion* g = tick_results_region(c, R.group)) {
+            if (g->held > 0) { g->held--; }
+        }
+        if (R.epoch != c->res_epoch) {  // a ring the results outgrew while the host held this block: freed with its last held block
+            for (size_t i = 0; i < c->res_retired.size(); i++) {
+                if (c->res_retired[i].epoch == R.epoch && --c->res_retired[i].held <= 0) {
+                    DeviceScope dev_scope_(c);
+                    (void)hipHostFree(c->res_retired[i].ring);
+                    c->res_retired.erase(c->res_retired.begin() + (long)i);
+                    break;
+                }
+            }
+        }
+    }
     R.held = false;
     R.ticket = 0;
-    std::vector<char*>& old = c->res_retired[buf];  // (buffers this slot outgrew while the host held blocks of it)
-    if (c->res_held[buf] == 0 && !old.empty()) {
-        DeviceScope dev_scope_(c);
-        for (char* q : old) { (void)hipHostFree(q); }
-        old.clear();
-    }
     return SDRPP_OK;
 }
 

@@ -288,35 +288,75 @@ size_t tick_results_need(sdrpp_ctx* c) {
 }
 int tick_results_ensure(sdrpp_ctx* c) {
     const size_t need = tick_results_need(c);
-    if (need <= c->res_cap) { return SDRPP_OK; }
-    // The slots grow (a VFO was added, a larger view / FFT configured) in the middle of a run: results that are complete or on their way
+    if (need <= c->res_cap && c->res_ring) { return SDRPP_OK; }
+    // The ring grows (a VFO was added, a larger view / FFT configured) in the middle of a run: results that are complete or on their way
     // but not yet collected must survive — a host keeps tickets across such a change (IQFrontEnd: pendingTickets across tempStop / addVFO).
-    // Everything queued runs to its end first, then every live slot moves into its larger buffer; a slot the host is holding (a block of it handed
-    // out by sdrpp_result_wait) keeps its old buffer alive until it is released — the pointers the host was given stay valid.
+    // Everything queued runs to its end first, then the ring's content moves into the larger one at the same offsets; a ring of which the host
+    // is holding blocks (handed out by sdrpp_result_wait) stays alive until they are released — the pointers the host was given stay valid.
     int rc = tick_drain(c);
     if (rc) { return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     tick_wait_done(c, c->ticks);
     const size_t cap = need + need / 8 + 4096;
-    for (int i = 0; i < kResSlots; i++) {
-        char* nh = nullptr;
-        char* nd = nullptr;
-        if (hipHostMalloc((void**)&nh, cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&nd, nh, 0) != hipSuccess) {
-            if (nh) { (void)hipHostFree(nh); }
-            return fail(c, SDRPP_ERR_NOMEM, "page-locked result slots of %zu bytes", cap);  // (slots < i are already the larger ones: res_cap stays, the next push tries again)
-        }
-        char* old = c->res_host[i];
-        if (old && c->res_group[i] != 0 && c->res_cap_slot[i] > 0) { memcpy(nh, old, std::min(cap, c->res_cap_slot[i])); }
-        if (old) {
-            if (c->res_held[i] > 0) { c->res_retired[i].push_back(old); }  // freed when the slot's last held block is released / at sdrpp_destroy
-            else { (void)hipHostFree(old); }
-        }
-        c->res_host[i] = nh;
-        c->res_dev[i] = nd;
-        c->res_cap_slot[i] = cap;
+    const size_t bytes = (size_t)kResSlots * ((cap + 4095) & ~(size_t)4095);
+    char* nh = nullptr;
+    char* nd = nullptr;
+    if (hipHostMalloc((void**)&nh, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&nd, nh, 0) != hipSuccess) {
+        if (nh) { (void)hipHostFree(nh); }
+        return fail(c, SDRPP_ERR_NOMEM, "page-locked result ring of %zu bytes", bytes);
     }
+    if (c->res_ring) {
+        int held = 0;
+        for (auto& g : c->res_live) {
+            memcpy(nh + g.off, c->res_ring + g.off, g.bytes);
+            held += g.held;
+        }
+        for (auto& R : c->res) {  // blocks the host has not asked for yet follow their bytes into the new ring (held ones keep the address they were given)
+            if (R.ticket != 0 && !R.held && R.epoch == c->res_epoch && R.base) {
+                R.base = nh + (R.base - c->res_ring);
+                R.epoch = c->res_epoch + 1;
+            }
+        }
+        if (held > 0) { c->res_retired.push_back(sdrpp_ctx::ResRetired{ c->res_ring, c->res_epoch, held }); }
+        else { (void)hipHostFree(c->res_ring); }
+    }
+    c->res_ring = nh;
+    c->res_ring_dev = nd;
+    c->res_ring_bytes = bytes;
     c->res_cap = cap;
+    c->res_epoch++;
     return SDRPP_OK;
+}
+// a region of the result ring for launch group `gid`; regions the ring has come round to are taken back, oldest first (their blocks' results are
+// gone: sdrpp_result_wait says so), unless the host still holds one — then nothing is touched and the push fails
+int tick_results_alloc(sdrpp_ctx* c, uint64_t gid, size_t bytes, size_t* off_out) {
+    const size_t need = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    if (!c->res_ring || need > c->res_ring_bytes) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes, ring of %zu", need, c->res_ring_bytes); }
+    size_t off = c->res_head;
+    if (off + need > c->res_ring_bytes) { off = 0; }
+    size_t npop = 0;
+    for (size_t i = 0; i < c->res_live.size(); i++) {
+        const sdrpp_ctx::ResRegion& g = c->res_live[i];
+        if (g.off < off + need && off < g.off + g.bytes) { npop = i + 1; }
+    }
+    for (size_t i = 0; i < npop; i++) {
+        if (c->res_live[i].held > 0) {
+            return fail(c, SDRPP_ERR_INVALID, "results of launch group %llu are still held (%d blocks) and the result ring has come round to them: release results sooner", (unsigned long long)c->res_live[i].gid,
+                        c->res_live[i].held);
+        }
+    }
+    c->res_live.erase(c->res_live.begin(), c->res_live.begin() + (long)npop);
+    c->res_live.push_back(sdrpp_ctx::ResRegion{ gid, off, need, 0 });
+    c->res_head = off + need;
+    *off_out = off;
+    return SDRPP_OK;
+}
+sdrpp_ctx::ResRegion* tick_results_region(sdrpp_ctx* c, uint64_t gid) {
+    for (auto it = c->res_live.rbegin(); it != c->res_live.rend(); ++it) {
+        if (it->gid == gid) { return &*it; }
+        if (it->gid < gid) { break; }
+    }
+    return nullptr;
 }
 
 // ---- what a block's results consist of: one push — or a launch group of k pushes (c->grp_ends: their cumulative ends), planned as ONE block ----
@@ -328,25 +368,26 @@ int64_t tick_frames_by(const sdrpp_ctx* c, int64_t e) {  // lines complete once 
     const int64_t a = c->plan_fft_pos0 + e - c->nz - c->plan_fft_next0 * P;
     return a >= 0 ? a / P + 1 : 0;
 }
-int tick_results_describe(sdrpp_ctx* c, uint64_t first_ticket, int k, std::vector<ResCopy>& copies) {
+int tick_results_describe(sdrpp_ctx* c, uint64_t first_ticket, int k, std::vector<ResCopy>& copies, size_t* region_off) {
     copies.clear();
-    const int slot = (int)(c->groups % kResSlots);
+    *region_off = 0;
     if (!c->res_flags) {
-        for (int j = 0; j < k; j++) { c->res[(first_ticket + (uint64_t)j) % kResMeta] = sdrpp_ctx::Result{}; }
+        for (int j = 0; j < k; j++) {
+            sdrpp_ctx::Result& R0 = c->res[(first_ticket + (uint64_t)j) % kResMeta];
+            if (!R0.held) { R0 = sdrpp_ctx::Result{}; }
+        }
         return SDRPP_OK;
     }
-    if (c->res_held[slot] > 0) {
-        return fail(c, SDRPP_ERR_INVALID, "a result slot is still held (%d blocks of launch group %llu: release results before %d more groups are pushed)", c->res_held[slot], (unsigned long long)c->res_group[slot], kResSlots);
-    }
-    c->res_group[slot] = c->groups;
     const bool split = k > 1;
     if (split && (int)c->grp_ends.size() != k) { return fail(c, SDRPP_ERR_INVALID, "internal: %d blocks, %zu push ends", k, c->grp_ends.size()); }
     sdrpp_ctx::Result* R[kGroupMax];
     for (int j = 0; j < k; j++) {
         R[j] = &c->res[(first_ticket + (uint64_t)j) % kResMeta];
+        if (R[j]->held) { return fail(c, SDRPP_ERR_INVALID, "results of block %llu are still held %d pushes later: release results sooner", (unsigned long long)R[j]->ticket, kResMeta); }
+    }
+    for (int j = 0; j < k; j++) {
         *R[j] = sdrpp_ctx::Result{};
         R[j]->ticket = first_ticket + (uint64_t)j;
-        R[j]->buf = slot;
         R[j]->group = c->groups;
         R[j]->fft_size = c->fft_size;
         R[j]->data_width = c->data_width;
@@ -401,16 +442,26 @@ int tick_results_describe(sdrpp_ctx* c, uint64_t first_ticket, int k, std::vecto
             off += (bytes + 15) & ~(size_t)15;
         }
     }
-    if (off > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes exceed the slot (%zu)", off, c->res_cap); }
+    if (off > c->res_cap) { return fail(c, SDRPP_ERR_INVALID, "internal: results of %zu bytes exceed what a launch may deliver (%zu)", off, c->res_cap); }
+    int rc = tick_results_alloc(c, c->groups, off, region_off);
+    if (rc) {
+        for (int j = 0; j < k; j++) { R[j]->ticket = 0; }
+        return rc;
+    }
+    for (int j = 0; j < k; j++) {
+        R[j]->base = c->res_ring + *region_off;
+        R[j]->epoch = c->res_epoch;
+    }
     return SDRPP_OK;
 }
 // gather roles of the block just planned -> c->emits (one level behind the producers); fills the result entries of its pushes
 int tick_results_plan(sdrpp_ctx* c, uint64_t first_ticket, int k) {
     static thread_local std::vector<ResCopy> copies;
-    int rc = tick_results_describe(c, first_ticket, k, copies);
+    size_t region = 0;
+    int rc = tick_results_describe(c, first_ticket, k, copies, &region);
     if (rc || copies.empty()) { return rc; }
     Lev<CopyJob> jobs;
-    char* base = c->res_dev[c->groups % kResSlots];
+    char* base = c->res_ring_dev + region;
     for (auto& q : copies) { jobs.add(q.level, CopyJob{ q.src, base + q.off, (long long)q.bytes, 0x100, 0 }); }
     if (!arena_push_lev(c, jobs)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }
     for (int l = 0; l < jobs.top; l++) {
@@ -431,9 +482,10 @@ int tick_results_direct(sdrpp_ctx* c, uint64_t first_ticket, int k) {
     int rc = tick_results_ensure(c);
     if (rc) { return rc; }
     static thread_local std::vector<ResCopy> copies;
-    rc = tick_results_describe(c, first_ticket, k, copies);
+    size_t region = 0;
+    rc = tick_results_describe(c, first_ticket, k, copies, &region);
     if (rc) { return rc; }
-    char* base = c->res_host[c->groups % kResSlots];
+    char* base = c->res_ring + region;
     for (auto& q : copies) { HIPCHK(c, hipMemcpyAsync(base + q.off, q.src, q.bytes, hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int j = 0; j < k; j++) {

@@ -217,8 +217,13 @@ public:
     // results earlier makes the library run the missing stages without new input, launch by launch.
     // Takes effect with the next block.  The tail still in flight when the input stops is handed out by drainPipeline() (worker stopped)
     // or with the next blocks.
-    void setPipelining(bool enabled, int lagBlocks = 8) {
+    // groupBlocks > 1 (round 6): up to that many consecutive blocks share ONE launch while the device is the slower side
+    // (sdrpp_set_pipeline_group, adaptive: a block goes out at once while the device has fewer than two launches in flight — a real-time stream
+    // keeps one launch per block and its latency).  Results are handed out as soon as they are complete (polled once per block), at the latest
+    // when (depth + 1) x groupBlocks blocks are outstanding.
+    void setPipelining(bool enabled, int lagBlocks = 8, int groupBlocks = 1) {
         _pipeLag = lagBlocks < 1 ? 1 : (lagBlocks > 12 ? 12 : lagBlocks);
+        _pipeGroup = groupBlocks < 1 ? 1 : (groupBlocks > SDRPP_GROUP_MAX ? SDRPP_GROUP_MAX : groupBlocks);
         _pipelining = enabled;
     }
     // Hands out everything still in flight (call with the block stopped, or from a control operation): -1 if a stream was stopped
@@ -419,7 +424,7 @@ public:
         if (!_buffering) {
             drainControl();
             if (_pipelining && pipelineEligible()) {
-                if (pipeOn && pipeFlags != pipelineFlags() && leavePipelined() < 0) { return -1; }  // (a stream was bound / a chain configured since)
+                if (pipeOn && (pipeFlags != pipelineFlags() || pipeGroupOn != _pipeGroup) && leavePipelined() < 0) { return -1; }  // (a stream was bound / a chain configured / the group size changed since)
                 if (!pipeOn && enterPipelined() < 0) { return -1; }
                 if (!iqStreams.empty() && !(pipeFlags & 8)) {  // bound streams, no chain in front: they receive this very block (Splitter::run) — when its turn comes
                     tapPending.emplace_back(0, std::vector<dsp::complex_t>(_in->readBuf, _in->readBuf + count));
@@ -474,8 +479,12 @@ public:
                 // (a block's results are complete `depth` launches after its push — 6-7 levels for a WFM bank + FFT, 12 with the AF chain, 3 more behind a
                 // pre-processing chain: asking for them sooner makes the library run the missing stages as launches without new input)
                 int64_t pst[SDRPP_PIPELINE_STATS_HEAD] = {};
-                const int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(SDRPP_RESULT_SLOTS - 2, std::max(_pipeLag, (int)pst[4] + 1)) : _pipeLag;
-                if ((int)pendingTickets.size() > lagNow) {  // one block out per block in; its hand-over runs on the helpers while the next block arrives
+                int lagNow = (sdrpp_pipeline_stats(ctx, pst, SDRPP_PIPELINE_STATS_HEAD) >= 5) ? std::min(SDRPP_RESULT_SLOTS - 2, std::max(_pipeLag, (int)pst[4] + 1)) : _pipeLag;
+                lagNow *= pipeGroupOn;  // (`depth` counts LAUNCHES: with launch groups a block is complete depth launches of up to pipeGroupOn blocks later)
+                // one block out per block in, its hand-over on the helpers while the next block arrives — the oldest block when more than lagNow are
+                // outstanding (the device is the slower side: waiting for it is what back-pressure means), else the oldest one only if it is
+                // complete already (a real-time stream: results leave as soon as they exist, not a fixed number of blocks late)
+                if (!pendingTickets.empty() && ((int)pendingTickets.size() > lagNow || (pipeGroupOn > 1 && sdrpp_result_ready(ctx, pendingTickets.front()) == 1))) {
                     const uint64_t t = pendingTickets.front();
                     pendingTickets.erase(pendingTickets.begin());
                     if (startDelivery(t) < 0) { return -1; }
@@ -559,13 +568,14 @@ public:
 #define SDRPP_BLOCKS_TICK0()
 #endif
     static constexpr int64_t SDRPP_GPU_MAX_BLOCK = 1000000;
+    static constexpr int kHelpers = 8;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log)
 
 protected:
     // dsp::block hooks: the frame-buffer worker lives and dies with the block's own worker (SampleFrameBuffer::doStart / doStop,
     // frame_buffer.h:105-124)
     void doStart() override {
         stopFrameWorker = false;
-        helpers.start(6);  // hand-overs: 32 stream swaps per block are 32 futex wake-ups (~3 us each for the waker)
+        helpers.start(kHelpers);  // hand-overs: 32 stream swaps per block are 32 futex wake-ups (~3 us each for the waker)
         stagers.start(3);
         workerDone.store(false, std::memory_order_relaxed);
         workerThread = std::thread([this]() {
@@ -669,11 +679,14 @@ private:
             _pipelining = false;
             return 0;
         }
+        pipeGroupOn = _pipeGroup;
+        sdrpp_set_pipeline_group(ctx, pipeGroupOn, 1);
         pipeOn = true;
         return 0;
     }
     int leavePipelined() {
         const int rc = drainPipeline();
+        sdrpp_set_pipeline_group(ctx, 1, 0);
         sdrpp_set_pipelined(ctx, 0, 0);
         sdrpp_set_deferred(ctx, 1);
         pipeOn = false;
@@ -745,7 +758,7 @@ private:
                 }
             }
         }
-        const int groups = 6;  // (one per helper)
+        const int groups = kHelpers;  // (one per helper)
         for (int g = 0; g < groups && !order.empty(); g++) {
             jobs.emplace_back([this, g, groups, &order, &r]() {
                 std::atomic<bool>& failed = deliveryFailed;
@@ -898,7 +911,7 @@ private:
             std::vector<std::pair<RxVFO*, int>> order;
             k = 0;
             for (auto& kv : vfos) { order.emplace_back(kv.second, k++); }
-            const int groups = 6;
+            const int groups = kHelpers;
             for (int g = 0; g < groups; g++) {
                 jobs.emplace_back([this, g, groups, order, &failed]() {
                     for (size_t q = (size_t)g; q < order.size(); q += (size_t)groups) {
@@ -1080,6 +1093,8 @@ private:
     std::atomic<bool> _buffering{ false };
     std::atomic<bool> _pipelining{ false };
     int _pipeLag = 8;
+    int _pipeGroup = 1;                     // setPipelining: blocks one launch may carry
+    int pipeGroupOn = 1;                    // ... as the context has it now (worker)
     bool pipeOn = false;                    // the context is in pipelined mode (owned by the worker)
     std::atomic<uint64_t> _blocksTaken{ 0 };
     std::atomic<bool> workerDone{ true };   // the worker thread has left its loop (doStop's grace period)

@@ -2,8 +2,9 @@
 // (core/src/dsp/bench/speed_tester.h:31-92): an unthrottled source thread swap()s fixed-size IQ blocks into the front end's input
 // stream (back-pressured by the stream hand-off), sink threads read() / flush() every output stream, and the rate is samples
 // ingested per wall second.  Workload = BASELINE cfg 3 (65536-point FFT, nvfo WFM VFOs 300 kHz apart) at the block size given.
-//   usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered 0|1> [pipelined 0|1]
-// Prints one JSON object.  Built by bench.py against tests/host_cpp/standalone (the test double of dsp::block / dsp::stream).
+//   usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered 0|1> [pipelined 0|1 [blocks per launch]]
+// Prints one JSON object.  Built by oracle/Makefile against the reference's own dsp/stream.h + dsp/block.h (oracle/_ref/bench_blocks_ref: what
+// bench.py runs) and, where the reference tree is absent, by bench.py against tests/host_cpp/standalone (the test double of those headers).
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -34,6 +35,7 @@ int main(int argc, char** argv) {
     const double seconds = atof(argv[6]);
     const bool buffered = atoi(argv[7]) != 0;
     const bool pipelined = argc > 8 && atoi(argv[8]) != 0;  // bypass path as one launch per block (IQFrontEnd::setPipelining)
+    const int group = argc > 9 ? atoi(argv[9]) : 1;         // ... or up to `group` blocks per launch while the device is the slower side
     g_line.assign((size_t)fftSize, 0.0f);
 
     // four distinct blocks of tones + FM carriers (content does not change the work)
@@ -55,7 +57,7 @@ int main(int argc, char** argv) {
     dsp::stream<dsp::complex_t> src;
     sdrpp_gpu::IQFrontEnd fe;
     fe.init(&src, sr, buffered, 1, false, fftSize, sr / (double)fftSize /* dense framing */, sdrpp_gpu::IQFrontEnd::NUTTALL, acquire, release, nullptr, 0, &plans);
-    fe.setPipelining(pipelined);
+    fe.setPipelining(pipelined, 8, group);
     std::vector<sdrpp_gpu::RxVFO*> vfos;
     for (int k = 0; k < nvfo; k++) {
         sdrpp_gpu::RxVFO* v = fe.addVFO("vfo" + std::to_string(k), 250000.0, 150000.0, (k - (nvfo - 1) / 2.0) * 300e3);
@@ -103,7 +105,7 @@ int main(int argc, char** argv) {
 #endif
     // the frame buffer does not back-pressure its producer (an overrun drops a lap, like the reference's): count what came OUT
     const double processed = nvfo > 0 ? ((double)(a1 - a0) / nvfo) * (sr / 250000.0) : (double)(l1 - l0) * fftSize;
-    printf("{\"block\": %d, \"buffered\": %s, \"pipelined\": %s, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f}\n", block,
-           buffered ? "true" : "false", pipelined ? "true" : "false", nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt);
+    printf("{\"block\": %d, \"buffered\": %s, \"pipelined\": %s, \"blocks_per_launch_max\": %d, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f}\n", block,
+           buffered ? "true" : "false", pipelined ? "true" : "false", pipelined ? group : 1, nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt);
     return 0;
 }

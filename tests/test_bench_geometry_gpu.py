@@ -117,12 +117,17 @@ def test_cfg3_pipelined_bench_geometry_vs_oracle(fed):
 
 @pytest.mark.parametrize("B,nblk", [(1000000, 10), (307200, 12)])
 def test_cfg4_pipelined_vs_oracle(B, nblk):
-    """(c) 128 VFOs NFM / AM / USB at 61.44 MS/s + the 2^20-point FFT, pipelined.  NFM / AM against the PINNED oracle; USB against the oracle
-    with its ideal-NCO switch (the default closed-form NCO differs from the reference by the reference rotator's own drift, DESIGN.md 5 —
-    the reference-rotator mode that meets the pinned oracle is tested in test_full_configs_gpu.py)."""
+    """(c) 128 VFOs NFM / AM / USB at 61.44 MS/s + the 2^20-point FFT, pipelined.  EVERY channel against the PINNED oracle (the reference's own
+    code paths, its float rotator included): NFM / AM over the whole stream; USB over the window in which the default closed-form NCO holds
+    BASELINE.json's 1e-5 against the reference's rotator — the first 2e5 input samples (measured: test_closed_form_nco_validity_window_vs_pinned_oracle;
+    why no calibration of the closed form can widen it: profiles/r06_rotator_drift.md — the rotator's rounding drift is a random walk of ~3e-8 rad
+    per step on top of a slope that changes with the phase, 2e-5 .. 1e-3 rad after 10^6 samples with the best linear fit taken out).  Beyond the
+    window the USB channels are checked against the oracle with an EXACT NCO in the reference's place (`ideal_nco`: a statement about this
+    library's arithmetic, not about parity); parity with the reference's own phase sequence for any length is nco_mode 2
+    (test_full_configs_gpu.py::test_cfg4_all_128_vfos_every_mode_within_1e5[reference_rotator])."""
     from sdrplusplus_amd import capi, workloads
 
-    RB = 307200
+    RB, W = 307200, 200000
     x = _synth_threaded(4, B * nblk, seed=0x4C)
     ctx = capi.Context(0, max_push=B)
     info = workloads.setup(ctx, 4, dense_fft=True, data_width=1024)
@@ -140,12 +145,36 @@ def test_cfg4_pipelined_vs_oracle(B, nblk):
     spec = S.OracleSpectrum(N, N, 0, capi.design_fft_window(2, N))
     nlines = _check_lines(spec, info["view"], x, cuts, results)
     assert nlines == (B * nblk) // N
-    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m], ideal_nco=(m == "USB")) for m, r, bw, c, _ in info["plan"]]
     # the reference's blocks: RB-sample blocks restarting with every push (sdrpp_set_reference_block cuts every push from its start)
     per = [RB] * (B // RB) + ([B % RB] if B % RB else [])
-    ref = _oracle_streams(chains, x, per * nblk)
-    worst = _audio_check(info, results, ref, what="cfg4 B=%d" % B)
-    print("cfg4 pipelined B=%d: %d 2^20-point lines bit-exact, worst relative audio error per mode %s" % (B, nlines, {m: "%.2e" % v for m, v in worst.items()}))
+    pinned = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m]) for m, r, bw, c, _ in info["plan"]]
+    ref = _oracle_streams(pinned, x, per * nblk)
+    worst = {}
+    usb = []
+    for k, (vid, (m, _, _, _, _)) in enumerate(zip(info["vids"], info["plan"])):
+        ga = np.concatenate([r["vfo"][vid] for r in results])
+        oa = ref[k][1]
+        assert ga.shape == oa.shape, (k, m, ga.shape, oa.shape)
+        if m == "USB":  # the window that holds: audio produced by the first W input samples, relative to the RMS of the whole reference stream
+            nwin = int(len(oa) * (W / float(B * nblk)))
+            assert nwin >= 70, nwin
+            e = rms(ga[:nwin] - oa[:nwin]) / max(1.0, rms(oa))
+            usb.append(k)
+        else:
+            e = rms(ga - oa) / max(1.0, rms(oa))
+        worst[m] = max(worst.get(m, 0.0), e)
+        assert e < 1e-5, ("cfg4 B=%d vs the pinned oracle" % B, k, m, e)
+    assert len(usb) >= 40
+    ideal = [S.OracleChain(info["sr"], *info["plan"][k][1:4], S.MODES["USB"], ideal_nco=True) for k in usb]
+    ref_i = _oracle_streams(ideal, x, per * nblk)
+    worst_i = 0.0
+    for q, k in enumerate(usb):
+        ga = np.concatenate([r["vfo"][info["vids"][k]] for r in results])
+        e = rms(ga - ref_i[q][1]) / max(1.0, rms(ref_i[q][1]))
+        worst_i = max(worst_i, e)
+        assert e < 1e-5, ("cfg4 B=%d USB vs the exact-NCO oracle, whole stream" % B, k, e)
+    print("cfg4 pipelined B=%d: %d 2^20-point lines bit-exact; vs the PINNED oracle, worst relative audio error per mode %s (USB: first %d input samples); USB over all %d samples vs the exact-NCO oracle %.2e"
+          % (B, nlines, {m: "%.2e" % v for m, v in worst.items()}, W, B * nblk, worst_i))
     del keep
     ctx.close()
 

@@ -100,8 +100,10 @@ def test_cfg4_1m_point_line_vs_oracle():
 def test_cfg4_all_128_vfos_every_mode_within_1e5(nco):
     """BASELINE cfg 4 at full size: all 128 VFOs (NFM / AM / USB at offsets (k - 63.5) * 400 kHz: none a multiple of sr/8), 10.1 M
     samples = 33 reference blocks of 307 200, pushed three blocks at a time with sdrpp_set_reference_block.
-      reference_rotator: device runs the reference's float rotator recursion -> compared with the PINNED oracle (= the reference);
-      closed_form      : default device path -> compared with the oracle's ideal-NCO variant (isolates the rotator).
+      reference_rotator: device runs the reference's float rotator recursion -> every channel, whole stream, against the PINNED oracle (= the reference);
+      closed_form      : default device path -> NFM / AM over the whole stream and USB over the first 2e5 input samples against the PINNED oracle
+                         (the window in which the closed form holds 1e-5 against the reference's drifting rotator); USB beyond it against the
+                         oracle with an exact NCO (isolates the rotator; not a parity statement).
     Every mode, every VFO: audio within 1e-5 RMS (relative to max(1, rms)), as BASELINE.json's north_star states."""
     from sdrplusplus_amd import capi, workloads
 
@@ -112,7 +114,7 @@ def test_cfg4_all_128_vfos_every_mode_within_1e5(nco):
     ctx.set_reference_block(B)
     info = workloads.setup(ctx, 4, fft=False)
     assert len(info["vids"]) == 128
-    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m], ideal_nco=(nco == "closed_form")) for m, r, bw, c, _ in info["plan"]]
+    chains = [S.OracleChain(info["sr"], r, bw, c, S.MODES[m]) for m, r, bw, c, _ in info["plan"]]  # PINNED: the reference's own rotator
     ref = _oracle_streams(chains, x, [B] * nblk)
     got = [[] for _ in info["vids"]]
     for p in range(0, nblk, per_push):
@@ -120,13 +122,30 @@ def test_cfg4_all_128_vfos_every_mode_within_1e5(nco):
         for k, vid in enumerate(info["vids"]):
             got[k].append(ctx.vfo_read(vid))
     worst = {}
+    W = 200000  # closed form, SSB: the window in which it holds 1e-5 against the reference's rotator (test_bench_geometry_gpu.py::test_closed_form_nco_validity_window_vs_pinned_oracle)
+    usb = []
     for k, (m, _, _, _, _) in enumerate(info["plan"]):
         ga, oa = np.concatenate(got[k]), ref[k][1]
         assert ga.shape == oa.shape, (k, m, ga.shape, oa.shape)
-        e = rms(ga - oa) / max(1.0, rms(oa))
+        if nco == "closed_form" and m == "USB":
+            nwin = int(len(oa) * (W / float(B * nblk)))
+            e = rms(ga[:nwin] - oa[:nwin]) / max(1.0, rms(oa))
+            usb.append(k)
+        else:
+            e = rms(ga - oa) / max(1.0, rms(oa))
         worst[m] = max(worst.get(m, 0.0), e)
         assert e < 1e-5, (nco, k, m, e)
-    print("cfg4 %s worst relative audio error per mode over 10.1 M samples: %s" % (nco, {m: "%.2e" % v for m, v in worst.items()}))
+    msg = "cfg4 %s vs the PINNED oracle, worst relative audio error per mode over 10.1 M samples%s: %s" % (nco, " (USB: first %d input samples)" % W if usb else "", {m: "%.2e" % v for m, v in worst.items()})
+    if usb:  # beyond the window: the same channels against the oracle with an exact NCO in the reference's place (this library's arithmetic, not parity)
+        ideal = [S.OracleChain(info["sr"], *info["plan"][k][1:4], S.MODES["USB"], ideal_nco=True) for k in usb]
+        ref_i = _oracle_streams(ideal, x, [B] * nblk)
+        wi = 0.0
+        for q, k in enumerate(usb):
+            e = rms(np.concatenate(got[k]) - ref_i[q][1]) / max(1.0, rms(ref_i[q][1]))
+            wi = max(wi, e)
+            assert e < 1e-5, (nco, "USB vs the exact-NCO oracle", k, e)
+        msg += "; USB over the whole stream vs the exact-NCO oracle %.2e" % wi
+    print(msg)
     ctx.close()
 
 

@@ -403,42 +403,52 @@ def test_pipelined_result_slots_and_modes(backend):
     from sdrplusplus_amd import capi, workloads
 
     nv, B = (20, 4000) if backend == "gpu" else (17, 2000)  # (>= 17 VFOs: the matrix-core front end, i.e. blocks that really run as ticks)
-    S = capi.RESULT_SLOTS
-    x = workloads.synth(3, B * (S + 12), seed=3, nvfo=nv)
+    S, M = capi.RESULT_SLOTS, capi.RESULT_SLOTS * capi.GROUP_MAX
+    x = workloads.synth(3, B * 16, seed=3, nvfo=nv)
+    blk_of = lambda i: x[(i % 16) * B:(i % 16 + 1) * B]
     (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 0, flags=1)
     with pytest.raises(capi.SdrppError):
         cb.set_deferred(True)
     refs = []
     for i in range(S + 4):
-        blk = x[i * B:(i + 1) * B]
-        refs.append(_ordinary_results(ca, va, blk, False))
-        cb.push(blk)
-    # S slots: blocks 1 .. 4 have been overwritten by S + 1 .. S + 4
-    with pytest.raises(capi.SdrppError):
-        cb.result_wait(2)
-    got = cb.result_wait(7)
-    _compare({"vfo": dict(zip(vb, refs[6]["vfo"].values()))}, got, False, "block 7")
-    assert cb.result_ready(S + 4) in (True, False)
+        refs.append(_ordinary_results(ca, va, blk_of(i), False))
+        cb.push(blk_of(i))
+    # the result ring holds AT LEAST the last S launches of max_push samples (round 6: a byte ring — more when the launches deliver less than the
+    # largest possible; the entries themselves are a ring of S x GROUP_MAX blocks): the newest S blocks are all there
+    for t in (5, 7, S + 4):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, refs[t - 1]["vfo"].values()))}, got, False, "block %d" % t)
+        if t != 7:
+            cb.result_release(t)
+    assert cb.result_ready(S + 3) in (True, False)
     cb.pipeline_flush()
     cb.sync()
-    assert cb.result_ready(S + 4)
-    # block 7 is still held: pushing on until its slot comes round again must fail, and work again after the release
+    assert cb.result_ready(S + 3)
+    # block 7 is still held: pushing on until the ring comes round to it must fail (at the latest when its ENTRY comes round, M pushes after it),
+    # change nothing, and work again after the release; by then the oldest blocks are gone
+    n0 = S + 4
+    failed_at = None
+    for i in range(n0, M + 12):
+        try:
+            cb.push(blk_of(i))
+        except capi.SdrppError:
+            failed_at = i + 1
+            break
+        _ordinary_results(ca, va, blk_of(i), False)
+    assert failed_at is not None and 7 + S <= failed_at <= 7 + M, failed_at
+    assert cb.ticket() == failed_at - 1  # the push did not happen
     with pytest.raises(capi.SdrppError):
-        for i in range(S + 4, S + 12):
-            cb.push(x[i * B:(i + 1) * B])
-    assert cb.ticket() == S + 6  # block S + 7 would have needed slot 7
+        cb.result_wait(2)  # long overwritten
     cb.result_release(7)
-    blk = x[(S + 6) * B:(S + 7) * B]
-    for i in range(S + 4, S + 6):
-        _ordinary_results(ca, va, x[i * B:(i + 1) * B], False)
-    ref = _ordinary_results(ca, va, blk, False)
-    cb.push(blk)
-    got = cb.result_wait(S + 7)
-    _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "block S + 7")
+    ref = _ordinary_results(ca, va, blk_of(failed_at - 1), False)
+    cb.push(blk_of(failed_at - 1))
+    got = cb.result_wait(failed_at)
+    _compare({"vfo": dict(zip(vb, ref["vfo"].values()))}, got, False, "the block after the release")
+    S = failed_at - 7  # (the code below names blocks relative to S + 7)
     # leaving the mode flushes; ordinary passes continue the same streams
     cb.result_release(S + 7)
     cb.set_pipelined(False)
-    blk = x[(S + 7) * B:(S + 8) * B]
+    blk = blk_of(S + 7)
     ref = _ordinary_results(ca, va, blk, False)
     cb.push(blk)
     for v_a, v_b in zip(va, vb):
@@ -783,25 +793,28 @@ def test_grouped_results_hold_release_and_adaptive(backend):
     r1 = cb.result_wait(1, copy=False)
     a1 = {v: a.copy() for v, a in r1["vfo"].items()}
     cb.result_release(2)
-    # 24 groups later the slot of group 1 comes round: block 1 is still held -> the push that sends that group out fails (and takes the group's
-    # tickets back), the stream goes on once the block is released
-    i = 4
-    while cb.pipeline_group_stats()["groups"] < capi.RESULT_SLOTS or cb.pipeline_group_stats()["held"]:
-        cb.push(x[(i % 8) * B:(i % 8 + 1) * B])
+    # the result ring holds at least RESULT_SLOTS launches of max_push samples (more of these small groups), the ring of result entries RESULT_SLOTS x
+    # GROUP_MAX blocks.  When either comes round to block 1, which is still held, the push that sends that group out fails (and takes the group's
+    # tickets back); the stream goes on once the block is released
+    i, failed_at = 4, None
+    while failed_at is None and i < capi.GROUP_MAX * capi.RESULT_SLOTS + 8:
+        t0 = cb.ticket()
+        try:
+            cb.push(x[(i % 8) * B:(i % 8 + 1) * B])
+        except capi.SdrppError:
+            failed_at = cb.pipeline_group_stats()["groups"]
+            assert cb.ticket() == t0 - 1 and cb.pipeline_group_stats()["held"] == 0  # the group (this push and the one held before it) did not happen
+            break
         i += 1
         if i >= 8 and not cb.pipeline_group_stats()["held"]:
             for t in (i - 5, i - 4):  # (blocks of groups that have gone out: asking for them flushes nothing that is held)
                 cb.result_wait(t)
                 cb.result_release(t)
-    assert cb.pipeline_group_stats()["groups"] == capi.RESULT_SLOTS
+    assert failed_at is not None and capi.RESULT_SLOTS <= failed_at <= capi.GROUP_MAX * capi.RESULT_SLOTS // 2 + 2, failed_at
     for v in vb:
         assert np.array_equal(a1[v], r1["vfo"][v])  # untouched while held
-    t0 = cb.ticket()
-    cb.push(x[0:B])
-    with pytest.raises(capi.SdrppError):
-        cb.push(x[B:2 * B])
-    assert cb.ticket() == t0 and cb.pipeline_group_stats()["held"] == 0  # the group did not happen
     cb.result_release(1)
+    t0 = cb.ticket()
     cb.push(x[0:B])
     cb.push(x[B:2 * B])
     t = cb.ticket()
