@@ -196,6 +196,18 @@ typedef struct sdrpp_vfo_desc {
 int sdrpp_vfo_add(sdrpp_ctx* ctx, const sdrpp_vfo_desc* desc, int* id);
 int sdrpp_vfo_remove(sdrpp_ctx* ctx, int id);
 int sdrpp_vfo_count(sdrpp_ctx* ctx);
+/* RxVFO::setInSamplerate / setOutSamplerate (rx_vfo.h:35-58) — and with them IQFrontEnd::setSampleRate / setDecimation (iq_frontend.cpp:76-123) and
+ * the radio module's demodulator switch (vfo_manager.cpp:52, radio_module.h:419-563): the VFO is described anew (`desc`: new plan, new taps), the
+ * old handle dies, *new_id takes its place — and what the reference's objects carry across such a change is carried here:
+ *   keep & 1: the RxVFO's own state — the translation's phase (FrequencyXlator::setOffset swaps phaseDelta only) and the channel filter's delay line
+ *             (FIR::setTaps moves it under the new tap count, fir.h:31-52; a filter bypassed under the new settings keeps it for when it wakes up).
+ *             The decimator stages and the polyphase resampler start from cleared state, as the reference re-creates / resets them
+ *             (power_decimator.h:91-108, polyphase_resampler.h:38-67).
+ *   keep & 2: the demodulator behind it lives on (setInSamplerate: the radio's demodulator block is not touched): discriminator and audio low-pass
+ *             history, AGC / DC-blocker state, SSB's second translation.  Only where the new description has the same demodulator; a demodulator
+ *             SWITCH creates a new demodulator object in the reference too: leave the bit off.
+ * An AF chain (sdrpp_vfo_set_af) is not carried over: attach it to the new handle (it starts cleared, as afChain's blocks do after a restart). */
+int sdrpp_vfo_replace(sdrpp_ctx* ctx, int old_id, const sdrpp_vfo_desc* desc, int keep, int* new_id);
 /* RxVFO::setOffset (rx_vfo.h:72-77): only phaseDelta changes, phase stays continuous; the samples already inside the first
  * decimator's delay line keep their old rotation (the first outputs after the change are handed over sample-exactly). */
 int sdrpp_vfo_set_phase_delta(sdrpp_ctx* ctx, int id, float re, float im);
@@ -292,6 +304,14 @@ int sdrpp_wf_raster(sdrpp_ctx* ctx, int draw_data_start, int draw_data_size, int
 int sdrpp_preproc_set_reference_order(sdrpp_ctx* ctx, int on);
 int sdrpp_preproc_configure(sdrpp_ctx* ctx, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps,
                             float dc_rate, int conjugate);
+/* The same for a chain that is RE-planned while the stream runs — what IQFrontEnd's setters do to their blocks (iq_frontend.cpp:76-130):
+ *   keep & 1: the decimator's delay lines and offsets stay if the new description has the same stages (setSampleRate / setDCBlocking / setInvertIQ
+ *             do not touch the decimator; setDecimation creates new stages — PowerDecimator::setRatio, power_decimator.h:91-108 — so it passes 0 here);
+ *   keep & 2: the DC blocker continues from its estimate (DCBlocker::setRate swaps the rate only; a blocker switched off and on again is the same
+ *             object, dc_blocker.h:54-60).
+ * sdrpp_preproc_configure = keep 0: everything cleared. */
+int sdrpp_preproc_reconfigure(sdrpp_ctx* ctx, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps,
+                              float dc_rate, int conjugate, int keep);
 /* The pre-processed samples of the most recent push — what Splitter hands to streams bound with bindIQStream (iq_frontend.cpp:132-138). */
 int sdrpp_preproc_out_count(sdrpp_ctx* ctx);
 int sdrpp_preproc_read(sdrpp_ctx* ctx, float* dst_host, int max);

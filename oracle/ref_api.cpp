@@ -89,6 +89,8 @@ void ref_rxvfo_destroy(void* h) {
 }
 void ref_rxvfo_set_offset(void* h, double offset) { ((RefRxVFO*)h)->vfo.setOffset(offset); }
 void ref_rxvfo_set_bandwidth(void* h, double bandwidth) { ((RefRxVFO*)h)->vfo.setBandwidth(bandwidth); }  // rx_vfo.h:60-70 (FIR::setTaps keeps the delay line)
+void ref_rxvfo_set_in_samplerate(void* h, double sr) { ((RefRxVFO*)h)->vfo.setInSamplerate(sr); }                              // rx_vfo.h:35-43
+void ref_rxvfo_set_out_samplerate(void* h, double sr, double bandwidth) { ((RefRxVFO*)h)->vfo.setOutSamplerate(sr, bandwidth); }  // rx_vfo.h:45-58
 // count <= 1 000 000 (STREAM_BUFFER_SIZE, dsp/stream.h:9); out must hold `count` complex samples.
 int ref_rxvfo_process(void* h, int count, const float* in, float* out) {
     RefRxVFO* r = (RefRxVFO*)h;
@@ -167,6 +169,16 @@ void ref_preproc_destroy(void* h) {
     RefPreproc* p = (RefPreproc*)h;
     dsp::buffer::free(p->work);
     delete p;
+}
+// what IQFrontEnd's setters do to the chain's block objects while the stream runs (iq_frontend.cpp:76-130): setDecimation -> decim.setRatio (new stages)
+// only for ratio > 1; setSampleRate -> dcBlock.setRate (the estimate stays); setDCBlocking / setInvertIQ only take a block in or out of the chain
+void ref_preproc_set(void* h, int ratio, int dcBlocking, double dcRate, int conjugate, int newDecimator) {
+    RefPreproc* p = (RefPreproc*)h;
+    p->ratio = ratio;
+    if (newDecimator && ratio > 1) { p->decim.setRatio(ratio); }
+    p->dcBlock.setRate(dcRate);
+    p->dc = dcBlocking;
+    p->conj = conjugate;
 }
 // count <= STREAM_BUFFER_SIZE; the chain enables the decimator only for ratio > 1 (iq_frontend.cpp:37)
 int ref_preproc_process(void* h, int count, const float* in, float* out) {
@@ -360,16 +372,18 @@ double ref_bench_cfg(const float* iq, long long totalSamples, int blockSize, dou
                     if (dem[v]) { ref_demod_process(dem[v], n, (const float*)work, (float*)audio); }
                 }
             }
-            if (t == 0 && fftSize > 0) {
-                for (int rep = 0; rep < repeat; rep++)
-                for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
-                    volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
-                    fftwf_execute(plan);
-                    volk_32fc_s32f_power_spectrum_32f(db.data(), (lv_32fc_t*)fout, fftSize, fftSize);
-                }
-            }
             dsp::buffer::free(work);
             dsp::buffer::free(audio);
+        });
+    }
+    if (fftSize > 0) {  // the FFT branch on a thread of its own (the reference runs it on the Handler sink's thread, iq_frontend.cpp:41-44) — never behind a VFO worker's blocks
+        th.emplace_back([&]() {
+            for (int rep = 0; rep < repeat; rep++)
+            for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
+                volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
+                fftwf_execute(plan);
+                volk_32fc_s32f_power_spectrum_32f(db.data(), (lv_32fc_t*)fout, fftSize, fftSize);
+            }
         });
     }
     for (auto& x : th) { x.join(); }
@@ -384,6 +398,151 @@ double ref_bench_cfg(const float* iq, long long totalSamples, int blockSize, dou
         fftwf_free(fout);
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- CPU baseline as SURVEY.md 8(d) defines it: the reference's own THREADED graph, timed the way dsp::bench::SpeedTester times a block
+//      (speed_tester.h:31-56, 78-92) -------------------------------------------------------------------------------------------------------
+// IQFrontEnd (iq_frontend.cpp verbatim: inBuf -> preproc -> Splitter -> Reshaper -> Handler -> handler(), its own threads) + per VFO the RxVFO
+// that IQFrontEnd::addVFO creates on the Splitter and starts (one thread), the radio demodulator as a started dsp::block behind RxVFO::out (one
+// thread) and a reader thread that read()s / flush()es the audio stream like SpeedTester::readWorker — ~3 threads per VFO + the front end's seven,
+// every hand-over a dsp::stream swap, exactly the reference's threading model (block.h:71-73, splitter.h:46-61).  An unthrottled source thread
+// memcpy()s fixed blocks into the input stream and swap()s (SpeedTester::writeWorker).  After `warmupS` seconds the samples the source got rid
+// of during `runS` seconds are counted — back-pressured by the slowest branch — `nRuns` times; out_rates[i] = samples per second of run i.
+// Returns the number of runs measured (0 on failure).  WFM / NFM / AM / SSB demodulators as ref_demod_create initialises them.
+int ref_bench_graph(const float* iq, long long totalSamples, int blockSize, double inSR, int nVfo, const double* offsets, const double* ifRates, const double* bandwidths, const int* modes,
+                    int fftSize, double fftRate, double warmupS, double runS, int nRuns, double* out_rates, long long* out_audio_frames, long long* out_lines) {
+    struct Graph {
+        IQFrontEnd fe;
+        dsp::stream<complex_t> in;
+        std::vector<float> line;
+        std::atomic<long long> nlines{ 0 };
+    };
+    Graph* g = new Graph;
+    g->line.assign((size_t)(fftSize > 0 ? fftSize : 1), 0.0f);
+    auto acq = [](void* c) -> float* { return ((Graph*)c)->line.data(); };
+    auto rel = [](void* c) { ((Graph*)c)->nlines++; };
+    g->fe.init(&g->in, inSR, /*buffering*/ false, /*decim*/ 1, /*dcBlocking*/ false, fftSize > 0 ? fftSize : 1024, fftSize > 0 ? fftRate : 1.0, IQFrontEnd::FFTWindow::NUTTALL, acq, rel, g);
+    g->fe.setFFTWindow(IQFrontEnd::FFTWindow::NUTTALL);
+    std::vector<dsp::channel::RxVFO*> vfos;
+    std::vector<RefDemod*> dem;
+    std::vector<std::thread> readers;
+    std::atomic<long long> audio{ 0 };
+    std::vector<dsp::stream<stereo_t>*> outs;
+    for (int v = 0; v < nVfo; v++) {
+        dsp::channel::RxVFO* x = g->fe.addVFO("v" + std::to_string(v), ifRates[v], bandwidths[v], offsets[v]);  // (starts the RxVFO's thread)
+        if (!x) { return 0; }
+        vfos.push_back(x);
+        RefDemod* d = (RefDemod*)ref_demod_create(modes[v], bandwidths[v], ifRates[v], 1, 50.0, 5.0, 0);
+        dsp::stream<stereo_t>* o = NULL;
+        if (d->wfm) { d->wfm->setInput(&x->out); d->wfm->start(); o = &d->wfm->out; }
+        else if (d->nfm) { d->nfm->setInput(&x->out); d->nfm->start(); o = &d->nfm->out; }
+        else if (d->am) { d->am->setInput(&x->out); d->am->start(); o = &d->am->out; }
+        else { d->ssb->setInput(&x->out); d->ssb->start(); o = &d->ssb->out; }
+        dem.push_back(d);
+        outs.push_back(o);
+        readers.emplace_back([o, &audio]() {
+            while (true) {
+                int n = o->read();
+                o->flush();
+                if (n < 0) { return; }
+                audio += n;
+            }
+        });
+    }
+    g->fe.start();
+    std::atomic<long long> fed{ 0 };
+    std::atomic<bool> stop{ false };
+    std::thread source([&]() {
+        long long pos = 0;
+        while (!stop) {
+            if (pos + blockSize > totalSamples) { pos = 0; }
+            memcpy(g->in.writeBuf, iq + 2 * pos, sizeof(complex_t) * (size_t)blockSize);
+            if (!g->in.swap(blockSize)) { return; }
+            fed += blockSize;
+            pos += blockSize;
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::duration<double>(warmupS));
+    int done = 0;
+    long long a0 = audio, l0 = g->nlines;
+    for (int r = 0; r < nRuns; r++) {
+        const long long f0 = fed;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::this_thread::sleep_for(std::chrono::duration<double>(runS));
+        const long long f1 = fed;
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out_rates[done++] = (double)(f1 - f0) / dt;
+    }
+    if (out_audio_frames) { *out_audio_frames = audio - a0; }
+    if (out_lines) { *out_lines = g->nlines - l0; }
+    stop = true;
+    g->in.stopWriter();
+    source.join();
+    g->fe.stop();
+    for (size_t v = 0; v < vfos.size(); v++) {
+        RefDemod* d = dem[v];
+        if (d->wfm) { d->wfm->stop(); }
+        if (d->nfm) { d->nfm->stop(); }
+        if (d->am) { d->am->stop(); }
+        if (d->ssb) { d->ssb->stop(); }
+        outs[v]->stopReader();
+    }
+    for (auto& t : readers) { t.join(); }
+    for (size_t v = 0; v < vfos.size(); v++) {
+        g->fe.removeVFO("v" + std::to_string(v));
+        ref_demod_destroy(dem[v]);
+    }
+    delete g;
+    return done;
+}
+
+// single-thread process()-only rate of ONE stage of a cfg-3-style VFO chain, for the per-stage table SURVEY.md 8(d) asks for: stage 0 = the whole
+// RxVFO (translation + decimators + resampler + channel filter), 1 = the demodulator alone (fed the RxVFO's output), 2 = one windowed FFT + log-power
+// per fftSize samples.  Returns INPUT samples per second of that stage (stage 1: IF samples per second).
+double ref_bench_stage(int stage, const float* iq, long long totalSamples, int blockSize, double inSR, double ifRate, double bandwidth, double offset, int mode, int fftSize, double seconds) {
+    if (stage == 2) {
+        std::vector<float> window((size_t)fftSize), db((size_t)fftSize);
+        for (int i = 0; i < fftSize; i++) { window[i] = dsp::window::nuttall(i, fftSize) * ((i % 2) ? -1.0f : 1.0f); }
+        fftwf_complex* fin = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+        fftwf_complex* fout = (fftwf_complex*)fftwf_malloc(sizeof(fftwf_complex) * (size_t)fftSize);
+        fftwf_plan plan = fftwf_plan_dft_1d(fftSize, fin, fout, FFTW_FORWARD, FFTW_ESTIMATE);
+        long long n = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        double dt = 0.0;
+        do {
+            for (long long pos = 0; pos + fftSize <= totalSamples; pos += fftSize) {
+                volk_32fc_32f_multiply_32fc((lv_32fc_t*)fin, (const lv_32fc_t*)(iq + 2 * pos), window.data(), fftSize);
+                fftwf_execute(plan);
+                volk_32fc_s32f_power_spectrum_32f(db.data(), (lv_32fc_t*)fout, fftSize, fftSize);
+                n += fftSize;
+            }
+            dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        } while (dt < seconds);
+        fftwf_destroy_plan(plan);
+        fftwf_free(fin);
+        fftwf_free(fout);
+        return (double)n / dt;
+    }
+    dsp::channel::RxVFO vfo;
+    vfo.init(NULL, inSR, ifRate, bandwidth, offset);
+    void* d = ref_demod_create(mode, bandwidth, ifRate, 1, 50.0, 5.0, 0);
+    complex_t* work = dsp::buffer::alloc<complex_t>(STREAM_BUFFER_SIZE);
+    stereo_t* audio = dsp::buffer::alloc<stereo_t>(STREAM_BUFFER_SIZE);
+    int nif = vfo.process(blockSize, (const complex_t*)iq, work);  // (a block of IF for stage 1)
+    long long n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    double dt = 0.0;
+    do {
+        for (long long pos = 0; pos + blockSize <= totalSamples; pos += blockSize) {
+            if (stage == 0) { n += blockSize; (void)vfo.process(blockSize, (const complex_t*)(iq + 2 * pos), work); }
+            else { n += nif; (void)ref_demod_process(d, nif, (const float*)work, (float*)audio); }
+        }
+        dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (dt < seconds);
+    ref_demod_destroy(d);
+    dsp::buffer::free(work);
+    dsp::buffer::free(audio);
+    return (double)n / dt;
 }
 
 } // extern "C"

@@ -181,6 +181,7 @@ def load():
     L.sdrpp_fft_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p]
     L.sdrpp_vfo_add.argtypes = [vp, C.POINTER(VfoDesc), c_int_p]
     L.sdrpp_vfo_remove.argtypes = [vp, C.c_int]
+    L.sdrpp_vfo_replace.argtypes = [vp, C.c_int, C.POINTER(VfoDesc), C.c_int, c_int_p]
     L.sdrpp_vfo_count.argtypes = [vp]
     L.sdrpp_vfo_set_phase_delta.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.sdrpp_vfo_set_channel_taps.argtypes = [vp, C.c_int, c_float_p, C.c_int]
@@ -242,10 +243,10 @@ EXPORTED_SYMBOLS = [
     "sdrpp_design_phase_delta", "sdrpp_design_resampler", "sdrpp_design_waterfall_view", "sdrpp_design_deemphasis_alpha",
     "sdrpp_vfo_read_pcm", "sdrpp_vfo_read_compressed", "sdrpp_preproc_read_pcm",
     "sdrpp_wf_configure", "sdrpp_wf_set_smoothing", "sdrpp_wf_set_hold", "sdrpp_wf_latest", "sdrpp_wf_raster", "sdrpp_wf_signal_info",
-    "sdrpp_preproc_configure", "sdrpp_preproc_set_reference_order", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
+    "sdrpp_preproc_configure", "sdrpp_preproc_reconfigure", "sdrpp_preproc_set_reference_order", "sdrpp_preproc_out_count", "sdrpp_preproc_read", "sdrpp_preproc_device_buffer",
     "sdrpp_vfo_set_af", "sdrpp_vfo_af_count", "sdrpp_vfo_af_read", "sdrpp_vfo_af_device_buffer", "sdrpp_abi_sizeof_af_desc",
     "sdrpp_fft_configure", "sdrpp_fft_disable", "sdrpp_fft_set_view", "sdrpp_fft_lines", "sdrpp_fft_read", "sdrpp_fft_copy_device", "sdrpp_fft_device_buffers",
-    "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
+    "sdrpp_vfo_add", "sdrpp_vfo_remove", "sdrpp_vfo_replace", "sdrpp_vfo_count", "sdrpp_vfo_set_phase_delta", "sdrpp_vfo_set_channel_taps", "sdrpp_vfo_reset",
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_copy", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
@@ -422,6 +423,14 @@ class Context:
 
     def vfo_remove(self, vid):
         self._chk(self.L.sdrpp_vfo_remove(self.h, vid))
+
+    def vfo_replace(self, vid, desc, keep, keepalive=()):
+        """sdrpp_vfo_replace: RxVFO::setInSamplerate / setOutSamplerate — a new description, the RxVFO's own state (keep & 1) and the demodulator's
+        (keep & 2) carried over as the reference's objects carry it.  Returns the new handle."""
+        nid = C.c_int()
+        self._chk(self.L.sdrpp_vfo_replace(self.h, vid, C.byref(desc), int(keep), C.byref(nid)))
+        del keepalive
+        return nid.value
 
     def vfo_count(self):
         return self._chk(self.L.sdrpp_vfo_count(self.h))

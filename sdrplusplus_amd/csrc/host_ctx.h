@@ -316,6 +316,7 @@ struct sdrpp_ctx {
     long test_fail_pass = 0;              // SDRPP_GPU_TEST_FAIL_ARENA (see arena_push)
     int test_fail_alloc = 0;
     bool pre_ref_order = false;           // survives sdrpp_preproc_configure (which rebuilds `pre`)
+    float2 pre_dc_last = { 0.0f, 0.0f };  // the DC blocker's estimate when it was last looked at (sdrpp_preproc_reconfigure: the reference's block object lives on through every re-plan of the chain)
     std::vector<const volatile uint32_t*> stage_pend;  // sdrpp_push_staged_when: the block's first launch waits (on the host) for these words to reach 0
     bool rot_exact_single = getenv("SDRPP_GPU_ROT_EXACT_SINGLE") != nullptr;  // measurement switch: the one-wavefront form of the reference rotator
     // VFOs per workgroup of vfo_rotate_exact4_kernel (1 .. 64).  The chain wavefront costs the same for 1 or 64 VFOs (a lane each); the three

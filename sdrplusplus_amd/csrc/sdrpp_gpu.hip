@@ -695,6 +695,45 @@ int sdrpp_preproc_configure(sdrpp_ctx* c, int n_stages, const int* stage_decim, 
     return SDRPP_OK;
 }
 
+// IQFrontEnd's setters re-plan the chain but its blocks live on (iq_frontend.cpp:76-130): setSampleRate / setDCBlocking / setInvertIQ do not touch
+// the decimator (its delay lines stay), and the DC blocker keeps its estimate through everything — setRate only swaps the rate, a blocker that
+// is switched off and on again continues from where it was (dc_blocker.h: the object is only taken out of the chain).  setDecimation creates
+// new decimator stages (PowerDecimator::setRatio -> reconfigure: power_decimator.h:91-108): cleared delay lines.
+//   keep & 1: the decimator's delay lines and offsets, if the new description has the same stages;   keep & 2: the DC blocker's estimate
+int sdrpp_preproc_reconfigure(sdrpp_ctx* c, int n_stages, const int* stage_decim, const int* stage_ntaps, const float* const* stage_taps, float dc_rate, int conjugate, int keep) {
+    DeviceScope dev_scope_(c);
+    if (!c || n_stages < 0 || n_stages > SDRPP_MAX_DECIM_STAGES || keep < 0 || keep > 3) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    sdrpp_ctx::Pre& P = c->pre;
+    if (P.on && P.dc_rate != 0.0f && P.d_off) { HIPCHK(c, hipMemcpy(&c->pre_dc_last, P.d_off + P.state_cur, sizeof(float2), hipMemcpyDeviceToHost)); }
+    bool same = (keep & 1) && P.on && n_stages > 0 && P.n_stages == n_stages && stage_decim && stage_ntaps && stage_taps;
+    for (int s = 0; same && s < n_stages; s++) {
+        same = P.decim_s[s] == stage_decim[s] && (int)P.staps[s].size() == stage_ntaps[s] && stage_taps[s] && memcmp(P.staps[s].data(), stage_taps[s], sizeof(float) * (size_t)stage_ntaps[s]) == 0;
+    }
+    sdrpp_ctx::Pre old;
+    if (same) {  // set the decimator's streams (delay lines, ring buffers) and offsets aside; the rest of the old chain is freed by the configure below
+        std::swap(old.raw, P.raw);
+        std::swap(old.st, P.st);
+        for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { old.soff[s] = P.soff[s]; }
+    }
+    int rc = sdrpp_preproc_configure(c, n_stages, stage_decim, stage_ntaps, stage_taps, dc_rate, conjugate);
+    if (same) {
+        if (!rc && P.on) {
+            std::swap(old.raw, P.raw);
+            std::swap(old.st, P.st);
+            for (int s = 0; s < SDRPP_MAX_DECIM_STAGES; s++) { P.soff[s] = old.soff[s]; }
+        }
+        old.raw.data = nullptr;
+        stream_free(old.raw);
+        for (auto& st : old.st) { stream_free(st); }
+    }
+    if (rc) { return rc; }
+    if ((keep & 2) && P.on && P.dc_rate != 0.0f && P.d_off) { HIPCHK(c, hipMemcpy(P.d_off + P.state_cur, &c->pre_dc_last, sizeof(float2), hipMemcpyHostToDevice)); }
+    if (!(keep & 2)) { c->pre_dc_last = make_float2(0.0f, 0.0f); }
+    return SDRPP_OK;
+}
+
 int sdrpp_preproc_set_reference_order(sdrpp_ctx* c, int on) {
     DeviceScope dev_scope_(c);
     if (!c) { return SDRPP_ERR_INVALID; }
@@ -940,6 +979,80 @@ int sdrpp_vfo_remove(sdrpp_ctx* c, int id) {
 }
 
 int sdrpp_vfo_count(sdrpp_ctx* c) { return c ? (int)c->vfos.size() : SDRPP_ERR_INVALID; }
+
+// RxVFO::setInSamplerate / setOutSamplerate (rx_vfo.h:35-58): the channeliser is re-planned, but not everything starts over.  The reference keeps
+//   * the translation's phase (FrequencyXlator::setOffset only swaps phaseDelta, frequency_xlator.h:24-30) and
+//   * the channel filter's delay line (setOutSamplerate: FIR::setTaps moves it under the new tap count, fir.h:31-52; setInSamplerate does not touch the
+//     filter at all; a filter that is bypassed under the new settings keeps what it held, one that wakes up continues from that)          -> keep bit 0
+// while its decimator stages are new objects and the polyphase resampler is reset (power_decimator.h:91-108, polyphase_resampler.h:38-67), and
+//   * the demodulator behind it is a separate block that setInSamplerate leaves alone: discriminator / audio low-pass history, AGC and DC-blocker
+//     states, SSB's second translation                                                                                                     -> keep bit 1
+// (a demodulator SWITCH deletes and creates it, radio_module.h:419-563: bit 1 off).  The AF chain is re-attached by the caller and starts cleared.
+static int hist_tail_copy(sdrpp_ctx* c, Stream& to, const Stream& from, int max_samples) {
+    if (!to.hist[to.cur] || !from.hist[from.cur] || to.width != from.width) { return SDRPP_OK; }
+    const int H = std::min(std::min(from.hist_len, to.hist_len), max_samples);
+    if (H <= 0) { return SDRPP_OK; }
+    const size_t w = (size_t)to.width;
+    HIPCHK(c, hipMemcpy(to.hist[to.cur] + (size_t)(to.hist_len - H) * w, from.hist[from.cur] + (size_t)(from.hist_len - H) * w, (size_t)H * w * sizeof(float), hipMemcpyDeviceToDevice));
+    return SDRPP_OK;
+}
+int sdrpp_vfo_replace(sdrpp_ctx* c, int old_id, const sdrpp_vfo_desc* d, int keep, int* new_id) {
+    DeviceScope dev_scope_(c);
+    if (!c || !d || !new_id || keep < 0 || keep > 3) { return SDRPP_ERR_INVALID; }
+    FLUSH_PENDING(c);
+    if (c->vfos.find(old_id) == c->vfos.end()) { return fail(c, SDRPP_ERR_NOT_FOUND, "no VFO %d", old_id); }
+    int nid = 0;
+    int rc = sdrpp_vfo_add(c, d, &nid);
+    if (rc) { return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Vfo& o = *c->vfos[old_id];
+    Vfo& n = *c->vfos[nid];
+    auto feed_idx = [](const Vfo& v) { return (v.i_poly >= 0) ? v.i_poly : v.i_first + std::max(v.d.n_stages, 1) - 1; };  // the stream the channel filter reads
+    Stream& of = o.st[(size_t)feed_idx(o)];
+    Stream& nf = n.st[(size_t)feed_idx(n)];
+    if (keep & 1) {
+        if (o.nco_exact == n.nco_exact) {
+            n.phi = o.phi;
+            if (o.d_rot && n.d_rot) { HIPCHK(c, hipMemcpy(n.d_rot, o.d_rot, sizeof(float2), hipMemcpyDeviceToDevice)); }
+        }
+        // the channel filter's delay line as the reference's FIR object holds it now: the newest old_taps - 1 samples it was fed, or what it held
+        // when it was last bypassed
+        const int w = of.width;
+        std::vector<float> line;
+        if (o.chan_ntaps > 1 && of.hist[of.cur] && of.hist_len >= o.chan_ntaps - 1) {
+            line.resize((size_t)(o.chan_ntaps - 1) * (size_t)w);
+            HIPCHK(c, hipMemcpy(line.data(), of.hist[of.cur] + (size_t)(of.hist_len - (o.chan_ntaps - 1)) * w, line.size() * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        else if (o.chan_ntaps == 0) { line = o.chan_stale; }
+        if (n.chan_ntaps > 0 && nf.width == w) {  // FIR::setTaps: the newest min(old, new) - 1 samples stay, zeros in front of them
+            if (nf.hist[nf.cur]) {
+                HIPCHK(c, hipMemset(nf.hist[nf.cur], 0, (size_t)nf.hist_len * (size_t)w * sizeof(float)));
+                const int have = (int)(line.size() / (size_t)w), m = std::min(have, std::min(n.chan_ntaps - 1, nf.hist_len));
+                if (m > 0) { HIPCHK(c, hipMemcpy(nf.hist[nf.cur] + (size_t)(nf.hist_len - m) * w, line.data() + (size_t)(have - m) * w, (size_t)m * w * sizeof(float), hipMemcpyHostToDevice)); }
+            }
+        }
+        else if (n.chan_ntaps == 0) { n.chan_stale = line; }  // bypassed under the new settings: the filter object keeps what it held
+    }
+    if ((keep & 2) && o.d.demod == n.d.demod) {
+        // the demodulator's view of the IF stream: the discriminator's previous sample and the audio low-pass's delay line are its newest samples
+        Stream& oif = (o.chan_ntaps > 0 && o.i_chan >= 0) ? o.st[(size_t)o.i_chan] : of;
+        Stream& nif = (n.chan_ntaps > 0 && n.i_chan >= 0) ? n.st[(size_t)n.i_chan] : nf;
+        const int if_need = (n.d.demod == SDRPP_DEMOD_WFM || n.d.demod == SDRPP_DEMOD_NFM) ? std::max(n.audio_ntaps, 1) + 1 : 1;
+        rc = hist_tail_copy(c, nif, oif, if_need);
+        if (rc) { return rc; }
+        if (o.i_dem >= 0 && n.i_dem >= 0) {
+            rc = hist_tail_copy(c, n.st[(size_t)n.i_dem], o.st[(size_t)o.i_dem], 1 << 30);
+            if (rc) { return rc; }
+        }
+        if (o.d_state && n.d_state) { HIPCHK(c, hipMemcpy(n.d_state, o.d_state, 2 * sizeof(AgcState) + sizeof(float), hipMemcpyDeviceToDevice)); }
+        n.phi2 = o.phi2;
+        if (o.d_rot && n.d_rot) { HIPCHK(c, hipMemcpy(n.d_rot + 1, o.d_rot + 1, sizeof(float2), hipMemcpyDeviceToDevice)); }
+    }
+    rc = sdrpp_vfo_remove(c, old_id);
+    if (rc) { return rc; }
+    *new_id = nid;
+    return SDRPP_OK;
+}
 
 int sdrpp_vfo_set_phase_delta(sdrpp_ctx* c, int id, float re, float im) {
     DeviceScope dev_scope_(c);

@@ -155,7 +155,7 @@ int tick_launch(sdrpp_ctx* c, const CopyJob* land) {
         blocks += r.e.gx * r.e.gy;
         role_wgs += (long long)r.e.gx * r.e.gy;
         lds = std::max(lds, r.lds);
-        set1 = set1 || r.e.role == TR_FCL_PF;
+        set1 = set1 || r.e.role == TR_FCL_PF || r.e.role == TR_FCM_6 || r.e.role == TR_FCM_10 || r.e.role == TR_FCM_16;  // (roles that exist in the 247-register build only: tick_kernels.h)
         set2 = set2 && !(r.e.role == TR_ROTX16 || r.e.role == TR_FCL_PF || r.e.role == TR_FCL_0 || r.e.role == TR_FCM_132_4 || r.e.role == TR_FCM_6 || r.e.role == TR_FCM_10 || r.e.role == TR_FCM_16 || r.e.role == TR_FFT_S12);
         if (r.e.role >= 0 && r.e.role < 64) { c->stat_role_wgs[r.e.role] += (int64_t)r.e.gx * r.e.gy; }
     }

@@ -291,14 +291,17 @@ __global__ __launch_bounds__(256, SET == 1 ? 2 : (SET == 2 ? 4 : 3)) void tick_k
             case TR_FCM_132_4:
                 if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
+            // (the front ends with RUN-TIME geometry — any composite filter but the ratio-32 plan's <132 taps, / 16> — need more registers than the 168 of the
+            // SET = 0 build: there they spilled 57 registers, 204 bytes of scratch per work-item for the whole kernel, VERDICT r5.  They live in the
+            // 247-register build only; a tick that holds one runs as tick_kernel<1>)
             case TR_FCM_6:
-                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcm_body<6, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
             case TR_FCM_10:
-                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcm_body<10, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
             case TR_FCM_16:
-                if constexpr (SET != 2) { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
+                if constexpr (SET == 1) { const IqSrc src = e.p.src; vfo_frontcm_body<16, 0, 0>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); }
                 break;
             case TR_FCM16_132_4: { const IqSrc src = e.p.src; vfo_frontcm16_body<132, 4>(bid, smem, src, reinterpret_cast<const FrontCMJob*>(e_jobs)); } break;
             case TR_FCL_0:

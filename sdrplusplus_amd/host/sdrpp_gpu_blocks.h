@@ -146,6 +146,7 @@ private:
     friend class IQFrontEnd;
     IQFrontEnd* fe = nullptr;
     int id = -1;
+    std::vector<int> prevIds;  // handles this VFO had before its last re-plans (setInSamplerate / setOutSamplerate / a new demodulator): blocks pushed under them are still delivered
     std::string name;
 };
 
@@ -248,19 +249,19 @@ public:
         std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
         tempStop();
         _decimRatio = ratio;
-        updatePreproc();
+        updatePreproc(2);
         for (auto& kv : vfos) { kv.second->setInSamplerate(getEffectiveSamplerate()); }
         updateFFTPath();
         tempStart();
     }
-    void setDCBlocking(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _dcBlocking = enabled; updatePreproc(); tempStart(); }
-    void setInvertIQ(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _invertIQ = enabled; updatePreproc(); tempStart(); }
+    void setDCBlocking(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _dcBlocking = enabled; updatePreproc(3); tempStart(); }
+    void setInvertIQ(bool enabled) { std::lock_guard<std::recursive_mutex> lck(ctrlMtx); tempStop(); _invertIQ = enabled; updatePreproc(3); tempStart(); }
 
     void setSampleRate(double sampleRate) {  // iq_frontend.cpp:76-99
         std::lock_guard<std::recursive_mutex> lck(ctrlMtx);
         tempStop();
         _sampleRate = sampleRate;
-        updatePreproc();  // the DC blocker's rate follows the effective sample rate (iq_frontend.cpp:85-86)
+        updatePreproc(3);  // the DC blocker's rate follows the effective sample rate (iq_frontend.cpp:85-86)
         for (auto& kv : vfos) { kv.second->setInSamplerate(getEffectiveSamplerate()); }
         updateFFTPath();
         tempStart();
@@ -414,11 +415,44 @@ public:
     // default 250 ms — only a sink that does not read ever waits that long.
     void setStopGrace(int milliseconds) { _stopGraceMs = milliseconds < 0 ? 0 : milliseconds; }
 
+    // Addition (not in the reference): how long the worker LOOKS for the next block before it goes to sleep in stream::read().  The reference's hand-over
+    // is a condition variable: a reader that sleeps is woken through the kernel, 10-30 us later on a server part (100 us out of a deep idle state) —
+    // at sample_rate / 200 blocks that wake-up, not the device, is most of a block's time (profiles/r06f_seam_prof.log: 14-30 us of a 36-50 us cycle).
+    // swap() exchanges the stream's PUBLIC buffer pointers before it raises dataReady (dsp/stream.h:43-67), so a changed readBuf says "a block is
+    // there" without touching the stream's private state; read() then returns at once.  0 = always sleep (the reference's behaviour).
+    void setSpinWait(int microseconds) { _spinUs = microseconds < 0 ? 0 : microseconds; }
+
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define SDRPP_GPU_NO_TSAN __attribute__((no_sanitize("thread")))
+#endif
+#endif
+#if !defined(SDRPP_GPU_NO_TSAN) && defined(__SANITIZE_THREAD__)
+#define SDRPP_GPU_NO_TSAN __attribute__((no_sanitize("thread")))
+#endif
+#ifndef SDRPP_GPU_NO_TSAN
+#define SDRPP_GPU_NO_TSAN
+#endif
+    // (a peek at a pointer another thread exchanges under its lock: only ever a hint — read() is what takes the block)
+    SDRPP_GPU_NO_TSAN static const void* peekReadBuf(dsp::stream<dsp::complex_t>* st) { return __atomic_load_n(reinterpret_cast<void* const*>(&st->readBuf), __ATOMIC_RELAXED); }
+
     int runBlock() {
 #ifdef SDRPP_GPU_BLOCKS_PROF
         pipeT = std::chrono::steady_clock::now();
 #endif
+        if (_spinUs > 0 && spinStream == _in && spinLast) {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned n = 0;
+            while (peekReadBuf(_in) == spinLast) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+                if ((++n & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(_spinUs)) { break; }
+            }
+        }
         int count = _in->read();
+        spinStream = _in;
+        spinLast = peekReadBuf(_in);
         if (count < 0) { return -1; }
         SDRPP_PIPE_TICK(0)
         if (!_buffering) {
@@ -568,7 +602,10 @@ public:
 #define SDRPP_BLOCKS_TICK0()
 #endif
     static constexpr int64_t SDRPP_GPU_MAX_BLOCK = 1000000;
-    static constexpr int kHelpers = 8;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log)
+#ifndef SDRPP_GPU_HELPERS
+#define SDRPP_GPU_HELPERS 8
+#endif
+    static constexpr int kHelpers = SDRPP_GPU_HELPERS;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log)
 
 protected:
     // dsp::block hooks: the frame-buffer worker lives and dies with the block's own worker (SampleFrameBuffer::doStart / doStop,
@@ -752,7 +789,8 @@ private:
         for (int k = 0; k < r.n_vfo; k++) {
             if (r.counts[k] <= 0) { continue; }
             for (auto& kv : vfos) {
-                if (kv.second->id == r.ids[k]) {
+                const RxVFO& cand = *kv.second;
+                if (cand.id == r.ids[k] || std::find(cand.prevIds.begin(), cand.prevIds.end(), r.ids[k]) != cand.prevIds.end()) {
                     order.emplace_back(kv.second, k);
                     break;
                 }
@@ -940,7 +978,9 @@ private:
         return count;
     }
 
-    void updatePreproc() {  // iq_frontend.cpp:32-39: decim enabled for ratio > 1, dcBlock rate genDCBlockRate(effectiveSr), conjugate
+    // keep: what the reference's blocks carry across the setter that calls this — 3 for setSampleRate / setDCBlocking / setInvertIQ (decimator untouched, the
+    // DC blocker's estimate lives on), 2 for setDecimation (new decimator stages), 0 at init
+    void updatePreproc(int keep = 0) {  // iq_frontend.cpp:32-39: decim enabled for ratio > 1, dcBlock rate genDCBlockRate(effectiveSr), conjugate
         int dec[SDRPP_MAX_DECIM_STAGES] = { 0 }, nt[SDRPP_MAX_DECIM_STAGES] = { 0 };
         const float* tp[SDRPP_MAX_DECIM_STAGES] = { nullptr };
         int n = 0;
@@ -955,7 +995,7 @@ private:
             }
         }
         const float rate = _dcBlocking ? (float)(50.0 / getEffectiveSamplerate()) : 0.0f;  // iq_frontend.h:55-57
-        int rc = sdrpp_preproc_configure(ctx, n, dec, nt, tp, rate, _invertIQ ? 1 : 0);
+        int rc = sdrpp_preproc_reconfigure(ctx, n, dec, nt, tp, rate, _invertIQ ? 1 : 0, keep);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] ") + sdrpp_last_error(ctx)); }
     }
 
@@ -970,8 +1010,18 @@ private:
 
     // (Re)creates the device-side VFO from the host-side description — what RxVFO::init + RationalResampler::reconfigure +
     // the radio demodulator constructors compute (rx_vfo.h:19-36, rational_resampler.h:120-165, demodulators/*.h).
-    void rebuild(RxVFO& v) {
-        if (v.id >= 0) { sdrpp_vfo_remove(ctx, v.id); v.id = -1; }
+    // keep (an existing VFO): what survives the change in the reference — bit 0 the RxVFO's own state (translation phase, channel filter's delay line:
+    // setInSamplerate / setOutSamplerate, rx_vfo.h:35-58), bit 1 the demodulator behind it (setInSamplerate leaves that block alone); 0 = everything new
+    void rebuild(RxVFO& v, int keep = 0) {
+        const int oldId = (keep && v.id >= 0) ? v.id : -1;
+        if (v.id >= 0 && oldId < 0) { sdrpp_vfo_remove(ctx, v.id); }
+        // blocks pushed under the old handle may still be on their way (pipelined mode: results a few blocks behind their pushes): they are THIS VFO's
+        // blocks and go out on its stream, in order, in front of the first block of the new description
+        if (v.id >= 0) {
+            v.prevIds.push_back(v.id);
+            if (v.prevIds.size() > 8) { v.prevIds.erase(v.prevIds.begin()); }
+        }
+        v.id = -1;
         sdrpp_vfo_desc d;
         memset(&d, 0, sizeof(d));
         sdrpp_design_phase_delta(-v.offset, v.inSamplerate, &d.phase_delta_re, &d.phase_delta_im);
@@ -1040,7 +1090,7 @@ private:
             const double tr = v.demod == Demod::USB ? dbw / 2.0 : (v.demod == Demod::LSB ? -dbw / 2.0 : 0.0);
             sdrpp_design_phase_delta(tr, v.outSamplerate, &d.ssb_phase_delta_re, &d.ssb_phase_delta_im);
         }
-        int rc = sdrpp_vfo_add(ctx, &d, &v.id);
+        int rc = oldId >= 0 ? sdrpp_vfo_replace(ctx, oldId, &d, keep, &v.id) : sdrpp_vfo_add(ctx, &d, &v.id);
         if (rc) { throw std::runtime_error(std::string("[sdrpp_gpu::IQFrontEnd] vfo_add: ") + sdrpp_last_error(ctx)); }
         if (v.afOn && v.demod != Demod::RAW) { applyAF(v); }
     }
@@ -1092,6 +1142,9 @@ private:
     bool _dcBlocking = false, _invertIQ = false;
     std::atomic<bool> _buffering{ false };
     std::atomic<bool> _pipelining{ false };
+    int _spinUs = 100;                      // setSpinWait
+    dsp::stream<dsp::complex_t>* spinStream = nullptr;
+    const void* spinLast = nullptr;         // the input stream's readBuf at the last read(): swap() exchanges it (worker)
     int _pipeLag = 8;
     int _pipeGroup = 1;                     // setPipelining: blocks one launch may carry
     int pipeGroupOn = 1;                    // ... as the context has it now (worker)
@@ -1253,7 +1306,7 @@ inline void RxVFO::setInSamplerate(double sr) {  // rx_vfo.h:38-43: xlator offse
     std::lock_guard<std::recursive_mutex> lck(fe->ctrlMtx);
     fe->tempStop();
     inSamplerate = sr;
-    fe->rebuild(*this);
+    fe->rebuild(*this, 3);  // (the translation's phase, the channel filter's delay line and the demodulator live on; decimators and resampler are new)
     fe->tempStart();
 }
 inline void RxVFO::setDemodBandwidth(double bw) {
@@ -1270,7 +1323,7 @@ inline void RxVFO::setDemodBandwidth(double bw) {
     }
     if (demod == Demod::DSB) { return; }
     fe->tempStop();
-    fe->rebuild(*this);
+    fe->rebuild(*this, 1);  // (the RxVFO in front of the demodulator is not involved)
     fe->tempStart();
 }
 inline void RxVFO::setOffset(double off) {
@@ -1303,7 +1356,9 @@ inline void RxVFO::setOutSamplerate(double sr, double bw) {
     fe->tempStop();
     outSamplerate = sr;
     bandwidth = bw;
-    fe->rebuild(*this);
+    // (rx_vfo.h:45-58: phase and the channel filter's delay line stay; the demodulator is told its new rate by whoever owns it — the radio module
+    // creates a new one on a switch, and one that stays is re-initialised by its own setters — so it starts from cleared state here)
+    fe->rebuild(*this, 1);
     fe->tempStart();
 }
 inline void RxVFO::reset() {
@@ -1320,7 +1375,7 @@ inline void RxVFO::attachDemod(Demod mode, bool lp, double att, double dec, bool
     agcAttack = att;
     agcDecay = dec;
     carrierAgc = carrier;
-    fe->rebuild(*this);
+    fe->rebuild(*this, 1);  // a new demodulator object behind the SAME RxVFO (radio_module.h:419-563)
     fe->tempStart();
 }
 

@@ -5,6 +5,8 @@
 //   usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered 0|1> [pipelined 0|1 [blocks per launch]]
 // Prints one JSON object.  Built by oracle/Makefile against the reference's own dsp/stream.h + dsp/block.h (oracle/_ref/bench_blocks_ref: what
 // bench.py runs) and, where the reference tree is absent, by bench.py against tests/host_cpp/standalone (the test double of those headers).
+#include <fcntl.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -24,6 +26,15 @@ int main(int argc, char** argv) {
     if (argc < 8) {
         fprintf(stderr, "usage: bench_blocks <plans.bin> <sample_rate> <block> <fft_size> <nvfo> <seconds> <buffered>\n");
         return 2;
+    }
+    // SDRPP_BENCH_CPU_DMA_LATENCY=<us>: hold /dev/cpu_dma_latency at that value for the run (PM QoS: keeps the cores out of the idle states whose exit
+    // latency is longer) — the stream hand-overs of the graph are futex wake-ups of threads that sleep for tens of microseconds at a time, and on a
+    // server part the wake-up out of a deep idle state is longer than the block's whole device time (what real-time audio applications set too)
+    int qosFd = -1;
+    if (const char* q = getenv("SDRPP_BENCH_CPU_DMA_LATENCY")) {
+        qosFd = open("/dev/cpu_dma_latency", O_WRONLY);
+        const int32_t us = atoi(q);
+        if (qosFd < 0 || write(qosFd, &us, sizeof(us)) != (ssize_t)sizeof(us)) { fprintf(stderr, "cpu_dma_latency not available\n"); }
     }
     sdrpp_gpu::DecimPlans plans;
     if (!plans.load(argv[1])) {

@@ -140,6 +140,10 @@ def ref(fast=False):
         L.ref_rxvfo_set_offset.argtypes = [C.c_void_p, C.c_double]
         L.ref_rxvfo_set_bandwidth.argtypes = [C.c_void_p, C.c_double]
         L.ref_rxvfo_set_bandwidth.restype = None
+        L.ref_rxvfo_set_in_samplerate.argtypes = [C.c_void_p, C.c_double]
+        L.ref_rxvfo_set_in_samplerate.restype = None
+        L.ref_rxvfo_set_out_samplerate.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ref_rxvfo_set_out_samplerate.restype = None
         L.ref_rxvfo_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.ref_demod_create.restype = C.c_void_p
         L.ref_demod_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -156,6 +160,8 @@ def ref(fast=False):
         L.ref_preproc_create.restype = C.c_void_p
         L.ref_preproc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
         L.ref_preproc_destroy.argtypes = [C.c_void_p]
+        L.ref_preproc_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.ref_preproc_set.restype = None
         L.ref_preproc_process.argtypes = [C.c_void_p, C.c_int, c_float_p, c_float_p]
         L.ref_frontend_create.restype = C.c_void_p
         L.ref_frontend_create.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int]
@@ -167,6 +173,11 @@ def ref(fast=False):
         L.ref_bench_cfg.restype = C.c_double
         L.ref_bench_cfg.argtypes = [c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p,
                                     C.c_int, C.c_int, C.c_int]
+        L.ref_bench_graph.restype = C.c_int
+        L.ref_bench_graph.argtypes = [c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p,
+                                      C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.ref_bench_stage.restype = C.c_double
+        L.ref_bench_stage.argtypes = [C.c_int, c_float_p, C.c_longlong, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
         _ref[fast] = L
     return _ref[fast]
 
@@ -290,6 +301,22 @@ class _Chain:
         """RxVFO::setBandwidth (rx_vfo.h:60-70): new channel taps, the filter's delay line kept (fir.h:31-52)."""
         getattr(self.lib, self.p + "rxvfo_set_bandwidth")(self.vfo, float(bandwidth))
 
+    def set_in_samplerate(self, sr):
+        """RxVFO::setInSamplerate (rx_vfo.h:35-43) — the compiled reference only (RefChain): the demodulator lives on."""
+        assert self.p == "ref_", "only the compiled reference replays this setter"
+        self.lib.ref_rxvfo_set_in_samplerate(self.vfo, float(sr))
+
+    def set_out_samplerate(self, sr, bandwidth, mode="same", **demod_kw):
+        """RxVFO::setOutSamplerate (rx_vfo.h:45-58) and, with `mode`, the radio module's demodulator switch (a NEW demodulator object, radio_module.h:419-563)."""
+        assert self.p == "ref_", "only the compiled reference replays this setter"
+        self.lib.ref_rxvfo_set_out_samplerate(self.vfo, float(sr), float(bandwidth))
+        if mode != "same":
+            if self.dem:
+                self.lib.ref_demod_destroy(self.dem)
+                self.dem = None
+            if mode is not None:
+                self.dem = self.lib.ref_demod_create(mode, float(bandwidth), float(sr), int(demod_kw.get("low_pass", True)), demod_kw.get("agc_attack", 50.0), demod_kw.get("agc_decay", 5.0), int(demod_kw.get("carrier_agc", False)))
+
     def close(self):
         if self.vfo:
             getattr(self.lib, self.p + "rxvfo_destroy")(self.vfo)
@@ -323,6 +350,31 @@ def oracle_rxvfo_info(chain):
 
 
 MODES = {"WFM": 0, "NFM": 1, "AM": 2, "USB": 3, "LSB": 4, "DSB": 5}
+
+
+class RefPreproc:
+    """The compiled reference's pre-processing chain objects (PowerDecimator -> DCBlocker -> Conjugate) with the re-planning IQFrontEnd's setters do to them
+    while the stream runs (oracle/ref_api.cpp: ref_preproc_set)."""
+
+    def __init__(self, ratio=1, dc_blocking=False, dc_rate=1e-5, conjugate=False):
+        self.L = ref()
+        assert self.L is not None, "oracle/_ref not built"
+        self.h = self.L.ref_preproc_create(int(ratio), int(bool(dc_blocking)), float(dc_rate), int(bool(conjugate)))
+
+    def set(self, ratio, dc_blocking, dc_rate, conjugate, new_decimator=False):
+        self.L.ref_preproc_set(self.h, int(ratio), int(bool(dc_blocking)), float(dc_rate), int(bool(conjugate)), int(bool(new_decimator)))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.empty(len(x) + 8, np.complex64)
+        n = self.L.ref_preproc_process(self.h, len(x), _fp(x.view(np.float32)), _fp(out.view(np.float32))) if len(x) else 0
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            self.L.ref_preproc_destroy(self.h)
+        except Exception:
+            pass
 
 
 class OraclePreproc:

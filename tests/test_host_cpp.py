@@ -177,6 +177,33 @@ def test_reconfigure_while_running_on_the_emulator():
 
 
 @pytest.mark.parametrize("san", ["address", "thread"])
+def test_reconfigure2_while_running_host_side_under_sanitizers(san):
+    """tests/host_cpp/test_reconfig2.cpp (the rest of the control surface) with the HOST side compiled with -fsanitize=address / thread, emulator library: no
+    memory error, no data race (the one filtered report: see the test below).  The outputs are checked by the un-instrumented legs; here the run must be clean
+    and deliver every block."""
+    S.locked_make("-C", EMU, "-s")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "test_reconfig2_" + san)
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-w", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-o", exe, os.path.join(ROOT, "tests", "host_cpp", "test_reconfig2.cpp"),
+                            "-I" + os.path.join(ROOT, "tests", "host_cpp", "standalone"), "-L" + EMU, "-l:libsdrpp_gpu_emu.so", "-Wl,-rpath," + EMU, "-lpthread"], capture_output=True, text=True)
+        if r.returncode != 0 and ("cannot find" in r.stderr or "sanitizer" in r.stderr.lower()):
+            pytest.skip("no %s sanitizer runtime in this toolchain" % san)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sr, B, nblk = 2.4e6, 12000, 14
+        rg = np.random.default_rng(19)
+        x = (0.3 * np.exp(2j * np.pi * 300e3 * np.arange(B * nblk) / sr) + 0.01 * (rg.standard_normal(B * nblk) + 1j * rg.standard_normal(B * nblk))).astype(np.complex64)
+        x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0")
+        r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr), str(B), tmp, "0", "120000"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "blocks 14" in r.stdout and "in 14 blocks, steady" in r.stdout and r.stdout.rstrip().endswith("in 14"), r.stdout
+        assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+        reports = [ln for ln in r.stderr.splitlines() if ln.startswith("WARNING: ThreadSanitizer")]
+        assert all("double lock of a mutex" in ln for ln in reports), "\n".join(reports) + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("san", ["address", "thread"])
 def test_reconfigure_while_running_host_side_under_sanitizers(san):
     """The same program with the HOST side (the C++ mirror, the test double of dsp::stream / dsp::block, the test) compiled with
     -fsanitize=address / -fsanitize=thread and linked with the emulator library: no memory error, no data race.  (ThreadSanitizer of GCC 11 does
@@ -210,6 +237,120 @@ def test_reconfigure_while_running_on_the_device():
     with tempfile.TemporaryDirectory() as tmp:
         out = _run_reconfig_and_check(_build(tmp, source="test_reconfig.cpp"), tmp, 18, 20000)
         assert "blocks 13" in out
+
+
+def _run_reconfig2_and_check(exe, tmp, nextra, wait_ms):
+    """tests/host_cpp/test_reconfig2.cpp: the rest of IQFrontEnd's / RxVFO's setters between the blocks of a RUNNING pipelined graph; the same schedule replayed on
+    the compiled reference's own RxVFO / demodulator / pre-processing objects (their state across these calls is the specification) and the oracle's spectrum."""
+    from sdrplusplus_amd import capi, radio
+
+    sr0, B, nblk, N = 2.4e6, 12000, 14, 4096
+    r = np.random.default_rng(19)
+    t = np.arange(B * nblk) / sr0
+    x = (0.3 * np.exp(1j * (2 * np.pi * 300e3 * t + (75e3 / 1e3) * np.sin(2 * np.pi * 1e3 * t))) * (1.0 + 0.2 * np.cos(2 * np.pi * 600.0 * t))
+         + 0.2 * np.exp(1j * (2 * np.pi * -200e3 * t + (50e3 / 700.0) * np.sin(2 * np.pi * 700.0 * t)))
+         + (0.02 + 0.01j) + 0.01 * (r.standard_normal(len(t)) + 1j * r.standard_normal(len(t)))).astype(np.complex64)
+    x.view(np.float32).tofile(os.path.join(tmp, "iq.f32"))
+    rr = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), os.path.join(tmp, "iq.f32"), str(sr0), str(B), tmp, str(nextra), str(wait_ms)],
+                        capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stdout + rr.stderr
+    ld = lambda name, dt: np.fromfile(os.path.join(tmp, name), dt)
+    g_radio, g_steady = (ld(n + ".f32", np.float32).reshape(-1, 2) for n in ("radio", "steady"))
+    c_radio, c_steady = (ld(n + "_counts.i32", np.int32) for n in ("radio", "steady"))
+    g_lines = ld("lines.f32", np.float32).reshape(-1, N)
+    # ---- the reference under the same schedule ----
+    st = dict(sr=sr0, decim=1, dc=False, conj=False, win=2, rate=100.0)
+    eff = lambda: st["sr"] / st["decim"]
+    pre = S.RefPreproc(1, False, 50.0 / eff(), False)
+    o_radio = S.RefChain(eff(), 250e3, 150e3, 300e3, S.MODES["WFM"])
+    o_steady = S.RefChain(eff(), 250e3, 150e3, -200e3, S.MODES["WFM"])
+
+    def new_spec():  # updateFFTPath: the Reshaper restarts (iq_frontend.cpp:269-309)
+        nz, skip = capi.design_reshape_params(eff(), N, st["rate"])
+        return S.OracleSpectrum(N, nz, skip, capi.design_fft_window(st["win"], nz))
+
+    def rates_changed(new_decimator):
+        pre.set(st["decim"], st["dc"], 50.0 / eff(), st["conj"], new_decimator)  # genDCBlockRate: iq_frontend.h:55-57
+        o_radio.set_in_samplerate(eff())
+        o_steady.set_in_samplerate(eff())
+        return new_spec()
+
+    spec = new_spec()
+    e_radio, e_steady, e_lines, exact_lines = [], [], [], 0
+    for b in range(nblk):
+        if b == 2:
+            st["win"] = 1  # BLACKMAN
+            spec = new_spec()
+        if b == 3:
+            st["rate"] = 50.0
+            spec = new_spec()
+        if b == 4:
+            o_radio.set_out_samplerate(50e3, 12.5e3, mode=S.MODES["NFM"])
+        if b == 5:
+            st["conj"] = True
+            pre.set(st["decim"], st["dc"], 50.0 / eff(), True, False)
+        if b == 6:
+            o_radio.set_out_samplerate(24e3, 2.8e3, mode=S.MODES["USB"])
+        if b == 9:
+            o_radio.set_out_samplerate(250e3, 150e3, mode=S.MODES["WFM"])
+        if b == 10:
+            st["decim"] = 2
+            spec = rates_changed(True)
+        if b == 11:
+            st["sr"] = 2.0e6
+            spec = rates_changed(False)
+        if b == 12:
+            st["dc"] = True
+            pre.set(st["decim"], True, 50.0 / eff(), st["conj"], False)
+        if b == 13:
+            st["sr"] = 2.4e6
+            spec = rates_changed(False)
+        y = pre.process(x[b * B:(b + 1) * B])
+        ln = spec.push(y)
+        e_lines.append(ln)
+        if b < 10:
+            exact_lines += len(ln)
+        e_radio.append(o_radio.process(y)[1])
+        e_steady.append(o_steady.process(y)[1])
+    # every block of both radios exactly once, in order, every one from its first sample (the first 200 frames behind each change are looked at on their own)
+    for name, got, cnt, exp in (("radio", g_radio, c_radio, e_radio), ("steady", g_steady, c_steady, e_steady)):
+        assert [int(c) for c in cnt] == [len(e) for e in exp], (name, cnt.tolist(), [len(e) for e in exp])
+        pos = 0
+        for b, e in enumerate(exp):
+            g = got[pos:pos + len(e)]
+            pos += len(e)
+            tol = 1e-5 * max(1.0, float(np.sqrt(np.mean(e ** 2))))
+            h = min(len(e), 200)
+            err, err_h = float(np.sqrt(np.mean((g - e) ** 2))), float(np.sqrt(np.mean((g[:h] - e[:h]) ** 2)))
+            assert err < tol and err_h < tol, (name, "block", b, err, err_h, tol)
+    # lines: bit-exact while the pre-processing chain only conjugates; behind the decimator / DC blocker (default arithmetic: matrix-core sums, a parallel scan —
+    # include/sdrpp_gpu.h) within 0.05 dB; none lost, none twice across the five restarts of the framing
+    o = np.concatenate([l for l in e_lines if len(l)])
+    assert g_lines.shape == o.shape, (g_lines.shape, o.shape)
+    assert np.array_equal(g_lines[:exact_lines], o[:exact_lines])
+    if len(o) > exact_lines:
+        d = np.abs(g_lines[exact_lines:] - o[exact_lines:])
+        assert float(d.max()) < 0.05, float(d.max())
+    return rr.stdout
+
+
+@pytest.mark.skipif(not S.ref_available(), reason="oracle/_ref not built (needs the reference tree at build time)")
+def test_reconfigure2_while_running_on_the_emulator():
+    """setFFTWindow / setFFTRate / setInvertIQ / setBuffering on + off / setDecimation / setSampleRate / setDCBlocking and the radio's demodulator switch WFM -> NFM -> USB ->
+    WFM (RxVFO::setOutSamplerate + a new demodulator), RxVFO::setInSamplerate through the front end's rate changes — all between the blocks of a RUNNING pipelined graph
+    (iq_frontend.cpp:76-130, rx_vfo.h:35-58, radio_module.h:419-563), replayed on the compiled reference's objects.  CPU emulator build."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _run_reconfig2_and_check(_build(tmp, lib="emu", source="test_reconfig2.cpp"), tmp, 0, 60000)
+        assert "blocks 14" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not S.ref_available(), reason="oracle/_ref not built")
+def test_reconfigure2_while_running_on_the_device():
+    """The same on the device with 18 more radios (matrix front end: the blocks run as launches of the pipeline)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _run_reconfig2_and_check(_build(tmp, source="test_reconfig2.cpp"), tmp, 18, 20000)
+        assert "blocks 14" in out
 
 
 def test_device_math_helpers():

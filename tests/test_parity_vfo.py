@@ -1054,3 +1054,55 @@ def test_pipelined_fm_back_end_tiny_ragged_pushes(backend):
         assert a1.shape == a0.shape and i1.shape == i0.shape
         assert np.array_equal(a1.view(np.uint32), a0.view(np.uint32)), mode
         assert np.array_equal(i1.view(np.uint32), i0.view(np.uint32)), mode
+
+
+def test_vfo_replace_follows_the_reference_over_rate_changes(backend):
+    """sdrpp_vfo_replace = RxVFO::setInSamplerate / setOutSamplerate (rx_vfo.h:35-58) and the radio module's demodulator switch (vfo_manager.cpp:52,
+    radio_module.h:419-563: setOutSamplerate, then a NEW demodulator), against the COMPILED REFERENCE's own RxVFO and demodulators (oracle/_ref: the
+    reference's objects carry their state across these calls the way they do, and that is what must come out): the translation's phase and the channel
+    filter's delay line survive (keep & 1), the demodulator survives a change of the INPUT rate (keep & 2), decimators and resampler start cleared.
+    Sequence on one VFO: WFM -> NFM -> USB -> WFM (the radio's mode switch), then the input rate 10 MS/s -> 5 MS/s (IQFrontEnd::setDecimation(2) as the
+    VFO sees it) and back.  Audio of every block from its FIRST sample within 1e-5; for USB the raw IF too (the phase carried over is visible there)."""
+    from sdrplusplus_amd import capi, radio
+
+    if not S.ref_available():
+        pytest.skip("oracle/_ref not built (needs the reference tree at build time)")
+    sr, B = 10e6, 50000
+    off = sr / 8  # (an offset whose phase steps are exact in float: no rotator drift between the closed form and the reference's recursion)
+    r = np.random.default_rng(77)
+    n = 9 * B
+    t = np.arange(n) / sr
+    x = (0.3 * np.exp(2j * np.pi * (off * t + 5e3 / (2 * np.pi * 1e3) * np.sin(2 * np.pi * 1e3 * t))) * (1.0 + 0.3 * np.cos(2 * np.pi * 700.0 * t))
+         + 0.01 * (r.standard_normal(n) + 1j * r.standard_normal(n))).astype(np.complex64)
+    ctx = capi.Context(0, max_push=B)
+    mode, (if_rate, bw) = "WFM", radio.RADIO_DEFAULTS["WFM"]
+    d, keep = radio.vfo_desc(sr, if_rate, bw, off, mode)
+    vid = ctx.vfo_add(d, keep)
+    ch = S.RefChain(sr, if_rate, bw, off, S.MODES[mode])
+    in_sr = sr
+    steps = {2: ("out", "NFM"), 4: ("out", "USB"), 6: ("out", "WFM"), 7: ("in", 5e6), 8: ("in", 10e6)}
+    pos = 0
+    for b in range(9):
+        if b in steps:
+            kind, arg = steps[b]
+            if kind == "out":
+                mode, (if_rate, bw) = arg, radio.RADIO_DEFAULTS[arg]
+                ch.set_out_samplerate(if_rate, bw, mode=S.MODES[mode])
+                d, keep = radio.vfo_desc(in_sr, if_rate, bw, off, mode)
+                vid = ctx.vfo_replace(vid, d, 1, keep)
+            else:
+                in_sr = arg
+                ch.set_in_samplerate(in_sr)
+                d, keep = radio.vfo_desc(in_sr, if_rate, bw, off, mode)
+                vid = ctx.vfo_replace(vid, d, 3, keep)
+        # (at 5 MS/s the same samples are simply read as a stream of half the rate: the arithmetic is what is compared)
+        blk = x[pos:pos + B]
+        pos += B
+        ctx.push(blk)
+        oi, oa = ch.process(blk)
+        gi, ga = ctx.vfo_read_if(vid), ctx.vfo_read(vid)
+        assert gi.shape == oi.shape and ga.shape == oa.shape, (b, mode, gi.shape, oi.shape, ga.shape, oa.shape)
+        head = min(len(oa), 400)
+        assert rms(ga - oa) < _audio_tol(oa) and rms(ga[:head] - oa[:head]) < _audio_tol(oa), (b, mode, in_sr, rms(ga - oa), rms(ga[:head] - oa[:head]))
+        assert rms(gi - oi) / max(rms(oi), 1e-9) < 5e-6 and rms(gi[:head] - oi[:head]) / max(rms(oi), 1e-9) < 5e-6, (b, mode, in_sr, "IF", rms(gi - oi) / rms(oi))
+    ctx.close()
