@@ -133,6 +133,14 @@ def cpu_baseline(base_cfg, nvfo, fft_size):
                                      "audio_frames": int(af.value), "lines": int(ln.value)}
     except Exception as e:
         out["threaded_graph"] = {"error": repr(e)[:200]}
+    # `value` = the reference's threaded graph (what SURVEY.md 8(d) defines as the CPU baseline) when it ran; the process()-only figure stays beside it
+    tg = out.get("threaded_graph", {})
+    if "value" in tg:
+        out["process_only"] = {"value": out["value"], "unit": "Msamples/s", "threads": out["cores"], "sample": out["sample"]}
+        out["value"] = tg["value"]
+        out["cores"] = min(ncpu, tg["threads"])
+        out["sample"] = ("the reference's own threaded graph, SpeedTester-style: " + tg["what"] + "; %d threads on %d hardware threads; reference headers + iq_frontend.cpp compiled -O3 -march=native against "
+                         "the restated VOLK (vectorised dot products) / FFT shim — genuine libvolk / libfftw3f are not installed; median of %s; 10.5 s of wall time" % (tg["threads"], ncpu, tg["runs"]))
     try:  # per-stage single-thread rates
         m0, r0, b0, c0 = (modes[0], rates[0], bws[0], offs[len(offs) // 3]) if plan else (0, 250e3, 150e3, 0.0)
         out["per_stage_single_thread"] = {
@@ -223,18 +231,23 @@ def algorithmic_work(push, plan, sr, nvfo, piped=False, fft_n=0, data_width=1024
     return fl, by, bound
 
 
-def pmc_traffic(cfg, push, nvfo, dom, af=False):
+def pmc_traffic(cfg, push, nvfo, dom, af=False, group=1, per_block=False):
     """HBM bytes per launch set of the dominant family from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
-    FETCH_SIZE x2 per MI355X_MICROARCH.md, tools/rocpd_summary.py) — only when that profile was taken on this very workload."""
-    for name in ("pmc_traffic_cfg%d_push%d.json" % (cfg, push), "pmc_traffic_cfg%d.json" % cfg, "pmc_traffic.json"):
+    FETCH_SIZE x2 per MI355X_MICROARCH.md, tools/rocpd_summary.py) — only when that profile was taken on this very workload (same block size, VFO count
+    and blocks per launch).  per_block: the tick's bytes per BLOCK (a launch of pipelined mode carries up to `group` blocks)."""
+    for name in ("pmc_traffic_cfg%d_push%d_group%d.json" % (cfg, push, group), "pmc_traffic_cfg%d_push%d.json" % (cfg, push), "pmc_traffic_cfg%d.json" % cfg, "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         try:
             prof = json.load(open(path))
             meta = prof.get("_meta", {})
-            if int(meta.get("push", 0)) != push or int(meta.get("cfg", 0)) != cfg or int(meta.get("nvfo", -1)) != nvfo or bool(int(meta.get("af", 0))) != bool(af):
+            if int(meta.get("push", 0)) != push or int(meta.get("cfg", 0)) != cfg or int(meta.get("nvfo", -1)) != nvfo or bool(int(meta.get("af", 0))) != bool(af) or int(meta.get("group", 1)) != group:
                 continue
+            if per_block:
+                return round(float(meta["tick_hbm_bytes_per_block"])) if "tick_hbm_bytes_per_block" in meta else None
+            if dom == "tick" and "tick_hbm_bytes_per_block" in meta and meta.get("tick_launches"):
+                return round(float(meta["tick_hbm_bytes_per_block"]) * float(meta["blocks"]) / float(meta["tick_launches"]))  # the average launch of that run
             hits = [v["hbm_bytes_per_launch"] * v.get("launches_per_push", 1) for k, v in prof.items() if k != "_meta" and any(k.startswith(p) for p in FAMILY_KERNELS.get(dom, []))]
             if hits:
                 return round(max(hits) if dom == "tick" else sum(hits))  # (a tick is ONE launch; cfg 4's profile holds both builds of the tick kernel: the steady-state one is the larger)
@@ -473,7 +486,8 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
         if dom is not None and dom in kernel_ms and dom in by:
             dur = kernel_ms[dom] * 1e-3
             gbs = by[dom] / dur / 1e9
-            traffic = pmc_traffic(base, push, nvfo, dom, af)
+            traffic = pmc_traffic(base, push, nvfo, dom, af, group=group)
+            traffic_block = pmc_traffic(base, push, nvfo, dom, af, group=group, per_block=True) if dom == "tick" else None
             if bound_of.get(dom) == "mfma" and fl.get(dom):
                 tf = fl[dom] / dur / 1e12
                 # pipelined: a timed region of K blocks holds K + depth - 1 launches (the last ones drain the pipeline and carry less than a block's
@@ -485,7 +499,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
                 roof = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5), "traffic": traffic,
                         "frac_full_launch": round(tf_full / FP32_PEAK_TFLOPS, 5), "sum_launch_ms": round(fam[dom][0], 4), "blocks_timed": steps,
                         "algorithmic_flops_per_launch": fl[dom], "algorithmic_bytes_per_launch": by[dom], "hbm_GBps_at_this_rate": round(gbs, 2), "avg_launch_ms": round(kernel_ms[dom], 5),
-                        "launches_timed": launches.get(dom),
+                        "launches_timed": launches.get(dom), "traffic_per_block": traffic_block,
                         "note": ("tick = the ONE launch per block of pipelined mode: every stage of the path (front end, three decimator / resampler / channel stages, discriminator + audio filter, "
                                  "FFT pass 1 / pass 2, zoom, carries, result copies), each working on a different block; flops / bytes = SURVEY.md 8(d) whole-path figures x samples per block; "
                                  if dom == "tick" else
@@ -529,7 +543,7 @@ def run_workload(torch, np, device, local, cfg, push, mode, steps, warmup, nvfo,
             out["result_lag_blocks"] = lag
             st = ctx.pipeline_stats()
             out["pipeline"] = {"ticks": st["ticks"], "blocks_as_ticks": st["tick_blocks"], "blocks_as_ordinary_passes": st["pass_blocks"], "crowded_ticks": st["crowded_ticks"], "depth_levels": st["depth"],
-                               "roles": sorted(st["roles"])}
+                               "roles": sorted(st["roles"]), "blocks_pushed_by_this_context": ctx.ticket()}
             out["blocks_per_launch"] = {"max": group, "adaptive": bool(adaptive and group > 1),
                                         "first_timed_region": {"blocks": steps, "launches": ticks1 - ticks0, "launch_groups": gs1["groups"] - gs0["groups"],
                                                                "groups_of_several_blocks": gs1["multi_groups"] - gs0["multi_groups"], "blocks_in_those": gs1["multi_blocks"] - gs0["multi_blocks"]},
@@ -684,7 +698,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
         ctx.set_deferred(False)
         pflops, _pb, _bps = path_work(B, info["plan"], sr, nvfo, N)
         entry["frac_of_fp32_mfma_peak"] = {k: round(v * 1e6 * pflops / B / 1e12 / FP32_PEAK_TFLOPS, 5) for k, v in entry.items() if isinstance(v, float) and k not in ("push",)}
-        tr = pmc_traffic(3, B, nvfo, "tick")  # pipelined mode, device-resident blocks (committed PMC passes of exactly this workload, or null)
+        tr = pmc_traffic(3, B, nvfo, "tick", group=G, per_block=True)  # pipelined mode, device-resident blocks (committed PMC passes of exactly this workload, or null)
         entry["pipelined_tick_traffic_bytes_per_block"] = tr
         entry["pipelined_tick_traffic_over_algorithmic"] = round(tr / _pb, 2) if tr else None
         ctx.L.sdrpp_host_free(pin_base)
@@ -711,7 +725,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
             cpus = gpu_numa_cpus(torch)
             res["cpp_iqfrontend_cpus"] = ("%d hardware threads of NUMA node %s (the GPU's)" % (len(cpus[1]), cpus[0])) if cpus else "not pinned (no NUMA information)"
             pre = (lambda: os.sched_setaffinity(0, cpus[1])) if cpus else None
-            for name, buffered, pipelined, reps, grp in (("bypass_pipelined", 0, 1, 5, capi.GROUP_MAX), ("bypass_pipelined_one_block_per_launch", 0, 1, 5, 1), ("bypass_per_block", 0, 0, 1, 1), ("buffered", 1, 0, 1, 1)):
+            for name, buffered, pipelined, reps, grp in (("bypass_pipelined", 0, 1, 5, 1), ("bypass_pipelined_launch_groups", 0, 1, 5, capi.GROUP_MAX), ("bypass_per_block", 0, 0, 1, 1), ("buffered", 1, 0, 1, 1)):
                 runs = []  # (the pipelined figure depends on how the host schedules 34 threads: five runs, median reported, min / max and all five listed)
                 for _ in range(reps):
                     r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "2" if reps > 1 else "3", str(buffered), str(pipelined), str(grp)],
@@ -1064,9 +1078,9 @@ def main():
         try:
             out["cpu_baseline"] = cpu_baseline(base, nvfo, N)
             if out["cpu_baseline"]:
-                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)  # (against the process()-only figure: the CPU at its best)
-                if "value" in out["cpu_baseline"].get("threaded_graph", {}):
-                    out["gpu_over_cpu_threaded_graph"] = round(out["value"] / out["cpu_baseline"]["threaded_graph"]["value"], 1)
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                if "value" in out["cpu_baseline"].get("process_only", {}):
+                    out["gpu_over_cpu_process_only"] = round(out["value"] / out["cpu_baseline"]["process_only"]["value"], 1)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
             out["cpu_baseline"] = {"error": repr(e)}
     if world == 1 and base == 3 and not args.no_by_push:

@@ -332,6 +332,11 @@ struct sdrpp_ctx {
     // profiles/r03x_*; the applying wavefronts take up to SKIP - 1 steps per sample themselves, so fewer VFOs per workgroup go with a larger stride)
     int rot_exact_skip = getenv("SDRPP_GPU_ROTX_SKIP") ? atoi(getenv("SDRPP_GPU_ROTX_SKIP")) : 16;
     int rot_exact_vpw = [] { const char* e = getenv("SDRPP_GPU_ROTX_VPW"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    // Grids of a block that is planned while the device has nothing (factor 4) or one launch (2) in flight: its roles will run in ticks that hold little
+    // else — the fill of the pipeline after a pause, a host slower than the device — where the grid rules above (sized for a tick that ~8 roles of
+    // as many blocks share) leave most of the device idle.  The results do not depend on the grids.  SDRPP_GPU_TICK_SPARSE=0: off (measurements).
+    int plan_sparse = 1;
+    bool tick_sparse_boost = getenv("SDRPP_GPU_TICK_SPARSE") ? atoi(getenv("SDRPP_GPU_TICK_SPARSE")) != 0 : false;  // (measured: no gain on the 20-step line, profiles/r06j_sparse_ab.log — off)
     bool tick_planning = false;           // a block is being planned for the tick queue: emit() queues, plain launches abort the plan
     bool tick_abort = false;              // ... and met a launch that has no role in the tick kernel: the block runs as an ordinary pass
     int plan_top = 0;                     // highest level + 1 the block being planned uses

@@ -826,7 +826,7 @@ struct BankPlan {
                 const int long_blocks = m_long ? std::max(1, (int)((size_t)(160 * 1024) / ((size_t)frontcl_lds_floats(K, lgD, fcl_nw) * 4))) : 0;
                 // (a launch group brings one job per push: together they get the wavefronts one job of the whole block would)
                 const int nsub = std::max<int>(1, (int)c->grp_ends.size());
-                const int resident = std::max(64, (m_long ? 256 * long_blocks * fcl_nw : (c->tick_planning ? c->tick_fcm_waves : 3072)) / nsub);
+                const int resident = std::max(64, (m_long ? 256 * long_blocks * fcl_nw : (c->tick_planning ? std::min(3072, c->tick_fcm_waves * c->plan_sparse) : 3072)) / nsub);
                 job.tiles_per_wave = std::max(1, (ntiles + resident - 1) / resident);
                 job.atab = reinterpret_cast<const float*>(d_taps);
                 job.ptab = d_taps + (size_t)NP4 * 32;
@@ -1044,7 +1044,7 @@ struct BankPlan {
             Lev<ToepJob>& L = *tlists[i].L;
             for (int l = 0; l < L.top; l++) {
                 if (L.at[l].empty()) { continue; }
-                tplan[i][l] = toep_plan(L.at[l], tlists[i].npl, c->tick_planning ? c->tick_toep_blocks : 2048);
+                tplan[i][l] = toep_plan(L.at[l], tlists[i].npl, c->tick_planning ? std::min(2048, c->tick_toep_blocks * c->plan_sparse) : 2048);
                 if (tplan[i][l].lds > (size_t)kMaxLds) { return fail(c, SDRPP_ERR_UNSUPPORTED, "matrix-core FIR window does not fit in LDS"); }
             }
             if (!arena_push_lev(c, L)) { return fail(c, SDRPP_ERR_UNSUPPORTED, "job arena exhausted"); }

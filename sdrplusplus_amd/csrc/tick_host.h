@@ -575,6 +575,11 @@ int tick_push(sdrpp_ctx* c, const float* d_iq, int64_t count, const CopyJob* lan
             for (auto& st : c->pre.st) { stream_rotate(st); }
             stream_rotate(c->pre.out);
         }
+        c->plan_sparse = 1;
+        if (c->tick_sparse_boost && c->h_tick_flag) {
+            const int in_flight = (int)((unsigned)c->ticks - *(const volatile unsigned*)c->h_tick_flag);
+            c->plan_sparse = in_flight <= 0 ? 4 : (in_flight == 1 ? 2 : 1);
+        }
         c->tick_planning = true;
         c->tick_abort = false;
         c->emits.clear();

@@ -56,6 +56,7 @@ def main():
         for p in a.pmc:
             for k, c, n, v, d in pmc_stats(p):
                 note, b = "", None
+                per.setdefault(k, {})["n"] = n
                 if c == "FETCH_SIZE":
                     b = v * 1024.0
                     note = "raw; x2 = %.0f (gfx950 FETCH_SIZE correction)" % (2 * b)
@@ -68,7 +69,7 @@ def main():
                 lines.append("| %s | %s | %d | %.1f | %s | %s |" % (k, c, n, v, ("%.0f" % b) if b is not None else "", note))
         for k, d in per.items():
             if "fetch_x2" in d and "write" in d:
-                traffic[k] = {"hbm_bytes_per_launch": d["fetch_x2"] + d["write"], "fetch_raw": d["fetch_raw"], "fetch_x2": d["fetch_x2"], "write": d["write"]}
+                traffic[k] = {"hbm_bytes_per_launch": d["fetch_x2"] + d["write"], "fetch_raw": d["fetch_raw"], "fetch_x2": d["fetch_x2"], "write": d["write"], "dispatches": d.get("n")}
     text = "\n".join(lines) + "\n"
     if a.out:
         open(a.out, "w").write(text)
@@ -76,6 +77,17 @@ def main():
         sys.stdout.write(text)
     if a.json:
         traffic["_meta"] = dict(kv.split("=", 1) for kv in a.meta)
+        # launch groups (round 6): a launch carries several blocks — with blocks=<pushes of the profiled run> the bytes per BLOCK follow
+        if "blocks" in traffic["_meta"]:
+            nb = float(traffic["_meta"]["blocks"])
+            tick = [k for k in traffic if k != "_meta" and "tick_kernel" in k and traffic[k].get("dispatches")]
+            if tick and nb > 0:
+                total = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["dispatches"] for k in tick)
+                traffic["_meta"]["tick_hbm_bytes_per_block"] = total / nb
+                traffic["_meta"]["tick_launches"] = sum(traffic[k]["dispatches"] for k in tick)
+                lines_extra = "\n## per block\n\n%d tick launches carried %d blocks: %.0f HBM bytes per block (FETCH_SIZE x 2 + WRITE_SIZE over all tick launches / blocks)\n" % (traffic["_meta"]["tick_launches"], int(nb), total / nb)
+                if a.out:
+                    open(a.out, "a").write(lines_extra)
         json.dump(traffic, open(a.json, "w"), indent=1)
 
 
