@@ -978,6 +978,20 @@ struct BankPlan {
             const int long_blocks = std::max(1, (int)((size_t)(160 * 1024) / std::max<size_t>(lds_max, 1)));
             const double target = 0.7 * 256.0 * (double)long_blocks * (double)fcl_nw;
             fcl.max_blocks = 0;
+            // Round 6: the jobs of a tick differ in what a tile costs — 257 .. 400 taps (NFM / USB / AM at 61.44 MS/s), 32-row or 16-row tiles — and a walk of
+            // the SAME number of tiles took 1.5x as long in one job as in another: the tick ended on the 400-tap jobs' workgroups (last end 337 us against a
+            // mean life of 220, profiles/r06q_tick_timeline_cfg4_B1000000_group4.txt).  Walk lengths now follow a cost model, tile ~ c0 + c1 * taps (16-row
+            // tiles: 0.45 of the matrix part), so that every wavefront of the role is busy about equally long; the total number of wavefronts still follows
+            // the 0.7-of-the-resident-slots rule.  SDRPP_GPU_FCL_BALANCE=0: the old rule (measurements).
+            static const bool balance = getenv("SDRPP_GPU_FCL_BALANCE") ? atoi(getenv("SDRPP_GPU_FCL_BALANCE")) != 0 : true;
+            static const double c0 = getenv("SDRPP_GPU_FCL_C0") ? atof(getenv("SDRPP_GPU_FCL_C0")) : 1.5, c1 = getenv("SDRPP_GPU_FCL_C1") ? atof(getenv("SDRPP_GPU_FCL_C1")) : 0.031;
+            auto tile_cost = [&](const FrontCMJob& jb) { return c0 + c1 * (double)jb.ntaps * (jb.nv <= 16 ? 0.45 : 1.0); };
+            double total_cost = 0.0;
+            for (auto& jb : fcl.jobs) {
+                const int tile_n = jb.nv <= 16 ? 16 : SDRPP_FCM_TILE;
+                total_cost += tile_cost(jb) * (double)((jb.nout + tile_n - 1) / tile_n);
+            }
+            const double per_wave = total_cost / target;  // what one wavefront should carry
             for (auto& jb : fcl.jobs) {
                 const int tile_n = jb.nv <= 16 ? 16 : SDRPP_FCM_TILE;
                 const int ntiles = (jb.nout + tile_n - 1) / tile_n;
@@ -985,7 +999,8 @@ struct BankPlan {
                 // (ticks: the rule above.  An ordinary pass has the device to itself and its pushes are long: one resident round per JOB as before —
                 // the 0.7 rule gave walks of 34 tiles at 2^24-sample pushes and lost 17 % there, profiles/r05z_bench_default.json vs r05d)
                 const int resident = 256 * long_blocks * fcl_nw;
-                const int tpw = env > 0 ? env : (ticking ? std::max(1, (int)((double)ntiles * (double)fcl.jobs.size() / target + 0.75)) : std::max(1, (ntiles + resident - 1) / resident));
+                int tpw = env > 0 ? env : (ticking ? std::max(1, (int)((double)ntiles * (double)fcl.jobs.size() / target + 0.75)) : std::max(1, (ntiles + resident - 1) / resident));
+                if (env <= 0 && ticking && balance && fcl.jobs.size() > 1) { tpw = std::max(1, (int)(per_wave / tile_cost(jb) + 0.5)); }
                 jb.tiles_per_wave = tpw;
                 fcl.max_blocks = std::max(fcl.max_blocks, (ntiles + fcl_nw * tpw - 1) / (fcl_nw * tpw));
             }

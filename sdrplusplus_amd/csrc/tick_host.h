@@ -92,7 +92,10 @@ inline int tick_role_weight(int role, bool crowded) {
     case TR_PIPE: return 80;  // the longest-lived workgroups behind the front end: a whole segment of four stages
     case TR_TOEP_Q: return 65;
     case TR_TOEP_C: case TR_TOEP_R: case TR_FFT_S10: case TR_FFT_S11: case TR_FFT_S12: return 60;
-    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: case TR_FFT_P2ROW: return 50;
+    case TR_FFT_P2_7: case TR_FFT_P2_8: case TR_FFT_P2_9: case TR_FFT_P2_10: case TR_FFT_P2ROW: {
+        static const int p2_weight = getenv("SDRPP_GPU_TICK_P2_WEIGHT") ? atoi(getenv("SDRPP_GPU_TICK_P2_WEIGHT")) : 50;  // (measurement switch)
+        return p2_weight;
+    }
     case TR_FFT_TR: return 25;
     case TR_ROT: case TR_PRE: return 30;
     case TR_ZOOM_16: case TR_ZOOM_4: case TR_ZOOM_1: return 20;

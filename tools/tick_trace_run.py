@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run N pipelined blocks of a configuration on the `make ticktrace` build and dump the per-workgroup timeline of the tick kernel.
-   tools/tick_trace_run.py <cfg> <block> <nblocks> <dump.bin> [host|af]   (af: the radio's AF chain behind every VFO)"""
+   tools/tick_trace_run.py <cfg> <block> <nblocks> <dump.bin> [host|af]   (af: the radio's AF chain behind every VFO)
+   TICK_GROUP=<k>: up to k blocks per launch (sdrpp_set_pipeline_group, fixed; the blocks are consecutive slices of one device tensor)"""
 import os
 import sys
 
@@ -19,7 +20,8 @@ os.environ["SDRPP_TICK_TRACE_FILE"] = path
 if os.path.exists(path):
     os.remove(path)
 nvfo = workloads.CFG[cfg]["nvfo"]
-ctx = capi.Context(0, max_push=B)
+G = int(os.environ.get("TICK_GROUP", "1"))
+ctx = capi.Context(0, max_push=B * G)
 info = workloads.setup(ctx, cfg, dense_fft=True, data_width=1024, nvfo=nvfo or None)
 if len(sys.argv) > 5 and sys.argv[5] == "af":
     from sdrplusplus_amd import radio
@@ -28,8 +30,12 @@ if len(sys.argv) > 5 and sys.argv[5] == "af":
         a_, k_ = radio.af_desc(r_, 48000.0, 50e-6 if m_ == "WFM" else None, m_ == "NFM")
         ctx.vfo_set_af(vid, a_, k_)
         _keep.append(k_)
-xd = [torch.from_numpy(workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None).view(np.float32)).to("cuda") for i in range(4)]
+nslice = max(4, G)
+xall = torch.from_numpy(np.concatenate([workloads.synth(cfg, B, seed=7 + i, nvfo=nvfo or None) for i in range(nslice)]).view(np.float32)).to("cuda")
+xd = [xall[2 * i * B:2 * (i + 1) * B] for i in range(nslice)]
 ctx.set_pipelined(True, 0)
+if G > 1:
+    ctx.set_pipeline_group(G, False)
 if from_host:
     import ctypes as C
     ptrs = []
@@ -42,7 +48,7 @@ for i in range(n):
     if from_host:
         ctx.push_host_ptr_async(ptrs[i % 4], B)
     else:
-        ctx.push_device(xd[i % 4].data_ptr(), B)
+        ctx.push_device(xd[i % nslice].data_ptr(), B)
 ctx.sync()
 ctx.close()
 print("dumped", os.path.getsize(path) // 72, "records")
