@@ -155,6 +155,7 @@ def load():
     L.sdrpp_wf_signal_info.argtypes = [vp, C.c_double, C.c_double, C.c_double, c_float_p, c_float_p]
     L.sdrpp_wf_raster.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_int32_p, c_int_p]
     L.sdrpp_preproc_configure.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_float, C.c_int]
+    L.sdrpp_preproc_reconfigure.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_float, C.c_int, C.c_int]
     L.sdrpp_preproc_out_count.argtypes = [vp]
     L.sdrpp_preproc_read.argtypes = [vp, c_float_p, C.c_int]
     L.sdrpp_preproc_device_buffer.argtypes = [vp, C.POINTER(vp), c_int_p]
@@ -515,6 +516,15 @@ class Context:
         arrs = [np.ascontiguousarray(t, dtype=np.float32) for _, t in stages]
         ptrs = (c_float_p * max(n, 1))(*[a.ctypes.data_as(c_float_p) for a in arrs])
         self._chk(self.L.sdrpp_preproc_configure(self.h, n, dec, nt, ptrs, float(dc_rate), int(bool(conjugate))))
+
+    def preproc_reconfigure(self, stages=(), dc_rate=0.0, conjugate=False, keep=3):
+        """sdrpp_preproc_reconfigure: re-plan the chain while the stream runs; keep & 1 = the decimator's delay lines (same stages), keep & 2 = the DC blocker's estimate."""
+        n = len(stages)
+        dec = (C.c_int * max(n, 1))(*[int(d) for d, _ in stages])
+        nt = (C.c_int * max(n, 1))(*[len(t) for _, t in stages])
+        arrs = [np.ascontiguousarray(t, dtype=np.float32) for _, t in stages]
+        ptrs = (c_float_p * max(n, 1))(*[a.ctypes.data_as(c_float_p) for a in arrs])
+        self._chk(self.L.sdrpp_preproc_reconfigure(self.h, n, dec, nt, ptrs, float(dc_rate), int(bool(conjugate)), int(keep)))
 
     def preproc_set_reference_order(self, on=True):
         """Parity mode of the pre-processing chain: the reference's own tap-ordered multiply-then-add decimator and sequential DC blocker."""

@@ -629,11 +629,15 @@ protected:
         // the worker finishes the block it holds (its read() fails next) and the open hand-over completes — microseconds when the sinks read —
         // and only a sink that does not read (the case stopWriter() exists for) runs into the time-out and loses the block, as in the reference.
         {
+            // (every setter goes through here with ctrlMtx held — a sink that has stopped reading must not cost EVERY setter the whole grace
+            // period: once a stop has run into the time-out, the following ones wait 5 ms at most until one completes in time again)
             const auto t0 = std::chrono::steady_clock::now();
-            const auto limit = std::chrono::milliseconds(_stopGraceMs);
-            while ((!workerDone.load(std::memory_order_acquire) || helpers.busy()) && std::chrono::steady_clock::now() - t0 < limit) {
+            const auto limit = std::chrono::milliseconds(_lastStopTimedOut ? std::min(_stopGraceMs, 5) : _stopGraceMs);
+            bool pending = true;
+            while ((pending = (!workerDone.load(std::memory_order_acquire) || helpers.busy())) && std::chrono::steady_clock::now() - t0 < limit) {
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
+            _lastStopTimedOut = pending;
         }
         for (auto& out : outputs) { out->stopWriter(); }
         {
@@ -1142,6 +1146,7 @@ private:
     bool _dcBlocking = false, _invertIQ = false;
     std::atomic<bool> _buffering{ false };
     std::atomic<bool> _pipelining{ false };
+    bool _lastStopTimedOut = false;         // doStop: the previous stop ran into its grace period (a sink is not reading)
     int _spinUs = 100;                      // setSpinWait
     dsp::stream<dsp::complex_t>* spinStream = nullptr;
     const void* spinLast = nullptr;         // the input stream's readBuf at the last read(): swap() exchanges it (worker)

@@ -52,7 +52,10 @@ int main(int argc, char** argv) {
     const bool buffered = argc > 8 && std::string(argv[8]) == "buffered";
     // "pipelined": the bypass path as one launch per block (IQFrontEnd::setPipelining), results handed out a few blocks late and the tail by
     // drainPipeline() after stop() — with the IQ tap bound and the AF chain attached like in the other modes (round 4: both stay pipelined).
-    const bool pipelined = argc > 8 && std::string(argv[8]) == "pipelined";
+    // "pipelined_groups": the same with up to four blocks per launch (setPipelining(true, lag, 4): sdrpp_set_pipeline_group, adaptive) — the source here is
+    // far slower than a launch, so groups form only when the worker falls behind; the results must not depend on whether they do.
+    const bool groups = argc > 8 && std::string(argv[8]) == "pipelined_groups";
+    const bool pipelined = groups || (argc > 8 && std::string(argv[8]) == "pipelined");
     const int drainMs = argc > 9 ? atoi(argv[9]) : (buffered ? 1500 : 300);  // time to let handed-over blocks drain (the CPU emulator needs seconds)
     const size_t nsamp = iq.size() / 2;
 
@@ -86,7 +89,7 @@ int main(int argc, char** argv) {
 #endif
     // a consumer of the (pre-processed) wideband IQ, like the recorder's baseband tap (recorder/src/main.cpp:209,229)
     dsp::stream<dsp::complex_t> iqTap;
-    if (pipelined) { fe.setPipelining(true, 4); }
+    if (pipelined) { fe.setPipelining(true, 4, groups ? 4 : 1); }
     fe.bindIQStream(&iqTap);
     {
         bool threw = false;

@@ -86,7 +86,7 @@ def _run_graph_and_check(exe, mode, tmp, drain_ms=None):
     assert np.sqrt(np.mean(np.abs(ifs[:n2] - oi[:n2]) ** 2)) / np.sqrt(np.mean(np.abs(oi[:n2]) ** 2)) < 5e-6
 
 
-@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined"])
+@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined", "pipelined_groups"])
 def test_host_mirror_threaded_graph_on_the_emulator(mode):
     """The C++ mirror built against the test double of dsp::block / dsp::stream, linked with the CPU emulator build of the library:
     source thread, front-end worker (+ frame-buffer worker when buffering is on), sink threads; setInput, bindIQStream,
@@ -94,7 +94,7 @@ def test_host_mirror_threaded_graph_on_the_emulator(mode):
     # (pipelined: the source is decoupled from the emulated launch by one more block and the 20-VFO bank takes seconds per block there,
     # so "everything handed over has been consumed" needs a longer wait before the change of source; the figures are ~5 x what the emulator needs since its fibers switch in user space)
     with tempfile.TemporaryDirectory() as tmp:
-        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=6000 if mode == "pipelined" else 3000)
+        _run_graph_and_check(_build(tmp, lib="emu"), mode, tmp, drain_ms=6000 if mode.startswith("pipelined") else 3000)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/core/src/dsp"), reason="needs the reference tree")
@@ -366,7 +366,7 @@ def test_device_math_helpers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined"])
+@pytest.mark.parametrize("mode", ["bypass", "buffered", "pipelined", "pipelined_groups"])
 def test_threaded_graph_matches_oracle(mode):
     with tempfile.TemporaryDirectory() as tmp:
         _run_graph_and_check(_build(tmp), mode, tmp)

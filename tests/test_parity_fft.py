@@ -483,3 +483,51 @@ def test_reference_blocks_behind_the_preproc_decimator(backend):
             e = rms(g - ref[k]) / max(1.0, rms(ref[k]))
             assert e < 1e-5, (name, m, e)
         ctx.close()
+
+
+def test_preproc_reconfigure_carries_what_the_reference_carries(backend):
+    """sdrpp_preproc_reconfigure against the compiled reference's chain objects re-planned the way IQFrontEnd's setters re-plan them (iq_frontend.cpp:76-130;
+    oracle/ref_api.cpp: ref_preproc_set): setDecimation(4) (new stages), setDCBlocking(true), setSampleRate (the DC blocker's rate changes, its estimate and the
+    decimator's delay lines stay), setInvertIQ(true), setDCBlocking(false) and on again (the estimate it had), setDecimation(2).  In the reference's own arithmetic
+    (sdrpp_preproc_set_reference_order) the pre-processed stream is BIT-identical block for block; in the default arithmetic it is within the chain's tolerance."""
+    from sdrplusplus_amd import capi, radio
+
+    if not S.ref_available():
+        pytest.skip("oracle/_ref not built (needs the reference tree at build time)")
+    B = 24000
+    steps = [  # (ratio, dc, effective rate for the DC blocker, conj, new decimator, keep)
+        (1, False, 2.4e6, False, False, 3),
+        (4, False, 0.6e6, False, True, 2),
+        (4, True, 0.6e6, False, False, 3),
+        (4, True, 0.5e6, False, False, 3),
+        (4, True, 0.5e6, True, False, 3),
+        (4, False, 0.5e6, True, False, 3),
+        (4, True, 0.5e6, True, False, 3),
+        (2, True, 1.0e6, True, True, 2),
+    ]
+    rng = np.random.default_rng(91)
+    n = np.arange(B * len(steps) * 2)
+    x = (0.2 * np.exp(2j * np.pi * 0.11 * n) + (0.07 - 0.04j) + 0.01 * (rng.standard_normal(len(n)) + 1j * rng.standard_normal(len(n)))).astype(np.complex64)
+    for ref_order in (True, False):
+        ctx = capi.Context(0, max_push=B)
+        ctx.preproc_set_reference_order(ref_order)
+        pre = S.RefPreproc(1, False, 50.0 / 2.4e6, False)
+        pos = 0
+        for k, (ratio, dc, eff, conj, newdec, keep) in enumerate(steps):
+            rate = 50.0 / eff
+            pre.set(ratio, dc, rate, conj, newdec)
+            ctx.preproc_reconfigure(radio.plans().stages(ratio) if ratio > 1 else [], rate if dc else 0.0, conj, keep)
+            for _ in range(2):
+                blk = x[pos:pos + B]
+                pos += B
+                want = pre.process(blk)
+                if ratio == 1 and not dc and not conj:
+                    continue  # (no chain: the device hands the block straight through, nothing to read back)
+                ctx.push(blk)
+                got = ctx.preproc_read()
+                assert got.shape == want.shape, (k, got.shape, want.shape)
+                if ref_order:
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, ratio, dc, conj, float(np.max(np.abs(got - want))))
+                else:
+                    assert rms(got - want) / max(rms(want), 1e-9) < 2e-4 and rms(got[:64] - want[:64]) / max(rms(want), 1e-9) < 5e-4, (k, ratio, dc, conj, rms(got - want) / rms(want))
+        ctx.close()
