@@ -584,13 +584,14 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
     dev = torch.device("cuda", torch.cuda.current_device())
     for B in (int(sr / 200), STREAM_CAP):
         per_pass = max(1, STREAM_CAP // B)
-        # blocks per launch of the grouped legs: what the headline uses at the stream cap, SDRPP_GROUP_MAX at the reference's block size (a launch of
-        # 8 x 50 000 samples is still a fraction of one at 10^6)
+        # blocks per launch of the grouped legs: what the headline uses at the stream cap, SDRPP_GROUP_MAX = 32 at the reference's block size (a launch of
+        # 8 x 50 000 samples is still a fraction of one at 10^6: 13.1 GS/s at 8, 16.4 at 16, 17.3 at 24-32 where the host's 3 us per push take over,
+        # profiles/r06t_group_sweep.log)
         G = max(1, min(capi.GROUP_MAX, group if B >= STREAM_CAP else capi.GROUP_MAX))
         ctx = capi.Context(dev.index or 0, max_push=B * max(per_pass, G))
         info = workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=nvfo)
         vids = info["vids"]
-        nb = 8  # consecutive blocks of ONE allocation (device and page-locked host): contiguous, so that they can share a launch; the wrap-around starts a new group
+        nb = max(8, 2 * G)  # consecutive blocks of ONE allocation (device and page-locked host): contiguous, so that they can share a launch; the wrap-around starts a new group
         xs = [workloads.synth(3, B, seed=7 + i, nvfo=nvfo) for i in range(nb)]
         pin_base = ctx.L.sdrpp_host_alloc(nb * B * 8)
         ptrs = []
@@ -615,7 +616,8 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
                 best = max(best, B * npush / (time.perf_counter() - t0) / 1e6)
             return round(best, 1)
 
-        npush = max(8, min(400, (1 << 26) // B))
+        npush = max(8, min(400, (1 << 26) // B), 40 * G if B < STREAM_CAP else 0)  # (a launch group of G blocks: 40 launches per trial, the pipeline's fill and drain are 7 of them)
+        xp = [t.data_ptr() for t in xd]
         # ---- ordinary passes ----
         def sync_pinned(i):
             ctx.push_host_ptr(ptrs[i % nb], B)
@@ -629,13 +631,13 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
 
         entry["per_push_read_pinned"] = rate(sync_pinned, min(npush, 200))
         entry["per_push_read_pageable"] = rate(sync_pageable, min(npush, 200))
-        entry["device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        entry["device_no_read"] = rate(lambda i: ctx.push_device(xp[i % nb], B), npush)
         # ---- pipelined: one launch per block (rounds 3-5), then up to G blocks per launch (sdrpp_set_pipeline_group, adaptive) ----
         ctx.set_pipelined(True, 0)
-        entry["pipelined_device_no_read_one_block_per_launch"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        entry["pipelined_device_no_read_one_block_per_launch"] = rate(lambda i: ctx.push_device(xp[i % nb], B), npush)
         entry["pipelined_pinned_no_read_one_block_per_launch"] = rate(lambda i: ctx.push_host_ptr_async(ptrs[i % nb], B), npush)
         ctx.set_pipeline_group(G, True)
-        entry["pipelined_device_no_read"] = rate(lambda i: ctx.push_device(xd[i % nb].data_ptr(), B), npush)
+        entry["pipelined_device_no_read"] = rate(lambda i: ctx.push_device(xp[i % nb], B), npush)
         entry["pipelined_pinned_no_read"] = rate(lambda i: ctx.push_host_ptr_async(ptrs[i % nb], B), npush)
         gs = ctx.pipeline_group_stats()
         entry["pipelined_blocks_per_launch_seen"] = round(gs["multi_blocks"] / max(1, gs["multi_groups"]), 2)
@@ -668,7 +670,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
         lag = min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1) * G
 
         def with_results_device(i):
-            ctx.push_device(xd[i % nb].data_ptr(), B)
+            ctx.push_device(xp[i % nb], B)
             collect(ctx.ticket() - lag)
 
         entry["pipelined_pinned_results_delivered"] = rate(with_results, npush, lambda: collect(ctx.ticket()))
@@ -725,7 +727,7 @@ def by_push_report(torch, capi, workloads, sr, nvfo, N, group=4):
             cpus = gpu_numa_cpus(torch)
             res["cpp_iqfrontend_cpus"] = ("%d hardware threads of NUMA node %s (the GPU's)" % (len(cpus[1]), cpus[0])) if cpus else "not pinned (no NUMA information)"
             pre = (lambda: os.sched_setaffinity(0, cpus[1])) if cpus else None
-            for name, buffered, pipelined, reps, grp in (("bypass_pipelined", 0, 1, 5, 1), ("bypass_pipelined_launch_groups", 0, 1, 5, capi.GROUP_MAX), ("bypass_per_block", 0, 0, 1, 1), ("buffered", 1, 0, 1, 1)):
+            for name, buffered, pipelined, reps, grp in (("bypass_pipelined", 0, 1, 5, 1), ("bypass_pipelined_launch_groups", 0, 1, 5, 8), ("bypass_per_block", 0, 0, 1, 1), ("buffered", 1, 0, 1, 1)):
                 runs = []  # (the pipelined figure depends on how the host schedules 34 threads: five runs, median reported, min / max and all five listed)
                 for _ in range(reps):
                     r = subprocess.run([exe, os.path.join(ROOT, "sdrplusplus_amd", "data", "decim_plans.bin"), str(sr), str(int(sr / 200)), str(N), str(nvfo), "2" if reps > 1 else "3", str(buffered), str(pipelined), str(grp)],

@@ -407,7 +407,7 @@ int sdrpp_push_staged(sdrpp_ctx* ctx, int64_t count);
  * a word that does not reach 0 within 5 s fails the push.  sdrpp_gpu::IQFrontEnd's pipelined worker stages its blocks this way. */
 int sdrpp_push_staged_when(sdrpp_ctx* ctx, int64_t count, const volatile uint32_t* pending);
 #define SDRPP_RESULT_SLOTS 24
-#define SDRPP_GROUP_MAX 8
+#define SDRPP_GROUP_MAX 32
 typedef struct sdrpp_result {
     uint64_t ticket;          /* the block: 1 for the first push in pipelined mode, counted by sdrpp_ticket                          */
     int n_vfo;                /* VFO blocks delivered (0 without result flag 1), in sdrpp_vfo_add order                              */

@@ -100,7 +100,7 @@ class Result(C.Structure):
 
 ABI_VERSION = 2    # SDRPP_ABI_VERSION (include/sdrpp_gpu.h)
 RESULT_SLOTS = 24  # SDRPP_RESULT_SLOTS: launches (one block each, or a group of up to GROUP_MAX: sdrpp_set_pipeline_group) whose pipelined results can exist at a time
-GROUP_MAX = 8      # SDRPP_GROUP_MAX
+GROUP_MAX = 32     # SDRPP_GROUP_MAX
 
 
 class SdrppError(RuntimeError):

@@ -434,6 +434,31 @@ public:
 #define SDRPP_GPU_NO_TSAN
 #endif
     // (a peek at a pointer another thread exchanges under its lock: only ever a hint — read() is what takes the block)
+    // The input stream's buffer is read by THIS side's threads and filled again by the source's thread two blocks later.  Lines that other cores have read
+    // cost the writer an ownership request each: at the seam a SpeedTester-style source (speed_tester.h:75-81: one memcpy + swap() per block) needed
+    // 38-44 us for its 400 KB memcpy — ~10 GB/s, the whole cycle of a block — while this side's copy took 8.  So the copy threads write the lines back and
+    // drop them from every cache (clflushopt) once they are in the staging slot: the source's fill 41 -> 15 us, the seam 1 030-1 190 -> 1 590-1 650 MS/s
+    // (same box, alternating runs: profiles/r06v_seam_evict.log).  SDRPP_GPU_STAGE_EVICT=0 turns it off (measurements); not x86-64 / no clflushopt: off.
+    static bool cpuHasClflushopt() {
+#if defined(__x86_64__)
+        unsigned a = 7, b = 0, c = 0, d = 0;
+        __asm__ volatile("cpuid" : "+a"(a), "=b"(b), "+c"(c), "=d"(d));
+        return ((b >> 23) & 1u) != 0;
+#else
+        return false;
+#endif
+    }
+    static void evictLines(const void* ptr, size_t n) {
+#if defined(__x86_64__)
+        const char* p = (const char*)ptr;
+        const char* e = p + n;
+        for (const char* q = (const char*)((uintptr_t)p & ~(uintptr_t)63); q < e; q += 64) { __asm__ volatile(".byte 0x66; clflush %0" : "+m"(*(volatile char*)q)); }  // (= clflushopt)
+        __asm__ volatile("sfence" ::: "memory");
+#else
+        (void)ptr; (void)n;
+#endif
+    }
+    bool _stageEvict = cpuHasClflushopt() && !(getenv("SDRPP_GPU_STAGE_EVICT") && atoi(getenv("SDRPP_GPU_STAGE_EVICT")) == 0);
     SDRPP_GPU_NO_TSAN static const void* peekReadBuf(dsp::stream<dsp::complex_t>* st) { return __atomic_load_n(reinterpret_cast<void* const*>(&st->readBuf), __ATOMIC_RELAXED); }
 
     int runBlock() {
@@ -486,6 +511,7 @@ public:
                         if (!n) { continue; }
                         cj.emplace_back([this, srcb, dstb, o, n]() {
                             memcpy(dstb + o, srcb + o, n);
+                            if (_stageEvict) { evictLines(srcb + o, n); }
                             if (stageLeft.fetch_sub(1, std::memory_order_acq_rel) == 1) { _in->flush(); }  // the stream buffer is free (BEFORE the word reaches 0: the worker's next read() follows it)
                             stagePending.fetch_sub(1, std::memory_order_release);
                         });
@@ -531,6 +557,7 @@ public:
             }
             if (pipeOn && leavePipelined() < 0) { return -1; }
             int rc = stage((const dsp::complex_t*)_in->readBuf, count);  // the H2D copy is complete on return: the stream buffer is free
+            if (_stageEvict) { evictLines(_in->readBuf, (size_t)count * sizeof(dsp::complex_t)); }
             _in->flush();
             if (rc >= 0) { rc = deliver((const dsp::complex_t*)nullptr, count); }
             return rc < 0 ? -1 : count;
@@ -543,6 +570,7 @@ public:
                 if (!frames[frameWrite]) { throw std::runtime_error("[sdrpp_gpu::IQFrontEnd] cannot allocate a frame-buffer slot"); }
             }
             memcpy(frames[frameWrite], _in->readBuf, (size_t)count * sizeof(dsp::complex_t));
+            if (_stageEvict) { evictLines(_in->readBuf, (size_t)count * sizeof(dsp::complex_t)); }
             frameSizes[frameWrite] = count;
             frameWrite = (frameWrite + 1) % FRAME_SLOTS;
         }

@@ -7,6 +7,7 @@
 // bench.py runs) and, where the reference tree is absent, by bench.py against tests/host_cpp/standalone (the test double of those headers).
 #include <fcntl.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -91,11 +92,20 @@ int main(int argc, char** argv) {
     fe.start();
     std::atomic<bool> stop{ false };
     std::atomic<long long> fed{ 0 };
+    // where the source thread's time goes (two clock reads per block): filling writeBuf (the SpeedTester's memcpy — the lines of that buffer were last read
+    // by OTHER cores, the front end's copy helpers) and swap() (waiting for the reader's flush() of the block before)
+    std::atomic<long long> srcFillNs{ 0 }, srcSwapNs{ 0 }, srcBlocks{ 0 };
     std::thread source([&]() {
         int b = 0;
         while (!stop) {
+            const auto a0 = std::chrono::steady_clock::now();
             memcpy(src.writeBuf, blocks[(size_t)(b++ & 3)].data(), sizeof(dsp::complex_t) * (size_t)block);
+            const auto a1 = std::chrono::steady_clock::now();
             if (!src.swap(block)) { break; }
+            const auto a2 = std::chrono::steady_clock::now();
+            srcFillNs += std::chrono::duration_cast<std::chrono::nanoseconds>(a1 - a0).count();
+            srcSwapNs += std::chrono::duration_cast<std::chrono::nanoseconds>(a2 - a1).count();
+            srcBlocks++;
             fed += block;
         }
     });
@@ -116,7 +126,10 @@ int main(int argc, char** argv) {
 #endif
     // the frame buffer does not back-pressure its producer (an overrun drops a lap, like the reference's): count what came OUT
     const double processed = nvfo > 0 ? ((double)(a1 - a0) / nvfo) * (sr / 250000.0) : (double)(l1 - l0) * fftSize;
-    printf("{\"block\": %d, \"buffered\": %s, \"pipelined\": %s, \"blocks_per_launch_max\": %d, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f}\n", block,
-           buffered ? "true" : "false", pipelined ? "true" : "false", pipelined ? group : 1, nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt);
+    const double nb = (double)std::max<long long>(1, srcBlocks);
+    printf("{\"block\": %d, \"buffered\": %s, \"pipelined\": %s, \"blocks_per_launch_max\": %d, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f, "
+           "\"source_us_per_block_fill\": %.1f, \"source_us_per_block_swap\": %.1f}\n", block,
+           buffered ? "true" : "false", pipelined ? "true" : "false", pipelined ? group : 1, nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt,
+           (double)srcFillNs / nb / 1e3, (double)srcSwapNs / nb / 1e3);
     return 0;
 }

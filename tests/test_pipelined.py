@@ -714,6 +714,46 @@ def test_grouped_launches_equal_block_by_block(backend, feed):
     cb.close()
 
 
+@pytest.mark.parametrize("feed", ["host", "device"])
+def test_largest_group_of_reference_size_blocks(backend, feed):
+    """SDRPP_GROUP_MAX blocks of the reference's size in ONE launch (what a file played faster than the device works comes to): 2 x GROUP_MAX + 3 pushes
+    of uneven small blocks, every push with its own ticket, VFO blocks and lines, bit-identical to the ordinary pass block by block."""
+    from sdrplusplus_amd import capi, workloads
+
+    K = capi.GROUP_MAX
+    nv = 12 if backend == "gpu" else 5
+    base = 12000 if backend == "gpu" else 2400
+    rng = np.random.default_rng(11)
+    pushes = [int(base + rng.integers(-base // 10, base // 10)) for _ in range(2 * K + 3)]
+    x = workloads.synth(3, sum(pushes), seed=9, nvfo=nv)
+    cap = sum(sorted(pushes)[-K:]) + 16
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, cap, 4096)
+    cb.set_pipeline_group(K)
+    dev = _device_copy_of(cb, x) if feed == "device" else None
+    refs, pos = [], 0
+    for i, n in enumerate(pushes):
+        blk = x[pos:pos + n]
+        refs.append(_ordinary_results(ca, va, blk, True))
+        if feed == "host":
+            cb.push(blk)
+        else:
+            cb.push_device(dev + 8 * pos, n)
+        pos += n
+        assert cb.ticket() == i + 1
+    gs = cb.pipeline_group_stats()
+    assert gs["held"] == 3 and gs["largest"] == K and gs["groups"] == 2, gs
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    gs = cb.pipeline_group_stats()
+    assert gs["held"] == 0 and gs["groups"] == 3, gs
+    if dev:
+        cb.L.sdrpp_device_free(cb.h, dev)
+    ca.close()
+    cb.close()
+
+
 def test_grouped_launches_mixed_modes_af_and_reference_blocks(backend):
     """Groups of four over a cfg 4 bank (NFM / AM / USB: chains of different depth and rate, AGC look-ahead that follows the reference's blocks inside every
     push) with the radio's AF chain on some VFOs: per-push shares of every output — the AF chain's 48 kHz stream included — identical to the ordinary pass;

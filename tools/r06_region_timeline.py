@@ -23,10 +23,12 @@ ctx.set_pipelined(True, 2)
 ctx.set_pipeline_group(G, adaptive)
 max_lines = (push + N - 1) // N + 1
 lines = torch.zeros((4, max_lines + 1, width), dtype=torch.float32, device=dev)
-r = multi.StreamRunner(ctx, bufs, push, lines, sync=torch.cuda.synchronize, pipelined=True, lag=8 * G, gather_every=4)
+r = multi.StreamRunner(ctx, bufs, push, lines, sync=torch.cuda.synchronize, pipelined=True, lag=8, gather_every=4)
 for i in range(25):
     r.step(i)
 r.finish(); torch.cuda.synchronize()
+r.lag = max(r.lag, min(capi.RESULT_SLOTS - 2, int(ctx.pipeline_stats()["depth"]) + 1) * G)  # as bench.py sets it
+print("lag", r.lag, "depth", ctx.pipeline_stats()["depth"])
 for rep in range(3):
     ev = []
     torch.cuda.synchronize()
