@@ -490,8 +490,7 @@ public:
                 }
                 // The block goes into the library's page-locked staging slot — the largest single host cost of a block (400 KB at sr/200 of
                 // 10 MS/s) — and is fetched from there by the launch.  Round 3b, in the order that frees the source soonest: the copy starts at
-                // once on threads of its own (`stagers`), the one that finishes last frees the stream buffer; meanwhile this thread joins the
-                // hand-over of the block delivered last (the helpers have had a block's time for it) and plans the new block inside
+                // once on threads of its own (`stagers`), the one that finishes last frees the stream buffer; meanwhile this thread plans the new block inside
                 // sdrpp_push_staged_when — the job tables do not depend on the samples — and the library holds the block's launch back until the
                 // last part has landed.  (Per block the reference's stream costs two futex wake-ups, source -> worker -> source, ~10 us each:
                 // the time from read() to flush() is the one part of that cycle this side controls; it went from ~19 us to the copy's ~7.)
@@ -500,7 +499,7 @@ public:
                 if (!prc) {
                     const char* srcb = (const char*)_in->readBuf;
                     char* dstb = (char*)slot;
-                    const size_t bytes = (size_t)count * sizeof(dsp::complex_t), parts = bytes >= (size_t)(64 << 10) ? 3 : 1, per = ((bytes / parts) + 63) & ~(size_t)63;
+                    const size_t bytes = (size_t)count * sizeof(dsp::complex_t), parts = bytes >= (size_t)(64 << 10) ? (size_t)kStagers : 1, per = ((bytes / parts) + 63) & ~(size_t)63;
                     std::vector<std::function<void()>> cj;
                     size_t njobs = 0;
                     for (size_t q = 0; q < parts; q++) { njobs += (q * per < bytes) ? 1 : 0; }
@@ -517,9 +516,9 @@ public:
                         });
                     }
                     stagers.begin(std::move(cj));
-                    // (a hand-over that failed means its stream was stopped under it — that block is gone, like a block the reference has in flight
-                    // at a stop; whether THIS worker ends is decided by read() alone)
-                    (void)finishDelivery();
+                    // The hand-over of the block delivered last (32 swap()s = 32 futex wake-ups on the helpers, ~16-18 us of wall time) is NOT joined here
+                    // any more: it runs while this thread plans and launches the new block, startDelivery joins it below.  (Round 6: with the source no
+                    // longer the slow side — see evictLines — the join here had become 15.7 us of a 34 us cycle, profiles/r06v_seam_prof_evict.log.)
                     SDRPP_PIPE_TICK(1)
                     static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the pending word is handed to the C ABI as a plain uint32_t");
                     prc = sdrpp_push_staged_when(ctx, count, reinterpret_cast<const volatile uint32_t*>(&stagePending));
@@ -633,6 +632,7 @@ public:
 #ifndef SDRPP_GPU_HELPERS
 #define SDRPP_GPU_HELPERS 8
 #endif
+    int kStagers = [] { const char* e = getenv("SDRPP_GPU_STAGERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();  // threads of the staging copy (measurement switch)
     static constexpr int kHelpers = SDRPP_GPU_HELPERS;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log)
 
 protected:
@@ -641,7 +641,7 @@ protected:
     void doStart() override {
         stopFrameWorker = false;
         helpers.start(kHelpers);  // hand-overs: 32 stream swaps per block are 32 futex wake-ups (~3 us each for the waker)
-        stagers.start(3);
+        stagers.start(kStagers);
         workerDone.store(false, std::memory_order_relaxed);
         workerThread = std::thread([this]() {
             workerLoop();
