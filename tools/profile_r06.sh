@@ -20,10 +20,10 @@ except Exception:
     print(0)
 PY
 }
-prof() {  # name, bench args
-    name=$1; shift; args=$1; shift
+prof() {  # name, bench args [, steps + warmup]
+    name=$1; shift; args=$1; shift; sw=${1:---steps 60 --warmup 10}
     for ctr in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_${name}_$ctr -o p -- $BENCH $args --steps 60 --warmup 10 > $R/$O/pmc_${name}_$ctr.log 2>&1
+        timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $R/$O/pmc_${name}_$ctr -o p -- $BENCH $args $sw > $R/$O/pmc_${name}_$ctr.log 2>&1
     done
 }
 prof cfg3 ""
@@ -31,6 +31,7 @@ prof cfg3_g1 "--group 1"
 prof cfg2 "--cfg 2"
 prof cfg4 "--cfg 4"
 prof cfg3_sr200 "--push 50000 --group 8"
+prof cfg3_sr200_g32 "--push 50000 --group 32" "--steps 960 --warmup 96"
 MIX=""
 i=0
 for ctr in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU" \
@@ -47,7 +48,7 @@ python tools/rocpd_summary.py $(db trace) --pmc $(db pmc_cfg3_FETCH_SIZE) $(db p
     --meta push=1000000 cfg=3 nvfo=32 mode=pipelined group=4 blocks=$(blocks_of $O/pmc_cfg3_FETCH_SIZE.log) 2>&1 | tail -2
 python tools/rocpd_summary.py $(db pmc_cfg3_g1_FETCH_SIZE) --pmc $(db pmc_cfg3_g1_FETCH_SIZE) $(db pmc_cfg3_g1_WRITE_SIZE) --out $O/${TAG}_cfg3_pipelined_1M_group1.md --json $O/pmc_traffic_cfg3_push1000000.json \
     --title "round 6: the same with ONE block per launch (--group 1)" --meta push=1000000 cfg=3 nvfo=32 mode=pipelined group=1 blocks=$(blocks_of $O/pmc_cfg3_g1_FETCH_SIZE.log) 2>&1 | tail -1
-for spec in "cfg2 2 1000000 0 4" "cfg4 4 1000000 128 4" "cfg3_sr200 3 50000 32 8"; do
+for spec in "cfg2 2 1000000 0 4" "cfg4 4 1000000 128 4" "cfg3_sr200 3 50000 32 8" "cfg3_sr200_g32 3 50000 32 32"; do
     set -- $spec
     python tools/rocpd_summary.py $(db pmc_$1_FETCH_SIZE) --pmc $(db pmc_$1_FETCH_SIZE) $(db pmc_$1_WRITE_SIZE) --out $O/${TAG}_$1_pipelined.md --json $O/pmc_traffic_cfg$2_push$3_group$5.json \
         --title "round 6: $1, pipelined mode, $3-sample blocks, up to $5 blocks per launch (kernel durations here are those of the PMC pass)" --meta push=$3 cfg=$2 nvfo=$4 mode=pipelined group=$5 blocks=$(blocks_of $O/pmc_$1_FETCH_SIZE.log) 2>&1 | tail -1
