@@ -1102,6 +1102,7 @@ def main():
                 "device_resident_every_VFO_block_and_lines_delivered": bp[k200].get("pipelined_device_results_delivered"),
                 "host_fed_page_locked_every_VFO_block_and_lines_delivered": bp[k200].get("pipelined_pinned_results_delivered"),
                 "cpp_IQFrontEnd_run_seam_median_of_5": cpp.get("msps"), "cpp_IQFrontEnd_run_seam_min_max": [cpp.get("msps_min"), cpp.get("msps_max")],
+                "cpp_IQFrontEnd_run_seam_launch_groups_of_8_median_of_5": bp.get("cpp_iqfrontend_run_bypass_pipelined_launch_groups", {}).get("msps"),
                 "cpp_seam_built_against": bp.get("cpp_iqfrontend_built_against"), "cpp_seam_cpus": bp.get("cpp_iqfrontend_cpus"),
             }
             k1m = "B=%d" % STREAM_CAP

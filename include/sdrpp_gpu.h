@@ -441,8 +441,14 @@ int sdrpp_set_pipelined(sdrpp_ctx* ctx, int on, int result_flags);
  * max_blocks (deterministic: tests, benchmarks).  What it costs: a held block waits for its group, and a block's results are complete `depth`
  * LAUNCHES after its group went out — a streaming host asks (depth + 1) * max_blocks blocks behind (sdrpp_pipeline_stats out[4] is still the
  * depth in launches).  max_blocks = 1 (default): one launch per push, as before.  Groups do not form behind a pre-processing chain
- * (sdrpp_preproc_configure) or while a block cannot run as a launch of the pipeline at all: such pushes go out one by one. */
+ * (sdrpp_preproc_configure) or while a block cannot run as a launch of the pipeline at all: such pushes go out one by one.
+ * `adaptive` is a set of flags: 1 as above; 2: the words handed to sdrpp_push_staged_when stay valid until their block has been LAUNCHED (not just for the
+ * call) — a push that is merely held then returns at once instead of waiting for its copy threads, and the copy runs on under whatever the host does next
+ * (the launch of the group waits for every word).  sdrpp_gpu::IQFrontEnd uses 2 with a ring of words and decides on the HOST side when a group goes out: full,
+ * or no new block for a few microseconds (sdrpp_pipeline_launch_held) — at the stream seam the device is never the slower side, so rule 1 would never group. */
 int sdrpp_set_pipeline_group(sdrpp_ctx* ctx, int max_blocks, int adaptive);
+/* Launches what is held (nothing held: no-op).  Unlike sdrpp_pipeline_flush it does not run the queued stages of earlier blocks to completion. */
+int sdrpp_pipeline_launch_held(sdrpp_ctx* ctx);
 /* out[0] launch groups so far (single blocks included), [1] groups of more than one block, [2] the blocks in those, [3] the largest group,
  * [4] pushes held right now.  Returns the number of entries written. */
 int sdrpp_pipeline_group_stats(sdrpp_ctx* ctx, int64_t* out, int max);

@@ -222,6 +222,7 @@ def load():
     L.sdrpp_ticket.restype = C.c_uint64
     L.sdrpp_ticket.argtypes = [vp]
     L.sdrpp_pipeline_flush.argtypes = [vp]
+    L.sdrpp_pipeline_launch_held.argtypes = [vp]
     L.sdrpp_result_ready.argtypes = [vp, C.c_uint64]
     L.sdrpp_result_wait.argtypes = [vp, C.c_uint64, C.POINTER(Result)]
     L.sdrpp_result_release.argtypes = [vp, C.c_uint64]
@@ -251,7 +252,7 @@ EXPORTED_SYMBOLS = [
     "sdrpp_vfo_out_count", "sdrpp_vfo_read", "sdrpp_vfo_device_buffers",
     "sdrpp_set_reference_block", "sdrpp_set_nco_mode", "sdrpp_set_backend_pipeline", "sdrpp_vfo_set_ssb_phase_delta", "sdrpp_vfo_read_many", "sdrpp_set_deferred", "sdrpp_push_pinned_async", "sdrpp_push_wait", "sdrpp_pending", "sdrpp_host_alloc", "sdrpp_host_free", "sdrpp_device_alloc", "sdrpp_device_free", "sdrpp_device_copy", "sdrpp_device_count",
     "sdrpp_push", "sdrpp_push_device", "sdrpp_push_int16", "sdrpp_push_stage", "sdrpp_push_staged", "sdrpp_push_staged_when",
-    "sdrpp_set_pipelined", "sdrpp_set_pipeline_group", "sdrpp_pipeline_group_stats", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
+    "sdrpp_set_pipelined", "sdrpp_set_pipeline_group", "sdrpp_pipeline_group_stats", "sdrpp_ticket", "sdrpp_pipeline_flush", "sdrpp_pipeline_launch_held", "sdrpp_result_ready", "sdrpp_result_wait", "sdrpp_result_release", "sdrpp_result_take_lines", "sdrpp_pipeline_stats", "sdrpp_pipeline_role_name",
     "sdrpp_timing_enable", "sdrpp_timing_read", "sdrpp_kernel_family_name",
 ]
 
@@ -601,10 +602,14 @@ class Context:
         8 = the pre-processed IQ stream (with a pre-processing chain) into page-locked result slots."""
         self._chk(self.L.sdrpp_set_pipelined(self.h, int(bool(on)), int(result_flags)))
 
-    def set_pipeline_group(self, max_blocks, adaptive=False):
+    def set_pipeline_group(self, max_blocks, adaptive=False, stable_words=False):
         """sdrpp_set_pipeline_group: up to `max_blocks` pushes per launch (every push keeps its own ticket and results); adaptive: the group follows
-        what is queued on the device (1 while the host is the slower side)."""
-        self._chk(self.L.sdrpp_set_pipeline_group(self.h, int(max_blocks), int(bool(adaptive))))
+        what is queued on the device (1 while the host is the slower side); stable_words (flag 2): the words of sdrpp_push_staged_when live until the
+        launch, a held push does not wait for its copy."""
+        self._chk(self.L.sdrpp_set_pipeline_group(self.h, int(max_blocks), int(bool(adaptive)) | (2 if stable_words else 0)))
+
+    def pipeline_launch_held(self):
+        self._chk(self.L.sdrpp_pipeline_launch_held(self.h))
 
     def pipeline_group_stats(self):
         buf = (C.c_int64 * 8)()

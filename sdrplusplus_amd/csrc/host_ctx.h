@@ -378,6 +378,7 @@ struct sdrpp_ctx {
     //      block of the tick queue whose reference-block ends are the push ends (what a deferred pass does with its staged pushes, plan_push.h) ----
     int group_max = 1;                    // blocks per launch, at most
     int group_adaptive = 0;               // 1: a group goes out as soon as the device has fewer than two launches in flight (a host slower than the device: one block per launch)
+    bool stage_pend_stable = false;       // sdrpp_set_pipeline_group flag 2: the words handed to sdrpp_push_staged_when stay valid until their block has been LAUNCHED — a held push does not wait for its copy
     struct Held {
         int kind = -1;                    // -1: nothing held; 0: device memory read in place; 1 / 2: float / int16 samples in a page-locked staging slot; 3: the caller's page-locked memory
         const char* base = nullptr;       // kind 0 / 3: address of the first block (the following ones are contiguous with it)

@@ -1892,8 +1892,14 @@ int sdrpp_set_pipeline_group(sdrpp_ctx* c, int max_blocks, int adaptive) {
         if (rc) { return rc; }
     }
     c->group_max = max_blocks;
-    c->group_adaptive = adaptive != 0;
+    c->group_adaptive = (adaptive & 1) != 0;
+    c->stage_pend_stable = (adaptive & 2) != 0;
     return SDRPP_OK;
+}
+int sdrpp_pipeline_launch_held(sdrpp_ctx* c) {
+    DeviceScope dev_scope_(c);
+    if (!c) { return SDRPP_ERR_INVALID; }
+    return c->pipelined ? tick_group_launch(c) : SDRPP_OK;
 }
 int sdrpp_pipeline_group_stats(sdrpp_ctx* c, int64_t* out, int max) {
     if (!c || !out || max < 0) { return SDRPP_ERR_INVALID; }

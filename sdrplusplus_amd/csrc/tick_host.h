@@ -775,9 +775,10 @@ int tick_hold(sdrpp_ctx* c, int kind, const void* p, int64_t count, const volati
     if (pending) {
         // sdrpp_push_staged_when: the word belongs to the caller and is only promised to live for the call.  The push that sends the group on its
         // way is planned while its copy threads are still at work (the wait comes just before the launch, stage_pending_wait); one that is merely
-        // held has nothing to overlap with: it waits here.
+        // held has nothing to overlap with: it waits here — unless the caller has promised (sdrpp_set_pipeline_group flag 2) that its words live until
+        // the launch: then the hold returns at once and the copy runs on under whatever the caller does next; the launch of the group waits for all of them.
         c->stage_pend.push_back(pending);
-        if (!go) {
+        if (!go && !c->stage_pend_stable) {
             int rc = stage_pending_wait(c);
             if (rc) {  // the block did not arrive: it is not part of the group
                 H.ends.pop_back();

@@ -465,16 +465,29 @@ public:
 #ifdef SDRPP_GPU_BLOCKS_PROF
         pipeT = std::chrono::steady_clock::now();
 #endif
-        if (_spinUs > 0 && spinStream == _in && spinLast) {
+        // The staging copy of a HELD block may still be running (its push returned without waiting for it): the copy's last part is what flush()es the input
+        // stream, and read() must not be called before that — the stream would hand out the same block again (dsp/stream.h: dataReady stays up until
+        // flush()).  Nothing is lost by waiting here: the source cannot swap() the next block in before the flush either.
+        stagers.finish();
+        // Blocks held for a launch group (setPipelining's groupBlocks > 1) go out when the group is full — or HERE, when no new block has shown up for
+        // _kickUs: the host side of "adaptive".  (The library's own rule — send a push at once while the device has fewer than two launches in flight —
+        // never groups at this seam: the device is always ahead of a dsp::stream.  A real-time stream pays _kickUs of latency, nothing else.)
+        if (spinStream == _in && spinLast && (_spinUs > 0 || heldBlocks > 0)) {
             const auto t0 = std::chrono::steady_clock::now();
+            const long kickUs = std::min<long>(_kickUs, _spinUs);
             unsigned n = 0;
             while (peekReadBuf(_in) == spinLast) {
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
 #endif
-                if ((++n & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(_spinUs)) { break; }
+                if ((++n & 15u) == 0) {
+                    const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                    if (heldBlocks > 0 && us >= kickUs && launchHeld() < 0) { return -1; }
+                    if (us >= _spinUs) { break; }
+                }
             }
         }
+        else if (heldBlocks > 0 && launchHeld() < 0) { return -1; }
         int count = _in->read();
         spinStream = _in;
         spinLast = peekReadBuf(_in);
@@ -503,16 +516,23 @@ public:
                     std::vector<std::function<void()>> cj;
                     size_t njobs = 0;
                     for (size_t q = 0; q < parts; q++) { njobs += (q * per < bytes) ? 1 : 0; }
+                    // (one pair of words per block, a ring longer than the largest launch group: the library keeps the word of a HELD block until
+                    // the group's launch — sdrpp_set_pipeline_group flag 2 — and the copy of a held block runs on while this thread is back in read())
+                    stageWord = (stageWord + 1) % kStageWords;
+                    std::atomic<uint32_t>& stageLeft = stageLeftRing[stageWord];
+                    std::atomic<uint32_t>& stagePending = stagePendingRing[stageWord];
                     stageLeft.store((uint32_t)njobs, std::memory_order_relaxed);
                     stagePending.store((uint32_t)njobs, std::memory_order_release);
                     for (size_t q = 0; q < parts; q++) {
                         const size_t o = q * per, n = o >= bytes ? 0 : std::min(per, bytes - o);
                         if (!n) { continue; }
-                        cj.emplace_back([this, srcb, dstb, o, n]() {
+                        std::atomic<uint32_t>* left = &stageLeft;
+                        std::atomic<uint32_t>* pend = &stagePending;
+                        cj.emplace_back([this, srcb, dstb, o, n, left, pend]() {
                             memcpy(dstb + o, srcb + o, n);
                             if (_stageEvict) { evictLines(srcb + o, n); }
-                            if (stageLeft.fetch_sub(1, std::memory_order_acq_rel) == 1) { _in->flush(); }  // the stream buffer is free (BEFORE the word reaches 0: the worker's next read() follows it)
-                            stagePending.fetch_sub(1, std::memory_order_release);
+                            if (left->fetch_sub(1, std::memory_order_acq_rel) == 1) { _in->flush(); }  // the stream buffer is free (BEFORE the word reaches 0: the worker's next read() follows it)
+                            pend->fetch_sub(1, std::memory_order_release);
                         });
                     }
                     stagers.begin(std::move(cj));
@@ -522,7 +542,11 @@ public:
                     SDRPP_PIPE_TICK(1)
                     static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "the pending word is handed to the C ABI as a plain uint32_t");
                     prc = sdrpp_push_staged_when(ctx, count, reinterpret_cast<const volatile uint32_t*>(&stagePending));
-                    stagers.finish();  // (joins the copy on a failed plan, which returns without waiting; a no-op otherwise)
+                    if (prc) { stagers.finish(); }  // (a failed plan returns without waiting for the copy: join it)
+                    else if (pipeGroupOn > 1) {
+                        int64_t gst[5] = {};
+                        heldBlocks = sdrpp_pipeline_group_stats(ctx, gst, 5) >= 5 ? (int)gst[4] : 0;
+                    }
                 }
                 else {
                     (void)finishDelivery();
@@ -633,7 +657,7 @@ public:
 #define SDRPP_GPU_HELPERS 8
 #endif
     int kStagers = [] { const char* e = getenv("SDRPP_GPU_STAGERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 16 ? 16 : v); }();  // threads of the staging copy (measurement switch)
-    static constexpr int kHelpers = SDRPP_GPU_HELPERS;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log)
+    static constexpr int kHelpers = SDRPP_GPU_HELPERS;  // threads that hand a block's outputs to the streams (round 6: 8 — with 6, the hand-over of 32 streams took as long as planning the next block: profiles/r06d_seam_prof.log; 12 / 16 / 32 are progressively SLOWER, with or without a back-off or a yield in the idle loop: r06w_seam_helpers.log, r06w_seam_pauses.log)
 
 protected:
     // dsp::block hooks: the frame-buffer worker lives and dies with the block's own worker (SampleFrameBuffer::doStart / doStop,
@@ -749,11 +773,22 @@ private:
             return 0;
         }
         pipeGroupOn = _pipeGroup;
-        sdrpp_set_pipeline_group(ctx, pipeGroupOn, 1);
+        // fixed groups + words that live until the launch (flag 2): WHEN a group goes out is decided in runBlock (full, or no new block for _kickUs)
+        sdrpp_set_pipeline_group(ctx, pipeGroupOn, 2);
+        heldBlocks = 0;
         pipeOn = true;
         return 0;
     }
+    int launchHeld() {
+        heldBlocks = 0;
+        if (sdrpp_pipeline_launch_held(ctx)) {
+            fprintf(stderr, "[sdrpp_gpu::IQFrontEnd] launch of the held blocks failed: %s\n", sdrpp_last_error(ctx));
+            return -1;
+        }
+        return 0;
+    }
     int leavePipelined() {
+        heldBlocks = 0;
         const int rc = drainPipeline();
         sdrpp_set_pipeline_group(ctx, 1, 0);
         sdrpp_set_pipelined(ctx, 0, 0);
@@ -1186,7 +1221,11 @@ private:
     std::atomic<bool> workerDone{ true };   // the worker thread has left its loop (doStop's grace period)
     int _stopGraceMs = 250;                 // how long doStop lets the block in hand and the open hand-over finish before it stops the writers
     std::vector<uint64_t> pendingTickets;   // blocks launched whose results have not been handed out yet
-    std::atomic<uint32_t> stageLeft{ 0 }, stagePending{ 0 };  // staging copy of the block being pushed: parts not yet copied / not yet accounted for
+    static constexpr int kStageWords = SDRPP_GROUP_MAX + 2;
+    std::atomic<uint32_t> stageLeftRing[kStageWords] = {}, stagePendingRing[kStageWords] = {};  // staging copy of a block: parts not yet copied / not yet accounted for
+    int stageWord = 0;
+    int heldBlocks = 0;                     // blocks the library holds for a launch group (worker)
+    int _kickUs = [] { const char* e = getenv("SDRPP_GPU_KICK_US"); const int v = e ? atoi(e) : 20; return v < 0 ? 0 : v; }();  // a held group goes out after this long without a new block
     uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
     sdrpp_result inflight{};
     std::vector<std::pair<RxVFO*, int>> inflightOrder;

@@ -818,6 +818,62 @@ def test_grouped_launches_mixed_modes_af_and_reference_blocks(backend):
     cb.close()
 
 
+def test_held_staged_pushes_with_words_that_live_until_the_launch(backend):
+    """sdrpp_set_pipeline_group flag 2 (what sdrpp_gpu::IQFrontEnd runs with): a staged push that is merely HELD returns while its slot is still being
+    filled — the word it handed over lives until the launch — and sdrpp_pipeline_launch_held sends the group on its way without draining the pipeline.
+    The launch waits for every word; results are those of block-by-block processing."""
+    import ctypes as C
+    import threading
+    import time
+    from sdrplusplus_amd import capi, workloads
+
+    nv = 6 if backend == "gpu" else 3
+    pushes = [20000, 7000, 20000, 12345, 20000] if backend == "gpu" else [5000, 1700, 5000, 3086, 5000]
+    x = workloads.synth(3, sum(pushes), seed=21, nvfo=nv)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, sum(pushes[:3]) + 64, 4096)
+    cb.set_pipeline_group(3, adaptive=False, stable_words=True)
+    words = [C.c_uint32(1) for _ in pushes]
+    fills, refs, pos = [], [], 0
+    for i, n in enumerate(pushes):
+        blk = np.ascontiguousarray(x[pos:pos + n])
+        refs.append(_ordinary_results(ca, va, blk, True))
+        slot = capi.c_float_p()
+        cb._chk(cb.L.sdrpp_push_stage(cb.h, n, C.byref(slot)))
+        dst = C.cast(slot, C.c_void_p).value
+
+        def fill(dst=dst, blk=blk, w=words[i]):
+            time.sleep(0.05)
+            C.memmove(dst, blk.ctypes.data, blk.nbytes)
+            w.value = 0
+
+        th = threading.Thread(target=fill)
+        t0 = time.perf_counter()
+        th.start()
+        cb._chk(cb.L.sdrpp_push_staged_when(cb.h, n, C.byref(words[i])))
+        dt = time.perf_counter() - t0
+        held = cb.pipeline_group_stats()["held"]
+        if (i + 1) % 3:   # held: the call came back although the slot was not filled yet
+            assert held == (i + 1) % 3 and dt < 0.04 and words[i].value == 1, (i, held, dt)
+        else:             # the third push of a group launches it: it waited for all three words
+            assert held == 0 and all(w.value == 0 for w in words[:i + 1]), (i, held)
+        fills.append(th)
+        pos += n
+    assert cb.pipeline_group_stats()["held"] == 2
+    ticks0 = cb.pipeline_stats()["ticks"]
+    cb.pipeline_launch_held()   # waits for the two words, ONE launch, no drain
+    assert cb.pipeline_group_stats()["held"] == 0 and cb.pipeline_stats()["ticks"] == ticks0 + 1
+    cb.pipeline_launch_held()   # nothing held: no-op
+    assert cb.pipeline_stats()["ticks"] == ticks0 + 1
+    for th in fills:
+        th.join()
+    for t, ref in enumerate(refs, start=1):
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    ca.close()
+    cb.close()
+
+
 def test_grouped_results_hold_release_and_adaptive(backend):
     """The result slots belong to launch groups: blocks of a group can be held and released in any order, a slot still held when its turn comes round again
     fails the push (and nothing else); adaptive grouping on an idle device sends every push at once."""
