@@ -927,3 +927,129 @@ def test_grouped_results_hold_release_and_adaptive(backend):
     assert g1["groups"] - g0["groups"] == 3 and g1["multi_groups"] == g0["multi_groups"], (g0, g1)
     ca.close()
     cb.close()
+
+
+def test_result_ring_grows_under_held_and_uncollected_results(backend):
+    """A VFO added in the middle of a pipelined run makes the result ring grow (tick_results_ensure): a block the host is HOLDING keeps the address it was
+    given (its ring stays alive until the release), blocks pushed before the change and not yet collected follow their bytes into the new ring, blocks
+    pushed after it carry the new VFO — everything equal to the ordinary pass block by block."""
+    from sdrplusplus_amd import radio, workloads
+
+    nv = 4 if backend == "gpu" else 2
+    B = 20000 if backend == "gpu" else 5000
+    x = workloads.synth(3, 8 * B, seed=31, nvfo=nv + 6)
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, B, 4096)
+    cb.set_pipeline_group(2)
+    refs = []
+    for i in range(4):
+        blk = x[i * B:(i + 1) * B]
+        refs.append((list(va), list(vb), _ordinary_results(ca, va, blk, True)))
+        cb.push(blk)
+    held = cb.result_wait(1, copy=False)          # block 1 handed out and HELD across the change (views into the old ring)
+    held_copy = {v: a.copy() for v, a in held["vfo"].items()}
+    # six more VFOs: every launch now delivers more than twice the bytes the ring was sized for
+    sr = workloads.CFG[3]["sr"]
+    keep = []
+    for mode, if_rate, bw, centre, _ in workloads.vfo_plan(3, nv + 6)[nv:]:
+        d, k = radio.vfo_desc(sr, if_rate, bw, centre, mode)
+        va.append(ca.vfo_add(d, k))
+        vb.append(cb.vfo_add(d, k))
+        keep.append(k)
+    for i in range(4, 8):
+        blk = x[i * B:(i + 1) * B]
+        refs.append((list(va), list(vb), _ordinary_results(ca, va, blk, True)))
+        cb.push(blk)
+    for v, a in held["vfo"].items():               # the held block's memory is still the block's
+        _same(held_copy[v], a, "held block vfo %d after the ring grew" % v)
+    _compare({"vfo": dict(zip(refs[0][1], refs[0][2]["vfo"].values())), **{k: refs[0][2][k] for k in ("raw", "zoomed", "index")}}, held, True, "held block 1")
+    cb.result_release(1)
+    for t in range(2, 9):
+        ra, rb, ref = refs[t - 1]
+        got = cb.result_wait(t)
+        _compare({"vfo": dict(zip(rb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "block %d" % t)
+        cb.result_release(t)
+    ca.close()
+    cb.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_schedules_equal_block_by_block(backend, seed):
+    """A random schedule against the ordinary pass, block by block, bit for bit: block sizes from 1 sample to a whole group's room, every way a block can
+    arrive (host, device and page-locked memory contiguous / not contiguous, staged, staged with a late fill), the group size and rule changed on the way, results collected
+    out of step (some held across many pushes, released later), flushes, a retune and a channel-filter change between pushes."""
+    from sdrplusplus_amd import capi, workloads
+
+    rng = np.random.default_rng(1000 + seed)
+    nv = 5 if backend == "gpu" else 3
+    base = 16000 if backend == "gpu" else 3000
+    sr = workloads.CFG[3]["sr"]
+    nsteps = 40
+    sizes = [int(rng.choice([1, 7, base // 3, base, base, base + 11, 2 * base])) for _ in range(nsteps)]
+    x = workloads.synth(3, sum(sizes), seed=40 + seed, nvfo=nv)
+    cap = 4 * base + 64
+    (ca, va), (cb, vb) = _ctx_pair(3, nv, cap, 4096)
+    dev = _device_copy_of(cb, x)
+    import ctypes as C
+
+    pin = cb.L.sdrpp_host_alloc(x.nbytes)
+    assert pin
+    C.memmove(pin, x.ctypes.data, x.nbytes)
+    refs, held, collected, pos = {}, [], 0, 0
+    for i, n in enumerate(sizes):
+        op = rng.integers(0, 12)
+        if op == 0:
+            cb.set_pipeline_group(int(rng.integers(1, 6)), adaptive=bool(rng.integers(0, 2)))
+        elif op == 1:
+            cb.pipeline_flush()
+        elif op == 2:
+            re, im = capi.design_phase_delta(float(rng.uniform(-2e6, 2e6)), sr)
+            k = int(rng.integers(0, nv))
+            ca.vfo_set_phase_delta(va[k], re, im)
+            cb.vfo_set_phase_delta(vb[k], re, im)
+        elif op == 3:
+            taps = capi.design_low_pass(float(rng.uniform(40e3, 90e3)), 20e3, 250000.0)
+            k = int(rng.integers(0, nv))
+            ca.vfo_set_channel_taps(va[k], taps)
+            cb.vfo_set_channel_taps(vb[k], taps)
+        blk = np.ascontiguousarray(x[pos:pos + n])
+        refs[i + 1] = _ordinary_results(ca, va, blk, True)
+        feed = rng.integers(0, 5)
+        if feed == 0:
+            cb.push(blk)
+        elif feed == 1:
+            cb.push_device(dev + 8 * pos, n)              # contiguous with the block before when that one came from the device too
+        elif feed == 2:
+            cb.push_staged_from(blk)
+        elif feed == 3:
+            cb.push_staged_late_fill(blk, delay_s=0.0005)
+        else:
+            cb.push_host_ptr_async(pin + 8 * pos, n)      # the caller's page-locked memory, fetched by the launch's landing copy
+        pos += n
+        assert cb.ticket() == i + 1
+        # collect out of step: usually the oldest outstanding block, sometimes held for a while
+        while collected + len(held) < i + 1 - int(rng.integers(0, 7)):
+            t = collected + len(held) + 1
+            got = cb.result_wait(t, copy=False)
+            ref = refs.pop(t)
+            _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "seed %d block %d" % (seed, t))
+            held.append(t)
+            if len(held) > int(rng.integers(0, 4)):
+                for h in held:
+                    cb.result_release(h)
+                collected += len(held)
+                held = []
+    for h in held:
+        cb.result_release(h)
+    collected += len(held)
+    for t in range(collected + 1, nsteps + 1):
+        got = cb.result_wait(t)
+        ref = refs.pop(t)
+        _compare({"vfo": dict(zip(vb, ref["vfo"].values())), **{k: ref[k] for k in ("raw", "zoomed", "index")}}, got, True, "seed %d block %d (tail)" % (seed, t))
+        cb.result_release(t)
+    st = cb.pipeline_stats()
+    assert st["tick_blocks"] + st["pass_blocks"] == nsteps, st
+    cb.sync()
+    cb.L.sdrpp_device_free(cb.h, dev)
+    cb.L.sdrpp_host_free(pin)
+    ca.close()
+    cb.close()
