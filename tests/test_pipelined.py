@@ -402,7 +402,7 @@ def test_pipelined_falls_back_to_ordinary_passes(backend):
 def test_pipelined_result_slots_and_modes(backend):
     from sdrplusplus_amd import capi, workloads
 
-    nv, B = (20, 4000) if backend == "gpu" else (17, 2000)  # (>= 17 VFOs: the matrix-core front end, i.e. blocks that really run as ticks)
+    nv, B = (20, 4000) if backend == "gpu" else (3, 2000)  # (gpu: >= 17 VFOs = the matrix-core front end; the emulator: a small bank, which runs as launches of the pipeline as well)
     S, M = capi.RESULT_SLOTS, capi.RESULT_SLOTS * capi.GROUP_MAX
     x = workloads.synth(3, B * 16, seed=3, nvfo=nv)
     blk_of = lambda i: x[(i % 16) * B:(i % 16 + 1) * B]
@@ -879,7 +879,7 @@ def test_grouped_results_hold_release_and_adaptive(backend):
     fails the push (and nothing else); adaptive grouping on an idle device sends every push at once."""
     from sdrplusplus_amd import capi, workloads
 
-    nv, B = 17, 12000
+    nv, B = (17, 12000) if backend == "gpu" else (3, 3000)  # (the emulator: a small bank — it runs as launches of the pipeline too — and short blocks)
     x = workloads.synth(3, 8 * B, seed=3, nvfo=nv)
     (ca, va), (cb, vb) = _ctx_pair(3, nv, 4 * B, 4096, flags=3)
     cb.set_pipeline_group(2)
