@@ -78,11 +78,23 @@ int main(int argc, char** argv) {
         vfos.push_back(v);
     }
     std::atomic<long long> audioFrames{ 0 };
+    const int sinkSpinUs = getenv("SDRPP_BENCH_SINK_SPIN_US") ? atoi(getenv("SDRPP_BENCH_SINK_SPIN_US")) : 0;
     std::vector<std::thread> sinks;
     for (auto* v : vfos) {
-        sinks.emplace_back([v, &audioFrames]() {
+        sinks.emplace_back([v, &audioFrames, sinkSpinUs]() {
+            const void* last = nullptr;
             while (true) {
+                // DIAGNOSTIC (SDRPP_BENCH_SINK_SPIN_US, default 0 = the reference's sleeping reader): the sink looks for its next block before it sleeps —
+                // shows how much of a block's cycle is the wake-up of 32 sleeping sink threads (one futex wake-up per stream and block)
+                if (sinkSpinUs > 0 && last) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    unsigned q = 0;
+                    while (__atomic_load_n((void* const*)&v->audio.readBuf, __ATOMIC_RELAXED) == last) {
+                        if ((++q & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(sinkSpinUs)) { break; }
+                    }
+                }
                 int n = v->audio.read();
+                last = __atomic_load_n((void* const*)&v->audio.readBuf, __ATOMIC_RELAXED);
                 if (n < 0) { break; }
                 audioFrames += n;
                 v->audio.flush();
