@@ -1053,3 +1053,53 @@ def test_random_schedules_equal_block_by_block(backend, seed):
     cb.L.sdrpp_host_free(pin)
     ca.close()
     cb.close()
+
+
+def test_long_stream_is_identical_under_every_launch_grouping(backend):
+    """A long stream three times — one block per launch, adaptive groups (their sizes follow the timing of host and device), fixed groups of GROUP_MAX —
+    every VFO block and every line of every block delivered: identical bytes for every block (tools/r06_soak.py is the 60 000-block version of this)."""
+    import ctypes as C
+    import hashlib
+    from sdrplusplus_amd import capi, workloads
+
+    nv, B, NB, ring = (32, 50000, 1500, 64) if backend == "gpu" else (3, 2000, 150, 40)
+    xs = np.concatenate([workloads.synth(3, B, seed=100 + i, nvfo=nv) for i in range(ring)])
+
+    def run(k, adaptive):
+        ctx = capi.Context(0, max_push=B * k)
+        workloads.setup(ctx, 3, dense_fft=True, data_width=1024, nvfo=nv)
+        ctx.set_pipelined(True, 3)
+        ctx.set_pipeline_group(k, adaptive)
+        dev = _device_copy_of(ctx, xs)
+        lag = min(capi.RESULT_SLOTS - 2, 8) * k
+        res, digests, nxt = capi.Result(), [], 1
+        for i in range(NB + lag):
+            if i < NB:
+                ctx.push_device(dev + 8 * B * (i % ring), B)
+            upto = min(NB, i + 1 - lag) if i < NB else NB
+            while nxt <= upto:
+                ctx._chk(ctx.L.sdrpp_result_wait(ctx.h, C.c_uint64(nxt), C.byref(res)))
+                h = hashlib.blake2b(digest_size=16)
+                for q in range(res.n_vfo):
+                    if res.counts[q] > 0:
+                        h.update(C.string_at(C.addressof(res.samples.contents) + 8 * res.offsets[q], 8 * res.counts[q]))
+                if res.n_lines > 0:
+                    h.update(C.string_at(res.zoomed, 4 * res.n_lines * res.data_width))
+                    h.update(C.string_at(res.index, 4 * res.n_lines * res.data_width))
+                digests.append((res.n_lines, h.digest()))
+                ctx._chk(ctx.L.sdrpp_result_release(ctx.h, C.c_uint64(nxt)))
+                nxt += 1
+        st, gs = ctx.pipeline_stats(), ctx.pipeline_group_stats()
+        ctx.L.sdrpp_device_free(ctx.h, dev)
+        ctx.close()
+        assert len(digests) == NB and st["tick_blocks"] == NB and st["pass_blocks"] == 0, (len(digests), st)
+        return digests, gs
+
+    ref, _ = run(1, False)
+    assert sum(n for n, _ in ref) > 0
+    for k, adaptive in ((4, True), (capi.GROUP_MAX, False)):
+        got, gs = run(k, adaptive)
+        bad = [i + 1 for i, (a, b) in enumerate(zip(ref, got)) if a != b]
+        assert not bad, ("blocks per launch up to %d%s: first differing blocks %s" % (k, " (adaptive)" if adaptive else "", bad[:8]))
+        if not adaptive:
+            assert gs["largest"] == k and gs["multi_groups"] >= NB // k - 1, gs
