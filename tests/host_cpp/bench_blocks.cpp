@@ -78,10 +78,16 @@ int main(int argc, char** argv) {
         vfos.push_back(v);
     }
     std::atomic<long long> audioFrames{ 0 };
+    // SOAK MODE (SDRPP_BENCH_BLOCKS=N): the source hands over exactly N blocks, the run ends when every stream has received every frame of them (stop() +
+    // drainPipeline() hand out what is in flight), the JSON carries the frames and a digest of every byte the sinks saw — two runs with different launch
+    // grouping (whose group sizes follow the timing of the threads) must print the same digest
+    const long long soakBlocks = getenv("SDRPP_BENCH_BLOCKS") ? atoll(getenv("SDRPP_BENCH_BLOCKS")) : 0;
+    std::vector<uint64_t> digests((size_t)std::max(1, nvfo), 14695981039346656037ull);
     const int sinkSpinUs = getenv("SDRPP_BENCH_SINK_SPIN_US") ? atoi(getenv("SDRPP_BENCH_SINK_SPIN_US")) : 0;
     std::vector<std::thread> sinks;
     for (auto* v : vfos) {
-        sinks.emplace_back([v, &audioFrames, sinkSpinUs]() {
+        const int k = (int)sinks.size();
+        sinks.emplace_back([v, k, soakBlocks, &digests, &audioFrames, sinkSpinUs]() {
             const void* last = nullptr;
             while (true) {
                 // DIAGNOSTIC (SDRPP_BENCH_SINK_SPIN_US, default 0 = the reference's sleeping reader): the sink looks for its next block before it sleeps —
@@ -97,6 +103,12 @@ int main(int argc, char** argv) {
                 last = __atomic_load_n((void* const*)&v->audio.readBuf, __ATOMIC_RELAXED);
                 if (n < 0) { break; }
                 audioFrames += n;
+                if (soakBlocks > 0) {  // (soak mode: every byte of every stream goes into a per-stream FNV-1a digest, in stream order)
+                    const unsigned char* b = (const unsigned char*)v->audio.readBuf;
+                    uint64_t h = digests[(size_t)k];
+                    for (size_t q = 0; q < (size_t)n * sizeof(dsp::stereo_t); q++) { h = (h ^ b[q]) * 1099511628211ull; }
+                    digests[(size_t)k] = h;
+                }
                 v->audio.flush();
             }
         });
@@ -109,7 +121,7 @@ int main(int argc, char** argv) {
     std::atomic<long long> srcFillNs{ 0 }, srcSwapNs{ 0 }, srcBlocks{ 0 };
     std::thread source([&]() {
         int b = 0;
-        while (!stop) {
+        while (!stop && (soakBlocks <= 0 || b < soakBlocks)) {
             const auto a0 = std::chrono::steady_clock::now();
             memcpy(src.writeBuf, blocks[(size_t)(b++ & 3)].data(), sizeof(dsp::complex_t) * (size_t)block);
             const auto a1 = std::chrono::steady_clock::now();
@@ -121,27 +133,35 @@ int main(int argc, char** argv) {
             fed += block;
         }
     });
-    std::this_thread::sleep_for(std::chrono::milliseconds(500));  // warm-up
-    const long long f0 = fed, a0 = audioFrames, l0 = g_lines;
+    if (soakBlocks <= 0) { std::this_thread::sleep_for(std::chrono::milliseconds(500)); }  // warm-up
+    const long long f0 = soakBlocks > 0 ? 0 : (long long)fed, a0 = soakBlocks > 0 ? 0 : (long long)audioFrames, l0 = soakBlocks > 0 ? 0 : (long long)g_lines;
     const auto t0 = std::chrono::steady_clock::now();
-    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    if (soakBlocks > 0) { while (fed.load() < soakBlocks * (long long)block) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); } }
+    else { std::this_thread::sleep_for(std::chrono::duration<double>(seconds)); }
     const long long f1 = fed, a1 = audioFrames, l1 = g_lines;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stop = true;
     src.stopWriter();
     source.join();
     fe.stop();
+    if (soakBlocks > 0 && fe.drainPipeline() < 0) { fprintf(stderr, "drainPipeline failed\n"); }
+    if (soakBlocks > 0) {  // (swap() returns when the block lies in the stream: give the sinks a moment to take the last ones)
+        const long long want = soakBlocks * (long long)block / (long long)(sr / 250000.0 + 0.5) * (long long)nvfo;
+        for (int w = 0; w < 2000 && audioFrames.load() < want; w++) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+    }
     for (auto* v : vfos) { v->audio.stopReader(); }
     for (auto& t : sinks) { t.join(); }
 #ifdef SDRPP_GPU_BLOCKS_PROF
     fe.profReport();
 #endif
+    uint64_t soakDigest = 0;
+    for (int q = 0; q < nvfo; q++) { soakDigest = soakDigest * 1099511628211ull + digests[(size_t)q]; }  // (per stream in order, streams in VFO order)
     // the frame buffer does not back-pressure its producer (an overrun drops a lap, like the reference's): count what came OUT
     const double processed = nvfo > 0 ? ((double)(a1 - a0) / nvfo) * (sr / 250000.0) : (double)(l1 - l0) * fftSize;
     const double nb = (double)std::max<long long>(1, srcBlocks);
     printf("{\"block\": %d, \"buffered\": %s, \"pipelined\": %s, \"blocks_per_launch_max\": %d, \"nvfo\": %d, \"msps\": %.2f, \"msps_fed\": %.2f, \"audio_frames_per_s\": %.0f, \"lines_per_s\": %.1f, \"seconds\": %.2f, "
-           "\"source_us_per_block_fill\": %.1f, \"source_us_per_block_swap\": %.1f}\n", block,
+           "\"source_us_per_block_fill\": %.1f, \"source_us_per_block_swap\": %.1f, \"soak_blocks\": %lld, \"soak_audio_frames\": %lld, \"soak_digest\": \"%016llx\"}\n", block,
            buffered ? "true" : "false", pipelined ? "true" : "false", pipelined ? group : 1, nvfo, processed / dt / 1e6, (double)(f1 - f0) / dt / 1e6, (double)(a1 - a0) / dt, (double)(l1 - l0) / dt, dt,
-           (double)srcFillNs / nb / 1e3, (double)srcSwapNs / nb / 1e3);
+           (double)srcFillNs / nb / 1e3, (double)srcSwapNs / nb / 1e3, soakBlocks, soakBlocks > 0 ? (long long)audioFrames : 0ll, (unsigned long long)soakDigest);
     return 0;
 }
