@@ -474,8 +474,12 @@ public:
         // never groups at this seam: the device is always ahead of a dsp::stream.  A real-time stream pays _kickUs of latency, nothing else.)
         if (spinStream == _in && spinLast && (_spinUs > 0 || heldBlocks > 0)) {
             const auto t0 = std::chrono::steady_clock::now();
-            const long kickUs = std::min<long>(_kickUs, _spinUs);
+            // (how long "no new block" is follows the stream: twice what the last blocks took to arrive after the flush — a source that needs 22 us per block
+            // must not have its groups sent off after 20 —, at least _kickUs, at most 200 us / the spin window)
+            static const bool kickFixed = getenv("SDRPP_GPU_KICK_FIXED") != nullptr;  // (measurement switch)
+            const long kickUs = std::min<long>(kickFixed ? (long)_kickUs : std::max<long>(_kickUs, std::min<long>(200, (long)(2.0 * arriveEmaUs) + 5)), _spinUs);
             unsigned n = 0;
+            bool arrived = true;
             while (peekReadBuf(_in) == spinLast) {
 #if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
@@ -483,8 +487,12 @@ public:
                 if ((++n & 15u) == 0) {
                     const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
                     if (heldBlocks > 0 && us >= kickUs && launchHeld() < 0) { return -1; }
-                    if (us >= _spinUs) { break; }
+                    if (us >= _spinUs) { arrived = false; break; }
                 }
+            }
+            if (arrived) {
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                arriveEmaUs += 0.125 * (us - arriveEmaUs);
             }
         }
         else if (heldBlocks > 0 && launchHeld() < 0) { return -1; }
@@ -1225,6 +1233,7 @@ private:
     std::atomic<uint32_t> stageLeftRing[kStageWords] = {}, stagePendingRing[kStageWords] = {};  // staging copy of a block: parts not yet copied / not yet accounted for
     int stageWord = 0;
     int heldBlocks = 0;                     // blocks the library holds for a launch group (worker)
+    double arriveEmaUs = 0.0;               // how long the last blocks took to arrive after the flush of the one before (worker; only arrivals inside the spin window count)
     int _kickUs = [] { const char* e = getenv("SDRPP_GPU_KICK_US"); const int v = e ? atoi(e) : 20; return v < 0 ? 0 : v; }();  // a held group goes out after this long without a new block
     uint64_t inflightTicket = 0;            // the block whose hand-over is running on the helpers (its result slot is held)
     sdrpp_result inflight{};
