@@ -91,6 +91,23 @@ def test_bandwidth_change_mid_stream_bit_exact():
         assert oi.shape == ri.shape and np.array_equal(oi, ri), "block %d (bandwidth %g)" % (b, bw)
 
 
+def test_one_tap_filter_bypass_long_taps_bit_exact():
+    """A bandwidth far above the IF rate makes taps::lowPass return ONE tap (windowed_sinc.h: 3.8 * rate / transition < 2); FIR::setTaps then leaves an
+    empty delay line (fir.h:31-52).  Bypassed behind that and switched on again with long taps, the filter starts from ZEROS — not from what an earlier
+    bypass left behind.  Oracle restatement vs the compiled reference, bit for bit."""
+    oc = S.OracleChain(10e6, 250e3, 150e3, 0.7e6, None)
+    rc = S.RefChain(10e6, 250e3, 150e3, 0.7e6, None)
+    seq = (150e3, 250e3, 120e3, 10e6, 250e3, 150e3, 250e3, 10e6, 90e3)
+    x = _noise(len(seq) * 50000, 16)
+    for b, bw in enumerate(seq):
+        if b:
+            oc.set_bandwidth(bw)
+            rc.set_bandwidth(bw)
+        oi, _ = oc.process(x[b * 50000:(b + 1) * 50000])
+        ri, _ = rc.process(x[b * 50000:(b + 1) * 50000])
+        assert oi.shape == ri.shape and np.array_equal(oi, ri), "block %d (bandwidth %g)" % (b, bw)
+
+
 def test_frontend_lines_bit_exact():
     """IQFrontEnd (threads, Splitter, Reshaper, handler — iq_frontend.cpp verbatim) vs the streaming restatement."""
     o, r = S.oracle(), S.ref()

@@ -639,6 +639,38 @@ def test_bandwidth_change_mid_stream(backend):
     ctx.close()
 
 
+def test_one_tap_filter_then_bypass_then_long_taps(backend):
+    """ADVICE r5: a channel filter of ONE tap (a bandwidth far above the IF rate: taps::lowPass returns a single tap, FIR::setTaps leaves an empty delay line)
+    that goes to sleep (bandwidth == IF rate) and wakes up with long taps starts from zeros in the reference — not from the delay line an EARLIER bypass left
+    behind.  Sequence with an earlier bypass in it; IF against the oracle (pinned for this sequence: test_one_tap_filter_bypass_long_taps_bit_exact) from the
+    first sample of every block."""
+    from sdrplusplus_amd import capi
+
+    sr, B, if_rate = 10e6, 50000, 250e3
+    seq = (150e3, 250e3, 120e3, 10e6, 250e3, 150e3, 250e3, 10e6, 90e3)
+    ctx, vids, chains, _ = _setup(sr, [("WFM", sr / 8), ("WFM", -sr / 4)], B)
+    r = np.random.default_rng(27)
+    t = np.arange(len(seq) * B) / sr
+    x = (0.3 * np.exp(2j * np.pi * (sr / 8 + 2.0e3) * t) + 0.2 * np.exp(2j * np.pi * (-sr / 4 - 1.1e3) * t)
+         + 0.01 * (r.standard_normal(len(t)) + 1j * r.standard_normal(len(t)))).astype(np.complex64)
+    lens = []
+    for b, bw in enumerate(seq):
+        if b:
+            taps = capi.design_low_pass(bw / 2.0, bw / 2.0 * 0.1, if_rate) if bw != if_rate else np.zeros(0, np.float32)
+            lens.append(len(taps))
+            for vid, ch in zip(vids, chains):
+                ch.set_bandwidth(bw)
+                ctx.vfo_set_channel_taps(vid, taps)
+        blk = x[b * B:(b + 1) * B]
+        ctx.push(blk)
+        for vid, ch in zip(vids, chains):
+            oi, _ = ch.process(blk)
+            gi = ctx.vfo_read_if(vid)
+            assert gi.shape == oi.shape and rms(gi - oi) / rms(oi) < 2e-6 and rms(gi[:300] - oi[:300]) / rms(oi) < 2e-6, (b, bw, rms(gi - oi) / rms(oi), rms(gi[:300] - oi[:300]) / rms(oi))
+    assert 1 in lens and 0 in lens and max(lens) > 100, lens
+    ctx.close()
+
+
 def test_very_long_channel_filter_histories(backend):
     """Channel filters of thousands of taps (16 kHz, then 5 kHz of bandwidth at a 250 kHz IF: 1 187 and 3 800 taps; the C-ABI takes up to 4 096): the filter runs in
     the VALU form and its delay line — the stream's history, up to 8 190 floats — is carried block to block by the one-wavefront-per-job form of the carry role
